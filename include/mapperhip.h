@@ -1,0 +1,283 @@
+/*
+ * libmapperhip -- C ABI of the MI355X-native (gfx950) audio->event hot path of Mapperatorinator.
+ *
+ * Every entry point below replaces a *Python call site into third-party device code* of the
+ * reference (the reference owns no native code); the file:line after each
+ * declaration is the reference interface it stands in for (paths relative to the reference root).
+ *
+ * Conventions (all entry points):
+ *   - plain C: raw DEVICE pointers + sizes, no torch / C++ types;
+ *   - asynchronous on the given `hipStream_t` (passed as void*), no hidden allocation, no host sync
+ *     (the one exception, mh_t5_generate, documents its polling); caller owns every buffer;
+ *   - returns MH_OK (0) or a negative MhStatus; the message is available from mh_last_error();
+ *     never throws, never aborts;
+ *   - `dtype` is MH_F32 or MH_BF16: the storage type of weights and GEMM operands.  Accumulation,
+ *     normalisation, softmax, the residual stream and logits are always fp32.
+ */
+#ifndef MAPPERHIP_H_
+#define MAPPERHIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MH_ABI_VERSION 1
+#define MH_MAX_LAYERS 32
+
+typedef enum MhStatus {
+  MH_OK = 0,
+  MH_ERR_ARG = -1,     /* bad argument (shape / alignment / null) */
+  MH_ERR_LAUNCH = -2,  /* HIP launch or runtime error */
+  MH_ERR_STATE = -3,   /* object used in the wrong state */
+} MhStatus;
+
+typedef enum MhDtype { MH_F32 = 0, MH_BF16 = 1 } MhDtype;
+
+/* epilogues of mh_gemm */
+typedef enum MhEpilogue {
+  MH_EPI_STORE = 0,      /* C[T]   = A W^T (+bias)                                  */
+  MH_EPI_STORE_F32 = 1,  /* C[f32] = A W^T (+bias)                                  */
+  MH_EPI_RESID = 2,      /* C[f32] += A W^T (+bias)                                 */
+  MH_EPI_GEGLU = 3,      /* C[T][M,N/2] = gelu_tanh(acc[:,blk even]) * acc[:,blk odd];
+                            W rows interleaved in blocks of 16 (wi_0 blk, wi_1 blk, ...) */
+  MH_EPI_BIAS_GELU = 4,  /* C[T]   = gelu_tanh(A W^T + bias)                        */
+  MH_EPI_GATE_RESID = 5, /* C[f32][m,n] += gate[m / rows_per_batch, n] * (A W^T + bias)[m,n] */
+  MH_EPI_KV_SCATTER = 6, /* C[T] scattered to [(layer,kv)][b][h][key][64]; see mh_t5_cross_kv */
+  MH_EPI_QKV_VT = 7,     /* cols < n_split: C[T] = A W^T (+bias) (q|k block, ldc);
+                            cols >= n_split (the v block, col' = h*64+dd, row = b*kv_L+key):
+                            C2[T][((b*kv_H + h)*64 + dd)*kv_Lpad + key]  (V transposed per head)  */
+} MhEpilogue;
+
+const char* mh_last_error(void);
+int mh_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * K1  mel frontend.  Replaces `nnAudio.features.MelSpectrogram` as constructed and called at
+ *     osuT5/osuT5/model/spectrogram.py:50-61 and :63-83 (zero-pad n_fft/2, hann STFT, power
+ *     spectrum, Slaney mel filterbank, optional log1p, (B, frames, n_mels) layout).
+ * audio   [B, n_samples] fp32.
+ * out     [B, n_frames, ld_out] (fp32 if out_dtype==MH_F32 else bf16), n_frames = n_samples/hop + 1;
+ *         columns [n_mels, ld_out) are written as zero (K padding for the following GEMM).
+ * The sparse filterbank (CSR over mel rows) and the twiddle table are built on the host
+ * (mapperatorinator_amd/mel.py) and passed in:
+ *   fb_start[n_mels], fb_len[n_mels], fb_off[n_mels] (int32), fb_w[sum(len)] fp32,
+ *   window[n_fft] fp32 (periodic hann), twiddle[n_fft] (cos, sin) pairs fp32.
+ * n_fft must be 1024 (the only size the reference configs use: configs/model/default.yaml:29-37). */
+int mh_mel(const float* audio, int B, int n_samples, int n_fft, int hop, int n_mels,
+           const float* window, const float* twiddle, const int32_t* fb_start, const int32_t* fb_len,
+           const int32_t* fb_off, const float* fb_w, int log_scale, void* out, int ld_out,
+           int out_dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Dense layer.  Replaces `nn.Linear` / `torch.matmul` call sites on the hot path
+ * (modeling_mapperatorinator.py:195-196; HF T5Attention q/k/v/o, T5DenseGatedActDense;
+ *  osu_diffusion/utils/models.py:111-116,145-155).  C = A[M,K] * W[N,K]^T with a fused epilogue.
+ * A, W have element type `dtype`; lda/ldw/ldc in elements; K % 8 == 0 (bf16) or % 4 (f32),
+ * row starts 16-byte aligned.  bias fp32[N] or NULL.  gate fp32 [.., gate_ld].
+ * For MH_EPI_KV_SCATTER: kv_B, kv_H, kv_L describe the scatter (rows m = b*kv_L + key). */
+typedef struct MhGemm {
+  const void* A; int lda;
+  const void* W; int ldw;
+  void* C; int ldc;
+  int M, N, K;
+  const float* bias;
+  const float* gate; int gate_ld; int rows_per_batch;
+  int kv_B, kv_H, kv_L;
+  void* C2; int n_split; int kv_Lpad;   /* MH_EPI_QKV_VT only */
+  int dtype; int epilogue;
+} MhGemm;
+int mh_gemm(const MhGemm* g, void* stream);
+
+/* T5 RMSNorm (HF T5LayerNorm; restated at custom_transformers/t5.py:50-62):
+ * y[T] = w * x * rsqrt(mean(x^2) + eps), x fp32 [rows, d] (ldx), y [rows, ldy]. */
+int mh_rmsnorm(const float* x, int ldx, const float* w, void* y, int ldy, int rows, int d, float eps,
+               int out_dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K3  T5 encoder self-attention (HF T5Attention.forward, restated custom_transformers/t5.py:170-250):
+ *     softmax(scale * Q K^T + bias[h][k - q + L - 1]) V; T5: scale = 1 (no 1/sqrt(d)), bidirectional.
+ * qk   [B*L, ld_qk] element type `dtype`: q of head h at columns [h*64, h*64+64), k at
+ *      [k_col0 + h*64, ...);   vt [B][H][64][Lpad] = V transposed per head (MH_EPI_QKV_VT output,
+ *      pad columns zero);  bias fp32 [H][2L-1] (host-built bucket lookup by k - q) or NULL;
+ * out  [B*L, ld_out] element type `dtype`, head h at columns [h*64, h*64+64).
+ * K7  also the DiT attention (osu_diffusion/utils/models.py:145-151): scale = 1/8, bias NULL and
+ *     band > 0: query q attends key k iff -(band-1) <= k - q <= band, which is exactly the banded
+ *     bool mask built at diffusion_pipeline.py:146-148 (band = seq_len = 128).  band <= 0: no mask. */
+int mh_attention(const void* qk, int ld_qk, int k_col0, const void* vt, int Lpad, const float* bias,
+                 void* out, int ld_out, int B, int L, int H, float scale, int band, int dtype,
+                 void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * T5 model object: weights are caller-owned device buffers (packed by the host, see
+ * mapperatorinator_amd/t5_engine.py) described by MhT5Weights.  All matrices are [N][Kpad] row major,
+ * element type cfg.dtype, K padded with zeros to a multiple of 32.
+ */
+typedef struct MhT5Config {
+  int d_model, d_kv, d_ff, n_heads, n_enc_layers, n_dec_layers;
+  int vocab_in, vocab_out;
+  int n_mels, n_mels_pad;   /* encoder_embedder K and its padded leading dimension */
+  int src_len;              /* L: mel frames per chunk (encoder positions)             */
+  int tgt_len;              /* max_target_positions = StaticCache length                */
+  int dtype;                /* MhDtype                                                  */
+  float eps;                /* RMSNorm epsilon (1e-6)                                   */
+} MhT5Config;
+
+typedef struct MhT5Weights {
+  const void* enc_embed_w;            /* [d, n_mels_pad]           modeling_mapperatorinator.py:123-124 */
+  const float* enc_embed_b;           /* [d]                                                           */
+  const void* dec_embed;              /* [vocab_in, d]             modeling_mapperatorinator.py:126-128 */
+  const float* enc_rel_bias;          /* fp32 [H][2L-1]   bucketed lookup, encoder (bidirectional)      */
+  const float* dec_rel_bias;          /* fp32 [H][tgt_len] lookup by distance q-k >= 0 (causal)         */
+  /* encoder blocks */
+  const float* enc_ln1[MH_MAX_LAYERS];   /* [d]  layer.0.layer_norm                                   */
+  const void* enc_qkv[MH_MAX_LAYERS];    /* [3*inner, d]  q|k|v stacked                               */
+  const void* enc_o[MH_MAX_LAYERS];      /* [d, inner]                                                */
+  const float* enc_ln2[MH_MAX_LAYERS];   /* [d]  layer.1.layer_norm                                   */
+  const void* enc_wi[MH_MAX_LAYERS];     /* [2*d_ff, d]  wi_0 / wi_1 interleaved in 16-row blocks     */
+  const void* enc_wo[MH_MAX_LAYERS];     /* [d, d_ff]                                                 */
+  const float* enc_final_ln;             /* [d]                                                       */
+  /* decoder blocks */
+  const float* dec_ln1[MH_MAX_LAYERS];
+  const void* dec_qkv[MH_MAX_LAYERS];    /* [3*inner, d] self-attention                               */
+  const void* dec_o[MH_MAX_LAYERS];
+  const float* dec_ln2[MH_MAX_LAYERS];
+  const void* dec_cq[MH_MAX_LAYERS];     /* [inner, d]  cross-attention query                         */
+  const void* dec_ckv_all;               /* [n_dec*2*inner, d] rows ordered (layer, k|v, head, 64)    */
+  const void* dec_co[MH_MAX_LAYERS];     /* [d, inner]                                                */
+  const float* dec_ln3[MH_MAX_LAYERS];
+  const void* dec_wi[MH_MAX_LAYERS];
+  const void* dec_wo[MH_MAX_LAYERS];
+  const float* dec_final_ln;
+  const void* lm_head;                   /* [vocab_out, d]                                            */
+} MhT5Weights;
+
+/* bytes of scratch needed by mh_t5_encode for a batch of B chunks */
+int64_t mh_t5_encode_workspace_bytes(const MhT5Config* cfg, int B);
+
+/* K2/K3/K4  mel -> encoder_embedder -> T5 encoder stack (final RMSNorm included).
+ * Replaces OsuTEncoder.forward (modeling_mapperatorinator.py:392-443) + HF T5Stack (encoder).
+ * mel    [B*L, n_mels_pad] element type cfg.dtype (output of mh_mel with ld_out = n_mels_pad);
+ * enc_out[B*L, d] element type cfg.dtype (final-norm output, the cross-attention K/V GEMM operand);
+ * enc_out_f32 optional fp32 copy [B*L, d] (NULL to skip) for parity checks. */
+int mh_t5_encode(const MhT5Config* cfg, const MhT5Weights* w, const void* mel, int B, void* enc_out,
+                 float* enc_out_f32, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Cross-attention K/V projection of all decoder layers at once (HF T5Attention with
+ * key_value_states, computed once per chunk and kept in the encoder-side StaticCache:
+ * osuT5/osuT5/inference/cache_utils.py:32-35).
+ * cross_kv out: [n_dec][2][B][H][L][64] element type cfg.dtype. */
+int mh_t5_cross_kv(const MhT5Config* cfg, const MhT5Weights* w, const void* enc_out, int B,
+                   void* cross_kv, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K5/K6  autoregressive decode.  Replaces HF GenerationMixin.generate/_sample as driven by
+ * model_generate (osuT5/osuT5/inference/server.py:83-156) with MapperatorinatorCache
+ * (cache_utils.py:7-35) and the reference logits processors
+ * (osuT5/osuT5/inference/logit_processors.py:36-44,136-183; server.py:106-134).
+ */
+typedef struct MhSampling {
+  int do_sample;            /* 0: greedy argmax (first maximal index)                          */
+  int top_k;                /* >0: keep k best before sampling                                 */
+  float top_p;              /* <1: nucleus                                                     */
+  float temperature;        /* TemperatureLogitsWarper (server.py:131-132)                     */
+  float timeshift_bias;     /* TimeshiftBias (logit_processors.py:36-44), 0 = off              */
+  int ts_start, ts_end;     /* TIME_SHIFT id range [start, end)                                */
+  int n_sos; int sos_ids[16];   /* sos + context_sos ids (MonotonicTimeShiftLogitsProcessor)   */
+  int lookback_mask_end;    /* LookbackBiasLogitsWarper, types_first=False branch: ids in
+                               [ts_start, lookback_mask_end) get -inf; <= ts_start disables     */
+  int pad_id;
+  int max_length;           /* prompt + new tokens cap (MaxLengthCriteria)                      */
+  uint64_t seed;            /* Philox seed when do_sample                                       */
+} MhSampling;
+
+int64_t mh_t5_decode_workspace_bytes(const MhT5Config* cfg, int B);
+
+/* Runs prefill over the (left-padded) prompt and the AR loop until every row has emitted an id of
+ * the EOS set or max_length is reached.
+ *   prompt      int32 [B, P]    decoder_input_ids (pad_id = left padding)
+ *   prompt_mask uint8 [B, P]    decoder_attention_mask (1 = attend), NULL = all ones
+ *   eos_table   uint8 [vocab_out] 1 where the id is in get_eos_token_id(...) (server.py:72-80)
+ *   cross_kv    from mh_t5_cross_kv
+ *   tokens      int32 [B, max_length] out: prompt followed by generated ids, pad_id after EOS
+ *   n_steps_out int32 [1] device: number of valid columns of `tokens` (= HF output length)
+ *   logits_dump optional fp32 [max_length][B][vocab_out]: processed scores of every step (parity)
+ *   forced      optional int32 [B, max_length]: teacher forcing -- when non-NULL the id appended at
+ *               column c is forced[b][c] (argmax is still computed and written to `tokens`)
+ * The loop is captured into a hipGraph per step shape and replayed; the host polls a device
+ * "all finished" flag every `poll_every` steps (one 4-byte D2H on `stream`), otherwise no sync. */
+int mh_t5_generate(const MhT5Config* cfg, const MhT5Weights* w, const void* cross_kv, int B,
+                   const int32_t* prompt, const uint8_t* prompt_mask, int P, const uint8_t* eos_table,
+                   const MhSampling* sp, int32_t* tokens, int32_t* n_steps_out, float* logits_dump,
+                   const int32_t* forced, void* workspace, int64_t workspace_bytes, int poll_every,
+                   void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K7/K8/K9  osu_diffusion DiT + DDPM.  Replaces DiT.forward_with_cfg
+ * (osu_diffusion/utils/models.py:281-317) and GaussianDiffusion.p_sample
+ * (osu_diffusion/utils/diffusion/gaussian_diffusion.py:273-369, 420-467).  Always fp32
+ * (the reference never casts the DiT: inference.py:637-642).
+ */
+typedef struct MhDiTConfig {
+  int hidden, depth, n_heads, context_size, class_size, in_channels; /* in_channels = 2 */
+  int freq_dim;      /* FirstLayer frequency_embedding_size = 128                        */
+  int t_freq_dim;    /* TimestepEmbedder frequency_embedding_size = 256                  */
+  int first_k_pad;   /* padded K of the first layer GEMM (in_channels*freq_dim+context)  */
+  int class_pad;     /* padded K of y_embedder[0]                                        */
+} MhDiTConfig;
+
+typedef struct MhDiTWeights {       /* all fp32, matrices [N][Kpad]                                  */
+  const float* pos_freqs;   /* [freq_dim/2]   exp(-ln(1e4) i / (freq_dim/2)), host-built exactly as     */
+  const float* t_freqs;     /* [t_freq_dim/2] timestep_embedding does (positional_embedding.py:38-43)   */
+  const float* first_w; const float* first_b;        /* context_embedder.mlp[0]  models.py:194-201  */
+  const float* t_w0; const float* t_b0; const float* t_w1; const float* t_b1;   /* t_embedder.mlp   */
+  const float* y_w0; const float* y_b0; const float* y_w1; const float* y_b1;   /* y_embedder       */
+  const float* ada_w[MH_MAX_LAYERS]; const float* ada_b[MH_MAX_LAYERS];   /* [6D, D]               */
+  const float* qkv_w[MH_MAX_LAYERS]; const float* qkv_b[MH_MAX_LAYERS];   /* attn.in_proj [3D, D]  */
+  const float* out_w[MH_MAX_LAYERS]; const float* out_b[MH_MAX_LAYERS];   /* attn.out_proj         */
+  const float* fc1_w[MH_MAX_LAYERS]; const float* fc1_b[MH_MAX_LAYERS];   /* mlp.fc1 [4D, D]       */
+  const float* fc2_w[MH_MAX_LAYERS]; const float* fc2_b[MH_MAX_LAYERS];   /* mlp.fc2 [D, 4D]       */
+  const float* fin_ada_w; const float* fin_ada_b;    /* final_layer.adaLN_modulation [2D, D]       */
+  const float* fin_w; const float* fin_b;            /* final_layer.linear [4, D]                  */
+} MhDiTWeights;
+
+int64_t mh_dit_workspace_bytes(const MhDiTConfig* cfg, int N, int T);
+
+/* One denoiser evaluation with classifier-free guidance.
+ *   x [N,2,T] fp32 (first half is duplicated internally as forward_with_cfg does, models.py:306-307)
+ *   t [N] int32 original-scale timesteps (already mapped by _WrappedModel, respace.py:127-132)
+ *   c [N,context,T] fp32;  y [N,class] fp32;  band: |i-j| < band attends (banded bool mask of
+ *   diffusion_pipeline.py:146-148), band <= 0 = full attention
+ *   out [N,4,T] fp32: CFG-combined eps (duplicated) ++ variance channels (models.py:312-317). */
+int mh_dit_forward_cfg(const MhDiTConfig* cfg, const MhDiTWeights* w, const float* x, const int32_t* t,
+                       const float* c, const float* y, float cfg_scale, int band, int N, int T, float* out,
+                       void* workspace, int64_t workspace_bytes, void* stream);
+
+/* One p_sample update (learned-range variance, epsilon prediction, clip_denoised -> clamp(-2,2)):
+ *   coef fp32[7] for this step, extracted on the host from the float64 schedule exactly as
+ *   _extract_into_tensor does (gaussian_diffusion.py:951-963):
+ *     {posterior_log_variance_clipped, log(beta), sqrt_recip_alphas_cumprod,
+ *      sqrt_recipm1_alphas_cumprod, posterior_mean_coef1, posterior_mean_coef2, nonzero_mask}
+ *   model_out [N,4,T]; x [N,2,T] in; noise [N,2,T]; inpaint_mask uint8 [N,2,T] (1 = generate) and
+ *   inpaint_ref [N,2,T] implement denoised_fn's `torch.where(mask, x, z_part)`
+ *   (diffusion_pipeline.py:203-206), both NULL to skip;  x_out [N,2,T]; pred_xstart optional. */
+int mh_ddpm_step(const float* model_out, const float* x, const float* noise, const float* coef,
+                 const uint8_t* inpaint_mask, const float* inpaint_ref, int N, int T, float* x_out,
+                 float* pred_xstart, void* stream);
+
+/* Whole p_sample_loop on device (gaussian_diffusion.py:469-561): `n_steps` iterations of
+ * mh_dit_forward_cfg + mh_ddpm_step captured once into a hipGraph and replayed.
+ *   t_map int32 [n_steps] : timestep_map[i] for loop index i (SpacedDiffusion, respace.py:72-86)
+ *   coefs fp32 [n_steps][7]; noise fp32 [n_steps][N,2,T], both indexed by loop index i
+ *   (the loop runs i = n_steps-1 ... 0).  x_io [N,2,T] is updated in place. */
+int mh_ddpm_sample_loop(const MhDiTConfig* cfg, const MhDiTWeights* w, float* x_io, const float* c,
+                        const float* y, float cfg_scale, int band, int N, int T, int n_steps,
+                        const int32_t* t_map, const float* coefs, const float* noise,
+                        const uint8_t* inpaint_mask, const float* inpaint_ref, void* workspace,
+                        int64_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MAPPERHIP_H_ */

@@ -1,0 +1,345 @@
+// K7 / K8 / K9  osu_diffusion DiT denoiser (adaLN-Zero blocks) + DDPM p_sample update, fp32.
+//   DiT.forward / forward_with_cfg   osu_diffusion/utils/models.py:281-317
+//   FirstLayer / TimestepEmbedder / LabelEmbedder / DiTBlock / FinalLayer   models.py:20-55,103-210
+//   timestep_embedding / position_sequence_embedding   utils/positional_embedding.py:29-49,66-77
+//   GaussianDiffusion.p_mean_variance / p_sample      utils/diffusion/gaussian_diffusion.py:273-369,420-467
+// Dense layers run on the exact-f32 MFMA atom (gemm.hip), attention on the banded flash kernel
+// (attention.hip); this file holds the small glue kernels and the orchestration.
+#include "internal.hpp"
+
+namespace mh {
+namespace {
+
+#define MH_TRY(expr)              \
+  do {                            \
+    int _rc = (expr);             \
+    if (_rc != MH_OK) return _rc; \
+  } while (0)
+
+// E[n*T + tp][:] = [ emb(512*x[n',0,tp]) (F) | emb(512*x[n',1,tp]) (F) | c[n,:,tp] (ctx) | 0 pad ],
+// emb(v) = [cos(v f_i) i<F/2 | sin(v f_i) i<F/2]; n' = n mod (N/2) (forward_with_cfg duplicates the
+// first half, models.py:306-307).
+__global__ __launch_bounds__(256) void dit_embed_kernel(const float* __restrict__ x, const float* __restrict__ c,
+                                                       const float* __restrict__ freqs, int N, int T, int F, int ctx,
+                                                       int kpad, float* __restrict__ E) {
+  const int row = blockIdx.x;  // n*T + tp
+  const int n = row / T, tp = row - n * T;
+  const int half_n = N / 2 > 0 ? N / 2 : 1;
+  const int ns = n % half_n;
+  const int hf = F / 2;
+  float* er = E + (long)row * kpad;
+  for (int j = threadIdx.x; j < kpad; j += 256) {
+    float v = 0.f;
+    if (j < 2 * F) {
+      const int ch = j / F, i = j - ch * F;
+      const float xv = x[((long)ns * 2 + ch) * T + tp] * 512.0f;
+      const float a = xv * freqs[i < hf ? i : i - hf];
+      v = i < hf ? cosf(a) : sinf(a);
+    } else if (j < 2 * F + ctx) {
+      v = c[((long)n * ctx + (j - 2 * F)) * T + tp];
+    }
+    er[j] = v;
+  }
+}
+
+// timestep_embedding(t, F): [cos(t f_i) | sin(t f_i)]
+__global__ void dit_tfreq_kernel(const int32_t* __restrict__ t_vals, const int* __restrict__ sel,
+                                 const float* __restrict__ freqs, int N, int F, float* __restrict__ out) {
+  const int n = blockIdx.x;
+  const float tv = (float)(sel ? t_vals[*sel] : t_vals[n]);
+  const int hf = F / 2;
+  for (int i = threadIdx.x; i < F; i += blockDim.x) {
+    const float a = tv * freqs[i < hf ? i : i - hf];
+    out[(long)n * F + i] = i < hf ? cosf(a) : sinf(a);
+  }
+}
+
+// out[n][j] (+)= act_out?( sum_k act_in?(in[n][k]) * W[j][k] + b[j] );  one wave per (n, j)
+template <bool SILU_IN, bool ACCUM>
+__global__ __launch_bounds__(256) void small_linear_kernel(const float* __restrict__ in, int ldi,
+                                                          const float* __restrict__ W, int ldw,
+                                                          const float* __restrict__ b, float* __restrict__ out, int ldo,
+                                                          int N, int J, int K, int silu_out) {
+  const int lane = threadIdx.x & 63;
+  const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (o >= N * J) return;
+  const int n = o / J, j = o - n * J;
+  const float* ip = in + (long)n * ldi;
+  const float* wp = W + (long)j * ldw;
+  float s = 0.f;
+  for (int k = lane; k < K; k += 64) {
+    float v = ip[k];
+    if (SILU_IN) v = v / (1.0f + expf(-v));
+    s += v * wp[k];
+  }
+  s = wave_sum(s);
+  if (lane == 0) {
+    s += b ? b[j] : 0.f;
+    if (silu_out) s = s / (1.0f + expf(-s));
+    float* op = out + (long)n * ldo + j;
+    *op = ACCUM ? *op + s : s;
+  }
+}
+
+// final Linear(D -> 4) on the modulated activations, (N, T, 4) -> (N, 4, T), then CFG combine of the eps
+// channels (models.py:312-317).  One wave per sequence position, all n.
+__global__ __launch_bounds__(256) void dit_final_kernel(const float* __restrict__ xm, const float* __restrict__ W,
+                                                       int ldw, const float* __restrict__ b, int N, int T, int D,
+                                                       float cfg_scale, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int tp = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tp >= T) return;
+  const int hn = N / 2;
+  for (int n = 0; n < hn; ++n) {
+    float v[2][4];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const float* xr = xm + ((long)(n + s2 * hn) * T + tp) * D;
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {
+        float s = 0.f;
+        for (int k = lane; k < D; k += 64) s += xr[k] * W[(long)o * ldw + k];
+        v[s2][o] = wave_sum(s) + b[o];
+      }
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int o = 0; o < 2; ++o) {
+        const float cond = v[0][o], uncond = v[1][o];
+        const float he = uncond + cfg_scale * (cond - uncond);
+        out[((long)n * 4 + o) * T + tp] = he;
+        out[((long)(n + hn) * 4 + o) * T + tp] = he;
+      }
+#pragma unroll
+      for (int o = 2; o < 4; ++o) {
+        out[((long)n * 4 + o) * T + tp] = v[0][o];
+        out[((long)(n + hn) * 4 + o) * T + tp] = v[1][o];
+      }
+    }
+  }
+}
+
+#pragma clang fp contract(off)
+__global__ __launch_bounds__(256) void ddpm_step_kernel(const float* __restrict__ model_out,
+                                                       const float* __restrict__ x, const float* __restrict__ noise,
+                                                       const float* __restrict__ coef, const int* __restrict__ sel,
+                                                       long noise_stride, const uint8_t* __restrict__ imask,
+                                                       const float* __restrict__ iref, int N, int T,
+                                                       float* __restrict__ x_out, float* __restrict__ pred) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= N * 2 * T) return;
+  const int si = sel ? *sel : 0;
+  const float* cf = coef + (long)si * 7;
+  const float* nz = noise + (long)si * noise_stride;
+  const int n = idx / (2 * T), rem = idx - n * 2 * T, ch = rem / T, tp = rem - ch * T;
+  const float eps = model_out[((long)n * 4 + ch) * T + tp];
+  const float var = model_out[((long)n * 4 + 2 + ch) * T + tp];
+  const float xt = x[idx];
+  const float min_log = cf[0], max_log = cf[1];
+  const float frac = (var + 1.0f) / 2.0f;
+  const float logvar = frac * max_log + (1.0f - frac) * min_log;
+  float x0 = cf[2] * xt - cf[3] * eps;
+  if (imask) x0 = imask[idx] ? x0 : iref[idx];
+  x0 = fminf(fmaxf(x0, -2.0f), 2.0f);
+  const float mean = cf[4] * x0 + cf[5] * xt;
+  const float smp = mean + (cf[6] * expf(0.5f * logvar)) * nz[idx];
+  x_out[idx] = smp;
+  if (pred) pred[idx] = x0;
+}
+#pragma clang fp contract(fast)
+
+__global__ void loop_dec_kernel(int* sel) {
+  if (threadIdx.x == 0) *sel = *sel - 1;
+}
+__global__ void loop_set_kernel(int* sel, int v) {
+  if (threadIdx.x == 0) *sel = v;
+}
+
+struct DiTBuf {
+  float *E, *xs, *xm, *qk, *vt, *attn, *hid, *tfreq, *temb1, *temb, *yemb1, *bvec, *mod, *modf;
+  int* sel;
+  int Tpad;
+};
+
+int64_t dit_ws_layout(const MhDiTConfig* c, int N, int T, void* base, int64_t size, DiTBuf* b) {
+  Arena ar(base, size);
+  const int64_t NT = (int64_t)N * T;
+  const int D = c->hidden, Tpad = round_up(T, 64);
+  DiTBuf t;
+  t.Tpad = Tpad;
+  t.E = (float*)ar.take(NT * c->first_k_pad * 4);
+  t.xs = (float*)ar.take(NT * D * 4);
+  t.xm = (float*)ar.take(NT * D * 4);
+  t.qk = (float*)ar.take(NT * 2 * D * 4);
+  t.vt = (float*)ar.take((int64_t)N * D * Tpad * 4);
+  t.attn = (float*)ar.take(NT * D * 4);
+  t.hid = (float*)ar.take(NT * 4 * D * 4);
+  t.tfreq = (float*)ar.take((int64_t)N * c->t_freq_dim * 4);
+  t.temb1 = (float*)ar.take((int64_t)N * D * 4);
+  t.temb = (float*)ar.take((int64_t)N * D * 4);
+  t.yemb1 = (float*)ar.take((int64_t)N * D * 4);
+  t.bvec = (float*)ar.take((int64_t)N * D * 4);
+  t.mod = (float*)ar.take((int64_t)N * 6 * D * 4);
+  t.modf = (float*)ar.take((int64_t)N * 2 * D * 4);
+  t.sel = (int*)ar.take(256);
+  if (b) *b = t;
+  return ar.off;
+}
+
+template <bool SILU_IN, bool ACCUM>
+int small_linear(const float* in, int ldi, const float* W, int ldw, const float* b, float* out, int ldo, int N, int J,
+                 int K, int silu_out, hipStream_t s) {
+  hipLaunchKernelGGL((small_linear_kernel<SILU_IN, ACCUM>), dim3(ceil_div(N * J, 4)), dim3(256), 0, s, in, ldi, W, ldw,
+                     b, out, ldo, N, J, K, silu_out);
+  return check_launch("small_linear_kernel");
+}
+
+int check_dit(const MhDiTConfig* c, int N, int T) {
+  MH_REQUIRE(c, "dit: null config");
+  MH_REQUIRE(c->hidden == c->n_heads * 64, "dit: hidden must be n_heads*64");
+  MH_REQUIRE(c->depth <= MH_MAX_LAYERS && c->in_channels == 2, "dit: unsupported depth / in_channels");
+  MH_REQUIRE(c->first_k_pad % 32 == 0 && c->first_k_pad >= 2 * c->freq_dim + c->context_size, "dit: bad first_k_pad");
+  MH_REQUIRE(c->class_pad >= c->class_size, "dit: bad class_pad");
+  MH_REQUIRE(N >= 2 && N % 2 == 0 && T > 0, "dit: N must be even (CFG batch) and T > 0");
+  return MH_OK;
+}
+
+// t_vals/sel: see dit_tfreq_kernel.  `freqs` tables live behind the weights struct.
+int dit_forward(const MhDiTConfig* c, const MhDiTWeights* w, const float* x, const int32_t* t_vals, const int* sel,
+                const float* cc, const float* y, float cfg_scale, int band, int N, int T, float* out, const DiTBuf& b,
+                hipStream_t s) {
+  const int D = c->hidden, H = c->n_heads, NT = N * T;
+  hipLaunchKernelGGL(dit_embed_kernel, dim3(NT), dim3(256), 0, s, x, cc, w->pos_freqs, N, T, c->freq_dim,
+                     c->context_size, c->first_k_pad, b.E);
+  MH_TRY(check_launch("dit_embed_kernel"));
+  MhGemm g = MhGemm{};
+  g.A = b.E; g.lda = c->first_k_pad; g.W = w->first_w; g.ldw = c->first_k_pad; g.C = b.xs; g.ldc = D; g.M = NT; g.N = D;
+  g.K = c->first_k_pad; g.bias = w->first_b; g.dtype = MH_F32; g.epilogue = MH_EPI_STORE_F32;
+  MH_TRY(gemm(g, s));
+  // b = t_embedder(t) + y_embedder(y)
+  hipLaunchKernelGGL(dit_tfreq_kernel, dim3(N), dim3(256), 0, s, t_vals, sel, w->t_freqs, N, c->t_freq_dim, b.tfreq);
+  MH_TRY(check_launch("dit_tfreq_kernel"));
+  MH_TRY((small_linear<false, false>(b.tfreq, c->t_freq_dim, w->t_w0, c->t_freq_dim, w->t_b0, b.temb1, D, N, D,
+                                     c->t_freq_dim, 1, s)));
+  MH_TRY((small_linear<false, false>(b.temb1, D, w->t_w1, D, w->t_b1, b.bvec, D, N, D, D, 0, s)));
+  MH_TRY((small_linear<false, false>(y, c->class_size, w->y_w0, c->class_pad, w->y_b0, b.yemb1, D, N, D, c->class_size,
+                                     1, s)));
+  MH_TRY((small_linear<false, true>(b.yemb1, D, w->y_w1, D, w->y_b1, b.bvec, D, N, D, D, 0, s)));
+
+  if (hipMemsetAsync(b.vt, 0, (size_t)N * D * b.Tpad * 4, s) != hipSuccess) return check_launch("memset vt");
+  for (int l = 0; l < c->depth; ++l) {
+    MH_TRY((small_linear<true, false>(b.bvec, D, w->ada_w[l], D, w->ada_b[l], b.mod, 6 * D, N, 6 * D, D, 0, s)));
+    // attention branch
+    MH_TRY(ln_modulate(b.xs, D, b.mod + 0 * D, b.mod + 1 * D, 6 * D, T, b.xm, D, NT, D, 1e-6f, s));
+    g = MhGemm{};
+    g.A = b.xm; g.lda = D; g.W = w->qkv_w[l]; g.ldw = D; g.C = b.qk; g.ldc = 2 * D; g.M = NT; g.N = 3 * D; g.K = D;
+    g.bias = w->qkv_b[l]; g.dtype = MH_F32; g.epilogue = MH_EPI_QKV_VT; g.C2 = b.vt; g.n_split = 2 * D; g.kv_B = N;
+    g.kv_H = H; g.kv_L = T; g.kv_Lpad = b.Tpad;
+    MH_TRY(gemm(g, s));
+    MH_TRY(attention(b.qk, 2 * D, D, b.vt, b.Tpad, nullptr, b.attn, D, N, T, H, 0.125f, band, MH_F32, s));
+    g = MhGemm{};
+    g.A = b.attn; g.lda = D; g.W = w->out_w[l]; g.ldw = D; g.C = b.xs; g.ldc = D; g.M = NT; g.N = D; g.K = D;
+    g.bias = w->out_b[l]; g.gate = b.mod + 2 * D; g.gate_ld = 6 * D; g.rows_per_batch = T; g.dtype = MH_F32;
+    g.epilogue = MH_EPI_GATE_RESID;
+    MH_TRY(gemm(g, s));
+    // MLP branch
+    MH_TRY(ln_modulate(b.xs, D, b.mod + 3 * D, b.mod + 4 * D, 6 * D, T, b.xm, D, NT, D, 1e-6f, s));
+    g = MhGemm{};
+    g.A = b.xm; g.lda = D; g.W = w->fc1_w[l]; g.ldw = D; g.C = b.hid; g.ldc = 4 * D; g.M = NT; g.N = 4 * D; g.K = D;
+    g.bias = w->fc1_b[l]; g.dtype = MH_F32; g.epilogue = MH_EPI_BIAS_GELU;
+    MH_TRY(gemm(g, s));
+    g = MhGemm{};
+    g.A = b.hid; g.lda = 4 * D; g.W = w->fc2_w[l]; g.ldw = 4 * D; g.C = b.xs; g.ldc = D; g.M = NT; g.N = D; g.K = 4 * D;
+    g.bias = w->fc2_b[l]; g.gate = b.mod + 5 * D; g.gate_ld = 6 * D; g.rows_per_batch = T; g.dtype = MH_F32;
+    g.epilogue = MH_EPI_GATE_RESID;
+    MH_TRY(gemm(g, s));
+  }
+  MH_TRY((small_linear<true, false>(b.bvec, D, w->fin_ada_w, D, w->fin_ada_b, b.modf, 2 * D, N, 2 * D, D, 0, s)));
+  MH_TRY(ln_modulate(b.xs, D, b.modf, b.modf + D, 2 * D, T, b.xm, D, NT, D, 1e-6f, s));
+  hipLaunchKernelGGL(dit_final_kernel, dim3(ceil_div(T, 4)), dim3(256), 0, s, b.xm, w->fin_w, D, w->fin_b, N, T, D,
+                     cfg_scale, out);
+  return check_launch("dit_final_kernel");
+}
+
+int ddpm_step(const float* model_out, const float* x, const float* noise, const float* coef, const int* sel,
+              long noise_stride, const uint8_t* imask, const float* iref, int N, int T, float* x_out, float* pred,
+              hipStream_t s) {
+  hipLaunchKernelGGL(ddpm_step_kernel, dim3(ceil_div(N * 2 * T, 256)), dim3(256), 0, s, model_out, x, noise, coef, sel,
+                     noise_stride, imask, iref, N, T, x_out, pred);
+  return check_launch("ddpm_step_kernel");
+}
+
+}  // namespace
+}  // namespace mh
+
+using namespace mh;
+
+extern "C" int64_t mh_dit_workspace_bytes(const MhDiTConfig* c, int N, int T) {
+  if (!c || N <= 0 || T <= 0) return -1;
+  return dit_ws_layout(c, N, T, nullptr, 0, nullptr) + align256((int64_t)N * 4 * T * 4);
+}
+
+extern "C" int mh_dit_forward_cfg(const MhDiTConfig* c, const MhDiTWeights* w, const float* x, const int32_t* t,
+                                  const float* cc, const float* y, float cfg_scale, int band, int N, int T, float* out,
+                                  void* workspace, int64_t workspace_bytes, void* stream) {
+  MH_TRY(check_dit(c, N, T));
+  MH_REQUIRE(w && x && t && cc && y && out && workspace, "mh_dit_forward_cfg: null argument");
+  MH_REQUIRE(workspace_bytes >= mh_dit_workspace_bytes(c, N, T), "mh_dit_forward_cfg: workspace too small");
+  DiTBuf b;
+  dit_ws_layout(c, N, T, workspace, workspace_bytes, &b);
+  return dit_forward(c, w, x, t, nullptr, cc, y, cfg_scale, band, N, T, out, b, (hipStream_t)stream);
+}
+
+extern "C" int mh_ddpm_step(const float* model_out, const float* x, const float* noise, const float* coef,
+                            const uint8_t* inpaint_mask, const float* inpaint_ref, int N, int T, float* x_out,
+                            float* pred_xstart, void* stream) {
+  MH_REQUIRE(model_out && x && noise && coef && x_out && N > 0 && T > 0, "mh_ddpm_step: bad argument");
+  MH_REQUIRE((inpaint_mask == nullptr) == (inpaint_ref == nullptr), "mh_ddpm_step: inpaint mask/ref must come together");
+  return ddpm_step(model_out, x, noise, coef, nullptr, 0, inpaint_mask, inpaint_ref, N, T, x_out, pred_xstart,
+                   (hipStream_t)stream);
+}
+
+extern "C" int mh_ddpm_sample_loop(const MhDiTConfig* c, const MhDiTWeights* w, float* x_io, const float* cc,
+                                   const float* y, float cfg_scale, int band, int N, int T, int n_steps,
+                                   const int32_t* t_map, const float* coefs, const float* noise,
+                                   const uint8_t* inpaint_mask, const float* inpaint_ref, void* workspace,
+                                   int64_t workspace_bytes, void* stream) {
+  MH_TRY(check_dit(c, N, T));
+  MH_REQUIRE(w && x_io && cc && y && t_map && coefs && noise && workspace && n_steps > 0,
+             "mh_ddpm_sample_loop: null argument");
+  MH_REQUIRE(stream != nullptr, "mh_ddpm_sample_loop: needs a non-default stream (hipGraph capture)");
+  MH_REQUIRE(workspace_bytes >= mh_dit_workspace_bytes(c, N, T), "mh_ddpm_sample_loop: workspace too small");
+  MH_REQUIRE((inpaint_mask == nullptr) == (inpaint_ref == nullptr), "mh_ddpm_sample_loop: inpaint mask/ref mismatch");
+  hipStream_t s = (hipStream_t)stream;
+  DiTBuf b;
+  const int64_t used = dit_ws_layout(c, N, T, workspace, workspace_bytes, &b);
+  float* mout = (float*)((char*)workspace + used);
+  MH_TRY(gemm_prepare());
+  hipLaunchKernelGGL(loop_set_kernel, dim3(1), dim3(64), 0, s, b.sel, n_steps - 1);
+  MH_TRY(check_launch("loop_set_kernel"));
+
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) return check_launch("begin capture");
+  int rc = dit_forward(c, w, x_io, t_map, b.sel, cc, y, cfg_scale, band, N, T, mout, b, s);
+  if (rc == MH_OK)
+    rc = ddpm_step(mout, x_io, noise, coefs, b.sel, (long)N * 2 * T, inpaint_mask, inpaint_ref, N, T, x_io, nullptr, s);
+  if (rc == MH_OK) {
+    hipLaunchKernelGGL(loop_dec_kernel, dim3(1), dim3(64), 0, s, b.sel);
+    rc = check_launch("loop_dec_kernel");
+  }
+  hipError_t ce = hipStreamEndCapture(s, &graph);
+  if (rc != MH_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+  if (ce != hipSuccess || !graph) { set_error("mh_ddpm_sample_loop: capture failed: %s", hipGetErrorString(ce)); return MH_ERR_LAUNCH; }
+  if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+    (void)hipGraphDestroy(graph);
+    return check_launch("graph instantiate");
+  }
+  int rc2 = MH_OK;
+  for (int i = 0; i < n_steps; ++i)
+    if (hipGraphLaunch(exec, s) != hipSuccess) { rc2 = check_launch("graph launch"); break; }
+  (void)hipStreamSynchronize(s);
+  (void)hipGraphExecDestroy(exec);
+  (void)hipGraphDestroy(graph);
+  return rc2;
+}

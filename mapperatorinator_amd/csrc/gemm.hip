@@ -1,0 +1,294 @@
+// Dense layer C = A[M,K] * W[N,K]^T on the gfx950 matrix cores with fused epilogues.
+//
+// Structure: LDS-tiled, register-prefetched, double-buffered LDS, one barrier per K step.
+//   block = 256 threads = 4 waves as 2(M) x 2(N); tile BMxBN in {128x128, 64x64};
+//   K step = 128 bytes per row (64 bf16 / 32 f32) staged with 16-byte loads; LDS rows padded by 16 B.
+//   MFMA atom: v_mfma_f32_16x16x32_bf16 (bf16 storage) or the exact v_mfma_f32_16x16x4_f32 (f32).
+// Both operands are K-contiguous ("B^T input"), which is the nn.Linear weight layout -- no transposes.
+#include "common.hpp"
+
+namespace mh {
+
+namespace {
+
+constexpr int kRowBytes = 128;            // K-step bytes per tile row
+constexpr int kRowStride = kRowBytes + 16;  // padded LDS row stride in bytes
+
+struct GemmP {
+  const char* A; long lda_b;  // leading dimension in BYTES
+  const char* W; long ldw_b;
+  void* C; int ldc;
+  int M, N, K;
+  const float* bias;
+  const float* gate; int gate_ld; int rows_per_batch;
+  int kv_B, kv_H, kv_L;
+  void* C2; int n_split; int kv_Lpad;
+};
+
+template <typename T, int EPI>
+__device__ inline void epilogue_store(const GemmP& p, int row, int col, float v, float v2) {
+  // v2 only used by GEGLU (the paired linear value)
+  if (row >= p.M) return;
+  if (EPI == MH_EPI_GEGLU) {
+    // col is the output column in [0, N/2)
+    if (col >= p.N / 2) return;
+    T* C = reinterpret_cast<T*>(p.C);
+    C[(long)row * p.ldc + col] = Elem<T>::from_f32(gelu_tanh(v) * v2);
+    return;
+  }
+  if (col >= p.N) return;
+  if (EPI != MH_EPI_GEGLU && p.bias) v += p.bias[col];
+  if (EPI == MH_EPI_STORE) {
+    reinterpret_cast<T*>(p.C)[(long)row * p.ldc + col] = Elem<T>::from_f32(v);
+  } else if (EPI == MH_EPI_STORE_F32) {
+    reinterpret_cast<float*>(p.C)[(long)row * p.ldc + col] = v;
+  } else if (EPI == MH_EPI_RESID) {
+    float* c = reinterpret_cast<float*>(p.C) + (long)row * p.ldc + col;
+    *c = *c + v;
+  } else if (EPI == MH_EPI_BIAS_GELU) {
+    reinterpret_cast<T*>(p.C)[(long)row * p.ldc + col] = Elem<T>::from_f32(gelu_tanh(v));
+  } else if (EPI == MH_EPI_GATE_RESID) {
+    float g = p.gate[(long)(row / p.rows_per_batch) * p.gate_ld + col];
+    float* c = reinterpret_cast<float*>(p.C) + (long)row * p.ldc + col;
+    *c = *c + g * v;
+  } else if (EPI == MH_EPI_KV_SCATTER) {
+    // col = ((layer*2 + kv) * H + h) * 64 + dd ; row = b * L + key
+    const int dd = col & 63;
+    const int h = (col >> 6) % p.kv_H;
+    const int lk = (col >> 6) / p.kv_H;  // layer*2 + kv
+    const int b = row / p.kv_L, key = row - b * p.kv_L;
+    long dst = ((((long)lk * p.kv_B + b) * p.kv_H + h) * p.kv_L + key) * 64 + dd;
+    reinterpret_cast<T*>(p.C)[dst] = Elem<T>::from_f32(v);
+  } else if (EPI == MH_EPI_QKV_VT) {
+    if (col < p.n_split) {
+      reinterpret_cast<T*>(p.C)[(long)row * p.ldc + col] = Elem<T>::from_f32(v);
+    } else {
+      const int c2 = col - p.n_split;  // h*64 + dd
+      const int b = row / p.kv_L, key = row - b * p.kv_L;
+      long dst = ((long)b * p.kv_H * 64 + c2) * p.kv_Lpad + key;
+      reinterpret_cast<T*>(p.C2)[dst] = Elem<T>::from_f32(v);
+    }
+  }
+}
+
+template <typename T, int BM, int BN, int EPI>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmP p) {
+  constexpr int VEC = Elem<T>::kVec;          // elements per 16 B
+  constexpr int BK = kRowBytes / (int)sizeof(T);
+  constexpr int KM = Atom<T>::KM;
+  constexpr int KCH = Atom<T>::KCH;
+  constexpr int WM = BM / 2, WN = BN / 2;     // wave tile
+  constexpr int MI = WM / 16, NI = WN / 16;
+  constexpr int A_CHUNKS = BM * 8 / 256;      // 16-byte chunks per thread for the A tile
+  constexpr int B_CHUNKS = BN * 8 / 256;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int kBufBytes = (BM + BN) * kRowStride;  // one (A tile, B tile) stage
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wr = wid >> 1, wc = wid & 1;
+
+  // XCD-aware tile order: consecutive tiles that share an A panel land on the same XCD (8 XCDs,
+  // block b -> XCD b % 8 as dispatched).  Bijective remap for any grid size.
+  const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
+  const int nwg = nbm * nbn;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int bm = bid / nbn, bn = bid % nbn;
+  const int m0 = bm * BM, n0 = bn * BN;
+
+  const int cchunk = tid & 7;   // 16-byte chunk within the 128-byte K step
+  const int crow = tid >> 3;    // 0..31
+
+  uint4 ra[A_CHUNKS], rb[B_CHUNKS];
+  const int nk = (p.K + BK - 1) / BK;
+
+  auto load_tiles = [&](int kt) {
+    const int k_el = kt * BK + cchunk * VEC;
+    const bool kin = k_el < p.K;
+#pragma unroll
+    for (int i = 0; i < A_CHUNKS; ++i) {
+      int r = m0 + crow + 32 * i;
+      r = r < p.M ? r : p.M - 1;
+      ra[i] = kin ? *reinterpret_cast<const uint4*>(p.A + (long)r * p.lda_b + (long)k_el * sizeof(T))
+                  : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < B_CHUNKS; ++i) {
+      int r = n0 + crow + 32 * i;
+      r = r < p.N ? r : p.N - 1;
+      rb[i] = kin ? *reinterpret_cast<const uint4*>(p.W + (long)r * p.ldw_b + (long)k_el * sizeof(T))
+                  : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto store_tiles = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < A_CHUNKS; ++i)
+      *reinterpret_cast<uint4*>(smem + buf * kBufBytes + (crow + 32 * i) * kRowStride + cchunk * 16) = ra[i];
+#pragma unroll
+    for (int i = 0; i < B_CHUNKS; ++i)
+      *reinterpret_cast<uint4*>(smem + buf * kBufBytes + (BM + crow + 32 * i) * kRowStride + cchunk * 16) = rb[i];
+  };
+
+  f32x4_t acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  load_tiles(0);
+  store_tiles(0);
+  __syncthreads();
+
+  const int frow = lane & 15, fk = (lane >> 4) * KCH;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) load_tiles(kt + 1);
+    const char* a_base = smem + cur * kBufBytes + (wr * WM + frow) * kRowStride + fk * (int)sizeof(T);
+    const char* b_base = smem + cur * kBufBytes + (BM + wc * WN + frow) * kRowStride + fk * (int)sizeof(T);
+#pragma unroll
+    for (int ks = 0; ks < BK / KM; ++ks) {
+      typename Atom<T>::frag_t af[MI], bf[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+        af[i] = Atom<T>::load(reinterpret_cast<const T*>(a_base + i * 16 * kRowStride + ks * KM * (int)sizeof(T)));
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+        bf[j] = Atom<T>::load(reinterpret_cast<const T*>(b_base + j * 16 * kRowStride + ks * KM * (int)sizeof(T)));
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = Atom<T>::mma(af[i], bf[j], acc[i][j]);
+    }
+    if (kt + 1 < nk) store_tiles(cur ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: acc[i][j][r] = C[m0 + wr*WM + i*16 + (lane>>4)*4 + r][n0 + wc*WN + j*16 + (lane&15)]
+  const int erow0 = m0 + wr * WM + (lane >> 4) * 4;
+  const int ecol0 = n0 + wc * WN + (lane & 15);
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = erow0 + i * 16 + r;
+      if (EPI == MH_EPI_GEGLU) {
+#pragma unroll
+        for (int j = 0; j < NI; j += 2) {
+          // 16-row weight blocks alternate wi_0 / wi_1: fragment j is the gate, j+1 the linear half
+          const int ocol = (n0 + wc * WN) / 2 + (j / 2) * 16 + (lane & 15);
+          epilogue_store<T, EPI>(p, row, ocol, acc[i][j][r], acc[i][j + 1][r]);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) epilogue_store<T, EPI>(p, row, ecol0 + j * 16, acc[i][j][r], 0.f);
+      }
+    }
+  }
+}
+
+template <typename T, int BM, int BN, int EPI>
+int launch_gemm(const GemmP& p, hipStream_t s) {
+  const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
+  const size_t smem = 2 * (size_t)(BM + BN) * kRowStride;
+  hipLaunchKernelGGL((gemm_tn_kernel<T, BM, BN, EPI>), dim3(nbm * nbn), dim3(256), smem, s, p);
+  return check_launch("gemm_tn_kernel");
+}
+
+// > 64 KiB of dynamic LDS needs an explicit opt-in per kernel; done once for every instantiation,
+// outside any stream capture (gemm_prepare()).
+template <typename T, int BM, int BN, int EPI>
+bool prepare_one() {
+  const size_t smem = 2 * (size_t)(BM + BN) * kRowStride;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel<T, BM, BN, EPI>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) == hipSuccess;
+}
+template <typename T, int EPI>
+bool prepare_epi() {
+  return prepare_one<T, 128, 128, EPI>() && prepare_one<T, 64, 64, EPI>();
+}
+template <typename T>
+bool prepare_type() {
+  return prepare_epi<T, MH_EPI_STORE>() && prepare_epi<T, MH_EPI_STORE_F32>() && prepare_epi<T, MH_EPI_RESID>() &&
+         prepare_epi<T, MH_EPI_GEGLU>() && prepare_epi<T, MH_EPI_BIAS_GELU>() && prepare_epi<T, MH_EPI_GATE_RESID>() &&
+         prepare_epi<T, MH_EPI_KV_SCATTER>() && prepare_epi<T, MH_EPI_QKV_VT>();
+}
+
+template <typename T, int EPI>
+int dispatch_tile(const GemmP& p, hipStream_t s) {
+  const long tiles128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+  if (tiles128 >= 192) return launch_gemm<T, 128, 128, EPI>(p, s);
+  return launch_gemm<T, 64, 64, EPI>(p, s);
+}
+
+template <typename T>
+int dispatch_epi(const GemmP& p, int epi, hipStream_t s) {
+  switch (epi) {
+    case MH_EPI_STORE: return dispatch_tile<T, MH_EPI_STORE>(p, s);
+    case MH_EPI_STORE_F32: return dispatch_tile<T, MH_EPI_STORE_F32>(p, s);
+    case MH_EPI_RESID: return dispatch_tile<T, MH_EPI_RESID>(p, s);
+    case MH_EPI_GEGLU: return dispatch_tile<T, MH_EPI_GEGLU>(p, s);
+    case MH_EPI_BIAS_GELU: return dispatch_tile<T, MH_EPI_BIAS_GELU>(p, s);
+    case MH_EPI_GATE_RESID: return dispatch_tile<T, MH_EPI_GATE_RESID>(p, s);
+    case MH_EPI_KV_SCATTER: return dispatch_tile<T, MH_EPI_KV_SCATTER>(p, s);
+    case MH_EPI_QKV_VT: return dispatch_tile<T, MH_EPI_QKV_VT>(p, s);
+  }
+  set_error("mh_gemm: unknown epilogue %d", epi);
+  return MH_ERR_ARG;
+}
+
+}  // namespace
+
+int gemm_prepare() {
+  static bool done = false;
+  if (done) return MH_OK;
+  if (!(prepare_type<bf16_t>() && prepare_type<float>())) {
+    set_error("gemm_prepare: hipFuncSetAttribute failed: %s", hipGetErrorString(hipGetLastError()));
+    return MH_ERR_LAUNCH;
+  }
+  done = true;
+  return MH_OK;
+}
+
+int gemm(const MhGemm& g, hipStream_t s) {
+  { int rc = gemm_prepare(); if (rc != MH_OK) return rc; }
+  MH_REQUIRE(g.A && g.W && g.C, "mh_gemm: null operand");
+  MH_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0, "mh_gemm: bad shape M=%d N=%d K=%d", g.M, g.N, g.K);
+  MH_REQUIRE(g.dtype == MH_F32 || g.dtype == MH_BF16, "mh_gemm: bad dtype %d", g.dtype);
+  const int es = g.dtype == MH_BF16 ? 2 : 4;
+  const int vec = 16 / es;
+  MH_REQUIRE(g.K % vec == 0 && g.lda % vec == 0 && g.ldw % vec == 0,
+             "mh_gemm: K=%d lda=%d ldw=%d must be multiples of %d", g.K, g.lda, g.ldw, vec);
+  MH_REQUIRE(((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.W % 16) == 0, "mh_gemm: operands must be 16-byte aligned");
+  MH_REQUIRE(g.lda >= g.K && g.ldw >= g.K, "mh_gemm: leading dimension smaller than K");
+  if (g.epilogue == MH_EPI_GEGLU) MH_REQUIRE(g.N % 32 == 0, "mh_gemm: GEGLU needs N %% 32 == 0 (N=%d)", g.N);
+  if (g.epilogue == MH_EPI_GATE_RESID)
+    MH_REQUIRE(g.gate && g.rows_per_batch > 0, "mh_gemm: GATE_RESID needs gate and rows_per_batch");
+  if (g.epilogue == MH_EPI_KV_SCATTER)
+    MH_REQUIRE(g.kv_B > 0 && g.kv_H > 0 && g.kv_L > 0 && g.M == g.kv_B * g.kv_L && g.N % (g.kv_H * 64) == 0,
+               "mh_gemm: bad KV scatter geometry");
+  if (g.epilogue == MH_EPI_QKV_VT)
+    MH_REQUIRE(g.C2 && g.kv_H > 0 && g.kv_L > 0 && g.kv_Lpad >= g.kv_L && g.n_split > 0 &&
+                   g.N - g.n_split == g.kv_H * 64 && g.M % g.kv_L == 0,
+               "mh_gemm: bad QKV_VT geometry");
+  GemmP p;
+  p.C2 = g.C2; p.n_split = g.n_split; p.kv_Lpad = g.kv_Lpad;
+  p.A = (const char*)g.A; p.lda_b = (long)g.lda * es;
+  p.W = (const char*)g.W; p.ldw_b = (long)g.ldw * es;
+  p.C = g.C; p.ldc = g.ldc;
+  p.M = g.M; p.N = g.N; p.K = g.K;
+  p.bias = g.bias; p.gate = g.gate; p.gate_ld = g.gate_ld; p.rows_per_batch = g.rows_per_batch;
+  p.kv_B = g.kv_B; p.kv_H = g.kv_H; p.kv_L = g.kv_L;
+  if (g.dtype == MH_BF16) return dispatch_epi<bf16_t>(p, g.epilogue, s);
+  return dispatch_epi<float>(p, g.epilogue, s);
+}
+
+}  // namespace mh
+
+extern "C" int mh_gemm(const MhGemm* g, void* stream) {
+  if (!g) { mh::set_error("mh_gemm: null descriptor"); return MH_ERR_ARG; }
+  return mh::gemm(*g, (hipStream_t)stream);
+}

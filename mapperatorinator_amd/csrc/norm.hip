@@ -1,0 +1,103 @@
+// Row-wise normalisation kernels (HBM-bound, one wave per row, 16-byte vector access).
+//   rmsnorm      : T5LayerNorm  (HF modeling_t5 T5LayerNorm; restated custom_transformers/t5.py:50-62)
+//   ln_modulate  : LayerNorm(no affine, eps) followed by adaLN modulate x*(1+scale)+shift
+//                  (osu_diffusion/utils/models.py:11-12,110,117,140-155)
+#include "common.hpp"
+
+namespace mh {
+namespace {
+
+template <typename T>
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ x, int ldx,
+                                                     const float* __restrict__ w, T* __restrict__ y, int ldy,
+                                                     int rows, int d, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + (long)row * ldx;
+  float ss = 0.f;
+  for (int i = lane * 4; i < d; i += 256) {
+    float4 v = *reinterpret_cast<const float4*>(xr + i);
+    ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  ss = wave_sum(ss);
+  const float rs = rsqrtf(ss / (float)d + eps);
+  T* yr = y + (long)row * ldy;
+  for (int i = lane * 4; i < d; i += 256) {
+    float4 v = *reinterpret_cast<const float4*>(xr + i);
+    float4 g = *reinterpret_cast<const float4*>(w + i);
+    yr[i + 0] = Elem<T>::from_f32(g.x * (v.x * rs));
+    yr[i + 1] = Elem<T>::from_f32(g.y * (v.y * rs));
+    yr[i + 2] = Elem<T>::from_f32(g.z * (v.z * rs));
+    yr[i + 3] = Elem<T>::from_f32(g.w * (v.w * rs));
+  }
+}
+
+// x [rows, d] fp32; shift/scale: [n_batch, mod_ld] rows selected by row / rows_per_batch.
+__global__ __launch_bounds__(256) void ln_modulate_kernel(const float* __restrict__ x, int ldx,
+                                                         const float* __restrict__ shift,
+                                                         const float* __restrict__ scale, int mod_ld,
+                                                         int rows_per_batch, float* __restrict__ y, int ldy,
+                                                         int rows, int d, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + (long)row * ldx;
+  float s = 0.f;
+  for (int i = lane * 4; i < d; i += 256) {
+    float4 v = *reinterpret_cast<const float4*>(xr + i);
+    s += v.x + v.y + v.z + v.w;
+  }
+  const float mean = wave_sum(s) / (float)d;
+  float ss = 0.f;
+  for (int i = lane * 4; i < d; i += 256) {
+    float4 v = *reinterpret_cast<const float4*>(xr + i);
+    float a = v.x - mean, b = v.y - mean, c = v.z - mean, e = v.w - mean;
+    ss += a * a + b * b + c * c + e * e;
+  }
+  const float rs = rsqrtf(wave_sum(ss) / (float)d + eps);
+  const int bidx = row / rows_per_batch;
+  const float* sh = shift + (long)bidx * mod_ld;
+  const float* sc = scale + (long)bidx * mod_ld;
+  float* yr = y + (long)row * ldy;
+  for (int i = lane * 4; i < d; i += 256) {
+    float4 v = *reinterpret_cast<const float4*>(xr + i);
+    float4 a = *reinterpret_cast<const float4*>(sh + i);
+    float4 b = *reinterpret_cast<const float4*>(sc + i);
+    float4 o;
+    o.x = (v.x - mean) * rs * (1.f + b.x) + a.x;
+    o.y = (v.y - mean) * rs * (1.f + b.y) + a.y;
+    o.z = (v.z - mean) * rs * (1.f + b.z) + a.z;
+    o.w = (v.w - mean) * rs * (1.f + b.w) + a.w;
+    *reinterpret_cast<float4*>(yr + i) = o;
+  }
+}
+
+}  // namespace
+
+int rmsnorm(const float* x, int ldx, const float* w, void* y, int ldy, int rows, int d, float eps, int out_dtype,
+            hipStream_t s) {
+  MH_REQUIRE(x && w && y && rows > 0 && d > 0, "mh_rmsnorm: bad arguments");
+  MH_REQUIRE(d % 4 == 0 && ldx % 4 == 0, "mh_rmsnorm: d and ldx must be multiples of 4");
+  dim3 grid(ceil_div(rows, 4)), block(256);
+  if (out_dtype == MH_BF16)
+    hipLaunchKernelGGL(rmsnorm_kernel<bf16_t>, grid, block, 0, s, x, ldx, w, (bf16_t*)y, ldy, rows, d, eps);
+  else
+    hipLaunchKernelGGL(rmsnorm_kernel<float>, grid, block, 0, s, x, ldx, w, (float*)y, ldy, rows, d, eps);
+  return check_launch("rmsnorm_kernel");
+}
+
+int ln_modulate(const float* x, int ldx, const float* shift, const float* scale, int mod_ld, int rows_per_batch,
+                float* y, int ldy, int rows, int d, float eps, hipStream_t s) {
+  MH_REQUIRE(d % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && mod_ld % 4 == 0, "ln_modulate: alignment");
+  hipLaunchKernelGGL(ln_modulate_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, s, x, ldx, shift, scale, mod_ld,
+                     rows_per_batch, y, ldy, rows, d, eps);
+  return check_launch("ln_modulate_kernel");
+}
+
+}  // namespace mh
+
+extern "C" int mh_rmsnorm(const float* x, int ldx, const float* w, void* y, int ldy, int rows, int d, float eps,
+                          int out_dtype, void* stream) {
+  return mh::rmsnorm(x, ldx, w, y, ldy, rows, d, eps, out_dtype, (hipStream_t)stream);
+}

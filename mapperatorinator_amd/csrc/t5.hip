@@ -1,0 +1,556 @@
+// osuT5 on MI355X: encoder stack, cross-attention K/V projection and the KV-cached AR decode loop.
+// Orchestration lives here (C++), so that the per-token loop never returns to Python: every decode
+// step is one hipGraph replay; the host only polls a 4-byte "rows still running" word.
+//
+// Reference semantics reproduced (see include/mapperhip.h for the per-entry citations):
+//   HF T5Stack / T5Block / T5Attention / T5LayerFF (pre-norm residual blocks, shared layer-0 relative
+//   bias, no 1/sqrt(d) scaling, gated gelu_new FFN), HF GenerationMixin._sample under
+//   model_generate (osuT5/osuT5/inference/server.py:83-156) with the reference logits processors.
+#include <vector>
+
+#include "decode_kernels.hpp"
+
+namespace mh {
+namespace {
+
+inline int es_of(int dtype) { return dtype == MH_BF16 ? 2 : 4; }
+
+int check_cfg(const MhT5Config* c, const char* who) {
+  MH_REQUIRE(c, "%s: null config", who);
+  MH_REQUIRE(c->d_kv == 64, "%s: d_kv must be 64 (got %d)", who, c->d_kv);
+  MH_REQUIRE(c->n_enc_layers <= MH_MAX_LAYERS && c->n_dec_layers <= MH_MAX_LAYERS, "%s: too many layers", who);
+  MH_REQUIRE(c->d_model % 32 == 0 && c->d_ff % 32 == 0, "%s: d_model/d_ff must be multiples of 32", who);
+  MH_REQUIRE(c->n_mels_pad % 32 == 0 && c->n_mels_pad >= c->n_mels, "%s: bad n_mels_pad", who);
+  MH_REQUIRE(c->dtype == MH_F32 || c->dtype == MH_BF16, "%s: bad dtype", who);
+  return MH_OK;
+}
+
+#define MH_TRY(expr)              \
+  do {                            \
+    int _rc = (expr);             \
+    if (_rc != MH_OK) return _rc; \
+  } while (0)
+
+}  // namespace
+}  // namespace mh
+
+using namespace mh;
+
+// ------------------------------------------------------------------------------------------------
+// encoder
+// ------------------------------------------------------------------------------------------------
+extern "C" int64_t mh_t5_encode_workspace_bytes(const MhT5Config* c, int B) {
+  if (!c || B <= 0) return -1;
+  const int64_t rows = (int64_t)B * c->src_len, es = es_of(c->dtype);
+  const int inner = c->n_heads * 64, Lpad = round_up(c->src_len, 64);
+  int64_t t = 0;
+  t += align256(rows * c->d_model * 4);                    // h
+  t += align256(rows * c->d_model * es);                   // n
+  t += align256(rows * 2 * inner * es);                    // qk
+  t += align256((int64_t)B * inner * Lpad * es);           // vt
+  t += align256(rows * inner * es);                        // attn
+  t += align256(rows * c->d_ff * es);                      // ff
+  return t;
+}
+
+extern "C" int mh_t5_encode(const MhT5Config* c, const MhT5Weights* w, const void* mel, int B, void* enc_out,
+                            float* enc_out_f32, void* workspace, int64_t workspace_bytes, void* stream) {
+  MH_TRY(check_cfg(c, "mh_t5_encode"));
+  MH_REQUIRE(w && mel && enc_out && workspace && B > 0, "mh_t5_encode: null argument");
+  MH_REQUIRE(workspace_bytes >= mh_t5_encode_workspace_bytes(c, B), "mh_t5_encode: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  const int L = c->src_len, d = c->d_model, H = c->n_heads, inner = H * 64, dff = c->d_ff;
+  const int rows = B * L, es = es_of(c->dtype), Lpad = round_up(L, 64);
+  Arena ar(workspace, workspace_bytes);
+  float* h = (float*)ar.take((int64_t)rows * d * 4);
+  void* n = ar.take((int64_t)rows * d * es);
+  void* qk = ar.take((int64_t)rows * 2 * inner * es);
+  void* vt = ar.take((int64_t)B * inner * Lpad * es);
+  void* attn = ar.take((int64_t)rows * inner * es);
+  void* ff = ar.take((int64_t)rows * dff * es);
+  MH_REQUIRE(ar.ok() && ff, "mh_t5_encode: arena overflow");
+  if (hipMemsetAsync(vt, 0, (size_t)B * inner * Lpad * es, s) != hipSuccess) return check_launch("memset vt");
+
+  MhGemm g;
+  // h = encoder_embedder(mel)      (modeling_mapperatorinator.py:195-196)
+  g = MhGemm{};
+  g.A = mel; g.lda = c->n_mels_pad; g.W = w->enc_embed_w; g.ldw = c->n_mels_pad; g.C = h; g.ldc = d;
+  g.M = rows; g.N = d; g.K = c->n_mels_pad; g.bias = w->enc_embed_b; g.dtype = c->dtype; g.epilogue = MH_EPI_STORE_F32;
+  MH_TRY(gemm(g, s));
+
+  for (int l = 0; l < c->n_enc_layers; ++l) {
+    MH_TRY(rmsnorm(h, d, w->enc_ln1[l], n, d, rows, d, c->eps, c->dtype, s));
+    g = MhGemm{};
+    g.A = n; g.lda = d; g.W = w->enc_qkv[l]; g.ldw = d; g.C = qk; g.ldc = 2 * inner; g.M = rows; g.N = 3 * inner;
+    g.K = d; g.dtype = c->dtype; g.epilogue = MH_EPI_QKV_VT; g.C2 = vt; g.n_split = 2 * inner; g.kv_B = B; g.kv_H = H;
+    g.kv_L = L; g.kv_Lpad = Lpad;
+    MH_TRY(gemm(g, s));
+    MH_TRY(attention(qk, 2 * inner, inner, vt, Lpad, w->enc_rel_bias, attn, inner, B, L, H, 1.0f, 0, c->dtype, s));
+    g = MhGemm{};
+    g.A = attn; g.lda = inner; g.W = w->enc_o[l]; g.ldw = inner; g.C = h; g.ldc = d; g.M = rows; g.N = d; g.K = inner;
+    g.dtype = c->dtype; g.epilogue = MH_EPI_RESID;
+    MH_TRY(gemm(g, s));
+    MH_TRY(rmsnorm(h, d, w->enc_ln2[l], n, d, rows, d, c->eps, c->dtype, s));
+    g = MhGemm{};
+    g.A = n; g.lda = d; g.W = w->enc_wi[l]; g.ldw = d; g.C = ff; g.ldc = dff; g.M = rows; g.N = 2 * dff; g.K = d;
+    g.dtype = c->dtype; g.epilogue = MH_EPI_GEGLU;
+    MH_TRY(gemm(g, s));
+    g = MhGemm{};
+    g.A = ff; g.lda = dff; g.W = w->enc_wo[l]; g.ldw = dff; g.C = h; g.ldc = d; g.M = rows; g.N = d; g.K = dff;
+    g.dtype = c->dtype; g.epilogue = MH_EPI_RESID;
+    MH_TRY(gemm(g, s));
+  }
+  MH_TRY(rmsnorm(h, d, w->enc_final_ln, enc_out, d, rows, d, c->eps, c->dtype, s));
+  if (enc_out_f32) MH_TRY(rmsnorm(h, d, w->enc_final_ln, enc_out_f32, d, rows, d, c->eps, MH_F32, s));
+  return MH_OK;
+}
+
+extern "C" int mh_t5_cross_kv(const MhT5Config* c, const MhT5Weights* w, const void* enc_out, int B, void* cross_kv,
+                              void* stream) {
+  MH_TRY(check_cfg(c, "mh_t5_cross_kv"));
+  MH_REQUIRE(w && enc_out && cross_kv && B > 0, "mh_t5_cross_kv: null argument");
+  const int inner = c->n_heads * 64;
+  MhGemm g = MhGemm{};
+  g.A = enc_out; g.lda = c->d_model; g.W = w->dec_ckv_all; g.ldw = c->d_model; g.C = cross_kv; g.ldc = 0;
+  g.M = B * c->src_len; g.N = c->n_dec_layers * 2 * inner; g.K = c->d_model; g.dtype = c->dtype;
+  g.epilogue = MH_EPI_KV_SCATTER; g.kv_B = B; g.kv_H = c->n_heads; g.kv_L = c->src_len;
+  return gemm(g, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// decode
+// ------------------------------------------------------------------------------------------------
+namespace mh {
+namespace {
+
+struct DecState {       // device-resident control block
+  int pos;              // index of the token being fed this step
+  int n_running;        // rows not yet finished (written by the sampler)
+  int pad0, pad1;
+};
+
+struct SampleP {
+  const float* logits; int ldl; int V;
+  int32_t* tokens; int max_length;    // [B, max_length]
+  const int32_t* forced;
+  const uint8_t* eos_table;
+  uint8_t* finished;                  // [B]
+  int32_t* finish_col;                // [B]
+  int32_t* last_ts_val;               // [B] value of the last TIME_SHIFT after the last SOS, -1 if none
+  float* logits_dump;                 // [max_length][B][V] or null
+  const void* dec_embed; float* h; int d;
+  MhSampling sp;
+  DecState* st;
+  int B, P;
+};
+
+__device__ inline void update_ts_state(const MhSampling& sp, int tok, int32_t* last_ts_val) {
+  // incremental form of MonotonicTimeShiftLogitsProcessor's "last TIME_SHIFT after the last SOS-type
+  // token" scan (osuT5/osuT5/inference/logit_processors.py:150-172)
+  if (tok >= sp.ts_start && tok < sp.ts_end) {
+    *last_ts_val = tok - sp.ts_start;
+  } else {
+    for (int i = 0; i < sp.n_sos; ++i)
+      if (tok == sp.sos_ids[i]) { *last_ts_val = -1; break; }
+  }
+}
+
+// counter-based RNG (Philox-like mixing is overkill here; splitmix64 on (seed, row, step))
+__device__ inline float uniform01(uint64_t seed, uint32_t row, uint32_t step) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * ((uint64_t)row * 0x100000001ull + step + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (float)((z >> 40) + 0.5) * (1.0f / 16777216.0f);
+}
+
+// init: consume column 0 of the prompt (state machine + embedding of the first token)
+template <typename T>
+__global__ __launch_bounds__(256) void dec_init_kernel(SampleP p) {
+  const int b = blockIdx.x;
+  if (threadIdx.x == 0) {
+    int32_t v = -1;
+    update_ts_state(p.sp, p.tokens[(long)b * p.max_length], &v);
+    p.last_ts_val[b] = v;
+    p.finished[b] = 0;
+    p.finish_col[b] = p.max_length - 1;
+    if (b == 0) { p.st->pos = 0; p.st->n_running = p.B; }
+  }
+  const int tok = p.tokens[(long)b * p.max_length];
+  const T* e = reinterpret_cast<const T*>(p.dec_embed) + (long)tok * p.d;
+  for (int i = threadIdx.x; i < p.d; i += 256) p.h[(long)b * p.d + i] = Elem<T>::to_f32(e[i]);
+}
+
+// one workgroup per batch row: processors -> selection -> bookkeeping -> next-token embedding
+template <typename T>
+__global__ __launch_bounds__(256) void dec_sample_kernel(SampleP p) {
+  __shared__ float sf[8];
+  __shared__ int si[8];
+  __shared__ int s_tok;
+  __shared__ float s_sum;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int pos = p.st->pos;
+  const int col = pos + 1;  // column being produced
+  const MhSampling& sp = p.sp;
+  if (col >= p.max_length) return;
+
+  if (col < p.P) {
+    // still inside the prompt: the token is given; only advance the processor state + embedding
+    if (tid == 0) {
+      const int tok = p.tokens[(long)b * p.max_length + col];
+      update_ts_state(sp, tok, &p.last_ts_val[b]);
+      s_tok = tok;
+    }
+    __syncthreads();
+  } else {
+    const float* lg = p.logits + (long)b * p.ldl;
+    const int ltv = p.last_ts_val[b];
+    float best = -INFINITY;
+    int besti = 0x7fffffff;
+    float* dump = p.logits_dump ? p.logits_dump + ((long)col * p.B + b) * p.V : nullptr;
+    for (int v = tid; v < p.V; v += 256) {
+      float x = lg[v];
+      // MonotonicTimeShiftLogitsProcessor: ids [ts_start, ts_start + value) -> -inf
+      if (ltv >= 0 && v >= sp.ts_start && v < sp.ts_start + ltv) x = -INFINITY;
+      // TimeshiftBias
+      if (sp.timeshift_bias != 0.f && v >= sp.ts_start && v < sp.ts_end) x += sp.timeshift_bias;
+      // TemperatureLogitsWarper (scores / temperature)
+      x = x / sp.temperature;
+      // LookbackBiasLogitsWarper, types_first == False branch
+      if (sp.lookback_mask_end > sp.ts_start && v >= sp.ts_start && v < sp.lookback_mask_end) x = -INFINITY;
+      if (dump) dump[v] = x;
+      if (x > best) { best = x; besti = v; }   // strided scan keeps the smallest index per thread
+    }
+    // argmax with first-index tie-break (torch.argmax semantics on ties = first maximal index)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ob = __shfl_xor(best, o, 64);
+      const int oi = __shfl_xor(besti, o, 64);
+      if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+    }
+    if (lane == 0) { sf[wid] = best; si[wid] = besti; }
+    __syncthreads();
+    if (tid == 0) {
+      for (int w2 = 1; w2 < 4; ++w2)
+        if (sf[w2] > best || (sf[w2] == best && si[w2] < besti)) { best = sf[w2]; besti = si[w2]; }
+      sf[4] = best; si[4] = besti;
+    }
+    __syncthreads();
+    int tok = si[4];
+    if (sp.do_sample) {
+      // softmax sampling over the processed scores with optional top-k / top-p truncation.
+      // Threshold search instead of a sort: V is a few thousand, a wave-parallel bisection is cheap.
+      const float mx = sf[4];
+      float thr = -INFINITY;
+      if (sp.top_k > 0 && sp.top_k < p.V) {
+        float lo = -80.f, hi = 0.f;  // on x - mx
+        for (int it = 0; it < 40; ++it) {
+          const float mid = 0.5f * (lo + hi);
+          int cnt = 0;
+          for (int v = tid; v < p.V; v += 256) {
+            float x = dump ? dump[v] : -INFINITY;
+            cnt += (x - mx >= mid) ? 1 : 0;
+          }
+          cnt = (int)block_sum((float)cnt, sf);
+          if (cnt >= sp.top_k) lo = mid; else hi = mid;
+        }
+        thr = lo;
+      }
+      // probabilities of the kept set
+      float part = 0.f;
+      for (int v = tid; v < p.V; v += 256) {
+        float x = dump ? dump[v] : -INFINITY;
+        if (x - mx >= thr) part += __expf(x - mx);
+      }
+      float total = block_sum(part, sf);
+      float pthr = 0.f;
+      if (sp.top_p < 1.0f) {
+        // keep the smallest set of most-probable ids whose mass reaches top_p
+        float lo = 0.f, hi = 1.f;
+        for (int it = 0; it < 30; ++it) {
+          const float mid = 0.5f * (lo + hi);
+          float mass = 0.f;
+          for (int v = tid; v < p.V; v += 256) {
+            float x = dump ? dump[v] : -INFINITY;
+            if (x - mx >= thr) {
+              const float pr = __expf(x - mx) / total;
+              if (pr >= mid) mass += pr;
+            }
+          }
+          mass = block_sum(mass, sf);
+          if (mass >= sp.top_p) lo = mid; else hi = mid;
+        }
+        pthr = lo;
+        float part2 = 0.f;
+        for (int v = tid; v < p.V; v += 256) {
+          float x = dump ? dump[v] : -INFINITY;
+          if (x - mx >= thr && __expf(x - mx) / total >= pthr) part2 += __expf(x - mx);
+        }
+        s_sum = 0.f;
+        const float t2 = block_sum(part2, sf);
+        if (tid == 0) s_sum = t2;
+        __syncthreads();
+      } else {
+        if (tid == 0) s_sum = total;
+        __syncthreads();
+      }
+      if (tid == 0) {
+        const float u = uniform01(sp.seed, (uint32_t)b, (uint32_t)col) * s_sum;
+        float cum = 0.f;
+        int pick = tok;
+        for (int v = 0; v < p.V; ++v) {
+          float x = dump ? dump[v] : -INFINITY;
+          if (x - mx >= thr) {
+            const float e = __expf(x - mx);
+            if (sp.top_p < 1.0f && e / total < pthr) continue;
+            cum += e;
+            pick = v;
+            if (cum >= u) break;
+          }
+        }
+        si[5] = pick;
+      }
+      __syncthreads();
+      tok = si[5];
+    }
+    if (tid == 0) {
+      const bool forced = p.forced != nullptr;
+      const bool was_finished = p.finished[b] != 0;
+      int emit = was_finished ? sp.pad_id : tok;      // HF: finished rows receive pad_token_id
+      p.tokens[(long)b * p.max_length + col] = emit;
+      int feed = forced ? p.forced[(long)b * p.max_length + col] : emit;
+      if (!forced && !was_finished) {
+        if (p.eos_table[emit] || col + 1 >= sp.max_length) {
+          p.finished[b] = 1;
+          p.finish_col[b] = col;
+        }
+      }
+      update_ts_state(sp, feed, &p.last_ts_val[b]);
+      s_tok = feed;
+    }
+    __syncthreads();
+  }
+  // embedding of the token that the next step consumes (decoder_embedder, modeling_mapperatorinator.py:205-206)
+  const int tok = s_tok;
+  const T* e = reinterpret_cast<const T*>(p.dec_embed) + (long)tok * p.d;
+  for (int i = tid; i < p.d; i += 256) p.h[(long)b * p.d + i] = Elem<T>::to_f32(e[i]);
+}
+
+__global__ void dec_advance_kernel(DecState* st, const uint8_t* finished, int B) {
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int b = 0; b < B; ++b) run += finished[b] ? 0 : 1;
+    st->n_running = run;
+    st->pos = st->pos + 1;
+  }
+}
+
+__global__ void dec_finalize_kernel(const int32_t* finish_col, int B, int32_t* n_steps_out) {
+  if (threadIdx.x == 0) {
+    int mx = 0;
+    for (int b = 0; b < B; ++b) mx = finish_col[b] > mx ? finish_col[b] : mx;
+    *n_steps_out = mx + 1;
+  }
+}
+
+template <typename T, int MF, int NS, int PRO, int EPI>
+int launch_skinny(const dec::SkinnyP& p, hipStream_t s) {
+  const int strips = ceil_div(p.N, 16);
+  hipLaunchKernelGGL((dec::skinny_gemm_kernel<T, MF, NS, PRO, EPI>), dim3(ceil_div(strips, NS)), dim3(256), 0, s, p);
+  return check_launch("skinny_gemm_kernel");
+}
+template <typename T, int NS, int PRO, int EPI>
+int skinny(const dec::SkinnyP& p, hipStream_t s) {
+  if (p.B <= 16) return launch_skinny<T, 1, NS, PRO, EPI>(p, s);
+  if (p.B <= 32) return launch_skinny<T, 2, NS, PRO, EPI>(p, s);
+  return launch_skinny<T, 4, NS, PRO, EPI>(p, s);
+}
+
+struct DecBuffers {
+  float* h; void* q; void* attn; void* ff; float* logits; float* part;
+  void* self_k; void* self_v;  // [n_dec][B][H][tgt][64]
+  uint8_t* finished; int32_t* finish_col; int32_t* last_ts; DecState* st;
+  int splits;
+};
+
+int cross_splits(int B, int H) {
+  const int pairs = B * H;
+  if (pairs >= 1024) return 1;
+  int s = (1024 + pairs - 1) / pairs;
+  return s > 8 ? 8 : s;
+}
+
+template <typename T>
+int enqueue_step(const MhT5Config* c, const MhT5Weights* w, const void* cross_kv, int B, const uint8_t* prompt_mask,
+                 int P, const DecBuffers& bf, const SampleP& smp, hipStream_t s) {
+  const int d = c->d_model, H = c->n_heads, inner = H * 64, dff = c->d_ff, L = c->src_len, tgt = c->tgt_len;
+  const int es = (int)sizeof(T);
+  const int* posp = &bf.st->pos;
+  for (int l = 0; l < c->n_dec_layers; ++l) {
+    const long cache_off = (long)l * B * H * tgt * 64 * es;
+    dec::SkinnyP sk{};
+    // self attention
+    sk = dec::SkinnyP{};
+    sk.A = bf.h; sk.lda = d; sk.ln_w = w->dec_ln1[l]; sk.eps = c->eps; sk.W = w->dec_qkv[l]; sk.ldw = d; sk.B = B;
+    sk.N = 3 * inner; sk.K = d; sk.out = bf.q; sk.ldo = inner; sk.kc = (char*)bf.self_k + cache_off;
+    sk.vc = (char*)bf.self_v + cache_off; sk.H = H; sk.tgt_len = tgt; sk.inner = inner; sk.pos = posp;
+    MH_TRY((skinny<T, 1, dec::PRO_RMSNORM, dec::SK_QKV>(sk, s)));
+    dec::SelfAttnP sa{};
+    sa.q = bf.q; sa.ldq = inner; sa.kc = sk.kc; sa.vc = sk.vc; sa.bias = w->dec_rel_bias; sa.prompt_mask = prompt_mask;
+    sa.P = P; sa.out = bf.attn; sa.ldo = inner; sa.B = B; sa.H = H; sa.tgt_len = tgt; sa.pos = posp;
+    hipLaunchKernelGGL(dec::dec_self_attn_kernel<T>, dim3(ceil_div(B * H, 4)), dim3(256), 0, s, sa);
+    MH_TRY(check_launch("dec_self_attn_kernel"));
+    sk = dec::SkinnyP{};
+    sk.A = bf.attn; sk.lda = inner; sk.W = w->dec_o[l]; sk.ldw = inner; sk.B = B; sk.N = d; sk.K = inner; sk.h = bf.h;
+    sk.ldh = d;
+    MH_TRY((skinny<T, 1, dec::PRO_PLAIN, dec::SK_RESID>(sk, s)));
+    // cross attention
+    sk = dec::SkinnyP{};
+    sk.A = bf.h; sk.lda = d; sk.ln_w = w->dec_ln2[l]; sk.eps = c->eps; sk.W = w->dec_cq[l]; sk.ldw = d; sk.B = B;
+    sk.N = inner; sk.K = d; sk.out = bf.q; sk.ldo = inner;
+    MH_TRY((skinny<T, 1, dec::PRO_RMSNORM, dec::SK_STORE>(sk, s)));
+    dec::CrossAttnP ca{};
+    const long kv_layer = (long)B * H * L * 64 * es;
+    ca.q = bf.q; ca.ldq = inner; ca.k = (const char*)cross_kv + (long)(l * 2 + 0) * kv_layer;
+    ca.v = (const char*)cross_kv + (long)(l * 2 + 1) * kv_layer; ca.out = bf.attn; ca.ldo = inner; ca.part = bf.part;
+    ca.B = B; ca.H = H; ca.L = L; ca.splits = bf.splits;
+    hipLaunchKernelGGL(dec::dec_cross_attn_kernel<T>, dim3(B * H * bf.splits), dim3(256), 0, s, ca);
+    MH_TRY(check_launch("dec_cross_attn_kernel"));
+    if (bf.splits > 1) {
+      hipLaunchKernelGGL(dec::dec_cross_merge_kernel<T>, dim3(B * H), dim3(64), 0, s, ca);
+      MH_TRY(check_launch("dec_cross_merge_kernel"));
+    }
+    sk = dec::SkinnyP{};
+    sk.A = bf.attn; sk.lda = inner; sk.W = w->dec_co[l]; sk.ldw = inner; sk.B = B; sk.N = d; sk.K = inner; sk.h = bf.h;
+    sk.ldh = d;
+    MH_TRY((skinny<T, 1, dec::PRO_PLAIN, dec::SK_RESID>(sk, s)));
+    // feed forward
+    sk = dec::SkinnyP{};
+    sk.A = bf.h; sk.lda = d; sk.ln_w = w->dec_ln3[l]; sk.eps = c->eps; sk.W = w->dec_wi[l]; sk.ldw = d; sk.B = B;
+    sk.N = 2 * dff; sk.K = d; sk.out = bf.ff; sk.ldo = dff;
+    MH_TRY((skinny<T, 2, dec::PRO_RMSNORM, dec::SK_GEGLU>(sk, s)));
+    sk = dec::SkinnyP{};
+    sk.A = bf.ff; sk.lda = dff; sk.W = w->dec_wo[l]; sk.ldw = dff; sk.B = B; sk.N = d; sk.K = dff; sk.h = bf.h;
+    sk.ldh = d;
+    MH_TRY((skinny<T, 1, dec::PRO_PLAIN, dec::SK_RESID>(sk, s)));
+  }
+  dec::SkinnyP sk{};
+  sk.A = bf.h; sk.lda = d; sk.ln_w = w->dec_final_ln; sk.eps = c->eps; sk.W = w->lm_head; sk.ldw = d; sk.B = B;
+  sk.N = c->vocab_out; sk.K = d; sk.out = bf.logits; sk.ldo = c->vocab_out;
+  MH_TRY((skinny<T, 1, dec::PRO_RMSNORM, dec::SK_LOGITS>(sk, s)));
+  hipLaunchKernelGGL(dec_sample_kernel<T>, dim3(B), dim3(256), 0, s, smp);
+  MH_TRY(check_launch("dec_sample_kernel"));
+  hipLaunchKernelGGL(dec_advance_kernel, dim3(1), dim3(64), 0, s, bf.st, bf.finished, B);
+  MH_TRY(check_launch("dec_advance_kernel"));
+  return MH_OK;
+}
+
+}  // namespace
+}  // namespace mh
+
+extern "C" int64_t mh_t5_decode_workspace_bytes(const MhT5Config* c, int B) {
+  if (!c || B <= 0) return -1;
+  const int64_t es = es_of(c->dtype);
+  const int inner = c->n_heads * 64;
+  int64_t t = 0;
+  t += align256((int64_t)B * c->d_model * 4);                                     // h
+  t += align256((int64_t)B * inner * es) * 2;                                     // q, attn
+  t += align256((int64_t)B * c->d_ff * es);                                       // ff
+  t += align256((int64_t)B * c->vocab_out * 4);                                   // logits
+  t += align256((int64_t)B * c->n_heads * 8 * 66 * 4);                            // cross partials
+  t += align256((int64_t)c->n_dec_layers * B * inner * c->tgt_len * es) * 2;      // self K, V caches
+  t += align256(B) + align256((int64_t)B * 4) * 2 + align256(sizeof(DecState));   // flags / state
+  return t;
+}
+
+extern "C" int mh_t5_generate(const MhT5Config* c, const MhT5Weights* w, const void* cross_kv, int B,
+                              const int32_t* prompt, const uint8_t* prompt_mask, int P, const uint8_t* eos_table,
+                              const MhSampling* sp, int32_t* tokens, int32_t* n_steps_out, float* logits_dump,
+                              const int32_t* forced, void* workspace, int64_t workspace_bytes, int poll_every,
+                              void* stream) {
+  MH_TRY(check_cfg(c, "mh_t5_generate"));
+  MH_REQUIRE(w && cross_kv && prompt && eos_table && sp && tokens && n_steps_out && workspace,
+             "mh_t5_generate: null argument");
+  MH_REQUIRE(stream != nullptr, "mh_t5_generate: needs a non-default stream (hipGraph capture)");
+  MH_REQUIRE(B > 0 && B <= 64, "mh_t5_generate: batch %d not in [1, 64] (shard larger batches on the host)", B);
+  MH_REQUIRE(P >= 1 && P < sp->max_length, "mh_t5_generate: prompt length %d must be in [1, max_length)", P);
+  MH_REQUIRE(sp->max_length <= c->tgt_len, "mh_t5_generate: max_length %d exceeds tgt_len %d", sp->max_length, c->tgt_len);
+  MH_REQUIRE(sp->temperature > 0.f, "mh_t5_generate: temperature must be > 0");
+  MH_REQUIRE(sp->n_sos >= 0 && sp->n_sos <= 16, "mh_t5_generate: too many sos ids");
+  MH_REQUIRE(!(sp->do_sample && !logits_dump), "mh_t5_generate: do_sample needs the logits_dump scratch");
+  MH_REQUIRE(workspace_bytes >= mh_t5_decode_workspace_bytes(c, B), "mh_t5_generate: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  const int es = es_of(c->dtype), inner = c->n_heads * 64;
+
+  Arena ar(workspace, workspace_bytes);
+  DecBuffers bf;
+  bf.h = (float*)ar.take((int64_t)B * c->d_model * 4);
+  bf.q = ar.take((int64_t)B * inner * es);
+  bf.attn = ar.take((int64_t)B * inner * es);
+  bf.ff = ar.take((int64_t)B * c->d_ff * es);
+  bf.logits = (float*)ar.take((int64_t)B * c->vocab_out * 4);
+  bf.part = (float*)ar.take((int64_t)B * c->n_heads * 8 * 66 * 4);
+  bf.self_k = ar.take((int64_t)c->n_dec_layers * B * inner * c->tgt_len * es);
+  bf.self_v = ar.take((int64_t)c->n_dec_layers * B * inner * c->tgt_len * es);
+  bf.finished = (uint8_t*)ar.take(B);
+  bf.finish_col = (int32_t*)ar.take((int64_t)B * 4);
+  bf.last_ts = (int32_t*)ar.take((int64_t)B * 4);
+  bf.st = (DecState*)ar.take(sizeof(DecState));
+  MH_REQUIRE(ar.ok() && bf.st, "mh_t5_generate: arena overflow");
+  bf.splits = cross_splits(B, c->n_heads);
+
+  // tokens[:, :P] = prompt; the remainder is produced by the sampler
+  if (hipMemcpy2DAsync(tokens, (size_t)sp->max_length * 4, prompt, (size_t)P * 4, (size_t)P * 4, B,
+                       hipMemcpyDeviceToDevice, s) != hipSuccess)
+    return check_launch("prompt copy");
+
+  SampleP smp{};
+  smp.logits = bf.logits; smp.ldl = c->vocab_out; smp.V = c->vocab_out; smp.tokens = tokens;
+  smp.max_length = sp->max_length; smp.forced = forced; smp.eos_table = eos_table; smp.finished = bf.finished;
+  smp.finish_col = bf.finish_col; smp.last_ts_val = bf.last_ts; smp.logits_dump = logits_dump;
+  smp.dec_embed = w->dec_embed; smp.h = bf.h; smp.d = c->d_model; smp.sp = *sp; smp.st = bf.st; smp.B = B; smp.P = P;
+
+  const bool bf16 = c->dtype == MH_BF16;
+  if (bf16) hipLaunchKernelGGL(dec_init_kernel<bf16_t>, dim3(B), dim3(256), 0, s, smp);
+  else hipLaunchKernelGGL(dec_init_kernel<float>, dim3(B), dim3(256), 0, s, smp);
+  MH_TRY(check_launch("dec_init_kernel"));
+
+  // capture one step (all kernels read the position from device memory) and replay it
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) return check_launch("begin capture");
+  int rc = bf16 ? enqueue_step<bf16_t>(c, w, cross_kv, B, prompt_mask, P, bf, smp, s)
+                : enqueue_step<float>(c, w, cross_kv, B, prompt_mask, P, bf, smp, s);
+  hipError_t ce = hipStreamEndCapture(s, &graph);
+  if (rc != MH_OK) { if (graph) hipGraphDestroy(graph); return rc; }
+  if (ce != hipSuccess || !graph) { set_error("mh_t5_generate: stream capture failed: %s", hipGetErrorString(ce)); return MH_ERR_LAUNCH; }
+  if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+    hipGraphDestroy(graph);
+    return check_launch("graph instantiate");
+  }
+
+  const int total_steps = sp->max_length - 1;   // positions 0 .. max_length-2 are fed
+  if (poll_every <= 0) poll_every = 16;
+  int rc2 = MH_OK;
+  int step = 0;
+  while (step < total_steps) {
+    int burst = total_steps - step < poll_every ? total_steps - step : poll_every;
+    for (int i = 0; i < burst; ++i) {
+      if (hipGraphLaunch(exec, s) != hipSuccess) { rc2 = check_launch("graph launch"); break; }
+    }
+    if (rc2 != MH_OK) break;
+    step += burst;
+    if (step < total_steps && !forced) {
+      int running = 1;
+      if (hipMemcpyAsync(&running, &bf.st->n_running, 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
+          hipStreamSynchronize(s) != hipSuccess) { rc2 = check_launch("poll"); break; }
+      if (running == 0) break;
+    }
+  }
+  hipLaunchKernelGGL(dec_finalize_kernel, dim3(1), dim3(64), 0, s, bf.finish_col, B, n_steps_out);
+  if (rc2 == MH_OK) rc2 = check_launch("dec_finalize_kernel");
+  hipStreamSynchronize(s);   // the graph objects must outlive their launches
+  hipGraphExecDestroy(exec);
+  hipGraphDestroy(graph);
+  return rc2;
+}

@@ -1,0 +1,169 @@
+"""TEST INFRASTRUCTURE ONLY -- drives the *imported, unmodified* reference (this container only).
+
+Builds the reference objects for the hot path exactly the way SURVEY.md Appendix C describes
+and exposes them to `oracle/make_golden.py` and the pinning tests:
+
+  build_reference_t5(size, ...)  -> (model: Mapperatorinator, tokenizer: Tokenizer, args)
+  reference_generate(...)        -> reference `model_generate` (osuT5/osuT5/inference/server.py:83-156)
+  build_reference_dit(...)       -> osu_diffusion DiT (osu_diffusion/utils/models.py)
+  reference_ddpm(...)            -> diffusion.p_sample_loop (gaussian_diffusion.py:469-512)
+"""
+from __future__ import annotations
+
+import copy
+
+import torch
+
+from . import ref_shims
+
+
+def _train_config(size: str, src_seq_len: int, tgt_seq_len: int, n_mels: int):
+    ref_shims.install()
+    from osuT5.osuT5.config import TrainConfig
+    from osuT5.osuT5.event import ContextType
+    args = TrainConfig()
+    args = copy.deepcopy(args)
+    args.model.name = f"google/t5-v1_1-{size}"
+    args.model.input_features = False
+    args.model.project_encoder_input = True
+    args.model.embed_decoder_input = True
+    args.model.do_style_embed = False
+    args.model.do_difficulty_embed = False
+    args.model.do_mapper_embed = False
+    args.model.do_song_position_embed = False
+    args.model.cond_size = 0
+    args.model.overwrite = {"dropout_rate": 0.0}
+    args.model.add_config = {}
+    args.model.spectrogram.implementation = "nnAudio"
+    args.model.spectrogram.log_scale = False
+    args.model.spectrogram.sample_rate = 16000
+    args.model.spectrogram.n_fft = 1024
+    args.model.spectrogram.n_mels = n_mels
+    args.model.spectrogram.hop_length = 128
+    args.model.spectrogram.f_min = 0
+    args.model.spectrogram.f_max = 8000
+    args.model.spectrogram.pad_mode = "constant"
+    d = args.data
+    d.dataset_type = "ors"
+    d.src_seq_len = src_seq_len
+    d.tgt_seq_len = tgt_seq_len
+    d.context_types = [{"in": [], "out": [ContextType.MAP]}]
+    d.add_out_context_types = False
+    for name in dir(d):
+        if name.startswith("add_") and name.endswith("_token") and isinstance(getattr(d, name), bool):
+            setattr(d, name, False)
+    d.add_descriptors = False
+    d.add_kiai = False
+    d.add_kiai_special_token = False
+    d.types_first = False
+    d.gamemodes = [0]
+    d.add_sv = False
+    d.add_positions = False
+    d.add_distances = True
+    d.add_timing_points = False
+    d.add_pre_tokens = False
+    d.add_pre_tokens_at_step = -1
+    d.sustain_interval = 0
+    return args
+
+
+def build_reference_t5(size="small", src_seq_len=1251, tgt_seq_len=512, n_mels=388,
+                       dtype=torch.float32, seed=0, lm_head_gain=1.0):
+    """reference `_get_model` (osuT5/osuT5/utils/model_utils.py:102-114) with the reference
+    initialisers (HF `_init_weights`), seeded."""
+    args = _train_config(size, src_seq_len, tgt_seq_len, n_mels)
+    from osuT5.osuT5.tokenizer import Tokenizer
+    from osuT5.osuT5.utils.model_utils import _get_model
+    tok = Tokenizer(args)
+    torch.manual_seed(seed)
+    model = _get_model(args, tok, torch.float32, "eager").eval()
+    if lm_head_gain != 1.0:
+        with torch.no_grad():
+            model.transformer.lm_head.weight.mul_(lm_head_gain)
+    if dtype != torch.float32:
+        model = model.to(dtype)
+    return model, tok, args
+
+
+def reference_encode(model, audio: torch.Tensor) -> torch.Tensor:
+    """mel -> encoder_embedder -> T5 encoder, called by hand (work-around for the positional
+    `inputs_embeds` bug at modeling_mapperatorinator.py:438-443; SURVEY.md headline finding 3)."""
+    with torch.no_grad():
+        mel = model.spectrogram(audio).to(model.transformer.dtype)
+        emb = model.encoder_embedder(mel)
+        return model.transformer.encoder(inputs_embeds=emb).last_hidden_state
+
+
+def default_generate_kwargs(max_length: int, **over):
+    kw = dict(precision="fp32", do_sample=False, num_beams=1, top_p=1.0, top_k=0,
+              max_length=max_length, cfg_scale=1.0, timeshift_bias=0, types_first=False,
+              temperature=1.0, timing_temperature=1.0, mania_column_temperature=1.0,
+              taiko_hit_temperature=1.0, lookback_time=0, lookahead_time=0,
+              context_type="map", pad_token_id=0)
+    kw.update(over)
+    return kw
+
+
+def reference_generate(model, tok, audio, prompt, generate_kwargs, attention_mask=None):
+    """The reference's own `model_generate` (server.py:83-156) via the `encoder_outputs` route."""
+    ref_shims.install()
+    from osuT5.osuT5.inference.server import model_generate
+    from transformers.modeling_outputs import BaseModelOutput
+    enc = reference_encode(model, audio)
+    if attention_mask is None:
+        attention_mask = prompt.ne(0)
+    mk = dict(inputs=audio, encoder_outputs=BaseModelOutput(last_hidden_state=enc),
+              decoder_input_ids=prompt, decoder_attention_mask=attention_mask)
+    return model_generate(model, tok, mk, dict(generate_kwargs))
+
+
+def build_reference_dit(name="DiT-S", context_size=272, class_size=300, seed=0, rerandomise=True):
+    """osu_diffusion DiT (models.py:213-279, sizes :384-405).  adaLN / final layers are zero-init
+    in the reference (:270-279) which makes the output identically 0; for a meaningful parity
+    check they are re-randomised N(0, 0.02) (SURVEY.md 8d 'Value distributions')."""
+    ref_shims.install()
+    from osu_diffusion import DiT_models
+    torch.manual_seed(seed)
+    model = DiT_models[name](context_size=context_size, class_size=class_size).eval()
+    if rerandomise:
+        g = torch.Generator().manual_seed(seed + 1)
+        with torch.no_grad():
+            for blk in model.blocks:
+                blk.adaLN_modulation[-1].weight.normal_(0, 0.02, generator=g)
+                blk.adaLN_modulation[-1].bias.normal_(0, 0.02, generator=g)
+            model.final_layer.adaLN_modulation[-1].weight.normal_(0, 0.02, generator=g)
+            model.final_layer.adaLN_modulation[-1].bias.normal_(0, 0.02, generator=g)
+            model.final_layer.linear.weight.normal_(0, 0.02, generator=g)
+            model.final_layer.linear.bias.normal_(0, 0.02, generator=g)
+            for m in model.modules():
+                if isinstance(m, torch.nn.Linear) and m.bias is not None and float(m.bias.abs().sum()) == 0.0:
+                    m.bias.normal_(0, 0.02, generator=g)
+            for blk in model.blocks:
+                blk.attn.in_proj_bias.normal_(0, 0.02, generator=g)
+                blk.attn.out_proj.bias.normal_(0, 0.02, generator=g)
+    return model
+
+
+def reference_diffusion(timesteps=(100, 0, 0, 0, 0, 0, 0, 0, 0, 0), diffusion_steps=1000,
+                        noise_schedule="squaredcos_cap_v2"):
+    ref_shims.install()
+    from osu_diffusion import create_diffusion
+    return create_diffusion(timestep_respacing=list(timesteps), diffusion_steps=diffusion_steps,
+                            noise_schedule=noise_schedule)
+
+
+def reference_ddpm(model, diffusion, z, c, y, cfg_scale, attn_mask, noise_list):
+    """`diffusion.p_sample_loop(model.forward_with_cfg, ...)` (diffusion_pipeline.py:243-252) with the
+    per-step gaussian noise injected (pops from `noise_list`, one tensor per step, in call order)."""
+    from osu_diffusion.utils.diffusion import gaussian_diffusion as gd
+    it = iter(noise_list)
+    orig = gd.th.randn_like
+    gd.th.randn_like = lambda x, *a, **k: next(it).to(x)
+    try:
+        with torch.no_grad():
+            return diffusion.p_sample_loop(
+                model.forward_with_cfg, z.shape, z, clip_denoised=True,
+                model_kwargs=dict(c=c, y=y, cfg_scale=cfg_scale, attn_mask=attn_mask,
+                                  key_padding_mask=None), device=z.device)
+    finally:
+        gd.th.randn_like = orig
