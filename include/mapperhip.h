@@ -261,10 +261,14 @@ int mh_dit_forward_cfg(const MhDiTConfig* cfg, const MhDiTWeights* w, const floa
  *      sqrt_recipm1_alphas_cumprod, posterior_mean_coef1, posterior_mean_coef2, nonzero_mask}
  *   model_out [N,4,T]; x [N,2,T] in; noise [N,2,T]; inpaint_mask uint8 [N,2,T] (1 = generate) and
  *   inpaint_ref [N,2,T] implement denoised_fn's `torch.where(mask, x, z_part)`
- *   (diffusion_pipeline.py:203-206), both NULL to skip;  x_out [N,2,T]; pred_xstart optional. */
+ *   (diffusion_pipeline.py:203-206), both NULL to skip;  x_out [N,2,T]; pred_xstart optional.
+ *   Arbitrary host `denoised_fn`s (the slider re-projection of diffusion_pipeline.py:208-220) are
+ *   served by two calls: raw_pred=1 writes the unprocessed eps->x0 prediction to pred_xstart and
+ *   returns; the caller transforms it and passes it back as x0_override (clamp, posterior mean and
+ *   the noise step then proceed from that value). */
 int mh_ddpm_step(const float* model_out, const float* x, const float* noise, const float* coef,
-                 const uint8_t* inpaint_mask, const float* inpaint_ref, int N, int T, float* x_out,
-                 float* pred_xstart, void* stream);
+                 const uint8_t* inpaint_mask, const float* inpaint_ref, const float* x0_override,
+                 int raw_pred, int N, int T, float* x_out, float* pred_xstart, void* stream);
 
 /* Whole p_sample_loop on device (gaussian_diffusion.py:469-561): `n_steps` iterations of
  * mh_dit_forward_cfg + mh_ddpm_step captured once into a hipGraph and replayed.

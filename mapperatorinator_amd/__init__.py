@@ -1,0 +1,28 @@
+"""mapperatorinator_amd -- MI355X-native (gfx950) audio->event hot path of Mapperatorinator.
+
+  mel frontend (K1) -> osuT5 encoder/decoder with KV-cached AR decode (K3-K6) -> osu_diffusion DiT +
+  DDPM refinement (K7-K9), hand-written HIP behind the C ABI of include/mapperhip.h, with the host
+  side mirroring the reference's Python seams: `model_generate`, `Mapperatorinator`,
+  `DiT.forward_with_cfg`, `diffusion.p_sample_loop`, `Tokenizer` / `Event`.
+"""
+from .event import ContextType, Event, EventRange, EventType  # noqa: F401
+from .tokenizer import Tokenizer  # noqa: F401
+
+__all__ = ["ContextType", "Event", "EventRange", "EventType", "Tokenizer", "MapperatorinatorHIP",
+           "model_generate", "DiTHIP", "create_diffusion", "MelSpectrogram"]
+
+
+def __getattr__(name):  # torch-dependent pieces are imported lazily
+    if name == "MapperatorinatorHIP":
+        from .modeling import MapperatorinatorHIP
+        return MapperatorinatorHIP
+    if name in ("model_generate", "get_eos_token_id"):
+        from . import server
+        return getattr(server, name)
+    if name in ("DiTHIP", "create_diffusion", "InpaintSpec", "SpacedDiffusionHIP"):
+        from . import dit
+        return getattr(dit, name)
+    if name == "MelSpectrogram":
+        from .mel import MelSpectrogram
+        return MelSpectrogram
+    raise AttributeError(name)

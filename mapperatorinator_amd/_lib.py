@@ -1,0 +1,134 @@
+"""ctypes binding of libmapperhip.so (the C ABI declared in include/mapperhip.h).
+
+The product path FAILS LOUDLY when the HIP library is missing: there is no CPU fallback and
+nothing here imports `oracle/`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+MH_MAX_LAYERS = 32
+MH_F32, MH_BF16 = 0, 1
+(EPI_STORE, EPI_STORE_F32, EPI_RESID, EPI_GEGLU, EPI_BIAS_GELU, EPI_GATE_RESID, EPI_KV_SCATTER,
+ EPI_QKV_VT) = range(8)
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmapperhip.so")
+
+VP = C.c_void_p
+FP = C.c_void_p  # device float*
+_PTR_ARR = VP * MH_MAX_LAYERS
+
+
+class MhGemm(C.Structure):
+    _fields_ = [("A", VP), ("lda", C.c_int), ("W", VP), ("ldw", C.c_int), ("C", VP), ("ldc", C.c_int),
+                ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("bias", VP), ("gate", VP),
+                ("gate_ld", C.c_int), ("rows_per_batch", C.c_int), ("kv_B", C.c_int), ("kv_H", C.c_int),
+                ("kv_L", C.c_int), ("C2", VP), ("n_split", C.c_int), ("kv_Lpad", C.c_int),
+                ("dtype", C.c_int), ("epilogue", C.c_int)]
+
+
+class MhT5Config(C.Structure):
+    _fields_ = [("d_model", C.c_int), ("d_kv", C.c_int), ("d_ff", C.c_int), ("n_heads", C.c_int),
+                ("n_enc_layers", C.c_int), ("n_dec_layers", C.c_int), ("vocab_in", C.c_int),
+                ("vocab_out", C.c_int), ("n_mels", C.c_int), ("n_mels_pad", C.c_int), ("src_len", C.c_int),
+                ("tgt_len", C.c_int), ("dtype", C.c_int), ("eps", C.c_float)]
+
+
+class MhT5Weights(C.Structure):
+    _fields_ = [("enc_embed_w", VP), ("enc_embed_b", VP), ("dec_embed", VP), ("enc_rel_bias", VP),
+                ("dec_rel_bias", VP),
+                ("enc_ln1", _PTR_ARR), ("enc_qkv", _PTR_ARR), ("enc_o", _PTR_ARR), ("enc_ln2", _PTR_ARR),
+                ("enc_wi", _PTR_ARR), ("enc_wo", _PTR_ARR), ("enc_final_ln", VP),
+                ("dec_ln1", _PTR_ARR), ("dec_qkv", _PTR_ARR), ("dec_o", _PTR_ARR), ("dec_ln2", _PTR_ARR),
+                ("dec_cq", _PTR_ARR), ("dec_ckv_all", VP), ("dec_co", _PTR_ARR), ("dec_ln3", _PTR_ARR),
+                ("dec_wi", _PTR_ARR), ("dec_wo", _PTR_ARR), ("dec_final_ln", VP), ("lm_head", VP)]
+
+
+class MhSampling(C.Structure):
+    _fields_ = [("do_sample", C.c_int), ("top_k", C.c_int), ("top_p", C.c_float), ("temperature", C.c_float),
+                ("timeshift_bias", C.c_float), ("ts_start", C.c_int), ("ts_end", C.c_int), ("n_sos", C.c_int),
+                ("sos_ids", C.c_int * 16), ("lookback_mask_end", C.c_int), ("pad_id", C.c_int),
+                ("max_length", C.c_int), ("seed", C.c_uint64)]
+
+
+class MhDiTConfig(C.Structure):
+    _fields_ = [("hidden", C.c_int), ("depth", C.c_int), ("n_heads", C.c_int), ("context_size", C.c_int),
+                ("class_size", C.c_int), ("in_channels", C.c_int), ("freq_dim", C.c_int),
+                ("t_freq_dim", C.c_int), ("first_k_pad", C.c_int), ("class_pad", C.c_int)]
+
+
+class MhDiTWeights(C.Structure):
+    _fields_ = [("pos_freqs", VP), ("t_freqs", VP), ("first_w", VP), ("first_b", VP),
+                ("t_w0", VP), ("t_b0", VP), ("t_w1", VP), ("t_b1", VP),
+                ("y_w0", VP), ("y_b0", VP), ("y_w1", VP), ("y_b1", VP),
+                ("ada_w", _PTR_ARR), ("ada_b", _PTR_ARR), ("qkv_w", _PTR_ARR), ("qkv_b", _PTR_ARR),
+                ("out_w", _PTR_ARR), ("out_b", _PTR_ARR), ("fc1_w", _PTR_ARR), ("fc1_b", _PTR_ARR),
+                ("fc2_w", _PTR_ARR), ("fc2_b", _PTR_ARR), ("fin_ada_w", VP), ("fin_ada_b", VP),
+                ("fin_w", VP), ("fin_b", VP)]
+
+
+# every symbol include/mapperhip.h declares: (name, restype, argtypes)
+I, I64, F = C.c_int, C.c_int64, C.c_float
+SYMBOLS = {
+    "mh_last_error": (C.c_char_p, []),
+    "mh_abi_version": (I, []),
+    "mh_mel": (I, [VP, I, I, I, I, I, VP, VP, VP, VP, VP, VP, I, VP, I, I, VP]),
+    "mh_gemm": (I, [C.POINTER(MhGemm), VP]),
+    "mh_rmsnorm": (I, [VP, I, VP, VP, I, I, I, F, I, VP]),
+    "mh_attention": (I, [VP, I, I, VP, I, VP, VP, I, I, I, I, F, I, I, VP]),
+    "mh_t5_encode_workspace_bytes": (I64, [C.POINTER(MhT5Config), I]),
+    "mh_t5_encode": (I, [C.POINTER(MhT5Config), C.POINTER(MhT5Weights), VP, I, VP, VP, VP, I64, VP]),
+    "mh_t5_cross_kv": (I, [C.POINTER(MhT5Config), C.POINTER(MhT5Weights), VP, I, VP, VP]),
+    "mh_t5_decode_workspace_bytes": (I64, [C.POINTER(MhT5Config), I]),
+    "mh_t5_generate": (I, [C.POINTER(MhT5Config), C.POINTER(MhT5Weights), VP, I, VP, VP, I, VP,
+                           C.POINTER(MhSampling), VP, VP, VP, VP, VP, I64, I, VP]),
+    "mh_dit_workspace_bytes": (I64, [C.POINTER(MhDiTConfig), I, I]),
+    "mh_dit_forward_cfg": (I, [C.POINTER(MhDiTConfig), C.POINTER(MhDiTWeights), VP, VP, VP, VP, F, I, I, I,
+                               VP, VP, I64, VP]),
+    "mh_ddpm_step": (I, [VP, VP, VP, VP, VP, VP, VP, I, I, I, VP, VP, VP]),
+    "mh_ddpm_sample_loop": (I, [C.POINTER(MhDiTConfig), C.POINTER(MhDiTWeights), VP, VP, VP, F, I, I, I, I,
+                                VP, VP, VP, VP, VP, VP, I64, VP]),
+}
+
+_lib = None
+
+
+def lib_path() -> str:
+    return _LIB_PATH
+
+
+def load():
+    """Load libmapperhip.so once; raise RuntimeError (never fall back) if it is missing or stale."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise RuntimeError(
+            f"libmapperhip.so not found at {_LIB_PATH}: build it with `make` (or "
+            f"`python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+    lib = C.CDLL(_LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise RuntimeError(f"libmapperhip.so does not export {name} (stale build?)") from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.mh_abi_version() != 1:
+        raise RuntimeError("libmapperhip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().mh_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"libmapperhip {what} failed (status {rc}): {msg}")
+
+
+def ptr(t) -> int:
+    """device pointer of a torch tensor (or None -> NULL)"""
+    if t is None:
+        return None
+    return t.data_ptr()

@@ -124,8 +124,9 @@ __global__ __launch_bounds__(256) void ddpm_step_kernel(const float* __restrict_
                                                        const float* __restrict__ x, const float* __restrict__ noise,
                                                        const float* __restrict__ coef, const int* __restrict__ sel,
                                                        long noise_stride, const uint8_t* __restrict__ imask,
-                                                       const float* __restrict__ iref, int N, int T,
-                                                       float* __restrict__ x_out, float* __restrict__ pred) {
+                                                       const float* __restrict__ iref,
+                                                       const float* __restrict__ x0_override, int raw_pred, int N,
+                                                       int T, float* __restrict__ x_out, float* __restrict__ pred) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= N * 2 * T) return;
   const int si = sel ? *sel : 0;
@@ -138,7 +139,11 @@ __global__ __launch_bounds__(256) void ddpm_step_kernel(const float* __restrict_
   const float min_log = cf[0], max_log = cf[1];
   const float frac = (var + 1.0f) / 2.0f;
   const float logvar = frac * max_log + (1.0f - frac) * min_log;
-  float x0 = cf[2] * xt - cf[3] * eps;
+  float x0 = x0_override ? x0_override[idx] : cf[2] * xt - cf[3] * eps;
+  if (raw_pred) {  // only report the eps -> x0 prediction (caller applies its own denoised_fn)
+    if (pred) pred[idx] = x0;
+    return;
+  }
   if (imask) x0 = imask[idx] ? x0 : iref[idx];
   x0 = fminf(fmaxf(x0, -2.0f), 2.0f);
   const float mean = cf[4] * x0 + cf[5] * xt;
@@ -262,10 +267,10 @@ int dit_forward(const MhDiTConfig* c, const MhDiTWeights* w, const float* x, con
 }
 
 int ddpm_step(const float* model_out, const float* x, const float* noise, const float* coef, const int* sel,
-              long noise_stride, const uint8_t* imask, const float* iref, int N, int T, float* x_out, float* pred,
-              hipStream_t s) {
+              long noise_stride, const uint8_t* imask, const float* iref, const float* x0_override, int raw_pred, int N,
+              int T, float* x_out, float* pred, hipStream_t s) {
   hipLaunchKernelGGL(ddpm_step_kernel, dim3(ceil_div(N * 2 * T, 256)), dim3(256), 0, s, model_out, x, noise, coef, sel,
-                     noise_stride, imask, iref, N, T, x_out, pred);
+                     noise_stride, imask, iref, x0_override, raw_pred, N, T, x_out, pred);
   return check_launch("ddpm_step_kernel");
 }
 
@@ -291,12 +296,13 @@ extern "C" int mh_dit_forward_cfg(const MhDiTConfig* c, const MhDiTWeights* w, c
 }
 
 extern "C" int mh_ddpm_step(const float* model_out, const float* x, const float* noise, const float* coef,
-                            const uint8_t* inpaint_mask, const float* inpaint_ref, int N, int T, float* x_out,
-                            float* pred_xstart, void* stream) {
+                            const uint8_t* inpaint_mask, const float* inpaint_ref, const float* x0_override,
+                            int raw_pred, int N, int T, float* x_out, float* pred_xstart, void* stream) {
   MH_REQUIRE(model_out && x && noise && coef && x_out && N > 0 && T > 0, "mh_ddpm_step: bad argument");
   MH_REQUIRE((inpaint_mask == nullptr) == (inpaint_ref == nullptr), "mh_ddpm_step: inpaint mask/ref must come together");
-  return ddpm_step(model_out, x, noise, coef, nullptr, 0, inpaint_mask, inpaint_ref, N, T, x_out, pred_xstart,
-                   (hipStream_t)stream);
+  MH_REQUIRE(!raw_pred || pred_xstart, "mh_ddpm_step: raw_pred needs pred_xstart");
+  return ddpm_step(model_out, x, noise, coef, nullptr, 0, inpaint_mask, inpaint_ref, x0_override, raw_pred, N, T, x_out,
+                   pred_xstart, (hipStream_t)stream);
 }
 
 extern "C" int mh_ddpm_sample_loop(const MhDiTConfig* c, const MhDiTWeights* w, float* x_io, const float* cc,
@@ -323,7 +329,8 @@ extern "C" int mh_ddpm_sample_loop(const MhDiTConfig* c, const MhDiTWeights* w, 
   if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) return check_launch("begin capture");
   int rc = dit_forward(c, w, x_io, t_map, b.sel, cc, y, cfg_scale, band, N, T, mout, b, s);
   if (rc == MH_OK)
-    rc = ddpm_step(mout, x_io, noise, coefs, b.sel, (long)N * 2 * T, inpaint_mask, inpaint_ref, N, T, x_io, nullptr, s);
+    rc = ddpm_step(mout, x_io, noise, coefs, b.sel, (long)N * 2 * T, inpaint_mask, inpaint_ref, nullptr, 0, N, T, x_io,
+                   nullptr, s);
   if (rc == MH_OK) {
     hipLaunchKernelGGL(loop_dec_kernel, dim3(1), dim3(64), 0, s, b.sel);
     rc = check_launch("loop_dec_kernel");

@@ -1,0 +1,309 @@
+"""Host side of the osu_diffusion refinement stage: `DiTHIP` (boundary B3) and `SpacedDiffusionHIP`
+(boundary B4), SURVEY.md 8b.
+
+  DiTHIP.forward_with_cfg(x, t, c, y, cfg_scale, attn_mask=None, key_padding_mask=None)
+      == DiT.forward_with_cfg            osu_diffusion/utils/models.py:301-317
+  create_diffusion(...).p_sample_loop(model.forward_with_cfg, shape, noise, denoised_fn=..., ...)
+      == SpacedDiffusion.p_sample_loop   utils/diffusion/gaussian_diffusion.py:469-561, respace.py:63-132
+
+The schedule tables are derived in float64 on the host from the same published IDDPM formulas
+(cosine alpha-bar schedule, respacing by re-deriving betas from the kept alpha-bars, learned-range
+variance interpolation) and handed to the kernels as fp32 exactly the way `_extract_into_tensor`
+casts them (gaussian_diffusion.py:951-963).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Callable, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from .testing import DIT_PRESETS
+
+
+def _round_up(a, b):
+    return (a + b - 1) // b * b
+
+
+class DiTHIP:
+    """fp32 DiT denoiser on libmapperhip.  `state_dict` uses the reference's parameter names."""
+
+    def __init__(self, state_dict: dict, depth: int, hidden: int, num_heads: int, context_size: int = 272,
+                 class_size: int = 300, device="cuda"):
+        if not torch.cuda.is_available():
+            raise RuntimeError("DiTHIP needs a ROCm GPU; there is no CPU fallback")
+        if hidden != num_heads * 64:
+            raise NotImplementedError("HIP attention kernels are built for head_dim = 64")
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        self.in_channels, self.learn_sigma = 2, True
+        self.depth, self.hidden, self.num_heads = depth, hidden, num_heads
+        self.context_size, self.class_size = context_size, class_size
+        self._keep = []
+        dev = self.device
+
+        def t(x, kpad=None):
+            x = x.detach().to(torch.float32)
+            if kpad is not None and x.shape[-1] != kpad:
+                x = torch.nn.functional.pad(x, (0, kpad - x.shape[-1]))
+            x = x.contiguous().to(dev)
+            self._keep.append(x)
+            return x.data_ptr()
+
+        k1 = 2 * 128 + context_size
+        cfg = _lib.MhDiTConfig(hidden, depth, num_heads, context_size, class_size, 2, 128, 256, _round_up(k1, 32),
+                               class_size)
+        w = _lib.MhDiTWeights()
+        # frequency tables with the same fp32 tensor ops as timestep_embedding (positional_embedding.py:38-43)
+        w.pos_freqs = t(torch.exp(-math.log(10000) * torch.arange(0, 64, dtype=torch.float32) / 64))
+        w.t_freqs = t(torch.exp(-math.log(10000) * torch.arange(0, 128, dtype=torch.float32) / 128))
+        sd = state_dict
+        w.first_w, w.first_b = t(sd["context_embedder.mlp.0.weight"], cfg.first_k_pad), t(sd["context_embedder.mlp.0.bias"])
+        w.t_w0, w.t_b0 = t(sd["t_embedder.mlp.0.weight"]), t(sd["t_embedder.mlp.0.bias"])
+        w.t_w1, w.t_b1 = t(sd["t_embedder.mlp.2.weight"]), t(sd["t_embedder.mlp.2.bias"])
+        w.y_w0, w.y_b0 = t(sd["y_embedder.class_embedding.0.weight"]), t(sd["y_embedder.class_embedding.0.bias"])
+        w.y_w1, w.y_b1 = t(sd["y_embedder.class_embedding.2.weight"]), t(sd["y_embedder.class_embedding.2.bias"])
+        for l in range(depth):
+            b = f"blocks.{l}."
+            w.ada_w[l], w.ada_b[l] = t(sd[b + "adaLN_modulation.1.weight"]), t(sd[b + "adaLN_modulation.1.bias"])
+            w.qkv_w[l], w.qkv_b[l] = t(sd[b + "attn.in_proj_weight"]), t(sd[b + "attn.in_proj_bias"])
+            w.out_w[l], w.out_b[l] = t(sd[b + "attn.out_proj.weight"]), t(sd[b + "attn.out_proj.bias"])
+            w.fc1_w[l], w.fc1_b[l] = t(sd[b + "mlp.fc1.weight"]), t(sd[b + "mlp.fc1.bias"])
+            w.fc2_w[l], w.fc2_b[l] = t(sd[b + "mlp.fc2.weight"]), t(sd[b + "mlp.fc2.bias"])
+        w.fin_ada_w, w.fin_ada_b = t(sd["final_layer.adaLN_modulation.1.weight"]), t(sd["final_layer.adaLN_modulation.1.bias"])
+        w.fin_w, w.fin_b = t(sd["final_layer.linear.weight"]), t(sd["final_layer.linear.bias"])
+        self.cfg, self.w = cfg, w
+        self.stream = torch.cuda.Stream(self.device)
+        self._ws = None
+        self._band_cache = {}
+
+    @classmethod
+    def from_preset(cls, name: str, state_dict: dict, **kw):
+        depth, hidden, heads = DIT_PRESETS[name]
+        return cls(state_dict, depth, hidden, heads, **kw)
+
+    @classmethod
+    def from_reference(cls, model, device="cuda"):
+        """`model`: a reference osu_diffusion `DiT` module."""
+        return cls(model.state_dict(), len(model.blocks), model.final_layer.linear.in_features, model.num_heads,
+                   context_size=model.context_size, class_size=model.y_embedder.class_embedding[0].in_features,
+                   device=device)
+
+    # nn.Module-ish conveniences used by the reference pipeline
+    def eval(self):
+        return self
+
+    def parameters(self):
+        return iter(self._keep)
+
+    # ---- helpers -----------------------------------------------------------------------------------
+    def workspace(self, N: int, T: int) -> torch.Tensor:
+        need = self.lib.mh_dit_workspace_bytes(C.byref(self.cfg), N, T)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(int(need), dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def band_from_mask(self, attn_mask: Optional[torch.Tensor], T: int) -> int:
+        """The reference passes a (T, T) bool mask, True = masked, built as a band
+        (diffusion_pipeline.py:146-148): query q may attend key k iff -(band-1) <= k - q <= band.
+        Recover `band` and verify the mask really is that band (anything else is refused)."""
+        if attn_mask is None:
+            return 0
+        key = (attn_mask.data_ptr(), tuple(attn_mask.shape), attn_mask._version)
+        if key in self._band_cache:
+            return self._band_cache[key]
+        m = attn_mask.to("cpu")
+        if m.dtype != torch.bool or m.shape != (T, T):
+            raise NotImplementedError("attn_mask must be a (T, T) bool band mask")
+        allowed0 = int((~m[0]).sum().item())  # keys 0..band visible from query 0
+        band = 0 if allowed0 >= T and not bool(m.any()) else allowed0 - 1
+        if band > 0:
+            q = torch.arange(T)[:, None]
+            k = torch.arange(T)[None, :]
+            expect = ~(((k - q) >= -(band - 1)) & ((k - q) <= band))
+            if not torch.equal(expect, m):
+                raise NotImplementedError("attn_mask is not the banded mask of diffusion_pipeline.py:146-148")
+        elif bool(m.any()):
+            raise NotImplementedError("attn_mask is not the banded mask of diffusion_pipeline.py:146-148")
+        self._band_cache[key] = band
+        return band
+
+    # ---- B3 ------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward_with_cfg(self, x, t, c, y, cfg_scale, attn_mask=None, key_padding_mask=None):
+        """key_padding_mask is accepted and ignored, exactly like the reference block
+        (models.py:132,145-151 never forwards it)."""
+        dev = self.device
+        N, _, T = x.shape
+        band = self.band_from_mask(attn_mask, T)
+        x = x.to(dev, torch.float32).contiguous()
+        c = c.to(dev, torch.float32).contiguous()
+        y = y.to(dev, torch.float32).contiguous()
+        t32 = t.to(dev, torch.int32).contiguous()
+        out = torch.empty((N, 4, T), dtype=torch.float32, device=dev)
+        ws = self.workspace(N, T)
+        s = torch.cuda.current_stream(dev).cuda_stream
+        rc = self.lib.mh_dit_forward_cfg(C.byref(self.cfg), C.byref(self.w), x.data_ptr(), t32.data_ptr(),
+                                         c.data_ptr(), y.data_ptr(), float(cfg_scale), band, N, T, out.data_ptr(),
+                                         ws.data_ptr(), ws.numel(), s)
+        _lib.check(rc, "mh_dit_forward_cfg")
+        return out
+
+    __call__ = forward_with_cfg
+
+
+class InpaintSpec:
+    """`denoised_fn` of the reference pipeline when no sliders need re-projection:
+    `x = torch.where(mask, x, z_part)` (diffusion_pipeline.py:203-206).  Callable so that it also works
+    with the reference's own python loop; recognised by SpacedDiffusionHIP and fused into K9."""
+
+    def __init__(self, mask: torch.Tensor, ref: torch.Tensor):
+        self.mask, self.ref = mask, ref
+
+    def __call__(self, x):
+        return torch.where(self.mask.to(x.device), x, self.ref.to(x.device))
+
+
+# ---- schedule (host, float64) --------------------------------------------------------------------
+def named_beta_schedule(name: str, n: int) -> np.ndarray:
+    if name == "linear":
+        scale = 1000 / n
+        return np.linspace(scale * 0.0001, scale * 0.02, n, dtype=np.float64)
+    if name == "squaredcos_cap_v2":
+        f = lambda u: math.cos((u + 0.008) / 1.008 * math.pi / 2) ** 2
+        return np.array([min(1 - f((i + 1) / n) / f(i / n), 0.999) for i in range(n)], dtype=np.float64)
+    raise NotImplementedError(f"unknown beta schedule: {name}")
+
+
+def space_timesteps(num_timesteps: int, section_counts) -> set:
+    if isinstance(section_counts, str):
+        if section_counts.startswith("ddim"):
+            want = int(section_counts[4:])
+            for stride in range(1, num_timesteps):
+                if len(range(0, num_timesteps, stride)) == want:
+                    return set(range(0, num_timesteps, stride))
+            raise ValueError(f"cannot create exactly {num_timesteps} steps with an integer stride")
+        section_counts = [int(v) for v in section_counts.split(",")]
+    per, extra = divmod(num_timesteps, len(section_counts))
+    start, steps = 0, []
+    for i, cnt in enumerate(section_counts):
+        size = per + (1 if i < extra else 0)
+        if size < cnt:
+            raise ValueError(f"cannot divide section of {size} steps into {cnt}")
+        stride = 1 if cnt <= 1 else (size - 1) / (cnt - 1)
+        cur = 0.0
+        for _ in range(cnt):
+            steps.append(start + round(cur))
+            cur += stride
+        start += size
+    return set(steps)
+
+
+class SpacedDiffusionHIP:
+    """epsilon-prediction / learned-range-variance sampler (what `create_diffusion` returns with its
+    defaults, utils/diffusion/__init__.py:10-47), sampling only."""
+
+    def __init__(self, use_timesteps, betas: np.ndarray):
+        base_ac = np.cumprod(1.0 - np.asarray(betas, dtype=np.float64))
+        last, new_betas, self.timestep_map = 1.0, [], []
+        for i, ac in enumerate(base_ac):
+            if i in use_timesteps:
+                new_betas.append(1 - ac / last)
+                last = ac
+                self.timestep_map.append(i)
+        b = np.array(new_betas, dtype=np.float64)
+        self.betas = b
+        self.num_timesteps = len(b)
+        ac = np.cumprod(1.0 - b)
+        ac_prev = np.append(1.0, ac[:-1])
+        self.sqrt_recip_alphas_cumprod = np.sqrt(1.0 / ac)
+        self.sqrt_recipm1_alphas_cumprod = np.sqrt(1.0 / ac - 1)
+        pv = b * (1.0 - ac_prev) / (1.0 - ac)
+        self.posterior_log_variance_clipped = np.log(np.append(pv[1], pv[1:])) if len(pv) > 1 else np.array([])
+        self.posterior_mean_coef1 = b * np.sqrt(ac_prev) / (1.0 - ac)
+        self.posterior_mean_coef2 = (1.0 - ac_prev) * np.sqrt(1.0 - b) / (1.0 - ac)
+
+    def coef_table(self) -> torch.Tensor:
+        """fp32 [n_steps, 7] rows = (min_log, max_log, sqrt_recip, sqrt_recipm1, coef1, coef2, nonzero)."""
+        n = self.num_timesteps
+        tab = np.stack([self.posterior_log_variance_clipped, np.log(self.betas), self.sqrt_recip_alphas_cumprod,
+                        self.sqrt_recipm1_alphas_cumprod, self.posterior_mean_coef1, self.posterior_mean_coef2,
+                        (np.arange(n) != 0).astype(np.float64)], axis=1)
+        return torch.from_numpy(tab).float()  # float64 -> .float(), as _extract_into_tensor does
+
+    @torch.no_grad()
+    def p_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn: Optional[Callable] = None,
+                      cond_fn=None, model_kwargs=None, device=None, progress=False, step_noise=None):
+        """Signature of GaussianDiffusion.p_sample_loop.  `model` must be `DiTHIP.forward_with_cfg` (or a
+        DiTHIP).  `step_noise` (optional, [n_steps, *shape], index = call order) injects the per-step
+        gaussian noise for parity tests; otherwise `torch.randn_like` is called once per step on the
+        device, consuming the global generator exactly as the reference loop does."""
+        dit = getattr(model, "__self__", model)
+        if not isinstance(dit, DiTHIP):
+            raise TypeError("p_sample_loop: model must be DiTHIP.forward_with_cfg")
+        if cond_fn is not None or not clip_denoised:
+            raise NotImplementedError("cond_fn / clip_denoised=False are not used by the pipeline and not built")
+        mk = dict(model_kwargs or {})
+        dev = dit.device
+        x = (noise if noise is not None else torch.randn(*shape, device=dev)).to(dev, torch.float32).contiguous().clone()
+        N, _, T = x.shape
+        c = mk["c"].to(dev, torch.float32).contiguous()
+        y = mk["y"].to(dev, torch.float32).contiguous()
+        cfg_scale = float(mk.get("cfg_scale", 1.0))
+        band = dit.band_from_mask(mk.get("attn_mask"), T)
+        n = self.num_timesteps
+        if step_noise is None:
+            step_noise = torch.stack([torch.randn_like(x) for _ in range(n)])
+        step_noise = step_noise.to(dev, torch.float32)
+        noise_by_i = torch.flip(step_noise, dims=[0]).contiguous()  # call k handles loop index i = n-1-k
+        coefs = self.coef_table().to(dev).contiguous()
+        t_map = torch.tensor(self.timestep_map, dtype=torch.int32, device=dev)
+        lib, s = dit.lib, None
+        ws = dit.workspace(N, T)
+
+        if denoised_fn is None or isinstance(denoised_fn, InpaintSpec):
+            imask = iref = None
+            if denoised_fn is not None:
+                imask = denoised_fn.mask.to(dev).to(torch.uint8).contiguous()
+                iref = denoised_fn.ref.to(dev, torch.float32).contiguous()
+            dit.stream.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(dit.stream):
+                rc = lib.mh_ddpm_sample_loop(C.byref(dit.cfg), C.byref(dit.w), x.data_ptr(), c.data_ptr(),
+                                             y.data_ptr(), cfg_scale, band, N, T, n, t_map.data_ptr(),
+                                             coefs.data_ptr(), noise_by_i.data_ptr(), _lib.ptr(imask), _lib.ptr(iref),
+                                             ws.data_ptr(), ws.numel(), dit.stream.cuda_stream)
+            _lib.check(rc, "mh_ddpm_sample_loop")
+            torch.cuda.current_stream(dev).wait_stream(dit.stream)
+            return x
+
+        # arbitrary host denoised_fn (slider re-projection): per-step launches, x0 round trip through python
+        s = torch.cuda.current_stream(dev).cuda_stream
+        mout = torch.empty((N, 4, T), dtype=torch.float32, device=dev)
+        x0 = torch.empty_like(x)
+        for i in reversed(range(n)):
+            t32 = torch.full((N,), self.timestep_map[i], dtype=torch.int32, device=dev)
+            _lib.check(lib.mh_dit_forward_cfg(C.byref(dit.cfg), C.byref(dit.w), x.data_ptr(), t32.data_ptr(),
+                                              c.data_ptr(), y.data_ptr(), cfg_scale, band, N, T, mout.data_ptr(),
+                                              ws.data_ptr(), ws.numel(), s), "mh_dit_forward_cfg")
+            _lib.check(lib.mh_ddpm_step(mout.data_ptr(), x.data_ptr(), noise_by_i[i].data_ptr(), coefs[i].data_ptr(),
+                                        None, None, None, 1, N, T, x.data_ptr(), x0.data_ptr(), s), "mh_ddpm_step")
+            x0n = denoised_fn(x0.clone()).to(dev, torch.float32).contiguous()
+            _lib.check(lib.mh_ddpm_step(mout.data_ptr(), x.data_ptr(), noise_by_i[i].data_ptr(), coefs[i].data_ptr(),
+                                        None, None, x0n.data_ptr(), 0, N, T, x.data_ptr(), None, s), "mh_ddpm_step")
+        return x
+
+
+def create_diffusion(timestep_respacing, noise_schedule="linear", use_kl=False, sigma_small=False,
+                     predict_xstart=False, learn_sigma=True, rescale_learned_sigmas=False, diffusion_steps=1000,
+                     use_l1=False) -> SpacedDiffusionHIP:
+    """Same signature as the reference factory (utils/diffusion/__init__.py:10-47); only the sampling
+    configuration the pipeline uses is built (epsilon prediction, learned-range sigma)."""
+    if predict_xstart or not learn_sigma or sigma_small:
+        raise NotImplementedError("the pipeline samples with epsilon prediction + learned-range variance only")
+    betas = named_beta_schedule(noise_schedule, diffusion_steps)
+    if timestep_respacing is None or timestep_respacing == "":
+        timestep_respacing = [diffusion_steps]
+    return SpacedDiffusionHIP(space_timesteps(diffusion_steps, timestep_respacing), betas)

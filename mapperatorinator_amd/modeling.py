@@ -1,0 +1,84 @@
+"""`MapperatorinatorHIP`: the boundary object B2.
+
+Stands where the reference's `Mapperatorinator` (osuT5/osuT5/model/modeling_mapperatorinator.py:60-353)
+stands for the *generate* path: same attributes the callers read (`.device`, `.dtype`,
+`.config.{max_target_positions, max_source_positions, hidden_size, vocab_size, ...}`,
+`.spectrogram`, `.generate(**kwargs)`), but the arithmetic underneath is libmapperhip.
+
+Only the T5-backbone configuration of the north star is wired (input_features=False,
+project_encoder_input=True, embed_decoder_input=True, no conditioning embedders:
+configs/model/default.yaml:1-4 + t5_small_v9.yaml:5); anything else raises NotImplementedError
+instead of silently running something different.
+"""
+from __future__ import annotations
+
+import types
+from typing import Optional
+
+import torch
+
+from .t5_engine import T5Dims, T5Engine, T5_PRESETS
+
+
+def dims_from_backbone_config(bc) -> T5Dims:
+    """HF T5Config-like object (d_model, d_ff, d_kv, num_heads, num_layers, num_decoder_layers, ...)."""
+    if getattr(bc, "d_kv", 64) != 64:
+        raise NotImplementedError("HIP attention kernels are built for d_kv = 64")
+    if not getattr(bc, "is_gated_act", True):
+        raise NotImplementedError("only the gated-gelu (T5 v1.1) FFN is built")
+    return T5Dims(d_model=bc.d_model, d_ff=bc.d_ff, n_heads=bc.num_heads, n_enc_layers=bc.num_layers,
+                  n_dec_layers=bc.num_decoder_layers, d_kv=64,
+                  n_buckets=bc.relative_attention_num_buckets,
+                  max_distance=bc.relative_attention_max_distance, eps=bc.layer_norm_epsilon)
+
+
+class MapperatorinatorHIP:
+    main_input_name = "frames"
+
+    def __init__(self, state_dict: dict, dims: T5Dims, *, vocab_size_in: int, vocab_size_out: int,
+                 n_mels: int = 388, src_seq_len: int = 1251, tgt_seq_len: int = 512,
+                 dtype: torch.dtype = torch.bfloat16, device="cuda", sample_rate: int = 16000, n_fft: int = 1024,
+                 hop_length: int = 128, f_min: int = 0, f_max: int = 8000, spectrogram_log_scale: bool = False,
+                 pad_token_id: int = 0, bos_token_id: int = 1, eos_token_id: int = 2):
+        self.engine = T5Engine(state_dict, dims, vocab_size_in, vocab_size_out, n_mels, src_seq_len, tgt_seq_len,
+                               dtype, device, sample_rate, n_fft, hop_length, f_min, f_max, spectrogram_log_scale)
+        self.device = self.engine.device
+        self.dtype = dtype
+        self.spectrogram = self.engine.spectrogram
+        self.config = types.SimpleNamespace(
+            hidden_size=dims.d_model, num_attention_heads=dims.n_heads, num_hidden_layers=dims.n_enc_layers,
+            max_source_positions=src_seq_len, max_target_positions=tgt_seq_len, vocab_size=vocab_size_out,
+            vocab_size_in=vocab_size_in, n_mels=n_mels, hop_length=hop_length, sample_rate=sample_rate,
+            pad_token_id=pad_token_id, bos_token_id=bos_token_id, eos_token_id=eos_token_id,
+            is_encoder_decoder=True, backbone_model_name="google/t5-v1_1(hip)")
+
+    # ---- construction from the reference object ---------------------------------------------------
+    @classmethod
+    def from_reference(cls, model, dtype: Optional[torch.dtype] = None, device="cuda"):
+        """`model`: a reference `Mapperatorinator` with a google/t5 backbone (possibly on the CPU)."""
+        cfg = model.config
+        if not str(cfg.backbone_model_name).startswith("google/t5"):
+            raise NotImplementedError("only T5 backbones run on the HIP path (Whisper-family: SURVEY.md 8f rank 2)")
+        if cfg.input_features or not cfg.project_encoder_input or not cfg.embed_decoder_input or cfg.input_raw_wave:
+            raise NotImplementedError("HIP path implements input_features=False, project_encoder_input=True, "
+                                      "embed_decoder_input=True")
+        if cfg.do_style_embed or cfg.do_difficulty_embed or cfg.do_mapper_embed or cfg.do_song_position_embed:
+            raise NotImplementedError("conditioning embedders are not part of the T5 north-star configs")
+        bc = cfg.backbone_config
+        return cls(model.state_dict(), dims_from_backbone_config(bc), vocab_size_in=cfg.vocab_size_in,
+                   vocab_size_out=cfg.vocab_size, n_mels=cfg.n_mels, src_seq_len=cfg.max_source_positions,
+                   tgt_seq_len=cfg.max_target_positions, dtype=dtype or model.dtype, device=device,
+                   sample_rate=cfg.sample_rate, n_fft=cfg.n_fft, hop_length=cfg.hop_length, f_min=cfg.f_min,
+                   f_max=cfg.f_max, spectrogram_log_scale=cfg.spectrogram_log_scale,
+                   pad_token_id=cfg.pad_token_id, bos_token_id=cfg.bos_token_id, eos_token_id=cfg.eos_token_id)
+
+    @classmethod
+    def from_preset(cls, name: str, state_dict: dict, **kw):
+        return cls(state_dict, T5_PRESETS[name], **kw)
+
+    # nn.Module-ish conveniences the reference callers use
+    def eval(self):
+        return self
+
+    def to(self, *a, **k):
+        return self

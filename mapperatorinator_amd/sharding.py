@@ -1,0 +1,70 @@
+"""Chunk-parallel sharding of the hot path over the GPUs of one node.
+
+The path shards naturally: `generate_parallel` windows / songs are independent units
+(osuT5/osuT5/inference/processor.py:370-419; preprocessor.py:20-21), every rank holds a full
+replica of the weights and runs mel -> encode -> decode (-> DiT) on its block of chunks with NO
+data-path collective.  The only exchange is one all_gather of the finished token streams
+(B_local x max_length int32, <= 256 KB per rank: latency-bound over xGMI) so that rank 0 -- or
+every rank -- can continue with the unchanged host loop.  Backend "nccl" is RCCL on ROCm; the same
+code runs on "gloo" with CPU tensors (tests/test_sharding_gloo.py, world_size 2).
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n_items: int, rank: int, world: int) -> tuple[int, int]:
+    """Contiguous block partition; the first `n_items % world` ranks get one extra item."""
+    base, extra = divmod(n_items, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def all_gather_ragged(local: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
+    """local: (n_local, W) on the backend's device; returns (n_total, W) with rows in global order.
+    Shards are padded to the largest shard so one fixed-size all_gather suffices."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    lo, hi = shard_bounds(n_total, rank, world)
+    assert local.shape[0] == hi - lo, f"rank {rank}: expected {hi - lo} rows, got {local.shape[0]}"
+    max_rows = -(-n_total // world)
+    buf = local.new_zeros((max_rows,) + tuple(local.shape[1:]))
+    buf[: local.shape[0]] = local
+    out = local.new_empty((world * max_rows,) + tuple(local.shape[1:]))
+    dist.all_gather_into_tensor(out, buf.contiguous(), group=group)
+    parts = []
+    for r in range(world):
+        a, b = shard_bounds(n_total, r, world)
+        parts.append(out[r * max_rows: r * max_rows + (b - a)])
+    return torch.cat(parts, 0)
+
+
+def sharded_generate(generate_fn: Callable, model_kwargs: dict, pad_id: int, max_length: int, group=None,
+                     comm_device: Optional[torch.device] = None):
+    """Run `generate_fn(shard_of_model_kwargs) -> (LongTensor[n_local, <=max_length] (CPU), stats)` on this
+    rank's block of chunks and all_gather the padded token streams.
+
+    Returns (tokens int64 CPU (B, max_length) padded with pad_id, lengths int64 (B,), local_stats)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    B = model_kwargs["inputs"].shape[0]
+    lo, hi = shard_bounds(B, rank, world)
+    shard = {k: (v[lo:hi] if isinstance(v, torch.Tensor) and v.shape[:1] == (B,) else v)
+             for k, v in model_kwargs.items()}
+    if hi > lo:
+        toks, stats = generate_fn(shard)
+    else:
+        toks, stats = torch.zeros((0, 1), dtype=torch.long), {"generated_tokens": 0}
+    local = torch.full((hi - lo, max_length + 1), pad_id, dtype=torch.int32)
+    local[:, : toks.shape[1]] = toks.to(torch.int32)
+    local[:, max_length] = toks.shape[1]          # last column carries the produced length
+    if world == 1:
+        full = local
+    else:
+        dev = comm_device or (torch.device("cuda", torch.cuda.current_device())
+                              if dist.get_backend(group) == "nccl" else torch.device("cpu"))
+        full = all_gather_ragged(local.to(dev), B, group).cpu()
+    return full[:, :max_length].to(torch.int64), full[:, max_length].to(torch.int64), stats

@@ -1,0 +1,288 @@
+"""Host side of the osuT5 hot path: weight ingestion from the reference `state_dict()` names into
+packed device buffers, relative-bias lookup tables, and the mel -> encode -> cross-KV -> AR-decode
+driver around libmapperhip (csrc/t5.hip).
+
+Numerics contract ("rounding points") of the two storage modes:
+  fp32 : everything fp32; GEMMs on the exact-f32 MFMA atom (bitwise an fmaf chain).
+  bf16 : parameters and GEMM operands are bf16 (`model.to(bfloat16)` semantics for the weights,
+         reference osuT5/osuT5/utils/model_utils.py:375-376); accumulation, the residual stream,
+         RMSNorm, softmax, GELU and logits stay fp32; activations are rounded to bf16 exactly where
+         they become a GEMM operand (after each RMSNorm, q/k/v, attention output, gated FFN hidden).
+         This keeps MORE precision than the reference's all-bf16 module (which also rounds the
+         residual stream); `oracle/t5.py` restates the same contract on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import dataclasses
+import math
+from typing import Optional
+
+import torch
+
+from . import _lib
+from .mel import MelSpectrogram
+
+
+@dataclasses.dataclass
+class T5Dims:
+    d_model: int
+    d_ff: int
+    n_heads: int
+    n_enc_layers: int
+    n_dec_layers: int
+    d_kv: int = 64
+    n_buckets: int = 32
+    max_distance: int = 128
+    eps: float = 1e-6
+
+    @property
+    def inner(self) -> int:
+        return self.n_heads * self.d_kv
+
+
+# google/t5-v1_1-{small,base,large} (the backbones `get_backbone_model` accepts under "google/t5",
+# modeling_mapperatorinator.py:20-24); "tiny" is a test-only size.
+T5_PRESETS = {
+    "tiny": T5Dims(d_model=128, d_ff=256, n_heads=2, n_enc_layers=2, n_dec_layers=2),
+    "small": T5Dims(d_model=512, d_ff=1024, n_heads=6, n_enc_layers=8, n_dec_layers=8),
+    "base": T5Dims(d_model=768, d_ff=2048, n_heads=12, n_enc_layers=12, n_dec_layers=12),
+    "large": T5Dims(d_model=1024, d_ff=2816, n_heads=16, n_enc_layers=24, n_dec_layers=24),
+}
+
+
+def relative_position_bucket(rel: torch.Tensor, bidirectional: bool, num_buckets: int, max_distance: int):
+    """The published T5 bucketing of `rel = key_pos - query_pos` (int64 tensor), evaluated with the
+    same fp32 tensor ops as HF `T5Attention._relative_position_bucket` / the restatement at
+    osuT5/osuT5/model/custom_transformers/t5.py:88-141, so bucket boundaries agree bit for bit."""
+    ret = torch.zeros_like(rel)
+    n = num_buckets
+    if bidirectional:
+        n //= 2
+        ret = ret + (rel > 0).to(torch.long) * n
+        rp = rel.abs()
+    else:
+        rp = -torch.min(rel, torch.zeros_like(rel))
+    max_exact = n // 2
+    is_small = rp < max_exact
+    large = max_exact + (torch.log(rp.float() / max_exact) / math.log(max_distance / max_exact)
+                         * (n - max_exact)).to(torch.long)
+    large = torch.min(large, torch.full_like(large, n - 1))
+    return ret + torch.where(is_small, rp, large)
+
+
+def rel_bias_tables(enc_table: torch.Tensor, dec_table: torch.Tensor, src_len: int, tgt_len: int, dims: T5Dims):
+    """enc [H, 2L-1] indexed by (k - q) + L - 1; dec [H, tgt_len] indexed by distance q - k >= 0."""
+    rel = torch.arange(-(src_len - 1), src_len, dtype=torch.long)
+    eb = relative_position_bucket(rel, True, dims.n_buckets, dims.max_distance)
+    enc = enc_table.float()[eb].t().contiguous()           # [H, 2L-1]
+    dist = torch.arange(0, tgt_len, dtype=torch.long)
+    db = relative_position_bucket(-dist, False, dims.n_buckets, dims.max_distance)
+    dec = dec_table.float()[db].t().contiguous()           # [H, tgt_len]
+    return enc, dec
+
+
+def _round_up(a, b):
+    return (a + b - 1) // b * b
+
+
+class PackedT5:
+    """Device-resident packed weights + the MhT5Config / MhT5Weights structs that describe them."""
+
+    def __init__(self, sd: dict, dims: T5Dims, vocab_in: int, vocab_out: int, n_mels: int, src_len: int,
+                 tgt_len: int, dtype: torch.dtype, device):
+        assert dtype in (torch.float32, torch.bfloat16)
+        self.dims, self.dtype, self.device = dims, dtype, torch.device(device)
+        self.vocab_in, self.vocab_out, self.n_mels = vocab_in, vocab_out, n_mels
+        self.n_mels_pad = _round_up(n_mels, 32)
+        self.src_len, self.tgt_len = src_len, tgt_len
+        self._keep = []
+        dev = self.device
+
+        def mat(t, kpad=None):  # GEMM operand: storage dtype, K padded with zeros
+            t = t.detach().to(torch.float32)
+            if kpad is not None and t.shape[1] != kpad:
+                t = torch.nn.functional.pad(t, (0, kpad - t.shape[1]))
+            t = t.to(dtype).contiguous().to(dev)
+            self._keep.append(t)
+            return t
+
+        def vec(t):  # fp32 vector holding the storage-dtype-rounded values
+            t = t.detach().to(dtype).to(torch.float32).contiguous().to(dev)
+            self._keep.append(t)
+            return t
+
+        def interleave16(a, b):  # wi_0 / wi_1 -> alternating 16-row blocks (MH_EPI_GEGLU layout)
+            dff, d = a.shape
+            assert dff % 16 == 0
+            return torch.stack([a.reshape(dff // 16, 16, d), b.reshape(dff // 16, 16, d)], dim=1).reshape(2 * dff, d)
+
+        pe, pd = "transformer.encoder.", "transformer.decoder."
+        cfg = _lib.MhT5Config(dims.d_model, dims.d_kv, dims.d_ff, dims.n_heads, dims.n_enc_layers, dims.n_dec_layers,
+                              vocab_in, vocab_out, n_mels, self.n_mels_pad, src_len, tgt_len,
+                              _lib.MH_BF16 if dtype == torch.bfloat16 else _lib.MH_F32, dims.eps)
+        w = _lib.MhT5Weights()
+        w.enc_embed_w = mat(sd["encoder_embedder.weight"], self.n_mels_pad).data_ptr()
+        w.enc_embed_b = vec(sd["encoder_embedder.bias"]).data_ptr()
+        w.dec_embed = mat(sd["decoder_embedder.weight"]).data_ptr()
+        enc_tab = sd[pe + "block.0.layer.0.SelfAttention.relative_attention_bias.weight"].detach().to(dtype).float().cpu()
+        dec_tab = sd[pd + "block.0.layer.0.SelfAttention.relative_attention_bias.weight"].detach().to(dtype).float().cpu()
+        eb, db = rel_bias_tables(enc_tab, dec_tab, src_len, tgt_len, dims)
+        eb, db = eb.to(dev), db.to(dev)
+        self._keep += [eb, db]
+        w.enc_rel_bias, w.dec_rel_bias = eb.data_ptr(), db.data_ptr()
+        for l in range(dims.n_enc_layers):
+            b = f"{pe}block.{l}."
+            a = b + "layer.0.SelfAttention."
+            w.enc_ln1[l] = vec(sd[b + "layer.0.layer_norm.weight"]).data_ptr()
+            w.enc_qkv[l] = mat(torch.cat([sd[a + "q.weight"], sd[a + "k.weight"], sd[a + "v.weight"]], 0)).data_ptr()
+            w.enc_o[l] = mat(sd[a + "o.weight"]).data_ptr()
+            w.enc_ln2[l] = vec(sd[b + "layer.1.layer_norm.weight"]).data_ptr()
+            f = b + "layer.1.DenseReluDense."
+            w.enc_wi[l] = mat(interleave16(sd[f + "wi_0.weight"], sd[f + "wi_1.weight"])).data_ptr()
+            w.enc_wo[l] = mat(sd[f + "wo.weight"]).data_ptr()
+        w.enc_final_ln = vec(sd[pe + "final_layer_norm.weight"]).data_ptr()
+        ckv = []
+        for l in range(dims.n_dec_layers):
+            b = f"{pd}block.{l}."
+            a = b + "layer.0.SelfAttention."
+            x = b + "layer.1.EncDecAttention."
+            w.dec_ln1[l] = vec(sd[b + "layer.0.layer_norm.weight"]).data_ptr()
+            w.dec_qkv[l] = mat(torch.cat([sd[a + "q.weight"], sd[a + "k.weight"], sd[a + "v.weight"]], 0)).data_ptr()
+            w.dec_o[l] = mat(sd[a + "o.weight"]).data_ptr()
+            w.dec_ln2[l] = vec(sd[b + "layer.1.layer_norm.weight"]).data_ptr()
+            w.dec_cq[l] = mat(sd[x + "q.weight"]).data_ptr()
+            ckv += [sd[x + "k.weight"], sd[x + "v.weight"]]
+            w.dec_co[l] = mat(sd[x + "o.weight"]).data_ptr()
+            w.dec_ln3[l] = vec(sd[b + "layer.2.layer_norm.weight"]).data_ptr()
+            f = b + "layer.2.DenseReluDense."
+            w.dec_wi[l] = mat(interleave16(sd[f + "wi_0.weight"], sd[f + "wi_1.weight"])).data_ptr()
+            w.dec_wo[l] = mat(sd[f + "wo.weight"]).data_ptr()
+        w.dec_ckv_all = mat(torch.cat(ckv, 0)).data_ptr()
+        w.dec_final_ln = vec(sd[pd + "final_layer_norm.weight"]).data_ptr()
+        w.lm_head = mat(sd["transformer.lm_head.weight"]).data_ptr()
+        self.cfg, self.w = cfg, w
+
+    def nbytes(self) -> int:
+        return sum(t.numel() * t.element_size() for t in self._keep)
+
+
+class T5Engine:
+    """mel -> encoder -> cross-KV -> KV-cached AR decode on one GPU."""
+
+    def __init__(self, state_dict: dict, dims: T5Dims, vocab_in: int, vocab_out: int, n_mels: int = 388,
+                 src_len: int = 1251, tgt_len: int = 512, dtype: torch.dtype = torch.bfloat16, device="cuda",
+                 sample_rate: int = 16000, n_fft: int = 1024, hop_length: int = 128, f_min: int = 0,
+                 f_max: int = 8000, log_scale: bool = False):
+        if not torch.cuda.is_available():
+            raise RuntimeError("T5Engine needs a ROCm GPU; there is no CPU fallback")
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        self.dims, self.dtype = dims, dtype
+        self.packed = PackedT5(state_dict, dims, vocab_in, vocab_out, n_mels, src_len, tgt_len, dtype, self.device)
+        self.spectrogram = MelSpectrogram("nnAudio", log_scale, sample_rate, n_fft, n_mels, hop_length, f_min,
+                                          f_max, "constant").to(self.device)
+        self.hop_length, self.src_len, self.tgt_len = hop_length, src_len, tgt_len
+        self.stream = torch.cuda.Stream(self.device)
+        self._ws = {}
+
+    # ---- buffers ---------------------------------------------------------------------------------
+    def _workspace(self, kind: str, nbytes: int) -> torch.Tensor:
+        t = self._ws.get(kind)
+        if t is None or t.numel() < nbytes:
+            t = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+            self._ws[kind] = t
+        return t
+
+    def _s(self) -> int:
+        return self.stream.cuda_stream
+
+    # ---- stages (all on self.stream; callers bracket with `_enter` / `_leave`) ----------------------
+    def _enter(self):
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+
+    def _leave(self):
+        torch.cuda.current_stream(self.device).wait_stream(self.stream)
+
+    def mel(self, audio: torch.Tensor) -> torch.Tensor:
+        """(B, Ns) fp32 -> (B, L, n_mels_pad) storage dtype (K-padded GEMM operand)."""
+        p = self.packed
+        if audio.shape[1] // self.hop_length + 1 != p.src_len:
+            raise ValueError(f"audio of {audio.shape[1]} samples gives {audio.shape[1] // self.hop_length + 1} frames; "
+                             f"this engine was built for src_len={p.src_len}")
+        return self.spectrogram.forward_padded(audio, p.n_mels_pad, self.dtype)
+
+    def encode_mel(self, mel: torch.Tensor, want_f32: bool = False):
+        p = self.packed
+        B = mel.shape[0]
+        need = self.lib.mh_t5_encode_workspace_bytes(C.byref(p.cfg), B)
+        ws = self._workspace("enc", need)
+        enc = torch.empty((B, p.src_len, self.dims.d_model), dtype=self.dtype, device=self.device)
+        enc32 = torch.empty((B, p.src_len, self.dims.d_model), dtype=torch.float32, device=self.device) if want_f32 else None
+        rc = self.lib.mh_t5_encode(C.byref(p.cfg), C.byref(p.w), mel.data_ptr(), B, enc.data_ptr(),
+                                   _lib.ptr(enc32), ws.data_ptr(), ws.numel(), self._s())
+        _lib.check(rc, "mh_t5_encode")
+        return (enc, enc32) if want_f32 else enc
+
+    def cross_kv(self, enc: torch.Tensor) -> torch.Tensor:
+        p = self.packed
+        B = enc.shape[0]
+        kv = torch.empty((self.dims.n_dec_layers, 2, B, self.dims.n_heads, p.src_len, 64), dtype=self.dtype,
+                         device=self.device)
+        rc = self.lib.mh_t5_cross_kv(C.byref(p.cfg), C.byref(p.w), enc.data_ptr(), B, kv.data_ptr(), self._s())
+        _lib.check(rc, "mh_t5_cross_kv")
+        return kv
+
+    def encode(self, audio: torch.Tensor, want_f32: bool = False):
+        """audio (B, Ns) on the GPU -> encoder last_hidden_state (final RMSNorm applied)."""
+        self._enter()
+        with torch.cuda.stream(self.stream):
+            out = self.encode_mel(self.mel(audio), want_f32)
+        self._leave()
+        return out
+
+    def decode(self, cross_kv: torch.Tensor, prompt: torch.Tensor, prompt_mask: Optional[torch.Tensor],
+               eos_table: torch.Tensor, sampling: _lib.MhSampling, forced: Optional[torch.Tensor] = None,
+               dump_logits: bool = False, poll_every: int = 16):
+        """prompt int32 (B, P) on device.  Returns (tokens int32 (B, max_length) device, n_cols int, logits|None)."""
+        p = self.packed
+        B, P = prompt.shape
+        need = self.lib.mh_t5_decode_workspace_bytes(C.byref(p.cfg), B)
+        ws = self._workspace("dec", need)
+        maxlen = sampling.max_length
+        tokens = torch.full((B, maxlen), int(sampling.pad_id), dtype=torch.int32, device=self.device)
+        n_out = torch.zeros(1, dtype=torch.int32, device=self.device)
+        logits = (torch.zeros((maxlen, B, p.vocab_out), dtype=torch.float32, device=self.device)
+                  if (dump_logits or sampling.do_sample) else None)
+        rc = self.lib.mh_t5_generate(C.byref(p.cfg), C.byref(p.w), cross_kv.data_ptr(), B, prompt.data_ptr(),
+                                     _lib.ptr(prompt_mask), P, eos_table.data_ptr(), C.byref(sampling),
+                                     tokens.data_ptr(), n_out.data_ptr(), _lib.ptr(logits), _lib.ptr(forced),
+                                     ws.data_ptr(), ws.numel(), poll_every, self._s())
+        _lib.check(rc, "mh_t5_generate")
+        return tokens, n_out, logits
+
+    def generate(self, audio: torch.Tensor, prompt: torch.Tensor, prompt_mask: Optional[torch.Tensor],
+                 eos_ids, sampling: _lib.MhSampling, forced: Optional[torch.Tensor] = None,
+                 dump_logits: bool = False, poll_every: int = 16):
+        """Full hot path for one batch of chunks.  Inputs may be CPU tensors (copied like
+        server.py:86-87 does).  Returns dict(tokens=int64 CPU (B, n_cols), logits=..., n_cols=int)."""
+        dev = self.device
+        audio = audio.to(dev, torch.float32)
+        prompt_d = prompt.to(dev, torch.int32).contiguous()
+        mask_d = prompt_mask.to(dev).to(torch.uint8).contiguous() if prompt_mask is not None else None
+        forced_d = forced.to(dev, torch.int32).contiguous() if forced is not None else None
+        eos_table = torch.zeros(self.packed.vocab_out, dtype=torch.uint8)
+        eos_table[torch.as_tensor(sorted(set(int(e) for e in eos_ids if 0 <= int(e) < self.packed.vocab_out)),
+                                  dtype=torch.long)] = 1
+        eos_table = eos_table.to(dev)
+        self._enter()
+        with torch.cuda.stream(self.stream):
+            enc = self.encode_mel(self.mel(audio))
+            kv = self.cross_kv(enc)
+            tokens, n_out, logits = self.decode(kv, prompt_d, mask_d, eos_table, sampling, forced_d, dump_logits,
+                                                poll_every)
+        self._leave()
+        torch.cuda.current_stream(dev).synchronize()
+        n_cols = int(n_out.item()) if forced is None else sampling.max_length
+        return dict(tokens=tokens[:, :n_cols].to(torch.int64).cpu(), n_cols=n_cols,
+                    logits=None if logits is None else logits[:n_cols])

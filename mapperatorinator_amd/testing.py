@@ -1,0 +1,129 @@
+"""Deterministic synthetic inputs / random-init weights shared by tests, bench.py and the golden
+generator (oracle/make_golden.py).  numpy's PCG64 stream is platform-stable, so the GPU box
+regenerates bit-identical weights from a seed instead of shipping 100s of MB of fixtures.
+
+Weight scales follow HF `T5PreTrainedModel._init_weights` (factor 1.0) and the reference wrapper's
+own initialisers (modeling_mapperatorinator.py:123-128: nn.Linear default, Embedding std=0.02);
+`lm_head_gain` optionally widens the logit gaps so that greedy ties are well above fp noise
+(SURVEY.md 7 "hard parts").
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .t5_engine import T5Dims
+
+
+def _normal(rng, shape, std):
+    return torch.from_numpy((rng.standard_normal(shape) * std).astype(np.float32))
+
+
+def random_t5_state_dict(dims: T5Dims, vocab_in: int, vocab_out: int, n_mels: int = 388, seed: int = 0,
+                         lm_head_gain: float = 1.0, ln_jitter: float = 0.1) -> dict:
+    rng = np.random.default_rng(seed)
+    d, dff, inner, H = dims.d_model, dims.d_ff, dims.inner, dims.n_heads
+    sd = {}
+    sd["encoder_embedder.weight"] = _normal(rng, (d, n_mels), 1.0 / np.sqrt(n_mels))
+    sd["encoder_embedder.bias"] = _normal(rng, (d,), 0.02)
+    sd["decoder_embedder.weight"] = _normal(rng, (vocab_in, d), 1.0)
+    sd["transformer.lm_head.weight"] = _normal(rng, (vocab_out, d), lm_head_gain * d ** -0.5)
+
+    def attn(prefix, with_bias_table):
+        sd[prefix + "q.weight"] = _normal(rng, (inner, d), (d * dims.d_kv) ** -0.5)
+        sd[prefix + "k.weight"] = _normal(rng, (inner, d), d ** -0.5)
+        sd[prefix + "v.weight"] = _normal(rng, (inner, d), d ** -0.5)
+        sd[prefix + "o.weight"] = _normal(rng, (d, inner), inner ** -0.5)
+        if with_bias_table:
+            sd[prefix + "relative_attention_bias.weight"] = _normal(rng, (dims.n_buckets, H), 0.5)
+
+    def ffn(prefix):
+        sd[prefix + "wi_0.weight"] = _normal(rng, (dff, d), d ** -0.5)
+        sd[prefix + "wi_1.weight"] = _normal(rng, (dff, d), d ** -0.5)
+        sd[prefix + "wo.weight"] = _normal(rng, (d, dff), dff ** -0.5)
+
+    def ln(name):
+        sd[name] = 1.0 + _normal(rng, (d,), ln_jitter)
+
+    for l in range(dims.n_enc_layers):
+        b = f"transformer.encoder.block.{l}."
+        attn(b + "layer.0.SelfAttention.", l == 0)
+        ln(b + "layer.0.layer_norm.weight")
+        ffn(b + "layer.1.DenseReluDense.")
+        ln(b + "layer.1.layer_norm.weight")
+    ln("transformer.encoder.final_layer_norm.weight")
+    for l in range(dims.n_dec_layers):
+        b = f"transformer.decoder.block.{l}."
+        attn(b + "layer.0.SelfAttention.", l == 0)
+        ln(b + "layer.0.layer_norm.weight")
+        attn(b + "layer.1.EncDecAttention.", False)
+        ln(b + "layer.1.layer_norm.weight")
+        ffn(b + "layer.2.DenseReluDense.")
+        ln(b + "layer.2.layer_norm.weight")
+    ln("transformer.decoder.final_layer_norm.weight")
+    return sd
+
+
+def synthetic_audio(batch: int, n_samples: int = 160000, seed: int = 0) -> torch.Tensor:
+    """N(0,1) noise plus two tones, peak-normalised to [-1, 1] per row (mirrors
+    `normalize_audio_samples`, osuT5/osuT5/dataset/data_utils.py:132-137)."""
+    rng = np.random.default_rng(1000 + seed)
+    x = rng.standard_normal((batch, n_samples)).astype(np.float32)
+    t = np.arange(n_samples, dtype=np.float32) / 16000.0
+    for b in range(batch):
+        x[b] += 2.0 * np.sin(2 * np.pi * (220.0 * (1 + b % 5)) * t) + 1.0 * np.sin(2 * np.pi * 3520.0 * t + b)
+    x /= np.abs(x).max(axis=1, keepdims=True)
+    return torch.from_numpy(x)
+
+
+# ---- DiT ------------------------------------------------------------------------------------------
+DIT_PRESETS = {  # osu_diffusion/utils/models.py:384-405 (depth, hidden, heads)
+    "DiT-XS": (2, 128, 2),  # test-only
+    "DiT-S": (12, 384, 6),
+    "DiT-B": (12, 768, 12),
+    "DiT-L": (24, 1024, 16),
+}
+
+
+def random_dit_state_dict(depth: int, hidden: int, context_size: int = 272, class_size: int = 300, seed: int = 0,
+                          std: float = 0.02) -> dict:
+    """Keys of `DiT.state_dict()` (osu_diffusion/utils/models.py:213-279).  adaLN / final layers are
+    zero-init in the reference (:270-279) => output identically 0; for parity tests they get N(0, std)."""
+    rng = np.random.default_rng(7000 + seed)
+    D = hidden
+    sd = {}
+
+    def lin(name, n_out, n_in, wstd=None, bstd=std):
+        sd[name + ".weight"] = _normal(rng, (n_out, n_in), wstd if wstd is not None else (2.0 / (n_in + n_out)) ** 0.5)
+        sd[name + ".bias"] = _normal(rng, (n_out,), bstd)
+
+    lin("context_embedder.mlp.0", D, 2 * 128 + context_size, std * 2)
+    lin("t_embedder.mlp.0", D, 256, std * 3)
+    lin("t_embedder.mlp.2", D, D, std * 3)
+    lin("y_embedder.class_embedding.0", D, class_size, std * 3)
+    lin("y_embedder.class_embedding.2", D, D, std * 3)
+    for l in range(depth):
+        b = f"blocks.{l}."
+        sd[b + "attn.in_proj_weight"] = _normal(rng, (3 * D, D), (2.0 / (4 * D)) ** 0.5)
+        sd[b + "attn.in_proj_bias"] = _normal(rng, (3 * D,), std)
+        lin(b + "attn.out_proj", D, D)
+        lin(b + "mlp.fc1", 4 * D, D)
+        lin(b + "mlp.fc2", D, 4 * D)
+        lin(b + "adaLN_modulation.1", 6 * D, D, std * 2)
+    lin("final_layer.adaLN_modulation.1", 2 * D, D, std * 2)
+    lin("final_layer.linear", 4, D, std * 4)
+    return sd
+
+
+def synthetic_dit_inputs(T: int = 128, context_size: int = 272, class_size: int = 300, seed: int = 0):
+    """One chunk's DiT inputs with CFG batch 2: z (2,2,T) U(-1,1) duplicated halves,
+    c (2,272,T), y (2,C) multi-hot (cond / null)."""
+    rng = np.random.default_rng(9000 + seed)
+    z1 = rng.uniform(-1, 1, (1, 2, T)).astype(np.float32)
+    c1 = rng.standard_normal((1, context_size, T)).astype(np.float32) * 0.5
+    y = np.zeros((2, class_size), np.float32)
+    y[0, rng.integers(0, class_size, 4)] = 1.0
+    y[1, class_size - 1] = 1.0
+    z = np.concatenate([z1, z1], 0)
+    c = np.concatenate([c1, c1], 0)
+    return torch.from_numpy(z), torch.from_numpy(c), torch.from_numpy(y)

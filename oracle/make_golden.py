@@ -1,0 +1,134 @@
+"""TEST INFRASTRUCTURE ONLY -- generates tests/golden/*.npz|json by running the IMPORTED REFERENCE
+(this container only: needs /root/reference).  Run:  python -m oracle.make_golden
+
+Every fixture is an output of reference code (reference `model_generate`, `Mapperatorinator`,
+HF T5 as wired by the reference, osu_diffusion `DiT` / `create_diffusion`, reference `Tokenizer`)
+on weights regenerated from a numpy seed (mapperatorinator_amd/testing.py), so the GPU box can
+rebuild the same weights and compare the HIP path against what the reference produced here.
+The mel frontend inside these runs is oracle/mel.py (nnAudio is not installable: parity unpinned
+for that one stage, see oracle/mel.py).
+"""
+from __future__ import annotations
+
+import json
+import os
+
+import numpy as np
+import torch
+
+from mapperatorinator_amd.t5_engine import T5_PRESETS
+from mapperatorinator_amd.testing import (DIT_PRESETS, random_dit_state_dict, random_t5_state_dict,
+                                          synthetic_audio, synthetic_dit_inputs)
+
+from . import dit as odit
+from . import mel as omel
+from . import ref_harness as rh
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+T5_CASES = {
+    # name: (size, n_samples, src_len, tgt_len, weight seed, lm_head gain, audio seed, prompts)
+    "t5_tiny": ("tiny", 32000, 251, 48, 11, 6.0, 4, [[0, 0, 1], [1, 40, 700], [0, 1, 9]]),
+    "t5_small": ("small", 160000, 1251, 96, 3, 4.0, 1, [[0, 1], [1, 5]]),
+}
+
+
+def t5_case(name):
+    size, ns, src, tgt, wseed, gain, aseed, prompts = T5_CASES[name]
+    model, tok, _ = rh.build_reference_t5(size, src_seq_len=src, tgt_seq_len=tgt)
+    dims = T5_PRESETS[size]
+    sd = random_t5_state_dict(dims, tok.vocab_size_in, tok.vocab_size_out, seed=wseed, lm_head_gain=gain)
+    res = model.load_state_dict(sd, strict=False)
+    assert not res.unexpected_keys, res
+    audio = synthetic_audio(len(prompts), ns, seed=aseed)
+    prompt = torch.tensor(prompts)
+    mask = prompt.ne(0)
+    with torch.no_grad():
+        mel = model.spectrogram(audio)
+    enc = rh.reference_encode(model, audio)
+    ids, stats = rh.reference_generate(model, tok, audio, prompt, rh.default_generate_kwargs(tgt), mask)
+    # a second run with processors switched on: temperature + timeshift bias + lookahead EOS window
+    ids2, _ = rh.reference_generate(model, tok, audio, prompt,
+                                    rh.default_generate_kwargs(tgt, temperature=0.7, timeshift_bias=0.35,
+                                                               lookahead_time=3000), mask)
+    np.savez_compressed(
+        os.path.join(OUT, name + ".npz"),
+        vocab_in=tok.vocab_size_in, vocab_out=tok.vocab_size_out, n_samples=ns, src_len=src, tgt_len=tgt,
+        weight_seed=wseed, lm_head_gain=gain, audio_seed=aseed, prompt=prompt.numpy(),
+        mel_slice=mel[:, ::37, ::29].numpy(), mel_sum=mel.double().sum().item(),
+        enc_slice=enc[:, ::53, ::17].numpy(), enc_abs_mean=enc.abs().double().mean().item(),
+        ids=ids.numpy(), ids_processors=ids2.numpy(),
+    )
+    print(name, "ids", ids.shape, "distinct", len(set(ids.flatten().tolist())), "tok/s(ref,cpu)", stats["tokens_per_second"])
+
+
+def tokenizer_case():
+    _, tok, _ = rh.build_reference_t5("small", src_seq_len=1251, tgt_seq_len=64)
+    with open(os.path.join(OUT, "tokenizer_benchmark_vocab.json"), "w") as f:
+        json.dump(tok.state_dict(), f)
+    # HF bucket function as the reference's backbone uses it
+    from transformers.models.t5.modeling_t5 import T5Attention
+    rel = torch.arange(-1300, 1301)
+    np.savez_compressed(os.path.join(OUT, "t5_buckets.npz"), rel=rel.numpy(),
+                        bidirectional=T5Attention._relative_position_bucket(rel, True, 32, 128).numpy(),
+                        unidirectional=T5Attention._relative_position_bucket(rel, False, 32, 128).numpy())
+
+
+def dit_case(name, preset, T, wseed, iseed, cfg_scale):
+    depth, hidden, heads = DIT_PRESETS[preset]
+    sd = random_dit_state_dict(depth, hidden, seed=wseed)
+    rh.ref_shims.install()
+    from osu_diffusion.utils.models import DiT
+    ref = DiT(context_size=272, hidden_size=hidden, depth=depth, num_heads=heads, class_size=300).eval()
+    ref.load_state_dict(sd, strict=True)
+    z, c, y = synthetic_dit_inputs(T, seed=iseed)
+    mask = odit.band_mask(T, 128)
+    diff = rh.reference_diffusion()
+    eps = {}
+    for tv in (99, 50, 0):
+        with torch.no_grad():
+            eps[tv] = ref.forward_with_cfg(z, torch.full((2,), tv, dtype=torch.long), c, y, cfg_scale, attn_mask=mask)
+    noise = torch.from_numpy(np.random.default_rng(500 + iseed).standard_normal((100, *z.shape)).astype(np.float32))
+    # one reference p_sample from z at loop index 57, and the full 100-step loop
+    from osu_diffusion.utils.diffusion import gaussian_diffusion as gd
+    orig = gd.th.randn_like
+    gd.th.randn_like = lambda v: noise[0]
+    try:
+        with torch.no_grad():
+            one = diff.p_sample(ref.forward_with_cfg, z, torch.full((2,), 57, dtype=torch.long), clip_denoised=True,
+                                model_kwargs=dict(c=c, y=y, cfg_scale=cfg_scale, attn_mask=mask, key_padding_mask=None))
+    finally:
+        gd.th.randn_like = orig
+    full = rh.reference_ddpm(ref, diff, z, c, y, cfg_scale, mask, list(noise))
+    np.savez_compressed(
+        os.path.join(OUT, name + ".npz"), preset=preset, T=T, weight_seed=wseed, input_seed=iseed, cfg_scale=cfg_scale,
+        eps_t99=eps[99].numpy(), eps_t50=eps[50].numpy(), eps_t0=eps[0].numpy(),
+        p_sample_i57=one["sample"].numpy(), p_sample_i57_x0=one["pred_xstart"].numpy(), sample_100=full.numpy(),
+        timestep_map=np.array(diff.timestep_map), betas=diff.betas,
+        posterior_log_variance_clipped=diff.posterior_log_variance_clipped,
+        posterior_mean_coef1=diff.posterior_mean_coef1, posterior_mean_coef2=diff.posterior_mean_coef2,
+        sqrt_recip_alphas_cumprod=diff.sqrt_recip_alphas_cumprod,
+        sqrt_recipm1_alphas_cumprod=diff.sqrt_recipm1_alphas_cumprod,
+    )
+    print(name, "eps scale", eps[50].abs().max().item(), "sample range", full.min().item(), full.max().item())
+
+
+def mel_case():
+    a = synthetic_audio(2, 16000, seed=9)
+    m = omel.mel_spectrogram(a)
+    np.savez_compressed(os.path.join(OUT, "mel_oracle.npz"), audio_seed=9, n_samples=16000, mel=m.numpy())
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    tokenizer_case()
+    mel_case()
+    for name in T5_CASES:
+        t5_case(name)
+    dit_case("dit_xs", "DiT-XS", 96, 21, 5, 1.5)
+    dit_case("dit_s", "DiT-S", 160, 1, 2, 2.0)
+
+
+if __name__ == "__main__":
+    main()

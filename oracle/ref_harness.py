@@ -67,11 +67,18 @@ def _train_config(size: str, src_seq_len: int, tgt_seq_len: int, n_mels: int):
     return args
 
 
+TINY_OVERWRITE = {"d_model": 128, "d_ff": 256, "num_heads": 2, "num_layers": 2, "num_decoder_layers": 2}
+
+
 def build_reference_t5(size="small", src_seq_len=1251, tgt_seq_len=512, n_mels=388,
-                       dtype=torch.float32, seed=0, lm_head_gain=1.0):
+                       dtype=torch.float32, seed=0, lm_head_gain=1.0, overwrite=None):
     """reference `_get_model` (osuT5/osuT5/utils/model_utils.py:102-114) with the reference
     initialisers (HF `_init_weights`), seeded."""
+    if size == "tiny":  # test-only size: t5-small backbone config with the dims overwritten
+        size, overwrite = "small", dict(TINY_OVERWRITE, **(overwrite or {}))
     args = _train_config(size, src_seq_len, tgt_seq_len, n_mels)
+    if overwrite:
+        args.model.overwrite = dict(args.model.overwrite, **overwrite)
     from osuT5.osuT5.tokenizer import Tokenizer
     from osuT5.osuT5.utils.model_utils import _get_model
     tok = Tokenizer(args)

@@ -1,0 +1,231 @@
+"""TEST INFRASTRUCTURE ONLY -- CPU restatement (plain torch-CPU fp32 tensor ops) of the osuT5 hot path.
+
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s cpu_baseline leg may import this module;
+it is the checker, never the product.  It follows, function by function:
+
+  rms_norm            HF T5LayerNorm (transformers 4.57.3 models/t5/modeling_t5.py, "T5LayerNorm");
+                      restated in the reference at osuT5/osuT5/model/custom_transformers/t5.py:50-62
+  bucket / bias       custom_transformers/t5.py:88-141 (`_relative_position_bucket`), :143-168 (`compute_bias`)
+  attention           custom_transformers/t5.py:170-250 (no 1/sqrt(d) scaling, additive bias, fp32 softmax)
+  gated FFN           HF T5DenseGatedActDense with gelu_new; custom_transformers/t5.py:50-62 region
+  encoder / decoder   custom_transformers/t5.py:305-355 (block), :358-469 (stack); bias shared from layer 0
+  wrapper             osuT5/osuT5/model/modeling_mapperatorinator.py:174-207 (mel -> encoder_embedder,
+                      decoder_embedder, lm_head without d^-0.5 rescale since tie_word_embeddings=False)
+  greedy loop         HF GenerationMixin._sample as driven by osuT5/osuT5/inference/server.py:83-156
+                      (SURVEY.md Appendix A), StaticCache semantics of inference/cache_utils.py:23-35
+  processors          osuT5/osuT5/inference/logit_processors.py:36-44 (TimeshiftBias), :136-183 (MonotonicTimeShift),
+                      :111-114 (LookbackBias, types_first=False), HF TemperatureLogitsWarper
+
+PINNING (tests/test_oracle_pinned.py, runs where /root/reference exists): hidden states, logits and
+greedy ids agree with the imported reference (`Mapperatorinator` + HF T5 via the reference's own
+`model_generate`) on seeded weights; the resulting golden vectors are committed under tests/golden/.
+
+`rounding`: None = pure fp32; "bf16" = the storage contract of mapperatorinator_amd/t5_engine.py
+(weights and GEMM operands rounded to bf16, everything else fp32).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import mel as omel
+
+
+def _bf16(x: torch.Tensor) -> torch.Tensor:
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+class Rounding:
+    def __init__(self, mode=None):
+        assert mode in (None, "bf16")
+        self.mode = mode
+
+    def __call__(self, x):  # activation that becomes a GEMM operand
+        return _bf16(x) if self.mode == "bf16" else x
+
+    w = __call__  # parameters
+
+
+def gelu_new(x):
+    return 0.5 * x * (1.0 + torch.tanh(math.sqrt(2.0 / math.pi) * (x + 0.044715 * torch.pow(x, 3.0))))
+
+
+def rms_norm(x, w, eps):
+    var = x.pow(2).mean(-1, keepdim=True)
+    return w * (x * torch.rsqrt(var + eps))
+
+
+def bucket(rel, bidirectional, num_buckets=32, max_distance=128):
+    ret = torch.zeros_like(rel)
+    n = num_buckets
+    if bidirectional:
+        n //= 2
+        ret = ret + (rel > 0).to(torch.long) * n
+        rp = torch.abs(rel)
+    else:
+        rp = -torch.min(rel, torch.zeros_like(rel))
+    max_exact = n // 2
+    is_small = rp < max_exact
+    big = max_exact + (torch.log(rp.float() / max_exact) / math.log(max_distance / max_exact)
+                       * (n - max_exact)).to(torch.long)
+    big = torch.min(big, torch.full_like(big, n - 1))
+    return ret + torch.where(is_small, rp, big)
+
+
+class T5Oracle:
+    """Stateless math over a reference-named state_dict (see PackedT5 for the same key names)."""
+
+    def __init__(self, sd: dict, d_model, d_ff, n_heads, n_enc, n_dec, eps=1e-6, n_buckets=32, max_distance=128,
+                 rounding=None):
+        self.r = Rounding(rounding)
+        self.sd = {k: self.r.w(v.detach().to(torch.float32)) for k, v in sd.items()
+                   if v.dtype.is_floating_point}
+        self.d, self.dff, self.H, self.ne, self.nd, self.eps = d_model, d_ff, n_heads, n_enc, n_dec, eps
+        self.nb, self.md = n_buckets, max_distance
+
+    # ---- pieces ----------------------------------------------------------------------------
+    def _heads(self, x):  # (B, T, H*64) -> (B, H, T, 64)
+        B, T, _ = x.shape
+        return x.view(B, T, self.H, 64).transpose(1, 2)
+
+    def _attn(self, q, k, v, bias, mask=None):
+        r = self.r
+        scores = torch.matmul(r(q), r(k).transpose(-1, -2))
+        if bias is not None:
+            scores = scores + bias
+        if mask is not None:
+            # HF adds finfo.min (not -inf): a fully masked (left-pad) query row stays finite
+            scores = scores.masked_fill(~mask, torch.finfo(torch.float32).min)
+        p = torch.softmax(scores, dim=-1)
+        out = torch.matmul(r(p), r(v))
+        B, H, T, _ = out.shape
+        return out.transpose(1, 2).reshape(B, T, H * 64)
+
+    def _ffn(self, x, pre):
+        r, sd = self.r, self.sd
+        g = x @ sd[pre + "wi_0.weight"].t()
+        u = x @ sd[pre + "wi_1.weight"].t()
+        return r(gelu_new(g) * u) @ sd[pre + "wo.weight"].t()
+
+    def enc_bias(self, L):
+        pos = torch.arange(L)
+        rel = pos[None, :] - pos[:, None]
+        tab = self.sd["transformer.encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight"]
+        return tab[bucket(rel, True, self.nb, self.md)].permute(2, 0, 1)[None]  # (1,H,L,L)
+
+    def dec_bias(self, q_pos, klen):
+        rel = torch.arange(klen)[None, :] - torch.as_tensor(q_pos).reshape(-1, 1)
+        tab = self.sd["transformer.decoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight"]
+        return tab[bucket(rel, False, self.nb, self.md)].permute(2, 0, 1)[None]  # (1,H,q,klen)
+
+    # ---- encoder ---------------------------------------------------------------------------
+    def embed_mel(self, mel):
+        r, sd = self.r, self.sd
+        return r(mel) @ sd["encoder_embedder.weight"].t() + sd["encoder_embedder.bias"]
+
+    def encoder(self, h):
+        r, sd = self.r, self.sd
+        B, L, _ = h.shape
+        bias = self.enc_bias(L)
+        for l in range(self.ne):
+            b = f"transformer.encoder.block.{l}."
+            a = b + "layer.0.SelfAttention."
+            n = r(rms_norm(h, sd[b + "layer.0.layer_norm.weight"], self.eps))
+            q = self._heads(r(n @ sd[a + "q.weight"].t()))
+            k = self._heads(r(n @ sd[a + "k.weight"].t()))
+            v = self._heads(r(n @ sd[a + "v.weight"].t()))
+            h = h + r(self._attn(q, k, v, bias)) @ sd[a + "o.weight"].t()
+            n = r(rms_norm(h, sd[b + "layer.1.layer_norm.weight"], self.eps))
+            h = h + self._ffn(n, b + "layer.1.DenseReluDense.")
+        return rms_norm(h, sd["transformer.encoder.final_layer_norm.weight"], self.eps)
+
+    def encode_audio(self, audio, n_mels=388):
+        mel = omel.mel_spectrogram(audio, n_mels=n_mels)
+        return self.encoder(self.embed_mel(mel))
+
+    # ---- decoder ---------------------------------------------------------------------------
+    def cross_kv(self, enc):
+        r, sd = self.r, self.sd
+        e = r(enc)
+        out = []
+        for l in range(self.nd):
+            x = f"transformer.decoder.block.{l}.layer.1.EncDecAttention."
+            out.append((self._heads(r(e @ sd[x + "k.weight"].t())), self._heads(r(e @ sd[x + "v.weight"].t()))))
+        return out
+
+    def decoder_step(self, tok, pos, cache, ckv, key_mask):
+        """tok (B,) ids fed at position `pos`; cache: list of (K,V) (B,H,Tmax,64) updated in place;
+        key_mask (B, Tmax) bool (True = attend) for positions <= pos.  Returns fp32 logits (B, V)."""
+        r, sd = self.r, self.sd
+        h = sd["decoder_embedder.weight"][tok][:, None, :]
+        bias = self.dec_bias([pos], pos + 1)
+        m = key_mask[:, None, None, :pos + 1]
+        for l in range(self.nd):
+            b = f"transformer.decoder.block.{l}."
+            a = b + "layer.0.SelfAttention."
+            x = b + "layer.1.EncDecAttention."
+            n = r(rms_norm(h, sd[b + "layer.0.layer_norm.weight"], self.eps))
+            q = self._heads(r(n @ sd[a + "q.weight"].t()))
+            K, V = cache[l]
+            K[:, :, pos] = self._heads(r(n @ sd[a + "k.weight"].t()))[:, :, 0]
+            V[:, :, pos] = self._heads(r(n @ sd[a + "v.weight"].t()))[:, :, 0]
+            h = h + r(self._attn(q, K[:, :, :pos + 1], V[:, :, :pos + 1], bias, m)) @ sd[a + "o.weight"].t()
+            n = r(rms_norm(h, sd[b + "layer.1.layer_norm.weight"], self.eps))
+            q = self._heads(r(n @ sd[x + "q.weight"].t()))
+            h = h + r(self._attn(q, ckv[l][0], ckv[l][1], None)) @ sd[x + "o.weight"].t()
+            n = r(rms_norm(h, sd[b + "layer.2.layer_norm.weight"], self.eps))
+            h = h + self._ffn(n, b + "layer.2.DenseReluDense.")
+        n = r(rms_norm(h, sd["transformer.decoder.final_layer_norm.weight"], self.eps))
+        return (n @ sd["transformer.lm_head.weight"].t())[:, 0, :]
+
+    # ---- generation ------------------------------------------------------------------------
+    def generate(self, enc, prompt, prompt_mask, eos_ids, max_length, ts_start, ts_end, sos_ids, pad_id=0,
+                 temperature=1.0, timeshift_bias=0.0, lookback_mask_end=0, forced=None, return_logits=False):
+        """Greedy decode with HF `_sample` bookkeeping.  prompt (B,P) int64 left-padded, prompt_mask bool.
+        Returns ids (B, n_cols) [, processed scores per produced column (list of (B,V))]."""
+        B, P = prompt.shape
+        ckv = self.cross_kv(enc)
+        cache = [(torch.zeros(B, self.H, max_length, 64), torch.zeros(B, self.H, max_length, 64))
+                 for _ in range(self.nd)]
+        key_mask = torch.ones(B, max_length, dtype=torch.bool)
+        key_mask[:, :P] = prompt_mask.bool() if prompt_mask is not None else True
+        ids = prompt.clone()
+        unfinished = torch.ones(B, dtype=torch.bool)
+        eos = torch.as_tensor(sorted(set(eos_ids)), dtype=torch.long)
+        sos = torch.as_tensor(list(sos_ids), dtype=torch.long)
+        all_scores = []
+        for pos in range(0, max_length - 1):
+            feed = ids[:, pos] if forced is None or pos < P else forced[:, pos]
+            logits = self.decoder_step(feed, pos, cache, ckv, key_mask)
+            if pos + 1 < P:
+                continue
+            hist = ids if forced is None else torch.cat([prompt, forced[:, P:pos + 1]], 1)
+            scores = logits.clone().float()
+            # MonotonicTimeShiftLogitsProcessor
+            idx = torch.arange(hist.shape[1]).expand(B, -1)
+            is_ts = (hist >= ts_start) & (hist < ts_end)
+            is_sos = torch.isin(hist, sos)
+            last_ts = torch.where(is_ts, idx, -1).max(1).values
+            last_sos = torch.where(is_sos, idx, -1).max(1).values
+            val = torch.where(last_ts != -1, hist[torch.arange(B), last_ts.clamp(min=0)] - ts_start, 0)
+            apply = (last_ts != -1) & (last_ts > last_sos)
+            vocab = torch.arange(ts_start, ts_end)
+            bad = vocab[None, :] < (ts_start + val)[:, None]
+            sl = scores[:, ts_start:ts_end]
+            sl[apply[:, None] & bad] = float("-inf")
+            if timeshift_bias != 0:
+                scores[:, ts_start:ts_end] += timeshift_bias
+            scores = scores / temperature
+            if lookback_mask_end > ts_start:
+                scores[:, ts_start:lookback_mask_end] = float("-inf")
+            all_scores.append(scores)
+            nxt = scores.argmax(-1)
+            nxt = torch.where(unfinished, nxt, torch.full_like(nxt, pad_id))
+            ids = torch.cat([ids, nxt[:, None]], 1)
+            if forced is None:
+                done = torch.isin(nxt, eos) | (ids.shape[1] >= max_length)
+                unfinished = unfinished & ~done
+                if not unfinished.any():
+                    break
+        return (ids, all_scores) if return_logits else ids

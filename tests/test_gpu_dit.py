@@ -1,0 +1,145 @@
+"""-m gpu: osu_diffusion DiT + DDPM on the HIP path vs the CPU oracle and the reference golden vectors.
+Tolerances (fp32 everywhere): eps 2e-4 abs, one p_sample step 2e-4 abs; a full 100-step trajectory is a
+chaotic map of its rounding noise (the reference on two BLAS builds already differs by ~1e-2 on these
+random weights, see oracle pin log), so the end-to-end sample is held to 5e-2 abs and the per-step error
+is the real parity gate."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def setup(name):
+    from mapperatorinator_amd.dit import DiTHIP
+    from mapperatorinator_amd.testing import DIT_PRESETS, random_dit_state_dict, synthetic_dit_inputs
+    from oracle import dit as odit
+    g = np.load(f"{GOLDEN}/{name}.npz")
+    preset = str(g["preset"])
+    depth, hidden, heads = DIT_PRESETS[preset]
+    sd = random_dit_state_dict(depth, hidden, seed=int(g["weight_seed"]))
+    T = int(g["T"])
+    z, c, y = synthetic_dit_inputs(T, seed=int(g["input_seed"]))
+    dit = DiTHIP(sd, depth, hidden, heads, device="cuda")
+    orc = odit.DiTOracle(sd, depth, hidden, heads)
+    return g, dit, orc, z, c, y, odit.band_mask(T, 128), float(g["cfg_scale"])
+
+
+@pytest.mark.parametrize("name", ["dit_xs", "dit_s"])
+def test_eps_matches_reference_golden(name):
+    g, dit, orc, z, c, y, mask, cfg = setup(name)
+    for tv in (99, 50, 0):
+        t = torch.full((2,), tv, dtype=torch.long)
+        got = dit.forward_with_cfg(z.cuda(), t.cuda(), c.cuda(), y.cuda(), cfg, attn_mask=mask).cpu()
+        ref = torch.from_numpy(g[f"eps_t{tv}"])
+        err = (got - ref).abs().max().item()
+        print(name, "t", tv, "max abs err vs reference", err, "scale", ref.abs().max().item())
+        assert got.shape == ref.shape == (2, 4, z.shape[2])
+        assert err < 2e-4
+        assert torch.equal(got[0, :2], got[1, :2]), "CFG-combined eps must be duplicated over both halves"
+
+
+@pytest.mark.parametrize("name", ["dit_xs", "dit_s"])
+def test_single_p_sample_and_loop(name):
+    import ctypes as C
+    from mapperatorinator_amd import _lib
+    from mapperatorinator_amd.dit import InpaintSpec, create_diffusion
+    from oracle import dit as odit
+    g, dit, orc, z, c, y, mask, cfg = setup(name)
+    diff = create_diffusion([100, 0, 0, 0, 0, 0, 0, 0, 0, 0], noise_schedule="squaredcos_cap_v2", diffusion_steps=1000)
+    assert diff.timestep_map == list(g["timestep_map"])
+    assert np.array_equal(diff.betas, g["betas"]) and np.array_equal(diff.posterior_mean_coef2, g["posterior_mean_coef2"])
+    noise = torch.from_numpy(np.random.default_rng(500 + int(g["input_seed"])).standard_normal((100, *z.shape)).astype(np.float32))
+    # --- one step at loop index 57 from x = z with noise[0]: reference golden
+    lib = _lib.load()
+    N, _, T = z.shape
+    zt = z.cuda()
+    t = torch.full((2,), diff.timestep_map[57], dtype=torch.long)
+    mo = dit.forward_with_cfg(zt, t.cuda(), c.cuda(), y.cuda(), cfg, attn_mask=mask)
+    coefs = diff.coef_table().cuda()
+    xo, pr = torch.empty_like(zt), torch.empty_like(zt)
+    nz = noise[0].cuda().contiguous()
+    _lib.check(lib.mh_ddpm_step(mo.data_ptr(), zt.data_ptr(), nz.data_ptr(), coefs[57].contiguous().data_ptr(), None, None,
+                                None, 0, N, T, xo.data_ptr(), pr.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    e1 = (xo.cpu() - torch.from_numpy(g["p_sample_i57"])).abs().max().item()
+    e2 = (pr.cpu() - torch.from_numpy(g["p_sample_i57_x0"])).abs().max().item()
+    print(name, "one p_sample vs reference: sample", e1, "pred_xstart", e2)
+    assert e1 < 2e-4 and e2 < 2e-4
+    # --- full fused loop (hipGraph) vs reference golden and vs oracle with the same injected noise
+    out = diff.p_sample_loop(dit.forward_with_cfg, z.shape, zt, model_kwargs=dict(c=c.cuda(), y=y.cuda(), cfg_scale=cfg,
+                             attn_mask=mask, key_padding_mask=None), step_noise=noise).cpu()
+    ref = torch.from_numpy(g["sample_100"])
+    e = (out - ref).abs().max().item()
+    print(name, "100-step loop vs reference: max abs", e)
+    assert torch.isfinite(out).all() and e < 5e-2
+    # --- per-step gate along the ORACLE trajectory (no chaotic amplification): every 9th step
+    od = odit.DiffusionOracle()
+    x = z.clone()
+    worst = 0.0
+    for k, i in enumerate(reversed(range(100))):
+        tt = torch.full((2,), od.timestep_map[i], dtype=torch.long)
+        eps_o = orc.forward_with_cfg(x, tt, c, y, cfg, mask)
+        x_next = od.p_sample(eps_o, x, i, noise[k])
+        if k % 9 == 0:
+            mo = dit.forward_with_cfg(x.cuda(), tt.cuda(), c.cuda(), y.cuda(), cfg, attn_mask=mask)
+            xd = x.cuda().contiguous()
+            _lib.check(lib.mh_ddpm_step(mo.data_ptr(), xd.data_ptr(), noise[k].cuda().contiguous().data_ptr(),
+                                        coefs[i].contiguous().data_ptr(), None, None, None, 0, N, T, xo.data_ptr(), None,
+                                        torch.cuda.current_stream().cuda_stream))
+            torch.cuda.synchronize()
+            worst = max(worst, (xo.cpu() - x_next).abs().max().item())
+        x = x_next
+    print(name, "per-step max abs err along oracle trajectory", worst)
+    assert worst < 2e-4
+    # --- in-paint mask (denoised_fn of the pipeline without sliders): masked-out positions keep their reference
+    imask = torch.ones_like(z, dtype=torch.bool)
+    imask[:, :, :17] = False
+    spec = InpaintSpec(imask, z)
+    out2 = diff.p_sample_loop(dit.forward_with_cfg, z.shape, zt, denoised_fn=spec, model_kwargs=dict(
+        c=c.cuda(), y=y.cuda(), cfg_scale=cfg, attn_mask=mask), step_noise=noise).cpu()
+    want2 = od.sample_loop(orc, z, c, y, cfg, mask, noise, denoised_fn=spec)
+    assert (out2 - want2).abs().max().item() < 5e-2
+    # generic python denoised_fn path (x0 round trip) must agree with the fused in-paint path
+    out3 = diff.p_sample_loop(dit.forward_with_cfg, z.shape, zt, denoised_fn=lambda v: spec(v), model_kwargs=dict(
+        c=c.cuda(), y=y.cuda(), cfg_scale=cfg, attn_mask=mask), step_noise=noise).cpu()
+    assert (out3 - out2).abs().max().item() < 1e-5
+
+
+def test_dit_rng_consumption_matches_reference_pattern():
+    """Without injected noise the loop draws randn_like(x) once per step from the global generator."""
+    from mapperatorinator_amd.dit import create_diffusion
+    g, dit, orc, z, c, y, mask, cfg = setup("dit_xs")
+    diff = create_diffusion([10, 0, 0, 0, 0, 0, 0, 0, 0, 0], noise_schedule="squaredcos_cap_v2", diffusion_steps=1000)
+    kw = dict(c=c.cuda(), y=y.cuda(), cfg_scale=cfg, attn_mask=mask)
+    torch.manual_seed(123)
+    a = diff.p_sample_loop(dit.forward_with_cfg, z.shape, z.cuda(), model_kwargs=kw)
+    torch.manual_seed(123)
+    zt = z.cuda()
+    noise = torch.stack([torch.randn_like(zt) for _ in range(10)])
+    b = diff.p_sample_loop(dit.forward_with_cfg, z.shape, zt, model_kwargs=kw, step_noise=noise)
+    assert torch.equal(a, b)
+
+
+def test_dit_b_full_size_properties():
+    """DiT-B at T=1024 (max window): finite, CFG halves identical, band locality (perturbing a point
+    further than band*depth away cannot change a far query... checked at depth-1 granularity)."""
+    from mapperatorinator_amd.dit import DiTHIP
+    from mapperatorinator_amd.testing import DIT_PRESETS, random_dit_state_dict, synthetic_dit_inputs
+    from oracle import dit as odit
+    depth, hidden, heads = DIT_PRESETS["DiT-B"]
+    sd = random_dit_state_dict(depth, hidden, seed=4)
+    dit = DiTHIP(sd, depth, hidden, heads, device="cuda")
+    T = 1024
+    z, c, y = synthetic_dit_inputs(T, seed=6)
+    mask = odit.band_mask(T, 32)   # narrow band so that 12 blocks reach < 12*32 = 384 positions
+    t = torch.full((2,), 40, dtype=torch.long)
+    a = dit.forward_with_cfg(z.cuda(), t.cuda(), c.cuda(), y.cuda(), 3.0, attn_mask=mask).cpu()
+    assert torch.isfinite(a).all() and torch.equal(a[0, :2], a[1, :2])
+    z2 = z.clone()
+    z2[:, :, 1000] += 0.5
+    b = dit.forward_with_cfg(z2.cuda(), t.cuda(), c.cuda(), y.cuda(), 3.0, attn_mask=mask).cpu()
+    assert torch.equal(a[:, :, :600], b[:, :, :600]), "band mask leaked information"
+    assert not torch.equal(a[:, :, 990:], b[:, :, 990:])

@@ -1,0 +1,258 @@
+"""-m gpu: kernel-level parity of libmapperhip (through the C ABI) against plain torch fp32 references
+of the same op, and K1 (mel) against the CPU oracle."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _lib():
+    from mapperatorinator_amd import _lib
+    return _lib, _lib.load()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _bf16r(x):
+    return x.to(torch.bfloat16).float()
+
+
+def run_gemm(A, W, epi, dtype, bias=None, C0=None, gate=None, rows_per_batch=0, kv=None, n_split=0, Lpad=0, out_cols=None):
+    L, lib = _lib()
+    dev = "cuda"
+    td = torch.bfloat16 if dtype == L.MH_BF16 else torch.float32
+    M, K = A.shape
+    N = W.shape[0]
+    Ad, Wd = A.to(dev, td).contiguous(), W.to(dev, td).contiguous()
+    g = L.MhGemm()
+    g.A, g.lda, g.W, g.ldw = Ad.data_ptr(), K, Wd.data_ptr(), K
+    g.M, g.N, g.K, g.dtype, g.epilogue = M, N, K, dtype, epi
+    keep = [Ad, Wd]
+    if bias is not None:
+        b = bias.to(dev, torch.float32).contiguous(); keep.append(b); g.bias = b.data_ptr()
+    if epi in (L.EPI_STORE, L.EPI_BIAS_GELU):
+        out = torch.zeros((M, N), dtype=td, device=dev); g.C, g.ldc = out.data_ptr(), N
+    elif epi == L.EPI_STORE_F32:
+        out = torch.zeros((M, N), dtype=torch.float32, device=dev); g.C, g.ldc = out.data_ptr(), N
+    elif epi in (L.EPI_RESID, L.EPI_GATE_RESID):
+        out = C0.to(dev, torch.float32).contiguous().clone(); g.C, g.ldc = out.data_ptr(), N
+        if gate is not None:
+            gt = gate.to(dev, torch.float32).contiguous(); keep.append(gt)
+            g.gate, g.gate_ld, g.rows_per_batch = gt.data_ptr(), gt.shape[1], rows_per_batch
+    elif epi == L.EPI_GEGLU:
+        out = torch.zeros((M, N // 2), dtype=td, device=dev); g.C, g.ldc = out.data_ptr(), N // 2
+    elif epi == L.EPI_KV_SCATTER:
+        B_, H_, L_ = kv
+        out = torch.zeros((N // (H_ * 64), B_, H_, L_, 64), dtype=td, device=dev)
+        g.C, g.kv_B, g.kv_H, g.kv_L = out.data_ptr(), B_, H_, L_
+    elif epi == L.EPI_QKV_VT:
+        B_, H_, L_ = kv
+        out = torch.zeros((M, n_split), dtype=td, device=dev)
+        vt = torch.zeros((B_, H_, 64, Lpad), dtype=td, device=dev); keep.append(vt)
+        g.C, g.ldc, g.C2, g.n_split, g.kv_B, g.kv_H, g.kv_L, g.kv_Lpad = out.data_ptr(), n_split, vt.data_ptr(), n_split, B_, H_, L_, Lpad
+    L.check(lib.mh_gemm(C.byref(g), _stream()), "mh_gemm")
+    torch.cuda.synchronize()
+    if epi == L.EPI_QKV_VT:
+        return out.float().cpu(), vt.float().cpu()
+    return out.float().cpu()
+
+
+def gelu_tanh(x):
+    return torch.nn.functional.gelu(x, approximate="tanh")
+
+
+@pytest.mark.parametrize("dtype_name", ["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(300, 200, 96), (1251, 768, 416), (33, 1849, 128), (2600, 1100, 64)])
+def test_gemm_store_and_transpose_detecting(dtype_name, shape):
+    L, _ = _lib()
+    dtype = L.MH_F32 if dtype_name == "f32" else L.MH_BF16
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M * 7 + N)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) * torch.linspace(0.5, 2.0, N)[:, None]   # asymmetric
+    bias = torch.randn(N, generator=g)
+    if dtype == L.MH_BF16:
+        A, W = _bf16r(A), _bf16r(W)
+    ref = A.double() @ W.double().t() + bias.double()
+    out = run_gemm(A, W, L.EPI_STORE_F32, dtype, bias=bias)
+    tol = 2e-5 * math.sqrt(K) * 4 + 1e-4
+    err = (out.double() - ref).abs().max().item()
+    assert err < tol * max(1.0, ref.abs().max().item() / 10), (err, tol)
+    out_t = run_gemm(A, W, L.EPI_STORE, dtype, bias=bias)
+    rel = 8e-3 if dtype == L.MH_BF16 else 1e-5
+    assert ((out_t.double() - ref).abs() <= rel * ref.abs() + 1e-3).all()
+
+
+@pytest.mark.parametrize("dtype_name", ["f32", "bf16"])
+def test_gemm_epilogues(dtype_name):
+    L, _ = _lib()
+    dtype = L.MH_F32 if dtype_name == "f32" else L.MH_BF16
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 260, 192, 160
+    A, W = torch.randn(M, K, generator=g) * 0.5, torch.randn(N, K, generator=g) * 0.2
+    if dtype == L.MH_BF16:
+        A, W = _bf16r(A), _bf16r(W)
+    bias = torch.randn(N, generator=g) * 0.1
+    acc = (A.double() @ W.double().t()).float()
+    rel = 1e-2 if dtype == L.MH_BF16 else 2e-5
+    # RESID
+    C0 = torch.randn(M, N, generator=g)
+    out = run_gemm(A, W, L.EPI_RESID, dtype, C0=C0)
+    assert torch.allclose(out, C0 + acc, atol=1e-3, rtol=1e-4)
+    # BIAS_GELU
+    out = run_gemm(A, W, L.EPI_BIAS_GELU, dtype, bias=bias)
+    assert torch.allclose(out, gelu_tanh(acc + bias), atol=2e-3, rtol=rel)
+    # GATE_RESID (rows_per_batch = 130 -> 2 batches)
+    gate = torch.randn(2, 3 * N, generator=g)
+    # gate passed as the [:, N:] view of a [2, 3N] modulation matrix: ld = 2N after .contiguous(), first N used
+    gexp = gate[:, N:2 * N].repeat_interleave(130, dim=0)
+    out2 = run_gemm(A, W, L.EPI_GATE_RESID, dtype, bias=bias, C0=C0, gate=gate[:, N:], rows_per_batch=130)
+    assert torch.allclose(out2, C0 + gexp * (acc + bias), atol=2e-3, rtol=1e-4)
+    # GEGLU: interleave wi0 / wi1 in 16-row blocks
+    dff = N // 2
+    wi0, wi1 = W[:dff], W[dff:]
+    Wi = torch.stack([wi0.reshape(dff // 16, 16, K), wi1.reshape(dff // 16, 16, K)], 1).reshape(2 * dff, K)
+    out = run_gemm(A, Wi, L.EPI_GEGLU, dtype)
+    exp = gelu_tanh((A.double() @ wi0.double().t()).float()) * (A.double() @ wi1.double().t()).float()
+    assert torch.allclose(out, exp, atol=3e-3, rtol=rel), (out - exp).abs().max()
+
+
+@pytest.mark.parametrize("dtype_name", ["f32", "bf16"])
+def test_gemm_kv_scatter_and_qkv_vt(dtype_name):
+    L, _ = _lib()
+    dtype = L.MH_F32 if dtype_name == "f32" else L.MH_BF16
+    g = torch.Generator().manual_seed(6)
+    B_, H_, L_, K = 2, 3, 70, 64
+    M = B_ * L_
+    A = torch.randn(M, K, generator=g)
+    nl = 2
+    W = torch.randn(nl * 2 * H_ * 64, K, generator=g) * 0.2
+    if dtype == L.MH_BF16:
+        A, W = _bf16r(A), _bf16r(W)
+    out = run_gemm(A, W, L.EPI_KV_SCATTER, dtype, kv=(B_, H_, L_))
+    full = (A.double() @ W.double().t()).float()               # [M, nl*2*H*64]
+    exp = full.view(B_, L_, nl * 2, H_, 64).permute(2, 0, 3, 1, 4)   # [(l,kv), B, H, L, 64]
+    tol = 2e-2 if dtype == L.MH_BF16 else 1e-4
+    assert torch.allclose(out, exp, atol=tol, rtol=1e-2 if dtype == L.MH_BF16 else 1e-5)
+    # QKV_VT
+    Wq = torch.randn(3 * H_ * 64, K, generator=g) * 0.2
+    if dtype == L.MH_BF16:
+        Wq = _bf16r(Wq)
+    qk, vt = run_gemm(A, Wq, L.EPI_QKV_VT, dtype, kv=(B_, H_, L_), n_split=2 * H_ * 64, Lpad=128)
+    full = (A.double() @ Wq.double().t()).float()
+    assert torch.allclose(qk, full[:, :2 * H_ * 64], atol=tol, rtol=1e-2)
+    v = full[:, 2 * H_ * 64:].view(B_, L_, H_, 64).permute(0, 2, 3, 1)   # [B,H,64,L]
+    assert torch.allclose(vt[..., :L_], v, atol=tol, rtol=1e-2)
+    assert (vt[..., L_:] == 0).all()
+
+
+@pytest.mark.parametrize("dtype_name", ["f32", "bf16"])
+def test_rmsnorm(dtype_name):
+    L, lib = _lib()
+    dt = L.MH_F32 if dtype_name == "f32" else L.MH_BF16
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(37, 768, generator=g) * 3
+    w = 1 + 0.1 * torch.randn(768, generator=g)
+    xd, wd = x.cuda(), w.cuda()
+    y = torch.empty((37, 768), dtype=torch.bfloat16 if dt == L.MH_BF16 else torch.float32, device="cuda")
+    L.check(lib.mh_rmsnorm(xd.data_ptr(), 768, wd.data_ptr(), y.data_ptr(), 768, 37, 768, 1e-6, dt, _stream()))
+    ref = w * (x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-6))
+    tol = 2e-2 if dt == L.MH_BF16 else 2e-6
+    assert torch.allclose(y.float().cpu(), ref, atol=tol, rtol=8e-3 if dt == L.MH_BF16 else 1e-5)
+
+
+def ref_attention(q, k, v, bias=None, scale=1.0, band=0):
+    """q,k,v [B,H,L,64] fp64 reference of mh_attention."""
+    s = torch.matmul(q.double(), k.double().transpose(-1, -2)) * scale
+    Ln = q.shape[2]
+    if bias is not None:
+        rel = torch.arange(Ln)[None, :] - torch.arange(Ln)[:, None]
+        s = s + bias.double()[:, rel + Ln - 1][None]
+    if band > 0:
+        rel = torch.arange(Ln)[None, :] - torch.arange(Ln)[:, None]
+        ok = (rel >= -(band - 1)) & (rel <= band)
+        s = s.masked_fill(~ok, float("-inf"))
+    return torch.matmul(torch.softmax(s, -1), v.double()).float()
+
+
+@pytest.mark.parametrize("dtype_name", ["f32", "bf16"])
+@pytest.mark.parametrize("case", [dict(B=2, H=3, L=251, bias=True, scale=1.0, band=0),
+                                  dict(B=1, H=2, L=1251, bias=True, scale=1.0, band=0),
+                                  dict(B=2, H=2, L=400, bias=False, scale=0.125, band=128),
+                                  dict(B=2, H=1, L=96, bias=False, scale=0.125, band=128)])
+def test_attention(dtype_name, case):
+    L, lib = _lib()
+    dt = L.MH_F32 if dtype_name == "f32" else L.MH_BF16
+    td = torch.bfloat16 if dt == L.MH_BF16 else torch.float32
+    B_, H_, Ln = case["B"], case["H"], case["L"]
+    g = torch.Generator().manual_seed(Ln)
+    q = torch.randn(B_, H_, Ln, 64, generator=g) * 0.6
+    k = torch.randn(B_, H_, Ln, 64, generator=g) * 0.6
+    v = torch.randn(B_, H_, Ln, 64, generator=g)
+    if dt == L.MH_BF16:
+        q, k, v = _bf16r(q), _bf16r(k), _bf16r(v)
+    bias = (torch.randn(H_, 2 * Ln - 1, generator=g) * 0.5) if case["bias"] else None
+    inner = H_ * 64
+    qk = torch.cat([q.permute(0, 2, 1, 3).reshape(B_ * Ln, inner), k.permute(0, 2, 1, 3).reshape(B_ * Ln, inner)], 1)
+    Lpad = (Ln + 63) // 64 * 64
+    vt = torch.zeros(B_, H_, 64, Lpad)
+    vt[..., :Ln] = v.transpose(-1, -2)
+    qk_d, vt_d = qk.to("cuda", td).contiguous(), vt.to("cuda", td).contiguous()
+    out = torch.zeros(B_ * Ln, inner, dtype=td, device="cuda")
+    bias_d = bias.cuda().contiguous() if bias is not None else None
+    L.check(lib.mh_attention(qk_d.data_ptr(), 2 * inner, inner, vt_d.data_ptr(), Lpad, L.ptr(bias_d), out.data_ptr(),
+                             inner, B_, Ln, H_, case["scale"], case["band"], dt, _stream()), "mh_attention")
+    torch.cuda.synchronize()
+    ref = ref_attention(q, k, v, bias, case["scale"], case["band"]).permute(0, 2, 1, 3).reshape(B_ * Ln, inner)
+    err = (out.float().cpu() - ref).abs().max().item()
+    assert err < (3e-2 if dt == L.MH_BF16 else 2e-5), err
+
+
+@pytest.mark.parametrize("B,ns", [(1, 16000), (3, 160000), (2, 32000 + 77)])
+def test_mel_vs_oracle(B, ns):
+    from mapperatorinator_amd.mel import MelSpectrogram
+    from mapperatorinator_amd.testing import synthetic_audio
+    from oracle import mel as omel
+    a = synthetic_audio(B, ns, seed=9)
+    m = MelSpectrogram().cuda()
+    got = m(a.cuda()).cpu()
+    want = omel.mel_spectrogram(a)
+    assert got.shape == want.shape == (B, ns // 128 + 1, 388)
+    f64 = torch.from_numpy(omel.mel_spectrogram_f64(a.numpy())).float()
+    scale = want.abs().max().item()
+    e_or = (got - want).abs().max().item() / scale
+    e_f64 = (got - f64).abs().max().item() / scale
+    o_f64 = (want - f64).abs().max().item() / scale
+    print(f"mel rel-to-max err: hip-vs-oracle {e_or:.2e}, hip-vs-f64 {e_f64:.2e}, oracle-vs-f64 {o_f64:.2e}")
+    # tolerance: 1e-4 of the spectrum peak (fp32 DFT-by-conv vs fp32 FFT differ by accumulated rounding)
+    assert e_or < 1e-4 and e_f64 < 1e-4
+    # elementwise relative where the value is not tiny
+    big = want > 1e-3 * scale
+    assert ((got - want).abs()[big] / want[big]).max().item() < 2e-3
+    # zero filterbank rows stay exactly zero; padded K columns are zero
+    zero_rows = (want.abs().sum((0, 1)) == 0)
+    assert (got[..., zero_rows] == 0).all()
+    pad = m.forward_padded(a.cuda(), 416, torch.bfloat16)
+    assert pad.shape[-1] == 416 and (pad[..., 388:] == 0).all()
+    assert torch.allclose(pad[..., :388].float().cpu(), want, rtol=1e-2, atol=1e-4 * scale)
+
+
+def test_mel_silence_and_tone():
+    from mapperatorinator_amd.mel import MelSpectrogram
+    m = MelSpectrogram().cuda()
+    z = torch.zeros(1, 16000, device="cuda")
+    assert (m(z) == 0).all()
+    n = torch.arange(16000, dtype=torch.float64)
+    k0 = 100
+    tone = torch.cos(2 * math.pi * k0 * n / 1024).float()[None]
+    mel = m(tone.cuda()).cpu()[0, 40]          # a frame fully inside the signal
+    # total energy = sum_k P[k] * colsum(W) -> compare against the f64 formulation
+    from oracle import mel as omel
+    ref = torch.from_numpy(omel.mel_spectrogram_f64(tone.numpy()))[0, 40].float()
+    assert torch.allclose(mel, ref, rtol=1e-3, atol=1e-3 * ref.max().item())
