@@ -254,7 +254,6 @@ int gemm_prepare() {
 }
 
 int gemm(const MhGemm& g, hipStream_t s) {
-  { int rc = gemm_prepare(); if (rc != MH_OK) return rc; }
   MH_REQUIRE(g.A && g.W && g.C, "mh_gemm: null operand");
   MH_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0, "mh_gemm: bad shape M=%d N=%d K=%d", g.M, g.N, g.K);
   MH_REQUIRE(g.dtype == MH_F32 || g.dtype == MH_BF16, "mh_gemm: bad dtype %d", g.dtype);
@@ -274,6 +273,7 @@ int gemm(const MhGemm& g, hipStream_t s) {
     MH_REQUIRE(g.C2 && g.kv_H > 0 && g.kv_L > 0 && g.kv_Lpad >= g.kv_L && g.n_split > 0 &&
                    g.N - g.n_split == g.kv_H * 64 && g.M % g.kv_L == 0,
                "mh_gemm: bad QKV_VT geometry");
+  { int rc = gemm_prepare(); if (rc != MH_OK) return rc; }
   GemmP p;
   p.C2 = g.C2; p.n_split = g.n_split; p.kv_Lpad = g.kv_Lpad;
   p.A = (const char*)g.A; p.lda_b = (long)g.lda * es;

@@ -373,12 +373,10 @@ struct DecBuffers {
   int splits;
 };
 
-int cross_splits(int B, int H) {
-  const int pairs = B * H;
-  if (pairs >= 1024) return 1;
-  int s = (1024 + pairs - 1) / pairs;
-  return s > 8 ? 8 : s;
-}
+// Key-range splits of the decode cross-attention.  A CONSTANT (not a function of the batch) so that a row's
+// reduction order -- and therefore its bf16 rounding and its greedy tokens -- does not depend on which other
+// chunks share its batch.  4 splits x 4 waves: B*H*4 workgroups (1536 at B=32, H=12) fill the 256 CUs.
+int cross_splits(int /*B*/, int /*H*/) { return 4; }
 
 template <typename T>
 int enqueue_step(const MhT5Config* c, const MhT5Weights* w, const void* cross_kv, int B, const uint8_t* prompt_mask,
@@ -553,4 +551,60 @@ extern "C" int mh_t5_generate(const MhT5Config* c, const MhT5Weights* w, const v
   hipGraphExecDestroy(exec);
   hipGraphDestroy(graph);
   return rc2;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Measurement hook for bench.py's roofline line: the dominant decode kernel (cross-attention over the
+// encoder keys) launched `reps` times back to back between two HIP events ON THE GIVEN STREAM, cycling
+// through the decoder layers exactly like a decode step does (so every launch streams a different layer's
+// K/V: B*H*L*64*2 elements).  ms_out[0] = average milliseconds per launch (split kernel + merge kernel).
+extern "C" int mh_t5_cross_attn_probe(const MhT5Config* c, const void* cross_kv, int B, int reps, float* ms_out,
+                                      void* workspace, int64_t workspace_bytes, void* stream) {
+  MH_TRY(check_cfg(c, "mh_t5_cross_attn_probe"));
+  MH_REQUIRE(cross_kv && ms_out && workspace && B > 0 && B <= 64 && reps > 0, "mh_t5_cross_attn_probe: bad argument");
+  MH_REQUIRE(workspace_bytes >= mh_t5_decode_workspace_bytes(c, B), "mh_t5_cross_attn_probe: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  const int es = es_of(c->dtype), H = c->n_heads, inner = H * 64, L = c->src_len;
+  Arena ar(workspace, workspace_bytes);
+  (void)ar.take((int64_t)B * c->d_model * 4);
+  void* q = ar.take((int64_t)B * inner * es);
+  void* attn = ar.take((int64_t)B * inner * es);
+  (void)ar.take((int64_t)B * c->d_ff * es);
+  (void)ar.take((int64_t)B * c->vocab_out * 4);
+  float* part = (float*)ar.take((int64_t)B * H * 8 * 66 * 4);
+  if (hipMemsetAsync(q, 0, (size_t)B * inner * es, s) != hipSuccess) return check_launch("probe memset");
+  const int splits = cross_splits(B, H);
+  const long kv_layer = (long)B * H * L * 64 * es;
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return check_launch("event create");
+  int rc = MH_OK;
+  for (int pass = 0; pass < 2 && rc == MH_OK; ++pass) {   // pass 0 = warm-up
+    if (pass == 1) (void)hipEventRecord(e0, s);
+    for (int r = 0; r < reps && rc == MH_OK; ++r) {
+      const int l = r % c->n_dec_layers;
+      dec::CrossAttnP ca{};
+      ca.q = q; ca.ldq = inner; ca.k = (const char*)cross_kv + (long)(l * 2 + 0) * kv_layer;
+      ca.v = (const char*)cross_kv + (long)(l * 2 + 1) * kv_layer; ca.out = attn; ca.ldo = inner; ca.part = part;
+      ca.B = B; ca.H = H; ca.L = L; ca.splits = splits;
+      if (c->dtype == MH_BF16) {
+        hipLaunchKernelGGL(dec::dec_cross_attn_kernel<bf16_t>, dim3(B * H * splits), dim3(256), 0, s, ca);
+        if (splits > 1) hipLaunchKernelGGL(dec::dec_cross_merge_kernel<bf16_t>, dim3(B * H), dim3(64), 0, s, ca);
+      } else {
+        hipLaunchKernelGGL(dec::dec_cross_attn_kernel<float>, dim3(B * H * splits), dim3(256), 0, s, ca);
+        if (splits > 1) hipLaunchKernelGGL(dec::dec_cross_merge_kernel<float>, dim3(B * H), dim3(64), 0, s, ca);
+      }
+      rc = check_launch("probe cross attn");
+    }
+    if (pass == 1) (void)hipEventRecord(e1, s);
+  }
+  if (rc == MH_OK) {
+    float ms = 0.f;
+    if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess)
+      rc = check_launch("probe events");
+    else
+      ms_out[0] = ms / (float)reps;
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return rc;
 }

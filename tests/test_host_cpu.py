@@ -1,0 +1,161 @@
+"""not gpu: host logic + the C-ABI library loads and exports every symbol include/mapperhip.h declares
+(no compute calls: there is no GPU here)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, ts_range
+from mapperatorinator_amd import ContextType, Event, EventType, Tokenizer, _lib
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "mapperhip.h")).read()
+    declared = set(re.findall(r"\b(mh_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.mh_abi_version() == 1
+    assert lib.mh_last_error() is not None
+
+
+def test_argument_validation_without_gpu():
+    """Entry points validate before touching the device: bad descriptors return MH_ERR_ARG + a message."""
+    lib = _lib.load()
+    g = _lib.MhGemm()
+    assert lib.mh_gemm(C.byref(g), None) == -1
+    assert b"null operand" in lib.mh_last_error()
+    assert lib.mh_gemm(None, None) == -1
+    cfg = _lib.MhT5Config(128, 32, 256, 2, 2, 2, 10, 10, 388, 416, 251, 48, 0, 1e-6)
+    assert lib.mh_t5_encode(C.byref(cfg), None, None, 1, None, None, None, 0, None) == -1
+    assert b"d_kv" in lib.mh_last_error()
+    with pytest.raises(RuntimeError, match="status -1"):
+        _lib.check(-1, "x")
+    assert lib.mh_t5_encode_workspace_bytes(C.byref(cfg), 0) == -1
+    cfg.d_kv = 64
+    assert lib.mh_t5_encode_workspace_bytes(C.byref(cfg), 2) > 0
+    assert lib.mh_t5_decode_workspace_bytes(C.byref(cfg), 2) > 0
+    dc = _lib.MhDiTConfig(128, 2, 2, 272, 300, 2, 128, 256, 544, 300)
+    assert lib.mh_dit_workspace_bytes(C.byref(dc), 2, 96) > 0
+
+
+def test_struct_layouts_match_header_sizes():
+    # pointer arrays of MH_MAX_LAYERS entries, ints packed as in C
+    assert C.sizeof(_lib.MhT5Config) == 14 * 4
+    assert C.sizeof(_lib.MhSampling) == 4 * 8 + 16 * 4 + 3 * 4 + 4 + 8  # 4B pad before the uint64 seed
+    assert C.sizeof(_lib.MhT5Weights) == 8 * (5 + 6 * 32 + 1 + 5 * 32 + 1 + 4 * 32 + 2)
+    assert C.sizeof(_lib.MhDiTWeights) == 8 * (12 + 10 * 32 + 4)
+
+
+def test_no_cpu_fallback():
+    from mapperatorinator_amd.mel import MelSpectrogram
+    m = MelSpectrogram()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(1, 4096))
+    if not torch.cuda.is_available():
+        from mapperatorinator_amd.t5_engine import T5Engine, T5_PRESETS
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            T5Engine({}, T5_PRESETS["tiny"], 10, 10)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "mapperatorinator_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f
+    assert not re.search(r"^\s*(from|import)\s+oracle", open(os.path.join(ROOT, "bench.py")).read().split("def cpu_baseline")[0], re.M)
+
+
+def test_tokenizer_api():
+    tok = Tokenizer.benchmark_vocab()
+    assert (tok.pad_id, tok.sos_id, tok.eos_id) == (0, 1, 2)
+    ts0, ts1 = ts_range(tok)
+    assert (ts0, ts1) == (3, 1004)
+    for ev in (Event(EventType.TIME_SHIFT, 0), Event(EventType.TIME_SHIFT, 1000), Event(EventType.DISTANCE, 640),
+               Event(EventType.MEASURE, 0), Event(EventType.HITSOUND, 71)):
+        assert tok.decode(tok.encode(ev)) == ev
+    with pytest.raises(ValueError):
+        tok.encode(Event(EventType.TIME_SHIFT, 1001))
+    with pytest.raises(ValueError):
+        tok.decode(tok.vocab_size_in)
+    assert tok.event_type_range(EventType.SNAPPING) == (1004, 1020)
+    t2 = Tokenizer.from_ranges([(EventType.TIME_SHIFT, -512, 512), (EventType.SNAPPING, 0, 16)],
+                               [(EventType.DIFFICULTY, 0, 9)], [ContextType.MAP, "gd"])
+    assert t2.context_sos == {ContextType.MAP: 3, ContextType.GD: 5} and t2.context_eos[ContextType.GD] == 6
+    assert t2.event_start[EventType.TIME_SHIFT] == 7 and t2.vocab_size_in == t2.vocab_size_out + 10
+    t3 = Tokenizer().load_state_dict(t2.state_dict())
+    assert t3.state_dict() == t2.state_dict()
+    assert repr(Event(EventType.TIME_SHIFT, 12)) == "t12"
+
+
+def test_eos_set_and_sampling_translation():
+    from mapperatorinator_amd.server import build_sampling, get_eos_token_id
+    tok = Tokenizer.from_ranges([(EventType.TIME_SHIFT, 0, 1000), (EventType.SNAPPING, 0, 16)], (), [ContextType.MAP])
+    ts0, ts1 = ts_range(tok)
+    assert get_eos_token_id(tok) == [2]
+    assert get_eos_token_id(tok, context_type=ContextType.MAP) == [2, 4]
+    ids = get_eos_token_id(tok, lookback_time=50, lookahead_time=30, context_type="map")
+    assert ids == [2, 4] + list(range(ts0, ts0 + 5)) + list(range(ts1 - 3, ts1))
+    sp, eos = build_sampling(tok, dict(do_sample=True, top_k=5, top_p=0.9, temperature=0.8, timeshift_bias=0.2,
+                                       lookback_time=120, max_length=77, context_type="map", pad_token_id=0), 512)
+    assert (sp.do_sample, sp.top_k, sp.max_length, sp.ts_start, sp.ts_end) == (1, 5, 77, ts0, ts1)
+    assert abs(sp.top_p - 0.9) < 1e-6 and abs(sp.temperature - 0.8) < 1e-6
+    assert sp.n_sos == 2 and list(sp.sos_ids[:2]) == [1, 3]
+    assert sp.lookback_mask_end == ts0 + 12
+    assert eos[:2] == [2, 4]
+    for bad in (dict(cfg_scale=2.0), dict(num_beams=2), dict(types_first=True, timing_temperature=0.5)):
+        with pytest.raises(NotImplementedError):
+            build_sampling(tok, bad, 512)
+
+
+def test_rel_bias_tables():
+    from mapperatorinator_amd.t5_engine import T5_PRESETS, rel_bias_tables
+    d = T5_PRESETS["tiny"]
+    enc_tab = torch.arange(32 * 2, dtype=torch.float32).reshape(32, 2)
+    dec_tab = -enc_tab
+    e, dcd = rel_bias_tables(enc_tab, dec_tab, 50, 20, d)
+    assert e.shape == (2, 99) and dcd.shape == (2, 20)
+    assert e[0, 49].item() == enc_tab[0, 0]                # rel 0 -> bucket 0
+    assert e[1, 49 + 3].item() == enc_tab[16 + 3, 1]       # k > q -> upper half
+    assert e[0, 49 - 3].item() == enc_tab[3, 0]
+    assert dcd[0, 5].item() == dec_tab[5, 0] and dcd[1, 16].item() == dec_tab[16, 1]
+
+
+def test_band_mask_recovery_and_inpaint():
+    from mapperatorinator_amd.dit import DiTHIP, InpaintSpec
+    from oracle.dit import band_mask
+    f = DiTHIP.band_from_mask
+    self = type("X", (), {"_band_cache": {}})()
+    assert f(self, None, 10) == 0
+    assert f(self, band_mask(300, 128), 300) == 128
+    assert f(self, band_mask(96, 128), 96) == 0
+    assert f(self, band_mask(200, 7), 200) == 7
+    bad = band_mask(200, 7)
+    bad[100, 100] = True
+    with pytest.raises(NotImplementedError):
+        f(self, bad, 200)
+    m = torch.tensor([[True, False]])
+    assert torch.equal(InpaintSpec(m, torch.tensor([[9.0, 9.0]]))(torch.tensor([[1.0, 2.0]])), torch.tensor([[1.0, 9.0]]))
+
+
+def test_mel_host_tables():
+    from mapperatorinator_amd.mel import MelSpectrogram, slaney_filterbank
+    from oracle import mel as omel
+    fb = slaney_filterbank(16000, 1024, 388, 0.0, 8000.0)
+    assert np.array_equal(fb, omel.mel_filterbank(16000, 1024, 388, 0, 8000))
+    m = MelSpectrogram()
+    dense = np.zeros_like(fb)
+    for i in range(388):
+        s, ln, of = int(m.fb_start[i]), int(m.fb_len[i]), int(m.fb_off[i])
+        dense[i, s:s + ln] = m.fb_w[of:of + ln].numpy()
+    assert np.array_equal(dense, fb)
+    assert m.n_frames(160000) == 1251
+    with pytest.raises(NotImplementedError):
+        MelSpectrogram(implementation="torchaudio")
