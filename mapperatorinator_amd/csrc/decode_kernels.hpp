@@ -102,30 +102,64 @@ template <> struct VecOps<float> {
   }
 };
 
+
+// Dynamic LDS layout of skinny_gemm_kernel:
+//   [ normalised A tile : MF*16 rows x (K*sizeof(T) + 16) bytes ]   (PRO_RMSNORM only)
+//   [ cross-wave reduction buffer : 4 x NS x MF x 64 x f32x4 ]      (aliases the A tile after the K loop)
+template <typename T, int MF, int NS, int PRO>
+inline size_t skinny_smem_bytes(int K) {
+  const size_t a = PRO == PRO_RMSNORM ? (size_t)MF * 16 * ((size_t)K * sizeof(T) + 16) : 0;
+  const size_t r = (size_t)4 * NS * MF * 64 * 16;
+  return a > r ? a : r;
+}
+
 template <typename T, int MF, int NS, int PRO, int EPI>
 __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyP p) {
   constexpr int VEC = Elem<T>::kVec;   // elements per 16-byte vector (per lane per k-block)
-  constexpr int KB = 4 * VEC;          // k elements per k-block (4 lane groups)
-  __shared__ float rs_s[64];
-  __shared__ f32x4_t red[4][NS][MF][64];
+  constexpr int KB = 4 * VEC;          // k elements per k-block (4 lane groups x 16 B)
+  constexpr int CH = 8;                // k-blocks per wave whose loads are all issued before the first MFMA
+  extern __shared__ __attribute__((aligned(16))) char sk_smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l15 = lane & 15, lg = lane >> 4;
   const int strip0 = blockIdx.x * NS;
+  const int a_stride = p.K * (int)sizeof(T) + 16;   // bytes per LDS A row
 
   if (PRO == PRO_RMSNORM) {
-    constexpr int TPR = 256 / (MF * 16);  // threads per row
-    const int row = tid / TPR, sub = tid % TPR;
-    float ss = 0.f;
-    if (row < p.B) {
-      const float* hr = reinterpret_cast<const float*>(p.A) + (long)row * p.lda;
-      for (int k = sub * 4; k < p.K; k += TPR * 4) {
-        const float4 v = *reinterpret_cast<const float4*>(hr + k);
-        ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    // 8 threads per row, 32 rows per pass; a thread keeps its slice of the fp32 residual row in registers
+    // (<= 32 float4 = d_model 1024), so h is read from L2 exactly once per workgroup, all loads in flight.
+    constexpr int NV = 32;
+    const int sub = tid & 7;
+    const int nvec = p.K / 32;           // float4 per thread (K multiple of 32)
+#pragma unroll 1
+    for (int pass = 0; pass < (MF * 16 + 31) / 32; ++pass) {
+      const int row = pass * 32 + (tid >> 3);
+      const bool live = row < p.B && row < MF * 16;
+      const float* hr = reinterpret_cast<const float*>(p.A) + (long)(live ? row : 0) * p.lda + sub * 4;
+      float4 hv[NV];
+#pragma unroll
+      for (int i = 0; i < NV; ++i)
+        hv[i] = (live && i < nvec) ? *reinterpret_cast<const float4*>(hr + i * 32) : make_float4(0.f, 0.f, 0.f, 0.f);
+      float ss = 0.f;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) ss += hv[i].x * hv[i].x + hv[i].y * hv[i].y + hv[i].z * hv[i].z + hv[i].w * hv[i].w;
+      ss = group_sum<8>(ss);
+      const float rs = live ? rsqrtf(ss / (float)p.K + p.eps) : 0.f;
+      if (row < MF * 16) {
+        T* ar = reinterpret_cast<T*>(sk_smem + (long)row * a_stride);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+          if (i < nvec) {
+            const int k = i * 32 + sub * 4;
+            const float4 g = *reinterpret_cast<const float4*>(p.ln_w + k);
+            ar[k + 0] = Elem<T>::from_f32(g.x * (hv[i].x * rs));
+            ar[k + 1] = Elem<T>::from_f32(g.y * (hv[i].y * rs));
+            ar[k + 2] = Elem<T>::from_f32(g.z * (hv[i].z * rs));
+            ar[k + 3] = Elem<T>::from_f32(g.w * (hv[i].w * rs));
+          }
+        }
       }
     }
-    ss = group_sum<TPR>(ss);
-    if (sub == 0) rs_s[row] = row < p.B ? rsqrtf(ss / (float)p.K + p.eps) : 0.f;
     __syncthreads();
   }
 
@@ -142,62 +176,69 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyP p) {
     wr = wr < p.N ? wr : p.N - 1;
     Wp[s] = reinterpret_cast<const T*>(p.W) + (long)wr * p.ldw + lg * VEC;
   }
-  float rsr[MF];
-  if (PRO == PRO_RMSNORM) {
-#pragma unroll
-    for (int f = 0; f < MF; ++f) rsr[f] = rs_s[f * 16 + l15];
-  }
 
   const int nkb = p.K / KB;
-#pragma unroll 4
-  for (int kb = wid; kb < nkb; kb += 4) {
-    const int kel = kb * KB;
-    uint4 wv[NS], av[MF];
+  // wave w owns k-blocks w, w+4, w+8, ...; CH of them per pass with every load issued up front
+  for (int kb0 = wid; kb0 < nkb; kb0 += 4 * CH) {
+    uint4 wv[CH][NS];
 #pragma unroll
-    for (int s = 0; s < NS; ++s) wv[s] = *reinterpret_cast<const uint4*>(Wp[s] + kel);
+    for (int c = 0; c < CH; ++c) {
+      const int kb = kb0 + 4 * c;
+      const int kel = (kb < nkb ? kb : kb0) * KB;
 #pragma unroll
-    for (int f = 0; f < MF; ++f) {
-      const int row = f * 16 + l15;
-      if (PRO == PRO_PLAIN) {
-        av[f] = row < p.B ? *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.A) + (long)row * p.lda + kel + lg * VEC)
-                          : make_uint4(0, 0, 0, 0);
-      } else {
-        if (row < p.B) {
-          const float* hr = reinterpret_cast<const float*>(p.A) + (long)row * p.lda + kel + lg * VEC;
-          av[f] = VecOps<T>::norm_frag(hr, p.ln_w + kel + lg * VEC, rsr[f]);
+      for (int s = 0; s < NS; ++s) wv[c][s] = *reinterpret_cast<const uint4*>(Wp[s] + kel);
+    }
+    uint4 av[CH][MF];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int kb = kb0 + 4 * c;
+      const int kel = (kb < nkb ? kb : kb0) * KB + lg * VEC;
+#pragma unroll
+      for (int f = 0; f < MF; ++f) {
+        const int row = f * 16 + l15;
+        if (PRO == PRO_PLAIN) {
+          av[c][f] = row < p.B ? *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.A) + (long)row * p.lda + kel)
+                               : make_uint4(0, 0, 0, 0);
         } else {
-          av[f] = make_uint4(0, 0, 0, 0);
+          av[c][f] = *reinterpret_cast<const uint4*>(sk_smem + (long)row * a_stride + (long)kel * sizeof(T));
         }
       }
     }
 #pragma unroll
-    for (int s = 0; s < NS; ++s)
+    for (int c = 0; c < CH; ++c) {
+      if (kb0 + 4 * c < nkb) {
 #pragma unroll
-      for (int f = 0; f < MF; ++f) acc[s][f] = VecOps<T>::mma(av[f], wv[s], acc[s][f]);
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+          for (int f = 0; f < MF; ++f) acc[s][f] = VecOps<T>::mma(av[c][f], wv[c][s], acc[s][f]);
+      }
+    }
   }
 
+  __syncthreads();   // every wave is done with the A tile: the reduction buffer may alias it
+  f32x4_t* red = reinterpret_cast<f32x4_t*>(sk_smem);   // [4][NS][MF][64]
 #pragma unroll
   for (int s = 0; s < NS; ++s)
 #pragma unroll
-    for (int f = 0; f < MF; ++f) red[wid][s][f][lane] = acc[s][f];
+    for (int f = 0; f < MF; ++f) red[((wid * NS + s) * MF + f) * 64 + lane] = acc[s][f];
   __syncthreads();
 
   const int pos = (EPI == SK_QKV) ? *p.pos : 0;
   constexpr int NSE = (EPI == SK_GEGLU) ? 1 : NS;
   for (int idx = tid; idx < NSE * MF * 64; idx += 256) {
     const int ln = idx & 63, f = (idx >> 6) % MF, s = (idx >> 6) / MF;
-    f32x4_t v = red[0][s][f][ln];
+    f32x4_t v = red[((0 * NS + s) * MF + f) * 64 + ln];
 #pragma unroll
     for (int w = 1; w < 4; ++w) {
-      const f32x4_t t = red[w][s][f][ln];
+      const f32x4_t t = red[((w * NS + s) * MF + f) * 64 + ln];
       v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
     }
     f32x4_t u = f32x4_t{0.f, 0.f, 0.f, 0.f};
     if (EPI == SK_GEGLU) {
-      u = red[0][1][f][ln];
+      u = red[((0 * NS + 1) * MF + f) * 64 + ln];
 #pragma unroll
       for (int w = 1; w < 4; ++w) {
-        const f32x4_t t = red[w][1][f][ln];
+        const f32x4_t t = red[((w * NS + 1) * MF + f) * 64 + ln];
         u[0] += t[0]; u[1] += t[1]; u[2] += t[2]; u[3] += t[3];
       }
     }
@@ -331,12 +372,39 @@ struct SelfAttnP {
   const int* pos;
 };
 
-// one wave per (b, h); keys 0..pos
+// merge the 4 waves' partial (m, l, acc[64]) through LDS; threads 0..63 return the merged (m, l, a[d])
+template <typename T>
+__device__ inline void block_merge(const Partial& st, float (*sm)[66], float& m, float& l, float& a) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int c8 = (lane & 7) * 8, g = lane >> 3;
+  if (g == 0) {
+    if (lane == 0) { sm[wid][0] = st.m; sm[wid][1] = st.l; }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sm[wid][2 + c8 + i] = st.acc[i];
+  }
+  __syncthreads();
+  m = -1e30f; l = 0.f; a = 0.f;
+  if (threadIdx.x < 64) {
+    const int d = threadIdx.x;
+    m = sm[0][0]; l = sm[0][1]; a = sm[0][2 + d];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      const float m2 = sm[w][0], l2 = sm[w][1], a2 = sm[w][2 + d];
+      const float mn = fmaxf(m, m2);
+      const float fa = fexp<T>(m - mn), fb = fexp<T>(m2 - mn);
+      l = l * fa + l2 * fb;
+      a = a * fa + a2 * fb;
+      m = mn;
+    }
+  }
+}
+
+// one workgroup (4 waves) per (b, h); keys 0..pos interleaved over the 32 key groups of the block
 template <typename T>
 __global__ __launch_bounds__(256) void dec_self_attn_kernel(SelfAttnP p) {
+  __shared__ float sm[4][66];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int pair = blockIdx.x * 4 + wid;
-  if (pair >= p.B * p.H) return;
+  const int pair = blockIdx.x;
   const int b = pair / p.H, h = pair % p.H;
   const int pos = *p.pos;
   const int c8 = (lane & 7) * 8, g = lane >> 3;
@@ -346,16 +414,13 @@ __global__ __launch_bounds__(256) void dec_self_attn_kernel(SelfAttnP p) {
   const T* vb = reinterpret_cast<const T*>(p.vc) + ((long)b * p.H + h) * p.tgt_len * 64;
   Partial st;
   partial_init(st);
-  attend_keys<T, 2>(st, q, kb, vb, g, pos + 1, 8, p.bias + (long)h * p.tgt_len, pos,
+  attend_keys<T, 4>(st, q, kb, vb, wid * 8 + g, pos + 1, 32, p.bias + (long)h * p.tgt_len, pos,
                     p.prompt_mask ? p.prompt_mask + (long)b * p.P : nullptr, p.P, 1.0f);
   partial_merge_groups<T>(st);
-  if (g == 0) {
-    const float inv = st.l > 0.f ? 1.0f / st.l : 0.f;
-    float o[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) o[i] = st.acc[i] * inv;
-    store8<T>(reinterpret_cast<T*>(p.out) + (long)b * p.ldo + h * 64 + c8, o);
-  }
+  float m, l, a;
+  block_merge<T>(st, sm, m, l, a);
+  if (threadIdx.x < 64)
+    reinterpret_cast<T*>(p.out)[(long)b * p.ldo + h * 64 + threadIdx.x] = Elem<T>::from_f32(l > 0.f ? a / l : 0.f);
 }
 
 struct CrossAttnP {
@@ -387,24 +452,10 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(CrossAttnP p) {
   partial_init(st);
   attend_keys<T, 4>(st, q, kb, vb, k_lo + wid * 8 + g, k_hi, 32, nullptr, 0, nullptr, 0, 1.0f);
   partial_merge_groups<T>(st);
-  if (g == 0) {
-    if (lane == 0) { sm[wid][0] = st.m; sm[wid][1] = st.l; }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) sm[wid][2 + c8 + i] = st.acc[i];
-  }
-  __syncthreads();
+  float m, l, a;
+  block_merge<T>(st, sm, m, l, a);
   if (threadIdx.x < 64) {
     const int d = threadIdx.x;
-    float m = sm[0][0], l = sm[0][1], a = sm[0][2 + d];
-#pragma unroll
-    for (int w = 1; w < 4; ++w) {
-      const float m2 = sm[w][0], l2 = sm[w][1], a2 = sm[w][2 + d];
-      const float mn = fmaxf(m, m2);
-      const float fa = fexp<T>(m - mn), fb = fexp<T>(m2 - mn);
-      l = l * fa + l2 * fb;
-      a = a * fa + a2 * fb;
-      m = mn;
-    }
     if (p.splits == 1) {
       reinterpret_cast<T*>(p.out)[(long)b * p.ldo + h * 64 + d] = Elem<T>::from_f32(l > 0.f ? a / l : 0.f);
     } else {

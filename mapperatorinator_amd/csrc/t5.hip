@@ -353,11 +353,43 @@ __global__ void dec_finalize_kernel(const int32_t* finish_col, int B, int32_t* n
   }
 }
 
+constexpr size_t kSkinnyMaxLds = 160 * 1024;
+
 template <typename T, int MF, int NS, int PRO, int EPI>
 int launch_skinny(const dec::SkinnyP& p, hipStream_t s) {
   const int strips = ceil_div(p.N, 16);
-  hipLaunchKernelGGL((dec::skinny_gemm_kernel<T, MF, NS, PRO, EPI>), dim3(ceil_div(strips, NS)), dim3(256), 0, s, p);
+  const size_t smem = dec::skinny_smem_bytes<T, MF, NS, PRO>(p.K);
+  MH_REQUIRE(smem <= kSkinnyMaxLds, "decode: batch %d x d_model %d does not fit the LDS tile of the skinny GEMM", p.B, p.K);
+  MH_REQUIRE(PRO != dec::PRO_RMSNORM || p.K <= 1024, "decode: d_model %d > 1024 is not built", p.K);
+  hipLaunchKernelGGL((dec::skinny_gemm_kernel<T, MF, NS, PRO, EPI>), dim3(ceil_div(strips, NS)), dim3(256), smem, s, p);
   return check_launch("skinny_gemm_kernel");
+}
+
+// > 64 KiB of dynamic LDS needs an explicit opt-in per kernel: done once, outside any stream capture
+template <typename T, int MF, int NS, int PRO, int EPI>
+bool skinny_prepare_one() {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&dec::skinny_gemm_kernel<T, MF, NS, PRO, EPI>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSkinnyMaxLds) == hipSuccess;
+}
+template <typename T, int MF>
+bool skinny_prepare_mf() {
+  return skinny_prepare_one<T, MF, 1, dec::PRO_RMSNORM, dec::SK_QKV>() &&
+         skinny_prepare_one<T, MF, 1, dec::PRO_PLAIN, dec::SK_RESID>() &&
+         skinny_prepare_one<T, MF, 1, dec::PRO_RMSNORM, dec::SK_STORE>() &&
+         skinny_prepare_one<T, MF, 2, dec::PRO_RMSNORM, dec::SK_GEGLU>() &&
+         skinny_prepare_one<T, MF, 1, dec::PRO_RMSNORM, dec::SK_LOGITS>();
+}
+int skinny_prepare() {
+  static bool done = false;
+  if (done) return MH_OK;
+  const bool ok = skinny_prepare_mf<bf16_t, 1>() && skinny_prepare_mf<bf16_t, 2>() && skinny_prepare_mf<bf16_t, 4>() &&
+                  skinny_prepare_mf<float, 1>() && skinny_prepare_mf<float, 2>() && skinny_prepare_mf<float, 4>();
+  if (!ok) {
+    set_error("skinny_prepare: hipFuncSetAttribute failed: %s", hipGetErrorString(hipGetLastError()));
+    return MH_ERR_LAUNCH;
+  }
+  done = true;
+  return MH_OK;
 }
 template <typename T, int NS, int PRO, int EPI>
 int skinny(const dec::SkinnyP& p, hipStream_t s) {
@@ -396,7 +428,7 @@ int enqueue_step(const MhT5Config* c, const MhT5Weights* w, const void* cross_kv
     dec::SelfAttnP sa{};
     sa.q = bf.q; sa.ldq = inner; sa.kc = sk.kc; sa.vc = sk.vc; sa.bias = w->dec_rel_bias; sa.prompt_mask = prompt_mask;
     sa.P = P; sa.out = bf.attn; sa.ldo = inner; sa.B = B; sa.H = H; sa.tgt_len = tgt; sa.pos = posp;
-    hipLaunchKernelGGL(dec::dec_self_attn_kernel<T>, dim3(ceil_div(B * H, 4)), dim3(256), 0, s, sa);
+    hipLaunchKernelGGL(dec::dec_self_attn_kernel<T>, dim3(B * H), dim3(256), 0, s, sa);
     MH_TRY(check_launch("dec_self_attn_kernel"));
     sk = dec::SkinnyP{};
     sk.A = bf.attn; sk.lda = inner; sk.W = w->dec_o[l]; sk.ldw = inner; sk.B = B; sk.N = d; sk.K = inner; sk.h = bf.h;
@@ -513,6 +545,7 @@ extern "C" int mh_t5_generate(const MhT5Config* c, const MhT5Weights* w, const v
   else hipLaunchKernelGGL(dec_init_kernel<float>, dim3(B), dim3(256), 0, s, smp);
   MH_TRY(check_launch("dec_init_kernel"));
 
+  MH_TRY(skinny_prepare());
   // capture one step (all kernels read the position from device memory) and replay it
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
