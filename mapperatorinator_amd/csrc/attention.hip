@@ -106,6 +106,26 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(AttnP p) {
 
     // ---- scale, bias, mask, online softmax ----
     float mx[4], rs[4], alpha[4];
+    // relative-position bias: ONE wave-uniform branch, 16 unconditional loads from clamped indices (a
+    // predicated load per element would serialise into 16 L2 round trips per tile)
+    float bv[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bv[r][j] = 0.f;
+    if (p.bias) {
+      const float* bh = p.bias + (long)h * (2 * L - 1) + (L - 1);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int qg = q0w + lg * 4 + r;
+        const int qgc = qg < L ? qg : L - 1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int kg = kv0 + j * 16 + l15;
+          bv[r][j] = bh[(kg < L ? kg : L - 1) - qgc];
+        }
+      }
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       int qg = q0w + lg * 4 + r;
@@ -114,11 +134,10 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(AttnP p) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int kg = kv0 + j * 16 + l15;
-        float v = s[j][r] * p.scale;
+        float v = s[j][r] * p.scale + bv[r][j];
         const int rel = kg - qgc;
         bool ok = kg < L;
         if (p.band > 0) ok = ok && (rel >= -(p.band - 1)) && (rel <= p.band);
-        if (p.bias && ok) v += p.bias[(long)h * (2 * L - 1) + rel + L - 1];
         v = ok ? v : -INFINITY;
         s[j][r] = v;
         mxr = fmaxf(mxr, v);

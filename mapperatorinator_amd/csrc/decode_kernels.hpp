@@ -46,6 +46,15 @@ template <> __device__ inline void store8<float>(float* p, const float (&o)[8]) 
   *reinterpret_cast<float4*>(p + 4) = make_float4(o[4], o[5], o[6], o[7]);
 }
 
+template <typename T> __device__ inline void store4(T* p, float a, float b, float c, float d);
+template <> __device__ inline void store4<bf16_t>(bf16_t* p, float a, float b, float c, float d) {
+  *reinterpret_cast<uint2*>(p) = make_uint2((uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16),
+                                            (uint32_t)f32_to_bf16(c) | ((uint32_t)f32_to_bf16(d) << 16));
+}
+template <> __device__ inline void store4<float>(float* p, float a, float b, float c, float d) {
+  *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
+}
+
 // ---- skinny GEMM ----------------------------------------------------------------------------
 enum { PRO_PLAIN = 0, PRO_RMSNORM = 1 };
 enum { SK_STORE = 0, SK_QKV = 1, SK_GEGLU = 2, SK_RESID = 3, SK_LOGITS = 4 };
@@ -136,26 +145,30 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyP p) {
       const int row = pass * 32 + (tid >> 3);
       const bool live = row < p.B && row < MF * 16;
       const float* hr = reinterpret_cast<const float*>(p.A) + (long)(live ? row : 0) * p.lda + sub * 4;
+      // UNCONDITIONAL loads from clamped addresses, masked afterwards: a predicated load inside an unrolled
+      // loop makes hipcc branch around every load and wait for each one (32 serial L2 round trips)
       float4 hv[NV];
 #pragma unroll
-      for (int i = 0; i < NV; ++i)
-        hv[i] = (live && i < nvec) ? *reinterpret_cast<const float4*>(hr + i * 32) : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int i = 0; i < NV; ++i) hv[i] = *reinterpret_cast<const float4*>(hr + (i < nvec ? i : nvec - 1) * 32);
       float ss = 0.f;
 #pragma unroll
-      for (int i = 0; i < NV; ++i) ss += hv[i].x * hv[i].x + hv[i].y * hv[i].y + hv[i].z * hv[i].z + hv[i].w * hv[i].w;
+      for (int i = 0; i < NV; ++i) {
+        const float q2 = hv[i].x * hv[i].x + hv[i].y * hv[i].y + hv[i].z * hv[i].z + hv[i].w * hv[i].w;
+        ss += (i < nvec) ? q2 : 0.f;
+      }
       ss = group_sum<8>(ss);
       const float rs = live ? rsqrtf(ss / (float)p.K + p.eps) : 0.f;
       if (row < MF * 16) {
         T* ar = reinterpret_cast<T*>(sk_smem + (long)row * a_stride);
+        float4 gv[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) gv[i] = *reinterpret_cast<const float4*>(p.ln_w + (i < nvec ? i : nvec - 1) * 32 + sub * 4);
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-          if (i < nvec) {
+          if (i < nvec) {   // LDS stores only (no loads under the branch)
             const int k = i * 32 + sub * 4;
-            const float4 g = *reinterpret_cast<const float4*>(p.ln_w + k);
-            ar[k + 0] = Elem<T>::from_f32(g.x * (hv[i].x * rs));
-            ar[k + 1] = Elem<T>::from_f32(g.y * (hv[i].y * rs));
-            ar[k + 2] = Elem<T>::from_f32(g.z * (hv[i].z * rs));
-            ar[k + 3] = Elem<T>::from_f32(g.w * (hv[i].w * rs));
+            store4<T>(ar + k, gv[i].x * (hv[i].x * rs), gv[i].y * (hv[i].y * rs), gv[i].z * (hv[i].z * rs),
+                      gv[i].w * (hv[i].w * rs));
           }
         }
       }
@@ -197,8 +210,10 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyP p) {
       for (int f = 0; f < MF; ++f) {
         const int row = f * 16 + l15;
         if (PRO == PRO_PLAIN) {
-          av[c][f] = row < p.B ? *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.A) + (long)row * p.lda + kel)
-                               : make_uint4(0, 0, 0, 0);
+          const int rc = row < p.B ? row : p.B - 1;   // clamped address, masked value (no predicated load)
+          uint4 t = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.A) + (long)rc * p.lda + kel);
+          const uint32_t keep = row < p.B ? 0xffffffffu : 0u;
+          av[c][f] = make_uint4(t.x & keep, t.y & keep, t.z & keep, t.w & keep);
         } else {
           av[c][f] = *reinterpret_cast<const uint4*>(sk_smem + (long)row * a_stride + (long)kel * sizeof(T));
         }
@@ -243,6 +258,15 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyP p) {
       }
     }
     const int c15 = ln & 15;
+    float oldh[4] = {0.f, 0.f, 0.f, 0.f};
+    if (EPI == SK_RESID) {   // unconditional loads of the residual stream from clamped addresses
+      const int colc = (strip0 + s) * 16 + c15;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = f * 16 + (ln >> 4) * 4 + r;
+        oldh[r] = p.h[(long)(row < p.B ? row : p.B - 1) * p.ldh + (colc < p.N ? colc : p.N - 1)];
+      }
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = f * 16 + (ln >> 4) * 4 + r;
@@ -260,8 +284,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyP p) {
       } else if (EPI == SK_LOGITS) {
         reinterpret_cast<float*>(p.out)[(long)row * p.ldo + col] = v[r];
       } else if (EPI == SK_RESID) {
-        float* hp = p.h + (long)row * p.ldh + col;
-        *hp = *hp + v[r];
+        p.h[(long)row * p.ldh + col] = oldh[r] + v[r];
       } else if (EPI == SK_QKV) {
         const int part = col / p.inner, c = col - part * p.inner;
         if (part == 0) {
@@ -331,6 +354,27 @@ __device__ inline void attend_keys(Partial& st, const float (&q)[8], const T* kb
       const int jc = jj < jend ? jj : j;
       load8<T>(vbase + (long)jc * 64 + c8, vv[u]);
     }
+    // bias / mask values: wave-uniform branch on the pointers, unconditional loads from clamped indices
+    float bv[U];
+    int mv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { bv[u] = 0.f; mv[u] = 1; }
+    if (bias_row) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int jj = j + u * jstride;
+        bv[u] = bias_row[pos - (jj < jend ? jj : j)];
+      }
+    }
+    if (mask_row) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int jj = j + u * jstride;
+        const int jm = jj < P ? jj : P - 1;
+        const int mval = mask_row[jm];
+        mv[u] = (jj < P) ? mval : 1;
+      }
+    }
     float cmax = -INFINITY;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -338,10 +382,8 @@ __device__ inline void attend_keys(Partial& st, const float (&q)[8], const T* kb
       float d = 0.f;
 #pragma unroll
       for (int i = 0; i < 8; ++i) d += q[i] * kv[u][i];
-      d = group_sum<8>(d) * scale;
-      bool ok = jj < jend;
-      if (bias_row && ok) d += bias_row[pos - jj];
-      if (mask_row && ok && jj < P) ok = mask_row[jj] != 0;
+      d = group_sum<8>(d) * scale + bv[u];
+      const bool ok = (jj < jend) && (mv[u] != 0);
       d = ok ? d : -INFINITY;
       s[u] = d;
       cmax = fmaxf(cmax, d);

@@ -25,32 +25,28 @@ struct GemmP {
   void* C2; int n_split; int kv_Lpad;
 };
 
+// `v` already contains the bias; `old` = previous C value (RESID / GATE_RESID), `g` = gate value, `v2` = paired
+// linear value (GEGLU).  All global LOADS feeding this function are issued unconditionally by the caller
+// (clamped addresses): predicated loads in an unrolled epilogue serialise into one round trip each.
 template <typename T, int EPI>
-__device__ inline void epilogue_store(const GemmP& p, int row, int col, float v, float v2) {
-  // v2 only used by GEGLU (the paired linear value)
+__device__ inline void epilogue_store(const GemmP& p, int row, int col, float v, float v2, float old, float g) {
   if (row >= p.M) return;
   if (EPI == MH_EPI_GEGLU) {
-    // col is the output column in [0, N/2)
-    if (col >= p.N / 2) return;
-    T* C = reinterpret_cast<T*>(p.C);
-    C[(long)row * p.ldc + col] = Elem<T>::from_f32(gelu_tanh(v) * v2);
+    if (col >= p.N / 2) return;   // col is the output column in [0, N/2)
+    reinterpret_cast<T*>(p.C)[(long)row * p.ldc + col] = Elem<T>::from_f32(gelu_tanh(v) * v2);
     return;
   }
   if (col >= p.N) return;
-  if (EPI != MH_EPI_GEGLU && p.bias) v += p.bias[col];
   if (EPI == MH_EPI_STORE) {
     reinterpret_cast<T*>(p.C)[(long)row * p.ldc + col] = Elem<T>::from_f32(v);
   } else if (EPI == MH_EPI_STORE_F32) {
     reinterpret_cast<float*>(p.C)[(long)row * p.ldc + col] = v;
   } else if (EPI == MH_EPI_RESID) {
-    float* c = reinterpret_cast<float*>(p.C) + (long)row * p.ldc + col;
-    *c = *c + v;
+    reinterpret_cast<float*>(p.C)[(long)row * p.ldc + col] = old + v;
   } else if (EPI == MH_EPI_BIAS_GELU) {
     reinterpret_cast<T*>(p.C)[(long)row * p.ldc + col] = Elem<T>::from_f32(gelu_tanh(v));
   } else if (EPI == MH_EPI_GATE_RESID) {
-    float g = p.gate[(long)(row / p.rows_per_batch) * p.gate_ld + col];
-    float* c = reinterpret_cast<float*>(p.C) + (long)row * p.ldc + col;
-    *c = *c + g * v;
+    reinterpret_cast<float*>(p.C)[(long)row * p.ldc + col] = old + g * v;
   } else if (EPI == MH_EPI_KV_SCATTER) {
     // col = ((layer*2 + kv) * H + h) * 64 + dd ; row = b * L + key
     const int dd = col & 63;
@@ -170,8 +166,34 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmP p) {
   // epilogue: acc[i][j][r] = C[m0 + wr*WM + i*16 + (lane>>4)*4 + r][n0 + wc*WN + j*16 + (lane&15)]
   const int erow0 = m0 + wr * WM + (lane >> 4) * 4;
   const int ecol0 = n0 + wc * WN + (lane & 15);
+  constexpr bool kReadsC = (EPI == MH_EPI_RESID || EPI == MH_EPI_GATE_RESID);
+  float bias_v[NI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j) bias_v[j] = 0.f;
+  if (EPI != MH_EPI_GEGLU && p.bias) {
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int c = ecol0 + j * 16;
+      bias_v[j] = p.bias[c < p.N ? c : p.N - 1];
+    }
+  }
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
+    f32x4_t oldv[NI], gv[NI];
+    if (kReadsC) {   // unconditional loads from clamped addresses, all in flight before the first store
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int row = erow0 + i * 16 + r;
+        row = row < p.M ? row : p.M - 1;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          int c = ecol0 + j * 16;
+          c = c < p.N ? c : p.N - 1;
+          oldv[j][r] = reinterpret_cast<const float*>(p.C)[(long)row * p.ldc + c];
+          gv[j][r] = (EPI == MH_EPI_GATE_RESID) ? p.gate[(long)(row / p.rows_per_batch) * p.gate_ld + c] : 0.f;
+        }
+      }
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = erow0 + i * 16 + r;
@@ -180,11 +202,13 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmP p) {
         for (int j = 0; j < NI; j += 2) {
           // 16-row weight blocks alternate wi_0 / wi_1: fragment j is the gate, j+1 the linear half
           const int ocol = (n0 + wc * WN) / 2 + (j / 2) * 16 + (lane & 15);
-          epilogue_store<T, EPI>(p, row, ocol, acc[i][j][r], acc[i][j + 1][r]);
+          epilogue_store<T, EPI>(p, row, ocol, acc[i][j][r], acc[i][j + 1][r], 0.f, 0.f);
         }
       } else {
 #pragma unroll
-        for (int j = 0; j < NI; ++j) epilogue_store<T, EPI>(p, row, ecol0 + j * 16, acc[i][j][r], 0.f);
+        for (int j = 0; j < NI; ++j)
+          epilogue_store<T, EPI>(p, row, ecol0 + j * 16, acc[i][j][r] + bias_v[j], 0.f, kReadsC ? oldv[j][r] : 0.f,
+                                 kReadsC ? gv[j][r] : 0.f);
       }
     }
   }
