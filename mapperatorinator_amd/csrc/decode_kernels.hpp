@@ -12,6 +12,8 @@
 // weight fragment loaded straight from HBM into registers (no LDS round trip for data used once), and
 // the 4 partial accumulators are combined through LDS in a fixed order (deterministic).
 #pragma once
+#include <type_traits>
+
 #include "internal.hpp"
 
 namespace mh {
@@ -56,16 +58,24 @@ template <> __device__ inline void store4<float>(float* p, float a, float b, flo
 }
 
 // ---- skinny GEMM ----------------------------------------------------------------------------
+// Every kernel has exactly ONE dependent memory round trip: weights, activations, the old residual
+// values and the RMSNorm statistics are all requested before anything is waited for.
+//   RMSNorm without a grid-wide pass: the kernel that PRODUCES the residual stream (a RESID GEMV or the
+//   sampler's embedding gather) also emits per-row partial sums of squares (one per 16-column strip,
+//   fixed order => deterministic); the consumer adds the <= 64 partials, takes rsqrt and normalises its
+//   fp32 A fragments in registers.
 enum { PRO_PLAIN = 0, PRO_RMSNORM = 1 };
 enum { SK_STORE = 0, SK_QKV = 1, SK_GEGLU = 2, SK_RESID = 3, SK_LOGITS = 4 };
 
 struct SkinnyP {
   const void* A; int lda;      // PRO_PLAIN: T [B, lda];  PRO_RMSNORM: fp32 residual stream [B, lda]
   const float* ln_w; float eps;
+  const float* ss_in; int ss_parts;   // PRO_RMSNORM: [ss_parts][64] partial sums of squares of the rows of A
   const void* W; int ldw;      // [N, ldw] element type T
   int B, N, K;
   void* out; int ldo;          // STORE: T [B, ldo]; GEGLU: T [B, ldo] (N/2 cols); LOGITS: f32 [B, ldo]
   float* h; int ldh;           // RESID: h[b][n] += acc
+  float* ss_out;               // RESID: [N/16][64] partial sums of squares of the updated rows
   void* kc; void* vc;          // QKV: this layer's self-attention caches [B][H][tgt_len][64]
   int H, tgt_len, inner;
   const int* pos;
@@ -73,28 +83,39 @@ struct SkinnyP {
 
 template <typename T> struct VecOps;
 template <> struct VecOps<bf16_t> {
-  static constexpr int NMMA = 1;  // MFMAs per 16-byte fragment vector
+  struct Raw { float4 a, b; };   // 8 consecutive fp32 values (one lane's k-chunk)
+  __device__ static inline Raw load_raw(const float* p) {
+    Raw r;
+    r.a = *reinterpret_cast<const float4*>(p);
+    r.b = *reinterpret_cast<const float4*>(p + 4);
+    return r;
+  }
+  __device__ static inline uint4 norm_frag(const Raw& x, const Raw& g, float rs) {
+    const uint32_t o0 = (uint32_t)f32_to_bf16(g.a.x * (x.a.x * rs)) | ((uint32_t)f32_to_bf16(g.a.y * (x.a.y * rs)) << 16);
+    const uint32_t o1 = (uint32_t)f32_to_bf16(g.a.z * (x.a.z * rs)) | ((uint32_t)f32_to_bf16(g.a.w * (x.a.w * rs)) << 16);
+    const uint32_t o2 = (uint32_t)f32_to_bf16(g.b.x * (x.b.x * rs)) | ((uint32_t)f32_to_bf16(g.b.y * (x.b.y * rs)) << 16);
+    const uint32_t o3 = (uint32_t)f32_to_bf16(g.b.z * (x.b.z * rs)) | ((uint32_t)f32_to_bf16(g.b.w * (x.b.w * rs)) << 16);
+    return make_uint4(o0, o1, o2, o3);
+  }
   __device__ static inline f32x4_t mma(const uint4& a, const uint4& b, f32x4_t c) {
     union U { uint4 u; bf16x8_t f; };
     U ua, ub;
     ua.u = a; ub.u = b;
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(ua.f, ub.f, c, 0, 0, 0);
   }
-  // normalised fp32 values -> one 16-byte fragment (8 k's)
-  __device__ static inline uint4 norm_frag(const float* hrow, const float* w, float rs) {
-    float x[8], g[8], y[8];
-    load8<float>(hrow, x);
-    load8<float>(w, g);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) y[i] = g[i] * (x[i] * rs);
-    uint32_t o[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) o[i] = (uint32_t)f32_to_bf16(y[2 * i]) | ((uint32_t)f32_to_bf16(y[2 * i + 1]) << 16);
-    return make_uint4(o[0], o[1], o[2], o[3]);
-  }
+  static constexpr int kRawRegs = 8;
 };
 template <> struct VecOps<float> {
-  static constexpr int NMMA = 4;
+  struct Raw { float4 a; };
+  __device__ static inline Raw load_raw(const float* p) {
+    Raw r;
+    r.a = *reinterpret_cast<const float4*>(p);
+    return r;
+  }
+  __device__ static inline uint4 norm_frag(const Raw& x, const Raw& g, float rs) {
+    return make_uint4(__float_as_uint(g.a.x * (x.a.x * rs)), __float_as_uint(g.a.y * (x.a.y * rs)),
+                      __float_as_uint(g.a.z * (x.a.z * rs)), __float_as_uint(g.a.w * (x.a.w * rs)));
+  }
   __device__ static inline f32x4_t mma(const uint4& a, const uint4& b, f32x4_t c) {
     // k permutation: element i of every lane's 4-float vector forms one 16x16x4 product
     c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
@@ -103,77 +124,54 @@ template <> struct VecOps<float> {
     c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
     return c;
   }
-  __device__ static inline uint4 norm_frag(const float* hrow, const float* w, float rs) {
-    const float4 x = *reinterpret_cast<const float4*>(hrow);
-    const float4 g = *reinterpret_cast<const float4*>(w);
-    return make_uint4(__float_as_uint(g.x * (x.x * rs)), __float_as_uint(g.y * (x.y * rs)),
-                      __float_as_uint(g.z * (x.z * rs)), __float_as_uint(g.w * (x.w * rs)));
-  }
+  static constexpr int kRawRegs = 4;
 };
 
-
-// Dynamic LDS layout of skinny_gemm_kernel:
-//   [ normalised A tile : MF*16 rows x (K*sizeof(T) + 16) bytes ]   (PRO_RMSNORM only)
-//   [ cross-wave reduction buffer : 4 x NS x MF x 64 x f32x4 ]      (aliases the A tile after the K loop)
+// k-blocks per wave whose loads are all in flight at once, bounded by the register budget
 template <typename T, int MF, int NS, int PRO>
-inline size_t skinny_smem_bytes(int K) {
-  const size_t a = PRO == PRO_RMSNORM ? (size_t)MF * 16 * ((size_t)K * sizeof(T) + 16) : 0;
-  const size_t r = (size_t)4 * NS * MF * 64 * 16;
-  return a > r ? a : r;
+constexpr int skinny_chunk() {
+  if (PRO == PRO_PLAIN) return 8;
+  const int per = 4 * NS + VecOps<T>::kRawRegs * (MF + 1);
+  return 8 * per <= 200 ? 8 : (6 * per <= 200 ? 6 : (4 * per <= 200 ? 4 : 2));
 }
 
 template <typename T, int MF, int NS, int PRO, int EPI>
 __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyP p) {
   constexpr int VEC = Elem<T>::kVec;   // elements per 16-byte vector (per lane per k-block)
   constexpr int KB = 4 * VEC;          // k elements per k-block (4 lane groups x 16 B)
-  constexpr int CH = 8;                // k-blocks per wave whose loads are all issued before the first MFMA
-  extern __shared__ __attribute__((aligned(16))) char sk_smem[];
+  constexpr int CH = skinny_chunk<T, MF, NS, PRO>();
+  constexpr int NSE = (EPI == SK_GEGLU) ? 1 : NS;
+  typedef typename VecOps<T>::Raw Raw;
+  __shared__ float ssp[4][64];
+  __shared__ f32x4_t red[4 * NS * MF * 64];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l15 = lane & 15, lg = lane >> 4;
   const int strip0 = blockIdx.x * NS;
-  const int a_stride = p.K * (int)sizeof(T) + 16;   // bytes per LDS A row
+  // epilogue role of this thread: one f32x4 accumulator vector (4 rows x 1 column)
+  const int ef = (tid >> 6) % MF, es = (tid >> 6) / MF;
+  const bool epi_thread = tid < NSE * MF * 64;
 
-  if (PRO == PRO_RMSNORM) {
-    // 8 threads per row, 32 rows per pass; a thread keeps its slice of the fp32 residual row in registers
-    // (<= 32 float4 = d_model 1024), so h is read from L2 exactly once per workgroup, all loads in flight.
-    constexpr int NV = 32;
-    const int sub = tid & 7;
-    const int nvec = p.K / 32;           // float4 per thread (K multiple of 32)
-#pragma unroll 1
-    for (int pass = 0; pass < (MF * 16 + 31) / 32; ++pass) {
-      const int row = pass * 32 + (tid >> 3);
-      const bool live = row < p.B && row < MF * 16;
-      const float* hr = reinterpret_cast<const float*>(p.A) + (long)(live ? row : 0) * p.lda + sub * 4;
-      // UNCONDITIONAL loads from clamped addresses, masked afterwards: a predicated load inside an unrolled
-      // loop makes hipcc branch around every load and wait for each one (32 serial L2 round trips)
-      float4 hv[NV];
+  // ---- requests that do not depend on anything: old residual values, RMSNorm statistics ----
+  float oldh[4] = {0.f, 0.f, 0.f, 0.f};
+  if (EPI == SK_RESID && epi_thread) {
+    const int colc = (strip0 + es) * 16 + l15;
 #pragma unroll
-      for (int i = 0; i < NV; ++i) hv[i] = *reinterpret_cast<const float4*>(hr + (i < nvec ? i : nvec - 1) * 32);
-      float ss = 0.f;
-#pragma unroll
-      for (int i = 0; i < NV; ++i) {
-        const float q2 = hv[i].x * hv[i].x + hv[i].y * hv[i].y + hv[i].z * hv[i].z + hv[i].w * hv[i].w;
-        ss += (i < nvec) ? q2 : 0.f;
-      }
-      ss = group_sum<8>(ss);
-      const float rs = live ? rsqrtf(ss / (float)p.K + p.eps) : 0.f;
-      if (row < MF * 16) {
-        T* ar = reinterpret_cast<T*>(sk_smem + (long)row * a_stride);
-        float4 gv[NV];
-#pragma unroll
-        for (int i = 0; i < NV; ++i) gv[i] = *reinterpret_cast<const float4*>(p.ln_w + (i < nvec ? i : nvec - 1) * 32 + sub * 4);
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-          if (i < nvec) {   // LDS stores only (no loads under the branch)
-            const int k = i * 32 + sub * 4;
-            store4<T>(ar + k, gv[i].x * (hv[i].x * rs), gv[i].y * (hv[i].y * rs), gv[i].z * (hv[i].z * rs),
-                      gv[i].w * (hv[i].w * rs));
-          }
-        }
-      }
+    for (int r = 0; r < 4; ++r) {
+      const int row = ef * 16 + lg * 4 + r;
+      oldh[r] = p.h[(long)(row < p.B ? row : p.B - 1) * p.ldh + (colc < p.N ? colc : p.N - 1)];
     }
-    __syncthreads();
+  }
+  if (PRO == PRO_RMSNORM) {
+    const int row = tid & 63, pg = tid >> 6;
+    float a = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int part = pg + 4 * i;
+      const float v = p.ss_in[(part < p.ss_parts ? part : 0) * 64 + row];
+      a += part < p.ss_parts ? v : 0.f;
+    }
+    ssp[pg][row] = a;
   }
 
   f32x4_t acc[NS][MF];
@@ -189,103 +187,115 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyP p) {
     wr = wr < p.N ? wr : p.N - 1;
     Wp[s] = reinterpret_cast<const T*>(p.W) + (long)wr * p.ldw + lg * VEC;
   }
+  int arow[MF];
+#pragma unroll
+  for (int f = 0; f < MF; ++f) arow[f] = (f * 16 + l15) < p.B ? (f * 16 + l15) : p.B - 1;
 
   const int nkb = p.K / KB;
-  // wave w owns k-blocks w, w+4, w+8, ...; CH of them per pass with every load issued up front
-  for (int kb0 = wid; kb0 < nkb; kb0 += 4 * CH) {
+  float rsr[MF];
+#pragma unroll
+  for (int f = 0; f < MF; ++f) rsr[f] = 0.f;
+
+  // wave w owns k-blocks w, w+4, w+8, ...; CH of them per pass, every load issued before the first use.
+  // All addresses are clamped and the loads unconditional (a predicated load in an unrolled loop makes
+  // hipcc branch around each load and wait for it: one L2 round trip per element).
+  auto chunk = [&](int kb0, auto first_tag) {
+    constexpr bool kFirst = decltype(first_tag)::value;
     uint4 wv[CH][NS];
+    uint4 av[CH][MF];
+    Raw hraw[PRO == PRO_RMSNORM ? CH : 1][PRO == PRO_RMSNORM ? MF : 1];
+    Raw graw[PRO == PRO_RMSNORM ? CH : 1];
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
       const int kb = kb0 + 4 * c;
-      const int kel = (kb < nkb ? kb : kb0) * KB;
+      const int kel = (kb < nkb ? kb : wid) * KB;
 #pragma unroll
       for (int s = 0; s < NS; ++s) wv[c][s] = *reinterpret_cast<const uint4*>(Wp[s] + kel);
-    }
-    uint4 av[CH][MF];
+      if (PRO == PRO_PLAIN) {
 #pragma unroll
-    for (int c = 0; c < CH; ++c) {
-      const int kb = kb0 + 4 * c;
-      const int kel = (kb < nkb ? kb : kb0) * KB + lg * VEC;
+        for (int f = 0; f < MF; ++f)
+          av[c][f] = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.A) + (long)arow[f] * p.lda + kel + lg * VEC);
+      } else {
+        graw[c] = VecOps<T>::load_raw(p.ln_w + kel + lg * VEC);
+#pragma unroll
+        for (int f = 0; f < MF; ++f)
+          hraw[c][f] = VecOps<T>::load_raw(reinterpret_cast<const float*>(p.A) + (long)arow[f] * p.lda + kel + lg * VEC);
+      }
+    }
+    if (PRO == PRO_RMSNORM && kFirst) {
+      __syncthreads();   // ssp complete (every wave reaches this exactly once)
 #pragma unroll
       for (int f = 0; f < MF; ++f) {
         const int row = f * 16 + l15;
-        if (PRO == PRO_PLAIN) {
-          const int rc = row < p.B ? row : p.B - 1;   // clamped address, masked value (no predicated load)
-          uint4 t = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.A) + (long)rc * p.lda + kel);
-          const uint32_t keep = row < p.B ? 0xffffffffu : 0u;
-          av[c][f] = make_uint4(t.x & keep, t.y & keep, t.z & keep, t.w & keep);
-        } else {
-          av[c][f] = *reinterpret_cast<const uint4*>(sk_smem + (long)row * a_stride + (long)kel * sizeof(T));
-        }
+        const float ss = (ssp[0][row] + ssp[1][row]) + (ssp[2][row] + ssp[3][row]);
+        rsr[f] = rsqrtf(ss / (float)p.K + p.eps);
       }
     }
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
       if (kb0 + 4 * c < nkb) {
 #pragma unroll
-        for (int s = 0; s < NS; ++s)
+        for (int f = 0; f < MF; ++f) {
+          uint4 a;
+          if (PRO == PRO_PLAIN) a = av[c][f];
+          else a = VecOps<T>::norm_frag(hraw[c][f], graw[c], rsr[f]);
+          if (f * 16 + l15 >= p.B) a = make_uint4(0, 0, 0, 0);   // rows beyond the batch contribute zeros
 #pragma unroll
-          for (int f = 0; f < MF; ++f) acc[s][f] = VecOps<T>::mma(av[c][f], wv[c][s], acc[s][f]);
+          for (int s = 0; s < NS; ++s) acc[s][f] = VecOps<T>::mma(a, wv[c][s], acc[s][f]);
+        }
       }
     }
-  }
+  };
+  chunk(wid, std::true_type{});
+  for (int kb0 = wid + 4 * CH; kb0 < nkb; kb0 += 4 * CH) chunk(kb0, std::false_type{});
 
-  __syncthreads();   // every wave is done with the A tile: the reduction buffer may alias it
-  f32x4_t* red = reinterpret_cast<f32x4_t*>(sk_smem);   // [4][NS][MF][64]
 #pragma unroll
   for (int s = 0; s < NS; ++s)
 #pragma unroll
     for (int f = 0; f < MF; ++f) red[((wid * NS + s) * MF + f) * 64 + lane] = acc[s][f];
   __syncthreads();
+  if (!epi_thread) return;
 
   const int pos = (EPI == SK_QKV) ? *p.pos : 0;
-  constexpr int NSE = (EPI == SK_GEGLU) ? 1 : NS;
-  for (int idx = tid; idx < NSE * MF * 64; idx += 256) {
-    const int ln = idx & 63, f = (idx >> 6) % MF, s = (idx >> 6) / MF;
-    f32x4_t v = red[((0 * NS + s) * MF + f) * 64 + ln];
+  f32x4_t v = red[((0 * NS + es) * MF + ef) * 64 + lane];
+#pragma unroll
+  for (int w = 1; w < 4; ++w) {
+    const f32x4_t t = red[((w * NS + es) * MF + ef) * 64 + lane];
+    v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
+  }
+  f32x4_t u = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  if (EPI == SK_GEGLU) {
+    u = red[((0 * NS + 1) * MF + ef) * 64 + lane];
 #pragma unroll
     for (int w = 1; w < 4; ++w) {
-      const f32x4_t t = red[((w * NS + s) * MF + f) * 64 + ln];
-      v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
+      const f32x4_t t = red[((w * NS + 1) * MF + ef) * 64 + lane];
+      u[0] += t[0]; u[1] += t[1]; u[2] += t[2]; u[3] += t[3];
     }
-    f32x4_t u = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = ef * 16 + lg * 4 + r;
+    const bool rok = row < p.B;
     if (EPI == SK_GEGLU) {
-      u = red[((0 * NS + 1) * MF + f) * 64 + ln];
-#pragma unroll
-      for (int w = 1; w < 4; ++w) {
-        const f32x4_t t = red[((w * NS + 1) * MF + f) * 64 + ln];
-        u[0] += t[0]; u[1] += t[1]; u[2] += t[2]; u[3] += t[3];
-      }
+      const int col = (strip0 / 2) * 16 + l15;
+      if (rok && col < p.N / 2)
+        reinterpret_cast<T*>(p.out)[(long)row * p.ldo + col] = Elem<T>::from_f32(gelu_tanh(v[r]) * u[r]);
+      continue;
     }
-    const int c15 = ln & 15;
-    float oldh[4] = {0.f, 0.f, 0.f, 0.f};
-    if (EPI == SK_RESID) {   // unconditional loads of the residual stream from clamped addresses
-      const int colc = (strip0 + s) * 16 + c15;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = f * 16 + (ln >> 4) * 4 + r;
-        oldh[r] = p.h[(long)(row < p.B ? row : p.B - 1) * p.ldh + (colc < p.N ? colc : p.N - 1)];
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = f * 16 + (ln >> 4) * 4 + r;
-      if (row >= p.B) continue;
-      if (EPI == SK_GEGLU) {
-        const int col = (strip0 / 2) * 16 + c15;
-        if (col < p.N / 2)
-          reinterpret_cast<T*>(p.out)[(long)row * p.ldo + col] = Elem<T>::from_f32(gelu_tanh(v[r]) * u[r]);
-        continue;
-      }
-      const int col = (strip0 + s) * 16 + c15;
-      if (col >= p.N) continue;
-      if (EPI == SK_STORE) {
-        reinterpret_cast<T*>(p.out)[(long)row * p.ldo + col] = Elem<T>::from_f32(v[r]);
-      } else if (EPI == SK_LOGITS) {
-        reinterpret_cast<float*>(p.out)[(long)row * p.ldo + col] = v[r];
-      } else if (EPI == SK_RESID) {
-        p.h[(long)row * p.ldh + col] = oldh[r] + v[r];
-      } else if (EPI == SK_QKV) {
+    const int col = (strip0 + es) * 16 + l15;
+    const bool ok = rok && col < p.N;
+    if (EPI == SK_STORE) {
+      if (ok) reinterpret_cast<T*>(p.out)[(long)row * p.ldo + col] = Elem<T>::from_f32(v[r]);
+    } else if (EPI == SK_LOGITS) {
+      if (ok) reinterpret_cast<float*>(p.out)[(long)row * p.ldo + col] = v[r];
+    } else if (EPI == SK_RESID) {
+      const float hn = oldh[r] + v[r];
+      if (ok) p.h[(long)row * p.ldh + col] = hn;
+      // partial sum of squares of this strip for the next RMSNorm (all 64 lanes take part in the shuffle)
+      const float sq = group_sum<16>(ok ? hn * hn : 0.f);
+      if (l15 == 0) p.ss_out[(long)(strip0 + es) * 64 + row] = sq;
+    } else if (EPI == SK_QKV) {
+      if (ok) {
         const int part = col / p.inner, c = col - part * p.inner;
         if (part == 0) {
           reinterpret_cast<T*>(p.out)[(long)row * p.ldo + c] = Elem<T>::from_f32(v[r]);

@@ -139,6 +139,7 @@ struct SampleP {
   int32_t* last_ts_val;               // [B] value of the last TIME_SHIFT after the last SOS, -1 if none
   float* logits_dump;                 // [max_length][B][V] or null
   const void* dec_embed; float* h; int d;
+  float* ss;                          // [64] sum of squares of the embedded row (RMSNorm statistics, 1 part)
   MhSampling sp;
   DecState* st;
   int B, P;
@@ -176,9 +177,17 @@ __global__ __launch_bounds__(256) void dec_init_kernel(SampleP p) {
     p.finish_col[b] = p.max_length - 1;
     if (b == 0) { p.st->pos = 0; p.st->n_running = p.B; }
   }
+  __shared__ float scratch[8];
   const int tok = p.tokens[(long)b * p.max_length];
   const T* e = reinterpret_cast<const T*>(p.dec_embed) + (long)tok * p.d;
-  for (int i = threadIdx.x; i < p.d; i += 256) p.h[(long)b * p.d + i] = Elem<T>::to_f32(e[i]);
+  float sq = 0.f;
+  for (int i = threadIdx.x; i < p.d; i += 256) {
+    const float v = Elem<T>::to_f32(e[i]);
+    p.h[(long)b * p.d + i] = v;
+    sq += v * v;
+  }
+  sq = block_sum(sq, scratch);
+  if (threadIdx.x == 0) p.ss[b] = sq;
 }
 
 // one workgroup per batch row: processors -> selection -> bookkeeping -> next-token embedding
@@ -333,7 +342,14 @@ __global__ __launch_bounds__(256) void dec_sample_kernel(SampleP p) {
   // embedding of the token that the next step consumes (decoder_embedder, modeling_mapperatorinator.py:205-206)
   const int tok = s_tok;
   const T* e = reinterpret_cast<const T*>(p.dec_embed) + (long)tok * p.d;
-  for (int i = tid; i < p.d; i += 256) p.h[(long)b * p.d + i] = Elem<T>::to_f32(e[i]);
+  float sq = 0.f;
+  for (int i = tid; i < p.d; i += 256) {
+    const float v = Elem<T>::to_f32(e[i]);
+    p.h[(long)b * p.d + i] = v;
+    sq += v * v;
+  }
+  sq = block_sum(sq, sf);
+  if (tid == 0) p.ss[b] = sq;   // RMSNorm statistics of the new residual row (one part)
 }
 
 __global__ void dec_advance_kernel(DecState* st, const uint8_t* finished, int B) {
@@ -353,44 +369,17 @@ __global__ void dec_finalize_kernel(const int32_t* finish_col, int B, int32_t* n
   }
 }
 
-constexpr size_t kSkinnyMaxLds = 160 * 1024;
-
 template <typename T, int MF, int NS, int PRO, int EPI>
 int launch_skinny(const dec::SkinnyP& p, hipStream_t s) {
   const int strips = ceil_div(p.N, 16);
-  const size_t smem = dec::skinny_smem_bytes<T, MF, NS, PRO>(p.K);
-  MH_REQUIRE(smem <= kSkinnyMaxLds, "decode: batch %d x d_model %d does not fit the LDS tile of the skinny GEMM", p.B, p.K);
-  MH_REQUIRE(PRO != dec::PRO_RMSNORM || p.K <= 1024, "decode: d_model %d > 1024 is not built", p.K);
-  hipLaunchKernelGGL((dec::skinny_gemm_kernel<T, MF, NS, PRO, EPI>), dim3(ceil_div(strips, NS)), dim3(256), smem, s, p);
+  const int kb = 4 * (16 / (int)sizeof(T));
+  MH_REQUIRE(p.K % kb == 0 && p.K / kb >= 4, "decode: K=%d must be a multiple of %d and >= %d", p.K, kb, 4 * kb);
+  MH_REQUIRE(PRO != dec::PRO_RMSNORM || (p.ss_in && p.ss_parts >= 1 && p.ss_parts <= 64), "decode: bad RMSNorm statistics");
+  MH_REQUIRE(EPI != dec::SK_RESID || (p.ss_out && p.N % 16 == 0 && p.N / 16 <= 64), "decode: RESID needs N %% 16 == 0, N <= 1024");
+  hipLaunchKernelGGL((dec::skinny_gemm_kernel<T, MF, NS, PRO, EPI>), dim3(ceil_div(strips, NS)), dim3(256), 0, s, p);
   return check_launch("skinny_gemm_kernel");
 }
 
-// > 64 KiB of dynamic LDS needs an explicit opt-in per kernel: done once, outside any stream capture
-template <typename T, int MF, int NS, int PRO, int EPI>
-bool skinny_prepare_one() {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(&dec::skinny_gemm_kernel<T, MF, NS, PRO, EPI>),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSkinnyMaxLds) == hipSuccess;
-}
-template <typename T, int MF>
-bool skinny_prepare_mf() {
-  return skinny_prepare_one<T, MF, 1, dec::PRO_RMSNORM, dec::SK_QKV>() &&
-         skinny_prepare_one<T, MF, 1, dec::PRO_PLAIN, dec::SK_RESID>() &&
-         skinny_prepare_one<T, MF, 1, dec::PRO_RMSNORM, dec::SK_STORE>() &&
-         skinny_prepare_one<T, MF, 2, dec::PRO_RMSNORM, dec::SK_GEGLU>() &&
-         skinny_prepare_one<T, MF, 1, dec::PRO_RMSNORM, dec::SK_LOGITS>();
-}
-int skinny_prepare() {
-  static bool done = false;
-  if (done) return MH_OK;
-  const bool ok = skinny_prepare_mf<bf16_t, 1>() && skinny_prepare_mf<bf16_t, 2>() && skinny_prepare_mf<bf16_t, 4>() &&
-                  skinny_prepare_mf<float, 1>() && skinny_prepare_mf<float, 2>() && skinny_prepare_mf<float, 4>();
-  if (!ok) {
-    set_error("skinny_prepare: hipFuncSetAttribute failed: %s", hipGetErrorString(hipGetLastError()));
-    return MH_ERR_LAUNCH;
-  }
-  done = true;
-  return MH_OK;
-}
 template <typename T, int NS, int PRO, int EPI>
 int skinny(const dec::SkinnyP& p, hipStream_t s) {
   if (p.B <= 16) return launch_skinny<T, 1, NS, PRO, EPI>(p, s);
@@ -399,7 +388,7 @@ int skinny(const dec::SkinnyP& p, hipStream_t s) {
 }
 
 struct DecBuffers {
-  float* h; void* q; void* attn; void* ff; float* logits; float* part;
+  float* h; void* q; void* attn; void* ff; float* logits; float* part; float* ss;
   void* self_k; void* self_v;  // [n_dec][B][H][tgt][64]
   uint8_t* finished; int32_t* finish_col; int32_t* last_ts; DecState* st;
   int splits;
@@ -422,6 +411,7 @@ int enqueue_step(const MhT5Config* c, const MhT5Weights* w, const void* cross_kv
     // self attention
     sk = dec::SkinnyP{};
     sk.A = bf.h; sk.lda = d; sk.ln_w = w->dec_ln1[l]; sk.eps = c->eps; sk.W = w->dec_qkv[l]; sk.ldw = d; sk.B = B;
+    sk.ss_in = bf.ss; sk.ss_parts = (l == 0) ? 1 : d / 16;
     sk.N = 3 * inner; sk.K = d; sk.out = bf.q; sk.ldo = inner; sk.kc = (char*)bf.self_k + cache_off;
     sk.vc = (char*)bf.self_v + cache_off; sk.H = H; sk.tgt_len = tgt; sk.inner = inner; sk.pos = posp;
     MH_TRY((skinny<T, 1, dec::PRO_RMSNORM, dec::SK_QKV>(sk, s)));
@@ -432,12 +422,12 @@ int enqueue_step(const MhT5Config* c, const MhT5Weights* w, const void* cross_kv
     MH_TRY(check_launch("dec_self_attn_kernel"));
     sk = dec::SkinnyP{};
     sk.A = bf.attn; sk.lda = inner; sk.W = w->dec_o[l]; sk.ldw = inner; sk.B = B; sk.N = d; sk.K = inner; sk.h = bf.h;
-    sk.ldh = d;
+    sk.ldh = d; sk.ss_out = bf.ss;
     MH_TRY((skinny<T, 1, dec::PRO_PLAIN, dec::SK_RESID>(sk, s)));
     // cross attention
     sk = dec::SkinnyP{};
     sk.A = bf.h; sk.lda = d; sk.ln_w = w->dec_ln2[l]; sk.eps = c->eps; sk.W = w->dec_cq[l]; sk.ldw = d; sk.B = B;
-    sk.N = inner; sk.K = d; sk.out = bf.q; sk.ldo = inner;
+    sk.N = inner; sk.K = d; sk.out = bf.q; sk.ldo = inner; sk.ss_in = bf.ss; sk.ss_parts = d / 16;
     MH_TRY((skinny<T, 1, dec::PRO_RMSNORM, dec::SK_STORE>(sk, s)));
     dec::CrossAttnP ca{};
     const long kv_layer = (long)B * H * L * 64 * es;
@@ -452,21 +442,21 @@ int enqueue_step(const MhT5Config* c, const MhT5Weights* w, const void* cross_kv
     }
     sk = dec::SkinnyP{};
     sk.A = bf.attn; sk.lda = inner; sk.W = w->dec_co[l]; sk.ldw = inner; sk.B = B; sk.N = d; sk.K = inner; sk.h = bf.h;
-    sk.ldh = d;
+    sk.ldh = d; sk.ss_out = bf.ss;
     MH_TRY((skinny<T, 1, dec::PRO_PLAIN, dec::SK_RESID>(sk, s)));
     // feed forward
     sk = dec::SkinnyP{};
     sk.A = bf.h; sk.lda = d; sk.ln_w = w->dec_ln3[l]; sk.eps = c->eps; sk.W = w->dec_wi[l]; sk.ldw = d; sk.B = B;
-    sk.N = 2 * dff; sk.K = d; sk.out = bf.ff; sk.ldo = dff;
+    sk.N = 2 * dff; sk.K = d; sk.out = bf.ff; sk.ldo = dff; sk.ss_in = bf.ss; sk.ss_parts = d / 16;
     MH_TRY((skinny<T, 2, dec::PRO_RMSNORM, dec::SK_GEGLU>(sk, s)));
     sk = dec::SkinnyP{};
     sk.A = bf.ff; sk.lda = dff; sk.W = w->dec_wo[l]; sk.ldw = dff; sk.B = B; sk.N = d; sk.K = dff; sk.h = bf.h;
-    sk.ldh = d;
+    sk.ldh = d; sk.ss_out = bf.ss;
     MH_TRY((skinny<T, 1, dec::PRO_PLAIN, dec::SK_RESID>(sk, s)));
   }
   dec::SkinnyP sk{};
   sk.A = bf.h; sk.lda = d; sk.ln_w = w->dec_final_ln; sk.eps = c->eps; sk.W = w->lm_head; sk.ldw = d; sk.B = B;
-  sk.N = c->vocab_out; sk.K = d; sk.out = bf.logits; sk.ldo = c->vocab_out;
+  sk.N = c->vocab_out; sk.K = d; sk.out = bf.logits; sk.ldo = c->vocab_out; sk.ss_in = bf.ss; sk.ss_parts = d / 16;
   MH_TRY((skinny<T, 1, dec::PRO_RMSNORM, dec::SK_LOGITS>(sk, s)));
   hipLaunchKernelGGL(dec_sample_kernel<T>, dim3(B), dim3(256), 0, s, smp);
   MH_TRY(check_launch("dec_sample_kernel"));
@@ -488,6 +478,7 @@ extern "C" int64_t mh_t5_decode_workspace_bytes(const MhT5Config* c, int B) {
   t += align256((int64_t)B * c->d_ff * es);                                       // ff
   t += align256((int64_t)B * c->vocab_out * 4);                                   // logits
   t += align256((int64_t)B * c->n_heads * 8 * 66 * 4);                            // cross partials
+  t += align256(64 * 64 * 4);                                                     // RMSNorm partial sums of squares
   t += align256((int64_t)c->n_dec_layers * B * inner * c->tgt_len * es) * 2;      // self K, V caches
   t += align256(B) + align256((int64_t)B * 4) * 2 + align256(sizeof(DecState));   // flags / state
   return t;
@@ -520,6 +511,7 @@ extern "C" int mh_t5_generate(const MhT5Config* c, const MhT5Weights* w, const v
   bf.ff = ar.take((int64_t)B * c->d_ff * es);
   bf.logits = (float*)ar.take((int64_t)B * c->vocab_out * 4);
   bf.part = (float*)ar.take((int64_t)B * c->n_heads * 8 * 66 * 4);
+  bf.ss = (float*)ar.take(64 * 64 * 4);
   bf.self_k = ar.take((int64_t)c->n_dec_layers * B * inner * c->tgt_len * es);
   bf.self_v = ar.take((int64_t)c->n_dec_layers * B * inner * c->tgt_len * es);
   bf.finished = (uint8_t*)ar.take(B);
@@ -538,14 +530,13 @@ extern "C" int mh_t5_generate(const MhT5Config* c, const MhT5Weights* w, const v
   smp.logits = bf.logits; smp.ldl = c->vocab_out; smp.V = c->vocab_out; smp.tokens = tokens;
   smp.max_length = sp->max_length; smp.forced = forced; smp.eos_table = eos_table; smp.finished = bf.finished;
   smp.finish_col = bf.finish_col; smp.last_ts_val = bf.last_ts; smp.logits_dump = logits_dump;
-  smp.dec_embed = w->dec_embed; smp.h = bf.h; smp.d = c->d_model; smp.sp = *sp; smp.st = bf.st; smp.B = B; smp.P = P;
+  smp.dec_embed = w->dec_embed; smp.h = bf.h; smp.d = c->d_model; smp.ss = bf.ss; smp.sp = *sp; smp.st = bf.st; smp.B = B; smp.P = P;
 
   const bool bf16 = c->dtype == MH_BF16;
   if (bf16) hipLaunchKernelGGL(dec_init_kernel<bf16_t>, dim3(B), dim3(256), 0, s, smp);
   else hipLaunchKernelGGL(dec_init_kernel<float>, dim3(B), dim3(256), 0, s, smp);
   MH_TRY(check_launch("dec_init_kernel"));
 
-  MH_TRY(skinny_prepare());
   // capture one step (all kernels read the position from device memory) and replay it
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
