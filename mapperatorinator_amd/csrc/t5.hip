@@ -6,6 +6,8 @@
 //   HF T5Stack / T5Block / T5Attention / T5LayerFF (pre-norm residual blocks, shared layer-0 relative
 //   bias, no 1/sqrt(d) scaling, gated gelu_new FFN), HF GenerationMixin._sample under
 //   model_generate (osuT5/osuT5/inference/server.py:83-156) with the reference logits processors.
+#include <stdlib.h>
+
 #include <vector>
 
 #include "decode_kernels.hpp"
@@ -142,7 +144,8 @@ struct SampleP {
   float* ss;                          // [64] sum of squares of the embedded row (RMSNorm statistics, 1 part)
   MhSampling sp;
   DecState* st;
-  int B, P;
+  int B, P;                           // B = rows of the WHOLE batch (logits_dump stride)
+  int b0;                             // first global row of this chain; logits / h / ss are chain-local
 };
 
 __device__ inline void update_ts_state(const MhSampling& sp, int tok, int32_t* last_ts_val) {
@@ -167,15 +170,15 @@ __device__ inline float uniform01(uint64_t seed, uint32_t row, uint32_t step) {
 
 // init: consume column 0 of the prompt (state machine + embedding of the first token)
 template <typename T>
-__global__ __launch_bounds__(256) void dec_init_kernel(SampleP p) {
-  const int b = blockIdx.x;
+__global__ __launch_bounds__(256) void dec_init_kernel(SampleP p, int chain_rows) {
+  const int lb = blockIdx.x, b = p.b0 + lb;
   if (threadIdx.x == 0) {
     int32_t v = -1;
     update_ts_state(p.sp, p.tokens[(long)b * p.max_length], &v);
     p.last_ts_val[b] = v;
     p.finished[b] = 0;
     p.finish_col[b] = p.max_length - 1;
-    if (b == 0) { p.st->pos = 0; p.st->n_running = p.B; }
+    if (lb == 0) { p.st->pos = 0; p.st->n_running = chain_rows; }
   }
   __shared__ float scratch[8];
   const int tok = p.tokens[(long)b * p.max_length];
@@ -183,11 +186,11 @@ __global__ __launch_bounds__(256) void dec_init_kernel(SampleP p) {
   float sq = 0.f;
   for (int i = threadIdx.x; i < p.d; i += 256) {
     const float v = Elem<T>::to_f32(e[i]);
-    p.h[(long)b * p.d + i] = v;
+    p.h[(long)lb * p.d + i] = v;
     sq += v * v;
   }
   sq = block_sum(sq, scratch);
-  if (threadIdx.x == 0) p.ss[b] = sq;
+  if (threadIdx.x == 0) p.ss[lb] = sq;
 }
 
 // one workgroup per batch row: processors -> selection -> bookkeeping -> next-token embedding
@@ -197,7 +200,7 @@ __global__ __launch_bounds__(256) void dec_sample_kernel(SampleP p) {
   __shared__ int si[8];
   __shared__ int s_tok;
   __shared__ float s_sum;
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int lb = blockIdx.x, b = p.b0 + lb, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int pos = p.st->pos;
   const int col = pos + 1;  // column being produced
   const MhSampling& sp = p.sp;
@@ -212,7 +215,7 @@ __global__ __launch_bounds__(256) void dec_sample_kernel(SampleP p) {
     }
     __syncthreads();
   } else {
-    const float* lg = p.logits + (long)b * p.ldl;
+    const float* lg = p.logits + (long)lb * p.ldl;
     const int ltv = p.last_ts_val[b];
     float best = -INFINITY;
     int besti = 0x7fffffff;
@@ -345,11 +348,11 @@ __global__ __launch_bounds__(256) void dec_sample_kernel(SampleP p) {
   float sq = 0.f;
   for (int i = tid; i < p.d; i += 256) {
     const float v = Elem<T>::to_f32(e[i]);
-    p.h[(long)b * p.d + i] = v;
+    p.h[(long)lb * p.d + i] = v;
     sq += v * v;
   }
   sq = block_sum(sq, sf);
-  if (tid == 0) p.ss[b] = sq;   // RMSNorm statistics of the new residual row (one part)
+  if (tid == 0) p.ss[lb] = sq;   // RMSNorm statistics of the new residual row (one part)
 }
 
 __global__ void dec_advance_kernel(DecState* st, const uint8_t* finished, int B) {
@@ -387,6 +390,8 @@ int skinny(const dec::SkinnyP& p, hipStream_t s) {
   return launch_skinny<T, 4, NS, PRO, EPI>(p, s);
 }
 
+constexpr int kMaxChains = 8;
+
 struct DecBuffers {
   float* h; void* q; void* attn; void* ff; float* logits; float* part; float* ss;
   void* self_k; void* self_v;  // [n_dec][B][H][tgt][64]
@@ -400,13 +405,15 @@ struct DecBuffers {
 int cross_splits(int /*B*/, int /*H*/) { return 4; }
 
 template <typename T>
-int enqueue_step(const MhT5Config* c, const MhT5Weights* w, const void* cross_kv, int B, const uint8_t* prompt_mask,
-                 int P, const DecBuffers& bf, const SampleP& smp, hipStream_t s) {
+int enqueue_step(const MhT5Config* c, const MhT5Weights* w, const void* cross_kv, int B, int Bfull,
+                 const uint8_t* prompt_mask, int P, const DecBuffers& bf, const SampleP& smp, hipStream_t s) {
+  // B rows of one chain; every pointer in `bf` / `cross_kv` / `prompt_mask` already points at the chain's first
+  // row, only the per-layer strides of the caches use the full batch size.
   const int d = c->d_model, H = c->n_heads, inner = H * 64, dff = c->d_ff, L = c->src_len, tgt = c->tgt_len;
   const int es = (int)sizeof(T);
   const int* posp = &bf.st->pos;
   for (int l = 0; l < c->n_dec_layers; ++l) {
-    const long cache_off = (long)l * B * H * tgt * 64 * es;
+    const long cache_off = (long)l * Bfull * H * tgt * 64 * es;
     dec::SkinnyP sk{};
     // self attention
     sk = dec::SkinnyP{};
@@ -430,7 +437,7 @@ int enqueue_step(const MhT5Config* c, const MhT5Weights* w, const void* cross_kv
     sk.N = inner; sk.K = d; sk.out = bf.q; sk.ldo = inner; sk.ss_in = bf.ss; sk.ss_parts = d / 16;
     MH_TRY((skinny<T, 1, dec::PRO_RMSNORM, dec::SK_STORE>(sk, s)));
     dec::CrossAttnP ca{};
-    const long kv_layer = (long)B * H * L * 64 * es;
+    const long kv_layer = (long)Bfull * H * L * 64 * es;
     ca.q = bf.q; ca.ldq = inner; ca.k = (const char*)cross_kv + (long)(l * 2 + 0) * kv_layer;
     ca.v = (const char*)cross_kv + (long)(l * 2 + 1) * kv_layer; ca.out = bf.attn; ca.ldo = inner; ca.part = bf.part;
     ca.B = B; ca.H = H; ca.L = L; ca.splits = bf.splits;
@@ -478,11 +485,52 @@ extern "C" int64_t mh_t5_decode_workspace_bytes(const MhT5Config* c, int B) {
   t += align256((int64_t)B * c->d_ff * es);                                       // ff
   t += align256((int64_t)B * c->vocab_out * 4);                                   // logits
   t += align256((int64_t)B * c->n_heads * 8 * 66 * 4);                            // cross partials
-  t += align256(64 * 64 * 4);                                                     // RMSNorm partial sums of squares
+  t += align256(64 * 64 * 4) * kMaxChains;                                        // RMSNorm partial sums of squares
   t += align256((int64_t)c->n_dec_layers * B * inner * c->tgt_len * es) * 2;      // self K, V caches
-  t += align256(B) + align256((int64_t)B * 4) * 2 + align256(sizeof(DecState));   // flags / state
+  t += align256(B) + align256((int64_t)B * 4) * 2 + align256(sizeof(DecState)) * kMaxChains;   // flags / state
   return t;
 }
+
+namespace mh {
+namespace {
+
+// Independent rows => independent "chains": the batch is cut into contiguous blocks of rows and every
+// block runs its own captured decode step on its own stream.  A decode step is ~110 dependent, mostly
+// tiny kernels (each costs a few microseconds of dispatch + drain whatever its size), so one chain leaves
+// the GPU idle most of the time; several chains overlap one another's dispatch gaps and let the
+// HBM-bound cross-attention of one chain run under the latency-bound GEMVs of the others.  Results do not
+// depend on the chain count (every kernel is batch-invariant by construction).
+int pick_chains(int B) {
+  int n = B >= 32 ? 4 : (B >= 16 ? 2 : 1);
+  if (const char* e = getenv("MH_DECODE_CHAINS")) {
+    const int v = atoi(e);
+    if (v >= 1) n = v;
+  }
+  if (n > kMaxChains) n = kMaxChains;
+  if (n > B) n = B;
+  return n;
+}
+
+struct ChainPool {   // extra streams + fork/join events, created once per process
+  hipStream_t streams[kMaxChains] = {};
+  hipEvent_t fork = nullptr, join[kMaxChains] = {};
+  bool ready = false;
+  int init() {
+    if (ready) return MH_OK;
+    if (hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess) return check_launch("event create");
+    for (int i = 0; i < kMaxChains; ++i) {
+      if (hipStreamCreateWithFlags(&streams[i], hipStreamNonBlocking) != hipSuccess ||
+          hipEventCreateWithFlags(&join[i], hipEventDisableTiming) != hipSuccess)
+        return check_launch("chain stream create");
+    }
+    ready = true;
+    return MH_OK;
+  }
+};
+ChainPool g_pool;
+
+}  // namespace
+}  // namespace mh
 
 extern "C" int mh_t5_generate(const MhT5Config* c, const MhT5Weights* w, const void* cross_kv, int B,
                               const int32_t* prompt, const uint8_t* prompt_mask, int P, const uint8_t* eos_table,
@@ -501,80 +549,121 @@ extern "C" int mh_t5_generate(const MhT5Config* c, const MhT5Weights* w, const v
   MH_REQUIRE(!(sp->do_sample && !logits_dump), "mh_t5_generate: do_sample needs the logits_dump scratch");
   MH_REQUIRE(workspace_bytes >= mh_t5_decode_workspace_bytes(c, B), "mh_t5_generate: workspace too small");
   hipStream_t s = (hipStream_t)stream;
-  const int es = es_of(c->dtype), inner = c->n_heads * 64;
+  const int es = es_of(c->dtype), H = c->n_heads, inner = H * 64, d = c->d_model, V = c->vocab_out;
 
   Arena ar(workspace, workspace_bytes);
-  DecBuffers bf;
-  bf.h = (float*)ar.take((int64_t)B * c->d_model * 4);
-  bf.q = ar.take((int64_t)B * inner * es);
-  bf.attn = ar.take((int64_t)B * inner * es);
-  bf.ff = ar.take((int64_t)B * c->d_ff * es);
-  bf.logits = (float*)ar.take((int64_t)B * c->vocab_out * 4);
-  bf.part = (float*)ar.take((int64_t)B * c->n_heads * 8 * 66 * 4);
-  bf.ss = (float*)ar.take(64 * 64 * 4);
-  bf.self_k = ar.take((int64_t)c->n_dec_layers * B * inner * c->tgt_len * es);
-  bf.self_v = ar.take((int64_t)c->n_dec_layers * B * inner * c->tgt_len * es);
-  bf.finished = (uint8_t*)ar.take(B);
-  bf.finish_col = (int32_t*)ar.take((int64_t)B * 4);
-  bf.last_ts = (int32_t*)ar.take((int64_t)B * 4);
-  bf.st = (DecState*)ar.take(sizeof(DecState));
-  MH_REQUIRE(ar.ok() && bf.st, "mh_t5_generate: arena overflow");
-  bf.splits = cross_splits(B, c->n_heads);
+  DecBuffers all;
+  all.h = (float*)ar.take((int64_t)B * d * 4);
+  all.q = ar.take((int64_t)B * inner * es);
+  all.attn = ar.take((int64_t)B * inner * es);
+  all.ff = ar.take((int64_t)B * c->d_ff * es);
+  all.logits = (float*)ar.take((int64_t)B * V * 4);
+  all.part = (float*)ar.take((int64_t)B * H * 8 * 66 * 4);
+  float* ss_all = (float*)ar.take((int64_t)64 * 64 * 4 * kMaxChains);
+  all.self_k = ar.take((int64_t)c->n_dec_layers * B * inner * c->tgt_len * es);
+  all.self_v = ar.take((int64_t)c->n_dec_layers * B * inner * c->tgt_len * es);
+  all.finished = (uint8_t*)ar.take(B);
+  all.finish_col = (int32_t*)ar.take((int64_t)B * 4);
+  all.last_ts = (int32_t*)ar.take((int64_t)B * 4);
+  DecState* st_all = (DecState*)ar.take((int64_t)align256(sizeof(DecState)) * kMaxChains);
+  MH_REQUIRE(ar.ok() && st_all, "mh_t5_generate: arena overflow");
+  all.splits = cross_splits(B, H);
+
+  const int n_chains = pick_chains(B);
+  const int rows_per = ceil_div(B, n_chains);
+  MH_TRY(g_pool.init());
 
   // tokens[:, :P] = prompt; the remainder is produced by the sampler
   if (hipMemcpy2DAsync(tokens, (size_t)sp->max_length * 4, prompt, (size_t)P * 4, (size_t)P * 4, B,
                        hipMemcpyDeviceToDevice, s) != hipSuccess)
     return check_launch("prompt copy");
-
-  SampleP smp{};
-  smp.logits = bf.logits; smp.ldl = c->vocab_out; smp.V = c->vocab_out; smp.tokens = tokens;
-  smp.max_length = sp->max_length; smp.forced = forced; smp.eos_table = eos_table; smp.finished = bf.finished;
-  smp.finish_col = bf.finish_col; smp.last_ts_val = bf.last_ts; smp.logits_dump = logits_dump;
-  smp.dec_embed = w->dec_embed; smp.h = bf.h; smp.d = c->d_model; smp.ss = bf.ss; smp.sp = *sp; smp.st = bf.st; smp.B = B; smp.P = P;
+  if (hipEventRecord(g_pool.fork, s) != hipSuccess) return check_launch("fork record");
 
   const bool bf16 = c->dtype == MH_BF16;
-  if (bf16) hipLaunchKernelGGL(dec_init_kernel<bf16_t>, dim3(B), dim3(256), 0, s, smp);
-  else hipLaunchKernelGGL(dec_init_kernel<float>, dim3(B), dim3(256), 0, s, smp);
-  MH_TRY(check_launch("dec_init_kernel"));
+  hipGraph_t graphs[kMaxChains] = {};
+  hipGraphExec_t execs[kMaxChains] = {};
+  DecState* states[kMaxChains] = {};
+  int used = 0, rc = MH_OK;
+  for (int ci = 0; ci < n_chains && rc == MH_OK; ++ci) {
+    const int b0 = ci * rows_per;
+    const int Bc = (b0 + rows_per <= B) ? rows_per : B - b0;
+    if (Bc <= 0) break;
+    hipStream_t cs = g_pool.streams[ci];
+    if (hipStreamWaitEvent(cs, g_pool.fork, 0) != hipSuccess) { rc = check_launch("fork wait"); break; }
+    DecBuffers bf = all;
+    bf.h = all.h + (long)b0 * d;
+    bf.q = (char*)all.q + (long)b0 * inner * es;
+    bf.attn = (char*)all.attn + (long)b0 * inner * es;
+    bf.ff = (char*)all.ff + (long)b0 * c->d_ff * es;
+    bf.logits = all.logits + (long)b0 * V;
+    bf.part = all.part + (long)b0 * H * 8 * 66;
+    bf.ss = ss_all + (long)ci * 64 * 64;
+    bf.self_k = (char*)all.self_k + (long)b0 * inner * c->tgt_len * es;
+    bf.self_v = (char*)all.self_v + (long)b0 * inner * c->tgt_len * es;
+    bf.finished = all.finished + b0;
+    bf.st = (DecState*)((char*)st_all + (long)ci * align256(sizeof(DecState)));
+    states[ci] = bf.st;
+    const void* ckv = (const char*)cross_kv + (long)b0 * H * c->src_len * 64 * es;
+    const uint8_t* pm = prompt_mask ? prompt_mask + (long)b0 * P : nullptr;
 
-  // capture one step (all kernels read the position from device memory) and replay it
-  hipGraph_t graph = nullptr;
-  hipGraphExec_t exec = nullptr;
-  if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) return check_launch("begin capture");
-  int rc = bf16 ? enqueue_step<bf16_t>(c, w, cross_kv, B, prompt_mask, P, bf, smp, s)
-                : enqueue_step<float>(c, w, cross_kv, B, prompt_mask, P, bf, smp, s);
-  hipError_t ce = hipStreamEndCapture(s, &graph);
-  if (rc != MH_OK) { if (graph) hipGraphDestroy(graph); return rc; }
-  if (ce != hipSuccess || !graph) { set_error("mh_t5_generate: stream capture failed: %s", hipGetErrorString(ce)); return MH_ERR_LAUNCH; }
-  if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
-    hipGraphDestroy(graph);
-    return check_launch("graph instantiate");
+    SampleP smp{};
+    smp.logits = bf.logits; smp.ldl = V; smp.V = V; smp.tokens = tokens; smp.max_length = sp->max_length;
+    smp.forced = forced; smp.eos_table = eos_table; smp.finished = all.finished; smp.finish_col = all.finish_col;
+    smp.last_ts_val = all.last_ts; smp.logits_dump = logits_dump; smp.dec_embed = w->dec_embed; smp.h = bf.h;
+    smp.d = d; smp.ss = bf.ss; smp.sp = *sp; smp.st = bf.st; smp.B = B; smp.P = P; smp.b0 = b0;
+
+    if (bf16) hipLaunchKernelGGL(dec_init_kernel<bf16_t>, dim3(Bc), dim3(256), 0, cs, smp, Bc);
+    else hipLaunchKernelGGL(dec_init_kernel<float>, dim3(Bc), dim3(256), 0, cs, smp, Bc);
+    rc = check_launch("dec_init_kernel");
+    if (rc != MH_OK) break;
+    // capture one step of this chain (every kernel reads the position from device memory) for replay
+    if (hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) != hipSuccess) { rc = check_launch("begin capture"); break; }
+    int rce = bf16 ? enqueue_step<bf16_t>(c, w, ckv, Bc, B, pm, P, bf, smp, cs)
+                   : enqueue_step<float>(c, w, ckv, Bc, B, pm, P, bf, smp, cs);
+    hipError_t ce = hipStreamEndCapture(cs, &graphs[ci]);
+    ++used;
+    if (rce != MH_OK) { rc = rce; break; }
+    if (ce != hipSuccess || !graphs[ci]) { set_error("mh_t5_generate: stream capture failed: %s", hipGetErrorString(ce)); rc = MH_ERR_LAUNCH; break; }
+    if (hipGraphInstantiate(&execs[ci], graphs[ci], nullptr, nullptr, 0) != hipSuccess) { rc = check_launch("graph instantiate"); break; }
   }
 
   const int total_steps = sp->max_length - 1;   // positions 0 .. max_length-2 are fed
   if (poll_every <= 0) poll_every = 16;
-  int rc2 = MH_OK;
   int step = 0;
-  while (step < total_steps) {
-    int burst = total_steps - step < poll_every ? total_steps - step : poll_every;
-    for (int i = 0; i < burst; ++i) {
-      if (hipGraphLaunch(exec, s) != hipSuccess) { rc2 = check_launch("graph launch"); break; }
-    }
-    if (rc2 != MH_OK) break;
+  while (rc == MH_OK && step < total_steps) {
+    const int burst = total_steps - step < poll_every ? total_steps - step : poll_every;
+    for (int i = 0; i < burst && rc == MH_OK; ++i)
+      for (int ci = 0; ci < used; ++ci)
+        if (hipGraphLaunch(execs[ci], g_pool.streams[ci]) != hipSuccess) { rc = check_launch("graph launch"); break; }
     step += burst;
-    if (step < total_steps && !forced) {
-      int running = 1;
-      if (hipMemcpyAsync(&running, &bf.st->n_running, 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
-          hipStreamSynchronize(s) != hipSuccess) { rc2 = check_launch("poll"); break; }
-      if (running == 0) break;
+    if (rc == MH_OK && step < total_steps && !forced) {
+      int running[kMaxChains] = {};
+      for (int ci = 0; ci < used; ++ci)
+        if (hipMemcpyAsync(&running[ci], &states[ci]->n_running, 4, hipMemcpyDeviceToHost, g_pool.streams[ci]) != hipSuccess)
+          rc = check_launch("poll");
+      int total = 0;
+      for (int ci = 0; ci < used && rc == MH_OK; ++ci) {
+        if (hipStreamSynchronize(g_pool.streams[ci]) != hipSuccess) rc = check_launch("poll sync");
+        total += running[ci];
+      }
+      if (rc == MH_OK && total == 0) break;
     }
   }
-  hipLaunchKernelGGL(dec_finalize_kernel, dim3(1), dim3(64), 0, s, bf.finish_col, B, n_steps_out);
-  if (rc2 == MH_OK) rc2 = check_launch("dec_finalize_kernel");
-  hipStreamSynchronize(s);   // the graph objects must outlive their launches
-  hipGraphExecDestroy(exec);
-  hipGraphDestroy(graph);
-  return rc2;
+  // join the chains back into the caller's stream
+  for (int ci = 0; ci < used; ++ci) {
+    (void)hipEventRecord(g_pool.join[ci], g_pool.streams[ci]);
+    (void)hipStreamWaitEvent(s, g_pool.join[ci], 0);
+  }
+  if (rc == MH_OK) {
+    hipLaunchKernelGGL(dec_finalize_kernel, dim3(1), dim3(64), 0, s, all.finish_col, B, n_steps_out);
+    rc = check_launch("dec_finalize_kernel");
+  }
+  (void)hipStreamSynchronize(s);   // the graph objects must outlive their launches
+  for (int ci = 0; ci < kMaxChains; ++ci) {
+    if (execs[ci]) (void)hipGraphExecDestroy(execs[ci]);
+    if (graphs[ci]) (void)hipGraphDestroy(graphs[ci]);
+  }
+  return rc;
 }
 
 // ------------------------------------------------------------------------------------------------
