@@ -480,6 +480,8 @@ struct CrossAttnP {
   const void* k; const void* v;  // this layer's [B][H][L][64]
   void* out; int ldo;       // T [B, inner] (splits == 1)
   float* part;              // fp32 [B][H][splits][66] = (m, l, acc[64]) (splits > 1)
+  int* ticket;              // [B*H] arrival counters, zero between launches; non-null: the last-arriving split
+                            // of a (b, h) pair merges the partials in-kernel (no separate merge launch)
   int B, H, L, splits;
 };
 
@@ -514,6 +516,41 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(CrossAttnP p) {
       float* pp = p.part + ((long)pair * p.splits + split) * 66;
       if (d == 0) { pp[0] = m; pp[1] = l; }
       pp[2 + d] = a;
+    }
+  }
+  if (p.splits > 1 && p.ticket) {
+    // Placement-independent hand-off (agent-scope release by every producer, one agent-scope acquire by the
+    // consumer; cdna_hip_programming.md guideline 16): partial stores drained -> barrier -> lane 0 releases,
+    // takes a ticket; the block that draws the last ticket acquires and merges all splits of its pair.
+    __shared__ int s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const int t = __hip_atomic_fetch_add(p.ticket + pair, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = (t == p.splits - 1) ? 1 : 0;
+      if (last) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        p.ticket[pair] = 0;   // re-armed for the next launch (made visible by the kernel boundary)
+      }
+      s_last = last;
+    }
+    __syncthreads();
+    if (s_last && threadIdx.x < 64) {
+      const int d = threadIdx.x;
+      const float* pp = p.part + (long)pair * p.splits * 66;
+      float mm = pp[0], ll = pp[1], aa = pp[2 + d];
+      for (int s2 = 1; s2 < p.splits; ++s2) {   // fixed split order: deterministic
+        const float* ps = pp + s2 * 66;
+        const float m2 = ps[0], l2 = ps[1], a2 = ps[2 + d];
+        const float mn = fmaxf(mm, m2);
+        const float fa = fexp<T>(mm - mn), fb = fexp<T>(m2 - mn);
+        ll = ll * fa + l2 * fb;
+        aa = aa * fa + a2 * fb;
+        mm = mn;
+      }
+      reinterpret_cast<T*>(p.out)[(long)b * p.ldo + h * 64 + d] = Elem<T>::from_f32(ll > 0.f ? aa / ll : 0.f);
     }
   }
 }

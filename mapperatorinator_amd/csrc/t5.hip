@@ -393,7 +393,7 @@ int skinny(const dec::SkinnyP& p, hipStream_t s) {
 constexpr int kMaxChains = 8;
 
 struct DecBuffers {
-  float* h; void* q; void* attn; void* ff; float* logits; float* part; float* ss;
+  float* h; void* q; void* attn; void* ff; float* logits; float* part; float* ss; int* ticket;
   void* self_k; void* self_v;  // [n_dec][B][H][tgt][64]
   uint8_t* finished; int32_t* finish_col; int32_t* last_ts; DecState* st;
   int splits;
@@ -440,10 +440,10 @@ int enqueue_step(const MhT5Config* c, const MhT5Weights* w, const void* cross_kv
     const long kv_layer = (long)Bfull * H * L * 64 * es;
     ca.q = bf.q; ca.ldq = inner; ca.k = (const char*)cross_kv + (long)(l * 2 + 0) * kv_layer;
     ca.v = (const char*)cross_kv + (long)(l * 2 + 1) * kv_layer; ca.out = bf.attn; ca.ldo = inner; ca.part = bf.part;
-    ca.B = B; ca.H = H; ca.L = L; ca.splits = bf.splits;
+    ca.B = B; ca.H = H; ca.L = L; ca.splits = bf.splits; ca.ticket = bf.ticket;
     hipLaunchKernelGGL(dec::dec_cross_attn_kernel<T>, dim3(B * H * bf.splits), dim3(256), 0, s, ca);
     MH_TRY(check_launch("dec_cross_attn_kernel"));
-    if (bf.splits > 1) {
+    if (bf.splits > 1 && !bf.ticket) {
       hipLaunchKernelGGL(dec::dec_cross_merge_kernel<T>, dim3(B * H), dim3(64), 0, s, ca);
       MH_TRY(check_launch("dec_cross_merge_kernel"));
     }
@@ -488,6 +488,7 @@ extern "C" int64_t mh_t5_decode_workspace_bytes(const MhT5Config* c, int B) {
   t += align256(64 * 64 * 4) * kMaxChains;                                        // RMSNorm partial sums of squares
   t += align256((int64_t)c->n_dec_layers * B * inner * c->tgt_len * es) * 2;      // self K, V caches
   t += align256(B) + align256((int64_t)B * 4) * 2 + align256(sizeof(DecState)) * kMaxChains;   // flags / state
+  t += align256((int64_t)B * c->n_heads * 4);                                     // cross-attention merge tickets
   return t;
 }
 
@@ -501,7 +502,7 @@ namespace {
 // HBM-bound cross-attention of one chain run under the latency-bound GEMVs of the others.  Results do not
 // depend on the chain count (every kernel is batch-invariant by construction).
 int pick_chains(int B) {
-  int n = B >= 32 ? 4 : (B >= 16 ? 2 : 1);
+  int n = B >= 16 ? 2 : 1;   // measured on MI355X (B=32, base): 1 -> 26.7k, 2 -> 28.0k, 4 -> 17.6k tok/s (host graph-launch bound)
   if (const char* e = getenv("MH_DECODE_CHAINS")) {
     const int v = atoi(e);
     if (v >= 1) n = v;
@@ -566,7 +567,10 @@ extern "C" int mh_t5_generate(const MhT5Config* c, const MhT5Weights* w, const v
   all.finish_col = (int32_t*)ar.take((int64_t)B * 4);
   all.last_ts = (int32_t*)ar.take((int64_t)B * 4);
   DecState* st_all = (DecState*)ar.take((int64_t)align256(sizeof(DecState)) * kMaxChains);
-  MH_REQUIRE(ar.ok() && st_all, "mh_t5_generate: arena overflow");
+  int* ticket_all = (int*)ar.take((int64_t)B * H * 4);
+  MH_REQUIRE(ar.ok() && ticket_all, "mh_t5_generate: arena overflow");
+  const bool fuse_merge = getenv("MH_DECODE_NO_FUSED_MERGE") == nullptr;
+  if (hipMemsetAsync(ticket_all, 0, (size_t)B * H * 4, s) != hipSuccess) return check_launch("ticket memset");
   all.splits = cross_splits(B, H);
 
   const int n_chains = pick_chains(B);
@@ -601,6 +605,7 @@ extern "C" int mh_t5_generate(const MhT5Config* c, const MhT5Weights* w, const v
     bf.self_k = (char*)all.self_k + (long)b0 * inner * c->tgt_len * es;
     bf.self_v = (char*)all.self_v + (long)b0 * inner * c->tgt_len * es;
     bf.finished = all.finished + b0;
+    bf.ticket = fuse_merge ? ticket_all + (long)b0 * H : nullptr;
     bf.st = (DecState*)((char*)st_all + (long)ci * align256(sizeof(DecState)));
     states[ci] = bf.st;
     const void* ckv = (const char*)cross_kv + (long)b0 * H * c->src_len * 64 * es;
@@ -698,7 +703,7 @@ extern "C" int mh_t5_cross_attn_probe(const MhT5Config* c, const void* cross_kv,
       dec::CrossAttnP ca{};
       ca.q = q; ca.ldq = inner; ca.k = (const char*)cross_kv + (long)(l * 2 + 0) * kv_layer;
       ca.v = (const char*)cross_kv + (long)(l * 2 + 1) * kv_layer; ca.out = attn; ca.ldo = inner; ca.part = part;
-      ca.B = B; ca.H = H; ca.L = L; ca.splits = splits;
+      ca.B = B; ca.H = H; ca.L = L; ca.splits = splits; ca.ticket = nullptr;
       if (c->dtype == MH_BF16) {
         hipLaunchKernelGGL(dec::dec_cross_attn_kernel<bf16_t>, dim3(B * H * splits), dim3(256), 0, s, ca);
         if (splits > 1) hipLaunchKernelGGL(dec::dec_cross_merge_kernel<bf16_t>, dim3(B * H), dim3(64), 0, s, ca);
