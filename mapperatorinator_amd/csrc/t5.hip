@@ -8,6 +8,7 @@
 //   model_generate (osuT5/osuT5/inference/server.py:83-156) with the reference logits processors.
 #include <stdlib.h>
 
+#include <thread>
 #include <vector>
 
 #include "decode_kernels.hpp"
@@ -569,7 +570,10 @@ extern "C" int mh_t5_generate(const MhT5Config* c, const MhT5Weights* w, const v
   DecState* st_all = (DecState*)ar.take((int64_t)align256(sizeof(DecState)) * kMaxChains);
   int* ticket_all = (int*)ar.take((int64_t)B * H * 4);
   MH_REQUIRE(ar.ok() && ticket_all, "mh_t5_generate: arena overflow");
-  const bool fuse_merge = getenv("MH_DECODE_NO_FUSED_MERGE") == nullptr;
+  // In-kernel merge (last-arriver ticket) is correct but measured SLOWER on MI355X (16.7k vs 26.7k tok/s): the
+  // agent-scope release in each of the 1536 workgroups writes back the XCD L2 and costs far more than the one
+  // 4.8 us merge launch it removes.  Kept behind an opt-in switch for experiments.
+  const bool fuse_merge = getenv("MH_DECODE_FUSED_MERGE") != nullptr;
   if (hipMemsetAsync(ticket_all, 0, (size_t)B * H * 4, s) != hipSuccess) return check_launch("ticket memset");
   all.splits = cross_splits(B, H);
 
@@ -634,25 +638,38 @@ extern "C" int mh_t5_generate(const MhT5Config* c, const MhT5Weights* w, const v
 
   const int total_steps = sp->max_length - 1;   // positions 0 .. max_length-2 are fed
   if (poll_every <= 0) poll_every = 16;
-  int step = 0;
-  while (rc == MH_OK && step < total_steps) {
-    const int burst = total_steps - step < poll_every ? total_steps - step : poll_every;
-    for (int i = 0; i < burst && rc == MH_OK; ++i)
-      for (int ci = 0; ci < used; ++ci)
-        if (hipGraphLaunch(execs[ci], g_pool.streams[ci]) != hipSuccess) { rc = check_launch("graph launch"); break; }
-    step += burst;
-    if (rc == MH_OK && step < total_steps && !forced) {
-      int running[kMaxChains] = {};
-      for (int ci = 0; ci < used; ++ci)
-        if (hipMemcpyAsync(&running[ci], &states[ci]->n_running, 4, hipMemcpyDeviceToHost, g_pool.streams[ci]) != hipSuccess)
-          rc = check_launch("poll");
-      int total = 0;
-      for (int ci = 0; ci < used && rc == MH_OK; ++ci) {
-        if (hipStreamSynchronize(g_pool.streams[ci]) != hipSuccess) rc = check_launch("poll sync");
-        total += running[ci];
+  // One launcher per chain.  Replaying a ~110-node graph costs ~0.4 ms of HOST time on ROCm 7.2, so with more
+  // than one chain the launches are issued from one host thread per chain (the chains are independent: each
+  // polls only its own "rows still running" word and stops launching when its rows are done).
+  auto run_chain = [&](int ci) -> int {
+    int step = 0;
+    while (step < total_steps) {
+      const int burst = total_steps - step < poll_every ? total_steps - step : poll_every;
+      for (int i = 0; i < burst; ++i)
+        if (hipGraphLaunch(execs[ci], g_pool.streams[ci]) != hipSuccess) return MH_ERR_LAUNCH;
+      step += burst;
+      if (step < total_steps && !forced) {
+        int running = 1;
+        if (hipMemcpyAsync(&running, &states[ci]->n_running, 4, hipMemcpyDeviceToHost, g_pool.streams[ci]) != hipSuccess ||
+            hipStreamSynchronize(g_pool.streams[ci]) != hipSuccess)
+          return MH_ERR_LAUNCH;
+        if (running == 0) break;
       }
-      if (rc == MH_OK && total == 0) break;
     }
+    return MH_OK;
+  };
+  if (rc == MH_OK) {
+    int rcs[kMaxChains] = {};
+    if (used <= 1) {
+      if (used == 1) rcs[0] = run_chain(0);
+    } else {
+      std::vector<std::thread> th;
+      for (int ci = 1; ci < used; ++ci) th.emplace_back([&, ci] { rcs[ci] = run_chain(ci); });
+      rcs[0] = run_chain(0);
+      for (auto& t : th) t.join();
+    }
+    for (int ci = 0; ci < used; ++ci)
+      if (rcs[ci] != MH_OK) { set_error("mh_t5_generate: graph launch / poll failed on chain %d: %s", ci, hipGetErrorString(hipGetLastError())); rc = rcs[ci]; }
   }
   // join the chains back into the caller's stream
   for (int ci = 0; ci < used; ++ci) {
