@@ -178,8 +178,15 @@ def main():
                                     ws.numel(), eng.stream.cuda_stream)
     _lib.check(rc, "mh_t5_cross_attn_probe")
     achieved = alg_bytes / (ms.value * 1e-3) / 1e9
+    # HBM bytes per launch from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 passes, gfx950
+    # correction applied -- profiles/r01_pmc_hbm_traffic.txt); only quoted for the exact workload it was taken on
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_cross_attn.json")
+    if os.path.exists(pmc_path) and args.size == "base" and args.dtype == "bf16" and B == 32:
+        with open(pmc_path) as f:
+            traffic = json.load(f).get("hbm_bytes_per_launch")
     roofline = {"bound": "hbm", "kernel": "dec_cross_attn_kernel (+merge)", "achieved": round(achieved, 1),
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "alg_bytes_per_launch": alg_bytes, "us_per_launch": round(ms.value * 1e3, 2),
                 "launches_per_token_step": dims.n_dec_layers}
 
