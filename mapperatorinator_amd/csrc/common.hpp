@@ -32,12 +32,23 @@ __host__ __device__ inline float bf16_to_f32(bf16_t v) {
   return c.f;
 }
 __host__ __device__ inline bf16_t f32_to_bf16(float f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_bit_cast(uint16_t, (__bf16)f);   // v_cvt_pk_bf16_f32 (round-to-nearest-even)
+#endif
   union { uint32_t u; float f; } c;
   c.f = f;
   uint32_t u = c.u;
   if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // quiet NaN
   u += 0x7fffu + ((u >> 16) & 1u);
   return (bf16_t)(u >> 16);
+}
+
+// two fp32 -> packed bf16x2 (lo in bits 0..15) with ONE v_cvt_pk_bf16_f32
+__device__ inline uint32_t pack_bf16x2(float lo, float hi) {
+  typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 
 template <typename T> struct Elem;

@@ -40,7 +40,7 @@ template <typename T> __device__ inline void store8(T* p, const float (&o)[8]);
 template <> __device__ inline void store8<bf16_t>(bf16_t* p, const float (&o)[8]) {
   uint32_t w[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) w[i] = (uint32_t)f32_to_bf16(o[2 * i]) | ((uint32_t)f32_to_bf16(o[2 * i + 1]) << 16);
+  for (int i = 0; i < 4; ++i) w[i] = pack_bf16x2(o[2 * i], o[2 * i + 1]);
   *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
 }
 template <> __device__ inline void store8<float>(float* p, const float (&o)[8]) {
@@ -50,8 +50,7 @@ template <> __device__ inline void store8<float>(float* p, const float (&o)[8]) 
 
 template <typename T> __device__ inline void store4(T* p, float a, float b, float c, float d);
 template <> __device__ inline void store4<bf16_t>(bf16_t* p, float a, float b, float c, float d) {
-  *reinterpret_cast<uint2*>(p) = make_uint2((uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16),
-                                            (uint32_t)f32_to_bf16(c) | ((uint32_t)f32_to_bf16(d) << 16));
+  *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16x2(a, b), pack_bf16x2(c, d));
 }
 template <> __device__ inline void store4<float>(float* p, float a, float b, float c, float d) {
   *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
@@ -91,10 +90,10 @@ template <> struct VecOps<bf16_t> {
     return r;
   }
   __device__ static inline uint4 norm_frag(const Raw& x, const Raw& g, float rs) {
-    const uint32_t o0 = (uint32_t)f32_to_bf16(g.a.x * (x.a.x * rs)) | ((uint32_t)f32_to_bf16(g.a.y * (x.a.y * rs)) << 16);
-    const uint32_t o1 = (uint32_t)f32_to_bf16(g.a.z * (x.a.z * rs)) | ((uint32_t)f32_to_bf16(g.a.w * (x.a.w * rs)) << 16);
-    const uint32_t o2 = (uint32_t)f32_to_bf16(g.b.x * (x.b.x * rs)) | ((uint32_t)f32_to_bf16(g.b.y * (x.b.y * rs)) << 16);
-    const uint32_t o3 = (uint32_t)f32_to_bf16(g.b.z * (x.b.z * rs)) | ((uint32_t)f32_to_bf16(g.b.w * (x.b.w * rs)) << 16);
+    const uint32_t o0 = pack_bf16x2(g.a.x * (x.a.x * rs), g.a.y * (x.a.y * rs));
+    const uint32_t o1 = pack_bf16x2(g.a.z * (x.a.z * rs), g.a.w * (x.a.w * rs));
+    const uint32_t o2 = pack_bf16x2(g.b.x * (x.b.x * rs), g.b.y * (x.b.y * rs));
+    const uint32_t o3 = pack_bf16x2(g.b.z * (x.b.z * rs), g.b.w * (x.b.w * rs));
     return make_uint4(o0, o1, o2, o3);
   }
   __device__ static inline f32x4_t mma(const uint4& a, const uint4& b, f32x4_t c) {
@@ -162,17 +161,6 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyP p) {
       oldh[r] = p.h[(long)(row < p.B ? row : p.B - 1) * p.ldh + (colc < p.N ? colc : p.N - 1)];
     }
   }
-  if (PRO == PRO_RMSNORM) {
-    const int row = tid & 63, pg = tid >> 6;
-    float a = 0.f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int part = pg + 4 * i;
-      const float v = p.ss_in[(part < p.ss_parts ? part : 0) * 64 + row];
-      a += part < p.ss_parts ? v : 0.f;
-    }
-    ssp[pg][row] = a;
-  }
 
   f32x4_t acc[NS][MF];
 #pragma unroll
@@ -223,6 +211,21 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyP p) {
       }
     }
     if (PRO == PRO_RMSNORM && kFirst) {
+      // RMSNorm statistics: requested AFTER the operand loads (in program order) so that the one wait below
+      // covers everything with a single round trip
+      {
+        const int row = tid & 63, pg = tid >> 6;
+        float sv[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int part = pg + 4 * i;
+          sv[i] = p.ss_in[(part < p.ss_parts ? part : 0) * 64 + row];
+        }
+        float a = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) a += (pg + 4 * i < p.ss_parts) ? sv[i] : 0.f;
+        ssp[pg][row] = a;
+      }
       __syncthreads();   // ssp complete (every wave reaches this exactly once)
 #pragma unroll
       for (int f = 0; f < MF; ++f) {
@@ -425,7 +428,7 @@ struct SelfAttnP {
 };
 
 // merge the 4 waves' partial (m, l, acc[64]) through LDS; threads 0..63 return the merged (m, l, a[d])
-template <typename T>
+template <typename T, int NW = 4>
 __device__ inline void block_merge(const Partial& st, float (*sm)[66], float& m, float& l, float& a) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int c8 = (lane & 7) * 8, g = lane >> 3;
@@ -440,7 +443,7 @@ __device__ inline void block_merge(const Partial& st, float (*sm)[66], float& m,
     const int d = threadIdx.x;
     m = sm[0][0]; l = sm[0][1]; a = sm[0][2 + d];
 #pragma unroll
-    for (int w = 1; w < 4; ++w) {
+    for (int w = 1; w < NW; ++w) {
       const float m2 = sm[w][0], l2 = sm[w][1], a2 = sm[w][2 + d];
       const float mn = fmaxf(m, m2);
       const float fa = fexp<T>(m - mn), fb = fexp<T>(m2 - mn);
@@ -485,10 +488,12 @@ struct CrossAttnP {
   int B, H, L, splits;
 };
 
-// one workgroup (4 waves) per (b, h, split); the waves interleave 8-key rows of the split's key range
-template <typename T>
-__global__ __launch_bounds__(256) void dec_cross_attn_kernel(CrossAttnP p) {
-  __shared__ float sm[4][66];
+// one workgroup (NW waves) per (b, h, split); the waves interleave 8-key rows of the split's key range.
+// NW = 4 with 4 key splits (+ merge kernel) or NW = 16 with one split (no merge launch): both keep the
+// reduction order of a row independent of the batch.
+template <typename T, int NW>
+__global__ __launch_bounds__(NW * 64) void dec_cross_attn_kernel(CrossAttnP p) {
+  __shared__ float sm[NW][66];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int split = blockIdx.x % p.splits;
   const int pair = blockIdx.x / p.splits;
@@ -504,10 +509,10 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(CrossAttnP p) {
   const T* vb = reinterpret_cast<const T*>(p.v) + ((long)b * p.H + h) * p.L * 64;
   Partial st;
   partial_init(st);
-  attend_keys<T, 4>(st, q, kb, vb, k_lo + wid * 8 + g, k_hi, 32, nullptr, 0, nullptr, 0, 1.0f);
+  attend_keys<T, 4>(st, q, kb, vb, k_lo + wid * 8 + g, k_hi, 8 * NW, nullptr, 0, nullptr, 0, 1.0f);
   partial_merge_groups<T>(st);
   float m, l, a;
-  block_merge<T>(st, sm, m, l, a);
+  block_merge<T, NW>(st, sm, m, l, a);
   if (threadIdx.x < 64) {
     const int d = threadIdx.x;
     if (p.splits == 1) {

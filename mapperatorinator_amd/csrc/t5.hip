@@ -403,7 +403,29 @@ struct DecBuffers {
 // Key-range splits of the decode cross-attention.  A CONSTANT (not a function of the batch) so that a row's
 // reduction order -- and therefore its bf16 rounding and its greedy tokens -- does not depend on which other
 // chunks share its batch.  4 splits x 4 waves: B*H*4 workgroups (1536 at B=32, H=12) fill the 256 CUs.
-int cross_splits(int /*B*/, int /*H*/) { return 4; }
+int cross_splits(int /*B*/, int /*H*/) {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("MH_CROSS_SPLITS");
+    v = (e && atoi(e) == 4) ? 4 : 1;
+  }
+  return v;   // 1: 16-wave workgroups, no merge launch;  4: 4-wave workgroups x 4 key splits + merge kernel
+}
+
+template <typename T>
+int launch_cross(const dec::CrossAttnP& ca, hipStream_t s) {
+  if (ca.splits == 1) {
+    hipLaunchKernelGGL((dec::dec_cross_attn_kernel<T, 16>), dim3(ca.B * ca.H), dim3(1024), 0, s, ca);
+    return check_launch("dec_cross_attn_kernel");
+  }
+  hipLaunchKernelGGL((dec::dec_cross_attn_kernel<T, 4>), dim3(ca.B * ca.H * ca.splits), dim3(256), 0, s, ca);
+  int rc = check_launch("dec_cross_attn_kernel");
+  if (rc == MH_OK && !ca.ticket) {
+    hipLaunchKernelGGL(dec::dec_cross_merge_kernel<T>, dim3(ca.B * ca.H), dim3(64), 0, s, ca);
+    rc = check_launch("dec_cross_merge_kernel");
+  }
+  return rc;
+}
 
 template <typename T>
 int enqueue_step(const MhT5Config* c, const MhT5Weights* w, const void* cross_kv, int B, int Bfull,
@@ -442,12 +464,7 @@ int enqueue_step(const MhT5Config* c, const MhT5Weights* w, const void* cross_kv
     ca.q = bf.q; ca.ldq = inner; ca.k = (const char*)cross_kv + (long)(l * 2 + 0) * kv_layer;
     ca.v = (const char*)cross_kv + (long)(l * 2 + 1) * kv_layer; ca.out = bf.attn; ca.ldo = inner; ca.part = bf.part;
     ca.B = B; ca.H = H; ca.L = L; ca.splits = bf.splits; ca.ticket = bf.ticket;
-    hipLaunchKernelGGL(dec::dec_cross_attn_kernel<T>, dim3(B * H * bf.splits), dim3(256), 0, s, ca);
-    MH_TRY(check_launch("dec_cross_attn_kernel"));
-    if (bf.splits > 1 && !bf.ticket) {
-      hipLaunchKernelGGL(dec::dec_cross_merge_kernel<T>, dim3(B * H), dim3(64), 0, s, ca);
-      MH_TRY(check_launch("dec_cross_merge_kernel"));
-    }
+    MH_TRY(launch_cross<T>(ca, s));
     sk = dec::SkinnyP{};
     sk.A = bf.attn; sk.lda = inner; sk.W = w->dec_co[l]; sk.ldw = inner; sk.B = B; sk.N = d; sk.K = inner; sk.h = bf.h;
     sk.ldh = d; sk.ss_out = bf.ss;
@@ -721,14 +738,7 @@ extern "C" int mh_t5_cross_attn_probe(const MhT5Config* c, const void* cross_kv,
       ca.q = q; ca.ldq = inner; ca.k = (const char*)cross_kv + (long)(l * 2 + 0) * kv_layer;
       ca.v = (const char*)cross_kv + (long)(l * 2 + 1) * kv_layer; ca.out = attn; ca.ldo = inner; ca.part = part;
       ca.B = B; ca.H = H; ca.L = L; ca.splits = splits; ca.ticket = nullptr;
-      if (c->dtype == MH_BF16) {
-        hipLaunchKernelGGL(dec::dec_cross_attn_kernel<bf16_t>, dim3(B * H * splits), dim3(256), 0, s, ca);
-        if (splits > 1) hipLaunchKernelGGL(dec::dec_cross_merge_kernel<bf16_t>, dim3(B * H), dim3(64), 0, s, ca);
-      } else {
-        hipLaunchKernelGGL(dec::dec_cross_attn_kernel<float>, dim3(B * H * splits), dim3(256), 0, s, ca);
-        if (splits > 1) hipLaunchKernelGGL(dec::dec_cross_merge_kernel<float>, dim3(B * H), dim3(64), 0, s, ca);
-      }
-      rc = check_launch("probe cross attn");
+      rc = c->dtype == MH_BF16 ? launch_cross<bf16_t>(ca, s) : launch_cross<float>(ca, s);
     }
     if (pass == 1) (void)hipEventRecord(e1, s);
   }
