@@ -517,6 +517,13 @@ __global__ __launch_bounds__(NW * 64) void dec_cross_attn_kernel(CrossAttnP p) {
     const int d = threadIdx.x;
     if (p.splits == 1) {
       reinterpret_cast<T*>(p.out)[(long)b * p.ldo + h * 64 + d] = Elem<T>::from_f32(l > 0.f ? a / l : 0.f);
+    } else if (p.ticket) {
+      float* pp = p.part + ((long)pair * p.splits + split) * 66;
+      if (d == 0) {
+        __hip_atomic_store(pp + 0, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(pp + 1, l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __hip_atomic_store(pp + 2 + d, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
       float* pp = p.part + ((long)pair * p.splits + split) * 66;
       if (d == 0) { pp[0] = m; pp[1] = l; }
@@ -524,31 +531,32 @@ __global__ __launch_bounds__(NW * 64) void dec_cross_attn_kernel(CrossAttnP p) {
     }
   }
   if (p.splits > 1 && p.ticket) {
-    // Placement-independent hand-off (agent-scope release by every producer, one agent-scope acquire by the
-    // consumer; cdna_hip_programming.md guideline 16): partial stores drained -> barrier -> lane 0 releases,
-    // takes a ticket; the block that draws the last ticket acquires and merges all splits of its pair.
+    // In-kernel merge by the last-arriving split of a (b, h) pair.  Hand-off in the write-through form of
+    // cdna_hip_programming.md guideline 16: the 66-float partial is stored with sc1 (agent-scope relaxed atomic
+    // stores lower to `global_store_dword sc1`), every wave drains its stores, one relaxed agent-scope ticket is
+    // taken, and the block that draws the last ticket reads all partials with sc1 loads (L1 bypass).  No L2
+    // write-back fence (an agent-scope release in each of the ~800 workgroups cost far more than a merge launch).
     __shared__ int s_last;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       const int t = __hip_atomic_fetch_add(p.ticket + pair, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const int last = (t == p.splits - 1) ? 1 : 0;
-      if (last) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        p.ticket[pair] = 0;   // re-armed for the next launch (made visible by the kernel boundary)
-      }
+      if (last) __hip_atomic_store(p.ticket + pair, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
       s_last = last;
     }
     __syncthreads();
     if (s_last && threadIdx.x < 64) {
       const int d = threadIdx.x;
       const float* pp = p.part + (long)pair * p.splits * 66;
-      float mm = pp[0], ll = pp[1], aa = pp[2 + d];
+      float mm = __hip_atomic_load(pp + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      float ll = __hip_atomic_load(pp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      float aa = __hip_atomic_load(pp + 2 + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       for (int s2 = 1; s2 < p.splits; ++s2) {   // fixed split order: deterministic
         const float* ps = pp + s2 * 66;
-        const float m2 = ps[0], l2 = ps[1], a2 = ps[2 + d];
+        const float m2 = __hip_atomic_load(ps + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float l2 = __hip_atomic_load(ps + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float a2 = __hip_atomic_load(ps + 2 + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const float mn = fmaxf(mm, m2);
         const float fa = fexp<T>(mm - mn), fb = fexp<T>(m2 - mn);
         ll = ll * fa + l2 * fb;

@@ -407,9 +407,10 @@ int cross_splits(int /*B*/, int /*H*/) {
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("MH_CROSS_SPLITS");
-    v = (e && atoi(e) == 4) ? 4 : 1;
+    v = e ? atoi(e) : 1;
+    if (v != 1 && v != 2 && v != 4) v = 1;
   }
-  return v;   // 1: 16-wave workgroups, no merge launch;  4: 4-wave workgroups x 4 key splits + merge kernel
+  return v;   // 1: 16-wave workgroups, no merge;  2: 8-wave x 2 key splits;  4: 4-wave x 4 key splits (+ merge)
 }
 
 template <typename T>
@@ -418,7 +419,10 @@ int launch_cross(const dec::CrossAttnP& ca, hipStream_t s) {
     hipLaunchKernelGGL((dec::dec_cross_attn_kernel<T, 16>), dim3(ca.B * ca.H), dim3(1024), 0, s, ca);
     return check_launch("dec_cross_attn_kernel");
   }
-  hipLaunchKernelGGL((dec::dec_cross_attn_kernel<T, 4>), dim3(ca.B * ca.H * ca.splits), dim3(256), 0, s, ca);
+  if (ca.splits == 2)
+    hipLaunchKernelGGL((dec::dec_cross_attn_kernel<T, 8>), dim3(ca.B * ca.H * 2), dim3(512), 0, s, ca);
+  else
+    hipLaunchKernelGGL((dec::dec_cross_attn_kernel<T, 4>), dim3(ca.B * ca.H * ca.splits), dim3(256), 0, s, ca);
   int rc = check_launch("dec_cross_attn_kernel");
   if (rc == MH_OK && !ca.ticket) {
     hipLaunchKernelGGL(dec::dec_cross_merge_kernel<T>, dim3(ca.B * ca.H), dim3(64), 0, s, ca);
@@ -587,10 +591,10 @@ extern "C" int mh_t5_generate(const MhT5Config* c, const MhT5Weights* w, const v
   DecState* st_all = (DecState*)ar.take((int64_t)align256(sizeof(DecState)) * kMaxChains);
   int* ticket_all = (int*)ar.take((int64_t)B * H * 4);
   MH_REQUIRE(ar.ok() && ticket_all, "mh_t5_generate: arena overflow");
-  // In-kernel merge (last-arriver ticket) is correct but measured SLOWER on MI355X (16.7k vs 26.7k tok/s): the
-  // agent-scope release in each of the 1536 workgroups writes back the XCD L2 and costs far more than the one
-  // 4.8 us merge launch it removes.  Kept behind an opt-in switch for experiments.
-  const bool fuse_merge = getenv("MH_DECODE_FUSED_MERGE") != nullptr;
+  // In-kernel merge of the cross-attention key splits (write-through partials + ticket, see dec_cross_attn_kernel);
+  // MH_DECODE_FUSED_MERGE=0 falls back to the separate merge launch.
+  const char* fm = getenv("MH_DECODE_FUSED_MERGE");
+  const bool fuse_merge = !(fm && atoi(fm) == 0);
   if (hipMemsetAsync(ticket_all, 0, (size_t)B * H * 4, s) != hipSuccess) return check_launch("ticket memset");
   all.splits = cross_splits(B, H);
 
