@@ -90,8 +90,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ   # under torch.distributed.run the RCCL path is used even for N=1
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
@@ -123,7 +125,7 @@ def main():
     gk = dict(do_sample=False, num_beams=1, max_length=1 + new, temperature=1.0, context_type="map", pad_token_id=0)
     sp, eos = build_sampling(tok, gk, tgt_len)
     eos_table = torch.zeros(tok.vocab_size_out, dtype=torch.uint8, device=dev)   # random-init: keep rows running
-    gathered = torch.empty((world * B, 1 + new), dtype=torch.int32, device=dev) if world > 1 else None
+    gathered = torch.empty((world * B, 1 + new), dtype=torch.int32, device=dev) if use_dist else None
 
     def one_step():
         eng._enter()
@@ -132,13 +134,13 @@ def main():
             kv = eng.cross_kv(enc)
             tokens, n_out, _ = eng.decode(kv, prompt, None, eos_table, sp, poll_every=64)
         eng._leave()
-        if world > 1:
+        if use_dist:
             dist.all_gather_into_tensor(gathered, tokens.contiguous())
         return tokens, kv
 
     def fence():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -152,7 +154,7 @@ def main():
     elapsed = time.perf_counter() - t0
     n_tok = int((tokens[:, 1:] != 0).sum().item())
     stat = torch.tensor([elapsed, float(n_tok)], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         tmax = stat.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = stat.clone()
@@ -164,7 +166,7 @@ def main():
     value = n_tok_total / (elapsed / args.steps)
 
     if rank != 0:
-        if world > 1:
+        if use_dist:
             dist.destroy_process_group()
         return
 
@@ -215,7 +217,7 @@ def main():
                "100-step DDPM (fused hipGraph loop)", "ms_per_100_steps": round(dt * 1e3, 2)}
 
     cpu = None
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:   # the CPU port is timed on rank 0 at N=1 only
         cpu = cpu_baseline(args.size, (tok.vocab_size_in, tok.vocab_size_out, ts0, ts1))
 
     line = {
@@ -230,7 +232,7 @@ def main():
         "roofline": roofline, "cpu_baseline": cpu, "aux": aux,
     }
     print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

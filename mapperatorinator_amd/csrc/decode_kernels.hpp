@@ -36,6 +36,25 @@ template <> __device__ inline void load8<float>(const float* p, float (&o)[8]) {
   o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w;
   o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
 }
+// streaming (non-temporal) variants for data that is read once per launch (K/V rows of the decode attention):
+// `global_load_dwordx4 ... nt` keeps the 1.5 GB/step K/V stream from evicting the decoder weights (226 MB) out of
+// the 256 MB Infinity Cache between token steps.
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+template <typename T> __device__ inline void load8_stream(const T* p, float (&o)[8]);
+template <> __device__ inline void load8_stream<bf16_t>(const bf16_t* p, float (&o)[8]) {
+  const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    o[2 * i] = __uint_as_float(v[i] << 16);
+    o[2 * i + 1] = __uint_as_float(v[i] & 0xffff0000u);
+  }
+}
+template <> __device__ inline void load8_stream<float>(const float* p, float (&o)[8]) {
+  const u32x4_t a = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+  const u32x4_t b = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p + 4));
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { o[i] = __uint_as_float(a[i]); o[4 + i] = __uint_as_float(b[i]); }
+}
 template <typename T> __device__ inline void store8(T* p, const float (&o)[8]);
 template <> __device__ inline void store8<bf16_t>(bf16_t* p, const float (&o)[8]) {
   uint32_t w[4];
@@ -134,15 +153,17 @@ constexpr int skinny_chunk() {
   return 8 * per <= 200 ? 8 : (6 * per <= 200 ? 6 : (4 * per <= 200 ? 4 : 2));
 }
 
-template <typename T, int MF, int NS, int PRO, int EPI>
-__global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyP p) {
+// NWV waves per workgroup split K (4, or 8 for the long-K PLAIN GEMVs so that one pass covers K = 2048)
+template <typename T, int MF, int NS, int PRO, int EPI, int NWV = 4>
+__global__ __launch_bounds__(NWV * 64) void skinny_gemm_kernel(SkinnyP p) {
+  static_assert(PRO == PRO_PLAIN || NWV == 4, "the RMSNorm prologue is written for 4 waves");
   constexpr int VEC = Elem<T>::kVec;   // elements per 16-byte vector (per lane per k-block)
   constexpr int KB = 4 * VEC;          // k elements per k-block (4 lane groups x 16 B)
   constexpr int CH = skinny_chunk<T, MF, NS, PRO>();
   constexpr int NSE = (EPI == SK_GEGLU) ? 1 : NS;
   typedef typename VecOps<T>::Raw Raw;
   __shared__ float ssp[4][64];
-  __shared__ f32x4_t red[4 * NS * MF * 64];
+  __shared__ f32x4_t red[NWV * NS * MF * 64];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l15 = lane & 15, lg = lane >> 4;
@@ -195,8 +216,8 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyP p) {
     Raw graw[PRO == PRO_RMSNORM ? CH : 1];
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
-      const int kb = kb0 + 4 * c;
-      const int kel = (kb < nkb ? kb : wid) * KB;
+      const int kb = kb0 + NWV * c;
+      const int kel = (kb < nkb ? kb : (wid < nkb ? wid : 0)) * KB;
 #pragma unroll
       for (int s = 0; s < NS; ++s) wv[c][s] = *reinterpret_cast<const uint4*>(Wp[s] + kel);
       if (PRO == PRO_PLAIN) {
@@ -236,7 +257,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyP p) {
     }
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
-      if (kb0 + 4 * c < nkb) {
+      if (kb0 + NWV * c < nkb) {
 #pragma unroll
         for (int f = 0; f < MF; ++f) {
           uint4 a;
@@ -250,7 +271,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyP p) {
     }
   };
   chunk(wid, std::true_type{});
-  for (int kb0 = wid + 4 * CH; kb0 < nkb; kb0 += 4 * CH) chunk(kb0, std::false_type{});
+  for (int kb0 = wid + NWV * CH; kb0 < nkb; kb0 += NWV * CH) chunk(kb0, std::false_type{});
 
 #pragma unroll
   for (int s = 0; s < NS; ++s)
@@ -262,7 +283,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyP p) {
   const int pos = (EPI == SK_QKV) ? *p.pos : 0;
   f32x4_t v = red[((0 * NS + es) * MF + ef) * 64 + lane];
 #pragma unroll
-  for (int w = 1; w < 4; ++w) {
+  for (int w = 1; w < NWV; ++w) {
     const f32x4_t t = red[((w * NS + es) * MF + ef) * 64 + lane];
     v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
   }
@@ -270,7 +291,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyP p) {
   if (EPI == SK_GEGLU) {
     u = red[((0 * NS + 1) * MF + ef) * 64 + lane];
 #pragma unroll
-    for (int w = 1; w < 4; ++w) {
+    for (int w = 1; w < NWV; ++w) {
       const f32x4_t t = red[((w * NS + 1) * MF + ef) * 64 + lane];
       u[0] += t[0]; u[1] += t[1]; u[2] += t[2]; u[3] += t[3];
     }
@@ -358,14 +379,14 @@ __device__ inline void attend_keys(Partial& st, const float (&q)[8], const T* kb
     for (int u = 0; u < U; ++u) {
       const int jj = j + u * jstride;
       const int jc = jj < jend ? jj : j;
-      load8<T>(kbase + (long)jc * 64 + c8, kv[u]);
+      load8_stream<T>(kbase + (long)jc * 64 + c8, kv[u]);
     }
     float vv[U][8];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int jj = j + u * jstride;
       const int jc = jj < jend ? jj : j;
-      load8<T>(vbase + (long)jc * 64 + c8, vv[u]);
+      load8_stream<T>(vbase + (long)jc * 64 + c8, vv[u]);
     }
     // bias / mask values: wave-uniform branch on the pointers, unconditional loads from clamped indices
     float bv[U];

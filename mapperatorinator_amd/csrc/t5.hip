@@ -377,9 +377,13 @@ template <typename T, int MF, int NS, int PRO, int EPI>
 int launch_skinny(const dec::SkinnyP& p, hipStream_t s) {
   const int strips = ceil_div(p.N, 16);
   const int kb = 4 * (16 / (int)sizeof(T));
-  MH_REQUIRE(p.K % kb == 0 && p.K / kb >= 4, "decode: K=%d must be a multiple of %d and >= %d", p.K, kb, 4 * kb);
+  MH_REQUIRE(p.K % kb == 0 && p.K / kb >= 1, "decode: K=%d must be a multiple of %d and >= %d", p.K, kb, 4 * kb);
   MH_REQUIRE(PRO != dec::PRO_RMSNORM || (p.ss_in && p.ss_parts >= 1 && p.ss_parts <= 64), "decode: bad RMSNorm statistics");
   MH_REQUIRE(EPI != dec::SK_RESID || (p.ss_out && p.N % 16 == 0 && p.N / 16 <= 64), "decode: RESID needs N %% 16 == 0, N <= 1024");
+  if (PRO == dec::PRO_PLAIN && p.K / kb > 32) {   // long K (wo): 8 waves so that a single pass covers it
+    hipLaunchKernelGGL((dec::skinny_gemm_kernel<T, MF, NS, dec::PRO_PLAIN, EPI, 8>), dim3(ceil_div(strips, NS)), dim3(512), 0, s, p);
+    return check_launch("skinny_gemm_kernel");
+  }
   hipLaunchKernelGGL((dec::skinny_gemm_kernel<T, MF, NS, PRO, EPI>), dim3(ceil_div(strips, NS)), dim3(256), 0, s, p);
   return check_launch("skinny_gemm_kernel");
 }
