@@ -197,3 +197,52 @@ def test_full_size_base_bf16_properties():
                                                  decoder_attention_mask=prompt[:1].ne(0)), eos)
         n = one.shape[1]
         assert torch.equal(one[0], ids[b, :n]) and (ids[b, n:] == 0).all(), f"row {b} depends on its batch"
+
+
+def test_sampling_topk_topp_distribution():
+    """do_sample path (row a9): sampling parity is RNG-bound, so it is checked distributionally --
+    every sampled id lies inside the top-k / nucleus set of the processed scores of its step, identical rows
+    draw from the softmax of the kept set (chi-square), and the stream is a deterministic function of the seed."""
+    from mapperatorinator_amd import Tokenizer
+    from mapperatorinator_amd.server import build_sampling
+    from mapperatorinator_amd.t5_engine import T5_PRESETS
+    from mapperatorinator_amd.testing import random_t5_state_dict, synthetic_audio
+    src, tgt, B = 251, 24, 64
+    tok = Tokenizer.benchmark_vocab(src_seq_len=src)
+    sd = random_t5_state_dict(T5_PRESETS["tiny"], tok.vocab_size_in, tok.vocab_size_out, seed=31, lm_head_gain=2.0)
+    model = build("tiny", tok, sd, src, tgt, torch.float32)
+    audio = synthetic_audio(1, 32000, seed=2).repeat(B, 1)          # identical rows -> identical step-1 scores
+    prompt = torch.tensor([[1]] * B)
+
+    def run(**kw):
+        sp, eos = build_sampling(tok, gen_kwargs(tgt, do_sample=True, **kw), tgt)
+        out = model.engine.generate(audio, prompt, None, [], sp, dump_logits=True)
+        return out["tokens"], out["logits"].cpu()
+
+    toks, lg = run(top_k=5, temperature=0.8, seed=1234)
+    toks2, _ = run(top_k=5, temperature=0.8, seed=1234)
+    toks3, _ = run(top_k=5, temperature=0.8, seed=99)
+    assert torch.equal(toks, toks2) and not torch.equal(toks, toks3)
+    for col in range(1, toks.shape[1]):
+        top = lg[col].topk(5, dim=-1)
+        assert (toks[:, col, None] == top.indices).any(-1).all(), f"column {col}: id outside the top-k set"
+    # chi-square of the first sampled column against softmax over the kept 5 (all rows share the scores)
+    top = lg[1][0].topk(5)
+    probs = torch.softmax(top.values, -1)
+    counts = torch.stack([(toks[:, 1] == i).sum() for i in top.indices]).float()
+    # pool several seeds for a usable sample size
+    for seed in range(20):
+        t, _ = run(top_k=5, temperature=0.8, seed=5000 + seed)
+        counts += torch.stack([(t[:, 1] == i).sum() for i in top.indices]).float()
+    n = counts.sum()
+    chi2 = (((counts - n * probs) ** 2) / (n * probs)).sum().item()
+    print("sampling chi2 (4 dof):", chi2, "counts", counts.tolist(), "expected", (n * probs).tolist())
+    assert chi2 < 25.0      # p ~ 5e-5 for 4 degrees of freedom
+    # nucleus: kept set = smallest prefix of the sorted probabilities whose mass reaches top_p
+    toks_p, lg_p = run(top_k=0, top_p=0.6, temperature=1.0, seed=7)
+    for col in range(1, toks_p.shape[1]):
+        p_sorted, idx = torch.softmax(lg_p[col], -1).sort(-1, descending=True)
+        keep = (p_sorted.cumsum(-1) - p_sorted) < 0.6 + 1e-4
+        for b in range(0, B, 7):
+            allowed = set(idx[b][keep[b]].tolist())
+            assert int(toks_p[b, col]) in allowed, f"column {col} row {b}: id outside the nucleus"
