@@ -281,7 +281,10 @@ int mh_ddpm_step(const float* model_out, const float* x, const float* noise, con
  * mh_dit_forward_cfg + mh_ddpm_step captured once into a hipGraph and replayed.
  *   t_map int32 [n_steps] : timestep_map[i] for loop index i (SpacedDiffusion, respace.py:72-86)
  *   coefs fp32 [n_steps][7]; noise fp32 [n_steps][N,2,T], both indexed by loop index i
- *   (the loop runs i = n_steps-1 ... 0).  x_io [N,2,T] is updated in place. */
+ *   (the loop runs i = n_steps-1 ... 0).  x_io [N,2,T] is updated in place.
+ *   Everything that depends only on (t, y) -- timestep/label embedders and every block's adaLN modulation --
+ *   is computed for all steps before the loop; workspace size from mh_ddpm_loop_workspace_bytes. */
+int64_t mh_ddpm_loop_workspace_bytes(const MhDiTConfig* cfg, int N, int T, int n_steps);
 int mh_ddpm_sample_loop(const MhDiTConfig* cfg, const MhDiTWeights* w, float* x_io, const float* c,
                         const float* y, float cfg_scale, int band, int N, int T, int n_steps,
                         const int32_t* t_map, const float* coefs, const float* noise,

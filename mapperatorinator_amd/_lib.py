@@ -88,6 +88,7 @@ SYMBOLS = {
     "mh_dit_forward_cfg": (I, [C.POINTER(MhDiTConfig), C.POINTER(MhDiTWeights), VP, VP, VP, VP, F, I, I, I,
                                VP, VP, I64, VP]),
     "mh_ddpm_step": (I, [VP, VP, VP, VP, VP, VP, VP, I, I, I, VP, VP, VP]),
+    "mh_ddpm_loop_workspace_bytes": (I64, [C.POINTER(MhDiTConfig), I, I, I]),
     "mh_ddpm_sample_loop": (I, [C.POINTER(MhDiTConfig), C.POINTER(MhDiTWeights), VP, VP, VP, F, I, I, I, I,
                                 VP, VP, VP, VP, VP, VP, I64, VP]),
 }

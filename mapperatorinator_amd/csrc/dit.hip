@@ -42,16 +42,32 @@ __global__ __launch_bounds__(256) void dit_embed_kernel(const float* __restrict_
   }
 }
 
-// timestep_embedding(t, F): [cos(t f_i) | sin(t f_i)]
-__global__ void dit_tfreq_kernel(const int32_t* __restrict__ t_vals, const int* __restrict__ sel,
-                                 const float* __restrict__ freqs, int N, int F, float* __restrict__ out) {
-  const int n = blockIdx.x;
-  const float tv = (float)(sel ? t_vals[*sel] : t_vals[n]);
+// timestep_embedding(t, F): [cos(t f_i) | sin(t f_i)];  row r uses t_vals[r / div] (div = N when the rows are
+// (step, n) pairs of a whole sampling loop, 1 for a single forward)
+__global__ void dit_tfreq_kernel(const int32_t* __restrict__ t_vals, int div, const float* __restrict__ freqs, int F,
+                                 float* __restrict__ out) {
+  const int r = blockIdx.x;
+  const float tv = (float)t_vals[r / div];
   const int hf = F / 2;
   for (int i = threadIdx.x; i < F; i += blockDim.x) {
     const float a = tv * freqs[i < hf ? i : i - hf];
-    out[(long)n * F + i] = i < hf ? cosf(a) : sinf(a);
+    out[(long)r * F + i] = i < hf ? cosf(a) : sinf(a);
   }
+}
+
+// dst[r][:] += src[r % N][:]   (label embedding broadcast over the steps)
+__global__ void add_rows_bcast_kernel(float* __restrict__ dst, const float* __restrict__ src, int rows, int N, int D) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * D) return;
+  const int r = i / D, d = i - r * D;
+  dst[i] += src[(long)(r % N) * D + d];
+}
+
+// conditioning of the current step: cur[:] = all[*sel][:]
+__global__ void select_step_kernel(const float* __restrict__ all, const int* __restrict__ sel, long per_step,
+                                   float* __restrict__ cur) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < per_step) cur[i] = all[(long)(*sel) * per_step + i];
 }
 
 // out[n][j] (+)= act_out?( sum_k act_in?(in[n][k]) * W[j][k] + b[j] );  one wave per (n, j)
@@ -161,10 +177,13 @@ __global__ void loop_set_kernel(int* sel, int v) {
 }
 
 struct DiTBuf {
-  float *E, *xs, *xm, *qk, *vt, *attn, *hid, *tfreq, *temb1, *temb, *yemb1, *bvec, *mod, *modf;
+  float *E, *xs, *xm, *qk, *vt, *attn, *hid, *yemb1, *yemb, *cond_cur;
   int* sel;
   int Tpad;
 };
+
+// conditioning vectors of ONE step, layout [n][depth][6D] followed by [n][2D] (final layer)
+inline long cond_floats(const MhDiTConfig* c, int N) { return (long)N * (c->depth * 6 + 2) * c->hidden; }
 
 int64_t dit_ws_layout(const MhDiTConfig* c, int N, int T, void* base, int64_t size, DiTBuf* b) {
   Arena ar(base, size);
@@ -179,16 +198,17 @@ int64_t dit_ws_layout(const MhDiTConfig* c, int N, int T, void* base, int64_t si
   t.vt = (float*)ar.take((int64_t)N * D * Tpad * 4);
   t.attn = (float*)ar.take(NT * D * 4);
   t.hid = (float*)ar.take(NT * 4 * D * 4);
-  t.tfreq = (float*)ar.take((int64_t)N * c->t_freq_dim * 4);
-  t.temb1 = (float*)ar.take((int64_t)N * D * 4);
-  t.temb = (float*)ar.take((int64_t)N * D * 4);
   t.yemb1 = (float*)ar.take((int64_t)N * D * 4);
-  t.bvec = (float*)ar.take((int64_t)N * D * 4);
-  t.mod = (float*)ar.take((int64_t)N * 6 * D * 4);
-  t.modf = (float*)ar.take((int64_t)N * 2 * D * 4);
+  t.yemb = (float*)ar.take((int64_t)N * D * 4);
+  t.cond_cur = (float*)ar.take(cond_floats(c, N) * 4);
   t.sel = (int*)ar.take(256);
   if (b) *b = t;
   return ar.off;
+}
+
+// scratch of the conditioning pass for `rows` (= steps * N) rows: tfreq, temb1, bvec
+int64_t cond_scratch_bytes(const MhDiTConfig* c, int rows) {
+  return align256((int64_t)rows * c->t_freq_dim * 4) + 2 * align256((int64_t)rows * c->hidden * 4);
 }
 
 template <bool SILU_IN, bool ACCUM>
@@ -209,11 +229,42 @@ int check_dit(const MhDiTConfig* c, int N, int T) {
   return MH_OK;
 }
 
-// t_vals/sel: see dit_tfreq_kernel.  `freqs` tables live behind the weights struct.
-int dit_forward(const MhDiTConfig* c, const MhDiTWeights* w, const float* x, const int32_t* t_vals, const int* sel,
-                const float* cc, const float* y, float cfg_scale, int band, int N, int T, float* out, const DiTBuf& b,
-                hipStream_t s) {
+// adaLN conditioning depends only on (t, y), never on x: b = t_embedder(t) + y_embedder(y), then every block's
+// SiLU -> Linear(D, 6D) and the final layer's Linear(D, 2D) (models.py:20-55,124-127,140-147,166-173).  Computed for
+// `steps` timesteps at once (rows = steps * N): a sampling loop hoists ALL of it out of the per-step graph.
+// out layout: [step][n][depth][6D] ... then [step][n][2D] interleaved per step: step block = cond_floats().
+int dit_conditioning(const MhDiTConfig* c, const MhDiTWeights* w, const int32_t* t_vals, int div, const float* y, int N,
+                     int steps, float* cond_out, const DiTBuf& b, void* scratch, hipStream_t s) {
+  const int D = c->hidden, rows = steps * N;
+  Arena ar(scratch, cond_scratch_bytes(c, rows));
+  float* tfreq = (float*)ar.take((int64_t)rows * c->t_freq_dim * 4);
+  float* temb1 = (float*)ar.take((int64_t)rows * D * 4);
+  float* bvec = (float*)ar.take((int64_t)rows * D * 4);
+  hipLaunchKernelGGL(dit_tfreq_kernel, dim3(rows), dim3(256), 0, s, t_vals, div, w->t_freqs, c->t_freq_dim, tfreq);
+  MH_TRY(check_launch("dit_tfreq_kernel"));
+  MH_TRY((small_linear<false, false>(tfreq, c->t_freq_dim, w->t_w0, c->t_freq_dim, w->t_b0, temb1, D, rows, D,
+                                     c->t_freq_dim, 1, s)));
+  MH_TRY((small_linear<false, false>(temb1, D, w->t_w1, D, w->t_b1, bvec, D, rows, D, D, 0, s)));
+  MH_TRY((small_linear<false, false>(y, c->class_size, w->y_w0, c->class_pad, w->y_b0, b.yemb1, D, N, D, c->class_size,
+                                     1, s)));
+  MH_TRY((small_linear<false, false>(b.yemb1, D, w->y_w1, D, w->y_b1, b.yemb, D, N, D, D, 0, s)));
+  hipLaunchKernelGGL(add_rows_bcast_kernel, dim3(ceil_div(rows * D, 256)), dim3(256), 0, s, bvec, b.yemb, rows, N, D);
+  MH_TRY(check_launch("add_rows_bcast_kernel"));
+  // row r = step*N + n of the output is [depth][6D] | [2D]; a step block is N consecutive rows
+  const int ld_row = c->depth * 6 * D + 2 * D;   // per (step, n) row: [depth][6D] | [2D]
+  for (int l = 0; l < c->depth; ++l)
+    MH_TRY((small_linear<true, false>(bvec, D, w->ada_w[l], D, w->ada_b[l], cond_out + (long)l * 6 * D, ld_row, rows,
+                                      6 * D, D, 0, s)));
+  MH_TRY((small_linear<true, false>(bvec, D, w->fin_ada_w, D, w->fin_ada_b, cond_out + (long)c->depth * 6 * D, ld_row,
+                                    rows, 2 * D, D, 0, s)));
+  return MH_OK;
+}
+
+// x-dependent part of the denoiser; the conditioning of this step is in b.cond_cur ([n][depth*6D + 2D])
+int dit_body(const MhDiTConfig* c, const MhDiTWeights* w, const float* x, const float* cc, float cfg_scale, int band,
+             int N, int T, float* out, const DiTBuf& b, hipStream_t s) {
   const int D = c->hidden, H = c->n_heads, NT = N * T;
+  const int ld_row = c->depth * 6 * D + 2 * D;
   hipLaunchKernelGGL(dit_embed_kernel, dim3(NT), dim3(256), 0, s, x, cc, w->pos_freqs, N, T, c->freq_dim,
                      c->context_size, c->first_k_pad, b.E);
   MH_TRY(check_launch("dit_embed_kernel"));
@@ -221,21 +272,10 @@ int dit_forward(const MhDiTConfig* c, const MhDiTWeights* w, const float* x, con
   g.A = b.E; g.lda = c->first_k_pad; g.W = w->first_w; g.ldw = c->first_k_pad; g.C = b.xs; g.ldc = D; g.M = NT; g.N = D;
   g.K = c->first_k_pad; g.bias = w->first_b; g.dtype = MH_F32; g.epilogue = MH_EPI_STORE_F32;
   MH_TRY(gemm(g, s));
-  // b = t_embedder(t) + y_embedder(y)
-  hipLaunchKernelGGL(dit_tfreq_kernel, dim3(N), dim3(256), 0, s, t_vals, sel, w->t_freqs, N, c->t_freq_dim, b.tfreq);
-  MH_TRY(check_launch("dit_tfreq_kernel"));
-  MH_TRY((small_linear<false, false>(b.tfreq, c->t_freq_dim, w->t_w0, c->t_freq_dim, w->t_b0, b.temb1, D, N, D,
-                                     c->t_freq_dim, 1, s)));
-  MH_TRY((small_linear<false, false>(b.temb1, D, w->t_w1, D, w->t_b1, b.bvec, D, N, D, D, 0, s)));
-  MH_TRY((small_linear<false, false>(y, c->class_size, w->y_w0, c->class_pad, w->y_b0, b.yemb1, D, N, D, c->class_size,
-                                     1, s)));
-  MH_TRY((small_linear<false, true>(b.yemb1, D, w->y_w1, D, w->y_b1, b.bvec, D, N, D, D, 0, s)));
-
-  if (hipMemsetAsync(b.vt, 0, (size_t)N * D * b.Tpad * 4, s) != hipSuccess) return check_launch("memset vt");
   for (int l = 0; l < c->depth; ++l) {
-    MH_TRY((small_linear<true, false>(b.bvec, D, w->ada_w[l], D, w->ada_b[l], b.mod, 6 * D, N, 6 * D, D, 0, s)));
+    const float* mod = b.cond_cur + (long)l * 6 * D;
     // attention branch
-    MH_TRY(ln_modulate(b.xs, D, b.mod + 0 * D, b.mod + 1 * D, 6 * D, T, b.xm, D, NT, D, 1e-6f, s));
+    MH_TRY(ln_modulate(b.xs, D, mod + 0 * D, mod + 1 * D, ld_row, T, b.xm, D, NT, D, 1e-6f, s));
     g = MhGemm{};
     g.A = b.xm; g.lda = D; g.W = w->qkv_w[l]; g.ldw = D; g.C = b.qk; g.ldc = 2 * D; g.M = NT; g.N = 3 * D; g.K = D;
     g.bias = w->qkv_b[l]; g.dtype = MH_F32; g.epilogue = MH_EPI_QKV_VT; g.C2 = b.vt; g.n_split = 2 * D; g.kv_B = N;
@@ -244,23 +284,23 @@ int dit_forward(const MhDiTConfig* c, const MhDiTWeights* w, const float* x, con
     MH_TRY(attention(b.qk, 2 * D, D, b.vt, b.Tpad, nullptr, b.attn, D, N, T, H, 0.125f, band, MH_F32, s));
     g = MhGemm{};
     g.A = b.attn; g.lda = D; g.W = w->out_w[l]; g.ldw = D; g.C = b.xs; g.ldc = D; g.M = NT; g.N = D; g.K = D;
-    g.bias = w->out_b[l]; g.gate = b.mod + 2 * D; g.gate_ld = 6 * D; g.rows_per_batch = T; g.dtype = MH_F32;
+    g.bias = w->out_b[l]; g.gate = mod + 2 * D; g.gate_ld = ld_row; g.rows_per_batch = T; g.dtype = MH_F32;
     g.epilogue = MH_EPI_GATE_RESID;
     MH_TRY(gemm(g, s));
     // MLP branch
-    MH_TRY(ln_modulate(b.xs, D, b.mod + 3 * D, b.mod + 4 * D, 6 * D, T, b.xm, D, NT, D, 1e-6f, s));
+    MH_TRY(ln_modulate(b.xs, D, mod + 3 * D, mod + 4 * D, ld_row, T, b.xm, D, NT, D, 1e-6f, s));
     g = MhGemm{};
     g.A = b.xm; g.lda = D; g.W = w->fc1_w[l]; g.ldw = D; g.C = b.hid; g.ldc = 4 * D; g.M = NT; g.N = 4 * D; g.K = D;
     g.bias = w->fc1_b[l]; g.dtype = MH_F32; g.epilogue = MH_EPI_BIAS_GELU;
     MH_TRY(gemm(g, s));
     g = MhGemm{};
     g.A = b.hid; g.lda = 4 * D; g.W = w->fc2_w[l]; g.ldw = 4 * D; g.C = b.xs; g.ldc = D; g.M = NT; g.N = D; g.K = 4 * D;
-    g.bias = w->fc2_b[l]; g.gate = b.mod + 5 * D; g.gate_ld = 6 * D; g.rows_per_batch = T; g.dtype = MH_F32;
+    g.bias = w->fc2_b[l]; g.gate = mod + 5 * D; g.gate_ld = ld_row; g.rows_per_batch = T; g.dtype = MH_F32;
     g.epilogue = MH_EPI_GATE_RESID;
     MH_TRY(gemm(g, s));
   }
-  MH_TRY((small_linear<true, false>(b.bvec, D, w->fin_ada_w, D, w->fin_ada_b, b.modf, 2 * D, N, 2 * D, D, 0, s)));
-  MH_TRY(ln_modulate(b.xs, D, b.modf, b.modf + D, 2 * D, T, b.xm, D, NT, D, 1e-6f, s));
+  const float* modf = b.cond_cur + (long)c->depth * 6 * D;
+  MH_TRY(ln_modulate(b.xs, D, modf, modf + D, ld_row, T, b.xm, D, NT, D, 1e-6f, s));
   hipLaunchKernelGGL(dit_final_kernel, dim3(ceil_div(T, 4)), dim3(256), 0, s, b.xm, w->fin_w, D, w->fin_b, N, T, D,
                      cfg_scale, out);
   return check_launch("dit_final_kernel");
@@ -281,7 +321,13 @@ using namespace mh;
 
 extern "C" int64_t mh_dit_workspace_bytes(const MhDiTConfig* c, int N, int T) {
   if (!c || N <= 0 || T <= 0) return -1;
-  return dit_ws_layout(c, N, T, nullptr, 0, nullptr) + align256((int64_t)N * 4 * T * 4);
+  return dit_ws_layout(c, N, T, nullptr, 0, nullptr) + align256((int64_t)N * 4 * T * 4) + cond_scratch_bytes(c, N);
+}
+
+extern "C" int64_t mh_ddpm_loop_workspace_bytes(const MhDiTConfig* c, int N, int T, int n_steps) {
+  if (!c || N <= 0 || T <= 0 || n_steps <= 0) return -1;
+  return dit_ws_layout(c, N, T, nullptr, 0, nullptr) + align256((int64_t)N * 4 * T * 4) +
+         cond_scratch_bytes(c, n_steps * N) + align256(cond_floats(c, N) * 4 * (int64_t)n_steps);
 }
 
 extern "C" int mh_dit_forward_cfg(const MhDiTConfig* c, const MhDiTWeights* w, const float* x, const int32_t* t,
@@ -290,9 +336,13 @@ extern "C" int mh_dit_forward_cfg(const MhDiTConfig* c, const MhDiTWeights* w, c
   MH_TRY(check_dit(c, N, T));
   MH_REQUIRE(w && x && t && cc && y && out && workspace, "mh_dit_forward_cfg: null argument");
   MH_REQUIRE(workspace_bytes >= mh_dit_workspace_bytes(c, N, T), "mh_dit_forward_cfg: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
   DiTBuf b;
-  dit_ws_layout(c, N, T, workspace, workspace_bytes, &b);
-  return dit_forward(c, w, x, t, nullptr, cc, y, cfg_scale, band, N, T, out, b, (hipStream_t)stream);
+  const int64_t used = dit_ws_layout(c, N, T, workspace, workspace_bytes, &b);
+  void* scratch = (char*)workspace + used + align256((int64_t)N * 4 * T * 4);
+  if (hipMemsetAsync(b.vt, 0, (size_t)N * c->hidden * b.Tpad * 4, s) != hipSuccess) return check_launch("memset vt");
+  MH_TRY(dit_conditioning(c, w, t, 1, y, N, 1, b.cond_cur, b, scratch, s));
+  return dit_body(c, w, x, cc, cfg_scale, band, N, T, out, b, s);
 }
 
 extern "C" int mh_ddpm_step(const float* model_out, const float* x, const float* noise, const float* coef,
@@ -314,20 +364,29 @@ extern "C" int mh_ddpm_sample_loop(const MhDiTConfig* c, const MhDiTWeights* w, 
   MH_REQUIRE(w && x_io && cc && y && t_map && coefs && noise && workspace && n_steps > 0,
              "mh_ddpm_sample_loop: null argument");
   MH_REQUIRE(stream != nullptr, "mh_ddpm_sample_loop: needs a non-default stream (hipGraph capture)");
-  MH_REQUIRE(workspace_bytes >= mh_dit_workspace_bytes(c, N, T), "mh_ddpm_sample_loop: workspace too small");
+  MH_REQUIRE(workspace_bytes >= mh_ddpm_loop_workspace_bytes(c, N, T, n_steps), "mh_ddpm_sample_loop: workspace too small");
   MH_REQUIRE((inpaint_mask == nullptr) == (inpaint_ref == nullptr), "mh_ddpm_sample_loop: inpaint mask/ref mismatch");
   hipStream_t s = (hipStream_t)stream;
   DiTBuf b;
   const int64_t used = dit_ws_layout(c, N, T, workspace, workspace_bytes, &b);
   float* mout = (float*)((char*)workspace + used);
+  void* scratch = (char*)mout + align256((int64_t)N * 4 * T * 4);
+  float* cond_all = (float*)((char*)scratch + cond_scratch_bytes(c, n_steps * N));
   MH_TRY(gemm_prepare());
+  // hoisted out of the per-step graph: V^T padding, the conditioning of EVERY step, the loop counter
+  if (hipMemsetAsync(b.vt, 0, (size_t)N * c->hidden * b.Tpad * 4, s) != hipSuccess) return check_launch("memset vt");
+  MH_TRY(dit_conditioning(c, w, t_map, N, y, N, n_steps, cond_all, b, scratch, s));
   hipLaunchKernelGGL(loop_set_kernel, dim3(1), dim3(64), 0, s, b.sel, n_steps - 1);
   MH_TRY(check_launch("loop_set_kernel"));
 
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
   if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) return check_launch("begin capture");
-  int rc = dit_forward(c, w, x_io, t_map, b.sel, cc, y, cfg_scale, band, N, T, mout, b, s);
+  const long per_step = cond_floats(c, N);
+  hipLaunchKernelGGL(select_step_kernel, dim3((unsigned)ceil_div((int)per_step, 256)), dim3(256), 0, s, cond_all, b.sel,
+                     per_step, b.cond_cur);
+  int rc = check_launch("select_step_kernel");
+  if (rc == MH_OK) rc = dit_body(c, w, x_io, cc, cfg_scale, band, N, T, mout, b, s);
   if (rc == MH_OK)
     rc = ddpm_step(mout, x_io, noise, coefs, b.sel, (long)N * 2 * T, inpaint_mask, inpaint_ref, nullptr, 0, N, T, x_io,
                    nullptr, s);

@@ -100,8 +100,9 @@ class DiTHIP:
         return iter(self._keep)
 
     # ---- helpers -----------------------------------------------------------------------------------
-    def workspace(self, N: int, T: int) -> torch.Tensor:
-        need = self.lib.mh_dit_workspace_bytes(C.byref(self.cfg), N, T)
+    def workspace(self, N: int, T: int, n_steps: int = 0) -> torch.Tensor:
+        need = (self.lib.mh_ddpm_loop_workspace_bytes(C.byref(self.cfg), N, T, n_steps) if n_steps > 0
+                else self.lib.mh_dit_workspace_bytes(C.byref(self.cfg), N, T))
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(int(need), dtype=torch.uint8, device=self.device)
         return self._ws
@@ -262,7 +263,7 @@ class SpacedDiffusionHIP:
         coefs = self.coef_table().to(dev).contiguous()
         t_map = torch.tensor(self.timestep_map, dtype=torch.int32, device=dev)
         lib, s = dit.lib, None
-        ws = dit.workspace(N, T)
+        ws = dit.workspace(N, T, n)
 
         if denoised_fn is None or isinstance(denoised_fn, InpaintSpec):
             imask = iref = None
