@@ -512,7 +512,7 @@ struct CrossAttnP {
 // one workgroup (NW waves) per (b, h, split); the waves interleave 8-key rows of the split's key range.
 // NW = 4 with 4 key splits (+ merge kernel) or NW = 16 with one split (no merge launch): both keep the
 // reduction order of a row independent of the batch.
-template <typename T, int NW>
+template <typename T, int NW, int U = 4>
 __global__ __launch_bounds__(NW * 64) void dec_cross_attn_kernel(CrossAttnP p) {
   __shared__ float sm[NW][66];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -530,7 +530,7 @@ __global__ __launch_bounds__(NW * 64) void dec_cross_attn_kernel(CrossAttnP p) {
   const T* vb = reinterpret_cast<const T*>(p.v) + ((long)b * p.H + h) * p.L * 64;
   Partial st;
   partial_init(st);
-  attend_keys<T, 4>(st, q, kb, vb, k_lo + wid * 8 + g, k_hi, 8 * NW, nullptr, 0, nullptr, 0, 1.0f);
+  attend_keys<T, U>(st, q, kb, vb, k_lo + wid * 8 + g, k_hi, 8 * NW, nullptr, 0, nullptr, 0, 1.0f);
   partial_merge_groups<T>(st);
   float m, l, a;
   block_merge<T, NW>(st, sm, m, l, a);

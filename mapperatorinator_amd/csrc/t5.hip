@@ -417,16 +417,36 @@ int cross_splits(int /*B*/, int /*H*/) {
   return v;   // 1: 16-wave workgroups, no merge;  2: 8-wave x 2 key splits;  4: 4-wave x 4 key splits (+ merge)
 }
 
+int cross_unroll() {   // keys in flight per 8-lane group (tuning knob, default 4)
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("MH_CROSS_U");
+    v = e ? atoi(e) : 4;
+    if (v != 2 && v != 4 && v != 8) v = 4;
+  }
+  return v;
+}
+
+template <typename T, int NW, int U>
+void launch_cross_one(const dec::CrossAttnP& ca, int blocks, hipStream_t s) {
+  hipLaunchKernelGGL((dec::dec_cross_attn_kernel<T, NW, U>), dim3(blocks), dim3(NW * 64), 0, s, ca);
+}
+template <typename T, int NW>
+void launch_cross_u(const dec::CrossAttnP& ca, int blocks, hipStream_t s) {
+  const int u = cross_unroll();
+  if (u == 2) launch_cross_one<T, NW, 2>(ca, blocks, s);
+  else if (u == 8) launch_cross_one<T, NW, 8>(ca, blocks, s);
+  else launch_cross_one<T, NW, 4>(ca, blocks, s);
+}
+
 template <typename T>
 int launch_cross(const dec::CrossAttnP& ca, hipStream_t s) {
   if (ca.splits == 1) {
-    hipLaunchKernelGGL((dec::dec_cross_attn_kernel<T, 16>), dim3(ca.B * ca.H), dim3(1024), 0, s, ca);
+    launch_cross_u<T, 16>(ca, ca.B * ca.H, s);
     return check_launch("dec_cross_attn_kernel");
   }
-  if (ca.splits == 2)
-    hipLaunchKernelGGL((dec::dec_cross_attn_kernel<T, 8>), dim3(ca.B * ca.H * 2), dim3(512), 0, s, ca);
-  else
-    hipLaunchKernelGGL((dec::dec_cross_attn_kernel<T, 4>), dim3(ca.B * ca.H * ca.splits), dim3(256), 0, s, ca);
+  if (ca.splits == 2) launch_cross_u<T, 8>(ca, ca.B * ca.H * 2, s);
+  else launch_cross_u<T, 4>(ca, ca.B * ca.H * ca.splits, s);
   int rc = check_launch("dec_cross_attn_kernel");
   if (rc == MH_OK && !ca.ticket) {
     hipLaunchKernelGGL(dec::dec_cross_merge_kernel<T>, dim3(ca.B * ca.H), dim3(64), 0, s, ca);
