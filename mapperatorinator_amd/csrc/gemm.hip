@@ -99,34 +99,41 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmP p) {
   const int cchunk = tid & 7;   // 16-byte chunk within the 128-byte K step
   const int crow = tid >> 3;    // 0..31
 
-  uint4 ra[A_CHUNKS], rb[B_CHUNKS];
+  // Register ring of D in-flight K tiles (tile t lives in slot t % D) in front of the double-buffered LDS stage:
+  // a tile's global loads have D-1 full iterations to land before they are written to LDS.  Small grids
+  // (M = 256 DiT GEMMs: 24-96 workgroups, up to 48 K steps) are latency-bound per K step, so depth matters
+  // there; the 128x128 tile keeps D = 1 (2 workgroups per CU hide the latency instead).
+  constexpr int D = (BM == 64) ? 4 : 1;
+  uint4 ra[D][A_CHUNKS], rb[D][B_CHUNKS];
   const int nk = (p.K + BK - 1) / BK;
 
-  auto load_tiles = [&](int kt) {
+  auto load_tiles = [&](int kt, uint4 (&xa)[A_CHUNKS], uint4 (&xb)[B_CHUNKS]) {
     const int k_el = kt * BK + cchunk * VEC;
     const bool kin = k_el < p.K;
+    const long k_off = (long)(kin ? k_el : 0) * sizeof(T);   // clamped address, value masked below (no predicated load)
+    const uint32_t keep = kin ? 0xffffffffu : 0u;
 #pragma unroll
     for (int i = 0; i < A_CHUNKS; ++i) {
       int r = m0 + crow + 32 * i;
       r = r < p.M ? r : p.M - 1;
-      ra[i] = kin ? *reinterpret_cast<const uint4*>(p.A + (long)r * p.lda_b + (long)k_el * sizeof(T))
-                  : make_uint4(0, 0, 0, 0);
+      const uint4 t = *reinterpret_cast<const uint4*>(p.A + (long)r * p.lda_b + k_off);
+      xa[i] = make_uint4(t.x & keep, t.y & keep, t.z & keep, t.w & keep);
     }
 #pragma unroll
     for (int i = 0; i < B_CHUNKS; ++i) {
       int r = n0 + crow + 32 * i;
       r = r < p.N ? r : p.N - 1;
-      rb[i] = kin ? *reinterpret_cast<const uint4*>(p.W + (long)r * p.ldw_b + (long)k_el * sizeof(T))
-                  : make_uint4(0, 0, 0, 0);
+      const uint4 t = *reinterpret_cast<const uint4*>(p.W + (long)r * p.ldw_b + k_off);
+      xb[i] = make_uint4(t.x & keep, t.y & keep, t.z & keep, t.w & keep);
     }
   };
-  auto store_tiles = [&](int buf) {
+  auto store_tiles = [&](int buf, const uint4 (&xa)[A_CHUNKS], const uint4 (&xb)[B_CHUNKS]) {
 #pragma unroll
     for (int i = 0; i < A_CHUNKS; ++i)
-      *reinterpret_cast<uint4*>(smem + buf * kBufBytes + (crow + 32 * i) * kRowStride + cchunk * 16) = ra[i];
+      *reinterpret_cast<uint4*>(smem + buf * kBufBytes + (crow + 32 * i) * kRowStride + cchunk * 16) = xa[i];
 #pragma unroll
     for (int i = 0; i < B_CHUNKS; ++i)
-      *reinterpret_cast<uint4*>(smem + buf * kBufBytes + (BM + crow + 32 * i) * kRowStride + cchunk * 16) = rb[i];
+      *reinterpret_cast<uint4*>(smem + buf * kBufBytes + (BM + crow + 32 * i) * kRowStride + cchunk * 16) = xb[i];
   };
 
   f32x4_t acc[MI][NI];
@@ -135,32 +142,39 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmP p) {
 #pragma unroll
     for (int j = 0; j < NI; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  load_tiles(0);
-  store_tiles(0);
+#pragma unroll
+  for (int d = 0; d < D; ++d)
+    if (d < nk) load_tiles(d, ra[d], rb[d]);
+  store_tiles(0, ra[0], rb[0]);
   __syncthreads();
 
   const int frow = lane & 15, fk = (lane >> 4) * KCH;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) load_tiles(kt + 1);
-    const char* a_base = smem + cur * kBufBytes + (wr * WM + frow) * kRowStride + fk * (int)sizeof(T);
-    const char* b_base = smem + cur * kBufBytes + (BM + wc * WN + frow) * kRowStride + fk * (int)sizeof(T);
+  for (int kt0 = 0; kt0 < nk; kt0 += D) {
 #pragma unroll
-    for (int ks = 0; ks < BK / KM; ++ks) {
-      typename Atom<T>::frag_t af[MI], bf[NI];
+    for (int d = 0; d < D; ++d) {
+      const int kt = kt0 + d;
+      if (kt >= nk) break;
+      const int cur = kt & 1;
+      if (kt + D < nk) load_tiles(kt + D, ra[d], rb[d]);   // slot d was drained into LDS one iteration ago
+      const char* a_base = smem + cur * kBufBytes + (wr * WM + frow) * kRowStride + fk * (int)sizeof(T);
+      const char* b_base = smem + cur * kBufBytes + (BM + wc * WN + frow) * kRowStride + fk * (int)sizeof(T);
 #pragma unroll
-      for (int i = 0; i < MI; ++i)
-        af[i] = Atom<T>::load(reinterpret_cast<const T*>(a_base + i * 16 * kRowStride + ks * KM * (int)sizeof(T)));
+      for (int ks = 0; ks < BK / KM; ++ks) {
+        typename Atom<T>::frag_t af[MI], bf[NI];
 #pragma unroll
-      for (int j = 0; j < NI; ++j)
-        bf[j] = Atom<T>::load(reinterpret_cast<const T*>(b_base + j * 16 * kRowStride + ks * KM * (int)sizeof(T)));
+        for (int i = 0; i < MI; ++i)
+          af[i] = Atom<T>::load(reinterpret_cast<const T*>(a_base + i * 16 * kRowStride + ks * KM * (int)sizeof(T)));
 #pragma unroll
-      for (int i = 0; i < MI; ++i)
+        for (int j = 0; j < NI; ++j)
+          bf[j] = Atom<T>::load(reinterpret_cast<const T*>(b_base + j * 16 * kRowStride + ks * KM * (int)sizeof(T)));
 #pragma unroll
-        for (int j = 0; j < NI; ++j) acc[i][j] = Atom<T>::mma(af[i], bf[j], acc[i][j]);
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j) acc[i][j] = Atom<T>::mma(af[i], bf[j], acc[i][j]);
+      }
+      if (kt + 1 < nk) store_tiles(cur ^ 1, ra[(d + 1) % D], rb[(d + 1) % D]);
+      __syncthreads();
     }
-    if (kt + 1 < nk) store_tiles(cur ^ 1);
-    __syncthreads();
   }
 
   // epilogue: acc[i][j][r] = C[m0 + wr*WM + i*16 + (lane>>4)*4 + r][n0 + wc*WN + j*16 + (lane&15)]
