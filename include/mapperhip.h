@@ -48,6 +48,10 @@ typedef enum MhEpilogue {
   MH_EPI_QKV_VT = 7,     /* cols < n_split: C[T] = A W^T (+bias) (q|k block, ldc);
                             cols >= n_split (the v block, col' = h*64+dd, row = b*kv_L+key):
                             C2[T][((b*kv_H + h)*64 + dd)*kv_Lpad + key]  (V transposed per head)  */
+  MH_EPI_QKV_CACHE = 8,  /* decoder prompt prefill: rows m = b*kv_L + i (prompt position i of chunk b);
+                            cols < n_split: C[T] (q, ldc); then the k block -> C2 and the v block -> C3, both
+                            [B][H][cache_len][64] at position i; the v block is also written transposed to
+                            C4[T][((b*kv_H + h)*64 + dd)*kv_Lpad + i]                                     */
 } MhEpilogue;
 
 const char* mh_last_error(void);
@@ -85,7 +89,8 @@ typedef struct MhGemm {
   const float* bias;
   const float* gate; int gate_ld; int rows_per_batch;
   int kv_B, kv_H, kv_L;
-  void* C2; int n_split; int kv_Lpad;   /* MH_EPI_QKV_VT only */
+  void* C2; int n_split; int kv_Lpad;   /* MH_EPI_QKV_VT / MH_EPI_QKV_CACHE */
+  void* C3; void* C4; int cache_len;    /* MH_EPI_QKV_CACHE only */
   int dtype; int epilogue;
 } MhGemm;
 int mh_gemm(const MhGemm* g, void* stream);

@@ -11,7 +11,7 @@ import os
 MH_MAX_LAYERS = 32
 MH_F32, MH_BF16 = 0, 1
 (EPI_STORE, EPI_STORE_F32, EPI_RESID, EPI_GEGLU, EPI_BIAS_GELU, EPI_GATE_RESID, EPI_KV_SCATTER,
- EPI_QKV_VT) = range(8)
+ EPI_QKV_VT, EPI_QKV_CACHE) = range(9)
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmapperhip.so")
 
@@ -25,6 +25,7 @@ class MhGemm(C.Structure):
                 ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("bias", VP), ("gate", VP),
                 ("gate_ld", C.c_int), ("rows_per_batch", C.c_int), ("kv_B", C.c_int), ("kv_H", C.c_int),
                 ("kv_L", C.c_int), ("C2", VP), ("n_split", C.c_int), ("kv_Lpad", C.c_int),
+                ("C3", VP), ("C4", VP), ("cache_len", C.c_int),
                 ("dtype", C.c_int), ("epilogue", C.c_int)]
 
 

@@ -1,29 +1,25 @@
 // Fused (flash-style) multi-head attention for head_dim = 64 on the gfx950 matrix cores.
 //   T5 encoder self-attention : softmax(Q K^T + rel_bias[h][k - q]) V, scale 1 (T5 folds 1/sqrt(d) into init)
 //                               HF T5Attention.forward; restated custom_transformers/t5.py:170-250
+//   T5 decoder prompt prefill : causal self-attention over the (left-padded) prompt with the unidirectional
+//                               bias table and the key-padding mask; cross-attention of all prompt positions
+//                               over the encoder keys (no bias) -- the batched form of what the per-token
+//                               decode kernels do one position at a time
 //   DiT self-attention        : softmax(Q K^T / 8 + band mask) V (nn.MultiheadAttention with the banded
 //                               bool mask of diffusion_pipeline.py:146-148; models.py:111-116,145-151)
 // Layout: block = 4 waves, 64 query rows (16 per wave) of one (batch, head); K tile [64 keys][64] and the
 // pre-transposed V tile [64 d][64 keys] staged in LDS with 16-byte accesses; S and O live in MFMA
 // accumulators, softmax reductions are 16-lane shuffles, P goes through a wave-private LDS patch to
-// become the A operand of the PV product.  V^T is produced by the QKV GEMM epilogue (MH_EPI_QKV_VT).
+// become the A operand of the PV product.  Q, K, V^T, the output and the masks are addressed through
+// explicit (row, batch, head) strides so that the same kernel reads the packed QKV GEMM output, the
+// [B][H][L][64] K/V caches of the decoder and their transposed copies.
 #include "internal.hpp"
 
 namespace mh {
 namespace {
 
-struct AttnP {
-  const char* qk; long ld_qk_b; int k_col0;
-  const char* vt; int Lpad;
-  const float* bias;
-  char* out; long ld_out_b;
-  int B, L, H;
-  float scale; int band;
-};
-
-
 template <typename T>
-__global__ __launch_bounds__(256) void flash_attn_kernel(AttnP p) {
+__global__ __launch_bounds__(256) void flash_attn_kernel(AttnArgs p) {
   constexpr int ES = (int)sizeof(T);
   constexpr int KM = Atom<T>::KM, KCH = Atom<T>::KCH;
   constexpr int KS = 64 / KM;               // MFMA k-steps over a 64-wide contraction
@@ -38,7 +34,7 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(AttnP p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-  const int L = p.L;
+  const int Lq = p.Lq, Lk = p.Lk;
   const int qb0 = qt * 64;
   const int q0w = qb0 + wid * 16;
   const int l15 = lane & 15, lg = lane >> 4;
@@ -47,8 +43,8 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(AttnP p) {
   typename Atom<T>::frag_t qf[KS];
   {
     int qr = q0w + l15;
-    qr = qr < L ? qr : L - 1;
-    const char* qp = p.qk + (long)(b * L + qr) * p.ld_qk_b + (long)(h * 64 + lg * KCH) * ES;
+    qr = qr < Lq ? qr : Lq - 1;
+    const char* qp = (const char*)p.q + (long)b * p.q_bs + (long)qr * p.q_rs + (long)(h * 64 + lg * KCH) * ES;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) qf[ks] = Atom<T>::load(reinterpret_cast<const T*>(qp + ks * KM * ES));
   }
@@ -60,18 +56,26 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(AttnP p) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) { m[r] = -1e30f; l[r] = 0.f; }
 
-  int t_lo = 0, t_hi = (L - 1) / 64;
+  // key tiles this query block can see
+  int t_lo = 0, t_hi = (Lk - 1) / 64;
   if (p.band > 0) {
     int klo = qb0 - (p.band - 1);
     klo = klo < 0 ? 0 : klo;
     int khi = qb0 + 63 + p.band;
-    khi = khi > L - 1 ? L - 1 : khi;
+    khi = khi > Lk - 1 ? Lk - 1 : khi;
     t_lo = klo / 64;
     t_hi = khi / 64;
   }
+  if (p.causal) {
+    int khi = p.q_pos0 + qb0 + 63;
+    khi = khi > Lk - 1 ? Lk - 1 : khi;
+    t_hi = khi / 64;
+  }
 
-  const char* kbase = p.qk + (long)(p.k_col0 + h * 64) * ES;
-  const char* vbase = p.vt + ((long)(b * p.H + h) * 64) * (long)p.Lpad * ES;
+  const char* kbase = (const char*)p.k + (long)b * p.k_bs + (long)h * p.k_hs;
+  const char* vbase = (const char*)p.vt + (long)b * p.vt_bs + (long)h * p.vt_hs;
+  const float* bh = p.bias ? p.bias + (long)h * p.bias_hs + p.bias_center : nullptr;
+  const uint8_t* mrow = p.key_mask ? p.key_mask + (long)b * p.mask_ld : nullptr;
   char* Pw = Ps + wid * 16 * RS;
 
   for (int kt = t_lo; kt <= t_hi; ++kt) {
@@ -82,9 +86,9 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(AttnP p) {
       const int idx = tid + 256 * i;
       const int row = idx / CPR, ch = idx % CPR;
       int kr = kv0 + row;
-      kr = kr < L ? kr : L - 1;
-      uint4 kv = *reinterpret_cast<const uint4*>(kbase + (long)(b * L + kr) * p.ld_qk_b + ch * 16);
-      uint4 vv = *reinterpret_cast<const uint4*>(vbase + ((long)row * p.Lpad + kv0) * ES + ch * 16);
+      kr = kr < Lk ? kr : Lk - 1;
+      uint4 kv = *reinterpret_cast<const uint4*>(kbase + (long)kr * p.k_rs + ch * 16);
+      uint4 vv = *reinterpret_cast<const uint4*>(vbase + ((long)row * p.Lkpad + kv0) * ES + ch * 16);
       *reinterpret_cast<uint4*>(Ks + row * RS + ch * 16) = kv;
       *reinterpret_cast<uint4*>(Vts + row * RS + ch * 16) = vv;
     }
@@ -106,38 +110,51 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(AttnP p) {
 
     // ---- scale, bias, mask, online softmax ----
     float mx[4], rs[4], alpha[4];
-    // relative-position bias: ONE wave-uniform branch, 16 unconditional loads from clamped indices (a
-    // predicated load per element would serialise into 16 L2 round trips per tile)
+    // bias / key-mask values: wave-uniform branches, unconditional loads from clamped indices (a predicated
+    // load per element would serialise into one L2 round trip each)
     float bv[4][4];
+    int kmv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) kmv[j] = 1;
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
       for (int j = 0; j < 4; ++j) bv[r][j] = 0.f;
-    if (p.bias) {
-      const float* bh = p.bias + (long)h * (2 * L - 1) + (L - 1);
+    if (bh) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int qg = q0w + lg * 4 + r;
-        const int qgc = qg < L ? qg : L - 1;
+        const int qpos = p.q_pos0 + (qg < Lq ? qg : Lq - 1);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int kg = kv0 + j * 16 + l15;
-          bv[r][j] = bh[(kg < L ? kg : L - 1) - qgc];
+          int idx = p.bias_sign * ((kg < Lk ? kg : Lk - 1) - qpos);
+          idx = idx < p.bias_min ? p.bias_min : (idx > p.bias_max ? p.bias_max : idx);
+          bv[r][j] = bh[idx];
         }
+      }
+    }
+    if (mrow) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int kg = kv0 + j * 16 + l15;
+        const int mval = mrow[kg < p.mask_len ? kg : p.mask_len - 1];
+        kmv[j] = (kg < p.mask_len) ? mval : 1;
       }
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      int qg = q0w + lg * 4 + r;
-      const int qgc = qg < L ? qg : L - 1;
+      const int qg = q0w + lg * 4 + r;
+      const int qpos = p.q_pos0 + (qg < Lq ? qg : Lq - 1);
       float mxr = -INFINITY;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int kg = kv0 + j * 16 + l15;
         float v = s[j][r] * p.scale + bv[r][j];
-        const int rel = kg - qgc;
-        bool ok = kg < L;
+        const int rel = kg - qpos;
+        bool ok = (kg < Lk) && (kmv[j] != 0);
         if (p.band > 0) ok = ok && (rel >= -(p.band - 1)) && (rel <= p.band);
+        if (p.causal) ok = ok && (rel <= 0);
         v = ok ? v : -INFINITY;
         s[j][r] = v;
         mxr = fmaxf(mxr, v);
@@ -188,39 +205,79 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(AttnP p) {
     __syncthreads();
   }
 
-  // ---- normalise and store ----
+  // ---- normalise and store (a fully masked query row -- a left-pad position -- yields zeros) ----
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int qg = q0w + lg * 4 + r;
-    if (qg >= L) continue;
-    const float inv = 1.0f / l[r];
-    T* op = reinterpret_cast<T*>(p.out + (long)(b * L + qg) * p.ld_out_b) + h * 64 + l15;
+    if (qg >= Lq) continue;
+    const float inv = l[r] > 0.f ? 1.0f / l[r] : 0.f;
+    T* op = reinterpret_cast<T*>((char*)p.out + (long)b * p.out_bs + (long)qg * p.out_rs) + h * 64 + l15;
 #pragma unroll
     for (int j = 0; j < 4; ++j) op[j * 16] = Elem<T>::from_f32(o[j][r] * inv);
   }
 }
 
+// V [B][H][Lk][64] (row stride 64) -> V^T [B][H][64][Lkpad]; pad columns are left untouched (zeroed once by the caller)
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_v_kernel(const T* __restrict__ v, long v_bs, long v_hs, int Lk, T* __restrict__ vt,
+                                                         int Lkpad, int H) {
+  __shared__ T tile[64][66];
+  const int k0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+  const T* src = v + b * v_bs + h * v_hs;
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int kr = i >> 6, d = i & 63;
+    tile[kr][d] = (k0 + kr < Lk) ? src[(long)(k0 + kr) * 64 + d] : T(0);
+  }
+  __syncthreads();
+  T* dst = vt + ((long)(b * H + h) * 64) * Lkpad;
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int d = i >> 6, kr = i & 63;
+    if (k0 + kr < Lk) dst[(long)d * Lkpad + k0 + kr] = tile[kr][d];
+  }
+}
+
 }  // namespace
+
+int attention_general(const AttnArgs& a, int B, int H, int dtype, hipStream_t s) {
+  MH_REQUIRE(a.q && a.k && a.vt && a.out, "attention: null operand");
+  MH_REQUIRE(B > 0 && a.Lq > 0 && a.Lk > 0 && H > 0, "attention: bad shape");
+  MH_REQUIRE(a.Lkpad % 64 == 0 && a.Lkpad >= a.Lk, "attention: Lkpad=%d must be a multiple of 64 and >= Lk=%d", a.Lkpad, a.Lk);
+  MH_REQUIRE(a.q_rs % 16 == 0 && a.k_rs % 16 == 0 && a.q_bs % 16 == 0 && a.k_bs % 16 == 0 && a.k_hs % 16 == 0 &&
+                 a.vt_bs % 16 == 0 && a.vt_hs % 16 == 0,
+             "attention: strides must be multiples of 16 bytes");
+  const int es = dtype == MH_BF16 ? 2 : 4;
+  dim3 grid(ceil_div(a.Lq, 64), H, B), block(256);
+  const size_t smem = (size_t)(128 + 64) * (64 * es + 16);
+  if (dtype == MH_BF16)
+    hipLaunchKernelGGL(flash_attn_kernel<bf16_t>, grid, block, smem, s, a);
+  else
+    hipLaunchKernelGGL(flash_attn_kernel<float>, grid, block, smem, s, a);
+  return check_launch("flash_attn_kernel");
+}
 
 int attention(const void* qk, int ld_qk, int k_col0, const void* vt, int Lpad, const float* bias, void* out,
               int ld_out, int B, int L, int H, float scale, int band, int dtype, hipStream_t s) {
   MH_REQUIRE(qk && vt && out, "mh_attention: null operand");
-  MH_REQUIRE(B > 0 && L > 0 && H > 0, "mh_attention: bad shape");
-  MH_REQUIRE(Lpad % 64 == 0 && Lpad >= L, "mh_attention: Lpad=%d must be a multiple of 64 and >= L=%d", Lpad, L);
   const int es = dtype == MH_BF16 ? 2 : 4;
   MH_REQUIRE((ld_qk * es) % 16 == 0 && (k_col0 * es) % 16 == 0, "mh_attention: rows must be 16-byte aligned");
-  AttnP p;
-  p.qk = (const char*)qk; p.ld_qk_b = (long)ld_qk * es; p.k_col0 = k_col0;
-  p.vt = (const char*)vt; p.Lpad = Lpad; p.bias = bias;
-  p.out = (char*)out; p.ld_out_b = (long)ld_out * es;
-  p.B = B; p.L = L; p.H = H; p.scale = scale; p.band = band;
-  dim3 grid(ceil_div(L, 64), H, B), block(256);
-  const size_t smem = (size_t)(128 + 64) * (64 * es + 16);
+  AttnArgs a{};
+  a.q = qk; a.q_rs = (long)ld_qk * es; a.q_bs = (long)L * ld_qk * es;
+  a.k = (const char*)qk + (long)k_col0 * es; a.k_rs = (long)ld_qk * es; a.k_bs = (long)L * ld_qk * es; a.k_hs = 64L * es;
+  a.vt = vt; a.Lkpad = Lpad; a.vt_hs = 64L * Lpad * es; a.vt_bs = (long)H * 64 * Lpad * es;
+  a.bias = bias; a.bias_hs = 2L * L - 1; a.bias_center = L - 1; a.bias_sign = 1; a.bias_min = -(L - 1); a.bias_max = L - 1;
+  a.key_mask = nullptr; a.mask_ld = 0; a.mask_len = 0;
+  a.out = out; a.out_rs = (long)ld_out * es; a.out_bs = (long)L * ld_out * es;
+  a.Lq = L; a.Lk = L; a.scale = scale; a.band = band; a.causal = 0; a.q_pos0 = 0;
+  return attention_general(a, B, H, dtype, s);
+}
+
+int transpose_v(const void* v, long v_bs_el, long v_hs_el, int Lk, void* vt, int Lkpad, int B, int H, int dtype, hipStream_t s) {
+  dim3 grid(ceil_div(Lk, 64), H, B), block(256);
   if (dtype == MH_BF16)
-    hipLaunchKernelGGL(flash_attn_kernel<bf16_t>, grid, block, smem, s, p);
+    hipLaunchKernelGGL(transpose_v_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)v, v_bs_el, v_hs_el, Lk, (bf16_t*)vt, Lkpad, H);
   else
-    hipLaunchKernelGGL(flash_attn_kernel<float>, grid, block, smem, s, p);
-  return check_launch("flash_attn_kernel");
+    hipLaunchKernelGGL(transpose_v_kernel<float>, grid, block, 0, s, (const float*)v, v_bs_el, v_hs_el, Lk, (float*)vt, Lkpad, H);
+  return check_launch("transpose_v_kernel");
 }
 
 }  // namespace mh

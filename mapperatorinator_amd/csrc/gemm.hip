@@ -23,6 +23,7 @@ struct GemmP {
   const float* gate; int gate_ld; int rows_per_batch;
   int kv_B, kv_H, kv_L;
   void* C2; int n_split; int kv_Lpad;
+  void* C3; void* C4; int cache_len;
 };
 
 // `v` already contains the bias; `old` = previous C value (RESID / GATE_RESID), `g` = gate value, `v2` = paired
@@ -64,6 +65,23 @@ __device__ inline void epilogue_store(const GemmP& p, int row, int col, float v,
       long dst = ((long)b * p.kv_H * 64 + c2) * p.kv_Lpad + key;
       reinterpret_cast<T*>(p.C2)[dst] = Elem<T>::from_f32(v);
     }
+  } else if (EPI == MH_EPI_QKV_CACHE) {
+    if (col < p.n_split) {
+      reinterpret_cast<T*>(p.C)[(long)row * p.ldc + col] = Elem<T>::from_f32(v);
+    } else {
+      const int inner = p.kv_H * 64;
+      const int c2 = col - p.n_split;
+      const int kv = c2 / inner, c = c2 - kv * inner;   // 0 = k, 1 = v ; c = h*64 + dd
+      const int b = row / p.kv_L, i = row - b * p.kv_L;
+      const T tv = Elem<T>::from_f32(v);
+      const long dst = (((long)b * p.kv_H + (c >> 6)) * p.cache_len + i) * 64 + (c & 63);
+      if (kv == 0) {
+        reinterpret_cast<T*>(p.C2)[dst] = tv;
+      } else {
+        reinterpret_cast<T*>(p.C3)[dst] = tv;
+        reinterpret_cast<T*>(p.C4)[((long)b * p.kv_H * 64 + c) * p.kv_Lpad + i] = tv;
+      }
+    }
   }
 }
 
@@ -99,11 +117,11 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmP p) {
   const int cchunk = tid & 7;   // 16-byte chunk within the 128-byte K step
   const int crow = tid >> 3;    // 0..31
 
-  // Register ring of D in-flight K tiles (tile t lives in slot t % D) in front of the double-buffered LDS stage:
-  // a tile's global loads have D-1 full iterations to land before they are written to LDS.  Small grids
-  // (M = 256 DiT GEMMs: 24-96 workgroups, up to 48 K steps) are latency-bound per K step, so depth matters
-  // there; the 128x128 tile keeps D = 1 (2 workgroups per CU hide the latency instead).
-  constexpr int D = (BM == 64) ? 4 : 1;
+  // Register ring of D in-flight K tiles (tile t lives in slot t % D) in front of the double-buffered LDS stage.
+  // Measured: D = 4 made the small (M = 256) fp32 GEMMs of the DiT SLOWER (140 -> 188 ms per 100 steps): those are
+  // bound by the per-wave MFMA issue time of a K step (32 x 32-cycle f32 MFMAs), not by load latency; what helps
+  // them is more workgroups (the 32x32 tile below).  D stays 1.
+  constexpr int D = 1;
   uint4 ra[D][A_CHUNKS], rb[D][B_CHUNKS];
   const int nk = (p.K + BK - 1) / BK;
 
@@ -246,20 +264,30 @@ bool prepare_one() {
 }
 template <typename T, int EPI>
 bool prepare_epi() {
-  return prepare_one<T, 128, 128, EPI>() && prepare_one<T, 64, 64, EPI>();
+  bool ok = prepare_one<T, 128, 128, EPI>() && prepare_one<T, 64, 64, EPI>();
+  if constexpr (EPI != MH_EPI_GEGLU) ok = ok && prepare_one<T, 32, 32, EPI>();   // GEGLU pairs two 16-col blocks per wave
+  return ok;
 }
 template <typename T>
 bool prepare_type() {
   return prepare_epi<T, MH_EPI_STORE>() && prepare_epi<T, MH_EPI_STORE_F32>() && prepare_epi<T, MH_EPI_RESID>() &&
          prepare_epi<T, MH_EPI_GEGLU>() && prepare_epi<T, MH_EPI_BIAS_GELU>() && prepare_epi<T, MH_EPI_GATE_RESID>() &&
-         prepare_epi<T, MH_EPI_KV_SCATTER>() && prepare_epi<T, MH_EPI_QKV_VT>();
+         prepare_epi<T, MH_EPI_KV_SCATTER>() && prepare_epi<T, MH_EPI_QKV_VT>() && prepare_epi<T, MH_EPI_QKV_CACHE>();
 }
 
 template <typename T, int EPI>
 int dispatch_tile(const GemmP& p, hipStream_t s) {
+  // tile by grid size: the chip has 256 CUs; a K step of a wave costs MI*NI MFMAs, so small problems want
+  // many small tiles (DiT: M = 256 rows) and big ones the 128x128 tile (encoder: M = 40k rows)
   const long tiles128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+  const long tiles64 = (long)((p.M + 63) / 64) * ((p.N + 63) / 64);
   if (tiles128 >= 192) return launch_gemm<T, 128, 128, EPI>(p, s);
-  return launch_gemm<T, 64, 64, EPI>(p, s);
+  if constexpr (EPI == MH_EPI_GEGLU) {
+    return launch_gemm<T, 64, 64, EPI>(p, s);
+  } else {
+    if (tiles64 >= 192) return launch_gemm<T, 64, 64, EPI>(p, s);
+    return launch_gemm<T, 32, 32, EPI>(p, s);
+  }
 }
 
 template <typename T>
@@ -273,6 +301,7 @@ int dispatch_epi(const GemmP& p, int epi, hipStream_t s) {
     case MH_EPI_GATE_RESID: return dispatch_tile<T, MH_EPI_GATE_RESID>(p, s);
     case MH_EPI_KV_SCATTER: return dispatch_tile<T, MH_EPI_KV_SCATTER>(p, s);
     case MH_EPI_QKV_VT: return dispatch_tile<T, MH_EPI_QKV_VT>(p, s);
+    case MH_EPI_QKV_CACHE: return dispatch_tile<T, MH_EPI_QKV_CACHE>(p, s);
   }
   set_error("mh_gemm: unknown epilogue %d", epi);
   return MH_ERR_ARG;
@@ -311,8 +340,13 @@ int gemm(const MhGemm& g, hipStream_t s) {
     MH_REQUIRE(g.C2 && g.kv_H > 0 && g.kv_L > 0 && g.kv_Lpad >= g.kv_L && g.n_split > 0 &&
                    g.N - g.n_split == g.kv_H * 64 && g.M % g.kv_L == 0,
                "mh_gemm: bad QKV_VT geometry");
+  if (g.epilogue == MH_EPI_QKV_CACHE)
+    MH_REQUIRE(g.C2 && g.C3 && g.C4 && g.kv_H > 0 && g.kv_L > 0 && g.kv_Lpad >= g.kv_L && g.cache_len >= g.kv_L &&
+                   g.n_split == g.kv_H * 64 && g.N == 3 * g.kv_H * 64 && g.M % g.kv_L == 0,
+               "mh_gemm: bad QKV_CACHE geometry");
   { int rc = gemm_prepare(); if (rc != MH_OK) return rc; }
   GemmP p;
+  p.C3 = g.C3; p.C4 = g.C4; p.cache_len = g.cache_len;
   p.C2 = g.C2; p.n_split = g.n_split; p.kv_Lpad = g.kv_Lpad;
   p.A = (const char*)g.A; p.lda_b = (long)g.lda * es;
   p.W = (const char*)g.W; p.ldw_b = (long)g.ldw * es;

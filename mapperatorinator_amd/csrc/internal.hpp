@@ -13,6 +13,24 @@ int ln_modulate(const float* x, int ldx, const float* shift, const float* scale,
 int attention(const void* qk, int ld_qk, int k_col0, const void* vt, int Lpad, const float* bias, void* out,
               int ld_out, int B, int L, int H, float scale, int band, int dtype, hipStream_t s);
 
+// strided description of one attention problem (all byte strides; see attention.hip)
+struct AttnArgs {
+  const void* q; long q_rs, q_bs;            // query rows: + b*q_bs + row*q_rs + h*64*sizeof(T)
+  const void* k; long k_rs, k_bs, k_hs;      // key rows:   + b*k_bs + h*k_hs + key*k_rs
+  const void* vt; long vt_bs, vt_hs; int Lkpad;   // V^T [..][64][Lkpad]: + b*vt_bs + h*vt_hs + d*Lkpad*sizeof(T)
+  const float* bias; long bias_hs; int bias_center, bias_sign, bias_min, bias_max;   // bias[h*hs + center + clamp(sign*(k-q))]
+  const uint8_t* key_mask; int mask_ld, mask_len;   // [B][mask_ld], 1 = attend, keys >= mask_len always attend
+  void* out; long out_rs, out_bs;
+  int Lq, Lk;
+  float scale;
+  int band;        // > 0: attend iff -(band-1) <= k - q <= band
+  int causal;      // attend iff key position <= q_pos0 + query index
+  int q_pos0;
+};
+int attention_general(const AttnArgs& a, int B, int H, int dtype, hipStream_t s);
+int transpose_v(const void* v, long v_bs_el, long v_hs_el, int Lk, void* vt, int Lkpad, int B, int H, int dtype,
+                hipStream_t s);
+
 inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 inline int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
 

@@ -169,20 +169,21 @@ __device__ inline float uniform01(uint64_t seed, uint32_t row, uint32_t step) {
   return (float)((z >> 40) + 0.5) * (1.0f / 16777216.0f);
 }
 
-// init: consume column 0 of the prompt (state machine + embedding of the first token)
+// init: consume prompt columns 0..start_pos (processor state machine) and embed the token at start_pos, the first
+// position the per-token loop feeds (0 without prefill, P-1 after the batched prompt prefill)
 template <typename T>
-__global__ __launch_bounds__(256) void dec_init_kernel(SampleP p, int chain_rows) {
+__global__ __launch_bounds__(256) void dec_init_kernel(SampleP p, int chain_rows, int start_pos) {
   const int lb = blockIdx.x, b = p.b0 + lb;
   if (threadIdx.x == 0) {
     int32_t v = -1;
-    update_ts_state(p.sp, p.tokens[(long)b * p.max_length], &v);
+    for (int i = 0; i <= start_pos; ++i) update_ts_state(p.sp, p.tokens[(long)b * p.max_length + i], &v);
     p.last_ts_val[b] = v;
     p.finished[b] = 0;
     p.finish_col[b] = p.max_length - 1;
-    if (lb == 0) { p.st->pos = 0; p.st->n_running = chain_rows; }
+    if (lb == 0) { p.st->pos = start_pos; p.st->n_running = chain_rows; }
   }
   __shared__ float scratch[8];
-  const int tok = p.tokens[(long)b * p.max_length];
+  const int tok = p.tokens[(long)b * p.max_length + start_pos];
   const T* e = reinterpret_cast<const T*>(p.dec_embed) + (long)tok * p.d;
   float sq = 0.f;
   for (int i = threadIdx.x; i < p.d; i += 256) {
@@ -522,6 +523,13 @@ int enqueue_step(const MhT5Config* c, const MhT5Weights* w, const void* cross_kv
 }  // namespace
 }  // namespace mh
 
+namespace mh {
+namespace {
+struct PrefillBuf;
+int64_t prefill_layout(const MhT5Config* c, int B, int np_max, void* base, int64_t size, PrefillBuf* out);
+}  // namespace
+}  // namespace mh
+
 extern "C" int64_t mh_t5_decode_workspace_bytes(const MhT5Config* c, int B) {
   if (!c || B <= 0) return -1;
   const int64_t es = es_of(c->dtype);
@@ -536,11 +544,122 @@ extern "C" int64_t mh_t5_decode_workspace_bytes(const MhT5Config* c, int B) {
   t += align256((int64_t)c->n_dec_layers * B * inner * c->tgt_len * es) * 2;      // self K, V caches
   t += align256(B) + align256((int64_t)B * 4) * 2 + align256(sizeof(DecState)) * kMaxChains;   // flags / state
   t += align256((int64_t)B * c->n_heads * 4);                                     // cross-attention merge tickets
+  t += prefill_layout(c, B, c->tgt_len - 1, nullptr, 0, nullptr);                  // batched prompt prefill
   return t;
 }
 
 namespace mh {
 namespace {
+
+// rows r = b*np + i  <-  dec_embed[prompt[b][i]]   (fp32 residual stream of the prompt prefill)
+template <typename T>
+__global__ __launch_bounds__(256) void prefill_embed_kernel(const int32_t* __restrict__ prompt, int P, int np,
+                                                           const T* __restrict__ emb, int d, float* __restrict__ h) {
+  const int r = blockIdx.x, b = r / np, i = r - b * np;
+  const T* e = emb + (long)prompt[(long)b * P + i] * d;
+  for (int k = threadIdx.x; k < d; k += 256) h[(long)r * d + k] = Elem<T>::to_f32(e[k]);
+}
+
+struct PrefillBuf {
+  float* h; void* n; void* q; void* attn; void* ff; void* vt; void* cross_vt;
+  int np_pad, Lpad;
+};
+
+int64_t prefill_layout(const MhT5Config* c, int B, int np_max, void* base, int64_t size, PrefillBuf* out) {
+  Arena ar(base, size);
+  const int64_t es = es_of(c->dtype), rows = (int64_t)B * np_max, inner = c->n_heads * 64;
+  PrefillBuf t;
+  t.np_pad = round_up(np_max, 64);
+  t.Lpad = round_up(c->src_len, 64);
+  t.h = (float*)ar.take(rows * c->d_model * 4);
+  t.n = ar.take(rows * c->d_model * es);
+  t.q = ar.take(rows * inner * es);
+  t.attn = ar.take(rows * inner * es);
+  t.ff = ar.take(rows * c->d_ff * es);
+  t.vt = ar.take((int64_t)B * inner * t.np_pad * es);
+  t.cross_vt = ar.take((int64_t)c->n_dec_layers * B * inner * t.Lpad * es);
+  if (out) *out = t;
+  return ar.off;
+}
+
+// Batched prompt prefill: positions 0 .. P-2 of every row go through the decoder stack at once (MFMA GEMMs +
+// flash attention), filling the self-attention K/V caches exactly as P-1 single-token steps would
+// (HF prefill: SURVEY.md appendix A.1).  Position P-1 is left to the per-token loop, which also produces the
+// first sampled token.  Left-pad keys are masked, left-pad query rows produce unused garbage, as in HF.
+int prefill_prompt(const MhT5Config* c, const MhT5Weights* w, const void* cross_kv, int B, const int32_t* prompt,
+                   const uint8_t* prompt_mask, int P, void* self_k, void* self_v, const PrefillBuf& pb, hipStream_t s) {
+  const int np = P - 1, rows = B * np;
+  const int d = c->d_model, H = c->n_heads, inner = H * 64, dff = c->d_ff, L = c->src_len, tgt = c->tgt_len;
+  const int es = es_of(c->dtype);
+  const int np_pad = round_up(np, 64);
+  if (c->dtype == MH_BF16)
+    hipLaunchKernelGGL(prefill_embed_kernel<bf16_t>, dim3(rows), dim3(256), 0, s, prompt, P, np, (const bf16_t*)w->dec_embed, d, pb.h);
+  else
+    hipLaunchKernelGGL(prefill_embed_kernel<float>, dim3(rows), dim3(256), 0, s, prompt, P, np, (const float*)w->dec_embed, d, pb.h);
+  MH_TRY(check_launch("prefill_embed_kernel"));
+  if (hipMemsetAsync(pb.vt, 0, (size_t)B * inner * np_pad * es, s) != hipSuccess) return check_launch("memset prefill vt");
+  if (hipMemsetAsync(pb.cross_vt, 0, (size_t)c->n_dec_layers * B * inner * pb.Lpad * es, s) != hipSuccess)
+    return check_launch("memset cross vt");
+  const long kv_layer = (long)B * H * L * 64;   // elements per (layer, k|v) slab of cross_kv
+  for (int l = 0; l < c->n_dec_layers; ++l)
+    MH_TRY(transpose_v((const char*)cross_kv + (long)(l * 2 + 1) * kv_layer * es, (long)H * L * 64, (long)L * 64, L,
+                       (char*)pb.cross_vt + (long)l * B * inner * pb.Lpad * es, pb.Lpad, B, H, c->dtype, s));
+  MhGemm g;
+  for (int l = 0; l < c->n_dec_layers; ++l) {
+    char* kc = (char*)self_k + (long)l * B * H * tgt * 64 * es;
+    char* vc = (char*)self_v + (long)l * B * H * tgt * 64 * es;
+    // self attention over the prompt
+    MH_TRY(rmsnorm(pb.h, d, w->dec_ln1[l], pb.n, d, rows, d, c->eps, c->dtype, s));
+    g = MhGemm{};
+    g.A = pb.n; g.lda = d; g.W = w->dec_qkv[l]; g.ldw = d; g.C = pb.q; g.ldc = inner; g.M = rows; g.N = 3 * inner; g.K = d;
+    g.dtype = c->dtype; g.epilogue = MH_EPI_QKV_CACHE; g.n_split = inner; g.C2 = kc; g.C3 = vc; g.C4 = pb.vt; g.kv_B = B;
+    g.kv_H = H; g.kv_L = np; g.kv_Lpad = np_pad; g.cache_len = tgt;
+    MH_TRY(gemm(g, s));
+    AttnArgs a{};
+    a.q = pb.q; a.q_rs = (long)inner * es; a.q_bs = (long)np * inner * es;
+    a.k = kc; a.k_rs = 64L * es; a.k_hs = (long)tgt * 64 * es; a.k_bs = (long)H * tgt * 64 * es;
+    a.vt = pb.vt; a.Lkpad = np_pad; a.vt_hs = 64L * np_pad * es; a.vt_bs = (long)H * 64 * np_pad * es;
+    a.bias = w->dec_rel_bias; a.bias_hs = tgt; a.bias_center = 0; a.bias_sign = -1; a.bias_min = 0; a.bias_max = tgt - 1;
+    a.key_mask = prompt_mask; a.mask_ld = P; a.mask_len = np;
+    a.out = pb.attn; a.out_rs = (long)inner * es; a.out_bs = (long)np * inner * es;
+    a.Lq = np; a.Lk = np; a.scale = 1.0f; a.band = 0; a.causal = 1; a.q_pos0 = 0;
+    MH_TRY(attention_general(a, B, H, c->dtype, s));
+    g = MhGemm{};
+    g.A = pb.attn; g.lda = inner; g.W = w->dec_o[l]; g.ldw = inner; g.C = pb.h; g.ldc = d; g.M = rows; g.N = d; g.K = inner;
+    g.dtype = c->dtype; g.epilogue = MH_EPI_RESID;
+    MH_TRY(gemm(g, s));
+    // cross attention of every prompt position over the encoder keys
+    MH_TRY(rmsnorm(pb.h, d, w->dec_ln2[l], pb.n, d, rows, d, c->eps, c->dtype, s));
+    g = MhGemm{};
+    g.A = pb.n; g.lda = d; g.W = w->dec_cq[l]; g.ldw = d; g.C = pb.q; g.ldc = inner; g.M = rows; g.N = inner; g.K = d;
+    g.dtype = c->dtype; g.epilogue = MH_EPI_STORE;
+    MH_TRY(gemm(g, s));
+    a = AttnArgs{};
+    a.q = pb.q; a.q_rs = (long)inner * es; a.q_bs = (long)np * inner * es;
+    a.k = (const char*)cross_kv + (long)(l * 2 + 0) * kv_layer * es; a.k_rs = 64L * es; a.k_hs = (long)L * 64 * es;
+    a.k_bs = (long)H * L * 64 * es;
+    a.vt = (char*)pb.cross_vt + (long)l * B * inner * pb.Lpad * es; a.Lkpad = pb.Lpad; a.vt_hs = 64L * pb.Lpad * es;
+    a.vt_bs = (long)H * 64 * pb.Lpad * es;
+    a.out = pb.attn; a.out_rs = (long)inner * es; a.out_bs = (long)np * inner * es;
+    a.Lq = np; a.Lk = L; a.scale = 1.0f;
+    MH_TRY(attention_general(a, B, H, c->dtype, s));
+    g = MhGemm{};
+    g.A = pb.attn; g.lda = inner; g.W = w->dec_co[l]; g.ldw = inner; g.C = pb.h; g.ldc = d; g.M = rows; g.N = d; g.K = inner;
+    g.dtype = c->dtype; g.epilogue = MH_EPI_RESID;
+    MH_TRY(gemm(g, s));
+    // feed forward
+    MH_TRY(rmsnorm(pb.h, d, w->dec_ln3[l], pb.n, d, rows, d, c->eps, c->dtype, s));
+    g = MhGemm{};
+    g.A = pb.n; g.lda = d; g.W = w->dec_wi[l]; g.ldw = d; g.C = pb.ff; g.ldc = dff; g.M = rows; g.N = 2 * dff; g.K = d;
+    g.dtype = c->dtype; g.epilogue = MH_EPI_GEGLU;
+    MH_TRY(gemm(g, s));
+    g = MhGemm{};
+    g.A = pb.ff; g.lda = dff; g.W = w->dec_wo[l]; g.ldw = dff; g.C = pb.h; g.ldc = d; g.M = rows; g.N = d; g.K = dff;
+    g.dtype = c->dtype; g.epilogue = MH_EPI_RESID;
+    MH_TRY(gemm(g, s));
+  }
+  return MH_OK;
+}
 
 // Independent rows => independent "chains": the batch is cut into contiguous blocks of rows and every
 // block runs its own captured decode step on its own stream.  A decode step is ~110 dependent, mostly
@@ -631,6 +750,20 @@ extern "C" int mh_t5_generate(const MhT5Config* c, const MhT5Weights* w, const v
   if (hipMemcpy2DAsync(tokens, (size_t)sp->max_length * 4, prompt, (size_t)P * 4, (size_t)P * 4, B,
                        hipMemcpyDeviceToDevice, s) != hipSuccess)
     return check_launch("prompt copy");
+  // batched prompt prefill (positions 0..P-2); MH_DECODE_PREFILL=0 feeds the prompt token by token instead
+  int start_pos = 0;
+  {
+    const char* e = getenv("MH_DECODE_PREFILL");
+    if (P > 1 && !(e && atoi(e) == 0)) {
+      PrefillBuf pb;
+      const int64_t used_dec = ar.off;
+      prefill_layout(c, B, P - 1, (char*)workspace + used_dec, workspace_bytes - used_dec, &pb);
+      MH_REQUIRE(used_dec + prefill_layout(c, B, P - 1, nullptr, 0, nullptr) <= workspace_bytes,
+                 "mh_t5_generate: workspace too small for the prompt prefill");
+      MH_TRY(prefill_prompt(c, w, cross_kv, B, prompt, prompt_mask, P, all.self_k, all.self_v, pb, s));
+      start_pos = P - 1;
+    }
+  }
   if (hipEventRecord(g_pool.fork, s) != hipSuccess) return check_launch("fork record");
 
   const bool bf16 = c->dtype == MH_BF16;
@@ -667,8 +800,8 @@ extern "C" int mh_t5_generate(const MhT5Config* c, const MhT5Weights* w, const v
     smp.last_ts_val = all.last_ts; smp.logits_dump = logits_dump; smp.dec_embed = w->dec_embed; smp.h = bf.h;
     smp.d = d; smp.ss = bf.ss; smp.sp = *sp; smp.st = bf.st; smp.B = B; smp.P = P; smp.b0 = b0;
 
-    if (bf16) hipLaunchKernelGGL(dec_init_kernel<bf16_t>, dim3(Bc), dim3(256), 0, cs, smp, Bc);
-    else hipLaunchKernelGGL(dec_init_kernel<float>, dim3(Bc), dim3(256), 0, cs, smp, Bc);
+    if (bf16) hipLaunchKernelGGL(dec_init_kernel<bf16_t>, dim3(Bc), dim3(256), 0, cs, smp, Bc, start_pos);
+    else hipLaunchKernelGGL(dec_init_kernel<float>, dim3(Bc), dim3(256), 0, cs, smp, Bc, start_pos);
     rc = check_launch("dec_init_kernel");
     if (rc != MH_OK) break;
     // capture one step of this chain (every kernel reads the position from device memory) for replay
@@ -682,7 +815,7 @@ extern "C" int mh_t5_generate(const MhT5Config* c, const MhT5Weights* w, const v
     if (hipGraphInstantiate(&execs[ci], graphs[ci], nullptr, nullptr, 0) != hipSuccess) { rc = check_launch("graph instantiate"); break; }
   }
 
-  const int total_steps = sp->max_length - 1;   // positions 0 .. max_length-2 are fed
+  const int total_steps = sp->max_length - 1 - start_pos;   // positions start_pos .. max_length-2 are fed
   if (poll_every <= 0) poll_every = 16;
   // One launcher per chain.  Replaying a ~110-node graph costs ~0.4 ms of HOST time on ROCm 7.2, so with more
   // than one chain the launches are issued from one host thread per chain (the chains are independent: each
