@@ -4,7 +4,7 @@ ARCH ?= gfx950
 CSRC := mapperatorinator_amd/csrc
 OBJDIR := build/obj
 LIB := mapperatorinator_amd/lib/libmapperhip.so
-SRCS := $(CSRC)/api.hip $(CSRC)/gemm.hip $(CSRC)/norm.hip $(CSRC)/attention.hip $(CSRC)/mel.hip $(CSRC)/t5.hip $(CSRC)/dit.hip
+SRCS := $(CSRC)/api.hip $(CSRC)/gemm.hip $(CSRC)/norm.hip $(CSRC)/attention.hip $(CSRC)/mel.hip $(CSRC)/conv.hip $(CSRC)/t5.hip $(CSRC)/dit.hip
 OBJS := $(patsubst $(CSRC)/%.hip,$(OBJDIR)/%.o,$(SRCS))
 HDRS := $(wildcard $(CSRC)/*.hpp) include/mapperhip.h
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wno-unused-value -Wno-pass-failed

@@ -52,6 +52,8 @@ typedef enum MhEpilogue {
                             cols < n_split: C[T] (q, ldc); then the k block -> C2 and the v block -> C3, both
                             [B][H][cache_len][64] at position i; the v block is also written transposed to
                             C4[T][((b*kv_H + h)*64 + dd)*kv_Lpad + i]                                     */
+  MH_EPI_BIAS_GELU_ERF = 9, /* C[T] = gelu_erf(A W^T + bias) (+ gate[m % rows_per_batch, n] when gate != NULL:
+                               the Whisper position table)                                                 */
 } MhEpilogue;
 
 const char* mh_last_error(void);
@@ -113,6 +115,19 @@ int mh_rmsnorm(const float* x, int ldx, const float* w, void* y, int ldy, int ro
 int mh_attention(const void* qk, int ld_qk, int k_col0, const void* vt, int Lpad, const float* bias,
                  void* out, int ld_out, int B, int L, int H, float scale, int band, int dtype,
                  void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K2  Whisper-style audio front-end (HF WhisperEncoder.forward prologue; reference forks
+ *     osuT5/osuT5/model/custom_transformers/modeling_varwhisper.py:779-780,813-816):
+ *     y = gelu(conv1d(x, k=3, pad=1)); z = gelu(conv1d(y, k=3, stride=2, pad=1)); out = z (+ pos).
+ * x   [B, Lin, C]   time-major activations (element type `dtype`) -- the transpose of HF's input_features
+ * w1  [d, Kpad1], w2 [d, Kpad2]: conv weights repacked tap-major, W'[o][k*Cin + c] = W[o][c][k], K padded
+ *     with zeros to a multiple of 32;  b1, b2 fp32 [d];  pos fp32 [Lout, d] or NULL (fixed sinusoid table)
+ * out [B, Lout, d], Lout = (Lin - 1) / 2 + 1. */
+int64_t mh_whisper_frontend_workspace_bytes(int B, int Lin, int C, int d, int dtype);
+int mh_whisper_frontend(const void* x, int B, int Lin, int C, const void* w1, const float* b1, const void* w2,
+                        const float* b2, const float* pos, int d, void* out, void* workspace,
+                        int64_t workspace_bytes, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * T5 model object: weights are caller-owned device buffers (packed by the host, see

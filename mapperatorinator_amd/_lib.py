@@ -11,7 +11,7 @@ import os
 MH_MAX_LAYERS = 32
 MH_F32, MH_BF16 = 0, 1
 (EPI_STORE, EPI_STORE_F32, EPI_RESID, EPI_GEGLU, EPI_BIAS_GELU, EPI_GATE_RESID, EPI_KV_SCATTER,
- EPI_QKV_VT, EPI_QKV_CACHE) = range(9)
+ EPI_QKV_VT, EPI_QKV_CACHE, EPI_BIAS_GELU_ERF) = range(10)
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmapperhip.so")
 
@@ -78,6 +78,8 @@ SYMBOLS = {
     "mh_gemm": (I, [C.POINTER(MhGemm), VP]),
     "mh_rmsnorm": (I, [VP, I, VP, VP, I, I, I, F, I, VP]),
     "mh_attention": (I, [VP, I, I, VP, I, VP, VP, I, I, I, I, F, I, I, VP]),
+    "mh_whisper_frontend_workspace_bytes": (I64, [I, I, I, I, I]),
+    "mh_whisper_frontend": (I, [VP, I, I, I, VP, VP, VP, VP, VP, I, VP, VP, I64, I, VP]),
     "mh_t5_encode_workspace_bytes": (I64, [C.POINTER(MhT5Config), I]),
     "mh_t5_encode": (I, [C.POINTER(MhT5Config), C.POINTER(MhT5Weights), VP, I, VP, VP, VP, I64, VP]),
     "mh_t5_cross_kv": (I, [C.POINTER(MhT5Config), C.POINTER(MhT5Weights), VP, I, VP, VP]),

@@ -46,6 +46,9 @@ __device__ inline void epilogue_store(const GemmP& p, int row, int col, float v,
     reinterpret_cast<float*>(p.C)[(long)row * p.ldc + col] = old + v;
   } else if (EPI == MH_EPI_BIAS_GELU) {
     reinterpret_cast<T*>(p.C)[(long)row * p.ldc + col] = Elem<T>::from_f32(gelu_tanh(v));
+  } else if (EPI == MH_EPI_BIAS_GELU_ERF) {
+    // exact GELU (nn.functional.gelu default) + optional position row (passed in `g`)
+    reinterpret_cast<T*>(p.C)[(long)row * p.ldc + col] = Elem<T>::from_f32(0.5f * v * (1.0f + erff(v * 0.70710678118654752f)) + g);
   } else if (EPI == MH_EPI_GATE_RESID) {
     reinterpret_cast<float*>(p.C)[(long)row * p.ldc + col] = old + g * v;
   } else if (EPI == MH_EPI_KV_SCATTER) {
@@ -199,6 +202,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmP p) {
   const int erow0 = m0 + wr * WM + (lane >> 4) * 4;
   const int ecol0 = n0 + wc * WN + (lane & 15);
   constexpr bool kReadsC = (EPI == MH_EPI_RESID || EPI == MH_EPI_GATE_RESID);
+  constexpr bool kPos = (EPI == MH_EPI_BIAS_GELU_ERF);
   float bias_v[NI];
 #pragma unroll
   for (int j = 0; j < NI; ++j) bias_v[j] = 0.f;
@@ -212,6 +216,23 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmP p) {
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
     f32x4_t oldv[NI], gv[NI];
+    if (kPos) {
+#pragma unroll
+      for (int j = 0; j < NI; ++j) gv[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      if (p.gate) {   // position table row = row % rows_per_batch (wave-uniform branch, clamped unconditional loads)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          int row = erow0 + i * 16 + r;
+          row = row < p.M ? row : p.M - 1;
+#pragma unroll
+          for (int j = 0; j < NI; ++j) {
+            int c = ecol0 + j * 16;
+            c = c < p.N ? c : p.N - 1;
+            gv[j][r] = p.gate[(long)(row % p.rows_per_batch) * p.gate_ld + c];
+          }
+        }
+      }
+    }
     if (kReadsC) {   // unconditional loads from clamped addresses, all in flight before the first store
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -240,7 +261,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmP p) {
 #pragma unroll
         for (int j = 0; j < NI; ++j)
           epilogue_store<T, EPI>(p, row, ecol0 + j * 16, acc[i][j][r] + bias_v[j], 0.f, kReadsC ? oldv[j][r] : 0.f,
-                                 kReadsC ? gv[j][r] : 0.f);
+                                 (kReadsC || kPos) ? gv[j][r] : 0.f);
       }
     }
   }
@@ -272,7 +293,8 @@ template <typename T>
 bool prepare_type() {
   return prepare_epi<T, MH_EPI_STORE>() && prepare_epi<T, MH_EPI_STORE_F32>() && prepare_epi<T, MH_EPI_RESID>() &&
          prepare_epi<T, MH_EPI_GEGLU>() && prepare_epi<T, MH_EPI_BIAS_GELU>() && prepare_epi<T, MH_EPI_GATE_RESID>() &&
-         prepare_epi<T, MH_EPI_KV_SCATTER>() && prepare_epi<T, MH_EPI_QKV_VT>() && prepare_epi<T, MH_EPI_QKV_CACHE>();
+         prepare_epi<T, MH_EPI_KV_SCATTER>() && prepare_epi<T, MH_EPI_QKV_VT>() && prepare_epi<T, MH_EPI_QKV_CACHE>() &&
+         prepare_epi<T, MH_EPI_BIAS_GELU_ERF>();
 }
 
 template <typename T, int EPI>
@@ -302,6 +324,7 @@ int dispatch_epi(const GemmP& p, int epi, hipStream_t s) {
     case MH_EPI_KV_SCATTER: return dispatch_tile<T, MH_EPI_KV_SCATTER>(p, s);
     case MH_EPI_QKV_VT: return dispatch_tile<T, MH_EPI_QKV_VT>(p, s);
     case MH_EPI_QKV_CACHE: return dispatch_tile<T, MH_EPI_QKV_CACHE>(p, s);
+    case MH_EPI_BIAS_GELU_ERF: return dispatch_tile<T, MH_EPI_BIAS_GELU_ERF>(p, s);
   }
   set_error("mh_gemm: unknown epilogue %d", epi);
   return MH_ERR_ARG;

@@ -256,3 +256,44 @@ def test_mel_silence_and_tone():
     from oracle import mel as omel
     ref = torch.from_numpy(omel.mel_spectrogram_f64(tone.numpy()))[0, 40].float()
     assert torch.allclose(mel, ref, rtol=1e-3, atol=1e-3 * ref.max().item())
+
+
+def _whisper_case():
+    g = np.load(f"{__import__('conftest').GOLDEN}/whisper_frontend.npz")
+    rng = np.random.default_rng(int(g["seed"]))
+    d, c, Ln = int(g["d"]), int(g["c_in"]), int(g["L"])
+
+    def rnd(shape, std):
+        return torch.from_numpy((rng.standard_normal(shape) * std).astype(np.float32))
+    w1, b1 = rnd((d, c, 3), 0.08), rnd((d,), 0.05)
+    w2, b2 = rnd((d, d, 3), 0.06), rnd((d,), 0.05)
+    x = rnd((2, c, Ln), 1.0)
+    return g, x, w1, b1, w2, b2, torch.from_numpy(g["pos"])
+
+
+@pytest.mark.parametrize("dtype_name", ["f32", "bf16"])
+def test_whisper_frontend(dtype_name):
+    """K2 vs the HF WhisperEncoder golden (fp32: 2e-5 abs) and vs the bf16-contract oracle (bf16: 3e-2 abs)."""
+    from mapperatorinator_amd.whisper_frontend import WhisperFrontendHIP
+    from oracle.whisper_frontend import whisper_frontend
+    g, x, w1, b1, w2, b2, pos = _whisper_case()
+    dt = torch.float32 if dtype_name == "f32" else torch.bfloat16
+    fe = WhisperFrontendHIP(w1, b1, w2, b2, pos, dtype=dt)
+    got = fe(x.cuda()).float().cpu()
+    assert got.shape == (2, 75, 128)
+    if dt == torch.float32:
+        err = (got - torch.from_numpy(g["out"])).abs().max().item()
+        print("whisper front-end fp32 max abs err vs HF golden", err)
+        assert err < 2e-5
+    else:
+        want = whisper_frontend(x, w1, b1, w2, b2, pos, rounding="bf16")
+        err = (got - want).abs().max().item()
+        print("whisper front-end bf16 max abs err vs bf16 oracle", err)
+        assert err < 3e-2
+    # no position table (VarWhisper fork), odd length, batch 3
+    fe2 = WhisperFrontendHIP(w1, b1, w2, b2, None, dtype=dt)
+    x2 = torch.randn(3, 96, 77, generator=torch.Generator().manual_seed(1))
+    got2 = fe2(x2.cuda()).float().cpu()
+    want2 = whisper_frontend(x2, w1, b1, w2, b2, None, rounding=None if dt == torch.float32 else "bf16")
+    assert got2.shape == want2.shape == (3, 39, 128)
+    assert (got2 - want2).abs().max().item() < (2e-5 if dt == torch.float32 else 3e-2)
