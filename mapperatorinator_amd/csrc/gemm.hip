@@ -11,8 +11,10 @@ namespace mh {
 
 namespace {
 
-constexpr int kRowBytes = 128;            // K-step bytes per tile row
-constexpr int kRowStride = kRowBytes + 16;  // padded LDS row stride in bytes
+// K-step bytes per tile row: 128 for the big tiles; 512 for the 32x32 tile, whose problems (DiT, M = 256) are
+// bound by the global-load latency of a K step (~1 us per step whatever the tile: measured), so it takes 4x
+// fewer, 4x fatter steps with 8 loads in flight per thread.
+template <int BM> struct RowBytes { static constexpr int v = (BM == 32) ? 512 : 128; };
 
 struct GemmP {
   const char* A; long lda_b;  // leading dimension in BYTES
@@ -91,13 +93,17 @@ __device__ inline void epilogue_store(const GemmP& p, int row, int col, float v,
 template <typename T, int BM, int BN, int EPI>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmP p) {
   constexpr int VEC = Elem<T>::kVec;          // elements per 16 B
+  constexpr int kRowBytes = RowBytes<BM>::v;
+  constexpr int kRowStride = kRowBytes + 16;  // padded LDS row stride in bytes
+  constexpr int CPR = kRowBytes / 16;         // 16-byte chunks per tile row
+  constexpr int RPP = 256 / CPR;              // tile rows covered by one pass of the 256 threads
   constexpr int BK = kRowBytes / (int)sizeof(T);
   constexpr int KM = Atom<T>::KM;
   constexpr int KCH = Atom<T>::KCH;
   constexpr int WM = BM / 2, WN = BN / 2;     // wave tile
   constexpr int MI = WM / 16, NI = WN / 16;
-  constexpr int A_CHUNKS = BM * 8 / 256;      // 16-byte chunks per thread for the A tile
-  constexpr int B_CHUNKS = BN * 8 / 256;
+  constexpr int A_CHUNKS = BM * CPR / 256;    // 16-byte chunks per thread for the A tile
+  constexpr int B_CHUNKS = BN * CPR / 256;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int kBufBytes = (BM + BN) * kRowStride;  // one (A tile, B tile) stage
@@ -117,8 +123,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmP p) {
   const int bm = bid / nbn, bn = bid % nbn;
   const int m0 = bm * BM, n0 = bn * BN;
 
-  const int cchunk = tid & 7;   // 16-byte chunk within the 128-byte K step
-  const int crow = tid >> 3;    // 0..31
+  const int cchunk = tid % CPR;   // 16-byte chunk within the K step
+  const int crow = tid / CPR;     // 0..RPP-1
 
   // Register ring of D in-flight K tiles (tile t lives in slot t % D) in front of the double-buffered LDS stage.
   // Measured: D = 4 made the small (M = 256) fp32 GEMMs of the DiT SLOWER (140 -> 188 ms per 100 steps): those are
@@ -135,14 +141,14 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmP p) {
     const uint32_t keep = kin ? 0xffffffffu : 0u;
 #pragma unroll
     for (int i = 0; i < A_CHUNKS; ++i) {
-      int r = m0 + crow + 32 * i;
+      int r = m0 + crow + RPP * i;
       r = r < p.M ? r : p.M - 1;
       const uint4 t = *reinterpret_cast<const uint4*>(p.A + (long)r * p.lda_b + k_off);
       xa[i] = make_uint4(t.x & keep, t.y & keep, t.z & keep, t.w & keep);
     }
 #pragma unroll
     for (int i = 0; i < B_CHUNKS; ++i) {
-      int r = n0 + crow + 32 * i;
+      int r = n0 + crow + RPP * i;
       r = r < p.N ? r : p.N - 1;
       const uint4 t = *reinterpret_cast<const uint4*>(p.W + (long)r * p.ldw_b + k_off);
       xb[i] = make_uint4(t.x & keep, t.y & keep, t.z & keep, t.w & keep);
@@ -151,10 +157,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmP p) {
   auto store_tiles = [&](int buf, const uint4 (&xa)[A_CHUNKS], const uint4 (&xb)[B_CHUNKS]) {
 #pragma unroll
     for (int i = 0; i < A_CHUNKS; ++i)
-      *reinterpret_cast<uint4*>(smem + buf * kBufBytes + (crow + 32 * i) * kRowStride + cchunk * 16) = xa[i];
+      *reinterpret_cast<uint4*>(smem + buf * kBufBytes + (crow + RPP * i) * kRowStride + cchunk * 16) = xa[i];
 #pragma unroll
     for (int i = 0; i < B_CHUNKS; ++i)
-      *reinterpret_cast<uint4*>(smem + buf * kBufBytes + (BM + crow + 32 * i) * kRowStride + cchunk * 16) = xb[i];
+      *reinterpret_cast<uint4*>(smem + buf * kBufBytes + (BM + crow + RPP * i) * kRowStride + cchunk * 16) = xb[i];
   };
 
   f32x4_t acc[MI][NI];
@@ -270,7 +276,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmP p) {
 template <typename T, int BM, int BN, int EPI>
 int launch_gemm(const GemmP& p, hipStream_t s) {
   const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
-  const size_t smem = 2 * (size_t)(BM + BN) * kRowStride;
+  const size_t smem = 2 * (size_t)(BM + BN) * (RowBytes<BM>::v + 16);
   hipLaunchKernelGGL((gemm_tn_kernel<T, BM, BN, EPI>), dim3(nbm * nbn), dim3(256), smem, s, p);
   return check_launch("gemm_tn_kernel");
 }
@@ -279,7 +285,7 @@ int launch_gemm(const GemmP& p, hipStream_t s) {
 // outside any stream capture (gemm_prepare()).
 template <typename T, int BM, int BN, int EPI>
 bool prepare_one() {
-  const size_t smem = 2 * (size_t)(BM + BN) * kRowStride;
+  const size_t smem = 2 * (size_t)(BM + BN) * (RowBytes<BM>::v + 16);
   return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel<T, BM, BN, EPI>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) == hipSuccess;
 }
