@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MH_ABI_VERSION 1
+#define MH_ABI_VERSION 2
 #define MH_MAX_LAYERS 32
 
 typedef enum MhStatus {
@@ -210,6 +210,21 @@ typedef struct MhSampling {
   int pad_id;
   int max_length;           /* prompt + new tokens cap (MaxLengthCriteria)                      */
   uint64_t seed;            /* Philox seed when do_sample                                       */
+  /* --- ABI 2: the remaining processors of server.py:106-134 ----------------------------------- */
+  float cfg_scale;          /* > 1: ClassifierFreeGuidanceLogitsProcessor (server.py:107-108).  The batch
+                               holds 2G rows: rows [0, G) are fed the NEGATIVE prompt, rows [G, 2G) the
+                               prompt (prepare_inputs_for_generation, modeling_mapperatorinator.py:243-254);
+                               scores = l[G+g] + (l[g] - l[G+g]) * cfg_scale, exactly what HF's processor
+                               computes on that row order; both rows of a pair receive the sampled id;
+                               cross_kv then holds G rows (the encoder output is shared by the pair)      */
+  int n_cond;               /* ConditionalTemperatureLogitsWarper (logit_processors.py:47-82): up to 3   */
+  float cond_temp[3];       /*   (temperature, token set, offset) rules, first match wins; the token set */
+  int cond_offset[3];       /*   of rule j is bit (2 << j) of tok_flags; the lookback is ROW 0's history */
+  int lookback_types_first; /* LookbackBiasLogitsWarper types_first=True branch (:116-133) over
+                               [ts_start, lookback_mask_end): renormalise instead of masking             */
+  const uint8_t* tok_flags; /* device uint8 [vocab_out]: bit0 timed-event ids (:104-108), bits 1-3 the
+                               conditional-temperature sets, bit4 eos + context-eos ids (:99).  May be
+                               NULL when n_cond == 0 and lookback_types_first == 0                       */
 } MhSampling;
 
 int64_t mh_t5_decode_workspace_bytes(const MhT5Config* cfg, int B);

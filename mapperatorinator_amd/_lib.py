@@ -50,7 +50,9 @@ class MhSampling(C.Structure):
     _fields_ = [("do_sample", C.c_int), ("top_k", C.c_int), ("top_p", C.c_float), ("temperature", C.c_float),
                 ("timeshift_bias", C.c_float), ("ts_start", C.c_int), ("ts_end", C.c_int), ("n_sos", C.c_int),
                 ("sos_ids", C.c_int * 16), ("lookback_mask_end", C.c_int), ("pad_id", C.c_int),
-                ("max_length", C.c_int), ("seed", C.c_uint64)]
+                ("max_length", C.c_int), ("seed", C.c_uint64),
+                ("cfg_scale", C.c_float), ("n_cond", C.c_int), ("cond_temp", C.c_float * 3),
+                ("cond_offset", C.c_int * 3), ("lookback_types_first", C.c_int), ("tok_flags", VP)]
 
 
 class MhDiTConfig(C.Structure):
@@ -120,7 +122,7 @@ def load():
             raise RuntimeError(f"libmapperhip.so does not export {name} (stale build?)") from e
         fn.restype = res
         fn.argtypes = args
-    if lib.mh_abi_version() != 1:
+    if lib.mh_abi_version() != 2:
         raise RuntimeError("libmapperhip.so ABI version mismatch")
     _lib = lib
     return lib

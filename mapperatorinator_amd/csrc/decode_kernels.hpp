@@ -507,6 +507,7 @@ struct CrossAttnP {
   int* ticket;              // [B*H] arrival counters, zero between launches; non-null: the last-arriving split
                             // of a (b, h) pair merges the partials in-kernel (no separate merge launch)
   int B, H, L, splits;
+  int kv_B;                 // > 0: row b reads K/V row b % kv_B (CFG pairs share the encoder output)
 };
 
 // one workgroup (NW waves) per (b, h, split); the waves interleave 8-key rows of the split's key range.
@@ -517,8 +518,17 @@ __global__ __launch_bounds__(NW * 64) void dec_cross_attn_kernel(CrossAttnP p) {
   __shared__ float sm[NW][66];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int split = blockIdx.x % p.splits;
-  const int pair = blockIdx.x / p.splits;
-  const int b = pair / p.H, h = pair % p.H;
+  const int blk = blockIdx.x / p.splits;
+  int b, h;
+  if (p.kv_B > 0) {   // CFG (B == 2 kv_B): the two rows that share K/V sit in adjacent workgroups
+    const int q2 = blk >> 1;
+    b = (blk & 1) * p.kv_B + q2 / p.H;
+    h = q2 % p.H;
+  } else {
+    b = blk / p.H;
+    h = blk % p.H;
+  }
+  const int pair = b * p.H + h;
   const int c8 = (lane & 7) * 8, g = lane >> 3;
   const int per = (p.L + p.splits - 1) / p.splits;
   const int k_lo = split * per;
@@ -526,8 +536,9 @@ __global__ __launch_bounds__(NW * 64) void dec_cross_attn_kernel(CrossAttnP p) {
   k_hi = k_hi < p.L ? k_hi : p.L;
   float q[8];
   load8<T>(reinterpret_cast<const T*>(p.q) + (long)b * p.ldq + h * 64 + c8, q);
-  const T* kb = reinterpret_cast<const T*>(p.k) + ((long)b * p.H + h) * p.L * 64;
-  const T* vb = reinterpret_cast<const T*>(p.v) + ((long)b * p.H + h) * p.L * 64;
+  const int kvb = p.kv_B > 0 ? b % p.kv_B : b;   // row b reads K/V row b % kv_B
+  const T* kb = reinterpret_cast<const T*>(p.k) + ((long)kvb * p.H + h) * p.L * 64;
+  const T* vb = reinterpret_cast<const T*>(p.v) + ((long)kvb * p.H + h) * p.L * 64;
   Partial st;
   partial_init(st);
   attend_keys<T, U>(st, q, kb, vb, k_lo + wid * 8 + g, k_hi, 8 * NW, nullptr, 0, nullptr, 0, 1.0f);

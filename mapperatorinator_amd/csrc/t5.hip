@@ -140,13 +140,17 @@ struct SampleP {
   uint8_t* finished;                  // [B]
   int32_t* finish_col;                // [B]
   int32_t* last_ts_val;               // [B] value of the last TIME_SHIFT after the last SOS, -1 if none
-  float* logits_dump;                 // [max_length][B][V] or null
+  float* logits_dump;                 // [max_length][R][V] or null   (R = returned rows: B, or B/2 with CFG)
+  float* proc;                        // [R][V] processed scores of this step (read back by the sampling passes)
+  float* hist_scores;                 // [2][R][V] scores entering LookbackBias at this / the previous step
   const void* dec_embed; float* h; int d;
   float* ss;                          // [64] sum of squares of the embedded row (RMSNorm statistics, 1 part)
   MhSampling sp;
   DecState* st;
-  int B, P;                           // B = rows of the WHOLE batch (logits_dump stride)
+  int B, P;                           // B = rows of the WHOLE batch
   int b0;                             // first global row of this chain; logits / h / ss are chain-local
+  int pair;                           // CFG: distance between the negative-prompt row g and its prompt row g + pair
+                                      //      (= B/2, single chain); 0 = no guidance
 };
 
 __device__ inline void update_ts_state(const MhSampling& sp, int tok, int32_t* last_ts_val) {
@@ -158,6 +162,12 @@ __device__ inline void update_ts_state(const MhSampling& sp, int tok, int32_t* l
     for (int i = 0; i < sp.n_sos; ++i)
       if (tok == sp.sos_ids[i]) { *last_ts_val = -1; break; }
   }
+}
+
+// input_ids[row][i] as the reference's processors see it: the prompt, then the ids that were FED (the forced ids
+// under teacher forcing, the emitted ones otherwise)
+__device__ inline int history_id(const SampleP& p, int row, int i) {
+  return (p.forced && i >= p.P) ? p.forced[(long)row * p.max_length + i] : p.tokens[(long)row * p.max_length + i];
 }
 
 // counter-based RNG (Philox-like mixing is overkill here; splitmix64 on (seed, row, step))
@@ -195,14 +205,25 @@ __global__ __launch_bounds__(256) void dec_init_kernel(SampleP p, int chain_rows
   if (threadIdx.x == 0) p.ss[lb] = sq;
 }
 
-// one workgroup per batch row: processors -> selection -> bookkeeping -> next-token embedding
+// One workgroup per returned row (per CFG pair): processors -> selection -> bookkeeping -> next-token embedding.
+// Processor order = server.py:106-134: CFG -> MonotonicTimeShift -> TimeshiftBias -> (Conditional)Temperature ->
+// LookbackBias, then HF's own top-k / top-p warpers and the multinomial draw.
 template <typename T>
 __global__ __launch_bounds__(256) void dec_sample_kernel(SampleP p) {
   __shared__ float sf[8];
   __shared__ int si[8];
-  __shared__ int s_tok;
-  __shared__ float s_sum;
-  const int lb = blockIdx.x, b = p.b0 + lb, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  __shared__ int s_tok[2];
+  __shared__ float s_sum, s_temp;
+  __shared__ int s_timed;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const bool cfg = p.pair > 0;
+  const int nrow = cfg ? 2 : 1;
+  const int lneg = blockIdx.x;                 // chain-local row of the negative prompt (CFG only)
+  const int lb = cfg ? lneg + p.pair : lneg;   // chain-local returned row (the row whose ids are `input_ids`)
+  const int b = p.b0 + lb;                     // its global row
+  const int bneg = p.b0 + lneg;
+  const int gr = cfg ? lneg : b;               // index among the returned rows
+  const int R = cfg ? p.pair : p.B;
   const int pos = p.st->pos;
   const int col = pos + 1;  // column being produced
   const MhSampling& sp = p.sp;
@@ -210,30 +231,102 @@ __global__ __launch_bounds__(256) void dec_sample_kernel(SampleP p) {
 
   if (col < p.P) {
     // still inside the prompt: the token is given; only advance the processor state + embedding
-    if (tid == 0) {
-      const int tok = p.tokens[(long)b * p.max_length + col];
-      update_ts_state(sp, tok, &p.last_ts_val[b]);
-      s_tok = tok;
+    if (tid < nrow) {
+      const int row = tid == 0 ? b : bneg;
+      const int tok = p.tokens[(long)row * p.max_length + col];
+      if (tid == 0) update_ts_state(sp, tok, &p.last_ts_val[b]);
+      s_tok[tid] = tok;
     }
     __syncthreads();
   } else {
     const float* lg = p.logits + (long)lb * p.ldl;
+    const float* lgn = p.logits + (long)lneg * p.ldl;
     const int ltv = p.last_ts_val[b];
-    float best = -INFINITY;
-    int besti = 0x7fffffff;
-    float* dump = p.logits_dump ? p.logits_dump + ((long)col * p.B + b) * p.V : nullptr;
-    for (int v = tid; v < p.V; v += 256) {
+    if (tid == 0) {
+      // ConditionalTemperatureLogitsWarper: the lookback is ROW 0's history for the whole batch
+      // (logit_processors.py:75-80 `input_ids[0, -max_offset:]`), first matching rule wins
+      float temp = sp.temperature;
+      const int row0 = cfg ? p.pair : 0;
+      for (int j = 0; j < sp.n_cond; ++j) {
+        const int off = sp.cond_offset[j];
+        if (col >= off && (sp.tok_flags[history_id(p, row0, col - off)] & (2 << j))) { temp = sp.cond_temp[j]; break; }
+      }
+      s_temp = temp;
+      // LookbackBiasLogitsWarper types_first: "the scores are for a timeshift event" when the last id is a timed event
+      s_timed = (sp.lookback_types_first && col > p.P) ? (sp.tok_flags[history_id(p, b, col - 1)] & 1) : 0;
+    }
+    __syncthreads();
+    const float temp = s_temp;
+    const bool lb_range_on = sp.lookback_mask_end > sp.ts_start;
+    // CFG -> monotonic -> bias -> temperature
+    auto warped = [&](int v) -> float {
       float x = lg[v];
+      // HF ClassifierFreeGuidanceLogitsProcessor on the reference's row order (first half = negative prompt):
+      // uncond + (cond - uncond) * scale with cond = first half, no fused multiply-add
+      if (cfg) x = __fadd_rn(x, __fmul_rn(__fsub_rn(lgn[v], x), sp.cfg_scale));
       // MonotonicTimeShiftLogitsProcessor: ids [ts_start, ts_start + value) -> -inf
       if (ltv >= 0 && v >= sp.ts_start && v < sp.ts_start + ltv) x = -INFINITY;
       // TimeshiftBias
       if (sp.timeshift_bias != 0.f && v >= sp.ts_start && v < sp.ts_end) x += sp.timeshift_bias;
-      // TemperatureLogitsWarper (scores / temperature)
-      x = x / sp.temperature;
-      // LookbackBiasLogitsWarper, types_first == False branch
-      if (sp.lookback_mask_end > sp.ts_start && v >= sp.ts_start && v < sp.lookback_mask_end) x = -INFINITY;
+      // TemperatureLogitsWarper / ConditionalTemperatureLogitsWarper (scores / temperature)
+      return x / temp;
+    };
+    float* dump = p.logits_dump ? p.logits_dump + ((long)col * R + gr) * p.V : nullptr;
+    float* fin = p.proc + (long)gr * p.V;
+    float best = -INFINITY;
+    int besti = 0x7fffffff;
+    auto consider = [&](int v, float x) {
+      fin[v] = x;
       if (dump) dump[v] = x;
       if (x > best) { best = x; besti = v; }   // strided scan keeps the smallest index per thread
+    };
+    if (sp.lookback_types_first && lb_range_on) {
+      // LookbackBiasLogitsWarper, types_first == True (logit_processors.py:116-133).  `last_scores` = what entered
+      // this processor at the previous step: two row buffers indexed by the parity of the column.
+      float* cur = p.hist_scores + ((long)(col & 1) * R + gr) * p.V;
+      const float* last = p.hist_scores + ((long)((col & 1) ^ 1) * R + gr) * p.V;
+      const bool renorm = s_timed != 0;
+      float mc = -INFINITY, ml = -INFINITY;
+      for (int v = tid; v < p.V; v += 256) {
+        const float x = warped(v);
+        cur[v] = x;
+        mc = fmaxf(mc, x);
+        if (renorm) ml = fmaxf(ml, last[v]);
+      }
+      if (!renorm) {
+        for (int v = tid; v < p.V; v += 256) consider(v, cur[v]);
+      } else {
+        mc = block_max(mc, sf);
+        ml = block_max(ml, sf);
+        float s_cur = 0.f, o_cur = 0.f, s_last = 0.f, e_last = 0.f;
+        for (int v = tid; v < p.V; v += 256) {
+          const float ec = expf(cur[v] - mc), el = expf(last[v] - ml);
+          s_cur += ec;
+          if (!(v >= sp.ts_start && v < sp.lookback_mask_end)) o_cur += ec;
+          s_last += el;
+          if (sp.tok_flags[v] & 16) e_last += el;
+        }
+        s_cur = block_sum(s_cur, sf);
+        o_cur = block_sum(o_cur, sf);
+        s_last = block_sum(s_last, sf);
+        e_last = block_sum(e_last, sf);
+        const float prob_eos = e_last / s_last, prob_event = 1.f - prob_eos;
+        const float sc = 1.f / ((o_cur / s_cur) * prob_event + prob_eos);
+        const float extra = fminf(fmaxf((sc - 1.f) * prob_eos / prob_event, 0.f), 1.f);
+        for (int v = tid; v < p.V; v += 256) {
+          float x;
+          if (v >= sp.ts_start && v < sp.lookback_mask_end) x = (v == sp.ts_start) ? logf(extra) : -INFINITY;
+          else x = logf(expf(cur[v] - mc) / s_cur * sc);
+          consider(v, x);
+        }
+      }
+    } else {
+      for (int v = tid; v < p.V; v += 256) {
+        float x = warped(v);
+        // LookbackBiasLogitsWarper, types_first == False branch
+        if (lb_range_on && v >= sp.ts_start && v < sp.lookback_mask_end) x = -INFINITY;
+        consider(v, x);
+      }
     }
     // argmax with first-index tie-break (torch.argmax semantics on ties = first maximal index)
 #pragma unroll
@@ -242,6 +335,7 @@ __global__ __launch_bounds__(256) void dec_sample_kernel(SampleP p) {
       const int oi = __shfl_xor(besti, o, 64);
       if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
     }
+    __syncthreads();   // the reductions above may still be reading sf
     if (lane == 0) { sf[wid] = best; si[wid] = besti; }
     __syncthreads();
     if (tid == 0) {
@@ -255,16 +349,14 @@ __global__ __launch_bounds__(256) void dec_sample_kernel(SampleP p) {
       // softmax sampling over the processed scores with optional top-k / top-p truncation.
       // Threshold search instead of a sort: V is a few thousand, a wave-parallel bisection is cheap.
       const float mx = sf[4];
+      __syncthreads();   // sf[4] is reused as reduction scratch below
       float thr = -INFINITY;
       if (sp.top_k > 0 && sp.top_k < p.V) {
         float lo = -80.f, hi = 0.f;  // on x - mx
         for (int it = 0; it < 40; ++it) {
           const float mid = 0.5f * (lo + hi);
           int cnt = 0;
-          for (int v = tid; v < p.V; v += 256) {
-            float x = dump ? dump[v] : -INFINITY;
-            cnt += (x - mx >= mid) ? 1 : 0;
-          }
+          for (int v = tid; v < p.V; v += 256) cnt += (fin[v] - mx >= mid) ? 1 : 0;
           cnt = (int)block_sum((float)cnt, sf);
           if (cnt >= sp.top_k) lo = mid; else hi = mid;
         }
@@ -273,7 +365,7 @@ __global__ __launch_bounds__(256) void dec_sample_kernel(SampleP p) {
       // probabilities of the kept set
       float part = 0.f;
       for (int v = tid; v < p.V; v += 256) {
-        float x = dump ? dump[v] : -INFINITY;
+        const float x = fin[v];
         if (x - mx >= thr) part += __expf(x - mx);
       }
       float total = block_sum(part, sf);
@@ -285,7 +377,7 @@ __global__ __launch_bounds__(256) void dec_sample_kernel(SampleP p) {
           const float mid = 0.5f * (lo + hi);
           float mass = 0.f;
           for (int v = tid; v < p.V; v += 256) {
-            float x = dump ? dump[v] : -INFINITY;
+            const float x = fin[v];
             if (x - mx >= thr) {
               const float pr = __expf(x - mx) / total;
               if (pr >= mid) mass += pr;
@@ -297,10 +389,9 @@ __global__ __launch_bounds__(256) void dec_sample_kernel(SampleP p) {
         pthr = lo;
         float part2 = 0.f;
         for (int v = tid; v < p.V; v += 256) {
-          float x = dump ? dump[v] : -INFINITY;
+          const float x = fin[v];
           if (x - mx >= thr && __expf(x - mx) / total >= pthr) part2 += __expf(x - mx);
         }
-        s_sum = 0.f;
         const float t2 = block_sum(part2, sf);
         if (tid == 0) s_sum = t2;
         __syncthreads();
@@ -309,11 +400,11 @@ __global__ __launch_bounds__(256) void dec_sample_kernel(SampleP p) {
         __syncthreads();
       }
       if (tid == 0) {
-        const float u = uniform01(sp.seed, (uint32_t)b, (uint32_t)col) * s_sum;
+        const float u = uniform01(sp.seed, (uint32_t)gr, (uint32_t)col) * s_sum;
         float cum = 0.f;
         int pick = tok;
         for (int v = 0; v < p.V; ++v) {
-          float x = dump ? dump[v] : -INFINITY;
+          const float x = fin[v];
           if (x - mx >= thr) {
             const float e = __expf(x - mx);
             if (sp.top_p < 1.0f && e / total < pthr) continue;
@@ -330,31 +421,31 @@ __global__ __launch_bounds__(256) void dec_sample_kernel(SampleP p) {
     if (tid == 0) {
       const bool forced = p.forced != nullptr;
       const bool was_finished = p.finished[b] != 0;
-      int emit = was_finished ? sp.pad_id : tok;      // HF: finished rows receive pad_token_id
-      p.tokens[(long)b * p.max_length + col] = emit;
-      int feed = forced ? p.forced[(long)b * p.max_length + col] : emit;
-      if (!forced && !was_finished) {
-        if (p.eos_table[emit] || col + 1 >= sp.max_length) {
-          p.finished[b] = 1;
-          p.finish_col[b] = col;
-        }
+      const int emit = was_finished ? sp.pad_id : tok;      // HF: finished rows receive pad_token_id
+      const bool done = !forced && !was_finished && (p.eos_table[emit] || col + 1 >= sp.max_length);
+      for (int j = 0; j < nrow; ++j) {   // the rows of a CFG pair receive the same id (decoder_input_ids.repeat)
+        const int row = j == 0 ? b : bneg;
+        p.tokens[(long)row * p.max_length + col] = emit;
+        s_tok[j] = forced ? p.forced[(long)row * p.max_length + col] : emit;
+        if (done) { p.finished[row] = 1; p.finish_col[row] = col; }
       }
-      update_ts_state(sp, feed, &p.last_ts_val[b]);
-      s_tok = feed;
+      update_ts_state(sp, s_tok[0], &p.last_ts_val[b]);
     }
     __syncthreads();
   }
   // embedding of the token that the next step consumes (decoder_embedder, modeling_mapperatorinator.py:205-206)
-  const int tok = s_tok;
-  const T* e = reinterpret_cast<const T*>(p.dec_embed) + (long)tok * p.d;
-  float sq = 0.f;
-  for (int i = tid; i < p.d; i += 256) {
-    const float v = Elem<T>::to_f32(e[i]);
-    p.h[(long)lb * p.d + i] = v;
-    sq += v * v;
+  for (int j = 0; j < nrow; ++j) {
+    const int lrow = j == 0 ? lb : lneg;
+    const T* e = reinterpret_cast<const T*>(p.dec_embed) + (long)s_tok[j] * p.d;
+    float sq = 0.f;
+    for (int i = tid; i < p.d; i += 256) {
+      const float v = Elem<T>::to_f32(e[i]);
+      p.h[(long)lrow * p.d + i] = v;
+      sq += v * v;
+    }
+    sq = block_sum(sq, sf);
+    if (tid == 0) p.ss[lrow] = sq;   // RMSNorm statistics of the new residual row (one part)
   }
-  sq = block_sum(sq, sf);
-  if (tid == 0) p.ss[lb] = sq;   // RMSNorm statistics of the new residual row (one part)
 }
 
 __global__ void dec_advance_kernel(DecState* st, const uint8_t* finished, int B) {
@@ -458,10 +549,11 @@ int launch_cross(const dec::CrossAttnP& ca, hipStream_t s) {
 }
 
 template <typename T>
-int enqueue_step(const MhT5Config* c, const MhT5Weights* w, const void* cross_kv, int B, int Bfull,
+int enqueue_step(const MhT5Config* c, const MhT5Weights* w, const void* cross_kv, int B, int Bfull, int kvB,
                  const uint8_t* prompt_mask, int P, const DecBuffers& bf, const SampleP& smp, hipStream_t s) {
   // B rows of one chain; every pointer in `bf` / `cross_kv` / `prompt_mask` already points at the chain's first
-  // row, only the per-layer strides of the caches use the full batch size.
+  // row, only the per-layer strides of the caches use the full batch size.  kvB = rows of cross_kv (B/2 under CFG:
+  // a pair shares its encoder output, row b reads K/V row b % kvB).
   const int d = c->d_model, H = c->n_heads, inner = H * 64, dff = c->d_ff, L = c->src_len, tgt = c->tgt_len;
   const int es = (int)sizeof(T);
   const int* posp = &bf.st->pos;
@@ -490,10 +582,10 @@ int enqueue_step(const MhT5Config* c, const MhT5Weights* w, const void* cross_kv
     sk.N = inner; sk.K = d; sk.out = bf.q; sk.ldo = inner; sk.ss_in = bf.ss; sk.ss_parts = d / 16;
     MH_TRY((skinny<T, 1, dec::PRO_RMSNORM, dec::SK_STORE>(sk, s)));
     dec::CrossAttnP ca{};
-    const long kv_layer = (long)Bfull * H * L * 64 * es;
+    const long kv_layer = (long)kvB * H * L * 64 * es;
     ca.q = bf.q; ca.ldq = inner; ca.k = (const char*)cross_kv + (long)(l * 2 + 0) * kv_layer;
     ca.v = (const char*)cross_kv + (long)(l * 2 + 1) * kv_layer; ca.out = bf.attn; ca.ldo = inner; ca.part = bf.part;
-    ca.B = B; ca.H = H; ca.L = L; ca.splits = bf.splits; ca.ticket = bf.ticket;
+    ca.B = B; ca.H = H; ca.L = L; ca.splits = bf.splits; ca.ticket = bf.ticket; ca.kv_B = kvB < Bfull ? kvB : 0;
     MH_TRY(launch_cross<T>(ca, s));
     sk = dec::SkinnyP{};
     sk.A = bf.attn; sk.lda = inner; sk.W = w->dec_co[l]; sk.ldw = inner; sk.B = B; sk.N = d; sk.K = inner; sk.h = bf.h;
@@ -513,7 +605,7 @@ int enqueue_step(const MhT5Config* c, const MhT5Weights* w, const void* cross_kv
   sk.A = bf.h; sk.lda = d; sk.ln_w = w->dec_final_ln; sk.eps = c->eps; sk.W = w->lm_head; sk.ldw = d; sk.B = B;
   sk.N = c->vocab_out; sk.K = d; sk.out = bf.logits; sk.ldo = c->vocab_out; sk.ss_in = bf.ss; sk.ss_parts = d / 16;
   MH_TRY((skinny<T, 1, dec::PRO_RMSNORM, dec::SK_LOGITS>(sk, s)));
-  hipLaunchKernelGGL(dec_sample_kernel<T>, dim3(B), dim3(256), 0, s, smp);
+  hipLaunchKernelGGL(dec_sample_kernel<T>, dim3(smp.pair > 0 ? smp.pair : B), dim3(256), 0, s, smp);
   MH_TRY(check_launch("dec_sample_kernel"));
   hipLaunchKernelGGL(dec_advance_kernel, dim3(1), dim3(64), 0, s, bf.st, bf.finished, B);
   MH_TRY(check_launch("dec_advance_kernel"));
@@ -544,6 +636,7 @@ extern "C" int64_t mh_t5_decode_workspace_bytes(const MhT5Config* c, int B) {
   t += align256((int64_t)c->n_dec_layers * B * inner * c->tgt_len * es) * 2;      // self K, V caches
   t += align256(B) + align256((int64_t)B * 4) * 2 + align256(sizeof(DecState)) * kMaxChains;   // flags / state
   t += align256((int64_t)B * c->n_heads * 4);                                     // cross-attention merge tickets
+  t += align256((int64_t)B * c->vocab_out * 4) * 3;                               // processed scores + LookbackBias history
   t += prefill_layout(c, B, c->tgt_len - 1, nullptr, 0, nullptr);                  // batched prompt prefill
   return t;
 }
@@ -586,7 +679,7 @@ int64_t prefill_layout(const MhT5Config* c, int B, int np_max, void* base, int64
 // flash attention), filling the self-attention K/V caches exactly as P-1 single-token steps would
 // (HF prefill: SURVEY.md appendix A.1).  Position P-1 is left to the per-token loop, which also produces the
 // first sampled token.  Left-pad keys are masked, left-pad query rows produce unused garbage, as in HF.
-int prefill_prompt(const MhT5Config* c, const MhT5Weights* w, const void* cross_kv, int B, const int32_t* prompt,
+int prefill_prompt(const MhT5Config* c, const MhT5Weights* w, const void* cross_kv, int B, int kvB, const int32_t* prompt,
                    const uint8_t* prompt_mask, int P, void* self_k, void* self_v, const PrefillBuf& pb, hipStream_t s) {
   const int np = P - 1, rows = B * np;
   const int d = c->d_model, H = c->n_heads, inner = H * 64, dff = c->d_ff, L = c->src_len, tgt = c->tgt_len;
@@ -598,12 +691,12 @@ int prefill_prompt(const MhT5Config* c, const MhT5Weights* w, const void* cross_
     hipLaunchKernelGGL(prefill_embed_kernel<float>, dim3(rows), dim3(256), 0, s, prompt, P, np, (const float*)w->dec_embed, d, pb.h);
   MH_TRY(check_launch("prefill_embed_kernel"));
   if (hipMemsetAsync(pb.vt, 0, (size_t)B * inner * np_pad * es, s) != hipSuccess) return check_launch("memset prefill vt");
-  if (hipMemsetAsync(pb.cross_vt, 0, (size_t)c->n_dec_layers * B * inner * pb.Lpad * es, s) != hipSuccess)
+  if (hipMemsetAsync(pb.cross_vt, 0, (size_t)c->n_dec_layers * kvB * inner * pb.Lpad * es, s) != hipSuccess)
     return check_launch("memset cross vt");
-  const long kv_layer = (long)B * H * L * 64;   // elements per (layer, k|v) slab of cross_kv
+  const long kv_layer = (long)kvB * H * L * 64;   // elements per (layer, k|v) slab of cross_kv (kvB = B/2 under CFG)
   for (int l = 0; l < c->n_dec_layers; ++l)
     MH_TRY(transpose_v((const char*)cross_kv + (long)(l * 2 + 1) * kv_layer * es, (long)H * L * 64, (long)L * 64, L,
-                       (char*)pb.cross_vt + (long)l * B * inner * pb.Lpad * es, pb.Lpad, B, H, c->dtype, s));
+                       (char*)pb.cross_vt + (long)l * kvB * inner * pb.Lpad * es, pb.Lpad, kvB, H, c->dtype, s));
   MhGemm g;
   for (int l = 0; l < c->n_dec_layers; ++l) {
     char* kc = (char*)self_k + (long)l * B * H * tgt * 64 * es;
@@ -634,15 +727,17 @@ int prefill_prompt(const MhT5Config* c, const MhT5Weights* w, const void* cross_
     g.A = pb.n; g.lda = d; g.W = w->dec_cq[l]; g.ldw = d; g.C = pb.q; g.ldc = inner; g.M = rows; g.N = inner; g.K = d;
     g.dtype = c->dtype; g.epilogue = MH_EPI_STORE;
     MH_TRY(gemm(g, s));
-    a = AttnArgs{};
-    a.q = pb.q; a.q_rs = (long)inner * es; a.q_bs = (long)np * inner * es;
-    a.k = (const char*)cross_kv + (long)(l * 2 + 0) * kv_layer * es; a.k_rs = 64L * es; a.k_hs = (long)L * 64 * es;
-    a.k_bs = (long)H * L * 64 * es;
-    a.vt = (char*)pb.cross_vt + (long)l * B * inner * pb.Lpad * es; a.Lkpad = pb.Lpad; a.vt_hs = 64L * pb.Lpad * es;
-    a.vt_bs = (long)H * 64 * pb.Lpad * es;
-    a.out = pb.attn; a.out_rs = (long)inner * es; a.out_bs = (long)np * inner * es;
-    a.Lq = np; a.Lk = L; a.scale = 1.0f;
-    MH_TRY(attention_general(a, B, H, c->dtype, s));
+    for (int b0 = 0; b0 < B; b0 += kvB) {   // under CFG both halves of the batch attend to the same kvB encoder rows
+      a = AttnArgs{};
+      a.q = (char*)pb.q + (long)b0 * np * inner * es; a.q_rs = (long)inner * es; a.q_bs = (long)np * inner * es;
+      a.k = (const char*)cross_kv + (long)(l * 2 + 0) * kv_layer * es; a.k_rs = 64L * es; a.k_hs = (long)L * 64 * es;
+      a.k_bs = (long)H * L * 64 * es;
+      a.vt = (char*)pb.cross_vt + (long)l * kvB * inner * pb.Lpad * es; a.Lkpad = pb.Lpad; a.vt_hs = 64L * pb.Lpad * es;
+      a.vt_bs = (long)H * 64 * pb.Lpad * es;
+      a.out = (char*)pb.attn + (long)b0 * np * inner * es; a.out_rs = (long)inner * es; a.out_bs = (long)np * inner * es;
+      a.Lq = np; a.Lk = L; a.scale = 1.0f;
+      MH_TRY(attention_general(a, kvB, H, c->dtype, s));
+    }
     g = MhGemm{};
     g.A = pb.attn; g.lda = inner; g.W = w->dec_co[l]; g.ldw = inner; g.C = pb.h; g.ldc = d; g.M = rows; g.N = d; g.K = inner;
     g.dtype = c->dtype; g.epilogue = MH_EPI_RESID;
@@ -713,7 +808,14 @@ extern "C" int mh_t5_generate(const MhT5Config* c, const MhT5Weights* w, const v
   MH_REQUIRE(sp->max_length <= c->tgt_len, "mh_t5_generate: max_length %d exceeds tgt_len %d", sp->max_length, c->tgt_len);
   MH_REQUIRE(sp->temperature > 0.f, "mh_t5_generate: temperature must be > 0");
   MH_REQUIRE(sp->n_sos >= 0 && sp->n_sos <= 16, "mh_t5_generate: too many sos ids");
-  MH_REQUIRE(!(sp->do_sample && !logits_dump), "mh_t5_generate: do_sample needs the logits_dump scratch");
+  const bool cfg = sp->cfg_scale > 1.0f;
+  MH_REQUIRE(!cfg || B % 2 == 0, "mh_t5_generate: classifier-free guidance needs an even batch (negative rows, then prompt rows)");
+  MH_REQUIRE(sp->n_cond >= 0 && sp->n_cond <= 3, "mh_t5_generate: n_cond %d not in [0, 3]", sp->n_cond);
+  for (int j = 0; j < sp->n_cond; ++j)
+    MH_REQUIRE(sp->cond_temp[j] > 0.f && sp->cond_offset[j] >= 1, "mh_t5_generate: bad conditional temperature rule %d", j);
+  MH_REQUIRE(sp->tok_flags || (sp->n_cond == 0 && !sp->lookback_types_first),
+             "mh_t5_generate: tok_flags is required by the conditional temperature / types_first lookback processors");
+  const int kvB = cfg ? B / 2 : B;
   MH_REQUIRE(workspace_bytes >= mh_t5_decode_workspace_bytes(c, B), "mh_t5_generate: workspace too small");
   hipStream_t s = (hipStream_t)stream;
   const int es = es_of(c->dtype), H = c->n_heads, inner = H * 64, d = c->d_model, V = c->vocab_out;
@@ -734,7 +836,9 @@ extern "C" int mh_t5_generate(const MhT5Config* c, const MhT5Weights* w, const v
   all.last_ts = (int32_t*)ar.take((int64_t)B * 4);
   DecState* st_all = (DecState*)ar.take((int64_t)align256(sizeof(DecState)) * kMaxChains);
   int* ticket_all = (int*)ar.take((int64_t)B * H * 4);
-  MH_REQUIRE(ar.ok() && ticket_all, "mh_t5_generate: arena overflow");
+  float* proc = (float*)ar.take((int64_t)B * V * 4);
+  float* hist_scores = (float*)ar.take((int64_t)B * V * 4 * 2);
+  MH_REQUIRE(ar.ok() && hist_scores, "mh_t5_generate: arena overflow");
   // In-kernel merge of the cross-attention key splits (write-through partials + ticket, see dec_cross_attn_kernel);
   // MH_DECODE_FUSED_MERGE=0 falls back to the separate merge launch.
   const char* fm = getenv("MH_DECODE_FUSED_MERGE");
@@ -742,7 +846,8 @@ extern "C" int mh_t5_generate(const MhT5Config* c, const MhT5Weights* w, const v
   if (hipMemsetAsync(ticket_all, 0, (size_t)B * H * 4, s) != hipSuccess) return check_launch("ticket memset");
   all.splits = cross_splits(B, H);
 
-  const int n_chains = pick_chains(B);
+  // a CFG pair spans both halves of the batch and the conditional temperature reads row 0's history: one chain
+  const int n_chains = (cfg || sp->n_cond > 0) ? 1 : pick_chains(B);
   const int rows_per = ceil_div(B, n_chains);
   MH_TRY(g_pool.init());
 
@@ -760,7 +865,7 @@ extern "C" int mh_t5_generate(const MhT5Config* c, const MhT5Weights* w, const v
       prefill_layout(c, B, P - 1, (char*)workspace + used_dec, workspace_bytes - used_dec, &pb);
       MH_REQUIRE(used_dec + prefill_layout(c, B, P - 1, nullptr, 0, nullptr) <= workspace_bytes,
                  "mh_t5_generate: workspace too small for the prompt prefill");
-      MH_TRY(prefill_prompt(c, w, cross_kv, B, prompt, prompt_mask, P, all.self_k, all.self_v, pb, s));
+      MH_TRY(prefill_prompt(c, w, cross_kv, B, kvB, prompt, prompt_mask, P, all.self_k, all.self_v, pb, s));
       start_pos = P - 1;
     }
   }
@@ -799,6 +904,7 @@ extern "C" int mh_t5_generate(const MhT5Config* c, const MhT5Weights* w, const v
     smp.forced = forced; smp.eos_table = eos_table; smp.finished = all.finished; smp.finish_col = all.finish_col;
     smp.last_ts_val = all.last_ts; smp.logits_dump = logits_dump; smp.dec_embed = w->dec_embed; smp.h = bf.h;
     smp.d = d; smp.ss = bf.ss; smp.sp = *sp; smp.st = bf.st; smp.B = B; smp.P = P; smp.b0 = b0;
+    smp.proc = proc; smp.hist_scores = hist_scores; smp.pair = cfg ? B / 2 : 0;
 
     if (bf16) hipLaunchKernelGGL(dec_init_kernel<bf16_t>, dim3(Bc), dim3(256), 0, cs, smp, Bc, start_pos);
     else hipLaunchKernelGGL(dec_init_kernel<float>, dim3(Bc), dim3(256), 0, cs, smp, Bc, start_pos);
@@ -806,8 +912,8 @@ extern "C" int mh_t5_generate(const MhT5Config* c, const MhT5Weights* w, const v
     if (rc != MH_OK) break;
     // capture one step of this chain (every kernel reads the position from device memory) for replay
     if (hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) != hipSuccess) { rc = check_launch("begin capture"); break; }
-    int rce = bf16 ? enqueue_step<bf16_t>(c, w, ckv, Bc, B, pm, P, bf, smp, cs)
-                   : enqueue_step<float>(c, w, ckv, Bc, B, pm, P, bf, smp, cs);
+    int rce = bf16 ? enqueue_step<bf16_t>(c, w, ckv, Bc, B, kvB, pm, P, bf, smp, cs)
+                   : enqueue_step<float>(c, w, ckv, Bc, B, kvB, pm, P, bf, smp, cs);
     hipError_t ce = hipStreamEndCapture(cs, &graphs[ci]);
     ++used;
     if (rce != MH_OK) { rc = rce; break; }

@@ -3,15 +3,17 @@
 (osuT5/osuT5/inference/server.py:83-156), with `model` a `MapperatorinatorHIP`.
 
 Same kwargs, same EOS-set construction (server.py:72-80), same processor order
-(MonotonicTimeShift -> TimeshiftBias -> Temperature -> LookbackBias, server.py:106-134), same
-stats dict (server.py:50-69).  Options the HIP path does not implement raise NotImplementedError
-(CFG batch doubling, beam search, types_first conditional temperature / lookback renormalisation:
-SURVEY.md 8f rank 3) -- never a silent approximation.
+(CFG -> MonotonicTimeShift -> TimeshiftBias -> Temperature | ConditionalTemperature -> LookbackBias,
+server.py:106-134), same stats dict (server.py:50-69).  Classifier-free guidance follows the reference's
+batch layout: the negative prompt rows first, the prompt rows second, one shared encoder output per pair
+(modeling_mapperatorinator.py:243-254).  Beam search is the one option the HIP path does not implement:
+it raises NotImplementedError -- never a silent approximation.
 """
 from __future__ import annotations
 
 import time
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -19,6 +21,18 @@ from .event import ContextType, EventType
 
 MILISECONDS_PER_SECOND = 1000
 MILISECONDS_PER_STEP = 10
+
+# events that carry a time (reference osuT5/osuT5/dataset/data_utils.py TIMED_EVENTS), by name
+TIMED_EVENT_NAMES = ("CIRCLE", "SPINNER", "SPINNER_END", "SLIDER_HEAD", "LAST_ANCHOR", "SLIDER_END", "BEAT", "MEASURE",
+                     "TIMING_POINT", "KIAI", "HOLD_NOTE", "HOLD_NOTE_END", "DRUMROLL", "DRUMROLL_END", "DENDEN",
+                     "DENDEN_END", "SCROLL_SPEED_CHANGE")
+
+FLAG_TIMED, FLAG_COND0, FLAG_LOOKBACK_EOS = 1, 2, 16   # bits of MhSampling.tok_flags (include/mapperhip.h)
+
+
+class Sampling(_lib.MhSampling):
+    """MhSampling + the host copy of its `tok_flags` table (the engine uploads it and fills the pointer)."""
+    host_tok_flags = None
 
 
 def get_eos_token_id(tokenizer, lookback_time: float = 0, lookahead_time: float = 0, context_type=None):
@@ -44,6 +58,32 @@ def _ev(table: dict, name: str):
         if getattr(k, "name", None) == name:
             return v
     raise KeyError(name)
+
+
+def _has(table: dict, name: str) -> bool:
+    return any(getattr(k, "name", None) == name for k in table)
+
+
+def get_beat_type_tokens(tokenizer):
+    """(reference logit_processors.py:14-21)"""
+    ids = [_ev(tokenizer.event_start, "BEAT"), _ev(tokenizer.event_start, "MEASURE")]
+    if _has(tokenizer.event_start, "TIMING_POINT"):
+        ids.append(_ev(tokenizer.event_start, "TIMING_POINT"))
+    return tuple(ids)
+
+
+def get_mania_type_tokens(tokenizer):
+    """(reference logit_processors.py:24-29)"""
+    if not _has(tokenizer.event_start, "HOLD_NOTE_END"):
+        return ()
+    return tuple(_ev(tokenizer.event_start, n) for n in ("CIRCLE", "HOLD_NOTE", "HOLD_NOTE_END"))
+
+
+def get_scroll_speed_tokens(tokenizer):
+    """(reference logit_processors.py:32-34)"""
+    if not _has(tokenizer.event_start, "SCROLL_SPEED"):
+        return ()
+    return tuple(range(_ev(tokenizer.event_start, "SCROLL_SPEED"), _ev(tokenizer.event_end, "SCROLL_SPEED")))
 
 
 def _prompt_token_counts(model_kwargs, pad_token_id):
@@ -87,17 +127,27 @@ def build_sampling(tokenizer, generate_kwargs: dict, max_target_positions: int):
     context_type = gk.pop("context_type", None)
     if context_type is not None:
         context_type = ContextType(getattr(context_type, "value", context_type))
-    if cfg_scale > 1.0:
-        raise NotImplementedError("classifier-free guidance (cfg_scale > 1) is not on the HIP path yet")
     if gk.get("num_beams", 1) != 1:
         raise NotImplementedError("beam search is not on the HIP path (num_beams must be 1)")
-    if types_first and (timing_t != temperature or mania_t != temperature or taiko_t != temperature):
-        raise NotImplementedError("ConditionalTemperatureLogitsWarper (types_first) is not on the HIP path")
-    if types_first and lookback_time > 0:
-        raise NotImplementedError("LookbackBiasLogitsWarper with types_first=True is not on the HIP path")
 
     ts0, ts1 = _ev(tokenizer.event_start, "TIME_SHIFT"), _ev(tokenizer.event_end, "TIME_SHIFT")
-    sp = _lib.MhSampling()
+    sp = Sampling()
+    sp.cfg_scale = float(cfg_scale) if cfg_scale > 1.0 else 1.0        # server.py:107 `if cfg_scale > 1.0`
+    flags = np.zeros(int(tokenizer.vocab_size_out), dtype=np.uint8)
+    need_flags = False
+    if types_first:
+        # ConditionalTemperatureLogitsWarper (logit_processors.py:59-73): (temperature, token set, offset) rules
+        rules = []
+        for t, ids, off in ((timing_t, get_beat_type_tokens(tokenizer), 1),
+                            (mania_t, get_mania_type_tokens(tokenizer), 3),
+                            (taiko_t, get_scroll_speed_tokens(tokenizer), 1)):
+            if t != temperature and len(ids) > 0:
+                rules.append((t, ids, off))
+        sp.n_cond = len(rules)
+        for j, (t, ids, off) in enumerate(rules):
+            sp.cond_temp[j], sp.cond_offset[j] = float(t), int(off)
+            flags[np.asarray(ids, dtype=np.int64)] |= FLAG_COND0 << j
+            need_flags = True
     sp.do_sample = int(bool(gk.get("do_sample", False)))
     sp.top_k = int(gk.get("top_k", 0) or 0)
     sp.top_p = float(gk.get("top_p", 1.0))
@@ -119,6 +169,16 @@ def build_sampling(tokenizer, generate_kwargs: dict, max_target_positions: int):
             if getattr(k, "name", None) == "TIME_SHIFT":
                 er = v
         sp.lookback_mask_end = int(ts0 + int(lookback_time / MILISECONDS_PER_STEP) - er.min_value)
+        if types_first:
+            # LookbackBiasLogitsWarper types_first=True (logit_processors.py:99-108): eos ids + timed-event ids
+            sp.lookback_types_first = 1
+            ceos_all = list((getattr(tokenizer, "context_eos", {}) or {}).values())
+            flags[np.asarray([tokenizer.eos_id] + ceos_all, dtype=np.int64)] |= FLAG_LOOKBACK_EOS
+            for name in TIMED_EVENT_NAMES:
+                if _has(tokenizer.event_start, name):
+                    flags[_ev(tokenizer.event_start, name):_ev(tokenizer.event_end, name)] |= FLAG_TIMED
+            need_flags = True
+    sp.host_tok_flags = flags if need_flags else None
     sp.pad_id = int(gk.get("pad_token_id", getattr(tokenizer, "pad_id", 0)) or 0)
     sp.max_length = int(gk.get("max_length", max_target_positions))
     sp.seed = int(gk.get("seed", torch.initial_seed())) & 0xFFFFFFFFFFFFFFFF
@@ -131,9 +191,6 @@ def build_sampling(tokenizer, generate_kwargs: dict, max_target_positions: int):
 def model_generate(model, tokenizer, model_kwargs, generate_kwargs):
     """See module docstring.  `model_kwargs['inputs']`: raw audio float32 (B, Ns)."""
     generate_kwargs = dict(generate_kwargs)
-    for k in ("negative_prompt", "negative_prompt_attention_mask"):
-        if model_kwargs.get(k) is not None:
-            raise NotImplementedError("negative prompts need CFG, which is not on the HIP path yet")
     for k in ("beatmap_idx", "difficulty", "mapper_idx", "song_position"):
         if model_kwargs.get(k) is not None:
             raise NotImplementedError(f"conditioning input {k!r} is not part of the T5 north-star configs")
@@ -146,8 +203,17 @@ def model_generate(model, tokenizer, model_kwargs, generate_kwargs):
                          f"{model.config.max_target_positions}")
     pad_token_id = generate_kwargs.get("pad_token_id", getattr(tokenizer, "pad_id", None))
 
+    neg, neg_mask = model_kwargs.get("negative_prompt"), model_kwargs.get("negative_prompt_attention_mask")
+    if sp.cfg_scale > 1.0 and neg is None:
+        # HF's processor would raise on the batch-size check (logits not doubled without a negative prompt)
+        raise ValueError("cfg_scale > 1 needs model_kwargs['negative_prompt'] (modeling_mapperatorinator.py:243-254)")
+    if sp.cfg_scale <= 1.0:
+        # the reference doubles the batch whenever a negative prompt is passed and, without the CFG processor, HF
+        # then fails on the shape mismatch; its own caller only passes one when cfg_scale > 1 (processor.py:1171)
+        neg = neg_mask = None
+
     start = time.perf_counter()
-    out = model.engine.generate(audio, prompt, mask, eos, sp)
+    out = model.engine.generate(audio, prompt, mask, eos, sp, negative_prompt=neg, negative_mask=neg_mask)
     elapsed = time.perf_counter() - start
     result = out["tokens"]
     stats = _build_generation_stats(result, model_kwargs, pad_token_id, elapsed)

@@ -244,16 +244,27 @@ class T5Engine:
     def decode(self, cross_kv: torch.Tensor, prompt: torch.Tensor, prompt_mask: Optional[torch.Tensor],
                eos_table: torch.Tensor, sampling: _lib.MhSampling, forced: Optional[torch.Tensor] = None,
                dump_logits: bool = False, poll_every: int = 16):
-        """prompt int32 (B, P) on device.  Returns (tokens int32 (B, max_length) device, n_cols int, logits|None)."""
+        """prompt int32 (B, P) on device.  Returns (tokens int32 (B, max_length) device, n_cols int, logits|None).
+        Under CFG (sampling.cfg_scale > 1) the B rows are [negative-prompt rows | prompt rows], `cross_kv` holds
+        B/2 rows and the logits dump has B/2 rows (the guided scores)."""
         p = self.packed
         B, P = prompt.shape
+        cfg = sampling.cfg_scale > 1.0
+        if cross_kv.shape[2] != (B // 2 if cfg else B):
+            raise ValueError(f"cross_kv holds {cross_kv.shape[2]} rows for a decode batch of {B} (cfg={cfg})")
+        flags = getattr(sampling, "host_tok_flags", None)
+        if flags is not None:   # keep the device copy alive for the duration of the call
+            flags_d = torch.as_tensor(flags, dtype=torch.uint8).to(self.device)
+            sampling.tok_flags = flags_d.data_ptr()
+        elif sampling.n_cond or sampling.lookback_types_first:
+            raise ValueError("sampling needs tok_flags (build it with server.build_sampling)")
         need = self.lib.mh_t5_decode_workspace_bytes(C.byref(p.cfg), B)
         ws = self._workspace("dec", need)
         maxlen = sampling.max_length
         tokens = torch.full((B, maxlen), int(sampling.pad_id), dtype=torch.int32, device=self.device)
         n_out = torch.zeros(1, dtype=torch.int32, device=self.device)
-        logits = (torch.zeros((maxlen, B, p.vocab_out), dtype=torch.float32, device=self.device)
-                  if (dump_logits or sampling.do_sample) else None)
+        logits = (torch.zeros((maxlen, B // 2 if cfg else B, p.vocab_out), dtype=torch.float32, device=self.device)
+                  if dump_logits else None)
         rc = self.lib.mh_t5_generate(C.byref(p.cfg), C.byref(p.w), cross_kv.data_ptr(), B, prompt.data_ptr(),
                                      _lib.ptr(prompt_mask), P, eos_table.data_ptr(), C.byref(sampling),
                                      tokens.data_ptr(), n_out.data_ptr(), _lib.ptr(logits), _lib.ptr(forced),
@@ -263,11 +274,33 @@ class T5Engine:
 
     def generate(self, audio: torch.Tensor, prompt: torch.Tensor, prompt_mask: Optional[torch.Tensor],
                  eos_ids, sampling: _lib.MhSampling, forced: Optional[torch.Tensor] = None,
-                 dump_logits: bool = False, poll_every: int = 16):
+                 dump_logits: bool = False, poll_every: int = 16, negative_prompt: Optional[torch.Tensor] = None,
+                 negative_mask: Optional[torch.Tensor] = None):
         """Full hot path for one batch of chunks.  Inputs may be CPU tensors (copied like
-        server.py:86-87 does).  Returns dict(tokens=int64 CPU (B, n_cols), logits=..., n_cols=int)."""
+        server.py:86-87 does).  Returns dict(tokens=int64 CPU (B, n_cols), logits=..., n_cols=int).
+        With `negative_prompt` (classifier-free guidance) the decode batch is doubled the way the reference's
+        prepare_inputs_for_generation does it (modeling_mapperatorinator.py:243-254): the first half carries the
+        negative prompt over the first columns of the prompt; the returned rows are the prompt rows."""
         dev = self.device
         audio = audio.to(dev, torch.float32)
+        G = prompt.shape[0]
+        cfg = negative_prompt is not None
+        if cfg != (sampling.cfg_scale > 1.0):
+            raise ValueError("negative_prompt and sampling.cfg_scale > 1 go together")
+        if cfg:
+            n = negative_prompt.shape[1]
+            if n > prompt.shape[1]:
+                raise ValueError("negative prompt longer than the prompt")
+            neg = prompt.clone()
+            neg[:, :n] = negative_prompt.to(prompt.dtype)
+            prompt = torch.cat([neg, prompt], 0)
+            if prompt_mask is not None:
+                # `negative_mask` is accepted for signature parity and deliberately unused: in the reference the
+                # kwarg `negative_prompt_attention_mask` is swallowed by HF `generate()` (a named parameter of its
+                # own) before prepare_inputs_for_generation runs, so the negative rows attend under the prompt's mask
+                prompt_mask = torch.cat([prompt_mask, prompt_mask], 0)
+            if forced is not None:
+                forced = torch.cat([forced, forced], 0)
         prompt_d = prompt.to(dev, torch.int32).contiguous()
         mask_d = prompt_mask.to(dev).to(torch.uint8).contiguous() if prompt_mask is not None else None
         forced_d = forced.to(dev, torch.int32).contiguous() if forced is not None else None
@@ -284,5 +317,7 @@ class T5Engine:
         self._leave()
         torch.cuda.current_stream(dev).synchronize()
         n_cols = int(n_out.item()) if forced is None else sampling.max_length
+        if cfg:
+            tokens = tokens[G:]
         return dict(tokens=tokens[:, :n_cols].to(torch.int64).cpu(), n_cols=n_cols,
                     logits=None if logits is None else logits[:n_cols])

@@ -127,3 +127,15 @@ def synthetic_dit_inputs(T: int = 128, context_size: int = 272, class_size: int 
     z = np.concatenate([z1, z1], 0)
     c = np.concatenate([c1, c1], 0)
     return torch.from_numpy(z), torch.from_numpy(c), torch.from_numpy(y)
+
+
+def boost_timed_rows(sd: dict, tok, gain: float) -> dict:
+    """Random weights almost never emit a timed event (CIRCLE, BEAT, HOLD_NOTE ...); scale their lm_head rows so that
+    the types_first processors, which key on them, fire in the parity cases.  In place; used identically by
+    oracle/make_golden.py and the tests."""
+    from .server import TIMED_EVENT_NAMES, _ev, _has
+    w = sd["transformer.lm_head.weight"]
+    for name in TIMED_EVENT_NAMES:
+        if _has(tok.event_start, name):
+            w[_ev(tok.event_start, name):_ev(tok.event_end, name)] *= gain
+    return sd

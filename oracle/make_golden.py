@@ -17,8 +17,8 @@ import numpy as np
 import torch
 
 from mapperatorinator_amd.t5_engine import T5_PRESETS
-from mapperatorinator_amd.testing import (DIT_PRESETS, random_dit_state_dict, random_t5_state_dict,
-                                          synthetic_audio, synthetic_dit_inputs)
+from mapperatorinator_amd.testing import (DIT_PRESETS, boost_timed_rows, random_dit_state_dict,
+                                          random_t5_state_dict, synthetic_audio, synthetic_dit_inputs)
 
 from . import dit as odit
 from . import mel as omel
@@ -60,6 +60,50 @@ def t5_case(name):
         ids=ids.numpy(), ids_processors=ids2.numpy(),
     )
     print(name, "ids", ids.shape, "distinct", len(set(ids.flatten().tolist())), "tok/s(ref,cpu)", stats["tokens_per_second"])
+
+
+TF_CASE = dict(src=251, tgt=48, n_samples=32000, weight_seed=21, lm_head_gain=6.0, timed_gain=2.0, audio_seed=5,
+               prompt=[[0, 0, 3], [3, 40, 2068], [0, 3, 9]], negative=[[0, 0, 1], [0, 1, 2069], [0, 0, 3]])
+TF_RUNS = {
+    # ConditionalTemperature + LookbackBias(types_first=True)
+    "tf": dict(types_first=True, temperature=0.9, timing_temperature=0.5, mania_column_temperature=0.6,
+               taiko_hit_temperature=0.7, lookback_time=500),
+    # classifier-free guidance alone
+    "cfg": dict(cfg_scale=2.5),
+    # everything at once
+    "all": dict(cfg_scale=1.7, types_first=True, temperature=1.1, timing_temperature=0.6, mania_column_temperature=0.8,
+                taiko_hit_temperature=0.5, lookback_time=800, lookahead_time=400, timeshift_bias=0.2),
+}
+
+
+def types_first_case():
+    """Reference `model_generate` with the types_first processors and classifier-free guidance: ids + the processed
+    scores of every step (observed at HF's LogitsProcessorList), on a tokenizer that has every token family."""
+    c = TF_CASE
+    model, tok, _ = rh.build_reference_t5("tiny", src_seq_len=c["src"], tgt_seq_len=c["tgt"], types_first=True)
+    with open(os.path.join(OUT, "tokenizer_types_first.json"), "w") as f:
+        json.dump(tok.state_dict(), f)
+    sd = random_t5_state_dict(T5_PRESETS["tiny"], tok.vocab_size_in, tok.vocab_size_out, seed=c["weight_seed"],
+                              lm_head_gain=c["lm_head_gain"])
+    boost_timed_rows(sd, tok, c["timed_gain"])
+    res = model.load_state_dict(sd, strict=False)
+    assert not res.unexpected_keys, res
+    audio = synthetic_audio(len(c["prompt"]), c["n_samples"], seed=c["audio_seed"])
+    prompt, neg = torch.tensor(c["prompt"]), torch.tensor(c["negative"])
+    out = dict(vocab_in=tok.vocab_size_in, vocab_out=tok.vocab_size_out, prompt=prompt.numpy(), negative=neg.numpy(),
+               runs=json.dumps(TF_RUNS),
+               **{k: v for k, v in c.items() if k not in ("prompt", "negative")})
+    for name, over in TF_RUNS.items():
+        rec = []
+        ids, _ = rh.reference_generate(model, tok, audio, prompt, rh.default_generate_kwargs(c["tgt"], **over),
+                                       prompt.ne(0), negative_prompt=neg if "cfg_scale" in over else None,
+                                       record_scores=rec)
+        out["ids_" + name] = ids.numpy()
+        out["scores_" + name] = torch.stack(rec).numpy()
+        timed_hits = sum(int(((ids[:, 3:-1] >= 2058) & (ids[:, 3:-1] < 2080)).sum()) for _ in [0])
+        print("types_first run", name, ids.shape, "steps", len(rec), "timed ids emitted", timed_hits,
+              "row0 scroll-speed ids", int(((ids[0] >= 882) & (ids[0] < 1883)).sum()))
+    np.savez_compressed(os.path.join(OUT, "t5_tiny_tf.npz"), **out)
 
 
 def tokenizer_case():
@@ -126,6 +170,7 @@ def main():
     mel_case()
     for name in T5_CASES:
         t5_case(name)
+    types_first_case()
     dit_case("dit_xs", "DiT-XS", 96, 21, 5, 1.5)
     dit_case("dit_s", "DiT-S", 160, 1, 2, 2.0)
 

@@ -71,12 +71,15 @@ TINY_OVERWRITE = {"d_model": 128, "d_ff": 256, "num_heads": 2, "num_layers": 2, 
 
 
 def build_reference_t5(size="small", src_seq_len=1251, tgt_seq_len=512, n_mels=388,
-                       dtype=torch.float32, seed=0, lm_head_gain=1.0, overwrite=None):
+                       dtype=torch.float32, seed=0, lm_head_gain=1.0, overwrite=None, types_first=False):
     """reference `_get_model` (osuT5/osuT5/utils/model_utils.py:102-114) with the reference
     initialisers (HF `_init_weights`), seeded."""
     if size == "tiny":  # test-only size: t5-small backbone config with the dims overwritten
         size, overwrite = "small", dict(TINY_OVERWRITE, **(overwrite or {}))
     args = _train_config(size, src_seq_len, tgt_seq_len, n_mels)
+    if types_first:
+        args = types_first_train_config(src_seq_len, tgt_seq_len, n_mels)
+        args.model.name = f"google/t5-v1_1-{size}"
     if overwrite:
         args.model.overwrite = dict(args.model.overwrite, **overwrite)
     from osuT5.osuT5.tokenizer import Tokenizer
@@ -111,17 +114,48 @@ def default_generate_kwargs(max_length: int, **over):
     return kw
 
 
-def reference_generate(model, tok, audio, prompt, generate_kwargs, attention_mask=None):
-    """The reference's own `model_generate` (server.py:83-156) via the `encoder_outputs` route."""
+def reference_generate(model, tok, audio, prompt, generate_kwargs, attention_mask=None, negative_prompt=None,
+                       negative_mask=None, record_scores=None):
+    """The reference's own `model_generate` (server.py:83-156) via the `encoder_outputs` route.
+    `record_scores`: a list that receives the processed scores of every step (what the merged
+    LogitsProcessorList returns inside HF `_sample`), observed without touching reference code."""
     ref_shims.install()
     from osuT5.osuT5.inference.server import model_generate
+    from transformers import LogitsProcessorList
     from transformers.modeling_outputs import BaseModelOutput
     enc = reference_encode(model, audio)
     if attention_mask is None:
         attention_mask = prompt.ne(0)
     mk = dict(inputs=audio, encoder_outputs=BaseModelOutput(last_hidden_state=enc),
               decoder_input_ids=prompt, decoder_attention_mask=attention_mask)
-    return model_generate(model, tok, mk, dict(generate_kwargs))
+    if negative_prompt is not None:
+        mk.update(negative_prompt=negative_prompt,
+                  negative_prompt_attention_mask=negative_prompt.ne(0) if negative_mask is None else negative_mask)
+    orig = LogitsProcessorList.__call__
+    if record_scores is not None:
+        def spy(self, input_ids, scores, **kw):
+            out = orig(self, input_ids, scores, **kw)
+            record_scores.append(out.detach().float().cpu().clone())
+            return out
+        LogitsProcessorList.__call__ = spy
+    try:
+        return model_generate(model, tok, mk, dict(generate_kwargs))
+    finally:
+        LogitsProcessorList.__call__ = orig
+
+
+def types_first_train_config(src_seq_len: int, tgt_seq_len: int, n_mels: int = 388):
+    """A tokenizer configuration that carries every token family the types_first processors look at: beat types,
+    mania types, scroll speeds, context sos/eos (all gamemodes, SVs, timing points, kiai)."""
+    args = _train_config("small", src_seq_len, tgt_seq_len, n_mels)
+    d = args.data
+    d.types_first = True
+    d.gamemodes = [0, 1, 2, 3]
+    d.add_sv = True
+    d.add_timing_points = True
+    d.add_kiai = True
+    d.add_out_context_types = True
+    return args
 
 
 def build_reference_dit(name="DiT-S", context_size=272, class_size=300, seed=0, rerandomise=True):

@@ -14,7 +14,10 @@ it is the checker, never the product.  It follows, function by function:
   greedy loop         HF GenerationMixin._sample as driven by osuT5/osuT5/inference/server.py:83-156
                       (SURVEY.md Appendix A), StaticCache semantics of inference/cache_utils.py:23-35
   processors          osuT5/osuT5/inference/logit_processors.py:36-44 (TimeshiftBias), :136-183 (MonotonicTimeShift),
-                      :111-114 (LookbackBias, types_first=False), HF TemperatureLogitsWarper
+                      :111-114 (LookbackBias, types_first=False), :116-133 (types_first=True),
+                      :47-82 (ConditionalTemperature), HF TemperatureLogitsWarper,
+                      HF ClassifierFreeGuidanceLogitsProcessor on the batch layout of
+                      modeling_mapperatorinator.py:243-254
 
 PINNING (tests/test_oracle_pinned.py, runs where /root/reference exists): hidden states, logits and
 greedy ids agree with the imported reference (`Mapperatorinator` + HF T5 via the reference's own
@@ -181,27 +184,51 @@ class T5Oracle:
 
     # ---- generation ------------------------------------------------------------------------
     def generate(self, enc, prompt, prompt_mask, eos_ids, max_length, ts_start, ts_end, sos_ids, pad_id=0,
-                 temperature=1.0, timeshift_bias=0.0, lookback_mask_end=0, forced=None, return_logits=False):
+                 temperature=1.0, timeshift_bias=0.0, lookback_mask_end=0, forced=None, return_logits=False,
+                 negative_prompt=None, negative_mask=None, cfg_scale=1.0, cond_rules=(), lookback_types_first=None):
         """Greedy decode with HF `_sample` bookkeeping.  prompt (B,P) int64 left-padded, prompt_mask bool.
-        Returns ids (B, n_cols) [, processed scores per produced column (list of (B,V))]."""
+        Returns ids (B, n_cols) [, processed scores per produced column (list of (B,V))].
+
+        negative_prompt/negative_mask/cfg_scale: classifier-free guidance with the reference's batch layout
+            (modeling_mapperatorinator.py:243-254 + HF ClassifierFreeGuidanceLogitsProcessor): rows [0,B) of the
+            doubled batch carry the negative prompt, rows [B,2B) the prompt.
+        cond_rules: [(temperature, token ids, offset)] of ConditionalTemperatureLogitsWarper (logit_processors.py:47-82)
+        lookback_types_first: dict(eos_ids=[...], timed_ids=[...]) switches LookbackBiasLogitsWarper to its
+            types_first=True branch (:116-133) over [ts_start, lookback_mask_end)."""
         B, P = prompt.shape
-        ckv = self.cross_kv(enc)
-        cache = [(torch.zeros(B, self.H, max_length, 64), torch.zeros(B, self.H, max_length, 64))
+        cfg = negative_prompt is not None and cfg_scale > 1.0
+        NB = 2 * B if cfg else B
+        ckv = self.cross_kv(enc.repeat(2, 1, 1) if cfg else enc)
+        cache = [(torch.zeros(NB, self.H, max_length, 64), torch.zeros(NB, self.H, max_length, 64))
                  for _ in range(self.nd)]
-        key_mask = torch.ones(B, max_length, dtype=torch.bool)
-        key_mask[:, :P] = prompt_mask.bool() if prompt_mask is not None else True
+        key_mask = torch.ones(NB, max_length, dtype=torch.bool)
+        key_mask[NB - B:, :P] = prompt_mask.bool() if prompt_mask is not None else True
+        if cfg:
+            # `negative_prompt_attention_mask` never reaches modeling_mapperatorinator.py:249-250: it is a named
+            # parameter of HF `GenerationMixin.generate` (unbatched-CFG support) and is consumed there, so both
+            # halves of the doubled batch run under the PROMPT's mask (observed on the imported reference; pinned
+            # by tests/golden/t5_tiny_tf.npz whose negative prompts are padded differently from the prompts)
+            key_mask[:B, :P] = key_mask[B:, :P]
         ids = prompt.clone()
         unfinished = torch.ones(B, dtype=torch.bool)
         eos = torch.as_tensor(sorted(set(eos_ids)), dtype=torch.long)
         sos = torch.as_tensor(list(sos_ids), dtype=torch.long)
         all_scores = []
+        last_scores = None
+        max_offset = max([o for _, _, o in cond_rules], default=0)
         for pos in range(0, max_length - 1):
             feed = ids[:, pos] if forced is None or pos < P else forced[:, pos]
+            if cfg:
+                neg_feed = negative_prompt[:, pos] if pos < negative_prompt.shape[1] else feed
+                feed = torch.cat([neg_feed, feed])
             logits = self.decoder_step(feed, pos, cache, ckv, key_mask)
             if pos + 1 < P:
                 continue
             hist = ids if forced is None else torch.cat([prompt, forced[:, P:pos + 1]], 1)
             scores = logits.clone().float()
+            if cfg:   # HF: first half = "cond", second half = "uncond"
+                cond_l, uncond_l = scores[:B], scores[B:]
+                scores = uncond_l + (cond_l - uncond_l) * cfg_scale
             # MonotonicTimeShiftLogitsProcessor
             idx = torch.arange(hist.shape[1]).expand(B, -1)
             is_ts = (hist >= ts_start) & (hist < ts_end)
@@ -216,9 +243,37 @@ class T5Oracle:
             sl[apply[:, None] & bad] = float("-inf")
             if timeshift_bias != 0:
                 scores[:, ts_start:ts_end] += timeshift_bias
-            scores = scores / temperature
+            # (Conditional)TemperatureLogitsWarper: row 0's last ids pick the temperature of the whole batch
+            temp = temperature
+            if cond_rules:
+                lookback = hist[0, -max_offset:]
+                for t, toks, off in cond_rules:
+                    if len(lookback) >= off and int(lookback[-off]) in toks:
+                        temp = t
+                        break
+            scores = scores / temp
             if lookback_mask_end > ts_start:
-                scores[:, ts_start:lookback_mask_end] = float("-inf")
+                if lookback_types_first is None:
+                    scores[:, ts_start:lookback_mask_end] = float("-inf")
+                else:
+                    entering = scores
+                    if last_scores is not None:
+                        timed = torch.as_tensor(sorted(lookback_types_first["timed_ids"]), dtype=torch.long)
+                        eos_l = torch.as_tensor(list(lookback_types_first["eos_ids"]), dtype=torch.long)
+                        last_timed = torch.isin(hist[:, -1], timed)
+                        if last_timed.any():
+                            in_lb = torch.zeros(scores.shape[1], dtype=torch.bool)
+                            in_lb[ts_start:lookback_mask_end] = True
+                            last_probs = torch.softmax(last_scores, -1)
+                            probs = torch.softmax(scores, -1)
+                            prob_eos = last_probs[:, eos_l].sum(-1)
+                            prob_event = 1 - prob_eos
+                            sc = 1 / (probs[:, ~in_lb].sum(-1) * prob_event + prob_eos)
+                            probs[:, in_lb] = 0
+                            probs[:, ~in_lb] *= sc[:, None]
+                            probs[:, ts_start] = torch.clip((sc - 1) * prob_eos / prob_event, 0, 1)
+                            scores = torch.where(last_timed[:, None], torch.log(probs), scores)
+                    last_scores = entering
             all_scores.append(scores)
             nxt = scores.argmax(-1)
             nxt = torch.where(unfinished, nxt, torch.full_like(nxt, pad_id))

@@ -23,3 +23,55 @@ def ts_range(tok):
     s = [v for k, v in tok.event_start.items() if k.name == "TIME_SHIFT"][0]
     e = [v for k, v in tok.event_end.items() if k.name == "TIME_SHIFT"][0]
     return s, e
+
+
+def types_first_case():
+    """tests/golden/t5_tiny_tf.npz: the reference's `model_generate` under the types_first processors and
+    classifier-free guidance (oracle/make_golden.py:types_first_case).  Returns (golden, tok, sd, audio, tgt, runs)."""
+    import json
+
+    import numpy as np
+
+    from mapperatorinator_amd import Tokenizer
+    from mapperatorinator_amd.t5_engine import T5_PRESETS
+    from mapperatorinator_amd.testing import boost_timed_rows, random_t5_state_dict, synthetic_audio
+    g = np.load(f"{GOLDEN}/t5_tiny_tf.npz")
+    tok = Tokenizer.from_json(f"{GOLDEN}/tokenizer_types_first.json")
+    assert tok.vocab_size_out == int(g["vocab_out"]) and tok.vocab_size_in == int(g["vocab_in"])
+    sd = random_t5_state_dict(T5_PRESETS["tiny"], tok.vocab_size_in, tok.vocab_size_out, seed=int(g["weight_seed"]),
+                              lm_head_gain=float(g["lm_head_gain"]))
+    boost_timed_rows(sd, tok, float(g["timed_gain"]))
+    audio = synthetic_audio(g["prompt"].shape[0], int(g["n_samples"]), seed=int(g["audio_seed"]))
+    return g, tok, sd, audio, int(g["tgt"]), json.loads(str(g["runs"]))
+
+
+def oracle_processor_kwargs(sp):
+    """MhSampling (server.build_sampling) -> the keyword arguments of oracle.t5.T5Oracle.generate."""
+    import numpy as np
+
+    from mapperatorinator_amd.server import FLAG_COND0, FLAG_LOOKBACK_EOS, FLAG_TIMED
+    fl = sp.host_tok_flags
+    rules = [(sp.cond_temp[j], set(np.nonzero(fl & (FLAG_COND0 << j))[0].tolist()), sp.cond_offset[j])
+             for j in range(sp.n_cond)]
+    ltf = None
+    if sp.lookback_types_first:
+        ltf = dict(eos_ids=np.nonzero(fl & FLAG_LOOKBACK_EOS)[0].tolist(), timed_ids=np.nonzero(fl & FLAG_TIMED)[0].tolist())
+    return dict(temperature=sp.temperature, timeshift_bias=sp.timeshift_bias, lookback_mask_end=sp.lookback_mask_end,
+                cfg_scale=sp.cfg_scale, cond_rules=rules, lookback_types_first=ltf)
+
+
+def assert_scores_close(got, want, tol, eos_extra_slot=None):
+    """processed scores: same -inf pattern, finite entries within `tol`.  `eos_extra_slot` (LookbackBias
+    types_first): that id holds log(clip((s-1)*p_eos/p_event, 0, 1)) whose argument is a difference of nearly equal
+    fp32 numbers -- compared as a probability instead."""
+    import torch
+    got, want = got.clone(), want.clone()
+    if eos_extra_slot is not None:
+        assert (got[:, eos_extra_slot].exp() - want[:, eos_extra_slot].exp()).abs().max().item() < 1e-5
+        got[:, eos_extra_slot] = 0
+        want[:, eos_extra_slot] = 0
+    fa, fb = torch.isfinite(got), torch.isfinite(want)
+    assert torch.equal(fa, fb), (fa != fb).nonzero()[:5]
+    err = (got[fa] - want[fa]).abs().max().item()
+    assert err < tol, err
+    return err

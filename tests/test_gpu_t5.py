@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN, ts_range
+from conftest import GOLDEN, assert_scores_close, oracle_processor_kwargs, ts_range, types_first_case
 
 pytestmark = pytest.mark.gpu
 
@@ -76,6 +76,85 @@ def test_fp32_matches_reference_golden(name):
     # processors on: temperature, timeshift bias, lookahead EOS window
     ids2, _ = model_generate(model, tok, mk, gen_kwargs(tgt, temperature=0.7, timeshift_bias=0.35, lookahead_time=3000))
     assert ids2.shape == g["ids_processors"].shape and np.array_equal(ids2.numpy(), g["ids_processors"])
+
+
+@pytest.mark.parametrize("run", ["tf", "cfg", "all"])
+def test_fp32_processors_and_cfg_match_reference_golden(run):
+    """Row a8: ConditionalTemperature + LookbackBias(types_first=True) ("tf"), classifier-free guidance with a
+    negative prompt ("cfg"), and both with TimeshiftBias and the lookback / lookahead EOS windows ("all"):
+    greedy ids BIT-EXACT vs the reference's `model_generate`, processed scores of every step within 5e-4."""
+    from mapperatorinator_amd.server import build_sampling, model_generate
+    g, tok, sd, audio, tgt, runs = types_first_case()
+    model = build("tiny", tok, sd, int(g["src"]), tgt, torch.float32)
+    prompt, neg = torch.from_numpy(g["prompt"]), torch.from_numpy(g["negative"])
+    kw = gen_kwargs(tgt, **runs[run])
+    cfg = kw["cfg_scale"] > 1
+    mk = dict(inputs=audio, decoder_input_ids=prompt, decoder_attention_mask=prompt.ne(0))
+    if cfg:
+        mk.update(negative_prompt=neg, negative_prompt_attention_mask=neg.ne(0))
+    ids, stats = model_generate(model, tok, mk, kw)
+    want = g["ids_" + run]
+    assert ids.shape == want.shape and np.array_equal(ids.numpy(), want), np.argwhere(ids.numpy() != want)[:3]
+    sp, eos = build_sampling(tok, kw, tgt)
+    out = model.engine.generate(audio, prompt, prompt.ne(0), eos, sp, dump_logits=True,
+                                negative_prompt=neg if cfg else None)
+    assert torch.equal(out["tokens"], ids)
+    scores = torch.from_numpy(g["scores_" + run])
+    P = prompt.shape[1]
+    lg = out["logits"].cpu()
+    assert lg.shape[1] == prompt.shape[0]
+    worst = 0.0
+    for i in range(min(scores.shape[0], out["n_cols"] - P)):
+        worst = max(worst, assert_scores_close(lg[P + i], scores[i], 5e-4, sp.ts_start if sp.lookback_types_first else None))
+    print(run, "worst |dscore| vs reference", worst)
+
+
+def test_bf16_cfg_and_types_first_teacher_forced():
+    """bf16 storage under classifier-free guidance + the types_first processors, teacher-forced on the bf16-contract
+    oracle's own ids: decisive steps agree; guided scores within 0.15 * (1 + 2 (cfg_scale - 1)) (the guidance
+    combination amplifies the per-row logit error by |1 - s| + |s|)."""
+    from mapperatorinator_amd.server import build_sampling
+    g, tok, sd, audio, tgt, runs = types_first_case()
+    model = build("tiny", tok, sd, int(g["src"]), tgt, torch.bfloat16)
+    prompt, neg = torch.from_numpy(g["prompt"]), torch.from_numpy(g["negative"])
+    kw = gen_kwargs(tgt, **runs["all"])
+    sp, eos = build_sampling(tok, kw, tgt)
+    o = oracle_for("tiny", sd, rounding="bf16")
+    enc_o = o.encode_audio(audio)
+    okw = oracle_processor_kwargs(sp)
+    sos = [sp.sos_ids[i] for i in range(sp.n_sos)]
+    free = o.generate(enc_o, prompt, prompt.ne(0), [], tgt, sp.ts_start, sp.ts_end, sos, negative_prompt=neg, **okw)
+    forced = torch.zeros((prompt.shape[0], tgt), dtype=torch.long)
+    forced[:, :free.shape[1]] = free
+    want, scores = o.generate(enc_o, prompt, prompt.ne(0), [], tgt, sp.ts_start, sp.ts_end, sos, forced=forced,
+                              return_logits=True, negative_prompt=neg, **okw)
+    out = model.engine.generate(audio, prompt, prompt.ne(0), [], sp, forced=forced, dump_logits=True, negative_prompt=neg)
+    got, lg = out["tokens"], out["logits"].cpu()
+    P = prompt.shape[1]
+    tol = 0.15 * (1 + 2 * (sp.cfg_scale - 1)) / min(sp.temperature, *[sp.cond_temp[j] for j in range(sp.n_cond)])
+    n_cmp = n_bad = n_tie = 0
+    worst = 0.0
+    for i, s_ in enumerate(scores):
+        col = P + i
+        a, b_ = lg[col].clone(), s_.clone()
+        a[:, sp.ts_start] = 0
+        b_[:, sp.ts_start] = 0      # the eos-extra slot (see conftest.assert_scores_close)
+        fin = torch.isfinite(a) & torch.isfinite(b_)
+        worst = max(worst, (a[fin] - b_[fin]).abs().max().item())
+        top2 = s_.topk(2, dim=-1).values
+        gap = top2[:, 0] - top2[:, 1]
+        for b in range(prompt.shape[0]):
+            n_cmp += 1
+            if got[b, col] != want[b, col]:
+                if gap[b] > 2 * tol:
+                    n_bad += 1
+                else:
+                    n_tie += 1
+    print(f"bf16 cfg+types_first teacher-forced: {n_cmp} steps, {n_tie} near-tie flips, {n_bad} real mismatches, "
+          f"worst |dscore| {worst:.3f} (tol {tol:.3f})")
+    assert n_bad == 0
+    assert worst < tol
+    assert n_tie <= 0.1 * n_cmp
 
 
 @pytest.mark.parametrize("seed", [101, 202])

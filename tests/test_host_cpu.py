@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.mh_abi_version() == 1
+    assert lib.mh_abi_version() == 2
     assert lib.mh_last_error() is not None
 
 
@@ -47,7 +47,8 @@ def test_argument_validation_without_gpu():
 def test_struct_layouts_match_header_sizes():
     # pointer arrays of MH_MAX_LAYERS entries, ints packed as in C
     assert C.sizeof(_lib.MhT5Config) == 14 * 4
-    assert C.sizeof(_lib.MhSampling) == 4 * 8 + 16 * 4 + 3 * 4 + 4 + 8  # 4B pad before the uint64 seed
+    base = 4 * 8 + 16 * 4 + 3 * 4 + 4 + 8                                # 4B pad before the uint64 seed
+    assert C.sizeof(_lib.MhSampling) == base + 9 * 4 + 4 + 8            # ABI 2 tail: 9 words, pad, tok_flags
     assert C.sizeof(_lib.MhT5Weights) == 8 * (5 + 6 * 32 + 1 + 5 * 32 + 1 + 4 * 32 + 2)
     assert C.sizeof(_lib.MhDiTWeights) == 8 * (12 + 10 * 32 + 4)
 
@@ -110,9 +111,39 @@ def test_eos_set_and_sampling_translation():
     assert sp.n_sos == 2 and list(sp.sos_ids[:2]) == [1, 3]
     assert sp.lookback_mask_end == ts0 + 12
     assert eos[:2] == [2, 4]
-    for bad in (dict(cfg_scale=2.0), dict(num_beams=2), dict(types_first=True, timing_temperature=0.5)):
-        with pytest.raises(NotImplementedError):
-            build_sampling(tok, bad, 512)
+    assert sp.cfg_scale == 1.0 and sp.n_cond == 0 and sp.lookback_types_first == 0 and sp.host_tok_flags is None
+    with pytest.raises(NotImplementedError):
+        build_sampling(tok, dict(num_beams=2), 512)
+
+
+def test_types_first_sampling_translation():
+    """ConditionalTemperature rules + the LookbackBias(types_first) tables, on the reference's own tokenizer state
+    (tests/golden/tokenizer_types_first.json; rule construction: logit_processors.py:59-73, tables :99-108)."""
+    from conftest import GOLDEN
+    from mapperatorinator_amd.server import (FLAG_COND0, FLAG_LOOKBACK_EOS, FLAG_TIMED, build_sampling,
+                                             get_beat_type_tokens, get_mania_type_tokens, get_scroll_speed_tokens)
+    tok = Tokenizer.from_json(f"{GOLDEN}/tokenizer_types_first.json")
+    assert get_beat_type_tokens(tok) == (2068, 2069, 2070)
+    assert get_mania_type_tokens(tok) == (2058, 2073, 2074)
+    assert get_scroll_speed_tokens(tok) == tuple(range(882, 1883))
+    kw = dict(types_first=True, temperature=0.9, timing_temperature=0.5, mania_column_temperature=0.9,
+              taiko_hit_temperature=0.7, lookback_time=500, cfg_scale=2.0, context_type="map")
+    sp, eos = build_sampling(tok, kw, 64)
+    assert sp.cfg_scale == 2.0 and sp.lookback_types_first == 1
+    # the mania rule is dropped (its temperature equals the default), the others keep their order and offsets
+    assert sp.n_cond == 2 and [round(sp.cond_temp[j], 6) for j in range(2)] == [0.5, 0.7]
+    assert [sp.cond_offset[j] for j in range(2)] == [1, 1]
+    fl = sp.host_tok_flags
+    assert fl.shape == (tok.vocab_size_out,)
+    assert np.nonzero(fl & FLAG_COND0)[0].tolist() == [2068, 2069, 2070]
+    assert np.nonzero(fl & (FLAG_COND0 << 1))[0].tolist() == list(range(882, 1883))
+    assert np.nonzero(fl & FLAG_LOOKBACK_EOS)[0].tolist() == [2, 4]
+    timed = np.nonzero(fl & FLAG_TIMED)[0].tolist()
+    assert 2058 in timed and 2068 in timed and 2079 in timed and 2062 not in timed and 5 not in timed
+    assert sp.lookback_mask_end == sp.ts_start + 50
+    # types_first=False: conditional temperatures are ignored (reference prints a warning and drops them)
+    sp2, _ = build_sampling(tok, dict(kw, types_first=False), 64)
+    assert sp2.n_cond == 0 and sp2.lookback_types_first == 0 and sp2.host_tok_flags is None
 
 
 def test_rel_bias_tables():
