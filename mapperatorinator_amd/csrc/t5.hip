@@ -313,10 +313,11 @@ __global__ __launch_bounds__(256) void dec_sample_kernel(SampleP p) {
         const float prob_eos = e_last / s_last, prob_event = 1.f - prob_eos;
         const float sc = 1.f / ((o_cur / s_cur) * prob_event + prob_eos);
         const float extra = fminf(fmaxf((sc - 1.f) * prob_eos / prob_event, 0.f), 1.f);
+        const float log_norm = logf(s_cur) - logf(sc);
         for (int v = tid; v < p.V; v += 256) {
           float x;
           if (v >= sp.ts_start && v < sp.lookback_mask_end) x = (v == sp.ts_start) ? logf(extra) : -INFINITY;
-          else x = logf(expf(cur[v] - mc) / s_cur * sc);
+          else x = (cur[v] - mc) - log_norm;   // log(softmax(cur)[v] * sc), kept in the log domain (no underflow)
           consider(v, x);
         }
       }

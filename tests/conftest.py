@@ -63,13 +63,17 @@ def oracle_processor_kwargs(sp):
 def assert_scores_close(got, want, tol, eos_extra_slot=None):
     """processed scores: same -inf pattern, finite entries within `tol`.  `eos_extra_slot` (LookbackBias
     types_first): that id holds log(clip((s-1)*p_eos/p_event, 0, 1)) whose argument is a difference of nearly equal
-    fp32 numbers -- compared as a probability instead."""
+    fp32 numbers -- compared as a probability instead; the renormalised scores are log(probability), where torch's
+    exp underflows to -inf below about -87 .. -103 while the log-domain form on the device stays finite: scores under
+    -80 (probability < 2e-35) count as -inf on both sides."""
     import torch
     got, want = got.clone(), want.clone()
     if eos_extra_slot is not None:
         assert (got[:, eos_extra_slot].exp() - want[:, eos_extra_slot].exp()).abs().max().item() < 1e-5
         got[:, eos_extra_slot] = 0
         want[:, eos_extra_slot] = 0
+        got[got < -80] = float("-inf")
+        want[want < -80] = float("-inf")
     fa, fb = torch.isfinite(got), torch.isfinite(want)
     assert torch.equal(fa, fb), (fa != fb).nonzero()[:5]
     err = (got[fa] - want[fa]).abs().max().item()
