@@ -297,6 +297,56 @@ class SpacedDiffusionHIP:
         return x
 
 
+    @torch.no_grad()
+    def p_sample(self, model, x, t, clip_denoised=True, denoised_fn: Optional[Callable] = None, cond_fn=None,
+                 model_kwargs=None, noise=None):
+        """One reverse step, signature of GaussianDiffusion.p_sample (gaussian_diffusion.py:420-467); `t` holds the
+        SPACED loop index of every batch row (all equal), mapped through `timestep_map` like _WrappedModel does
+        (respace.py:127-132).  `noise` injects the gaussian draw (default: torch.randn_like on the device -- drawn
+        even when t == 0, where it is multiplied by 0, as in the reference).  Returns sample / pred_xstart."""
+        dit = getattr(model, "__self__", model)
+        if not isinstance(dit, DiTHIP):
+            raise TypeError("p_sample: model must be DiTHIP.forward_with_cfg")
+        if cond_fn is not None or not clip_denoised:
+            raise NotImplementedError("cond_fn / clip_denoised=False are not used by the pipeline and not built")
+        mk = dict(model_kwargs or {})
+        dev = dit.device
+        x = x.to(dev, torch.float32).contiguous()
+        N, _, T = x.shape
+        ti = t.to("cpu").tolist()
+        if len(set(ti)) != 1:
+            raise NotImplementedError("p_sample: one loop index per call")
+        i = int(ti[0])
+        c = mk["c"].to(dev, torch.float32).contiguous()
+        y = mk["y"].to(dev, torch.float32).contiguous()
+        band = dit.band_from_mask(mk.get("attn_mask"), T)
+        noise = (torch.randn_like(x) if noise is None else noise.to(dev, torch.float32)).contiguous()
+        coef = self.coef_table()[i].to(dev).contiguous()
+        t32 = torch.full((N,), self.timestep_map[i], dtype=torch.int32, device=dev)
+        mout = torch.empty((N, 4, T), dtype=torch.float32, device=dev)
+        out, x0 = torch.empty_like(x), torch.empty_like(x)
+        ws = dit.workspace(N, T)
+        s = torch.cuda.current_stream(dev).cuda_stream
+        lib = dit.lib
+        _lib.check(lib.mh_dit_forward_cfg(C.byref(dit.cfg), C.byref(dit.w), x.data_ptr(), t32.data_ptr(), c.data_ptr(),
+                                          y.data_ptr(), float(mk.get("cfg_scale", 1.0)), band, N, T, mout.data_ptr(),
+                                          ws.data_ptr(), ws.numel(), s), "mh_dit_forward_cfg")
+        if denoised_fn is None or isinstance(denoised_fn, InpaintSpec):
+            imask = iref = None
+            if denoised_fn is not None:
+                imask = denoised_fn.mask.to(dev).to(torch.uint8).contiguous()
+                iref = denoised_fn.ref.to(dev, torch.float32).contiguous()
+            _lib.check(lib.mh_ddpm_step(mout.data_ptr(), x.data_ptr(), noise.data_ptr(), coef.data_ptr(), _lib.ptr(imask),
+                                        _lib.ptr(iref), None, 0, N, T, out.data_ptr(), x0.data_ptr(), s), "mh_ddpm_step")
+        else:
+            _lib.check(lib.mh_ddpm_step(mout.data_ptr(), x.data_ptr(), noise.data_ptr(), coef.data_ptr(), None, None,
+                                        None, 1, N, T, out.data_ptr(), x0.data_ptr(), s), "mh_ddpm_step")
+            x0n = denoised_fn(x0.clone()).to(dev, torch.float32).contiguous()
+            _lib.check(lib.mh_ddpm_step(mout.data_ptr(), x.data_ptr(), noise.data_ptr(), coef.data_ptr(), None, None,
+                                        x0n.data_ptr(), 0, N, T, out.data_ptr(), x0.data_ptr(), s), "mh_ddpm_step")
+        return {"sample": out, "pred_xstart": x0}
+
+
 def create_diffusion(timestep_respacing, noise_schedule="linear", use_kl=False, sigma_small=False,
                      predict_xstart=False, learn_sigma=True, rescale_learned_sigmas=False, diffusion_steps=1000,
                      use_l1=False) -> SpacedDiffusionHIP:

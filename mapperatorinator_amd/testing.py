@@ -139,3 +139,20 @@ def boost_timed_rows(sd: dict, tok, gain: float) -> dict:
         if _has(tok.event_start, name):
             w[_ev(tok.event_start, name):_ev(tok.event_end, name)] *= gain
     return sd
+
+
+def synthetic_hit_objects(T: int, seed: int, span_ms: float = 60000.0):
+    """Hit-object points for the diffusion pipeline cases: sorted times, playfield positions, distances, type rows."""
+    rng = np.random.default_rng(seed)
+    times = np.sort(rng.uniform(0, span_ms, T)).astype(np.float32)
+    x = rng.uniform(0, 512, T).astype(np.float32)
+    y = rng.uniform(0, 384, T).astype(np.float32)
+    dist = rng.uniform(0, 200, T).astype(np.float32)
+    typ = rng.integers(0, 16, T)
+    return x, y, times, dist, typ
+
+
+def pipeline_windows(seq_len: int, max_seq_len: int, overlap_buffer: int):
+    """(start, end) of every diffusion window (reference diffusion_pipeline.py:277-278)."""
+    return [(i, min(i + max_seq_len, seq_len))
+            for i in range(0, seq_len - overlap_buffer * 2, max_seq_len - overlap_buffer * 2)]

@@ -157,6 +157,47 @@ def dit_case(name, preset, T, wseed, iseed, cfg_scale):
     print(name, "eps scale", eps[50].abs().max().item(), "sample range", full.min().item(), full.max().item())
 
 
+PIPE_CASE = dict(preset="DiT-XS", T=300, weight_seed=31, point_seed=7, noise_seed=11, classes=[3, 40, 250],
+                 null_classes=[3, 299],
+                 knobs=dict(timesteps=[12, 0, 0, 0, 0, 0, 0, 0, 0, 0], seq_len=32, max_seq_len=160, overlap_buffer=16,
+                            cfg_scale=1.5, refine_iters=2))
+
+
+def pipeline_case():
+    """Reference `DiffisionPipeline.generate` (window loop, in-paint masks with start/end time, refine steps) on
+    synthetic hit objects, gaussian draws injected from a numpy stream (one draw per p_sample call, in call order)."""
+    from mapperatorinator_amd.diffusion_pipeline import points_to_sequence
+    from mapperatorinator_amd.testing import pipeline_windows, synthetic_hit_objects
+    c = PIPE_CASE
+    depth, hidden, heads = DIT_PRESETS[c["preset"]]
+    sd = random_dit_state_dict(depth, hidden, seed=c["weight_seed"])
+    rh.ref_shims.install()
+    from osu_diffusion.utils.models import DiT
+    ref = DiT(context_size=272, hidden_size=hidden, depth=depth, num_heads=heads, class_size=300).eval()
+    ref.load_state_dict(sd, strict=True)
+    x, y, times, dist, typ = synthetic_hit_objects(c["T"], c["point_seed"])
+    seq_x, seq_o, seq_c = points_to_sequence(x, y, times, dist, typ)
+    # the conditioning assembly itself against the reference's function
+    from osu_diffusion import timestep_embedding as ref_te
+    assert torch.equal(seq_c[:128], ref_te(seq_o * 0.1, 128).T) and torch.equal(seq_c[128:256], ref_te(torch.from_numpy(dist), 128).T)
+    cv, ucv = torch.zeros(300), torch.zeros(300)
+    cv[c["classes"]] = 1
+    ucv[c["null_classes"]] = 1
+    k = c["knobs"]
+    start_time, end_time = float(times[20]), float(times[280])
+    rng = np.random.default_rng(c["noise_seed"])
+    noise = []
+    for (a, b) in pipeline_windows(c["T"], k["max_seq_len"], k["overlap_buffer"]):
+        for _ in range(k["timesteps"][0] + k["refine_iters"]):
+            noise.append(torch.from_numpy(rng.standard_normal((2, 2, b - a)).astype(np.float32)))
+    pos = rh.reference_pipeline_positions(ref, seq_x, seq_o, seq_c, cv, ucv, noise, start_time=start_time,
+                                          end_time=end_time, **k)
+    np.savez_compressed(os.path.join(OUT, "dit_pipeline.npz"), case=json.dumps(c), start_time=start_time,
+                        end_time=end_time, positions=pos.numpy(), seq_c_slice=seq_c[:, ::37].numpy())
+    print("dit_pipeline positions", tuple(pos.shape), "range", pos.min().item(), pos.max().item(),
+          "moved", (pos[0] - torch.stack([torch.from_numpy(x), torch.from_numpy(y)])).abs().mean().item())
+
+
 def mel_case():
     a = synthetic_audio(2, 16000, seed=9)
     m = omel.mel_spectrogram(a)
@@ -173,6 +214,7 @@ def main():
     types_first_case()
     dit_case("dit_xs", "DiT-XS", 96, 21, 5, 1.5)
     dit_case("dit_s", "DiT-S", 160, 1, 2, 2.0)
+    pipeline_case()
 
 
 if __name__ == "__main__":

@@ -208,3 +208,47 @@ def reference_ddpm(model, diffusion, z, c, y, cfg_scale, attn_mask, noise_list):
                                   key_padding_mask=None), device=z.device)
     finally:
         gd.th.randn_like = orig
+
+
+def reference_pipeline_positions(model, seq_x, seq_o, seq_c, class_vector, unk_class_vector, noise_list, *, timesteps,
+                                 seq_len, max_seq_len, overlap_buffer, cfg_scale, refine_iters=0, start_time=None,
+                                 end_time=None, diffusion_steps=1000, noise_schedule="squaredcos_cap_v2"):
+    """The reference's own `DiffisionPipeline.generate` (diffusion_pipeline.py:111-287) driven from the tensors that
+    `events_to_sequence` returns: the object is built without its constructor, `events_to_sequence`,
+    `get_class_vector` and `events_with_pos` are replaced by stand-ins that hand the given tensors through (Event
+    grouping needs the `slider` package, absent here), everything in between is unmodified reference code.  The
+    gaussian draws are popped from `noise_list` in call order (one per p_sample call, refine steps included)."""
+    ref_shims.install()
+    import diffusion_pipeline as dp
+    from osu_diffusion.utils.diffusion import gaussian_diffusion as gd
+    pipe = object.__new__(dp.DiffisionPipeline)
+    pipe.device = "cpu"
+    pipe.model = model
+    pipe.tokenizer = None
+    pipe.refine_model = model if refine_iters > 0 else None
+    pipe.diffusion_steps, pipe.noise_schedule = diffusion_steps, noise_schedule
+    pipe.seq_len, pipe.max_seq_len, pipe.overlap_buffer = seq_len, max_seq_len, overlap_buffer
+    pipe.timesteps, pipe.cfg_scale, pipe.refine_iters = list(timesteps), cfg_scale, refine_iters
+    pipe.random_init, pipe.types_first, pipe.pad_sequence = False, False, False
+    pipe.start_time, pipe.end_time = start_time, end_time
+    calls = []
+
+    def get_class_vector(config):
+        calls.append(1)
+        return (class_vector if len(calls) == 1 else unk_class_vector).clone()
+
+    pipe.events_to_sequence = lambda events, timing, sm: (seq_x, seq_o, seq_c, seq_x.shape[1], {}, [])
+    pipe.get_class_vector = get_class_vector
+    pipe.events_with_pos = lambda events, positions, seq_indices: positions
+
+    class _Cfg:  # the fields `generate` reads (diffusion_pipeline.py:151-155)
+        slider_multiplier, difficulty, negative_descriptors, circle_size = 1.4, None, None, None
+
+    it = iter(noise_list)
+    orig = gd.th.randn_like
+    gd.th.randn_like = lambda x, *a, **k: next(it).to(x)
+    try:
+        with torch.no_grad():
+            return pipe.generate([], _Cfg(), None)
+    finally:
+        gd.th.randn_like = orig

@@ -143,3 +143,48 @@ def test_dit_b_full_size_properties():
     b = dit.forward_with_cfg(z2.cuda(), t.cuda(), c.cuda(), y.cuda(), 3.0, attn_mask=mask).cpu()
     assert torch.equal(a[:, :, :600], b[:, :, :600]), "band mask leaked information"
     assert not torch.equal(a[:, :, 990:], b[:, :, 990:])
+
+
+def test_window_pipeline_matches_reference_golden():
+    """Row a14: the reference's `DiffisionPipeline.generate` between `events_to_sequence` and `events_with_pos`
+    (3 overlapping windows, in-paint masks incl. start / end time, 12 DDPM steps + 2 refine steps per window, CFG)
+    vs `DiffusionPipelineHIP.generate_positions` with the same injected gaussian draws.  fp32 DiT, chaotic
+    amplification over 14 steps: positions within 0.5 px on the 512 x 384 playfield; frozen points bit-exact."""
+    import json
+
+    from mapperatorinator_amd.diffusion_pipeline import DiffusionPipelineHIP, points_to_sequence
+    from mapperatorinator_amd.dit import DiTHIP
+    from mapperatorinator_amd.testing import DIT_PRESETS, random_dit_state_dict, synthetic_hit_objects
+    g = np.load(f"{GOLDEN}/dit_pipeline.npz")
+    c = json.loads(str(g["case"]))
+    depth, hidden, heads = DIT_PRESETS[c["preset"]]
+    dit = DiTHIP(random_dit_state_dict(depth, hidden, seed=c["weight_seed"]), depth, hidden, heads, device="cuda")
+    x, y, times, dist, typ = synthetic_hit_objects(c["T"], c["point_seed"])
+    seq_x, seq_o, seq_c = points_to_sequence(x, y, times, dist, typ)
+    cv, ucv = torch.zeros(300), torch.zeros(300)
+    cv[c["classes"]] = 1
+    ucv[c["null_classes"]] = 1
+    k = c["knobs"]
+    pipe = DiffusionPipelineHIP(dit, timesteps=k["timesteps"], seq_len=k["seq_len"], max_seq_len=k["max_seq_len"],
+                                overlap_buffer=k["overlap_buffer"], cfg_scale=k["cfg_scale"], refine_model=dit,
+                                refine_iters=k["refine_iters"], start_time=float(g["start_time"]),
+                                end_time=float(g["end_time"]))
+    rng = np.random.default_rng(c["noise_seed"])
+
+    def noise_source(n, shape):
+        return torch.from_numpy(np.stack([rng.standard_normal(shape).astype(np.float32) for _ in range(n)]))
+
+    pos = pipe.generate_positions(seq_x, seq_o, seq_c, cv, ucv, noise_source=noise_source)
+    assert pos.shape == (1, 2, c["T"]) and pos.device.type == "cpu"
+    want = torch.from_numpy(g["positions"])
+    err = (pos[0] - want).abs()
+    print("pipeline positions: max err px", err.max().item(), "mean", err.mean().item())
+    assert err.max().item() < 0.5
+    # points outside [start_time, end_time] are never generated: they keep the given positions exactly
+    given = torch.stack([torch.from_numpy(x), torch.from_numpy(y)])
+    frozen = (torch.from_numpy(times) < float(g["start_time"])) | (torch.from_numpy(times) > float(g["end_time"]))
+    assert int(frozen.sum()) >= 30
+    assert (pos[0][:, frozen] - given[:, frozen]).abs().max().item() < 1e-3
+    assert (want[:, frozen] - given[:, frozen]).abs().max().item() < 1e-3
+    # and the generated ones moved
+    assert (pos[0][:, ~frozen] - given[:, ~frozen]).abs().mean().item() > 10

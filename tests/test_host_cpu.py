@@ -190,3 +190,33 @@ def test_mel_host_tables():
     assert m.n_frames(160000) == 1251
     with pytest.raises(NotImplementedError):
         MelSpectrogram(implementation="torchaudio")
+
+
+def test_diffusion_pipeline_host_glue():
+    """points_to_sequence / band mask / window plan of the diffusion stage (diffusion_pipeline.py:145-148,277-278,
+    361-387) -- conditioning rows pinned by the reference golden (which asserted equality with the reference's
+    `timestep_embedding` when it was generated)."""
+    import json
+
+    from conftest import GOLDEN
+    from mapperatorinator_amd.diffusion_pipeline import band_mask, points_to_sequence, repeat_type
+    from mapperatorinator_amd.testing import pipeline_windows, synthetic_hit_objects
+    g = np.load(f"{GOLDEN}/dit_pipeline.npz")
+    c = json.loads(str(g["case"]))
+    x, y, times, dist, typ = synthetic_hit_objects(c["T"], c["point_seed"])
+    seq_x, seq_o, seq_c = points_to_sequence(x, y, times, dist, typ)
+    assert seq_x.shape == (2, c["T"]) and seq_c.shape == (272, c["T"])
+    assert np.array_equal(seq_c[:, ::37].numpy(), g["seq_c_slice"])
+    assert torch.equal(seq_c[256:].sum(0), torch.ones(c["T"])) and torch.equal(seq_c[256:].argmax(0), torch.as_tensor(typ))
+    assert float(seq_x.min()) >= -1 and float(seq_x.max()) <= 1
+    # the band mask, column by column as the reference builds it
+    T, sl = 50, 8
+    ref = torch.full((T, T), True)
+    for i in range(T):
+        ref[max(0, i - sl): min(T, i + sl), i] = False
+    assert torch.equal(band_mask(T, sl), ref)
+    assert pipeline_windows(300, 160, 16) == [(0, 160), (128, 288), (256, 300)]
+    assert pipeline_windows(100, 1024, 128) == []      # shorter than two buffers: the reference loop does not run
+    assert [repeat_type(r) for r in (1, 2, 3, 4, 5, 6, 7)] == [0, 1, 2, 3, 4, 3, 4]
+    with pytest.raises(ValueError):
+        points_to_sequence(x, y, times, dist, typ + 16)
