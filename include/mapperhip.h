@@ -248,6 +248,15 @@ int mh_t5_generate(const MhT5Config* cfg, const MhT5Weights* w, const void* cros
                    const int32_t* forced, void* workspace, int64_t workspace_bytes, int poll_every,
                    void* stream);
 
+/* Teacher-forced decoder forward over whole sequences: `Mapperatorinator.forward` with `encoder_outputs` given
+ * (seam B2, osuT5/osuT5/model/modeling_mapperatorinator.py:174-228; used by server.py:160-181 `model_forward`).
+ *   ids  int32 [B, T] decoder_input_ids, mask uint8 [B, T] decoder_attention_mask (NULL = ones), T <= tgt_len
+ *   logits fp32 [B, T, vocab_out]: lm_head(final RMSNorm(decoder(ids)))  -- no processors, no sampling */
+int64_t mh_t5_forward_workspace_bytes(const MhT5Config* cfg, int B, int T);
+int mh_t5_decoder_forward(const MhT5Config* cfg, const MhT5Weights* w, const void* cross_kv, int B,
+                          const int32_t* ids, const uint8_t* mask, int T, float* logits, void* workspace,
+                          int64_t workspace_bytes, void* stream);
+
 /* Measurement hook (bench.py `roofline`): launches the dominant decode kernel -- cross-attention over
  * the encoder keys, algorithmic bytes per launch = B*H*src_len*64*2*sizeof(elem) -- `reps` times
  * back to back between two HIP events on `stream`, cycling through the decoder layers as a decode

@@ -681,8 +681,9 @@ int64_t prefill_layout(const MhT5Config* c, int B, int np_max, void* base, int64
 // (HF prefill: SURVEY.md appendix A.1).  Position P-1 is left to the per-token loop, which also produces the
 // first sampled token.  Left-pad keys are masked, left-pad query rows produce unused garbage, as in HF.
 int prefill_prompt(const MhT5Config* c, const MhT5Weights* w, const void* cross_kv, int B, int kvB, const int32_t* prompt,
-                   const uint8_t* prompt_mask, int P, void* self_k, void* self_v, const PrefillBuf& pb, hipStream_t s) {
-  const int np = P - 1, rows = B * np;
+                   const uint8_t* prompt_mask, int P, int np, void* self_k, void* self_v, const PrefillBuf& pb, hipStream_t s) {
+  // P = row stride of `prompt` / `prompt_mask`, np <= P = positions that go through the stack
+  const int rows = B * np;
   const int d = c->d_model, H = c->n_heads, inner = H * 64, dff = c->d_ff, L = c->src_len, tgt = c->tgt_len;
   const int es = es_of(c->dtype);
   const int np_pad = round_up(np, 64);
@@ -866,7 +867,7 @@ extern "C" int mh_t5_generate(const MhT5Config* c, const MhT5Weights* w, const v
       prefill_layout(c, B, P - 1, (char*)workspace + used_dec, workspace_bytes - used_dec, &pb);
       MH_REQUIRE(used_dec + prefill_layout(c, B, P - 1, nullptr, 0, nullptr) <= workspace_bytes,
                  "mh_t5_generate: workspace too small for the prompt prefill");
-      MH_TRY(prefill_prompt(c, w, cross_kv, B, kvB, prompt, prompt_mask, P, all.self_k, all.self_v, pb, s));
+      MH_TRY(prefill_prompt(c, w, cross_kv, B, kvB, prompt, prompt_mask, P, P - 1, all.self_k, all.self_v, pb, s));
       start_pos = P - 1;
     }
   }
@@ -972,6 +973,41 @@ extern "C" int mh_t5_generate(const MhT5Config* c, const MhT5Weights* w, const v
     if (graphs[ci]) (void)hipGraphDestroy(graphs[ci]);
   }
   return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Teacher-forced decoder forward over whole sequences: the `Mapperatorinator.forward` seam (B2,
+// modeling_mapperatorinator.py:174-228) with `encoder_outputs` given -- every position of `ids` goes through the
+// decoder stack at once (the batched prefill path: MFMA GEMMs + flash attention, causal + key mask), then the
+// final RMSNorm and lm_head.  logits fp32 [B, T, V].
+extern "C" int64_t mh_t5_forward_workspace_bytes(const MhT5Config* c, int B, int T) {
+  if (!c || B <= 0 || T <= 0) return -1;
+  const int64_t es = es_of(c->dtype);
+  return mh::prefill_layout(c, B, T, nullptr, 0, nullptr) +
+         2 * mh::align256((int64_t)c->n_dec_layers * B * c->n_heads * 64 * c->tgt_len * es);
+}
+
+extern "C" int mh_t5_decoder_forward(const MhT5Config* c, const MhT5Weights* w, const void* cross_kv, int B,
+                                     const int32_t* ids, const uint8_t* mask, int T, float* logits, void* workspace,
+                                     int64_t workspace_bytes, void* stream) {
+  MH_TRY(check_cfg(c, "mh_t5_decoder_forward"));
+  MH_REQUIRE(w && cross_kv && ids && logits && workspace, "mh_t5_decoder_forward: null argument");
+  MH_REQUIRE(B > 0 && T >= 1 && T <= c->tgt_len, "mh_t5_decoder_forward: T=%d not in [1, tgt_len=%d]", T, c->tgt_len);
+  MH_REQUIRE(workspace_bytes >= mh_t5_forward_workspace_bytes(c, B, T), "mh_t5_decoder_forward: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  const int es = es_of(c->dtype);
+  const int64_t cache = align256((int64_t)c->n_dec_layers * B * c->n_heads * 64 * c->tgt_len * es);
+  char* self_k = (char*)workspace;
+  char* self_v = self_k + cache;
+  PrefillBuf pb;
+  prefill_layout(c, B, T, self_v + cache, workspace_bytes - 2 * cache, &pb);
+  MH_TRY(prefill_prompt(c, w, cross_kv, B, B, ids, mask, T, T, self_k, self_v, pb, s));
+  const int rows = B * T, d = c->d_model;
+  MH_TRY(rmsnorm(pb.h, d, w->dec_final_ln, pb.n, d, rows, d, c->eps, c->dtype, s));
+  MhGemm g{};
+  g.A = pb.n; g.lda = d; g.W = w->lm_head; g.ldw = d; g.C = logits; g.ldc = c->vocab_out; g.M = rows; g.N = c->vocab_out;
+  g.K = d; g.dtype = c->dtype; g.epilogue = MH_EPI_STORE_F32;
+  return gemm(g, s);
 }
 
 // ------------------------------------------------------------------------------------------------

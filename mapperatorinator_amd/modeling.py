@@ -82,3 +82,68 @@ class MapperatorinatorHIP:
 
     def to(self, *a, **k):
         return self
+
+    # ---- B2: the two calls the reference makes on the model object -----------------------------------------
+    def _cross_kv(self, frames, encoder_outputs):
+        eng = self.engine
+        if encoder_outputs is not None:
+            enc = getattr(encoder_outputs, "last_hidden_state", encoder_outputs)
+            if isinstance(enc, (tuple, list)):
+                enc = enc[0]
+            return eng.cross_kv(enc.to(eng.device, eng.dtype).contiguous())
+        if frames is None:
+            raise ValueError("either frames (raw audio, (B, samples)) or encoder_outputs is required")
+        return eng.cross_kv(eng.encode_mel(eng.mel(frames.to(eng.device, torch.float32))))
+
+    @torch.no_grad()
+    def forward(self, frames=None, decoder_input_ids=None, decoder_attention_mask=None, encoder_outputs=None, **unused):
+        """Teacher-forced logits (B, T, vocab) fp32 -- `Mapperatorinator.forward` (modeling_mapperatorinator.py:174-228)
+        as `model_forward` uses it (server.py:160-181).  `frames` is raw audio, as in the reference (the spectrogram is
+        part of the model, :175).  Returns an object with `.logits` (+ `.encoder_last_hidden_state=None`)."""
+        for k in ("labels", "past_key_values", "decoder_inputs_embeds", "inputs_embeds"):
+            if unused.get(k) is not None:
+                raise NotImplementedError(f"forward({k}=...) is not part of the inference seam")
+        if decoder_input_ids is None:
+            raise ValueError("decoder_input_ids is required")
+        eng = self.engine
+        ids = decoder_input_ids.to(eng.device, torch.int32).contiguous()
+        mask = (decoder_attention_mask.to(eng.device).to(torch.uint8).contiguous()
+                if decoder_attention_mask is not None else None)
+        eng._enter()
+        with torch.cuda.stream(eng.stream):
+            logits = eng.decoder_forward(self._cross_kv(frames, encoder_outputs), ids, mask)
+        eng._leave()
+        return types.SimpleNamespace(logits=logits, encoder_last_hidden_state=None, past_key_values=None, loss=None)
+
+    __call__ = forward
+
+    @torch.no_grad()
+    def generate(self, inputs=None, frames=None, decoder_input_ids=None, decoder_attention_mask=None,
+                 negative_prompt=None, negative_prompt_attention_mask=None, encoder_outputs=None, logits_processor=None,
+                 eos_token_id=None, do_sample=False, num_beams=1, top_k=0, top_p=1.0, max_length=None,
+                 pad_token_id=None, seed=None, **unused):
+        """`model.generate(**model_kwargs, **generate_kwargs, logits_processor=..., eos_token_id=...)` exactly as the
+        reference's `model_generate` calls it (server.py:143-151): the processor OBJECTS are translated
+        (server.sampling_from_processors), `past_key_values` / `use_cache` are accepted and unused (the engine owns
+        its caches).  Returns int64 (B, prompt + new) on the model's device, pad_token_id after each row's EOS."""
+        from .server import sampling_from_processors
+        if num_beams != 1:
+            raise NotImplementedError("beam search is not on the HIP path (num_beams must be 1)")
+        audio = inputs if inputs is not None else frames
+        if decoder_input_ids is None:
+            raise ValueError("decoder_input_ids is required (the reference always passes the prompt)")
+        if encoder_outputs is not None:
+            raise NotImplementedError("generate(encoder_outputs=...) : pass the audio, the encoder is part of the hot path")
+        cfgm = self.config
+        max_length = int(max_length or cfgm.max_target_positions)
+        pad = cfgm.pad_token_id if pad_token_id is None else pad_token_id
+        sp = sampling_from_processors(logits_processor, cfgm.vocab_size, do_sample=do_sample, top_k=top_k, top_p=top_p,
+                                      max_length=max_length, pad_token_id=pad, seed=seed)
+        eos = eos_token_id if eos_token_id is not None else [cfgm.eos_token_id]
+        eos = [eos] if isinstance(eos, int) else list(eos)
+        if sp.cfg_scale > 1.0 and negative_prompt is None:
+            raise ValueError("guidance needs negative_prompt (modeling_mapperatorinator.py:243-254)")
+        out = self.engine.generate(audio, decoder_input_ids, decoder_attention_mask, eos, sp,
+                                   negative_prompt=negative_prompt if sp.cfg_scale > 1.0 else None,
+                                   negative_mask=negative_prompt_attention_mask)
+        return out["tokens"].to(self.device)

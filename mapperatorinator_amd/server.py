@@ -187,6 +187,73 @@ def build_sampling(tokenizer, generate_kwargs: dict, max_target_positions: int):
     return sp, eos
 
 
+def sampling_from_processors(processors, vocab_size_out: int, *, do_sample=False, top_k=0, top_p=1.0, max_length: int,
+                             pad_token_id: int = 0, seed=None):
+    """The reference's live processor OBJECTS (the `logits_processor=` list that server.py:106-134 builds and hands
+    to `model.generate`) -> MhSampling.  Recognised by class name so that both the reference's classes and HF's
+    are accepted without importing either; anything else is refused -- a python callable cannot run inside the
+    captured decode step."""
+    sp = Sampling()
+    sp.do_sample, sp.top_k, sp.top_p = int(bool(do_sample)), int(top_k or 0), float(1.0 if top_p is None else top_p)
+    sp.temperature, sp.cfg_scale, sp.pad_id, sp.max_length = 1.0, 1.0, int(pad_token_id or 0), int(max_length)
+    sp.seed = int(torch.initial_seed() if seed is None else seed) & 0xFFFFFFFFFFFFFFFF
+    flags = np.zeros(int(vocab_size_out), dtype=np.uint8)
+    need_flags = False
+    order = {"ClassifierFreeGuidanceLogitsProcessor": 0, "MonotonicTimeShiftLogitsProcessor": 1, "TimeshiftBias": 2,
+             "TemperatureLogitsWarper": 3, "ConditionalTemperatureLogitsWarper": 3, "LookbackBiasLogitsWarper": 4}
+    last = -1
+    bias_range = None
+    for proc in list(processors or []):
+        name = type(proc).__name__
+        if name not in order:
+            raise NotImplementedError(f"logits processor {name} is not one of the reference's (server.py:106-134)")
+        if order[name] <= last:
+            raise NotImplementedError("processors must come in the reference's order (server.py:106-134)")
+        last = order[name]
+        if name == "ClassifierFreeGuidanceLogitsProcessor":
+            sp.cfg_scale = float(proc.guidance_scale)
+        elif name == "MonotonicTimeShiftLogitsProcessor":
+            sp.ts_start, sp.ts_end = int(proc.time_shift_start), int(proc.time_shift_end)
+            sos = [int(v) for v in torch.as_tensor(proc.sos_ids).tolist()]
+            if len(sos) > 16:
+                raise NotImplementedError("more than 16 SOS-type ids")
+            sp.n_sos = len(sos)
+            for i, v in enumerate(sos):
+                sp.sos_ids[i] = v
+        elif name == "TimeshiftBias":
+            sp.timeshift_bias = float(proc.timeshift_bias)
+            bias_range = (int(proc.time_range.start), int(proc.time_range.stop))
+        elif name == "TemperatureLogitsWarper":
+            sp.temperature = float(proc.temperature)
+        elif name == "ConditionalTemperatureLogitsWarper":
+            sp.temperature = float(proc.temperature)
+            if len(proc.conditionals) > 3:
+                raise NotImplementedError("more than 3 conditional temperature rules")
+            sp.n_cond = len(proc.conditionals)
+            for j, (t, ids, off) in enumerate(proc.conditionals):
+                sp.cond_temp[j], sp.cond_offset[j] = float(t), int(off)
+                flags[np.asarray(list(ids), dtype=np.int64)] |= FLAG_COND0 << j
+                need_flags = True
+        elif name == "LookbackBiasLogitsWarper":
+            start, end = int(proc.lookback_start), int(proc.lookback_end)
+            sp.lookback_mask_end = end
+            if sp.ts_end > sp.ts_start and start != sp.ts_start:
+                raise NotImplementedError("lookback range must start at the first TIME_SHIFT id")
+            if sp.ts_end <= sp.ts_start:
+                raise NotImplementedError("LookbackBiasLogitsWarper without MonotonicTimeShiftLogitsProcessor")
+            if proc.types_first:
+                sp.lookback_types_first = 1
+                flags[torch.as_tensor(proc.eos_ids).cpu().numpy().astype(np.int64)] |= FLAG_LOOKBACK_EOS
+                flags[torch.as_tensor(proc.timed_tokens).cpu().numpy().astype(np.int64)] |= FLAG_TIMED
+                need_flags = True
+    if bias_range is not None and bias_range != (sp.ts_start, sp.ts_end):
+        raise NotImplementedError("TimeshiftBias over a range other than the TIME_SHIFT ids")
+    if sp.cfg_scale <= 1.0:
+        sp.cfg_scale = 1.0
+    sp.host_tok_flags = flags if need_flags else None
+    return sp
+
+
 @torch.no_grad()
 def model_generate(model, tokenizer, model_kwargs, generate_kwargs):
     """See module docstring.  `model_kwargs['inputs']`: raw audio float32 (B, Ns)."""

@@ -241,6 +241,20 @@ class T5Engine:
         self._leave()
         return out
 
+    def decoder_forward(self, cross_kv: torch.Tensor, ids: torch.Tensor, mask: Optional[torch.Tensor] = None):
+        """Teacher-forced logits of every position: ids int32 (B, T) on the device -> fp32 (B, T, vocab_out)."""
+        p = self.packed
+        B, T = ids.shape
+        if cross_kv.shape[2] != B:
+            raise ValueError(f"cross_kv holds {cross_kv.shape[2]} rows for {B} sequences")
+        need = self.lib.mh_t5_forward_workspace_bytes(C.byref(p.cfg), B, T)
+        ws = self._workspace("fwd", need)
+        logits = torch.empty((B, T, p.vocab_out), dtype=torch.float32, device=self.device)
+        rc = self.lib.mh_t5_decoder_forward(C.byref(p.cfg), C.byref(p.w), cross_kv.data_ptr(), B, ids.data_ptr(),
+                                            _lib.ptr(mask), T, logits.data_ptr(), ws.data_ptr(), ws.numel(), self._s())
+        _lib.check(rc, "mh_t5_decoder_forward")
+        return logits
+
     def decode(self, cross_kv: torch.Tensor, prompt: torch.Tensor, prompt_mask: Optional[torch.Tensor],
                eos_table: torch.Tensor, sampling: _lib.MhSampling, forced: Optional[torch.Tensor] = None,
                dump_logits: bool = False, poll_every: int = 16):

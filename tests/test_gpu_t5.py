@@ -363,3 +363,54 @@ def test_long_left_padded_prompts_batched_prefill(dtype, monkeypatch):
         assert torch.equal(fast, want)
     else:
         assert agree > 0.9      # bf16: the two paths round differently (flash vs single-query softmax)
+
+
+def test_model_object_generate_and_forward_seam_b2():
+    """B2: `model.generate(**model_kwargs, **generate_kwargs, logits_processor=[...], eos_token_id=[...])` as the
+    reference's model_generate calls it == our model_generate; `model.forward(frames=, decoder_input_ids=, ...)`
+    teacher-forced logits == the oracle's step-by-step logits (fp32, 5e-4) incl. left-padded prompts."""
+    from mapperatorinator_amd.server import get_eos_token_id, model_generate
+    g, size, tok, sd, audio, src, tgt = golden_case("t5_tiny")
+    model = build(size, tok, sd, src, tgt, torch.float32)
+    prompt = torch.from_numpy(g["prompt"])
+    ts0, ts1 = ts_range(tok)
+
+    class MonotonicTimeShiftLogitsProcessor:      # recognised by class name, like the reference's objects
+        time_shift_start, time_shift_end, sos_ids = ts0, ts1, torch.tensor([tok.sos_id])
+
+    class TimeshiftBias:
+        timeshift_bias, time_range = 0.35, slice(ts0, ts1)
+
+    class TemperatureLogitsWarper:
+        temperature = 0.7
+
+    eos = get_eos_token_id(tok, lookahead_time=3000, context_type="map")
+    ids = model.generate(inputs=audio, decoder_input_ids=prompt, decoder_attention_mask=prompt.ne(0), do_sample=False,
+                         num_beams=1, top_p=1.0, top_k=0, max_length=tgt, pad_token_id=0, use_cache=True,
+                         past_key_values=object(), eos_token_id=eos,
+                         logits_processor=[MonotonicTimeShiftLogitsProcessor(), TimeshiftBias(), TemperatureLogitsWarper()])
+    assert ids.device.type == "cuda" and ids.dtype == torch.int64
+    assert np.array_equal(ids.cpu().numpy(), g["ids_processors"])       # = the reference's own output for these kwargs
+    with pytest.raises(NotImplementedError):
+        model.generate(inputs=audio, decoder_input_ids=prompt, num_beams=2)
+
+    # forward: teacher-forced on the reference's greedy ids
+    seq = torch.from_numpy(g["ids"])[:, :-1]
+    mask = torch.ones_like(seq, dtype=torch.bool)
+    mask[:, :prompt.shape[1]] = prompt.ne(0)
+    out = model.forward(frames=audio, decoder_input_ids=seq, decoder_attention_mask=mask)
+    lg = out.logits.cpu()
+    assert lg.shape == (seq.shape[0], seq.shape[1], tok.vocab_size_out)
+    o = oracle_for(size, sd)
+    enc_o = o.encode_audio(audio)
+    ckv = o.cross_kv(enc_o)
+    B, T = seq.shape
+    cache = [(torch.zeros(B, o.H, T, 64), torch.zeros(B, o.H, T, 64)) for _ in range(o.nd)]
+    worst = 0.0
+    valid = mask.clone()
+    for pos in range(T):
+        want = o.decoder_step(seq[:, pos], pos, cache, ckv, mask)
+        rows = valid[:, pos]            # left-pad query rows are unused garbage on both sides
+        worst = max(worst, (lg[rows, pos] - want[rows]).abs().max().item())
+    print("forward logits worst abs err", worst)
+    assert worst < 5e-4
