@@ -20,6 +20,14 @@ def main(db, out=None):
              "kernel | calls | total_ms | avg_us | min_us | max_us | pct | vgpr | agpr | lds | grid_x"]
     for n, c, t, a, mn, mx, vg, ag, lds, gx in rows:
         lines.append(f"{short(n)} | {c} | {t / 1e6:.3f} | {a / 1e3:.2f} | {mn / 1e3:.2f} | {mx / 1e3:.2f} | {100 * t / total:.1f} | {vg} | {ag} | {lds} | {gx}")
+    # the dominant kernel split by stream: bench.py's roofline probe launches it back to back on the engine's stream,
+    # the decode step launches it from the chain streams
+    if rows:
+        top = rows[0][0]
+        lines.append(f"# {short(top)} by stream (stream_id | calls | avg_us | min_us | max_us)")
+        for sid, c, a, mn, mx in con.execute("select stream_id, count(*), avg(duration), min(duration), max(duration) from kernels "
+                                             "where name = ? group by stream_id order by stream_id", (top,)):
+            lines.append(f"#   stream {sid} | {c} | {a / 1e3:.2f} | {mn / 1e3:.2f} | {mx / 1e3:.2f}")
     txt = "\n".join(lines)
     if out:
         open(out, "w").write(txt + "\n")
