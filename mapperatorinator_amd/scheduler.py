@@ -1,0 +1,161 @@
+"""Window scheduler for sequential songs on top of the HIP engine.
+
+The reference generates a song window by window (`Processor.generate_sequential`, osuT5/osuT5/inference/
+processor.py:308-368): window i's prompt contains the events that window i-1 produced, so the windows of ONE song are
+a chain; each iteration runs mel -> encoder -> decode for a single window (batch 1) and hops through the host between
+the stages.  Two things in that loop do not depend on the chain and are taken out of it here:
+
+  * the mel + encoder + cross-K/V of EVERY window depends on the audio only: all windows of all songs are encoded up
+    front in MFMA-sized batches and their cross-attention K/V stays resident in HBM (46 MB per 10 s window at
+    osuT5-base; a 3-minute song is 0.8 GB -- hundreds of songs fit in 288 GB);
+  * different songs are independent: wave w decodes window w of every song that still has one as ONE batch
+    (rows grouped by identical generate kwargs -- the lookback / lookahead EOS windows differ on a song's first and
+    last window).
+
+Prompt building stays with the caller -- it is the reference's own integer host logic (`get_prompts`,
+`prepare_context_sequences`, `add_predicted_tokens_to_context`, processor.py:1022-1052,1226-1268): a `SongJob` supplies
+`prompt_fn(window) -> model_kwargs-like dict` and receives every finished window through `on_result`.  Rows are
+batch-invariant in the engine, so the tokens are exactly those of the reference-shaped loop (one `model_generate` per
+window), which is what tests/test_gpu_t5.py::test_window_scheduler_matches_sequential_loop checks.
+"""
+from __future__ import annotations
+
+import dataclasses
+import time
+from typing import Callable, Optional
+
+import torch
+
+from .server import _build_generation_stats, build_sampling
+
+
+@dataclasses.dataclass
+class SongJob:
+    """frames: (n_windows, samples) raw audio windows of one song (what `prepare_frames` yields per window).
+    prompt_fn(window_index) -> dict(decoder_input_ids=(1, P) int64, [decoder_attention_mask], [negative_prompt],
+        [generate_kwargs=dict]) -- called when the previous window of THIS song has been delivered.
+    on_result(window_index, tokens (P + new,) int64 cpu incl. the prompt, stats dict)."""
+    frames: torch.Tensor
+    prompt_fn: Callable[[int], dict]
+    on_result: Callable[[int, torch.Tensor, dict], None]
+    generate_kwargs: dict = dataclasses.field(default_factory=dict)
+
+
+def _left_pad(rows, pad_id: int, dtype):
+    width = max(r.shape[-1] for r in rows)
+    out = torch.full((len(rows), width), pad_id, dtype=dtype)
+    for i, r in enumerate(rows):
+        out[i, width - r.shape[-1]:] = r.reshape(-1).to(dtype)
+    return out
+
+
+class SequentialWindowScheduler:
+    def __init__(self, model, tokenizer, *, encode_batch: int = 32, decode_batch: int = 32):
+        if decode_batch > 64 or decode_batch < 1:
+            raise ValueError("decode_batch must be in [1, 64]")
+        self.model, self.tokenizer = model, tokenizer
+        self.engine = model.engine
+        self.encode_batch, self.decode_batch = int(encode_batch), int(decode_batch)
+        self.stats = dict(windows=0, decode_calls=0, encode_calls=0, generated_tokens=0, elapsed_seconds=0.0)
+
+    # ---- stage 1: everything that depends on the audio only ------------------------------------------------
+    @torch.no_grad()
+    def encode_all(self, jobs: list[SongJob]):
+        """-> per job a tensor [n_dec_layers, 2, n_windows, H, L, 64] of resident cross-attention K/V."""
+        eng = self.engine
+        flat = torch.cat([j.frames for j in jobs], 0).to(eng.device, torch.float32)
+        parts = []
+        eng._enter()
+        with torch.cuda.stream(eng.stream):
+            for a in range(0, flat.shape[0], self.encode_batch):
+                parts.append(eng.cross_kv(eng.encode_mel(eng.mel(flat[a:a + self.encode_batch]))))
+                self.stats["encode_calls"] += 1
+            kv = torch.cat(parts, 2) if len(parts) > 1 else parts[0]
+        eng._leave()
+        out, a = [], 0
+        for j in jobs:
+            out.append(kv[:, :, a:a + j.frames.shape[0]])
+            a += j.frames.shape[0]
+        return out
+
+    # ---- stage 2: waves of dependent windows -----------------------------------------------------------------
+    @torch.no_grad()
+    def run(self, jobs: list[SongJob]):
+        eng, tok = self.engine, self.tokenizer
+        start = time.perf_counter()
+        kvs = self.encode_all(jobs)
+        n_waves = max(j.frames.shape[0] for j in jobs)
+        pad_id = int(getattr(tok, "pad_id", 0))
+        for w in range(n_waves):
+            active = [i for i, j in enumerate(jobs) if w < j.frames.shape[0]]
+            asks = {}
+            for i in active:
+                ask = dict(jobs[i].prompt_fn(w))
+                gk = dict(jobs[i].generate_kwargs, **ask.pop("generate_kwargs", {}))
+                key = repr(sorted(gk.items(), key=lambda kv_: kv_[0]))
+                asks.setdefault(key, []).append((i, ask, gk))
+            for group in asks.values():
+                for a in range(0, len(group), self.decode_batch):
+                    self._decode_group(jobs, kvs, w, group[a:a + self.decode_batch], pad_id)
+        self.stats["elapsed_seconds"] += time.perf_counter() - start
+        return self.stats
+
+    def _decode_group(self, jobs, kvs, w, group, pad_id):
+        eng, tok = self.engine, self.tokenizer
+        gk = group[0][2]
+        sp, eos = build_sampling(tok, gk, self.model.config.max_target_positions)
+        cfg = sp.cfg_scale > 1.0
+        prompts = _left_pad([g[1]["decoder_input_ids"] for g in group], pad_id, torch.int64)
+        masks = None
+        if any(g[1].get("decoder_attention_mask") is not None for g in group):
+            masks = _left_pad([g[1]["decoder_attention_mask"] if g[1].get("decoder_attention_mask") is not None
+                               else torch.ones_like(g[1]["decoder_input_ids"]) for g in group], 0, torch.uint8)
+        elif any(g[1]["decoder_input_ids"].shape[-1] != prompts.shape[1] for g in group):
+            masks = prompts.ne(pad_id).to(torch.uint8)      # ragged prompts: the left padding must not be attended
+        neg = None
+        if cfg:
+            if any(g[1].get("negative_prompt") is None for g in group):
+                raise ValueError("cfg_scale > 1 needs a negative_prompt for every window")
+            neg_rows = _left_pad([g[1]["negative_prompt"] for g in group], pad_id, torch.int64)
+            if neg_rows.shape[1] > prompts.shape[1]:
+                raise ValueError("negative prompt longer than the prompt")
+            # as prepare_inputs_for_generation: the negative prompt overwrites the first columns of a copy of the prompt
+            neg = prompts.clone()
+            neg[:, :neg_rows.shape[1]] = neg_rows
+        dev = eng.device
+        eos_table = torch.zeros(eng.packed.vocab_out, dtype=torch.uint8)
+        eos_table[torch.as_tensor(sorted(set(int(e) for e in eos if 0 <= int(e) < eng.packed.vocab_out)),
+                                  dtype=torch.long)] = 1
+        eos_ids = torch.as_tensor(sorted(set(int(e) for e in eos)), dtype=torch.int64)
+        t0 = time.perf_counter()
+        eng._enter()
+        with torch.cuda.stream(eng.stream):
+            kv = torch.stack([kvs[i][:, :, w] for i, _, _ in group], 2).contiguous()   # rows of this wave, gathered
+            p_all = torch.cat([neg, prompts], 0) if cfg else prompts
+            m_all = None if masks is None else (torch.cat([masks, masks], 0) if cfg else masks)
+            tokens, n_out, _ = eng.decode(kv, p_all.to(dev, torch.int32).contiguous(),
+                                          None if m_all is None else m_all.to(dev).contiguous(),
+                                          eos_table.to(dev), sp)
+        eng._leave()
+        torch.cuda.current_stream(dev).synchronize()
+        n_cols = int(n_out.item())
+        if cfg:
+            tokens = tokens[len(group):]
+        result = tokens[:, :n_cols].to(torch.int64).cpu()
+        elapsed = time.perf_counter() - t0
+        self.stats["decode_calls"] += 1
+        P = prompts.shape[1]
+        for r, (i, ask, _) in enumerate(group):
+            own = ask["decoder_input_ids"].shape[-1]
+            row = result[r, P - own:]                      # strip the padding this batch added on the left
+            # a row that finished early carries pad_id up to the batch's longest row: cut after its first EOS-set id,
+            # which is where a batch-1 call for this window would have ended
+            body = row[own:]
+            hit = torch.isin(body, eos_ids).nonzero()
+            if hit.numel():
+                row = row[:own + int(hit[0]) + 1]
+            st = _build_generation_stats(row[None], dict(decoder_input_ids=ask["decoder_input_ids"].reshape(1, -1)),
+                                         pad_id, elapsed)
+            self.stats["windows"] += 1
+            self.stats["generated_tokens"] += st["generated_tokens"]
+            jobs[i].on_result(w, row, st)

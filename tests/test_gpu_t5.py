@@ -191,7 +191,8 @@ def test_fp32_fresh_seeds_vs_oracle(seed):
         assert (lg[P + i][fin] - s[fin]).abs().max().item() < 5e-4
 
 
-@pytest.mark.parametrize("size,B,src,ns,tgt", [("tiny", 5, 251, 32000, 40), ("small", 2, 1251, 160000, 48)])
+@pytest.mark.parametrize("size,B,src,ns,tgt", [("tiny", 5, 251, 32000, 40), ("small", 2, 1251, 160000, 48),
+                                              ("large", 2, 251, 32000, 24)])   # config-5 dims (d 1024, 16 heads, d_ff 2816, 24+24 layers)
 def test_bf16_teacher_forced_vs_bf16_oracle(size, B, src, ns, tgt):
     from mapperatorinator_amd import Tokenizer
     from mapperatorinator_amd.server import build_sampling
@@ -414,3 +415,63 @@ def test_model_object_generate_and_forward_seam_b2():
         worst = max(worst, (lg[rows, pos] - want[rows]).abs().max().item())
     print("forward logits worst abs err", worst)
     assert worst < 5e-4
+
+
+def test_window_scheduler_matches_sequential_loop():
+    """8f rank 1: three songs with 3 / 2 / 4 dependent windows through SequentialWindowScheduler (all windows encoded up
+    front, wave w decodes window w of every song as one batch) == the reference-shaped loop (one batch-1
+    `model_generate` per window, in order).  Each prompt is built from the previous window's output, so a scheduling
+    mistake (wrong K/V row, wrong order, stale prompt) changes the tokens."""
+    from mapperatorinator_amd.scheduler import SequentialWindowScheduler, SongJob
+    from mapperatorinator_amd.server import model_generate
+    g, size, tok, sd, _, src, tgt = golden_case("t5_tiny")
+    from mapperatorinator_amd.testing import synthetic_audio
+    model = build(size, tok, sd, src, tgt, torch.float32)
+    n_windows = [3, 2, 4]
+    songs = [synthetic_audio(n, int(g["n_samples"]), seed=40 + k) for k, n in enumerate(n_windows)]
+    ts0, ts1 = ts_range(tok)
+
+    def kwargs_for(w, n):   # first window: no lookback trimming; last: no lookahead (processor.py:327-328)
+        return gen_kwargs(tgt, lookback_time=400 if w != 0 else 0, lookahead_time=3000 if w != n - 1 else 0, temperature=0.9)
+
+    def prompt_from(prev):  # sos + up to 3 non-special ids of the previous window's output
+        if prev is None:
+            return torch.tensor([[tok.sos_id]])
+        carry = [t for t in prev.tolist() if t > 2][-3:]
+        return torch.tensor([[tok.sos_id] + carry])
+
+    # the reference-shaped loop
+    want = []
+    for k, n in enumerate(n_windows):
+        prev, rows = None, []
+        for w in range(n):
+            prompt = prompt_from(prev)
+            ids, _ = model_generate(model, tok, dict(inputs=songs[k][w:w + 1], decoder_input_ids=prompt,
+                                                     decoder_attention_mask=prompt.ne(0)), kwargs_for(w, n))
+            prev = ids[0, prompt.shape[1]:]
+            rows.append(ids[0])
+        want.append(rows)
+
+    got = [[None] * n for n in n_windows]
+    state = [None] * len(n_windows)
+
+    def make_job(k, n):
+        def prompt_fn(w):
+            return dict(decoder_input_ids=prompt_from(state[k]), generate_kwargs=kwargs_for(w, n))
+
+        def on_result(w, row, st):
+            p = prompt_from(state[k]).shape[1]
+            got[k][w] = row
+            state[k] = row[p:]
+            assert st["generated_tokens"] == int((row[p:] != 0).sum())
+        return SongJob(frames=songs[k], prompt_fn=prompt_fn, on_result=on_result)
+
+    sched = SequentialWindowScheduler(model, tok, encode_batch=4, decode_batch=32)
+    stats = sched.run([make_job(k, n) for k, n in enumerate(n_windows)])
+    assert stats["windows"] == sum(n_windows) and stats["encode_calls"] == 3
+    for k, n in enumerate(n_windows):
+        for w in range(n):
+            a, b = got[k][w], want[k][w]
+            assert a.shape == b.shape and torch.equal(a, b), (k, w, a.tolist(), b.tolist())
+    # fewer decode calls than windows: songs were interleaved
+    assert stats["decode_calls"] < sum(n_windows)
