@@ -22,6 +22,15 @@ def __getattr__(name):  # torch-dependent pieces are imported lazily
     if name in ("DiTHIP", "create_diffusion", "InpaintSpec", "SpacedDiffusionHIP"):
         from . import dit
         return getattr(dit, name)
+    if name in ("encode_events", "decode_tokens"):
+        from . import tokenizer
+        return getattr(tokenizer, name)
+    if name in ("DiffusionPipelineHIP", "points_to_sequence"):
+        from . import diffusion_pipeline
+        return getattr(diffusion_pipeline, name)
+    if name in ("SequentialWindowScheduler", "SongJob"):
+        from . import scheduler
+        return getattr(scheduler, name)
     if name == "MelSpectrogram":
         from .mel import MelSpectrogram
         return MelSpectrogram

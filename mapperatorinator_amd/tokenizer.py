@@ -169,3 +169,42 @@ class Tokenizer:
     def save_json(self, path: str):
         with open(path, "w", encoding="utf-8") as f:
             json.dump(self.state_dict(), f, ensure_ascii=False)
+
+
+# ---- ids <-> Events with absolute times (reference Processor._encode / _decode, processor.py:1215-1268) --------
+def encode_events(tokenizer: "Tokenizer", events, frame_time: float):
+    """Events with ABSOLUTE TIME_SHIFT values (ms) -> int64 ids (1, n) relative to the window start `frame_time`:
+    `int((ms - frame_time) / 10)` truncated toward zero and clipped to the TIME_SHIFT range (processor.py:1215-1224)."""
+    import numpy as np
+    import torch
+    tokens = torch.empty((1, len(events)), dtype=torch.long)
+    ts_range = tokenizer.event_range[EventType.TIME_SHIFT]
+    for i, event in enumerate(events):
+        if event.type == EventType.TIME_SHIFT:
+            value = int((event.value - frame_time) / MILISECONDS_PER_STEP)
+            value = int(np.clip(value, ts_range.min_value, ts_range.max_value))
+            event = Event(type=event.type, value=value)
+        tokens[0, i] = tokenizer.encode(event)
+    return tokens
+
+
+def decode_tokens(tokenizer: "Tokenizer", tokens, frame_time: float, allow_non_events: bool = False):
+    """ids -> Events, TIME_SHIFT steps back to absolute ms: `frame_time + steps * 10 + 5` for steps >= 0 (the half-step
+    de-bias of the truncating encoder), stops at eos unless `allow_non_events`, ids outside the vocabulary are skipped
+    or kept as CONTROL events (processor.py:1226-1268)."""
+    events = []
+    for token in tokens:
+        tid = int(token)
+        if tid == tokenizer.eos_id and not allow_non_events:
+            break
+        try:
+            event = tokenizer.decode(tid)
+        except ValueError:
+            if allow_non_events:
+                events.append(Event(EventType.CONTROL, tid))
+            continue
+        if event.type == EventType.TIME_SHIFT:
+            half_step = MILISECONDS_PER_STEP // 2 if event.value >= 0 else 0
+            event.value = frame_time + event.value * MILISECONDS_PER_STEP + half_step
+        events.append(event)
+    return events
