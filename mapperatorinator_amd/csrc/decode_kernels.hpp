@@ -600,6 +600,179 @@ __global__ __launch_bounds__(NW * 64) void dec_cross_attn_kernel(CrossAttnP p) {
   }
 }
 
+// ---- attention kernels that project their own query (and the new self-attention key / value) --------------------
+// A decode step is ~100 dependent kernels of a few microseconds each, so every kernel removed from the chain is worth
+// more than the work it did.  The per-head projections are tiny (64 outputs x d inputs): each attention workgroup
+// recomputes RMSNorm(h[b]) and its own 64-row slice of W (the slices of one head are shared by the B workgroups of
+// that head through L2), which removes the stand-alone QKV and cross-Q GEMV launches from every layer.
+struct HeadProjP {
+  const float* h; int ldh;            // fp32 residual stream [B, ldh]
+  const float* ln_w; float eps;
+  const float* ss_in; int ss_parts;   // [ss_parts][64] partial sums of squares of the rows of h
+  const void* W; int ldw;             // [rows, ldw] element type T (cross: Wq [inner][d]; self: Wqkv [3 inner][d])
+  int d;
+};
+
+template <typename T> struct Raw8;
+template <> struct Raw8<bf16_t> {
+  uint4 v;
+  __device__ inline void load(const bf16_t* p) { v = *reinterpret_cast<const uint4*>(p); }
+  __device__ inline void unpack(float (&o)[8]) const {
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { o[2 * i] = __uint_as_float(w[i] << 16); o[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+  }
+};
+template <> struct Raw8<float> {
+  float4 a, b;
+  __device__ inline void load(const float* p) { a = *reinterpret_cast<const float4*>(p); b = *reinterpret_cast<const float4*>(p + 4); }
+  __device__ inline void unpack(float (&o)[8]) const {
+    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+  }
+};
+
+// xn[k] = T-rounded ln_w[k] * (h[b][k] * rsqrt(mean(h[b]^2) + eps)) for k < d, by a 1024-thread workgroup (d <= 1024);
+// the operand loads are requested before the statistics are waited for.  `stat` is one LDS float.
+template <typename T>
+__device__ inline void norm_row_to_lds(const HeadProjP& hp, int b, float* xn, float* stat) {
+  const int tid = threadIdx.x;
+  const int kc = tid < hp.d ? tid : hp.d - 1;
+  const float x = hp.h[(long)b * hp.ldh + kc];
+  const float g = hp.ln_w[kc];
+  if (tid < 64) {
+    const float sv = hp.ss_in[(tid < hp.ss_parts ? tid : 0) * 64 + b];
+    const float tot = wave_sum(tid < hp.ss_parts ? sv : 0.f);
+    if (tid == 0) *stat = rsqrtf(tot / (float)hp.d + hp.eps);
+  }
+  __syncthreads();
+  const float rs = *stat;
+  if (tid < hp.d) xn[tid] = Elem<T>::to_f32(Elem<T>::from_f32(g * (x * rs)));
+  __syncthreads();
+}
+
+// NP projections of 64 outputs each: out[p][o] = T-rounded sum_k xn[k] * W[(row0[p] + o) * ldw + k].
+// 1024 threads: 16 consecutive lanes per output, KC 8-element chunks per lane (d = 128 KC); all loads up front.
+template <typename T, int KC, int NP>
+__device__ inline void head_proj(const HeadProjP& hp, const int (&row0)[NP], const float* xn, float (*out)[64]) {
+  const int tid = threadIdx.x, o = tid >> 4, ks = tid & 15;
+  constexpr int kper = KC * 8;
+  Raw8<T> raw[NP][KC];
+#pragma unroll
+  for (int q = 0; q < NP; ++q) {
+    const T* wp = reinterpret_cast<const T*>(hp.W) + (long)(row0[q] + o) * hp.ldw + ks * kper;
+#pragma unroll
+    for (int c = 0; c < KC; ++c) raw[q][c].load(wp + c * 8);
+  }
+#pragma unroll
+  for (int q = 0; q < NP; ++q) {
+    float acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+      float w[8];
+      raw[q][c].unpack(w);
+      const float4 x0 = *reinterpret_cast<const float4*>(xn + ks * kper + c * 8);
+      const float4 x1 = *reinterpret_cast<const float4*>(xn + ks * kper + c * 8 + 4);
+      acc += x0.x * w[0] + x0.y * w[1] + x0.z * w[2] + x0.w * w[3] + x1.x * w[4] + x1.y * w[5] + x1.z * w[6] + x1.w * w[7];
+    }
+    acc = group_sum<16>(acc);
+    if (ks == 0) out[q][o] = Elem<T>::to_f32(Elem<T>::from_f32(acc));
+  }
+}
+
+// cross-attention of one (b, h) with its own query projection; 16 waves, one key split (the default configuration
+// of dec_cross_attn_kernel, same key interleave and merge order)
+template <typename T, int KC, int U>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8)))   // <= 64 VGPRs: 2 workgroups per CU
+void dec_cross_attn_q_kernel(CrossAttnP p, HeadProjP hp) {
+  constexpr int NW = 16;
+  __shared__ float sm[NW][66];
+  __shared__ __attribute__((aligned(16))) float xn[1024];
+  __shared__ float qs[1][64];
+  __shared__ float stat;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int blk = blockIdx.x;
+  int b, h;
+  if (p.kv_B > 0) {
+    const int q2 = blk >> 1;
+    b = (blk & 1) * p.kv_B + q2 / p.H;
+    h = q2 % p.H;
+  } else {
+    b = blk / p.H;
+    h = blk % p.H;
+  }
+  const int c8 = (lane & 7) * 8, g = lane >> 3;
+  norm_row_to_lds<T>(hp, b, xn, &stat);
+  const int row0[1] = {h * 64};
+  head_proj<T, KC, 1>(hp, row0, xn, qs);
+  __syncthreads();
+  float q[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) q[i] = qs[0][c8 + i];
+  const int kvb = p.kv_B > 0 ? b % p.kv_B : b;
+  const T* kb = reinterpret_cast<const T*>(p.k) + ((long)kvb * p.H + h) * p.L * 64;
+  const T* vb = reinterpret_cast<const T*>(p.v) + ((long)kvb * p.H + h) * p.L * 64;
+  Partial st;
+  partial_init(st);
+  attend_keys<T, U>(st, q, kb, vb, wid * 8 + g, p.L, 8 * NW, nullptr, 0, nullptr, 0, 1.0f);
+  partial_merge_groups<T>(st);
+  float m, l, a;
+  block_merge<T, NW>(st, sm, m, l, a);
+  if (threadIdx.x < 64)
+    reinterpret_cast<T*>(p.out)[(long)b * p.ldo + h * 64 + threadIdx.x] = Elem<T>::from_f32(l > 0.f ? a / l : 0.f);
+}
+
+// self-attention of one (b, h) with its own q / k / v projections: appends the new key / value row to the caches and
+// attends over keys 0 .. pos-1 from the cache plus the new key straight from LDS (merged last)
+template <typename T, int KC>
+__global__ __launch_bounds__(1024) void dec_self_attn_qkv_kernel(SelfAttnP p, HeadProjP hp, int inner) {
+  constexpr int NW = 16;
+  __shared__ float sm[NW][66];
+  __shared__ __attribute__((aligned(16))) float xn[1024];
+  __shared__ float qkv[3][64];
+  __shared__ float stat;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
+  const int pos = *p.pos;
+  const int c8 = (lane & 7) * 8, g = lane >> 3;
+  norm_row_to_lds<T>(hp, b, xn, &stat);
+  if (sizeof(T) == 2) {
+    const int row0[3] = {h * 64, inner + h * 64, 2 * inner + h * 64};
+    head_proj<T, KC, 3>(hp, row0, xn, qkv);
+  } else {   // fp32 storage: one projection at a time (register budget of a 1024-thread workgroup)
+#pragma unroll
+    for (int q3 = 0; q3 < 3; ++q3) {
+      const int row0[1] = {q3 * inner + h * 64};
+      head_proj<T, KC, 1>(hp, row0, xn, qkv + q3);
+    }
+  }
+  __syncthreads();
+  T* kcache = reinterpret_cast<T*>(const_cast<void*>(p.kc)) + ((long)b * p.H + h) * p.tgt_len * 64;
+  T* vcache = reinterpret_cast<T*>(const_cast<void*>(p.vc)) + ((long)b * p.H + h) * p.tgt_len * 64;
+  if (threadIdx.x >= 64 && threadIdx.x < 128) kcache[(long)pos * 64 + (threadIdx.x - 64)] = Elem<T>::from_f32(qkv[1][threadIdx.x - 64]);
+  if (threadIdx.x >= 128 && threadIdx.x < 192) vcache[(long)pos * 64 + (threadIdx.x - 128)] = Elem<T>::from_f32(qkv[2][threadIdx.x - 128]);
+  float q[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) q[i] = qkv[0][c8 + i];
+  const float* bias_row = p.bias + (long)h * p.tgt_len;
+  const uint8_t* mask_row = p.prompt_mask ? p.prompt_mask + (long)b * p.P : nullptr;
+  Partial st;
+  partial_init(st);
+  attend_keys<T, 2>(st, q, kcache, vcache, wid * 8 + g, pos, 8 * NW, bias_row, pos, mask_row, p.P, 1.0f);
+  partial_merge_groups<T>(st);
+  float m, l, a;
+  block_merge<T, NW>(st, sm, m, l, a);
+  if (threadIdx.x < 64) {
+    const int d = threadIdx.x;
+    float sn = wave_sum(qkv[0][d] * qkv[1][d]) + bias_row[0];
+    if (mask_row && pos < p.P && mask_row[pos < p.P ? pos : 0] == 0) sn = -INFINITY;
+    const float mn = fmaxf(m, sn);
+    const float fa = fexp<T>(m - mn), fb = fexp<T>(sn - mn);
+    l = l * fa + fb;
+    a = a * fa + qkv[2][d] * fb;
+    reinterpret_cast<T*>(p.out)[(long)b * p.ldo + h * 64 + d] = Elem<T>::from_f32(l > 0.f ? a / l : 0.f);
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(64) void dec_cross_merge_kernel(CrossAttnP p) {
   const int pair = blockIdx.x, d = threadIdx.x;

@@ -549,6 +549,48 @@ int launch_cross(const dec::CrossAttnP& ca, hipStream_t s) {
   return rc;
 }
 
+// attention kernels that project their own q (/ k / v): see decode_kernels.hpp.  d_model = 128 KC, KC in {1, 4, 6, 8}
+// (tiny / small / base / large); MH_DECODE_FUSED_PROJ=0 restores the stand-alone QKV and cross-Q GEMV launches.
+bool fused_proj_enabled(int d) {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("MH_DECODE_FUSED_PROJ");
+    v = (e && atoi(e) == 0) ? 0 : 1;
+  }
+  return v == 1 && (d == 128 || d == 512 || d == 768 || d == 1024);
+}
+
+template <typename T, int KC>
+int launch_self_qkv(const dec::SelfAttnP& sa, const dec::HeadProjP& hp, int inner, hipStream_t s) {
+  hipLaunchKernelGGL((dec::dec_self_attn_qkv_kernel<T, KC>), dim3(sa.B * sa.H), dim3(1024), 0, s, sa, hp, inner);
+  return check_launch("dec_self_attn_qkv_kernel");
+}
+template <typename T>
+int launch_self_qkv_d(const dec::SelfAttnP& sa, const dec::HeadProjP& hp, int inner, hipStream_t s) {
+  switch (hp.d) {
+    case 128: return launch_self_qkv<T, 1>(sa, hp, inner, s);
+    case 512: return launch_self_qkv<T, 4>(sa, hp, inner, s);
+    case 768: return launch_self_qkv<T, 6>(sa, hp, inner, s);
+    default: return launch_self_qkv<T, 8>(sa, hp, inner, s);
+  }
+}
+template <typename T, int KC>
+int launch_cross_q(const dec::CrossAttnP& ca, const dec::HeadProjP& hp, hipStream_t s) {
+  // one key in flight per 8-lane group: 64 VGPRs without spills (two 16-wave workgroups per CU); U = 2 measured the
+  // same bandwidth in the stand-alone kernel
+  hipLaunchKernelGGL((dec::dec_cross_attn_q_kernel<T, KC, 1>), dim3(ca.B * ca.H), dim3(1024), 0, s, ca, hp);
+  return check_launch("dec_cross_attn_q_kernel");
+}
+template <typename T>
+int launch_cross_q_d(const dec::CrossAttnP& ca, const dec::HeadProjP& hp, hipStream_t s) {
+  switch (hp.d) {
+    case 128: return launch_cross_q<T, 1>(ca, hp, s);
+    case 512: return launch_cross_q<T, 4>(ca, hp, s);
+    case 768: return launch_cross_q<T, 6>(ca, hp, s);
+    default: return launch_cross_q<T, 8>(ca, hp, s);
+  }
+}
+
 template <typename T>
 int enqueue_step(const MhT5Config* c, const MhT5Weights* w, const void* cross_kv, int B, int Bfull, int kvB,
                  const uint8_t* prompt_mask, int P, const DecBuffers& bf, const SampleP& smp, hipStream_t s) {
@@ -562,32 +604,48 @@ int enqueue_step(const MhT5Config* c, const MhT5Weights* w, const void* cross_kv
     const long cache_off = (long)l * Bfull * H * tgt * 64 * es;
     dec::SkinnyP sk{};
     // self attention
-    sk = dec::SkinnyP{};
-    sk.A = bf.h; sk.lda = d; sk.ln_w = w->dec_ln1[l]; sk.eps = c->eps; sk.W = w->dec_qkv[l]; sk.ldw = d; sk.B = B;
-    sk.ss_in = bf.ss; sk.ss_parts = (l == 0) ? 1 : d / 16;
-    sk.N = 3 * inner; sk.K = d; sk.out = bf.q; sk.ldo = inner; sk.kc = (char*)bf.self_k + cache_off;
-    sk.vc = (char*)bf.self_v + cache_off; sk.H = H; sk.tgt_len = tgt; sk.inner = inner; sk.pos = posp;
-    MH_TRY((skinny<T, 1, dec::PRO_RMSNORM, dec::SK_QKV>(sk, s)));
+    const bool fused = fused_proj_enabled(d);
     dec::SelfAttnP sa{};
-    sa.q = bf.q; sa.ldq = inner; sa.kc = sk.kc; sa.vc = sk.vc; sa.bias = w->dec_rel_bias; sa.prompt_mask = prompt_mask;
+    sa.q = bf.q; sa.ldq = inner; sa.kc = (char*)bf.self_k + cache_off; sa.vc = (char*)bf.self_v + cache_off;
+    sa.bias = w->dec_rel_bias; sa.prompt_mask = prompt_mask;
     sa.P = P; sa.out = bf.attn; sa.ldo = inner; sa.B = B; sa.H = H; sa.tgt_len = tgt; sa.pos = posp;
-    hipLaunchKernelGGL(dec::dec_self_attn_kernel<T>, dim3(B * H), dim3(256), 0, s, sa);
-    MH_TRY(check_launch("dec_self_attn_kernel"));
+    if (fused) {
+      dec::HeadProjP hp{};
+      hp.h = bf.h; hp.ldh = d; hp.ln_w = w->dec_ln1[l]; hp.eps = c->eps; hp.ss_in = bf.ss;
+      hp.ss_parts = (l == 0) ? 1 : d / 16; hp.W = w->dec_qkv[l]; hp.ldw = d; hp.d = d;
+      MH_TRY(launch_self_qkv_d<T>(sa, hp, inner, s));
+    } else {
+      sk = dec::SkinnyP{};
+      sk.A = bf.h; sk.lda = d; sk.ln_w = w->dec_ln1[l]; sk.eps = c->eps; sk.W = w->dec_qkv[l]; sk.ldw = d; sk.B = B;
+      sk.ss_in = bf.ss; sk.ss_parts = (l == 0) ? 1 : d / 16;
+      sk.N = 3 * inner; sk.K = d; sk.out = bf.q; sk.ldo = inner; sk.kc = (char*)bf.self_k + cache_off;
+      sk.vc = (char*)bf.self_v + cache_off; sk.H = H; sk.tgt_len = tgt; sk.inner = inner; sk.pos = posp;
+      MH_TRY((skinny<T, 1, dec::PRO_RMSNORM, dec::SK_QKV>(sk, s)));
+      hipLaunchKernelGGL(dec::dec_self_attn_kernel<T>, dim3(B * H), dim3(256), 0, s, sa);
+      MH_TRY(check_launch("dec_self_attn_kernel"));
+    }
     sk = dec::SkinnyP{};
     sk.A = bf.attn; sk.lda = inner; sk.W = w->dec_o[l]; sk.ldw = inner; sk.B = B; sk.N = d; sk.K = inner; sk.h = bf.h;
     sk.ldh = d; sk.ss_out = bf.ss;
     MH_TRY((skinny<T, 1, dec::PRO_PLAIN, dec::SK_RESID>(sk, s)));
     // cross attention
-    sk = dec::SkinnyP{};
-    sk.A = bf.h; sk.lda = d; sk.ln_w = w->dec_ln2[l]; sk.eps = c->eps; sk.W = w->dec_cq[l]; sk.ldw = d; sk.B = B;
-    sk.N = inner; sk.K = d; sk.out = bf.q; sk.ldo = inner; sk.ss_in = bf.ss; sk.ss_parts = d / 16;
-    MH_TRY((skinny<T, 1, dec::PRO_RMSNORM, dec::SK_STORE>(sk, s)));
     dec::CrossAttnP ca{};
     const long kv_layer = (long)kvB * H * L * 64 * es;
     ca.q = bf.q; ca.ldq = inner; ca.k = (const char*)cross_kv + (long)(l * 2 + 0) * kv_layer;
     ca.v = (const char*)cross_kv + (long)(l * 2 + 1) * kv_layer; ca.out = bf.attn; ca.ldo = inner; ca.part = bf.part;
     ca.B = B; ca.H = H; ca.L = L; ca.splits = bf.splits; ca.ticket = bf.ticket; ca.kv_B = kvB < Bfull ? kvB : 0;
-    MH_TRY(launch_cross<T>(ca, s));
+    if (fused && bf.splits == 1) {
+      dec::HeadProjP hp{};
+      hp.h = bf.h; hp.ldh = d; hp.ln_w = w->dec_ln2[l]; hp.eps = c->eps; hp.ss_in = bf.ss; hp.ss_parts = d / 16;
+      hp.W = w->dec_cq[l]; hp.ldw = d; hp.d = d;
+      MH_TRY(launch_cross_q_d<T>(ca, hp, s));
+    } else {
+      sk = dec::SkinnyP{};
+      sk.A = bf.h; sk.lda = d; sk.ln_w = w->dec_ln2[l]; sk.eps = c->eps; sk.W = w->dec_cq[l]; sk.ldw = d; sk.B = B;
+      sk.N = inner; sk.K = d; sk.out = bf.q; sk.ldo = inner; sk.ss_in = bf.ss; sk.ss_parts = d / 16;
+      MH_TRY((skinny<T, 1, dec::PRO_RMSNORM, dec::SK_STORE>(sk, s)));
+      MH_TRY(launch_cross<T>(ca, s));
+    }
     sk = dec::SkinnyP{};
     sk.A = bf.attn; sk.lda = inner; sk.W = w->dec_co[l]; sk.ldw = inner; sk.B = B; sk.N = d; sk.K = inner; sk.h = bf.h;
     sk.ldh = d; sk.ss_out = bf.ss;
