@@ -176,8 +176,8 @@ def main():
     ms = C.c_float(0.0)
     ws = eng._workspace("dec", lib.mh_t5_decode_workspace_bytes(C.byref(eng.packed.cfg), B))
     reps = 20 * dims.n_dec_layers
-    rc = lib.mh_t5_cross_attn_probe(C.byref(eng.packed.cfg), kv.data_ptr(), B, reps, C.byref(ms), ws.data_ptr(),
-                                    ws.numel(), eng.stream.cuda_stream)
+    rc = lib.mh_t5_cross_attn_probe(C.byref(eng.packed.cfg), C.byref(eng.packed.w), kv.data_ptr(), B, reps, C.byref(ms),
+                                    ws.data_ptr(), ws.numel(), eng.stream.cuda_stream)
     _lib.check(rc, "mh_t5_cross_attn_probe")
     achieved = alg_bytes / (ms.value * 1e-3) / 1e9
     # HBM bytes per launch from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 passes, gfx950
@@ -187,7 +187,7 @@ def main():
     if os.path.exists(pmc_path) and args.size == "base" and args.dtype == "bf16" and B == 32:
         with open(pmc_path) as f:
             traffic = json.load(f).get("hbm_bytes_per_launch")
-    roofline = {"bound": "hbm", "kernel": "dec_cross_attn_kernel (+merge)", "achieved": round(achieved, 1),
+    roofline = {"bound": "hbm", "kernel": "dec_cross_attn_q_kernel (cross-attention over the encoder K/V incl. its query projection)", "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "alg_bytes_per_launch": alg_bytes, "us_per_launch": round(ms.value * 1e3, 2),
                 "launches_per_token_step": dims.n_dec_layers}

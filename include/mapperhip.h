@@ -260,9 +260,11 @@ int mh_t5_decoder_forward(const MhT5Config* cfg, const MhT5Weights* w, const voi
 /* Measurement hook (bench.py `roofline`): launches the dominant decode kernel -- cross-attention over
  * the encoder keys, algorithmic bytes per launch = B*H*src_len*64*2*sizeof(elem) -- `reps` times
  * back to back between two HIP events on `stream`, cycling through the decoder layers as a decode
- * step does.  ms_out (HOST float[1]) = average milliseconds per launch.  Synchronises `stream`. */
-int mh_t5_cross_attn_probe(const MhT5Config* cfg, const void* cross_kv, int B, int reps, float* ms_out,
-                           void* workspace, int64_t workspace_bytes, void* stream);
+ * step does.  With `w` given it is the kernel the decode step really launches (the cross-attention that also
+ * projects its own query from the residual row); w == NULL times the stand-alone attention kernel.
+ * ms_out (HOST float[1]) = average milliseconds per launch.  Synchronises `stream`. */
+int mh_t5_cross_attn_probe(const MhT5Config* cfg, const MhT5Weights* w, const void* cross_kv, int B, int reps,
+                           float* ms_out, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K7/K8/K9  osu_diffusion DiT + DDPM.  Replaces DiT.forward_with_cfg

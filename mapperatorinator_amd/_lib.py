@@ -90,7 +90,7 @@ SYMBOLS = {
                            C.POINTER(MhSampling), VP, VP, VP, VP, VP, I64, I, VP]),
     "mh_t5_forward_workspace_bytes": (I64, [C.POINTER(MhT5Config), I, I]),
     "mh_t5_decoder_forward": (I, [C.POINTER(MhT5Config), C.POINTER(MhT5Weights), VP, I, VP, VP, I, VP, VP, I64, VP]),
-    "mh_t5_cross_attn_probe": (I, [C.POINTER(MhT5Config), VP, I, I, C.POINTER(C.c_float), VP, I64, VP]),
+    "mh_t5_cross_attn_probe": (I, [C.POINTER(MhT5Config), C.POINTER(MhT5Weights), VP, I, I, C.POINTER(C.c_float), VP, I64, VP]),
     "mh_dit_workspace_bytes": (I64, [C.POINTER(MhDiTConfig), I, I]),
     "mh_dit_forward_cfg": (I, [C.POINTER(MhDiTConfig), C.POINTER(MhDiTWeights), VP, VP, VP, VP, F, I, I, I,
                                VP, VP, I64, VP]),

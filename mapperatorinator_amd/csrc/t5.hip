@@ -1073,22 +1073,28 @@ extern "C" int mh_t5_decoder_forward(const MhT5Config* c, const MhT5Weights* w, 
 // encoder keys) launched `reps` times back to back between two HIP events ON THE GIVEN STREAM, cycling
 // through the decoder layers exactly like a decode step does (so every launch streams a different layer's
 // K/V: B*H*L*64*2 elements).  ms_out[0] = average milliseconds per launch (split kernel + merge kernel).
-extern "C" int mh_t5_cross_attn_probe(const MhT5Config* c, const void* cross_kv, int B, int reps, float* ms_out,
-                                      void* workspace, int64_t workspace_bytes, void* stream) {
+extern "C" int mh_t5_cross_attn_probe(const MhT5Config* c, const MhT5Weights* w, const void* cross_kv, int B, int reps,
+                                      float* ms_out, void* workspace, int64_t workspace_bytes, void* stream) {
   MH_TRY(check_cfg(c, "mh_t5_cross_attn_probe"));
   MH_REQUIRE(cross_kv && ms_out && workspace && B > 0 && B <= 64 && reps > 0, "mh_t5_cross_attn_probe: bad argument");
   MH_REQUIRE(workspace_bytes >= mh_t5_decode_workspace_bytes(c, B), "mh_t5_cross_attn_probe: workspace too small");
   hipStream_t s = (hipStream_t)stream;
-  const int es = es_of(c->dtype), H = c->n_heads, inner = H * 64, L = c->src_len;
+  const int es = es_of(c->dtype), H = c->n_heads, inner = H * 64, L = c->src_len, d = c->d_model;
   Arena ar(workspace, workspace_bytes);
-  (void)ar.take((int64_t)B * c->d_model * 4);
+  float* h = (float*)ar.take((int64_t)B * d * 4);
   void* q = ar.take((int64_t)B * inner * es);
   void* attn = ar.take((int64_t)B * inner * es);
   (void)ar.take((int64_t)B * c->d_ff * es);
   (void)ar.take((int64_t)B * c->vocab_out * 4);
   float* part = (float*)ar.take((int64_t)B * H * 8 * 66 * 4);
+  float* ss = (float*)ar.take((int64_t)64 * 64 * 4 * kMaxChains);
   if (hipMemsetAsync(q, 0, (size_t)B * inner * es, s) != hipSuccess) return check_launch("probe memset");
+  if (hipMemsetAsync(h, 0, (size_t)B * d * 4, s) != hipSuccess) return check_launch("probe memset");
+  if (hipMemsetAsync(ss, 0, (size_t)64 * 64 * 4, s) != hipSuccess) return check_launch("probe memset");
   const int splits = cross_splits(B, H);
+  // the kernel the decode step launches: with weights given and the fused projections on, the cross-attention that
+  // also projects its query (dec_cross_attn_q_kernel); otherwise the stand-alone dec_cross_attn_kernel
+  const bool with_q = w != nullptr && splits == 1 && fused_proj_enabled(d);
   const long kv_layer = (long)B * H * L * 64 * es;
   hipEvent_t e0, e1;
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return check_launch("event create");
@@ -1101,7 +1107,14 @@ extern "C" int mh_t5_cross_attn_probe(const MhT5Config* c, const void* cross_kv,
       ca.q = q; ca.ldq = inner; ca.k = (const char*)cross_kv + (long)(l * 2 + 0) * kv_layer;
       ca.v = (const char*)cross_kv + (long)(l * 2 + 1) * kv_layer; ca.out = attn; ca.ldo = inner; ca.part = part;
       ca.B = B; ca.H = H; ca.L = L; ca.splits = splits; ca.ticket = nullptr;
-      rc = c->dtype == MH_BF16 ? launch_cross<bf16_t>(ca, s) : launch_cross<float>(ca, s);
+      if (with_q) {
+        dec::HeadProjP hp{};
+        hp.h = h; hp.ldh = d; hp.ln_w = w->dec_ln2[l]; hp.eps = c->eps; hp.ss_in = ss; hp.ss_parts = d / 16;
+        hp.W = w->dec_cq[l]; hp.ldw = d; hp.d = d;
+        rc = c->dtype == MH_BF16 ? launch_cross_q_d<bf16_t>(ca, hp, s) : launch_cross_q_d<float>(ca, hp, s);
+      } else {
+        rc = c->dtype == MH_BF16 ? launch_cross<bf16_t>(ca, s) : launch_cross<float>(ca, s);
+      }
     }
     if (pass == 1) (void)hipEventRecord(e1, s);
   }

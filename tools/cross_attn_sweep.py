@@ -22,7 +22,7 @@ def one():
     st = torch.cuda.Stream()
     best = 1e9
     for _ in range(3):
-        _lib.check(lib.mh_t5_cross_attn_probe(C.byref(cfg), kv.data_ptr(), B, 20 * nd, C.byref(ms), ws.data_ptr(), ws.numel(), st.cuda_stream))
+        _lib.check(lib.mh_t5_cross_attn_probe(C.byref(cfg), None, kv.data_ptr(), B, 20 * nd, C.byref(ms), ws.data_ptr(), ws.numel(), st.cuda_stream))
         best = min(best, ms.value)
     bytes_ = B * H * L * 64 * 2 * 2
     print(f"B={B} ({B*H} pairs) splits={os.environ.get('MH_CROSS_SPLITS')} U={os.environ.get('MH_CROSS_U')}: {best*1e3:.2f} us/launch  {bytes_/best/1e6:.0f} GB/s", flush=True)
