@@ -94,6 +94,16 @@ typedef struct MhGemm {
   void* C2; int n_split; int kv_Lpad;   /* MH_EPI_QKV_VT / MH_EPI_QKV_CACHE */
   void* C3; void* C4; int cache_len;    /* MH_EPI_QKV_CACHE only */
   int dtype; int epilogue;
+  /* fp32 only -- adaLN `modulate(LayerNorm(x), shift, scale)` (osu_diffusion/utils/models.py:11-12,145,152) fused
+   * around the GEMMs of a DiT block instead of a stand-alone pass over the activations:
+   *   stats_out  (MH_EPI_STORE_F32 / MH_EPI_GATE_RESID producers) fp32 [ceil(N/16)][M][2]: per 16-column strip the
+   *              sum and sum of squares of every output row, written by the epilogue;
+   *   ln_stats   (consumer) the same array for the rows of A (ln_strips strips, K columns): the A operand becomes
+   *              (a - mean) * rsqrt(var + ln_eps) * (1 + ln_scale[b][k]) + ln_shift[b][k], b = row / rows_per_batch,
+   *              ln_shift / ln_scale fp32 with row stride ln_ld. */
+  float* stats_out;
+  const float* ln_stats; int ln_strips;
+  const float* ln_shift; const float* ln_scale; int ln_ld; float ln_eps;
 } MhGemm;
 int mh_gemm(const MhGemm* g, void* stream);
 

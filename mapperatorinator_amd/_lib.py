@@ -26,7 +26,9 @@ class MhGemm(C.Structure):
                 ("gate_ld", C.c_int), ("rows_per_batch", C.c_int), ("kv_B", C.c_int), ("kv_H", C.c_int),
                 ("kv_L", C.c_int), ("C2", VP), ("n_split", C.c_int), ("kv_Lpad", C.c_int),
                 ("C3", VP), ("C4", VP), ("cache_len", C.c_int),
-                ("dtype", C.c_int), ("epilogue", C.c_int)]
+                ("dtype", C.c_int), ("epilogue", C.c_int),
+                ("stats_out", VP), ("ln_stats", VP), ("ln_strips", C.c_int), ("ln_shift", VP), ("ln_scale", VP),
+                ("ln_ld", C.c_int), ("ln_eps", C.c_float)]
 
 
 class MhT5Config(C.Structure):

@@ -178,6 +178,7 @@ __global__ void loop_set_kernel(int* sel, int v) {
 
 struct DiTBuf {
   float *E, *xs, *xm, *qk, *vt, *attn, *hid, *yemb1, *yemb, *cond_cur;
+  float* stats;   // [D/16][N*T][2] row sums / sums of squares of xs, written by the GEMM that produced xs
   int* sel;
   int Tpad;
 };
@@ -201,6 +202,7 @@ int64_t dit_ws_layout(const MhDiTConfig* c, int N, int T, void* base, int64_t si
   t.yemb1 = (float*)ar.take((int64_t)N * D * 4);
   t.yemb = (float*)ar.take((int64_t)N * D * 4);
   t.cond_cur = (float*)ar.take(cond_floats(c, N) * 4);
+  t.stats = (float*)ar.take((int64_t)ceil_div(D, 16) * NT * 2 * 4);
   t.sel = (int*)ar.take(256);
   if (b) *b = t;
   return ar.off;
@@ -268,35 +270,53 @@ int dit_body(const MhDiTConfig* c, const MhDiTWeights* w, const float* x, const 
   hipLaunchKernelGGL(dit_embed_kernel, dim3(NT), dim3(256), 0, s, x, cc, w->pos_freqs, N, T, c->freq_dim,
                      c->context_size, c->first_k_pad, b.E);
   MH_TRY(check_launch("dit_embed_kernel"));
+  // LayerNorm + adaLN modulate never runs as its own pass inside the blocks: every GEMM that writes the residual
+  // stream xs also emits per-row (sum, sum of squares) per 16-column strip, and the GEMM that consumes
+  // modulate(LN(xs)) normalises its A operand on the way into LDS (mh_gemm: stats_out / ln_stats).
+  const bool fuse_ln = (D % 16 == 0);
+  const int strips = D / 16;
   MhGemm g = MhGemm{};
   g.A = b.E; g.lda = c->first_k_pad; g.W = w->first_w; g.ldw = c->first_k_pad; g.C = b.xs; g.ldc = D; g.M = NT; g.N = D;
   g.K = c->first_k_pad; g.bias = w->first_b; g.dtype = MH_F32; g.epilogue = MH_EPI_STORE_F32;
+  g.stats_out = fuse_ln ? b.stats : nullptr;
   MH_TRY(gemm(g, s));
   for (int l = 0; l < c->depth; ++l) {
     const float* mod = b.cond_cur + (long)l * 6 * D;
     // attention branch
-    MH_TRY(ln_modulate(b.xs, D, mod + 0 * D, mod + 1 * D, ld_row, T, b.xm, D, NT, D, 1e-6f, s));
     g = MhGemm{};
-    g.A = b.xm; g.lda = D; g.W = w->qkv_w[l]; g.ldw = D; g.C = b.qk; g.ldc = 2 * D; g.M = NT; g.N = 3 * D; g.K = D;
+    g.A = b.xs; g.lda = D; g.W = w->qkv_w[l]; g.ldw = D; g.C = b.qk; g.ldc = 2 * D; g.M = NT; g.N = 3 * D; g.K = D;
     g.bias = w->qkv_b[l]; g.dtype = MH_F32; g.epilogue = MH_EPI_QKV_VT; g.C2 = b.vt; g.n_split = 2 * D; g.kv_B = N;
     g.kv_H = H; g.kv_L = T; g.kv_Lpad = b.Tpad;
+    if (fuse_ln) {
+      g.ln_stats = b.stats; g.ln_strips = strips; g.ln_shift = mod + 0 * D; g.ln_scale = mod + 1 * D; g.ln_ld = ld_row;
+      g.ln_eps = 1e-6f; g.rows_per_batch = T;
+    } else {
+      MH_TRY(ln_modulate(b.xs, D, mod + 0 * D, mod + 1 * D, ld_row, T, b.xm, D, NT, D, 1e-6f, s));
+      g.A = b.xm;
+    }
     MH_TRY(gemm(g, s));
     MH_TRY(attention(b.qk, 2 * D, D, b.vt, b.Tpad, nullptr, b.attn, D, N, T, H, 0.125f, band, MH_F32, s));
     g = MhGemm{};
     g.A = b.attn; g.lda = D; g.W = w->out_w[l]; g.ldw = D; g.C = b.xs; g.ldc = D; g.M = NT; g.N = D; g.K = D;
     g.bias = w->out_b[l]; g.gate = mod + 2 * D; g.gate_ld = ld_row; g.rows_per_batch = T; g.dtype = MH_F32;
-    g.epilogue = MH_EPI_GATE_RESID;
+    g.epilogue = MH_EPI_GATE_RESID; g.stats_out = fuse_ln ? b.stats : nullptr;
     MH_TRY(gemm(g, s));
     // MLP branch
-    MH_TRY(ln_modulate(b.xs, D, mod + 3 * D, mod + 4 * D, ld_row, T, b.xm, D, NT, D, 1e-6f, s));
     g = MhGemm{};
-    g.A = b.xm; g.lda = D; g.W = w->fc1_w[l]; g.ldw = D; g.C = b.hid; g.ldc = 4 * D; g.M = NT; g.N = 4 * D; g.K = D;
+    g.A = b.xs; g.lda = D; g.W = w->fc1_w[l]; g.ldw = D; g.C = b.hid; g.ldc = 4 * D; g.M = NT; g.N = 4 * D; g.K = D;
     g.bias = w->fc1_b[l]; g.dtype = MH_F32; g.epilogue = MH_EPI_BIAS_GELU;
+    if (fuse_ln) {
+      g.ln_stats = b.stats; g.ln_strips = strips; g.ln_shift = mod + 3 * D; g.ln_scale = mod + 4 * D; g.ln_ld = ld_row;
+      g.ln_eps = 1e-6f; g.rows_per_batch = T;
+    } else {
+      MH_TRY(ln_modulate(b.xs, D, mod + 3 * D, mod + 4 * D, ld_row, T, b.xm, D, NT, D, 1e-6f, s));
+      g.A = b.xm;
+    }
     MH_TRY(gemm(g, s));
     g = MhGemm{};
     g.A = b.hid; g.lda = 4 * D; g.W = w->fc2_w[l]; g.ldw = 4 * D; g.C = b.xs; g.ldc = D; g.M = NT; g.N = D; g.K = 4 * D;
     g.bias = w->fc2_b[l]; g.gate = mod + 5 * D; g.gate_ld = ld_row; g.rows_per_batch = T; g.dtype = MH_F32;
-    g.epilogue = MH_EPI_GATE_RESID;
+    g.epilogue = MH_EPI_GATE_RESID; g.stats_out = fuse_ln ? b.stats : nullptr;
     MH_TRY(gemm(g, s));
   }
   const float* modf = b.cond_cur + (long)c->depth * 6 * D;

@@ -5,6 +5,8 @@
 //   K step = 128 bytes per row (64 bf16 / 32 f32) staged with 16-byte loads; LDS rows padded by 16 B.
 //   MFMA atom: v_mfma_f32_16x16x32_bf16 (bf16 storage) or the exact v_mfma_f32_16x16x4_f32 (f32).
 // Both operands are K-contiguous ("B^T input"), which is the nn.Linear weight layout -- no transposes.
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace mh {
@@ -26,6 +28,9 @@ struct GemmP {
   int kv_B, kv_H, kv_L;
   void* C2; int n_split; int kv_Lpad;
   void* C3; void* C4; int cache_len;
+  float* stats_out;                                   // producer: [ceil(N/16)][M][2] row sums / sums of squares
+  const float* ln_stats; int ln_strips;               // consumer: LayerNorm + modulate applied to the A operand (f32)
+  const float* ln_shift; const float* ln_scale; int ln_ld; float ln_eps;
 };
 
 // `v` already contains the bias; `old` = previous C value (RESID / GATE_RESID), `g` = gate value, `v2` = paired
@@ -130,11 +135,17 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmP p) {
   // Measured: D = 4 made the small (M = 256) fp32 GEMMs of the DiT SLOWER (140 -> 188 ms per 100 steps): those are
   // bound by the per-wave MFMA issue time of a K step (32 x 32-cycle f32 MFMAs), not by load latency; what helps
   // them is more workgroups (the 32x32 tile below).  D stays 1.
-  constexpr int D = 1;
+  constexpr int D = 1;   // (D = 3 on the 32x32 tile, K = 384 all in flight: 97.1 vs 95.1 ms per 100 DiT-S steps)
   uint4 ra[D][A_CHUNKS], rb[D][B_CHUNKS];
   const int nk = (p.K + BK - 1) / BK;
 
-  auto load_tiles = [&](int kt, uint4 (&xa)[A_CHUNKS], uint4 (&xb)[B_CHUNKS]) {
+  // fused LayerNorm + adaLN modulate on the A operand (fp32 activations of the DiT): mean / rstd of this tile's rows
+  // from the producer's per-strip sums, kept in LDS behind the two tile stages
+  constexpr bool kLnCapable = std::is_same<T, float>::value;
+  const bool ln = kLnCapable && p.ln_stats != nullptr;   // block-uniform
+  float* lnst = reinterpret_cast<float*>(smem + 2 * kBufBytes);
+  uint4 rsc[D][kLnCapable ? A_CHUNKS : 1], rsh[D][kLnCapable ? A_CHUNKS : 1];
+  auto load_tiles = [&](int kt, uint4 (&xa)[A_CHUNKS], uint4 (&xb)[B_CHUNKS], uint4* xsc, uint4* xsh) {
     const int k_el = kt * BK + cchunk * VEC;
     const bool kin = k_el < p.K;
     const long k_off = (long)(kin ? k_el : 0) * sizeof(T);   // clamped address, value masked below (no predicated load)
@@ -145,6 +156,11 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmP p) {
       r = r < p.M ? r : p.M - 1;
       const uint4 t = *reinterpret_cast<const uint4*>(p.A + (long)r * p.lda_b + k_off);
       xa[i] = make_uint4(t.x & keep, t.y & keep, t.z & keep, t.w & keep);
+      if (kLnCapable && ln) {   // block-uniform branch; modulation vectors of this row's batch entry, same k range
+        const long mo = (long)(r / p.rows_per_batch) * p.ln_ld + (kin ? k_el : 0);
+        xsc[i] = *reinterpret_cast<const uint4*>(p.ln_scale + mo);
+        xsh[i] = *reinterpret_cast<const uint4*>(p.ln_shift + mo);
+      }
     }
 #pragma unroll
     for (int i = 0; i < B_CHUNKS; ++i) {
@@ -154,10 +170,22 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmP p) {
       xb[i] = make_uint4(t.x & keep, t.y & keep, t.z & keep, t.w & keep);
     }
   };
-  auto store_tiles = [&](int buf, const uint4 (&xa)[A_CHUNKS], const uint4 (&xb)[B_CHUNKS]) {
+  auto store_tiles = [&](int buf, int kt, const uint4 (&xa)[A_CHUNKS], const uint4 (&xb)[B_CHUNKS], const uint4* xsc,
+                         const uint4* xsh) {
 #pragma unroll
-    for (int i = 0; i < A_CHUNKS; ++i)
-      *reinterpret_cast<uint4*>(smem + buf * kBufBytes + (crow + RPP * i) * kRowStride + cchunk * 16) = xa[i];
+    for (int i = 0; i < A_CHUNKS; ++i) {
+      uint4 v = xa[i];
+      if (kLnCapable && ln) {
+        const bool kin = kt * BK + cchunk * VEC < p.K;   // K-tail columns stay zero
+        const float mu = lnst[2 * (crow + RPP * i)], rs = lnst[2 * (crow + RPP * i) + 1];
+        const float m = kin ? 1.f : 0.f;
+        v.x = __float_as_uint(m * ((__uint_as_float(v.x) - mu) * rs * (1.f + __uint_as_float(xsc[i].x)) + __uint_as_float(xsh[i].x)));
+        v.y = __float_as_uint(m * ((__uint_as_float(v.y) - mu) * rs * (1.f + __uint_as_float(xsc[i].y)) + __uint_as_float(xsh[i].y)));
+        v.z = __float_as_uint(m * ((__uint_as_float(v.z) - mu) * rs * (1.f + __uint_as_float(xsc[i].z)) + __uint_as_float(xsh[i].z)));
+        v.w = __float_as_uint(m * ((__uint_as_float(v.w) - mu) * rs * (1.f + __uint_as_float(xsc[i].w)) + __uint_as_float(xsh[i].w)));
+      }
+      *reinterpret_cast<uint4*>(smem + buf * kBufBytes + (crow + RPP * i) * kRowStride + cchunk * 16) = v;
+    }
 #pragma unroll
     for (int i = 0; i < B_CHUNKS; ++i)
       *reinterpret_cast<uint4*>(smem + buf * kBufBytes + (BM + crow + RPP * i) * kRowStride + cchunk * 16) = xb[i];
@@ -171,8 +199,67 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmP p) {
 
 #pragma unroll
   for (int d = 0; d < D; ++d)
-    if (d < nk) load_tiles(d, ra[d], rb[d]);
-  store_tiles(0, ra[0], rb[0]);
+    if (d < nk) load_tiles(d, ra[d], rb[d], rsc[d], rsh[d]);
+  // (the LayerNorm statistics below are requested after the first operand tiles: one round trip covers both)
+  // small tile: the epilogue's old C / gate values do not depend on the product either -- requested here, not after it
+  constexpr bool kReadsC = (EPI == MH_EPI_RESID || EPI == MH_EPI_GATE_RESID);
+  constexpr bool kPreEpi = kReadsC && BM == 32;
+  const int erow0 = m0 + wr * WM + (lane >> 4) * 4;
+  const int ecol0 = n0 + wc * WN + (lane & 15);
+  f32x4_t pre_old[kPreEpi ? MI : 1][kPreEpi ? NI : 1], pre_g[kPreEpi ? MI : 1][kPreEpi ? NI : 1];
+  if constexpr (kPreEpi) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int row = erow0 + i * 16 + r;
+        row = row < p.M ? row : p.M - 1;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          int c = ecol0 + j * 16;
+          c = c < p.N ? c : p.N - 1;
+          pre_old[i][j][r] = reinterpret_cast<const float*>(p.C)[(long)row * p.ldc + c];
+          pre_g[i][j][r] = (EPI == MH_EPI_GATE_RESID) ? p.gate[(long)(row / p.rows_per_batch) * p.gate_ld + c] : 0.f;
+        }
+      }
+  }
+  if (ln) {
+    // 256 threads = NG strip groups x BM rows; every thread has its (<= 8 per pass) strip loads in flight at once
+    // (a serial loop over the strips costs one L2 round trip per strip: measured +6 ms per 100 DiT steps)
+    constexpr int NG = 256 / BM;
+    float* red = lnst + 2 * BM;   // [NG][BM][2]
+    const int row_l = tid % BM, sg = tid / BM;
+    const int row = (m0 + row_l) < p.M ? (m0 + row_l) : p.M - 1;
+    float s1 = 0.f, s2 = 0.f;
+    for (int base = 0; base < p.ln_strips; base += 8 * NG) {
+      float2 v[8];
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int st = base + sg + it * NG;
+        v[it] = *reinterpret_cast<const float2*>(p.ln_stats + ((long)(st < p.ln_strips ? st : 0) * p.M + row) * 2);
+      }
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const bool ok = base + sg + it * NG < p.ln_strips;
+        s1 += ok ? v[it].x : 0.f;
+        s2 += ok ? v[it].y : 0.f;
+      }
+    }
+    red[(sg * BM + row_l) * 2] = s1;
+    red[(sg * BM + row_l) * 2 + 1] = s2;
+    __syncthreads();
+    if (tid < BM) {
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int gq = 0; gq < NG; ++gq) { t1 += red[(gq * BM + tid) * 2]; t2 += red[(gq * BM + tid) * 2 + 1]; }
+      const float mu = t1 / (float)p.K;
+      const float var = fmaxf(t2 / (float)p.K - mu * mu, 0.f);
+      lnst[2 * tid] = mu;
+      lnst[2 * tid + 1] = rsqrtf(var + p.ln_eps);
+    }
+    __syncthreads();
+  }
+  store_tiles(0, 0, ra[0], rb[0], rsc[0], rsh[0]);
   __syncthreads();
 
   const int frow = lane & 15, fk = (lane >> 4) * KCH;
@@ -182,7 +269,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmP p) {
       const int kt = kt0 + d;
       if (kt >= nk) break;
       const int cur = kt & 1;
-      if (kt + D < nk) load_tiles(kt + D, ra[d], rb[d]);   // slot d was drained into LDS one iteration ago
+      if (kt + D < nk) load_tiles(kt + D, ra[d], rb[d], rsc[d], rsh[d]);   // slot d was drained into LDS one iteration ago
       const char* a_base = smem + cur * kBufBytes + (wr * WM + frow) * kRowStride + fk * (int)sizeof(T);
       const char* b_base = smem + cur * kBufBytes + (BM + wc * WN + frow) * kRowStride + fk * (int)sizeof(T);
 #pragma unroll
@@ -199,15 +286,12 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmP p) {
 #pragma unroll
           for (int j = 0; j < NI; ++j) acc[i][j] = Atom<T>::mma(af[i], bf[j], acc[i][j]);
       }
-      if (kt + 1 < nk) store_tiles(cur ^ 1, ra[(d + 1) % D], rb[(d + 1) % D]);
+      if (kt + 1 < nk) store_tiles(cur ^ 1, kt + 1, ra[(d + 1) % D], rb[(d + 1) % D], rsc[(d + 1) % D], rsh[(d + 1) % D]);
       __syncthreads();
     }
   }
 
   // epilogue: acc[i][j][r] = C[m0 + wr*WM + i*16 + (lane>>4)*4 + r][n0 + wc*WN + j*16 + (lane&15)]
-  const int erow0 = m0 + wr * WM + (lane >> 4) * 4;
-  const int ecol0 = n0 + wc * WN + (lane & 15);
-  constexpr bool kReadsC = (EPI == MH_EPI_RESID || EPI == MH_EPI_GATE_RESID);
   constexpr bool kPos = (EPI == MH_EPI_BIAS_GELU_ERF);
   float bias_v[NI];
 #pragma unroll
@@ -239,7 +323,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmP p) {
         }
       }
     }
-    if (kReadsC) {   // unconditional loads from clamped addresses, all in flight before the first store
+    if constexpr (kPreEpi) {
+#pragma unroll
+      for (int j = 0; j < NI; ++j) { oldv[j] = pre_old[i][j]; gv[j] = pre_g[i][j]; }
+    } else if (kReadsC) {   // unconditional loads from clamped addresses, all in flight before the first store
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         int row = erow0 + i * 16 + r;
@@ -268,6 +355,21 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmP p) {
         for (int j = 0; j < NI; ++j)
           epilogue_store<T, EPI>(p, row, ecol0 + j * 16, acc[i][j][r] + bias_v[j], 0.f, kReadsC ? oldv[j][r] : 0.f,
                                  (kReadsC || kPos) ? gv[j][r] : 0.f);
+        if constexpr (EPI == MH_EPI_STORE_F32 || EPI == MH_EPI_GATE_RESID) {
+          if (p.stats_out) {   // block-uniform: row sums of the values just stored, one (sum, sum of squares) per 16 columns
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+              const float lin = acc[i][j][r] + bias_v[j];
+              float o = (EPI == MH_EPI_GATE_RESID) ? oldv[j][r] + gv[j][r] * lin : lin;
+              o = (row < p.M && ecol0 + j * 16 < p.N) ? o : 0.f;
+              const float s1 = group_sum<16>(o), s2 = group_sum<16>(o * o);
+              if ((lane & 15) == 0 && row < p.M) {
+                const int strip = (n0 + wc * WN + j * 16) >> 4;
+                *reinterpret_cast<float2*>(p.stats_out + ((long)strip * p.M + row) * 2) = make_float2(s1, s2);
+              }
+            }
+          }
+        }
       }
     }
   }
@@ -276,7 +378,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmP p) {
 template <typename T, int BM, int BN, int EPI>
 int launch_gemm(const GemmP& p, hipStream_t s) {
   const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
-  const size_t smem = 2 * (size_t)(BM + BN) * (RowBytes<BM>::v + 16);
+  const size_t smem = 2 * (size_t)(BM + BN) * (RowBytes<BM>::v + 16) + BM * 8 + 2048;   // + LayerNorm statistics
   hipLaunchKernelGGL((gemm_tn_kernel<T, BM, BN, EPI>), dim3(nbm * nbn), dim3(256), smem, s, p);
   return check_launch("gemm_tn_kernel");
 }
@@ -285,7 +387,7 @@ int launch_gemm(const GemmP& p, hipStream_t s) {
 // outside any stream capture (gemm_prepare()).
 template <typename T, int BM, int BN, int EPI>
 bool prepare_one() {
-  const size_t smem = 2 * (size_t)(BM + BN) * (RowBytes<BM>::v + 16);
+  const size_t smem = 2 * (size_t)(BM + BN) * (RowBytes<BM>::v + 16) + BM * 8 + 2048;   // + LayerNorm statistics
   return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel<T, BM, BN, EPI>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) == hipSuccess;
 }
@@ -383,6 +485,14 @@ int gemm(const MhGemm& g, hipStream_t s) {
   p.M = g.M; p.N = g.N; p.K = g.K;
   p.bias = g.bias; p.gate = g.gate; p.gate_ld = g.gate_ld; p.rows_per_batch = g.rows_per_batch;
   p.kv_B = g.kv_B; p.kv_H = g.kv_H; p.kv_L = g.kv_L;
+  p.stats_out = g.stats_out; p.ln_stats = g.ln_stats; p.ln_strips = g.ln_strips; p.ln_shift = g.ln_shift;
+  p.ln_scale = g.ln_scale; p.ln_ld = g.ln_ld; p.ln_eps = g.ln_eps;
+  if (g.stats_out)
+    MH_REQUIRE((g.epilogue == MH_EPI_STORE_F32 || g.epilogue == MH_EPI_GATE_RESID) && g.N % 16 == 0,
+               "mh_gemm: stats_out needs a fp32-output epilogue (STORE_F32 / GATE_RESID) and N %% 16 == 0");
+  if (g.ln_stats)
+    MH_REQUIRE(g.dtype == MH_F32 && g.ln_shift && g.ln_scale && g.ln_strips > 0 && g.rows_per_batch > 0 && g.ln_ld >= g.K,
+               "mh_gemm: the fused LayerNorm-modulate prologue is fp32 only and needs shift / scale / strips / rows_per_batch");
   if (g.dtype == MH_BF16) return dispatch_epi<bf16_t>(p, g.epilogue, s);
   return dispatch_epi<float>(p, g.epilogue, s);
 }
