@@ -16,7 +16,7 @@ namespace {
 // K-step bytes per tile row: 128 for the big tiles; 512 for the 32x32 tile, whose problems (DiT, M = 256) are
 // bound by the global-load latency of a K step (~1 us per step whatever the tile: measured), so it takes 4x
 // fewer, 4x fatter steps with 8 loads in flight per thread.
-template <int BM> struct RowBytes { static constexpr int v = (BM == 32) ? 512 : 128; };
+template <int BM> struct RowBytes { static constexpr int v = (BM <= 32) ? 512 : 128; };
 
 struct GemmP {
   const char* A; long lda_b;  // leading dimension in BYTES
@@ -105,7 +105,12 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmP p) {
   constexpr int BK = kRowBytes / (int)sizeof(T);
   constexpr int KM = Atom<T>::KM;
   constexpr int KCH = Atom<T>::KCH;
-  constexpr int WM = BM / 2, WN = BN / 2;     // wave tile
+  // BM = BN = 16: ONE 16x16 output tile per workgroup, its 4 waves split every K step four ways and the partial
+  // accumulators are added through LDS in wave order (deterministic).  For the tiny fp32 GEMMs of the DiT (M = 256
+  // rows, N = 384) this gives 4x the workgroups of the 32x32 tile and a quarter of the per-wave MFMA time.
+  constexpr bool kSplitK = (BM == 16);
+  static_assert(!kSplitK || BN == 16, "split-K tile is 16x16");
+  constexpr int WM = kSplitK ? 16 : BM / 2, WN = kSplitK ? 16 : BN / 2;     // wave tile
   constexpr int MI = WM / 16, NI = WN / 16;
   constexpr int A_CHUNKS = BM * CPR / 256;    // 16-byte chunks per thread for the A tile
   constexpr int B_CHUNKS = BN * CPR / 256;
@@ -114,7 +119,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmP p) {
   constexpr int kBufBytes = (BM + BN) * kRowStride;  // one (A tile, B tile) stage
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wr = wid >> 1, wc = wid & 1;
+  const int wr = kSplitK ? 0 : wid >> 1, wc = kSplitK ? 0 : wid & 1;
 
   // XCD-aware tile order: consecutive tiles that share an A panel land on the same XCD (8 XCDs,
   // block b -> XCD b % 8 as dispatched).  Bijective remap for any grid size.
@@ -203,7 +208,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmP p) {
   // (the LayerNorm statistics below are requested after the first operand tiles: one round trip covers both)
   // small tile: the epilogue's old C / gate values do not depend on the product either -- requested here, not after it
   constexpr bool kReadsC = (EPI == MH_EPI_RESID || EPI == MH_EPI_GATE_RESID);
-  constexpr bool kPreEpi = kReadsC && BM == 32;
+  constexpr bool kPreEpi = kReadsC && BM <= 32;
   const int erow0 = m0 + wr * WM + (lane >> 4) * 4;
   const int ecol0 = n0 + wc * WN + (lane & 15);
   f32x4_t pre_old[kPreEpi ? MI : 1][kPreEpi ? NI : 1], pre_g[kPreEpi ? MI : 1][kPreEpi ? NI : 1];
@@ -272,8 +277,12 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmP p) {
       if (kt + D < nk) load_tiles(kt + D, ra[d], rb[d], rsc[d], rsh[d]);   // slot d was drained into LDS one iteration ago
       const char* a_base = smem + cur * kBufBytes + (wr * WM + frow) * kRowStride + fk * (int)sizeof(T);
       const char* b_base = smem + cur * kBufBytes + (BM + wc * WN + frow) * kRowStride + fk * (int)sizeof(T);
+      constexpr int kKs = BK / KM, kKsW = kSplitK ? kKs / 4 : kKs;
+      static_assert(!kSplitK || kKs % 4 == 0, "K step not divisible among the 4 waves");
+      const int ks0 = kSplitK ? wid * kKsW : 0;
 #pragma unroll
-      for (int ks = 0; ks < BK / KM; ++ks) {
+      for (int kq = 0; kq < kKsW; ++kq) {
+        const int ks = ks0 + kq;
         typename Atom<T>::frag_t af[MI], bf[NI];
 #pragma unroll
         for (int i = 0; i < MI; ++i)
@@ -291,6 +300,19 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmP p) {
     }
   }
 
+  if constexpr (kSplitK) {   // (the K loop ended with a barrier: the tile stages are free)
+    f32x4_t* red = reinterpret_cast<f32x4_t*>(smem);
+    red[wid * 64 + lane] = acc[0][0];
+    __syncthreads();
+    if (wid != 0) return;
+    f32x4_t v = red[lane];
+#pragma unroll
+    for (int w2 = 1; w2 < 4; ++w2) {
+      const f32x4_t t = red[w2 * 64 + lane];
+      v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
+    }
+    acc[0][0] = v;
+  }
   // epilogue: acc[i][j][r] = C[m0 + wr*WM + i*16 + (lane>>4)*4 + r][n0 + wc*WN + j*16 + (lane&15)]
   constexpr bool kPos = (EPI == MH_EPI_BIAS_GELU_ERF);
   float bias_v[NI];
@@ -394,7 +416,7 @@ bool prepare_one() {
 template <typename T, int EPI>
 bool prepare_epi() {
   bool ok = prepare_one<T, 128, 128, EPI>() && prepare_one<T, 64, 64, EPI>();
-  if constexpr (EPI != MH_EPI_GEGLU) ok = ok && prepare_one<T, 32, 32, EPI>();   // GEGLU pairs two 16-col blocks per wave
+  if constexpr (EPI != MH_EPI_GEGLU) ok = ok && prepare_one<T, 32, 32, EPI>() && prepare_one<T, 16, 16, EPI>();   // GEGLU pairs two 16-col blocks per wave
   return ok;
 }
 template <typename T>
@@ -403,6 +425,16 @@ bool prepare_type() {
          prepare_epi<T, MH_EPI_GEGLU>() && prepare_epi<T, MH_EPI_BIAS_GELU>() && prepare_epi<T, MH_EPI_GATE_RESID>() &&
          prepare_epi<T, MH_EPI_KV_SCATTER>() && prepare_epi<T, MH_EPI_QKV_VT>() && prepare_epi<T, MH_EPI_QKV_CACHE>() &&
          prepare_epi<T, MH_EPI_BIAS_GELU_ERF>();
+}
+
+// below this many 32x32 tiles the 16x16 split-K tile is used (MH_GEMM_SPLITK_TILES overrides, 0 = never)
+long splitk_threshold() {
+  static long v = -1;
+  if (v < 0) {
+    const char* e = getenv("MH_GEMM_SPLITK_TILES");
+    v = e ? atol(e) : 192;
+  }
+  return v;
 }
 
 template <typename T, int EPI>
@@ -416,7 +448,9 @@ int dispatch_tile(const GemmP& p, hipStream_t s) {
     return launch_gemm<T, 64, 64, EPI>(p, s);
   } else {
     if (tiles64 >= 192) return launch_gemm<T, 64, 64, EPI>(p, s);
-    return launch_gemm<T, 32, 32, EPI>(p, s);
+    const long tiles32 = (long)((p.M + 31) / 32) * ((p.N + 31) / 32);
+    if (tiles32 >= splitk_threshold()) return launch_gemm<T, 32, 32, EPI>(p, s);
+    return launch_gemm<T, 16, 16, EPI>(p, s);
   }
 }
 
