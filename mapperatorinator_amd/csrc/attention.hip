@@ -255,11 +255,153 @@ int attention_general(const AttnArgs& a, int B, int H, int dtype, hipStream_t s)
   return check_launch("flash_attn_kernel");
 }
 
+namespace {
+
+// Short-sequence fp32 attention (the DiT at T <= 64 KBW keys): the flash kernel above gives a 128-point window 24
+// workgroups whose waves each walk every key tile; here a workgroup owns 16 query rows of one (batch, head) and its
+// 4 waves split the KEYS (KBW 16-key blocks each, operands straight from L2 into MFMA fragments, no LDS staging),
+// then merge their (max, sum, O) through LDS in wave order.  8x the workgroups, a quarter of the per-wave MFMA chain.
+struct SmallAttnP {
+  const float* q; const float* k; const float* vt; float* out;
+  long ld_qk, vt_hs, vt_bs; int ld_out;
+  int L, Lpad, H, band;
+  float scale;
+};
+
+template <int KBW>
+__global__ __launch_bounds__(256) void attn_small_f32_kernel(SmallAttnP p) {
+  constexpr int PW = KBW * 16 + 4;                 // P patch row stride (floats)
+  __shared__ float Ps[4][16][PW];
+  __shared__ float m_s[4][16], l_s[4][16];
+  __shared__ __attribute__((aligned(16))) float O_s[4][16][64];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int q0 = blockIdx.x * 16, h = blockIdx.y, b = blockIdx.z;
+  const int L = p.L;
+  const int kbase = wid * KBW * 16;                // this wave's first key
+  const float* qrow = p.q + ((long)b * L + (q0 + l15 < L ? q0 + l15 : L - 1)) * p.ld_qk + h * 64 + lg;
+  // operands: every load is independent of every other -- all requested before the first MFMA
+  float qf[16], kf[KBW][16], vf[4][KBW * 4];
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) qf[ks] = qrow[ks * 4];
+#pragma unroll
+  for (int kb = 0; kb < KBW; ++kb) {
+    const int key = kbase + kb * 16 + l15;
+    const float* krow = p.k + ((long)b * L + (key < L ? key : L - 1)) * p.ld_qk + h * 64 + lg;
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) kf[kb][ks] = krow[ks * 4];
+  }
+  const float* vtb = p.vt + (long)b * p.vt_bs + (long)h * p.vt_hs;
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+#pragma unroll
+    for (int kk = 0; kk < KBW * 4; ++kk) {
+      const int key = kbase + kk * 4 + lg;
+      vf[db][kk] = vtb[(long)(db * 16 + l15) * p.Lpad + (key < L ? key : L - 1)];   // never a pad column (P is 0 there)
+    }
+  // S = scale * Q K^T with the band mask; C layout: col = l15 (key in block), row = lg*4 + r (query)
+  const int rel_lo = p.band > 0 ? -(p.band - 1) : -(1 << 30), rel_hi = p.band > 0 ? p.band : (1 << 30);   // band 0 = open
+  f32x4_t sc[KBW];
+  float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+  for (int kb = 0; kb < KBW; ++kb) {
+    f32x4_t a = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) a = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[ks], kf[kb][ks], a, 0, 0, 0);
+    const int key = kbase + kb * 16 + l15;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int rel = key - (q0 + lg * 4 + r);
+      const bool ok = (key < L) && (rel >= rel_lo) && (rel <= rel_hi);
+      a[r] = ok ? a[r] * p.scale : -INFINITY;
+      m[r] = fmaxf(m[r], a[r]);
+    }
+    sc[kb] = a;
+  }
+  float l[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) m[r] = fmaxf(m[r], __shfl_xor(m[r], o, 64));
+    float part = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < KBW; ++kb) {
+      const float pv = (m[r] == -INFINITY) ? 0.f : expf(sc[kb][r] - m[r]);
+      sc[kb][r] = pv;
+      part += pv;
+    }
+    l[r] = group_sum<16>(part);
+  }
+  // P: C layout -> A layout through the wave's LDS patch
+#pragma unroll
+  for (int kb = 0; kb < KBW; ++kb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Ps[wid][lg * 4 + r][kb * 16 + l15] = sc[kb][r];
+  __syncthreads();
+  f32x4_t o[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db) o[db] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kk = 0; kk < KBW * 4; ++kk) {
+    const float pf = Ps[wid][l15][kk * 4 + lg];
+#pragma unroll
+    for (int db = 0; db < 4; ++db) o[db] = __builtin_amdgcn_mfma_f32_16x16x4f32(pf, vf[db][kk], o[db], 0, 0, 0);
+  }
+  if (l15 == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { m_s[wid][lg * 4 + r] = m[r]; l_s[wid][lg * 4 + r] = l[r]; }
+  }
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) O_s[wid][lg * 4 + r][db * 16 + l15] = o[db][r];
+  __syncthreads();
+  // merge the 4 key ranges in wave order: thread -> (row = tid / 16, 4 consecutive dims)
+  const int row = tid >> 4, d0 = (tid & 15) * 4;
+  float M = fmaxf(fmaxf(m_s[0][row], m_s[1][row]), fmaxf(m_s[2][row], m_s[3][row]));
+  float Ls = 0.f;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const float f = (m_s[w][row] == -INFINITY) ? 0.f : expf(m_s[w][row] - M);
+    Ls += l_s[w][row] * f;
+    const float4 ov = *reinterpret_cast<const float4*>(&O_s[w][row][d0]);
+    acc.x += ov.x * f; acc.y += ov.y * f; acc.z += ov.z * f; acc.w += ov.w * f;
+  }
+  if (q0 + row < L) {
+    const float inv = Ls > 0.f ? 1.f / Ls : 0.f;
+    *reinterpret_cast<float4*>(p.out + ((long)b * L + q0 + row) * p.ld_out + h * 64 + d0) =
+        make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+  }
+}
+
+// MH_ATTN_SMALL=0 routes the short fp32 sequences through the flash kernel again
+bool small_attn_enabled() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("MH_ATTN_SMALL");
+    v = (e && atoi(e) == 0) ? 0 : 1;
+  }
+  return v == 1;
+}
+
+}  // namespace
+
 int attention(const void* qk, int ld_qk, int k_col0, const void* vt, int Lpad, const float* bias, void* out,
               int ld_out, int B, int L, int H, float scale, int band, int dtype, hipStream_t s) {
   MH_REQUIRE(qk && vt && out, "mh_attention: null operand");
   const int es = dtype == MH_BF16 ? 2 : 4;
   MH_REQUIRE((ld_qk * es) % 16 == 0 && (k_col0 * es) % 16 == 0, "mh_attention: rows must be 16-byte aligned");
+  if (dtype == MH_F32 && !bias && L <= 256 && ld_out % 4 == 0 && small_attn_enabled()) {
+    SmallAttnP sp{};
+    sp.q = (const float*)qk; sp.k = (const float*)qk + k_col0; sp.vt = (const float*)vt; sp.out = (float*)out;
+    sp.ld_qk = ld_qk; sp.vt_hs = 64L * Lpad; sp.vt_bs = (long)H * 64 * Lpad; sp.ld_out = ld_out;
+    sp.L = L; sp.Lpad = Lpad; sp.H = H; sp.band = band; sp.scale = scale;
+    dim3 grid(ceil_div(L, 16), H, B), block(256);
+    if (L <= 128) hipLaunchKernelGGL(attn_small_f32_kernel<2>, grid, block, 0, s, sp);
+    else hipLaunchKernelGGL(attn_small_f32_kernel<4>, grid, block, 0, s, sp);
+    return check_launch("attn_small_f32_kernel");
+  }
   AttnArgs a{};
   a.q = qk; a.q_rs = (long)ld_qk * es; a.q_bs = (long)L * ld_qk * es;
   a.k = (const char*)qk + (long)k_col0 * es; a.k_rs = (long)ld_qk * es; a.k_bs = (long)L * ld_qk * es; a.k_hs = 64L * es;

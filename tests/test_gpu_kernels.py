@@ -185,7 +185,12 @@ def ref_attention(q, k, v, bias=None, scale=1.0, band=0):
 @pytest.mark.parametrize("case", [dict(B=2, H=3, L=251, bias=True, scale=1.0, band=0),
                                   dict(B=1, H=2, L=1251, bias=True, scale=1.0, band=0),
                                   dict(B=2, H=2, L=400, bias=False, scale=0.125, band=128),
-                                  dict(B=2, H=1, L=96, bias=False, scale=0.125, band=128)])
+                                  dict(B=2, H=1, L=96, bias=False, scale=0.125, band=128),
+                                  # short fp32 sequences without bias take the key-split kernel (attn_small_f32_kernel)
+                                  dict(B=2, H=2, L=96, bias=False, scale=0.125, band=0),
+                                  dict(B=2, H=2, L=128, bias=False, scale=0.125, band=0),
+                                  dict(B=1, H=3, L=160, bias=False, scale=0.125, band=32),
+                                  dict(B=2, H=2, L=250, bias=False, scale=0.125, band=128)])
 def test_attention(dtype_name, case):
     L, lib = _lib()
     dt = L.MH_F32 if dtype_name == "f32" else L.MH_BF16
