@@ -58,6 +58,9 @@ typedef enum MhEpilogue {
 
 const char* mh_last_error(void);
 int mh_abi_version(void);
+/* sizeof() of the ABI structs as this library was compiled, so that a binding can verify its own layout:
+ * which = 0 MhGemm, 1 MhT5Config, 2 MhT5Weights, 3 MhSampling, 4 MhDiTConfig, 5 MhDiTWeights; -1 otherwise. */
+int mh_struct_size(int which);
 
 /* ------------------------------------------------------------------------------------------------
  * K1  mel frontend.  Replaces `nnAudio.features.MelSpectrogram` as constructed and called at

@@ -78,6 +78,7 @@ I, I64, F = C.c_int, C.c_int64, C.c_float
 SYMBOLS = {
     "mh_last_error": (C.c_char_p, []),
     "mh_abi_version": (I, []),
+    "mh_struct_size": (I, [I]),
     "mh_mel": (I, [VP, I, I, I, I, I, VP, VP, VP, VP, VP, VP, I, VP, I, I, VP]),
     "mh_gemm": (I, [C.POINTER(MhGemm), VP]),
     "mh_rmsnorm": (I, [VP, I, VP, VP, I, I, I, F, I, VP]),
@@ -128,6 +129,10 @@ def load():
         fn.argtypes = args
     if lib.mh_abi_version() != 2:
         raise RuntimeError("libmapperhip.so ABI version mismatch")
+    for which, st in enumerate((MhGemm, MhT5Config, MhT5Weights, MhSampling, MhDiTConfig, MhDiTWeights)):
+        if lib.mh_struct_size(which) != C.sizeof(st):
+            raise RuntimeError(f"libmapperhip.so: layout of {st.__name__} differs from the binding "
+                               f"({lib.mh_struct_size(which)} vs {C.sizeof(st)} bytes)")
     _lib = lib
     return lib
 

@@ -28,3 +28,15 @@ int check_launch(const char* what) {
 
 extern "C" const char* mh_last_error(void) { return mh::g_err; }
 extern "C" int mh_abi_version(void) { return MH_ABI_VERSION; }
+
+extern "C" int mh_struct_size(int which) {
+  switch (which) {
+    case 0: return (int)sizeof(MhGemm);
+    case 1: return (int)sizeof(MhT5Config);
+    case 2: return (int)sizeof(MhT5Weights);
+    case 3: return (int)sizeof(MhSampling);
+    case 4: return (int)sizeof(MhDiTConfig);
+    case 5: return (int)sizeof(MhDiTWeights);
+  }
+  return -1;
+}
