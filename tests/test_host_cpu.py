@@ -220,3 +220,9 @@ def test_diffusion_pipeline_host_glue():
     assert [repeat_type(r) for r in (1, 2, 3, 4, 5, 6, 7)] == [0, 1, 2, 3, 4, 3, 4]
     with pytest.raises(ValueError):
         points_to_sequence(x, y, times, dist, typ + 16)
+
+
+def test_graft_entry_build():
+    """The driver's build check: `make` (incremental) + dlopen + ABI / layout verification, no GPU needed."""
+    import __graft_entry__ as g
+    g.build()
