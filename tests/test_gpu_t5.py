@@ -109,17 +109,28 @@ def test_fp32_processors_and_cfg_match_reference_golden(run):
     print(run, "worst |dscore| vs reference", worst)
 
 
-def test_bf16_cfg_and_types_first_teacher_forced():
+@pytest.mark.parametrize("size", ["tiny", "base"])
+def test_bf16_cfg_and_types_first_teacher_forced(size):
     """bf16 storage under classifier-free guidance + the types_first processors, teacher-forced on the bf16-contract
     oracle's own ids: decisive steps agree; guided scores within 0.15 * (1 + 2 (cfg_scale - 1)) (the guidance
-    combination amplifies the per-row logit error by |1 - s| + |s|)."""
+    combination amplifies the per-row logit error by |1 - s| + |s|).  "base" = the BASELINE dims and the 1251-frame
+    encoder window (the d_model = 768 instantiations of the fused-projection kernels, K/V rows shared by a pair)."""
     from mapperatorinator_amd.server import build_sampling
+    from mapperatorinator_amd.t5_engine import T5_PRESETS
+    from mapperatorinator_amd.testing import boost_timed_rows, random_t5_state_dict, synthetic_audio
     g, tok, sd, audio, tgt, runs = types_first_case()
-    model = build("tiny", tok, sd, int(g["src"]), tgt, torch.bfloat16)
+    src = int(g["src"])
     prompt, neg = torch.from_numpy(g["prompt"]), torch.from_numpy(g["negative"])
+    if size == "base":
+        src, tgt = 1251, 20
+        sd = boost_timed_rows(random_t5_state_dict(T5_PRESETS["base"], tok.vocab_size_in, tok.vocab_size_out, seed=9,
+                                                   lm_head_gain=6.0), tok, float(g["timed_gain"]))
+        audio = synthetic_audio(2, 160000, seed=12)
+        prompt, neg = prompt[:2], neg[:2]
+    model = build(size, tok, sd, src, tgt, torch.bfloat16)
     kw = gen_kwargs(tgt, **runs["all"])
     sp, eos = build_sampling(tok, kw, tgt)
-    o = oracle_for("tiny", sd, rounding="bf16")
+    o = oracle_for(size, sd, rounding="bf16")
     enc_o = o.encode_audio(audio)
     okw = oracle_processor_kwargs(sp)
     sos = [sp.sos_ids[i] for i in range(sp.n_sos)]
