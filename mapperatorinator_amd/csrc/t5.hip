@@ -129,7 +129,8 @@ namespace {
 struct DecState {       // device-resident control block
   int pos;              // index of the token being fed this step
   int n_running;        // rows not yet finished (written by the sampler)
-  int pad0, pad1;
+  int ticket;           // arrival counter of the sampler's workgroups (the last one advances `pos`)
+  int pad1;
 };
 
 struct SampleP {
@@ -151,6 +152,7 @@ struct SampleP {
   int b0;                             // first global row of this chain; logits / h / ss are chain-local
   int pair;                           // CFG: distance between the negative-prompt row g and its prompt row g + pair
                                       //      (= B/2, single chain); 0 = no guidance
+  int chain_rows;                     // rows of this chain (both halves under CFG)
 };
 
 __device__ inline void update_ts_state(const MhSampling& sp, int tok, int32_t* last_ts_val) {
@@ -190,7 +192,7 @@ __global__ __launch_bounds__(256) void dec_init_kernel(SampleP p, int chain_rows
     p.last_ts_val[b] = v;
     p.finished[b] = 0;
     p.finish_col[b] = p.max_length - 1;
-    if (lb == 0) { p.st->pos = start_pos; p.st->n_running = chain_rows; }
+    if (lb == 0) { p.st->pos = start_pos; p.st->n_running = chain_rows; p.st->ticket = 0; }
   }
   __shared__ float scratch[8];
   const int tok = p.tokens[(long)b * p.max_length + start_pos];
@@ -428,7 +430,10 @@ __global__ __launch_bounds__(256) void dec_sample_kernel(SampleP p) {
         const int row = j == 0 ? b : bneg;
         p.tokens[(long)row * p.max_length + col] = emit;
         s_tok[j] = forced ? p.forced[(long)row * p.max_length + col] : emit;
-        if (done) { p.finished[row] = 1; p.finish_col[row] = col; }
+        if (done) {
+          __hip_atomic_store(&p.finished[row], (uint8_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // read by the last-arriving workgroup below
+          p.finish_col[row] = col;
+        }
       }
       update_ts_state(sp, s_tok[0], &p.last_ts_val[b]);
     }
@@ -447,14 +452,21 @@ __global__ __launch_bounds__(256) void dec_sample_kernel(SampleP p) {
     sq = block_sum(sq, sf);
     if (tid == 0) p.ss[lrow] = sq;   // RMSNorm statistics of the new residual row (one part)
   }
-}
-
-__global__ void dec_advance_kernel(DecState* st, const uint8_t* finished, int B) {
-  if (threadIdx.x == 0) {
-    int run = 0;
-    for (int b = 0; b < B; ++b) run += finished[b] ? 0 : 1;
-    st->n_running = run;
-    st->pos = st->pos + 1;
+  // Step bookkeeping without a launch of its own: every workgroup read `pos` when it started, so the one that arrives
+  // last may advance it; it also recounts the running rows for the host's early-stop poll.  The `finished` flags are
+  // agent-scope stores drained before the ticket is taken and agent-scope loads here (write-through hand-off, no
+  // fence); a stale flag could only delay the early stop by a poll, never change a token.
+  if (tid == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int t = __hip_atomic_fetch_add(&p.st->ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == (int)gridDim.x - 1) {
+      __hip_atomic_store(&p.st->ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int run = 0;
+      for (int i = 0; i < p.chain_rows; ++i)
+        run += __hip_atomic_load(&p.finished[p.b0 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 0 : 1;
+      p.st->n_running = run;
+      p.st->pos = pos + 1;
+    }
   }
 }
 
@@ -666,8 +678,6 @@ int enqueue_step(const MhT5Config* c, const MhT5Weights* w, const void* cross_kv
   MH_TRY((skinny<T, 1, dec::PRO_RMSNORM, dec::SK_LOGITS>(sk, s)));
   hipLaunchKernelGGL(dec_sample_kernel<T>, dim3(smp.pair > 0 ? smp.pair : B), dim3(256), 0, s, smp);
   MH_TRY(check_launch("dec_sample_kernel"));
-  hipLaunchKernelGGL(dec_advance_kernel, dim3(1), dim3(64), 0, s, bf.st, bf.finished, B);
-  MH_TRY(check_launch("dec_advance_kernel"));
   return MH_OK;
 }
 
@@ -964,7 +974,7 @@ extern "C" int mh_t5_generate(const MhT5Config* c, const MhT5Weights* w, const v
     smp.forced = forced; smp.eos_table = eos_table; smp.finished = all.finished; smp.finish_col = all.finish_col;
     smp.last_ts_val = all.last_ts; smp.logits_dump = logits_dump; smp.dec_embed = w->dec_embed; smp.h = bf.h;
     smp.d = d; smp.ss = bf.ss; smp.sp = *sp; smp.st = bf.st; smp.B = B; smp.P = P; smp.b0 = b0;
-    smp.proc = proc; smp.hist_scores = hist_scores; smp.pair = cfg ? B / 2 : 0;
+    smp.proc = proc; smp.hist_scores = hist_scores; smp.pair = cfg ? B / 2 : 0; smp.chain_rows = Bc;
 
     if (bf16) hipLaunchKernelGGL(dec_init_kernel<bf16_t>, dim3(Bc), dim3(256), 0, cs, smp, Bc, start_pos);
     else hipLaunchKernelGGL(dec_init_kernel<float>, dim3(Bc), dim3(256), 0, cs, smp, Bc, start_pos);
