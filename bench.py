@@ -85,6 +85,27 @@ def cpu_baseline(size: str, vocab, seconds_budget: float = 25.0):
                       f"({n_tok / t_dec:.1f} tok/s decode-only); value = 384 / (encoder s per chunk + 384 x decode s per token)"}
 
 
+def cpu_dit_baseline(n_steps: int = 6):
+    """The DiT-S denoiser of configs[2] through the CPU oracle (oracle/dit.py: the checker, timed here as the `port`
+    baseline of the diffusion metric): `n_steps` forward_with_cfg calls at Tq = 128, CFG batch 2."""
+    from mapperatorinator_amd.testing import DIT_PRESETS, random_dit_state_dict, synthetic_dit_inputs
+    from oracle import dit as odit
+    cores = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(cores)
+    depth, hidden, heads = DIT_PRESETS["DiT-S"]
+    orc = odit.DiTOracle(random_dit_state_dict(depth, hidden, seed=0), depth, hidden, heads)
+    z, c, y = synthetic_dit_inputs(128, seed=0)
+    t = torch.full((2,), 50, dtype=torch.long)
+    orc.forward_with_cfg(z, t, c, y, 1.0)                     # warm-up
+    t0 = time.perf_counter()
+    for _ in range(n_steps):
+        orc.forward_with_cfg(z, t, c, y, 1.0)
+    dt = (time.perf_counter() - t0) / n_steps
+    return {"value": round(1.0 / dt, 2), "unit": "diffusion steps/s per chunk", "cores": cores, "kind": "port",
+            "sample": f"oracle/dit.py DiT-S fp32, Tq=128, CFG batch 2, {n_steps} denoiser calls ({dt * 1e3:.1f} ms each); the "
+                      f"DDPM update itself is negligible"}
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -219,6 +240,11 @@ def main():
     cpu = None
     if not args.no_cpu_baseline and world == 1:   # the CPU port is timed on rank 0 at N=1 only
         cpu = cpu_baseline(args.size, (tok.vocab_size_in, tok.vocab_size_out, ts0, ts1))
+        if aux:
+            try:
+                aux["cpu_baseline"] = cpu_dit_baseline()
+            except Exception as e:   # the auxiliary figure must never cost the bench line
+                print(f"cpu_dit_baseline failed: {e!r}", file=sys.stderr)
 
     line = {
         "metric": "beatmap event-tokens/sec (mel + osuT5 encoder + greedy AR decode), whole job",
