@@ -226,3 +226,14 @@ def test_graft_entry_build():
     """The driver's build check: `make` (incremental) + dlopen + ABI / layout verification, no GPU needed."""
     import __graft_entry__ as g
     g.build()
+
+
+def test_abi_header_is_plain_c():
+    """include/mapperhip.h is the contract a maintainer binds: it must compile as C99 and as C++ on its own."""
+    import shutil
+    import subprocess
+    hdr = os.path.join(ROOT, "include", "mapperhip.h")
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    subprocess.run(["gcc", "-x", "c", "-std=c99", "-fsyntax-only", "-Wall", "-Werror", hdr], check=True)
+    subprocess.run(["g++", "-x", "c++", "-std=c++17", "-fsyntax-only", hdr], check=True)
