@@ -10,6 +10,7 @@ for that one stage, see oracle/mel.py).
 """
 from __future__ import annotations
 
+import copy
 import json
 import os
 
@@ -17,8 +18,9 @@ import numpy as np
 import torch
 
 from mapperatorinator_amd.t5_engine import T5_PRESETS
-from mapperatorinator_amd.testing import (DIT_PRESETS, boost_timed_rows, random_dit_state_dict,
-                                          random_t5_state_dict, synthetic_audio, synthetic_dit_inputs)
+from mapperatorinator_amd.testing import (DIT_PRESETS, DIVERSE_GAINS, boost_timed_rows, random_dit_state_dict,
+                                          random_t5_state_dict, synthetic_audio, synthetic_audio_varied,
+                                          synthetic_dit_inputs)
 
 from . import dit as odit
 from . import mel as omel
@@ -27,39 +29,117 @@ from . import ref_harness as rh
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 
 T5_CASES = {
-    # name: (size, n_samples, src_len, tgt_len, weight seed, lm_head gain, audio seed, prompts)
-    "t5_tiny": ("tiny", 32000, 251, 48, 11, 6.0, 4, [[0, 0, 1], [1, 40, 700], [0, 1, 9]]),
-    "t5_small": ("small", 160000, 1251, 96, 3, 4.0, 1, [[0, 1], [1, 5]]),
+    # name: size, samples, src frames, tgt_len, weight seed, lm_head gain, audio seed, prompts (left-padded with 0),
+    #       audio kind, weight gains, record the per-step processed scores?
+    "t5_tiny": dict(size="tiny", ns=32000, src=251, tgt=48, wseed=11, gain=6.0, aseed=4,
+                    prompts=[[0, 0, 1], [1, 40, 700], [0, 1, 9]], audio="stationary", gains=None, scores=False),
+    "t5_small": dict(size="small", ns=160000, src=1251, tgt=96, wseed=3, gain=4.0, aseed=1, prompts=[[0, 1], [1, 5]],
+                     audio="varied", gains="diverse", scores=False),
+    # BASELINE configs[1] dims (osuT5-base, 1251 frames): ragged prompts, 133 new tokens per row, per-step scores
+    "t5_base": dict(size="base", ns=160000, src=1251, tgt=136, wseed=5, gain=4.0, aseed=2,
+                    prompts=[[0, 0, 1], [1, 40, 700], [0, 1, 9], [1, 5, 1003]], audio="varied", gains="diverse",
+                    scores=True),
 }
+TOPK = 16   # per (step, row): the TOPK largest processed scores + their ids + the row's logsumexp
+
+
+def case_audio(c, batch):
+    return (synthetic_audio_varied if c["audio"] == "varied" else synthetic_audio)(batch, c["ns"], seed=c["aseed"])
+
+
+def case_weights(c, tok):
+    return random_t5_state_dict(T5_PRESETS[c["size"]], tok.vocab_size_in, tok.vocab_size_out, seed=c["wseed"],
+                                lm_head_gain=c["gain"], gains=DIVERSE_GAINS if c["gains"] == "diverse" else None)
+
+
+def topk_scores(rec):
+    """list of (B, V) processed scores -> (steps, B, TOPK) values, ids, (steps, B) logsumexp"""
+    s = torch.stack(rec).float()
+    v, i = s.topk(TOPK, dim=-1)
+    return v.numpy(), i.numpy().astype(np.int32), torch.logsumexp(s, -1).numpy()
 
 
 def t5_case(name):
-    size, ns, src, tgt, wseed, gain, aseed, prompts = T5_CASES[name]
+    c = T5_CASES[name]
+    size, ns, src, tgt, prompts = c["size"], c["ns"], c["src"], c["tgt"], c["prompts"]
     model, tok, _ = rh.build_reference_t5(size, src_seq_len=src, tgt_seq_len=tgt)
-    dims = T5_PRESETS[size]
-    sd = random_t5_state_dict(dims, tok.vocab_size_in, tok.vocab_size_out, seed=wseed, lm_head_gain=gain)
+    sd = case_weights(c, tok)
     res = model.load_state_dict(sd, strict=False)
     assert not res.unexpected_keys, res
-    audio = synthetic_audio(len(prompts), ns, seed=aseed)
+    audio = case_audio(c, len(prompts))
     prompt = torch.tensor(prompts)
     mask = prompt.ne(0)
     with torch.no_grad():
         mel = model.spectrogram(audio)
     enc = rh.reference_encode(model, audio)
-    ids, stats = rh.reference_generate(model, tok, audio, prompt, rh.default_generate_kwargs(tgt), mask)
+    rec = [] if c["scores"] else None
+    ids, stats = rh.reference_generate(model, tok, audio, prompt, rh.default_generate_kwargs(tgt), mask, record_scores=rec)
     # a second run with processors switched on: temperature + timeshift bias + lookahead EOS window
     ids2, _ = rh.reference_generate(model, tok, audio, prompt,
                                     rh.default_generate_kwargs(tgt, temperature=0.7, timeshift_bias=0.35,
                                                                lookahead_time=3000), mask)
+    extra = {}
+    if rec is not None:
+        v, i, lse = topk_scores(rec)
+        gap = v[..., 0] - v[..., 1]
+        extra = dict(top_vals=v, top_ids=i, lse=lse)
+        print(name, "steps", len(rec), "top-2 gap min / median", float(gap.min()), float(np.median(gap)))
     np.savez_compressed(
         os.path.join(OUT, name + ".npz"),
         vocab_in=tok.vocab_size_in, vocab_out=tok.vocab_size_out, n_samples=ns, src_len=src, tgt_len=tgt,
-        weight_seed=wseed, lm_head_gain=gain, audio_seed=aseed, prompt=prompt.numpy(),
+        weight_seed=c["wseed"], lm_head_gain=c["gain"], audio_seed=c["aseed"], audio_kind=c["audio"],
+        gains=c["gains"] or "", prompt=prompt.numpy(),
         mel_slice=mel[:, ::37, ::29].numpy(), mel_sum=mel.double().sum().item(),
         enc_slice=enc[:, ::53, ::17].numpy(), enc_abs_mean=enc.abs().double().mean().item(),
-        ids=ids.numpy(), ids_processors=ids2.numpy(),
+        ids=ids.numpy(), ids_processors=ids2.numpy(), **extra,
     )
-    print(name, "ids", ids.shape, "distinct", len(set(ids.flatten().tolist())), "tok/s(ref,cpu)", stats["tokens_per_second"])
+    print(name, "ids", ids.shape, "distinct", len(set(ids.flatten().tolist())), "distinct(processors run)",
+          len(set(ids2.flatten().tolist())), "tok/s(ref,cpu)", stats["tokens_per_second"])
+
+
+def t5_bf16_reference_case(name="t5_base"):
+    """The reference itself in bfloat16 (`model.to(torch.bfloat16)`, the precision switch of
+    osuT5/osuT5/utils/model_utils.py:375-376) on the weights / audio / prompts of `name`: free-running greedy ids,
+    the top scores of every step, and how often the fp32 reference -- teacher-forced on those ids -- picks the same
+    token.  The GPU test runs the HIP bf16 path teacher-forced on the same ids and asserts its agreement."""
+    c = T5_CASES[name]
+    tgt, prompts = c["tgt"], c["prompts"]
+    model, tok, _ = rh.build_reference_t5(c["size"], src_seq_len=c["src"], tgt_seq_len=tgt)
+    model.load_state_dict(case_weights(c, tok), strict=False)
+    audio = case_audio(c, len(prompts))
+    prompt = torch.tensor(prompts)
+    m16 = copy.deepcopy(model).to(torch.bfloat16)
+    rec16 = []
+    ids16, _ = rh.reference_generate(m16, tok, audio, prompt, rh.default_generate_kwargs(tgt, precision="bf16"), prompt.ne(0),
+                                     record_scores=rec16)
+    v, i, lse = topk_scores(rec16)
+    # the CPU oracle teacher-forced on the bf16 run's ids: on which steps does it decide differently?  (steps after a
+    # row's EOS are pads and do not count)
+    from oracle import t5 as ot5
+    d = T5_PRESETS[c["size"]]
+    P = prompt.shape[1]
+    gap = torch.from_numpy(v[..., 0] - v[..., 1]).T                     # (B, steps)
+    ts0, ts1 = rh.ts_range(tok)
+    agree = {}
+    for tag, rounding in (("fp32", None), ("bf16_contract", "bf16")):
+        o = ot5.T5Oracle(case_weights(c, tok), d.d_model, d.d_ff, d.n_heads, d.n_enc_layers, d.n_dec_layers, rounding=rounding)
+        _, sc = o.generate(o.encode_audio(audio), prompt, prompt.ne(0), [], ids16.shape[1], ts0, ts1, [tok.sos_id],
+                           forced=ids16, return_logits=True)
+        pick = torch.stack([s.argmax(-1) for s in sc], 1)              # (B, steps)
+        want = ids16[:, P:P + pick.shape[1]]
+        live, ok = want.ne(0), pick == want
+        dec = live & (gap[:, :pick.shape[1]] >= BF16_DECISIVE_GAP)
+        agree[tag] = (ok[live].float().mean().item(), ok[dec].float().mean().item(), int(dec.sum()))
+    print(name, "bf16 reference: ids", tuple(ids16.shape), "distinct", len(set(ids16.flatten().tolist())),
+          "pads per row", (ids16 == 0).sum(1).tolist(), "top-2 gap median", float(gap.median()),
+          "| teacher-forced top-1 agreement with the bf16 reference (all live steps, steps with gap >= "
+          f"{BF16_DECISIVE_GAP}, their count): fp32 oracle {agree['fp32']}, bf16-contract oracle {agree['bf16_contract']}")
+    np.savez_compressed(os.path.join(OUT, name + "_bf16ref.npz"), ids=ids16.numpy(), top_vals=v, top_ids=i, lse=lse,
+                        decisive_gap=BF16_DECISIVE_GAP, agree_fp32_oracle=np.array(agree["fp32"]),
+                        agree_bf16_contract_oracle=np.array(agree["bf16_contract"]))
+
+
+BF16_DECISIVE_GAP = 0.5   # bf16 logits of magnitude 8..16 are spaced 0.0625..0.125: below this a "decision" is rounding
 
 
 TF_CASE = dict(src=251, tgt=48, n_samples=32000, weight_seed=21, lm_head_gain=6.0, timed_gain=2.0, audio_seed=5,
@@ -216,6 +296,7 @@ def main():
     mel_case()
     for name in T5_CASES:
         t5_case(name)
+    t5_bf16_reference_case("t5_base")
     types_first_case()
     dit_case("dit_xs", "DiT-XS", 96, 21, 5, 1.5)
     dit_case("dit_s", "DiT-S", 160, 1, 2, 2.0)

@@ -95,6 +95,13 @@ def build_reference_t5(size="small", src_seq_len=1251, tgt_seq_len=512, n_mels=3
     return model, tok, args
 
 
+def ts_range(tok):
+    """(first, one-past-last) TIME_SHIFT id of a reference or mirror tokenizer"""
+    s = [v for k, v in tok.event_start.items() if k.name == "TIME_SHIFT"][0]
+    e = [v for k, v in tok.event_end.items() if k.name == "TIME_SHIFT"][0]
+    return s, e
+
+
 def reference_encode(model, audio: torch.Tensor) -> torch.Tensor:
     """mel -> encoder_embedder -> T5 encoder, called by hand (work-around for the positional
     `inputs_embeds` bug at modeling_mapperatorinator.py:438-443; SURVEY.md headline finding 3)."""

@@ -182,6 +182,50 @@ class T5Oracle:
         n = r(rms_norm(h, sd["transformer.decoder.final_layer_norm.weight"], self.eps))
         return (n @ sd["transformer.lm_head.weight"].t())[:, 0, :]
 
+    def decoder_forward(self, ids, ckv, key_mask=None):
+        """Teacher-forced logits of EVERY position at once: ids (B, T) -> fp32 (B, T, V).  Same arithmetic and the same
+        rounding points as T calls of `decoder_step` (causal mask instead of a growing cache); exists because the
+        step-by-step form needs ~1 s per step at B = 32 on a CPU.  key_mask (B, T) bool, True = attend."""
+        r, sd = self.r, self.sd
+        B, T = ids.shape
+        h = sd["decoder_embedder.weight"][ids]
+        bias = self.dec_bias(list(range(T)), T)                       # (1, H, T, T)
+        m = torch.ones(T, T, dtype=torch.bool).tril()[None, None]
+        if key_mask is not None:
+            m = m & key_mask[:, None, None, :T]
+        for l in range(self.nd):
+            b = f"transformer.decoder.block.{l}."
+            a = b + "layer.0.SelfAttention."
+            x = b + "layer.1.EncDecAttention."
+            n = r(rms_norm(h, sd[b + "layer.0.layer_norm.weight"], self.eps))
+            q = self._heads(r(n @ sd[a + "q.weight"].t()))
+            k = self._heads(r(n @ sd[a + "k.weight"].t()))
+            v = self._heads(r(n @ sd[a + "v.weight"].t()))
+            h = h + r(self._attn(q, k, v, bias, m)) @ sd[a + "o.weight"].t()
+            n = r(rms_norm(h, sd[b + "layer.1.layer_norm.weight"], self.eps))
+            q = self._heads(r(n @ sd[x + "q.weight"].t()))
+            h = h + r(self._attn(q, ckv[l][0], ckv[l][1], None)) @ sd[x + "o.weight"].t()
+            n = r(rms_norm(h, sd[b + "layer.2.layer_norm.weight"], self.eps))
+            h = h + self._ffn(n, b + "layer.2.DenseReluDense.")
+        n = r(rms_norm(h, sd["transformer.decoder.final_layer_norm.weight"], self.eps))
+        return n @ sd["transformer.lm_head.weight"].t()
+
+    def monotonic_scores(self, logits, ids, ts_start, ts_end, sos_ids):
+        """MonotonicTimeShiftLogitsProcessor (logit_processors.py:136-183) applied to teacher-forced logits: row t of
+        `logits` (B, T, V) is masked with the history ids[:, :t+1].  Returns a new tensor."""
+        B, T, _ = logits.shape
+        out = logits.clone().float()
+        last_val = torch.full((B,), -1, dtype=torch.long)
+        sos = torch.as_tensor(list(sos_ids), dtype=torch.long)
+        col = torch.arange(ts_start, ts_end)
+        for t in range(T):
+            tok = ids[:, t]
+            is_ts = (tok >= ts_start) & (tok < ts_end)
+            last_val = torch.where(is_ts, tok - ts_start, torch.where(torch.isin(tok, sos), torch.full_like(tok, -1), last_val))
+            bad = (last_val >= 0)[:, None] & (col[None, :] < (ts_start + last_val)[:, None])
+            out[:, t, ts_start:ts_end][bad] = float("-inf")
+        return out
+
     # ---- generation ------------------------------------------------------------------------
     def generate(self, enc, prompt, prompt_mask, eos_ids, max_length, ts_start, ts_end, sos_ids, pad_id=0,
                  temperature=1.0, timeshift_bias=0.0, lookback_mask_end=0, forced=None, return_logits=False,

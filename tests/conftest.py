@@ -25,6 +25,51 @@ def ts_range(tok):
     return s, e
 
 
+def t5_golden_case(name):
+    """tests/golden/<name>.npz (oracle/make_golden.py:t5_case) -> (golden, size, tok, state_dict, audio, src, tgt):
+    weights and audio are regenerated from the seeds / kinds recorded in the fixture."""
+    import numpy as np
+
+    from mapperatorinator_amd import Tokenizer
+    from mapperatorinator_amd.t5_engine import T5_PRESETS
+    from mapperatorinator_amd.testing import DIVERSE_GAINS, random_t5_state_dict, synthetic_audio, synthetic_audio_varied
+    g = np.load(f"{GOLDEN}/{name}.npz")
+    size = name.split("_")[1]
+    src, tgt = int(g["src_len"]), int(g["tgt_len"])
+    tok = Tokenizer.benchmark_vocab(src_seq_len=src)
+    assert tok.vocab_size_out == int(g["vocab_out"]) and tok.vocab_size_in == int(g["vocab_in"])
+    gains = DIVERSE_GAINS if ("gains" in g.files and str(g["gains"]) == "diverse") else None
+    sd = random_t5_state_dict(T5_PRESETS[size], tok.vocab_size_in, tok.vocab_size_out, seed=int(g["weight_seed"]),
+                              lm_head_gain=float(g["lm_head_gain"]), gains=gains)
+    varied = "audio_kind" in g.files and str(g["audio_kind"]) == "varied"
+    audio = (synthetic_audio_varied if varied else synthetic_audio)(g["prompt"].shape[0], int(g["n_samples"]),
+                                                                    seed=int(g["audio_seed"]))
+    return g, size, tok, sd, audio, src, tgt
+
+
+def assert_topk_scores_match(dumped, g, P, tol):
+    """dumped: fp32 (cols, B, V) processed scores of a run (index = produced column); g: a fixture holding the
+    reference's per-step `top_vals` / `top_ids` (steps, B, K) and `lse` (steps, B).  The K best ids of every step must
+    be the same set in the same order wherever the reference separates them by more than 2*tol, values and the
+    row's logsumexp within tol."""
+    import numpy as np
+    import torch
+    tv, ti, lse = torch.from_numpy(g["top_vals"]), torch.from_numpy(g["top_ids"]).long(), torch.from_numpy(g["lse"])
+    steps, B, K = tv.shape
+    worst = 0.0
+    for i in range(steps):
+        s = dumped[P + i].float().cpu()
+        got = s.gather(-1, ti[i])
+        worst = max(worst, (got - tv[i]).abs().max().item(), (torch.logsumexp(s, -1) - lse[i]).abs().max().item())
+        gv, gi = s.topk(K, dim=-1)
+        sep = (tv[i][:, :-1] - tv[i][:, 1:]) > 2 * tol           # rank r clearly above rank r+1 in the reference
+        clear = torch.cat([sep, torch.zeros(B, 1, dtype=torch.bool)], 1)
+        clear[:, 1:] &= sep                                        # ... and clearly below rank r-1
+        assert torch.equal(gi[clear], ti[i][clear]), f"step {i}: ranking differs from the reference"
+    assert worst < tol, worst
+    return worst
+
+
 def types_first_case():
     """tests/golden/t5_tiny_tf.npz: the reference's `model_generate` under the types_first processors and
     classifier-free guidance (oracle/make_golden.py:types_first_case).  Returns (golden, tok, sd, audio, tgt, runs)."""
