@@ -283,6 +283,53 @@ def pipeline_case():
           "moved", (pos[0] - torch.stack([torch.from_numpy(x), torch.from_numpy(y)])).abs().mean().item())
 
 
+WHISPER_CASE = dict(seed=77, d=128, c_in=96, L=150)
+
+
+def whisper_weights(c):
+    """conv1 / conv2 weights + input of the front-end case, from the numpy seed (same draw order as the tests)"""
+    rng = np.random.default_rng(c["seed"])
+    d, cin, Ln = c["d"], c["c_in"], c["L"]
+    rnd = lambda shape, std: torch.from_numpy((rng.standard_normal(shape) * std).astype(np.float32))
+    w1, b1, w2, b2 = rnd((d, cin, 3), 0.08), rnd((d,), 0.05), rnd((d, d, 3), 0.06), rnd((d,), 0.05)
+    return w1, b1, w2, b2, rnd((2, cin, Ln), 1.0)
+
+
+def whisper_frontend_case():
+    """Row a3: the conv front-end as the REFERENCE's `VarWhisperEncoder.forward` computes it
+    (custom_transformers/modeling_varwhisper.py:779-780,813-816: conv1 k3 p1 -> gelu -> conv2 k3 s2 p1 -> gelu -> permute,
+    no position table), captured at the input of its final norm with zero encoder layers; and the installed HF
+    `WhisperEncoder` (the stock backbone `get_backbone_model` wires for openai/whisper names,
+    modeling_mapperatorinator.py:35-39), which adds its sinusoid `embed_positions`."""
+    c = WHISPER_CASE
+    w1, b1, w2, b2, x = whisper_weights(c)
+    rh.ref_shims.install()
+    from osuT5.osuT5.model.custom_transformers import modeling_varwhisper as mv
+    from transformers.models.whisper.modeling_whisper import WhisperConfig, WhisperEncoder
+    out = {}
+    for tag, enc in (("var", mv.VarWhisperEncoder(mv.VarWhisperConfig(
+                         d_model=c["d"], num_mel_bins=c["c_in"], encoder_layers=0, decoder_layers=0,
+                         encoder_attention_heads=2, decoder_attention_heads=2, encoder_ffn_dim=256, decoder_ffn_dim=256))),
+                     ("hf", WhisperEncoder(WhisperConfig(
+                         d_model=c["d"], num_mel_bins=c["c_in"], encoder_layers=0, decoder_layers=0,
+                         encoder_attention_heads=2, decoder_attention_heads=2, encoder_ffn_dim=256, decoder_ffn_dim=256,
+                         max_source_positions=c["L"] // 2)))):
+        enc = enc.eval()
+        with torch.no_grad():
+            enc.conv1.weight.copy_(w1); enc.conv1.bias.copy_(b1); enc.conv2.weight.copy_(w2); enc.conv2.bias.copy_(b2)
+        cap = {}
+        enc.layer_norm.register_forward_pre_hook(lambda m, inp: cap.__setitem__("x", inp[0].detach().clone()))
+        with torch.no_grad():
+            enc(x)
+        out[tag] = cap["x"]
+        if tag == "hf":
+            out["pos"] = enc.embed_positions.weight.detach().clone()
+    np.savez_compressed(os.path.join(OUT, "whisper_frontend.npz"), out=out["hf"].numpy(), pos=out["pos"].numpy(),
+                        out_var=out["var"].numpy(), **c)
+    print("whisper_frontend", tuple(out["var"].shape), "hf - var - pos max abs",
+          (out["hf"] - out["var"] - out["pos"]).abs().max().item())
+
+
 def mel_case():
     a = synthetic_audio(2, 16000, seed=9)
     m = omel.mel_spectrogram(a)
@@ -294,6 +341,7 @@ def main():
     torch.set_num_threads(max(1, os.cpu_count() or 1))
     tokenizer_case()
     mel_case()
+    whisper_frontend_case()
     for name in T5_CASES:
         t5_case(name)
     t5_bf16_reference_case("t5_base")

@@ -3,7 +3,9 @@
 Follows HF `WhisperEncoder.forward` (transformers models/whisper/modeling_whisper.py: conv1 k3 p1 -> gelu ->
 conv2 k3 s2 p1 -> gelu -> permute -> + embed_positions) which the reference's forks repeat verbatim
 (osuT5/osuT5/model/custom_transformers/modeling_varwhisper.py:779-780,813-816; no position table there).
-Pinned in tests/test_oracle_pinned.py against the installed HF WhisperEncoder and the golden file it produced.
+Pinned: tests/golden/whisper_frontend.npz is written by oracle/make_golden.py:whisper_frontend_case from the imported
+reference `VarWhisperEncoder` (`out_var`, no position table) and the installed HF `WhisperEncoder` (`out`, `pos`);
+tests/test_oracle_pinned.py checks this restatement against both.
 """
 import torch
 import torch.nn.functional as F

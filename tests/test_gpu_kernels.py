@@ -295,8 +295,13 @@ def test_whisper_frontend(dtype_name):
         err = (got - want).abs().max().item()
         print("whisper front-end bf16 max abs err vs bf16 oracle", err)
         assert err < 3e-2
-    # no position table (VarWhisper fork), odd length, batch 3
+    # no position table: the reference's VarWhisperEncoder conv stack (golden `out_var`, made by the imported fork)
     fe2 = WhisperFrontendHIP(w1, b1, w2, b2, None, dtype=dt)
+    got_var = fe2(x.cuda()).float().cpu()
+    err_var = (got_var - torch.from_numpy(g["out_var"])).abs().max().item()
+    print("whisper front-end", dtype_name, "max abs err vs the reference VarWhisperEncoder golden", err_var)
+    assert err_var < (2e-5 if dt == torch.float32 else 3e-2)
+    # odd length, batch 3
     x2 = torch.randn(3, 96, 77, generator=torch.Generator().manual_seed(1))
     got2 = fe2(x2.cuda()).float().cpu()
     want2 = whisper_frontend(x2, w1, b1, w2, b2, None, rounding=None if dt == torch.float32 else "bf16")
