@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MH_ABI_VERSION 2
+#define MH_ABI_VERSION 3
 #define MH_MAX_LAYERS 32
 
 typedef enum MhStatus {
@@ -238,6 +238,14 @@ typedef struct MhSampling {
   const uint8_t* tok_flags; /* device uint8 [vocab_out]: bit0 timed-event ids (:104-108), bits 1-3 the
                                conditional-temperature sets, bit4 eos + context-eos ids (:99).  May be
                                NULL when n_cond == 0 and lookback_types_first == 0                       */
+  /* --- ABI 3 ------------------------------------------------------------------------------------ */
+  int cond_per_row;         /* 0: the reference's batch behaviour -- ConditionalTemperatureLogitsWarper reads
+                               `input_ids[0, -max_offset:]`, ROW 0's history, for every row of the batch
+                               (logit_processors.py:75-80).  1: every row looks at its OWN history, i.e. what
+                               the reference computes when each row is a batch-1 call (generate_sequential,
+                               processor.py:308-368): used when rows of different songs / shards share a batch */
+  unsigned rng_row0;        /* do_sample: global index of this call's first returned row in the RNG key
+                               (seed, row, column), so shards of one job do not replay each other's draws  */
 } MhSampling;
 
 int64_t mh_t5_decode_workspace_bytes(const MhT5Config* cfg, int B);

@@ -54,7 +54,8 @@ class MhSampling(C.Structure):
                 ("sos_ids", C.c_int * 16), ("lookback_mask_end", C.c_int), ("pad_id", C.c_int),
                 ("max_length", C.c_int), ("seed", C.c_uint64),
                 ("cfg_scale", C.c_float), ("n_cond", C.c_int), ("cond_temp", C.c_float * 3),
-                ("cond_offset", C.c_int * 3), ("lookback_types_first", C.c_int), ("tok_flags", VP)]
+                ("cond_offset", C.c_int * 3), ("lookback_types_first", C.c_int), ("tok_flags", VP),
+                ("cond_per_row", C.c_int), ("rng_row0", C.c_uint)]
 
 
 class MhDiTConfig(C.Structure):
@@ -72,6 +73,8 @@ class MhDiTWeights(C.Structure):
                 ("fc2_w", _PTR_ARR), ("fc2_b", _PTR_ARR), ("fin_ada_w", VP), ("fin_ada_b", VP),
                 ("fin_w", VP), ("fin_b", VP)]
 
+
+ABI_VERSION = 3   # MH_ABI_VERSION of include/mapperhip.h
 
 # every symbol include/mapperhip.h declares: (name, restype, argtypes)
 I, I64, F = C.c_int, C.c_int64, C.c_float
@@ -127,7 +130,7 @@ def load():
             raise RuntimeError(f"libmapperhip.so does not export {name} (stale build?)") from e
         fn.restype = res
         fn.argtypes = args
-    if lib.mh_abi_version() != 2:
+    if lib.mh_abi_version() != ABI_VERSION:
         raise RuntimeError("libmapperhip.so ABI version mismatch")
     for which, st in enumerate((MhGemm, MhT5Config, MhT5Weights, MhSampling, MhDiTConfig, MhDiTWeights)):
         if lib.mh_struct_size(which) != C.sizeof(st):

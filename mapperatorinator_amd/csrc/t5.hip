@@ -8,6 +8,8 @@
 //   model_generate (osuT5/osuT5/inference/server.py:83-156) with the reference logits processors.
 #include <stdlib.h>
 
+#include <map>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -246,9 +248,10 @@ __global__ __launch_bounds__(256) void dec_sample_kernel(SampleP p) {
     const int ltv = p.last_ts_val[b];
     if (tid == 0) {
       // ConditionalTemperatureLogitsWarper: the lookback is ROW 0's history for the whole batch
-      // (logit_processors.py:75-80 `input_ids[0, -max_offset:]`), first matching rule wins
+      // (logit_processors.py:75-80 `input_ids[0, -max_offset:]`), first matching rule wins; cond_per_row: the row's
+      // own history (= the reference called with batch 1 per row: sequential songs, shards)
       float temp = sp.temperature;
-      const int row0 = cfg ? p.pair : 0;
+      const int row0 = sp.cond_per_row ? b : (cfg ? p.pair : 0);
       for (int j = 0; j < sp.n_cond; ++j) {
         const int off = sp.cond_offset[j];
         if (col >= off && (sp.tok_flags[history_id(p, row0, col - off)] & (2 << j))) { temp = sp.cond_temp[j]; break; }
@@ -403,7 +406,7 @@ __global__ __launch_bounds__(256) void dec_sample_kernel(SampleP p) {
         __syncthreads();
       }
       if (tid == 0) {
-        const float u = uniform01(sp.seed, (uint32_t)gr, (uint32_t)col) * s_sum;
+        const float u = uniform01(sp.seed, (uint32_t)gr + sp.rng_row0, (uint32_t)col) * s_sum;
         float cum = 0.f;
         int pick = tok;
         for (int v = 0; v < p.V; ++v) {
@@ -843,7 +846,7 @@ int pick_chains(int B) {
   return n;
 }
 
-struct ChainPool {   // extra streams + fork/join events, created once per process
+struct ChainPool {   // extra streams + fork/join events of ONE device, created on first use under that device
   hipStream_t streams[kMaxChains] = {};
   hipEvent_t fork = nullptr, join[kMaxChains] = {};
   bool ready = false;
@@ -859,7 +862,17 @@ struct ChainPool {   // extra streams + fork/join events, created once per proce
     return MH_OK;
   }
 };
-ChainPool g_pool;
+// one pool per device; mh_t5_generate holds the pool's mutex for the whole call, so two engines (or two host
+// threads) decoding on the same GPU take turns instead of sharing fork / join events
+struct DevicePool { ChainPool pool; std::mutex mu; };
+DevicePool* device_pool(int dev) {
+  static std::mutex table_mu;
+  static std::map<int, DevicePool*> table;
+  std::lock_guard<std::mutex> g(table_mu);
+  auto it = table.find(dev);
+  if (it == table.end()) it = table.emplace(dev, new DevicePool()).first;
+  return it->second;
+}
 
 }  // namespace
 }  // namespace mh
@@ -916,9 +929,19 @@ extern "C" int mh_t5_generate(const MhT5Config* c, const MhT5Weights* w, const v
   if (hipMemsetAsync(ticket_all, 0, (size_t)B * H * 4, s) != hipSuccess) return check_launch("ticket memset");
   all.splits = cross_splits(B, H);
 
-  // a CFG pair spans both halves of the batch and the conditional temperature reads row 0's history: one chain
-  const int n_chains = (cfg || sp->n_cond > 0) ? 1 : pick_chains(B);
+  // a CFG pair spans both halves of the batch and the (batch-wide) conditional temperature reads row 0's history: one chain
+  const int n_chains = (cfg || (sp->n_cond > 0 && !sp->cond_per_row)) ? 1 : pick_chains(B);
   const int rows_per = ceil_div(B, n_chains);
+  int dev = 0;   // the device that owns the caller's stream (not whatever happens to be current)
+  if (hipStreamGetDevice(s, &dev) != hipSuccess) { (void)hipGetLastError(); if (hipGetDevice(&dev) != hipSuccess) return check_launch("hipGetDevice"); }
+  struct DeviceGuard {   // streams / events of the pool are created under the stream's device; restored on every return path
+    int prev = -1;
+    explicit DeviceGuard(int want) { if (hipGetDevice(&prev) == hipSuccess && prev != want) (void)hipSetDevice(want); else prev = -1; }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+  } device_guard(dev);
+  DevicePool* dp = device_pool(dev);
+  std::lock_guard<std::mutex> pool_guard(dp->mu);
+  ChainPool& g_pool = dp->pool;
   MH_TRY(g_pool.init());
 
   // tokens[:, :P] = prompt; the remainder is produced by the sampler

@@ -78,7 +78,6 @@ class DiTHIP:
         self.cfg, self.w = cfg, w
         self.stream = torch.cuda.Stream(self.device)
         self._ws = None
-        self._band_cache = {}
 
     @classmethod
     def from_preset(cls, name: str, state_dict: dict, **kw):
@@ -113,9 +112,10 @@ class DiTHIP:
         Recover `band` and verify the mask really is that band (anything else is refused)."""
         if attn_mask is None:
             return 0
-        key = (attn_mask.data_ptr(), tuple(attn_mask.shape), attn_mask._version)
-        if key in self._band_cache:
-            return self._band_cache[key]
+        if isinstance(attn_mask, BandMask):      # our own pipeline: the band is known, nothing to analyse
+            if attn_mask.T != T:
+                raise ValueError(f"band mask built for T={attn_mask.T}, sequence has T={T}")
+            return attn_mask.band
         m = attn_mask.to("cpu")
         if m.dtype != torch.bool or m.shape != (T, T):
             raise NotImplementedError("attn_mask must be a (T, T) bool band mask")
@@ -129,7 +129,6 @@ class DiTHIP:
                 raise NotImplementedError("attn_mask is not the banded mask of diffusion_pipeline.py:146-148")
         elif bool(m.any()):
             raise NotImplementedError("attn_mask is not the banded mask of diffusion_pipeline.py:146-148")
-        self._band_cache[key] = band
         return band
 
     # ---- B3 ------------------------------------------------------------------------------------------
@@ -154,6 +153,22 @@ class DiTHIP:
         return out
 
     __call__ = forward_with_cfg
+
+
+class BandMask:
+    """The banded attention mask of diffusion_pipeline.py:145-148 as a description instead of a (T, T) tensor: query q
+    may attend key k iff -(band-1) <= k - q <= band (band = the pipeline's `seq_len`).  What DiffusionPipelineHIP
+    passes as `attn_mask`; a foreign caller's bool tensor is analysed (and verified to be a band) on every call."""
+
+    def __init__(self, T: int, seq_len: int):
+        self.T, self.band = int(T), (int(seq_len) if seq_len < T else 0)   # band >= T masks nothing
+
+    def to_tensor(self, device="cpu") -> torch.Tensor:
+        q = torch.arange(self.T, device=device)[:, None]
+        k = torch.arange(self.T, device=device)[None, :]
+        if self.band == 0:
+            return torch.zeros(self.T, self.T, dtype=torch.bool, device=device)
+        return ~((q >= k - self.band) & (q < k + self.band))
 
 
 class InpaintSpec:

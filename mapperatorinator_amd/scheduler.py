@@ -52,7 +52,7 @@ def _left_pad(rows, pad_id: int, dtype):
 class SequentialWindowScheduler:
     def __init__(self, model, tokenizer, *, encode_batch: int = 32, decode_batch: int = 32):
         if decode_batch > 64 or decode_batch < 1:
-            raise ValueError("decode_batch must be in [1, 64]")
+            raise ValueError("decode_batch must be in [1, 64] (32 at most when windows run under classifier-free guidance)")
         self.model, self.tokenizer = model, tokenizer
         self.engine = model.engine
         self.encode_batch, self.decode_batch = int(encode_batch), int(decode_batch)
@@ -95,23 +95,31 @@ class SequentialWindowScheduler:
                 key = repr(sorted(gk.items(), key=lambda kv_: kv_[0]))
                 asks.setdefault(key, []).append((i, ask, gk))
             for group in asks.values():
-                for a in range(0, len(group), self.decode_batch):
-                    self._decode_group(jobs, kvs, w, group[a:a + self.decode_batch], pad_id)
+                # guidance doubles the decode batch (negative rows + prompt rows): half as many windows per call
+                step = max(1, self.decode_batch // 2) if float(group[0][2].get("cfg_scale", 1.0)) > 1.0 else self.decode_batch
+                for a in range(0, len(group), step):
+                    self._decode_group(jobs, kvs, w, group[a:a + step], pad_id)
         self.stats["elapsed_seconds"] += time.perf_counter() - start
         return self.stats
 
     def _decode_group(self, jobs, kvs, w, group, pad_id):
         eng, tok = self.engine, self.tokenizer
-        gk = group[0][2]
+        # rows of different songs share this batch where the reference runs one batch-1 call per window: the conditional
+        # temperature must look at each row's OWN history (the reference's processor reads row 0 of its batch)
+        gk = dict(group[0][2], conditional_temperature_per_row=True)
         sp, eos = build_sampling(tok, gk, self.model.config.max_target_positions)
         cfg = sp.cfg_scale > 1.0
+        if len(group) * (2 if cfg else 1) > 64:
+            raise ValueError(f"{len(group)} windows{' x 2 (guidance)' if cfg else ''} exceed the engine's 64-row decode batch")
         prompts = _left_pad([g[1]["decoder_input_ids"] for g in group], pad_id, torch.int64)
         masks = None
         if any(g[1].get("decoder_attention_mask") is not None for g in group):
             masks = _left_pad([g[1]["decoder_attention_mask"] if g[1].get("decoder_attention_mask") is not None
                                else torch.ones_like(g[1]["decoder_input_ids"]) for g in group], 0, torch.uint8)
         elif any(g[1]["decoder_input_ids"].shape[-1] != prompts.shape[1] for g in group):
-            masks = prompts.ne(pad_id).to(torch.uint8)      # ragged prompts: the left padding must not be attended
+            # ragged prompts: only the left padding added HERE must not be attended -- a pad_id inside a caller's own
+            # prompt stays visible, exactly as in the batch-1 call without a mask
+            masks = _left_pad([torch.ones_like(g[1]["decoder_input_ids"]) for g in group], 0, torch.uint8)
         neg = None
         if cfg:
             if any(g[1].get("negative_prompt") is None for g in group):

@@ -111,6 +111,16 @@ def _build_generation_stats(result, model_kwargs, pad_token_id, elapsed_seconds)
             "tokens_per_second": total / elapsed_seconds if elapsed_seconds > 0 else 0.0}
 
 
+def fresh_seed(seed=None) -> int:
+    """Seed of one generate call.  The reference samples with `torch.multinomial`, which ADVANCES the global generator
+    on every draw, so two calls never replay the same uniforms; the in-kernel RNG is keyed by (seed, row, column), so
+    the call's seed must move instead: one 63-bit draw from torch's default generator per call (still a deterministic
+    function of `torch.manual_seed`).  An explicit `seed` is used as is."""
+    if seed is not None:
+        return int(seed) & 0xFFFFFFFFFFFFFFFF
+    return int(torch.randint(0, 2 ** 63 - 1, (1,), dtype=torch.int64).item())
+
+
 def build_sampling(tokenizer, generate_kwargs: dict, max_target_positions: int):
     """Translate the reference's generate kwargs (processor.py:156-170,358-360) into MhSampling + EOS ids."""
     gk = dict(generate_kwargs)
@@ -181,7 +191,12 @@ def build_sampling(tokenizer, generate_kwargs: dict, max_target_positions: int):
     sp.host_tok_flags = flags if need_flags else None
     sp.pad_id = int(gk.get("pad_token_id", getattr(tokenizer, "pad_id", 0)) or 0)
     sp.max_length = int(gk.get("max_length", max_target_positions))
-    sp.seed = int(gk.get("seed", torch.initial_seed())) & 0xFFFFFFFFFFFFFFFF
+    sp.seed = fresh_seed(gk.get("seed")) if sp.do_sample else 0     # greedy decoding leaves the global generator alone
+    # ConditionalTemperatureLogitsWarper looks at row 0's history for the whole batch in the reference
+    # (logit_processors.py:75-80); callers that batch rows of DIFFERENT songs / shards, where the reference would have
+    # run batch-1 calls, ask for the per-row form (scheduler.py, sharding.py)
+    sp.cond_per_row = int(bool(gk.get("conditional_temperature_per_row", False)))
+    sp.rng_row0 = int(gk.get("rng_row_offset", 0)) & 0xFFFFFFFF
     eos = get_eos_token_id(tokenizer, lookback_time=lookback_time, lookahead_time=lookahead_time,
                            context_type=context_type)
     return sp, eos
@@ -196,7 +211,7 @@ def sampling_from_processors(processors, vocab_size_out: int, *, do_sample=False
     sp = Sampling()
     sp.do_sample, sp.top_k, sp.top_p = int(bool(do_sample)), int(top_k or 0), float(1.0 if top_p is None else top_p)
     sp.temperature, sp.cfg_scale, sp.pad_id, sp.max_length = 1.0, 1.0, int(pad_token_id or 0), int(max_length)
-    sp.seed = int(torch.initial_seed() if seed is None else seed) & 0xFFFFFFFFFFFFFFFF
+    sp.seed = fresh_seed(seed) if sp.do_sample else 0
     flags = np.zeros(int(vocab_size_out), dtype=np.uint8)
     need_flags = False
     order = {"ClassifierFreeGuidanceLogitsProcessor": 0, "MonotonicTimeShiftLogitsProcessor": 1, "TimeshiftBias": 2,
