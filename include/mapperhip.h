@@ -58,6 +58,17 @@ typedef enum MhEpilogue {
 
 const char* mh_last_error(void);
 int mh_abi_version(void);
+
+/* Tuning options (process-wide): each has a default, an environment override read at first use and this run-time
+ * setter.  They choose between kernels that compute the same results (bit-identical unless noted):
+ *   "gemm_splitk_tiles"  MH_GEMM_SPLITK_TILES  192  fp32/bf16 GEMMs with fewer 32x32 tiles than this use the 16x16
+ *                                                   split-K tile (different fp32 summation order); 0 = never
+ *   "decode_chains"      MH_DECODE_CHAINS      0    independent row chains of a decode step (0 = automatic)
+ *   "decode_prefill"     MH_DECODE_PREFILL     1    batched prompt prefill (0: token by token)
+ *   "decode_gemv_cols"   MH_DECODE_GEMV_COLS   0    valid columns per 16-column tile of the decode GEMVs (0 = automatic)
+ * Unknown names return MH_ERR_ARG (set) / -1 (get). */
+int mh_set_option(const char* name, long value);
+long mh_get_option(const char* name);
 /* sizeof() of the ABI structs as this library was compiled, so that a binding can verify its own layout:
  * which = 0 MhGemm, 1 MhT5Config, 2 MhT5Weights, 3 MhSampling, 4 MhDiTConfig, 5 MhDiTWeights; -1 otherwise. */
 int mh_struct_size(int which);

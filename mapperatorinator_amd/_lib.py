@@ -82,6 +82,8 @@ SYMBOLS = {
     "mh_last_error": (C.c_char_p, []),
     "mh_abi_version": (I, []),
     "mh_struct_size": (I, [I]),
+    "mh_set_option": (I, [C.c_char_p, C.c_long]),
+    "mh_get_option": (C.c_long, [C.c_char_p]),
     "mh_mel": (I, [VP, I, I, I, I, I, VP, VP, VP, VP, VP, VP, I, VP, I, I, VP]),
     "mh_gemm": (I, [C.POINTER(MhGemm), VP]),
     "mh_rmsnorm": (I, [VP, I, VP, VP, I, I, I, F, I, VP]),
@@ -138,6 +140,14 @@ def load():
                                f"({lib.mh_struct_size(which)} vs {C.sizeof(st)} bytes)")
     _lib = lib
     return lib
+
+
+def set_option(name: str, value: int) -> int:
+    """mh_set_option: returns the previous value (so that tests can restore it)."""
+    lib = load()
+    old = lib.mh_get_option(name.encode())
+    check(lib.mh_set_option(name.encode(), int(value)), f"mh_set_option({name})")
+    return old
 
 
 def check(rc: int, what: str = ""):

@@ -1,6 +1,8 @@
 // Error plumbing + version of libmapperhip's C ABI (include/mapperhip.h).
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include "common.hpp"
 
@@ -24,7 +26,45 @@ int check_launch(const char* what) {
   return MH_OK;
 }
 
+// ---- tuning options: a default, an environment override read at first use, and mh_set_option() at run time --------
+// (process-wide, not per call: they select between kernels that compute the same results)
+struct OptionSlot { const char* name; const char* env; long value; bool resolved; };
+static OptionSlot g_options[OPT_COUNT] = {
+    {"gemm_splitk_tiles", "MH_GEMM_SPLITK_TILES", 192, false},   // below this many 32x32 tiles the 16x16 split-K tile is used (0 = never)
+    {"decode_chains", "MH_DECODE_CHAINS", 0, false},             // independent row chains of the decode step (0 = automatic)
+    {"decode_prefill", "MH_DECODE_PREFILL", 1, false},           // 1: batched prompt prefill, 0: feed the prompt token by token
+    {"decode_gemv_cols", "MH_DECODE_GEMV_COLS", 0, false},       // valid weight rows per 16-column MFMA tile of the decode GEMVs (0 = automatic)
+};
+
+long option(int id) {
+  OptionSlot& o = g_options[id];
+  if (!o.resolved) {
+    const char* e = getenv(o.env);
+    if (e && *e) o.value = atol(e);
+    o.resolved = true;
+  }
+  return o.value;
+}
+
 }  // namespace mh
+
+extern "C" int mh_set_option(const char* name, long value) {
+  for (int i = 0; name && i < mh::OPT_COUNT; ++i)
+    if (strcmp(mh::g_options[i].name, name) == 0) {
+      mh::g_options[i].value = value;
+      mh::g_options[i].resolved = true;
+      return MH_OK;
+    }
+  mh::set_error("mh_set_option: unknown option '%s'", name ? name : "(null)");
+  return MH_ERR_ARG;
+}
+
+extern "C" long mh_get_option(const char* name) {
+  for (int i = 0; name && i < mh::OPT_COUNT; ++i)
+    if (strcmp(mh::g_options[i].name, name) == 0) return mh::option(i);
+  mh::set_error("mh_get_option: unknown option '%s'", name ? name : "(null)");
+  return -1;
+}
 
 extern "C" const char* mh_last_error(void) { return mh::g_err; }
 extern "C" int mh_abi_version(void) { return MH_ABI_VERSION; }

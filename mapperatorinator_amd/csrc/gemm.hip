@@ -428,15 +428,8 @@ bool prepare_type() {
          prepare_epi<T, MH_EPI_BIAS_GELU_ERF>();
 }
 
-// below this many 32x32 tiles the 16x16 split-K tile is used (MH_GEMM_SPLITK_TILES overrides, 0 = never)
-long splitk_threshold() {
-  static long v = -1;
-  if (v < 0) {
-    const char* e = getenv("MH_GEMM_SPLITK_TILES");
-    v = e ? atol(e) : 192;
-  }
-  return v;
-}
+// below this many 32x32 tiles the 16x16 split-K tile is used (option gemm_splitk_tiles, 0 = never)
+long splitk_threshold() { return option(OPT_GEMM_SPLITK_TILES); }
 
 template <typename T, int EPI>
 int dispatch_tile(const GemmP& p, hipStream_t s) {

@@ -837,10 +837,7 @@ int prefill_prompt(const MhT5Config* c, const MhT5Weights* w, const void* cross_
 // depend on the chain count (every kernel is batch-invariant by construction).
 int pick_chains(int B) {
   int n = B >= 16 ? 2 : 1;   // measured on MI355X (B=32, base): 1 -> 26.7k, 2 -> 28.0k, 4 -> 17.6k tok/s (host graph-launch bound)
-  if (const char* e = getenv("MH_DECODE_CHAINS")) {
-    const int v = atoi(e);
-    if (v >= 1) n = v;
-  }
+  if (option(OPT_DECODE_CHAINS) >= 1) n = (int)option(OPT_DECODE_CHAINS);
   if (n > kMaxChains) n = kMaxChains;
   if (n > B) n = B;
   return n;
@@ -951,8 +948,7 @@ extern "C" int mh_t5_generate(const MhT5Config* c, const MhT5Weights* w, const v
   // batched prompt prefill (positions 0..P-2); MH_DECODE_PREFILL=0 feeds the prompt token by token instead
   int start_pos = 0;
   {
-    const char* e = getenv("MH_DECODE_PREFILL");
-    if (P > 1 && !(e && atoi(e) == 0)) {
+    if (P > 1 && option(OPT_DECODE_PREFILL) != 0) {
       PrefillBuf pb;
       const int64_t used_dec = ar.off;
       prefill_layout(c, B, P - 1, (char*)workspace + used_dec, workspace_bytes - used_dec, &pb);

@@ -22,7 +22,7 @@ from typing import Callable, Optional
 
 import torch
 
-from .dit import DiTHIP, InpaintSpec, create_diffusion
+from .dit import BandMask, DiTHIP, InpaintSpec, create_diffusion
 
 # one-hot row of each hit-object type inside the 16 type rows (diffusion_pipeline.py:304-315); +1 for a new combo on
 # CIRCLE / SLIDER_HEAD (:339-340), + repeat_type(repeats) on SLIDER_END (:343-347)
@@ -93,7 +93,7 @@ class DiffusionPipelineHIP:
         self.start_time, self.end_time = start_time, end_time
 
     def to_positions(self, samples: torch.Tensor) -> torch.Tensor:
-        """(:171-176) drop the null-class half, [-1, 1] -> playfield pixels, to the CPU."""
+        """(:171-176) drop the null-class half, [-1, 1] -> playfield pixels, to the CPU.  (2B, 2, T) -> (B, 2, T)"""
         samples, _ = samples.clone().chunk(2, dim=0)
         samples += 1
         samples /= 2
@@ -106,23 +106,42 @@ class DiffusionPipelineHIP:
                            noise_source: Optional[Callable] = None,
                            denoised_fn_factory: Optional[Callable] = None) -> torch.Tensor:
         """seq_* as returned by `events_to_sequence`; class vectors (C,) multi-hot.  Returns positions (1, 2, T) on the
-        CPU, what the reference hands to `events_with_pos`.
+        CPU, what the reference hands to `events_with_pos`.  (= generate_positions_batch with one chunk.)
 
         noise_source(n, shape) -> fp32 [n, *shape]: the gaussian noise of n consecutive p_sample calls (parity tests
             inject the reference's draws); default: torch.randn on the device, one draw per call like `th.randn_like`.
         denoised_fn_factory(mask, z_part, start, end) -> callable: replaces the in-paint-only `denoised_fn` (e.g. with
             the slider re-projection); forces the per-step host round trip."""
-        dev = self.device
-        seq_len = seq_x.shape[1]
-        if seq_len == 0:
+        if seq_x.shape[1] == 0:
             return torch.zeros(1, 2, 0)
+        return self.generate_positions_batch(seq_x[None], seq_o[None], seq_c[None], class_vector[None],
+                                             unk_class_vector[None], noise_source, denoised_fn_factory)
+
+    @torch.no_grad()
+    def generate_positions_batch(self, seq_x: torch.Tensor, seq_o: torch.Tensor, seq_c: torch.Tensor,
+                                 class_vectors: torch.Tensor, unk_class_vectors: torch.Tensor,
+                                 noise_source: Optional[Callable] = None,
+                                 denoised_fn_factory: Optional[Callable] = None) -> torch.Tensor:
+        """B song-chunks with the SAME number of points T through the diffusion stage as ONE denoiser batch:
+        seq_x (B, 2, T), seq_o (B, T), seq_c (B, 272, T), class vectors (B, C).  Returns positions (B, 2, T) on the CPU.
+
+        The reference runs its pipeline once per beatmap with `n = 1` (diffusion_pipeline.py:157-166): a CFG batch of
+        2 rows, i.e. M = 2 T rows per GEMM -- 67 latency-bound launches per step at T = 128.  Chunks are independent,
+        so the B conditional rows and the B null-class rows are stacked as [cond_0..cond_{B-1} | null_0..null_{B-1}]
+        (the layout `forward_with_cfg` splits in halves, models.py:306-317): M = 2 B T rows reach the 128x128 MFMA
+        tiles and every launch is shared by all chunks.  Row b of the result equals the single-chunk run of chunk b
+        (bit for bit when both use the same GEMM tile family: option gemm_splitk_tiles = 0).
+        `noise_source(n, shape)` is asked for shape (2B, 2, T_window): rows b and B + b are chunk b's pair."""
+        dev = self.device
+        B, _, seq_len = seq_x.shape
+        if seq_len == 0:
+            return torch.zeros(B, 2, 0)
         diffusion = create_diffusion(timestep_respacing=self.timesteps, diffusion_steps=self.diffusion_steps,
                                      noise_schedule=self.noise_schedule)
-        n = 1
-        z = seq_x.repeat(n, 1, 1).to(dev, torch.float32)
-        c = seq_c.repeat(n, 1, 1).to(dev, torch.float32)
-        y = class_vector.repeat(n, 1).to(dev, torch.float32)
-        y_null = unk_class_vector.repeat(n, 1).to(dev, torch.float32)
+        z = seq_x.to(dev, torch.float32)
+        c = seq_c.to(dev, torch.float32)
+        y = class_vectors.to(dev, torch.float32)
+        y_null = unk_class_vectors.to(dev, torch.float32)
         z = torch.cat([z, z], 0)
         c = torch.cat([c, c], 0)
         y = torch.cat([y, y_null], 0)
@@ -136,15 +155,20 @@ class DiffusionPipelineHIP:
         def sample_part(zfull, start, end, start_mask_size=0):
             z_part = zfull[:, :, start:end].contiguous()
             c_part = c[:, :, start:end].contiguous()
-            o_part = seq_o[start:end].contiguous()
             T = end - start
-            # True means it will be generated (:223-234)
+            # True means it will be generated (:223-234); per chunk, the pair of a chunk shares its mask
             mask = torch.full(z_part.shape, False, dtype=torch.bool, device=dev)
             mask[:, :, start_mask_size:] = True
-            if self.start_time is not None:
-                mask[:, :, :int(torch.searchsorted(o_part, self.start_time, right=False))] = False
-            if self.end_time is not None:
-                mask[:, :, int(torch.searchsorted(o_part, self.end_time, right=True)):] = False
+            for b in range(B):
+                o_part = seq_o[b, start:end].contiguous()
+                if self.start_time is not None:
+                    k0 = int(torch.searchsorted(o_part, self.start_time, right=False))
+                    mask[b, :, :k0] = False
+                    mask[B + b, :, :k0] = False
+                if self.end_time is not None:
+                    k1 = int(torch.searchsorted(o_part, self.end_time, right=True))
+                    mask[b, :, k1:] = False
+                    mask[B + b, :, k1:] = False
             if not bool(mask.any()):
                 return z_part
             if denoised_fn_factory is not None:
@@ -152,7 +176,7 @@ class DiffusionPipelineHIP:
             else:
                 denoised_fn = InpaintSpec(mask, z_part)
             z_part = denoised_fn(z_part)
-            model_kwargs = dict(c=c_part, y=y, cfg_scale=self.cfg_scale, attn_mask=band_mask(T, self.seq_len),
+            model_kwargs = dict(c=c_part, y=y, cfg_scale=self.cfg_scale, attn_mask=BandMask(T, self.seq_len),
                                 key_padding_mask=None)
             samples = diffusion.p_sample_loop(self.model.forward_with_cfg, z_part.shape, z_part, denoised_fn=denoised_fn,
                                               clip_denoised=True, model_kwargs=model_kwargs, device=dev,

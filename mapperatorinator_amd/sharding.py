@@ -43,28 +43,67 @@ def all_gather_ragged(local: torch.Tensor, n_total: int, group=None) -> torch.Te
 
 
 def sharded_generate(generate_fn: Callable, model_kwargs: dict, pad_id: int, max_length: int, group=None,
-                     comm_device: Optional[torch.device] = None):
+                     comm_device: Optional[torch.device] = None, refine_fn: Optional[Callable] = None):
     """Run `generate_fn(shard_of_model_kwargs) -> (LongTensor[n_local, <=max_length] (CPU), stats)` on this
     rank's block of chunks and all_gather the padded token streams.
 
-    Returns (tokens int64 CPU (B, max_length) padded with pad_id, lengths int64 (B,), local_stats)."""
+    refine_fn(shard_of_model_kwargs, tokens) -> fp32 (n_local, 2, Tq): the diffusion stage of the rank's chunks
+    (hit-object coordinates, SURVEY.md 8e "coords (32, 2, Tq) fp32").  Tq must be the same on every rank; the
+    coordinates travel in the SAME all_gather as the tokens (bit-cast to int32 columns behind them), so a stage still
+    costs one latency-bound collective.
+
+    Sampling under sharding: a shard is its own batch, so (i) pass `conditional_temperature_per_row=True` in the
+    generate kwargs when the ConditionalTemperature processor is on (the reference's batch form reads GLOBAL row 0,
+    which other ranks do not hold), and (ii) `rng_row_offset` = the shard's first global row (model_kwargs key
+    `_row_offset` is filled in here for generate_fn to forward) keeps the draws of different shards distinct.
+
+    Returns (tokens int64 CPU (B, max_length) padded with pad_id, lengths int64 (B,), local_stats) and, with
+    refine_fn, a 4th element: coords fp32 CPU (B, 2, Tq) in global chunk order."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     B = model_kwargs["inputs"].shape[0]
     lo, hi = shard_bounds(B, rank, world)
     shard = {k: (v[lo:hi] if isinstance(v, torch.Tensor) and v.shape[:1] == (B,) else v)
              for k, v in model_kwargs.items()}
+    shard["_row_offset"] = lo
     if hi > lo:
         toks, stats = generate_fn(shard)
     else:
         toks, stats = torch.zeros((0, 1), dtype=torch.long), {"generated_tokens": 0}
+    if toks.shape[1] > max_length:
+        raise ValueError(f"generate_fn returned {toks.shape[1]} columns, max_length is {max_length}")
     local = torch.full((hi - lo, max_length + 1), pad_id, dtype=torch.int32)
     local[:, : toks.shape[1]] = toks.to(torch.int32)
-    local[:, max_length] = toks.shape[1]          # last column carries the produced length
+    local[:, max_length] = toks.shape[1]          # column max_length carries the produced length
+    n_coord = 0
+    coord_shape = None
+    if refine_fn is not None:
+        coords = refine_fn(shard, toks) if hi > lo else None
+        # every rank must agree on Tq even when its shard is empty: settle it with the first non-empty shard's shape
+        shape_t = torch.tensor(list(coords.shape[1:]) if coords is not None else [0, 0], dtype=torch.int64)
+        if world > 1:
+            shapes = [torch.zeros_like(shape_t) for _ in range(world)]
+            dist.all_gather(shapes, shape_t.to(_comm_device(group, comm_device)), group=group)
+            shape_t = max((s_.cpu() for s_ in shapes), key=lambda s_: int(s_.prod()))
+        coord_shape = tuple(int(v) for v in shape_t)
+        n_coord = coord_shape[0] * coord_shape[1]
+        packed = torch.zeros((hi - lo, n_coord), dtype=torch.int32)
+        if coords is not None:
+            if tuple(coords.shape[1:]) != coord_shape:
+                raise ValueError(f"refine_fn returned {tuple(coords.shape)}; every rank must use the same (2, Tq) = {coord_shape}")
+            packed = coords.to(torch.float32).contiguous().cpu().reshape(hi - lo, n_coord).view(torch.int32)
+        local = torch.cat([local, packed], 1)
     if world == 1:
         full = local
     else:
-        dev = comm_device or (torch.device("cuda", torch.cuda.current_device())
-                              if dist.get_backend(group) == "nccl" else torch.device("cpu"))
-        full = all_gather_ragged(local.to(dev), B, group).cpu()
-    return full[:, :max_length].to(torch.int64), full[:, max_length].to(torch.int64), stats
+        full = all_gather_ragged(local.to(_comm_device(group, comm_device)), B, group).cpu()
+    out = (full[:, :max_length].to(torch.int64), full[:, max_length].to(torch.int64), stats)
+    if refine_fn is not None:
+        c = full[:, max_length + 1:].contiguous().view(torch.float32).reshape((B,) + coord_shape)
+        out = out + (c,)
+    return out
+
+
+def _comm_device(group, comm_device):
+    return comm_device or (torch.device("cuda", torch.cuda.current_device())
+                           if dist.get_backend(group) == "nccl" else torch.device("cpu"))

@@ -200,3 +200,86 @@ def test_window_pipeline_matches_reference_golden(variant):
     assert (pos[0][:, frozen] - given[:, frozen]).abs().max().item() < 1e-3
     assert (want[:, frozen] - given[:, frozen]).abs().max().item() < 1e-3
     assert (pos[0][:, ~frozen] - given[:, ~frozen]).abs().mean().item() > 10
+
+
+@pytest.mark.parametrize("variant", ["short", "full"])
+def test_batched_chunks_equal_independent_runs(variant):
+    """Config 3 runs the diffusion stage for many song-chunks: `generate_positions_batch` stacks B chunks into ONE
+    denoiser batch [cond_0..cond_{B-1} | null_0..null_{B-1}] (M = 2 B T rows per GEMM instead of 2 T).  Row b must be
+    what the single-chunk pipeline gives for chunk b with the same gaussian draws:
+      * bit for bit when both runs use the same GEMM tile family (option gemm_splitk_tiles = 0: every tile accumulates
+        k in ascending order; the 16x16 split-K tile the tiny single-chunk GEMMs otherwise pick adds four partial sums);
+      * with the default tiles: within 0.02 px on the short schedule (nothing compounds);
+    and chunk 0 is the reference-golden chunk of test_window_pipeline_matches_reference_golden: the batched row is
+    held to the reference's own positions as well."""
+    import json
+
+    from mapperatorinator_amd import _lib
+    from mapperatorinator_amd.diffusion_pipeline import DiffusionPipelineHIP, points_to_sequence
+    from mapperatorinator_amd.dit import DiTHIP
+    from mapperatorinator_amd.testing import DIT_PRESETS, random_dit_state_dict, synthetic_hit_objects
+    g = np.load(f"{GOLDEN}/dit_pipeline.npz")
+    c = json.loads(str(g["case"]))
+    depth, hidden, heads = DIT_PRESETS[c["preset"]]
+    dit = DiTHIP(random_dit_state_dict(depth, hidden, seed=c["weight_seed"]), depth, hidden, heads, device="cuda")
+    B, T = 4, c["T"]
+    k = dict(c["knobs"])
+    seed0, key = c["noise_seed"], "positions"
+    if variant == "short":
+        k.update(timesteps=[2] + [0] * 9, refine_iters=1)
+        seed0, key = seed0 + 1, "positions_short"
+    chunks = []
+    for b in range(B):
+        x, y, times, dist, typ = synthetic_hit_objects(T, c["point_seed"] + 13 * b)
+        if b > 0:   # the window / in-paint logic keys on the times: keep chunk 0's (start / end time are shared knobs)
+            times = chunks[0][2]
+        sx, so, sc = points_to_sequence(x, y, times, dist, typ)
+        cv, ucv = torch.zeros(300), torch.zeros(300)
+        cv[[(v + 7 * b) % 299 for v in c["classes"]]] = 1
+        ucv[c["null_classes"]] = 1
+        chunks.append((x, y, times, sx, so, sc, cv, ucv))
+    pipe = DiffusionPipelineHIP(dit, timesteps=k["timesteps"], seq_len=k["seq_len"], max_seq_len=k["max_seq_len"],
+                                overlap_buffer=k["overlap_buffer"], cfg_scale=k["cfg_scale"], refine_model=dit,
+                                refine_iters=k["refine_iters"], start_time=float(g["start_time"]),
+                                end_time=float(g["end_time"]))
+
+    def run_single(b):
+        rng = np.random.default_rng(seed0 + 1000 * b)
+        return pipe.generate_positions(*chunks[b][3:], noise_source=lambda n, shape: torch.from_numpy(
+            np.stack([rng.standard_normal(shape).astype(np.float32) for _ in range(n)])))[0]
+
+    def run_batched():
+        rngs = [np.random.default_rng(seed0 + 1000 * b) for b in range(B)]
+
+        def noise_source(n, shape):
+            assert shape[0] == 2 * B
+            out = np.empty((n,) + tuple(shape), np.float32)
+            for i in range(n):
+                for b in range(B):
+                    d = rngs[b].standard_normal((2,) + tuple(shape[1:])).astype(np.float32)
+                    out[i, b], out[i, B + b] = d[0], d[1]
+            return torch.from_numpy(out)
+        st = lambda j: torch.stack([ch[j] for ch in chunks])
+        return pipe.generate_positions_batch(st(3), st(4), st(5), st(6), st(7), noise_source=noise_source)
+
+    old = _lib.set_option("gemm_splitk_tiles", 0)
+    try:
+        same_tiles_single = [run_single(b) for b in range(B)]
+        same_tiles_batched = run_batched()
+    finally:
+        _lib.set_option("gemm_splitk_tiles", old)
+    assert same_tiles_batched.shape == (B, 2, T)
+    for b in range(B):
+        assert torch.equal(same_tiles_batched[b], same_tiles_single[b]), f"chunk {b}: batched row differs from its own run"
+    batched = run_batched()                       # default tile selection
+    single = [run_single(b) for b in range(B)]
+    err = max((batched[b] - single[b]).abs().max().item() for b in range(B))
+    ref_err = (batched[0] - torch.from_numpy(g[key])).abs().max(0).values
+    print(f"batched[{variant}] vs independent runs (default tiles): max {err:.5f} px; chunk 0 vs the reference golden: "
+          f"max {ref_err.max().item():.4f} median {ref_err.median().item():.4f} px")
+    if variant == "short":
+        assert err < 0.02
+        assert ref_err.max().item() < 0.05
+    else:
+        assert ref_err.median().item() < 0.1 and ref_err.quantile(0.9).item() < 1.0
+    assert (batched[1] - batched[0]).abs().mean().item() > 1.0, "chunks must differ"

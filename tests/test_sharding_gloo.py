@@ -20,16 +20,42 @@ def test_shard_bounds_cover_everything():
             assert max(sizes) - min(sizes) <= 1
 
 
-def _fake_generate(shard):
-    """stand-in for model_generate: token stream is a deterministic function of the chunk's audio"""
+MAXLEN, TQ = 12, 5
+
+
+def _standin_generate(shard):
+    """CPU stand-in for `model_generate` with its full contract: left-padded ragged prompts are kept in the output, rows
+    stop at their own EOS and are padded with 0 up to the longest row OF THE SHARD (so shards return different widths,
+    like batches that end at different steps), the token stream is a deterministic function of the chunk's audio and
+    of its prompt, never of the batch it sits in."""
+    x, prompt = shard["inputs"], shard["decoder_input_ids"]
+    n, P = prompt.shape
+    new = (x[:, 0].abs() * 10).long() % (MAXLEN - P) + 1
+    width = P + (int(new.max().item()) if n else 0)
+    out = torch.zeros((n, width), dtype=torch.long)
+    out[:, :P] = prompt
+    for i in range(n):
+        body = (x[i, : new[i]] * 1000).long().abs() % 1800 + 3 + prompt[i].sum()
+        out[i, P: P + new[i]] = body
+    return out, {"generated_tokens": int(new.sum()), "row_offset": shard.get("_row_offset", 0)}
+
+
+def _standin_refine(shard, toks):
+    """stand-in for the diffusion stage: coordinates are a function of the chunk's audio and its tokens"""
     x = shard["inputs"]
     n = x.shape[0]
-    lens = (x[:, 0].abs() * 10).long() % 7 + 2
-    width = int(lens.max().item()) if n else 1
-    out = torch.zeros((n, width), dtype=torch.long)
-    for i in range(n):
-        out[i, : lens[i]] = (x[i, : lens[i]] * 1000).long().abs() % 1800 + 3
-    return out, {"generated_tokens": int(lens.sum())}
+    base = x[:, : 2 * TQ].reshape(n, 2, TQ) * 100.0
+    return base + toks.sum(1).to(torch.float32)[:, None, None] * 1e-3
+
+
+def _inputs(B):
+    g = torch.Generator().manual_seed(0)
+    audio = torch.randn(B, 64, generator=g)
+    prompt = torch.zeros((B, 3), dtype=torch.long)
+    for b in range(B):                       # ragged, left-padded prompts
+        k = 1 + b % 3
+        prompt[b, 3 - k:] = torch.arange(1, k + 1) + b
+    return audio, prompt
 
 
 def _worker(rank, world, port, B, ret):
@@ -37,16 +63,21 @@ def _worker(rank, world, port, B, ret):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from mapperatorinator_amd.sharding import sharded_generate
-        g = torch.Generator().manual_seed(0)
-        audio = torch.randn(B, 64, generator=g)
-        toks, lens, stats = sharded_generate(_fake_generate, dict(inputs=audio, flag=3), pad_id=0, max_length=12)
-        ret[rank] = (toks, lens, stats)
+        audio, prompt = _inputs(B)
+        mk = dict(inputs=audio, decoder_input_ids=prompt, flag=3)
+        toks, lens, stats, coords = sharded_generate(_standin_generate, mk, pad_id=0, max_length=MAXLEN,
+                                                     refine_fn=_standin_refine)
+        plain = sharded_generate(_standin_generate, mk, pad_id=0, max_length=MAXLEN)
+        ret[rank] = (toks, lens, stats, coords, plain[0])
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("B", [5, 8, 1])
 def test_two_rank_gather_equals_single_process(B):
+    """world_size 2 over gloo: tokens (ragged widths per shard) AND the diffusion coordinates of every chunk arrive in
+    global order on both ranks and equal the single-process run; B = 1 leaves rank 1 with an empty shard."""
+    from mapperatorinator_amd.sharding import shard_bounds
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -54,18 +85,24 @@ def test_two_rank_gather_equals_single_process(B):
     mgr = mp.get_context("spawn").Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(2, port, B, ret), nprocs=2, join=True)
-    g = torch.Generator().manual_seed(0)
-    audio = torch.randn(B, 64, generator=g)
-    want, _ = _fake_generate(dict(inputs=audio))
+    audio, prompt = _inputs(B)
+    want, _ = _standin_generate(dict(inputs=audio, decoder_input_ids=prompt))
+    want_c = _standin_refine(dict(inputs=audio), want)
     for r in range(2):
-        toks, lens, _ = ret[r]
-        assert toks.shape == (B, 12)
+        toks, lens, stats, coords, plain = ret[r]
+        assert toks.shape == (B, MAXLEN) and torch.equal(toks, plain)
+        assert coords.shape == (B, 2, TQ) and coords.dtype == torch.float32
+        assert stats["row_offset"] == shard_bounds(B, r, 2)[0]
         for b in range(B):
-            n = int(lens[b])
-            assert n <= 12
-        full = torch.zeros((B, 12), dtype=torch.long)
-        # each shard pads to its own width; compare the non-pad prefix row by row
-        for b in range(B):
-            row = want[b][want[b] != 0]
-            assert torch.equal(toks[b][: len(row)], row) and (toks[b][len(row):] == 0).all()
-    assert torch.equal(ret[0][0], ret[1][0])
+            row = want[b]
+            n = int((row != 0).nonzero().max()) + 1
+            assert torch.equal(toks[b, :n], row[:n]) and (toks[b, n:] == 0).all()
+        # the refine stand-in sees the shard-local padded tokens: same sum as the global ones (pads are zeros)
+        assert torch.equal(coords, want_c), (coords - want_c).abs().max()
+        lo, hi = shard_bounds(B, r, 2)
+    assert torch.equal(ret[0][0], ret[1][0]) and torch.equal(ret[0][3], ret[1][3])
+    # the produced lengths are per SHARD (each shard pads to its own longest row)
+    for r in range(2):
+        lo, hi = shard_bounds(B, r, 2)
+        if hi > lo:
+            assert int(ret[0][1][lo:hi].max()) == int((want[lo:hi] != 0).nonzero()[:, 1].max()) + 1
