@@ -92,7 +92,9 @@ def test_two_rank_gather_equals_single_process(B):
         toks, lens, stats, coords, plain = ret[r]
         assert toks.shape == (B, MAXLEN) and torch.equal(toks, plain)
         assert coords.shape == (B, 2, TQ) and coords.dtype == torch.float32
-        assert stats["row_offset"] == shard_bounds(B, r, 2)[0]
+        lo, hi = shard_bounds(B, r, 2)
+        if hi > lo:     # (an empty shard never calls generate_fn)
+            assert stats["row_offset"] == lo
         for b in range(B):
             row = want[b]
             n = int((row != 0).nonzero().max()) + 1
