@@ -19,7 +19,22 @@ $(LIB): $(OBJS)
 	@mkdir -p $(dir $(LIB))
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(OBJS) -o $@
 
-clean:
-	rm -rf build $(LIB)
+# profiling build: the same sources with in-kernel phase stamps (tools/decode_phases.py); never loaded by the package
+PROF_OBJDIR := build/prof
+PROF_LIB := mapperatorinator_amd/lib/libmapperhip_prof.so
+PROF_OBJS := $(patsubst $(CSRC)/%.hip,$(PROF_OBJDIR)/%.o,$(SRCS))
 
-.PHONY: all clean
+$(PROF_OBJDIR)/%.o: $(CSRC)/%.hip $(HDRS)
+	@mkdir -p $(PROF_OBJDIR)
+	$(HIPCC) $(HIPFLAGS) -DMH_PHASE_STAMPS -c $< -o $@
+
+$(PROF_LIB): $(PROF_OBJS)
+	@mkdir -p $(dir $(PROF_LIB))
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(PROF_OBJS) -o $@
+
+prof: $(PROF_LIB)
+
+clean:
+	rm -rf build $(LIB) $(PROF_LIB)
+
+.PHONY: all clean prof

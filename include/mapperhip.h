@@ -66,6 +66,8 @@ int mh_abi_version(void);
  *   "decode_chains"      MH_DECODE_CHAINS      0    independent row chains of a decode step (0 = automatic)
  *   "decode_prefill"     MH_DECODE_PREFILL     1    batched prompt prefill (0: token by token)
  *   "decode_gemv_cols"   MH_DECODE_GEMV_COLS   0    valid columns per 16-column tile of the decode GEMVs (0 = automatic)
+ *   "decode_fused_proj"  MH_DECODE_FUSED_PROJ  1    decode attention kernels project their own q / k / v (0: stand-alone
+ *                                                   GEMV launches; fp32 summation order of the projections differs)
  * Unknown names return MH_ERR_ARG (set) / -1 (get). */
 int mh_set_option(const char* name, long value);
 long mh_get_option(const char* name);
@@ -297,6 +299,15 @@ int mh_t5_decoder_forward(const MhT5Config* cfg, const MhT5Weights* w, const voi
  * ms_out (HOST float[1]) = average milliseconds per launch.  Synchronises `stream`. */
 int mh_t5_cross_attn_probe(const MhT5Config* cfg, const MhT5Weights* w, const void* cross_kv, int B, int reps,
                            float* ms_out, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Measurement hook (bench.py `roofline`, in situ): with `buf` set, every cross-attention launch of the following
+ * mh_t5_generate calls records (earliest workgroup start, latest workgroup end) in wall-clock ticks
+ * (hipDeviceAttributeWallClockRate, kHz) into buf[chain][pos % ring][layer][2] (device uint64, pre-filled by the caller
+ * with (UINT64_MAX, 0)): the duration of the kernel exactly as the decode step launches it -- rows of one chain per
+ * launch, the other chain's kernels running beside it.  Two atomics per workgroup: use an extra decode pass, not a
+ * timed one.  buf == NULL (ring 0) switches it off.  mh_t5_decode_chains(B) = row chains mh_t5_generate uses for B. */
+int mh_t5_decode_timing(void* buf, int ring);
+int mh_t5_decode_chains(int B);
 
 /* ------------------------------------------------------------------------------------------------
  * K7/K8/K9  osu_diffusion DiT + DDPM.  Replaces DiT.forward_with_cfg

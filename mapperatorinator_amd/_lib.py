@@ -13,7 +13,9 @@ MH_F32, MH_BF16 = 0, 1
 (EPI_STORE, EPI_STORE_F32, EPI_RESID, EPI_GEGLU, EPI_BIAS_GELU, EPI_GATE_RESID, EPI_KV_SCATTER,
  EPI_QKV_VT, EPI_QKV_CACHE, EPI_BIAS_GELU_ERF) = range(10)
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmapperhip.so")
+# MAPPERHIP_LIB: developer override (tools/decode_phases.py loads the profiling build); the package default is the
+# in-tree production library
+_LIB_PATH = os.environ.get("MAPPERHIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmapperhip.so")
 
 VP = C.c_void_p
 FP = C.c_void_p  # device float*
@@ -99,6 +101,8 @@ SYMBOLS = {
     "mh_t5_forward_workspace_bytes": (I64, [C.POINTER(MhT5Config), I, I]),
     "mh_t5_decoder_forward": (I, [C.POINTER(MhT5Config), C.POINTER(MhT5Weights), VP, I, VP, VP, I, VP, VP, I64, VP]),
     "mh_t5_cross_attn_probe": (I, [C.POINTER(MhT5Config), C.POINTER(MhT5Weights), VP, I, I, C.POINTER(C.c_float), VP, I64, VP]),
+    "mh_t5_decode_timing": (I, [VP, I]),
+    "mh_t5_decode_chains": (I, [I]),
     "mh_dit_workspace_bytes": (I64, [C.POINTER(MhDiTConfig), I, I]),
     "mh_dit_forward_cfg": (I, [C.POINTER(MhDiTConfig), C.POINTER(MhDiTWeights), VP, VP, VP, VP, F, I, I, I,
                                VP, VP, I64, VP]),

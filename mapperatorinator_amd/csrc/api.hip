@@ -34,6 +34,8 @@ static OptionSlot g_options[OPT_COUNT] = {
     {"decode_chains", "MH_DECODE_CHAINS", 0, false},             // independent row chains of the decode step (0 = automatic)
     {"decode_prefill", "MH_DECODE_PREFILL", 1, false},           // 1: batched prompt prefill, 0: feed the prompt token by token
     {"decode_gemv_cols", "MH_DECODE_GEMV_COLS", 0, false},       // valid weight rows per 16-column MFMA tile of the decode GEMVs (0 = automatic)
+    {"decode_fused_proj", "MH_DECODE_FUSED_PROJ", 1, false},     // 1: attention kernels project their own q / k / v, 0: stand-alone GEMVs
+    {"decode_cu_split", "MH_DECODE_CU_SPLIT", 0, false},         // two chains on disjoint CU halves: 1 = XCDs 0-3 / 4-7, 2 = first / second 128 CU bits
 };
 
 long option(int id) {

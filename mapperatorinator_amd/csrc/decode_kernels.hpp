@@ -19,6 +19,25 @@
 namespace mh {
 namespace dec {
 
+// ---- phase stamps (profiling build only: `make prof` defines MH_PHASE_STAMPS) --------------------------------------------
+// Thread 0 of workgroup 0 adds (shader-clock ticks since its first instruction) to g_stamps[kernel][stamp] at marked
+// points; tools/decode_phases.py prints the averages.  The production library contains none of this.
+#ifdef MH_PHASE_STAMPS
+__device__ unsigned long long g_stamps[16 * 16 * 2];   // [kernel id][stamp][sum of ticks, count]
+#define MH_STAMP0() unsigned long long mh_t0_ = 0; if (blockIdx.x == 0 && threadIdx.x == 0) mh_t0_ = clock64()
+#define MH_STAMP(kid, i)                                                              \
+  do {                                                                                \
+    if (blockIdx.x == 0 && threadIdx.x == 0) {                                        \
+      atomicAdd(&g_stamps[((kid) * 16 + (i)) * 2], (unsigned long long)clock64() - mh_t0_); \
+      atomicAdd(&g_stamps[((kid) * 16 + (i)) * 2 + 1], 1ull);                         \
+    }                                                                                 \
+  } while (0)
+#else
+#define MH_STAMP0() do {} while (0)
+#define MH_STAMP(kid, i) do {} while (0)
+#endif
+enum { KID_GEMV = 0 /* + EPI * 2 + (NWV == 8) */, KID_SELF = 10, KID_CROSS = 11, KID_SAMPLE = 12 };
+
 // ---- 8-element chunk helpers ----------------------------------------------------------------
 template <typename T> __device__ inline void load8(const T* p, float (&o)[8]);
 template <> __device__ inline void load8<bf16_t>(const bf16_t* p, float (&o)[8]) {
@@ -75,25 +94,29 @@ template <> __device__ inline void store4<float>(float* p, float a, float b, flo
   *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
 }
 
-// ---- skinny GEMM ----------------------------------------------------------------------------
-// Every kernel has exactly ONE dependent memory round trip: weights, activations, the old residual
-// values and the RMSNorm statistics are all requested before anything is waited for.
-//   RMSNorm without a grid-wide pass: the kernel that PRODUCES the residual stream (a RESID GEMV or the
-//   sampler's embedding gather) also emits per-row partial sums of squares (one per 16-column strip,
-//   fixed order => deterministic); the consumer adds the <= 64 partials, takes rsqrt and normalises its
-//   fp32 A fragments in registers.
+// ---- decode GEMV ("skinny GEMM": M = batch rows <= 64) ------------------------------------------------------------
+// out[b][n] = sum_k A[b][k] * W[n][k] on the 16x16 MFMA atoms.  One workgroup owns ONE 16-column tile of which `nv`
+// columns are real (nv = 16, 8 or 4: a 768-column projection becomes 48, 96 or 192 workgroups; the other tile columns
+// repeat real ones and are never stored), its NWV waves split K (wave w takes k-blocks w, w + NWV, ...), the partial
+// accumulators are added through LDS in wave order (deterministic, independent of the batch).
+//   * straight-line code: every load of a pass is issued before the first wait, addresses are clamped instead of
+//     predicated, k-blocks beyond K are neutralised by AND-ing the activation fragment with 0 (no branches: a predicated
+//     load or a branch around an MFMA made hipcc serialise the loads of the previous version into several round trips);
+//   * PRO_RMSNORM: A is the fp32 residual stream; the workgroup holds all of its <= 64 rows x K values in registers at
+//     once (single pass), so the RMSNorm statistics come from those registers (lane -> 16-lane shuffle -> LDS over the
+//     waves): no statistics buffers, no extra memory round trip, one barrier;
+//   * weights are read exactly once per workgroup straight into MFMA fragments (no LDS round trip for data used once).
 enum { PRO_PLAIN = 0, PRO_RMSNORM = 1 };
 enum { SK_STORE = 0, SK_QKV = 1, SK_GEGLU = 2, SK_RESID = 3, SK_LOGITS = 4 };
 
 struct SkinnyP {
   const void* A; int lda;      // PRO_PLAIN: T [B, lda];  PRO_RMSNORM: fp32 residual stream [B, lda]
   const float* ln_w; float eps;
-  const float* ss_in; int ss_parts;   // PRO_RMSNORM: [ss_parts][64] partial sums of squares of the rows of A
   const void* W; int ldw;      // [N, ldw] element type T
   int B, N, K;
+  int nv;                      // real columns per 16-column tile: 16, 8 or 4 (GEGLU: 8 gate + 8 linear)
   void* out; int ldo;          // STORE: T [B, ldo]; GEGLU: T [B, ldo] (N/2 cols); LOGITS: f32 [B, ldo]
   float* h; int ldh;           // RESID: h[b][n] += acc
-  float* ss_out;               // RESID: [N/16][64] partial sums of squares of the updated rows
   void* kc; void* vc;          // QKV: this layer's self-attention caches [B][H][tgt_len][64]
   int H, tgt_len, inner;
   const int* pos;
@@ -108,6 +131,10 @@ template <> struct VecOps<bf16_t> {
     r.b = *reinterpret_cast<const float4*>(p + 4);
     return r;
   }
+  __device__ static inline float sumsq(const Raw& x) {
+    return (x.a.x * x.a.x + x.a.y * x.a.y) + (x.a.z * x.a.z + x.a.w * x.a.w) + (x.b.x * x.b.x + x.b.y * x.b.y) +
+           (x.b.z * x.b.z + x.b.w * x.b.w);
+  }
   __device__ static inline uint4 norm_frag(const Raw& x, const Raw& g, float rs) {
     const uint32_t o0 = pack_bf16x2(g.a.x * (x.a.x * rs), g.a.y * (x.a.y * rs));
     const uint32_t o1 = pack_bf16x2(g.a.z * (x.a.z * rs), g.a.w * (x.a.w * rs));
@@ -121,7 +148,6 @@ template <> struct VecOps<bf16_t> {
     ua.u = a; ub.u = b;
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(ua.f, ub.f, c, 0, 0, 0);
   }
-  static constexpr int kRawRegs = 8;
 };
 template <> struct VecOps<float> {
   struct Raw { float4 a; };
@@ -130,6 +156,7 @@ template <> struct VecOps<float> {
     r.a = *reinterpret_cast<const float4*>(p);
     return r;
   }
+  __device__ static inline float sumsq(const Raw& x) { return (x.a.x * x.a.x + x.a.y * x.a.y) + (x.a.z * x.a.z + x.a.w * x.a.w); }
   __device__ static inline uint4 norm_frag(const Raw& x, const Raw& g, float rs) {
     return make_uint4(__float_as_uint(g.a.x * (x.a.x * rs)), __float_as_uint(g.a.y * (x.a.y * rs)),
                       __float_as_uint(g.a.z * (x.a.z * rs)), __float_as_uint(g.a.w * (x.a.w * rs)));
@@ -142,195 +169,184 @@ template <> struct VecOps<float> {
     c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
     return c;
   }
-  static constexpr int kRawRegs = 4;
 };
 
-// k-blocks per wave whose loads are all in flight at once, bounded by the register budget
-template <typename T, int MF, int NS, int PRO>
-constexpr int skinny_chunk() {
-  if (PRO == PRO_PLAIN) return 8;
-  const int per = 4 * NS + VecOps<T>::kRawRegs * (MF + 1);
-  return 8 * per <= 200 ? 8 : (6 * per <= 200 ? 6 : (4 * per <= 200 ? 4 : 2));
-}
+constexpr int kGemvCH = 8;   // k-blocks per wave whose loads are in flight at once (one pass)
 
-// NWV waves per workgroup split K (4, or 8 for the long-K PLAIN GEMVs so that one pass covers K = 2048)
-template <typename T, int MF, int NS, int PRO, int EPI, int NWV = 4>
-__global__ __launch_bounds__(NWV * 64) void skinny_gemm_kernel(SkinnyP p) {
-  static_assert(PRO == PRO_PLAIN || NWV == 4, "the RMSNorm prologue is written for 4 waves");
+// MF 16-row fragments (B <= 16 MF), NWV waves.  NWV depends on K only (never on the batch): a row's summation order,
+// hence its rounding and its greedy tokens, must not depend on which other rows share the launch.
+template <typename T, int MF, int NWV, int PRO, int EPI>
+__global__ __launch_bounds__(NWV * 64) void gemv_kernel(SkinnyP p) {
   constexpr int VEC = Elem<T>::kVec;   // elements per 16-byte vector (per lane per k-block)
   constexpr int KB = 4 * VEC;          // k elements per k-block (4 lane groups x 16 B)
-  constexpr int CH = skinny_chunk<T, MF, NS, PRO>();
-  constexpr int NSE = (EPI == SK_GEGLU) ? 1 : NS;
+  constexpr int CH = kGemvCH;
   typedef typename VecOps<T>::Raw Raw;
-  __shared__ float ssp[4][64];
-  __shared__ f32x4_t red[NWV * NS * MF * 64];
+  __shared__ f32x4_t red[NWV * MF * 64];
+  __shared__ float ssw[PRO == PRO_RMSNORM ? NWV : 1][MF * 16];
+  __shared__ __attribute__((aligned(16))) float lnw[PRO == PRO_RMSNORM ? 1024 : 4];   // RMSNorm weight, staged once per workgroup
 
+  MH_STAMP0();
+  constexpr int KID = KID_GEMV + EPI * 2 + (NWV == 8 ? 1 : 0);
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l15 = lane & 15, lg = lane >> 4;
-  const int strip0 = blockIdx.x * NS;
-  // epilogue role of this thread: one f32x4 accumulator vector (4 rows x 1 column)
-  const int ef = (tid >> 6) % MF, es = (tid >> 6) / MF;
-  const bool epi_thread = tid < NSE * MF * 64;
-
-  // ---- requests that do not depend on anything: old residual values, RMSNorm statistics ----
-  float oldh[4] = {0.f, 0.f, 0.f, 0.f};
-  if (EPI == SK_RESID && epi_thread) {
-    const int colc = (strip0 + es) * 16 + l15;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = ef * 16 + lg * 4 + r;
-      oldh[r] = p.h[(long)(row < p.B ? row : p.B - 1) * p.ldh + (colc < p.N ? colc : p.N - 1)];
-    }
+  const int nv = p.nv;
+  // The vector-memory path of a CU moves 64 B per clock and charges every LANE of a load instruction, duplicates
+  // included: a tile whose 16 columns repeat nv real ones must not load the repeats (exec-masked W loads below), and
+  // the RMSNorm weight is fetched once per workgroup through LDS instead of once per 16-lane row group.
+  float4 lnraw = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (PRO == PRO_RMSNORM) {
+    const int i4 = tid * 4 < p.K ? tid * 4 : 0;     // K <= 1024 <= 4 * (NWV * 64)
+    lnraw = *reinterpret_cast<const float4*>(p.ln_w + i4);
   }
-
-  f32x4_t acc[NS][MF];
-#pragma unroll
-  for (int s = 0; s < NS; ++s)
-#pragma unroll
-    for (int f = 0; f < MF; ++f) acc[s][f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-  const T* Wp[NS];
-#pragma unroll
-  for (int s = 0; s < NS; ++s) {
-    int wr = (strip0 + s) * 16 + l15;
-    wr = wr < p.N ? wr : p.N - 1;
-    Wp[s] = reinterpret_cast<const T*>(p.W) + (long)wr * p.ldw + lg * VEC;
+  // weight row of this lane's tile column
+  int wrow, ocol;      // ocol: output column of tile column l15 (GEGLU: of the gate / linear PAIR)
+  bool wload;          // this lane fetches a weight fragment (tile columns >= nv are never stored: they keep zeros)
+  if (EPI == SK_GEGLU) {
+    // tile t = ff columns [8t, 8t + 8): tile columns 0..7 are their gate rows, 8..15 their linear rows; wi_0 / wi_1 are
+    // interleaved in 16-row blocks [gate | linear] (PackedT5.interleave16)
+    ocol = blockIdx.x * 8 + (l15 & 7);
+    const int oc = ocol < p.N / 2 ? ocol : p.N / 2 - 1;
+    wrow = (oc >> 4) * 32 + (l15 >> 3) * 16 + (oc & 15);
+    wload = true;
+  } else {
+    ocol = blockIdx.x * nv + l15;
+    wrow = ocol < p.N ? ocol : p.N - 1;
+    wload = l15 < nv;
   }
+  const T* Wp = reinterpret_cast<const T*>(p.W) + (long)wrow * p.ldw + lg * VEC;
   int arow[MF];
 #pragma unroll
   for (int f = 0; f < MF; ++f) arow[f] = (f * 16 + l15) < p.B ? (f * 16 + l15) : p.B - 1;
 
-  const int nkb = p.K / KB;
-  float rsr[MF];
+  // epilogue roles: the MF * 4 (fragment, accumulator register) units are dealt round-robin to the NWV waves -- one
+  // value per lane per unit (the gated-GELU epilogue is a tanh per value: on one wave it cost 0.9 us)
+  constexpr int UPW = (MF * 4 + NWV - 1) / NWV;
+  const bool col_ok = (EPI == SK_GEGLU) ? (l15 < 8 && ocol < p.N / 2) : (l15 < nv && ocol < p.N);
+  float oldh[UPW];
 #pragma unroll
-  for (int f = 0; f < MF; ++f) rsr[f] = 0.f;
+  for (int u = 0; u < UPW; ++u) oldh[u] = 0.f;
+  if (EPI == SK_RESID && l15 < nv) {   // requested before anything is waited for
+#pragma unroll
+    for (int u = 0; u < UPW; ++u) {
+      const int unit = wid + u * NWV;
+      const int row = (unit >> 2) * 16 + lg * 4 + (unit & 3);
+      if (unit < MF * 4) oldh[u] = p.h[(long)(row < p.B ? row : p.B - 1) * p.ldh + (ocol < p.N ? ocol : p.N - 1)];
+    }
+  }
 
-  // wave w owns k-blocks w, w+4, w+8, ...; CH of them per pass, every load issued before the first use.
-  // All addresses are clamped and the loads unconditional (a predicated load in an unrolled loop makes
-  // hipcc branch around each load and wait for it: one L2 round trip per element).
-  auto chunk = [&](int kb0, auto first_tag) {
-    constexpr bool kFirst = decltype(first_tag)::value;
-    uint4 wv[CH][NS];
-    uint4 av[CH][MF];
+  f32x4_t acc[MF];
+#pragma unroll
+  for (int f = 0; f < MF; ++f) acc[f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const int nkb = p.K / KB;
+
+  int kb0 = wid;
+  do {   // ONE pass for every RMSNorm shape and for K <= NWV * CH * KB; every wave runs at least one (its barrier)
+    uint4 wv[CH];
+    uint4 av[PRO == PRO_PLAIN ? CH : 1][PRO == PRO_PLAIN ? MF : 1];
     Raw hraw[PRO == PRO_RMSNORM ? CH : 1][PRO == PRO_RMSNORM ? MF : 1];
-    Raw graw[PRO == PRO_RMSNORM ? CH : 1];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) wv[c] = make_uint4(0, 0, 0, 0);
+    if (wload) {     // ONE exec-masked region around all weight loads (a branch per load would serialise them)
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const int kb = kb0 + NWV * c;
+        wv[c] = *reinterpret_cast<const uint4*>(Wp + (kb < nkb ? kb : nkb - 1) * KB);   // clamped address
+      }
+    }
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
       const int kb = kb0 + NWV * c;
-      const int kel = (kb < nkb ? kb : (wid < nkb ? wid : 0)) * KB;
-#pragma unroll
-      for (int s = 0; s < NS; ++s) wv[c][s] = *reinterpret_cast<const uint4*>(Wp[s] + kel);
+      const int kel = (kb < nkb ? kb : nkb - 1) * KB;
       if (PRO == PRO_PLAIN) {
 #pragma unroll
         for (int f = 0; f < MF; ++f)
           av[c][f] = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.A) + (long)arow[f] * p.lda + kel + lg * VEC);
       } else {
-        graw[c] = VecOps<T>::load_raw(p.ln_w + kel + lg * VEC);
 #pragma unroll
         for (int f = 0; f < MF; ++f)
           hraw[c][f] = VecOps<T>::load_raw(reinterpret_cast<const float*>(p.A) + (long)arow[f] * p.lda + kel + lg * VEC);
       }
     }
-    if (PRO == PRO_RMSNORM && kFirst) {
-      // RMSNorm statistics: requested AFTER the operand loads (in program order) so that the one wait below
-      // covers everything with a single round trip
-      {
-        const int row = tid & 63, pg = tid >> 6;
-        float sv[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int part = pg + 4 * i;
-          sv[i] = p.ss_in[(part < p.ss_parts ? part : 0) * 64 + row];
-        }
-        float a = 0.f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) a += (pg + 4 * i < p.ss_parts) ? sv[i] : 0.f;
-        ssp[pg][row] = a;
-      }
-      __syncthreads();   // ssp complete (every wave reaches this exactly once)
+    MH_STAMP(KID, 0);   // loads issued
+    float rsr[MF];
+    if (PRO == PRO_RMSNORM) {
+      // RMSNorm statistics of the rows from the registers: lane -> the 4 lane groups of the wave -> the NWV waves
 #pragma unroll
       for (int f = 0; f < MF; ++f) {
-        const int row = f * 16 + l15;
-        const float ss = (ssp[0][row] + ssp[1][row]) + (ssp[2][row] + ssp[3][row]);
+        float q = 0.f;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) q += (kb0 + NWV * c < nkb) ? VecOps<T>::sumsq(hraw[c][f]) : 0.f;
+        q += __shfl_xor(q, 16, 64);
+        q += __shfl_xor(q, 32, 64);
+        if (lg == 0) ssw[wid][f * 16 + l15] = q;
+      }
+      if (tid * 4 < p.K) *reinterpret_cast<float4*>(lnw + tid * 4) = lnraw;
+      __syncthreads();
+#pragma unroll
+      for (int f = 0; f < MF; ++f) {
+        float ss = 0.f;
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) ss += ssw[w][f * 16 + l15];
         rsr[f] = rsqrtf(ss / (float)p.K + p.eps);
       }
     }
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
-      if (kb0 + NWV * c < nkb) {
+      const uint32_t keep = (kb0 + NWV * c < nkb) ? 0xffffffffu : 0u;   // k-blocks beyond K contribute zeros
+      const int kc_el = ((kb0 + NWV * c < nkb) ? kb0 + NWV * c : nkb - 1) * KB + lg * VEC;
 #pragma unroll
-        for (int f = 0; f < MF; ++f) {
-          uint4 a;
-          if (PRO == PRO_PLAIN) a = av[c][f];
-          else a = VecOps<T>::norm_frag(hraw[c][f], graw[c], rsr[f]);
-          if (f * 16 + l15 >= p.B) a = make_uint4(0, 0, 0, 0);   // rows beyond the batch contribute zeros
-#pragma unroll
-          for (int s = 0; s < NS; ++s) acc[s][f] = VecOps<T>::mma(a, wv[c][s], acc[s][f]);
-        }
+      for (int f = 0; f < MF; ++f) {
+        uint4 a;
+        if (PRO == PRO_PLAIN) a = av[c][f];
+        else a = VecOps<T>::norm_frag(hraw[c][f], VecOps<T>::load_raw(lnw + kc_el), rsr[f]);
+        a = make_uint4(a.x & keep, a.y & keep, a.z & keep, a.w & keep);
+        acc[f] = VecOps<T>::mma(a, wv[c], acc[f]);
       }
     }
-  };
-  chunk(wid, std::true_type{});
-  for (int kb0 = wid + NWV * CH; kb0 < nkb; kb0 += NWV * CH) chunk(kb0, std::false_type{});
+    kb0 += NWV * CH;
+  } while (kb0 < nkb);
 
 #pragma unroll
-  for (int s = 0; s < NS; ++s)
-#pragma unroll
-    for (int f = 0; f < MF; ++f) red[((wid * NS + s) * MF + f) * 64 + lane] = acc[s][f];
+  for (int f = 0; f < MF; ++f) red[(wid * MF + f) * 64 + lane] = acc[f];
+  MH_STAMP(KID, 1);     // operands arrived, products done
   __syncthreads();
-  if (!epi_thread) return;
+  MH_STAMP(KID, 2);     // all waves done
 
   const int pos = (EPI == SK_QKV) ? *p.pos : 0;
-  f32x4_t v = red[((0 * NS + es) * MF + ef) * 64 + lane];
+  const float* redf = reinterpret_cast<const float*>(red);
 #pragma unroll
-  for (int w = 1; w < NWV; ++w) {
-    const f32x4_t t = red[((w * NS + es) * MF + ef) * 64 + lane];
-    v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
-  }
-  f32x4_t u = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  if (EPI == SK_GEGLU) {
-    u = red[((0 * NS + 1) * MF + ef) * 64 + lane];
+  for (int u = 0; u < UPW; ++u) {
+    const int unit = wid + u * NWV;
+    if (unit >= MF * 4) break;
+    const int ef = unit >> 2, r = unit & 3;
+    float v = 0.f;
 #pragma unroll
-    for (int w = 1; w < NWV; ++w) {
-      const f32x4_t t = red[((w * NS + 1) * MF + ef) * 64 + lane];
-      u[0] += t[0]; u[1] += t[1]; u[2] += t[2]; u[3] += t[3];
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
+    for (int w = 0; w < NWV; ++w) v += redf[((w * MF + ef) * 64 + lane) * 4 + r];    // wave order: deterministic
     const int row = ef * 16 + lg * 4 + r;
-    const bool rok = row < p.B;
+    const bool ok = col_ok && row < p.B;
     if (EPI == SK_GEGLU) {
-      const int col = (strip0 / 2) * 16 + l15;
-      if (rok && col < p.N / 2)
-        reinterpret_cast<T*>(p.out)[(long)row * p.ldo + col] = Elem<T>::from_f32(gelu_tanh(v[r]) * u[r]);
-      continue;
-    }
-    const int col = (strip0 + es) * 16 + l15;
-    const bool ok = rok && col < p.N;
-    if (EPI == SK_STORE) {
-      if (ok) reinterpret_cast<T*>(p.out)[(long)row * p.ldo + col] = Elem<T>::from_f32(v[r]);
+      const float lin = __shfl_down(v, 8, 16);   // the linear half of the pair sits 8 tile columns to the right
+      if (ok) reinterpret_cast<T*>(p.out)[(long)row * p.ldo + ocol] = Elem<T>::from_f32(gelu_tanh(v) * lin);
+    } else if (EPI == SK_STORE) {
+      if (ok) reinterpret_cast<T*>(p.out)[(long)row * p.ldo + ocol] = Elem<T>::from_f32(v);
     } else if (EPI == SK_LOGITS) {
-      if (ok) reinterpret_cast<float*>(p.out)[(long)row * p.ldo + col] = v[r];
+      if (ok) reinterpret_cast<float*>(p.out)[(long)row * p.ldo + ocol] = v;
     } else if (EPI == SK_RESID) {
-      const float hn = oldh[r] + v[r];
-      if (ok) p.h[(long)row * p.ldh + col] = hn;
-      // partial sum of squares of this strip for the next RMSNorm (all 64 lanes take part in the shuffle)
-      const float sq = group_sum<16>(ok ? hn * hn : 0.f);
-      if (l15 == 0) p.ss_out[(long)(strip0 + es) * 64 + row] = sq;
+      if (ok) p.h[(long)row * p.ldh + ocol] = oldh[u] + v;
     } else if (EPI == SK_QKV) {
       if (ok) {
-        const int part = col / p.inner, c = col - part * p.inner;
+        const int part = ocol / p.inner, c = ocol - part * p.inner;
         if (part == 0) {
-          reinterpret_cast<T*>(p.out)[(long)row * p.ldo + c] = Elem<T>::from_f32(v[r]);
+          reinterpret_cast<T*>(p.out)[(long)row * p.ldo + c] = Elem<T>::from_f32(v);
         } else {
           const int hh = c >> 6, dd = c & 63;
           T* cache = reinterpret_cast<T*>(part == 1 ? p.kc : p.vc);
-          cache[(((long)row * p.H + hh) * p.tgt_len + pos) * 64 + dd] = Elem<T>::from_f32(v[r]);
+          cache[(((long)row * p.H + hh) * p.tgt_len + pos) * 64 + dd] = Elem<T>::from_f32(v);
         }
       }
     }
   }
+  MH_STAMP(KID, 3);     // epilogue stores issued
 }
 
 // ---- single-query attention (online softmax in registers) -----------------------------------------
@@ -346,24 +362,23 @@ __device__ inline void partial_init(Partial& s) {
   for (int i = 0; i < 8; ++i) s.acc[i] = 0.f;
 }
 template <typename T>
-__device__ inline void partial_merge(Partial& a, float m2, float l2, const float (&acc2)[8]) {
-  const float mn = fmaxf(a.m, m2);
-  const float fa = fexp<T>(a.m - mn), fb = fexp<T>(m2 - mn);
-  a.l = a.l * fa + l2 * fb;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) a.acc[i] = a.acc[i] * fa + acc2[i] * fb;
-  a.m = mn;
-}
-template <typename T>
 __device__ inline void partial_merge_groups(Partial& s) {  // across the 8 key groups of a wave
+  // rescale to the wave-wide maximum first (ONE exponential per lane), then plain shuffle sums: no exponential sits in
+  // the 3-level reduction chain
+  float mw = s.m;
+#pragma unroll
+  for (int o = 8; o < 64; o <<= 1) mw = fmaxf(mw, __shfl_xor(mw, o, 64));
+  const float f = fexp<T>(s.m - mw);
+  s.l *= f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s.acc[i] *= f;
 #pragma unroll
   for (int o = 8; o < 64; o <<= 1) {
-    const float m2 = __shfl_xor(s.m, o, 64), l2 = __shfl_xor(s.l, o, 64);
-    float a2[8];
+    s.l += __shfl_xor(s.l, o, 64);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) a2[i] = __shfl_xor(s.acc[i], o, 64);
-    partial_merge<T>(s, m2, l2, a2);
+    for (int i = 0; i < 8; ++i) s.acc[i] += __shfl_xor(s.acc[i], o, 64);
   }
+  s.m = mw;
 }
 
 template <typename T, int U>
@@ -461,16 +476,17 @@ __device__ inline void block_merge(const Partial& st, float (*sm)[66], float& m,
   __syncthreads();
   m = -1e30f; l = 0.f; a = 0.f;
   if (threadIdx.x < 64) {
+    // two passes over the NW partials: the block-wide maximum, then NW INDEPENDENT exponentials (a running merge chains
+    // 2 (NW - 1) dependent ones: ~0.7 us at NW = 16); wave order fixed => deterministic
     const int d = threadIdx.x;
-    m = sm[0][0]; l = sm[0][1]; a = sm[0][2 + d];
+    m = sm[0][0];
 #pragma unroll
-    for (int w = 1; w < NW; ++w) {
-      const float m2 = sm[w][0], l2 = sm[w][1], a2 = sm[w][2 + d];
-      const float mn = fmaxf(m, m2);
-      const float fa = fexp<T>(m - mn), fb = fexp<T>(m2 - mn);
-      l = l * fa + l2 * fb;
-      a = a * fa + a2 * fb;
-      m = mn;
+    for (int w = 1; w < NW; ++w) m = fmaxf(m, sm[w][0]);
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const float f = fexp<T>(sm[w][0] - m);
+      l += sm[w][1] * f;
+      a += sm[w][2 + d] * f;
     }
   }
 }
@@ -500,27 +516,19 @@ __global__ __launch_bounds__(256) void dec_self_attn_kernel(SelfAttnP p) {
 }
 
 struct CrossAttnP {
-  const void* q; int ldq;   // T [B, inner]
+  const void* q; int ldq;   // T [B, inner]   (kernel without its own projection)
   const void* k; const void* v;  // this layer's [B][H][L][64]
-  void* out; int ldo;       // T [B, inner] (splits == 1)
-  float* part;              // fp32 [B][H][splits][66] = (m, l, acc[64]) (splits > 1)
-  int* ticket;              // [B*H] arrival counters, zero between launches; non-null: the last-arriving split
-                            // of a (b, h) pair merges the partials in-kernel (no separate merge launch)
-  int B, H, L, splits;
+  void* out; int ldo;       // T [B, inner]
+  int B, H, L;
   int kv_B;                 // > 0: row b reads K/V row b % kv_B (CFG pairs share the encoder output)
+  // measurement only (mh_t5_decode_timing): [slots][2] = (earliest workgroup start, latest workgroup end) of THIS
+  // launch in wall-clock ticks, slot = (*pos % ts_ring) * ts_layers + ts_layer; NULL in production
+  unsigned long long* tstamp; const int* pos; int ts_ring, ts_layers, ts_layer;
 };
 
-// one workgroup (NW waves) per (b, h, split); the waves interleave 8-key rows of the split's key range.
-// NW = 4 with 4 key splits (+ merge kernel) or NW = 16 with one split (no merge launch): both keep the
-// reduction order of a row independent of the batch.
-template <typename T, int NW, int U = 4>
-__global__ __launch_bounds__(NW * 64) void dec_cross_attn_kernel(CrossAttnP p) {
-  __shared__ float sm[NW][66];
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int split = blockIdx.x % p.splits;
-  const int blk = blockIdx.x / p.splits;
-  int b, h;
-  if (p.kv_B > 0) {   // CFG (B == 2 kv_B): the two rows that share K/V sit in adjacent workgroups
+// (b, h) of workgroup `blk`; under CFG (B == 2 kv_B) the two rows that share K/V sit in adjacent workgroups
+__device__ inline void cross_pair_of_block(const CrossAttnP& p, int blk, int& b, int& h) {
+  if (p.kv_B > 0) {
     const int q2 = blk >> 1;
     b = (blk & 1) * p.kv_B + q2 / p.H;
     h = q2 % p.H;
@@ -528,12 +536,19 @@ __global__ __launch_bounds__(NW * 64) void dec_cross_attn_kernel(CrossAttnP p) {
     b = blk / p.H;
     h = blk % p.H;
   }
-  const int pair = b * p.H + h;
+}
+
+// one 16-wave workgroup per (b, h): the waves interleave 8-key rows of the 1251 encoder keys, partial (max, sum, acc)
+// merged through LDS in wave order -- the reduction order of a row never depends on the batch.  Used when the query was
+// projected by its own GEMV (option decode_fused_proj = 0).
+template <typename T, int U>
+__global__ __launch_bounds__(1024) void dec_cross_attn_kernel(CrossAttnP p) {
+  constexpr int NW = 16;
+  __shared__ float sm[NW][66];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  int b, h;
+  cross_pair_of_block(p, blockIdx.x, b, h);
   const int c8 = (lane & 7) * 8, g = lane >> 3;
-  const int per = (p.L + p.splits - 1) / p.splits;
-  const int k_lo = split * per;
-  int k_hi = k_lo + per;
-  k_hi = k_hi < p.L ? k_hi : p.L;
   float q[8];
   load8<T>(reinterpret_cast<const T*>(p.q) + (long)b * p.ldq + h * 64 + c8, q);
   const int kvb = p.kv_B > 0 ? b % p.kv_B : b;   // row b reads K/V row b % kv_B
@@ -541,63 +556,12 @@ __global__ __launch_bounds__(NW * 64) void dec_cross_attn_kernel(CrossAttnP p) {
   const T* vb = reinterpret_cast<const T*>(p.v) + ((long)kvb * p.H + h) * p.L * 64;
   Partial st;
   partial_init(st);
-  attend_keys<T, U>(st, q, kb, vb, k_lo + wid * 8 + g, k_hi, 8 * NW, nullptr, 0, nullptr, 0, 1.0f);
+  attend_keys<T, U>(st, q, kb, vb, wid * 8 + g, p.L, 8 * NW, nullptr, 0, nullptr, 0, 1.0f);
   partial_merge_groups<T>(st);
   float m, l, a;
   block_merge<T, NW>(st, sm, m, l, a);
-  if (threadIdx.x < 64) {
-    const int d = threadIdx.x;
-    if (p.splits == 1) {
-      reinterpret_cast<T*>(p.out)[(long)b * p.ldo + h * 64 + d] = Elem<T>::from_f32(l > 0.f ? a / l : 0.f);
-    } else if (p.ticket) {
-      float* pp = p.part + ((long)pair * p.splits + split) * 66;
-      if (d == 0) {
-        __hip_atomic_store(pp + 0, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(pp + 1, l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      __hip_atomic_store(pp + 2 + d, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-      float* pp = p.part + ((long)pair * p.splits + split) * 66;
-      if (d == 0) { pp[0] = m; pp[1] = l; }
-      pp[2 + d] = a;
-    }
-  }
-  if (p.splits > 1 && p.ticket) {
-    // In-kernel merge by the last-arriving split of a (b, h) pair.  Hand-off in the write-through form of
-    // cdna_hip_programming.md guideline 16: the 66-float partial is stored with sc1 (agent-scope relaxed atomic
-    // stores lower to `global_store_dword sc1`), every wave drains its stores, one relaxed agent-scope ticket is
-    // taken, and the block that draws the last ticket reads all partials with sc1 loads (L1 bypass).  No L2
-    // write-back fence (an agent-scope release in each of the ~800 workgroups cost far more than a merge launch).
-    __shared__ int s_last;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      const int t = __hip_atomic_fetch_add(p.ticket + pair, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const int last = (t == p.splits - 1) ? 1 : 0;
-      if (last) __hip_atomic_store(p.ticket + pair, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
-      s_last = last;
-    }
-    __syncthreads();
-    if (s_last && threadIdx.x < 64) {
-      const int d = threadIdx.x;
-      const float* pp = p.part + (long)pair * p.splits * 66;
-      float mm = __hip_atomic_load(pp + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      float ll = __hip_atomic_load(pp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      float aa = __hip_atomic_load(pp + 2 + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      for (int s2 = 1; s2 < p.splits; ++s2) {   // fixed split order: deterministic
-        const float* ps = pp + s2 * 66;
-        const float m2 = __hip_atomic_load(ps + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const float l2 = __hip_atomic_load(ps + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const float a2 = __hip_atomic_load(ps + 2 + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const float mn = fmaxf(mm, m2);
-        const float fa = fexp<T>(mm - mn), fb = fexp<T>(m2 - mn);
-        ll = ll * fa + l2 * fb;
-        aa = aa * fa + a2 * fb;
-        mm = mn;
-      }
-      reinterpret_cast<T*>(p.out)[(long)b * p.ldo + h * 64 + d] = Elem<T>::from_f32(ll > 0.f ? aa / ll : 0.f);
-    }
-  }
+  if (threadIdx.x < 64)
+    reinterpret_cast<T*>(p.out)[(long)b * p.ldo + h * 64 + threadIdx.x] = Elem<T>::from_f32(l > 0.f ? a / l : 0.f);
 }
 
 // ---- attention kernels that project their own query (and the new self-attention key / value) --------------------
@@ -608,7 +572,6 @@ __global__ __launch_bounds__(NW * 64) void dec_cross_attn_kernel(CrossAttnP p) {
 struct HeadProjP {
   const float* h; int ldh;            // fp32 residual stream [B, ldh]
   const float* ln_w; float eps;
-  const float* ss_in; int ss_parts;   // [ss_parts][64] partial sums of squares of the rows of h
   const void* W; int ldw;             // [rows, ldw] element type T (cross: Wq [inner][d]; self: Wqkv [3 inner][d])
   int d;
 };
@@ -631,53 +594,59 @@ template <> struct Raw8<float> {
   }
 };
 
-// xn[k] = T-rounded ln_w[k] * (h[b][k] * rsqrt(mean(h[b]^2) + eps)) for k < d, by a 1024-thread workgroup (d <= 1024);
-// the operand loads are requested before the statistics are waited for.  `stat` is one LDS float.
+// xn[k] = T-rounded ln_w[k] * (h[b][k] * rsqrt(mean(h[b]^2) + eps)) for k < d, by a 1024-thread workgroup (d <= 1024).
+// The statistics come from the row itself (wave sums -> 16 LDS floats that every thread adds in the same order).
 template <typename T>
-__device__ inline void norm_row_to_lds(const HeadProjP& hp, int b, float* xn, float* stat) {
+__device__ inline void norm_row_to_lds(const HeadProjP& hp, int b, float* xn, float* red16) {
   const int tid = threadIdx.x;
   const int kc = tid < hp.d ? tid : hp.d - 1;
   const float x = hp.h[(long)b * hp.ldh + kc];
   const float g = hp.ln_w[kc];
-  if (tid < 64) {
-    const float sv = hp.ss_in[(tid < hp.ss_parts ? tid : 0) * 64 + b];
-    const float tot = wave_sum(tid < hp.ss_parts ? sv : 0.f);
-    if (tid == 0) *stat = rsqrtf(tot / (float)hp.d + hp.eps);
-  }
+  const float sq = wave_sum(tid < hp.d ? x * x : 0.f);
+  if ((tid & 63) == 0) red16[tid >> 6] = sq;
   __syncthreads();
-  const float rs = *stat;
+  float tot = 0.f;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) tot += red16[w];
+  const float rs = rsqrtf(tot / (float)hp.d + hp.eps);
   if (tid < hp.d) xn[tid] = Elem<T>::to_f32(Elem<T>::from_f32(g * (x * rs)));
   __syncthreads();
 }
 
 // NP projections of 64 outputs each: out[p][o] = T-rounded sum_k xn[k] * W[(row0[p] + o) * ldw + k].
-// 1024 threads: 16 consecutive lanes per output, KC 8-element chunks per lane (d = 128 KC); all loads up front.
+// 1024 threads: 16 consecutive lanes per output, KC 8-element chunks per lane (d = 128 KC).  The weight slice does not
+// depend on the activations: `load` is called at kernel entry, `apply` after the normalised row is in LDS.
 template <typename T, int KC, int NP>
-__device__ inline void head_proj(const HeadProjP& hp, const int (&row0)[NP], const float* xn, float (*out)[64]) {
-  const int tid = threadIdx.x, o = tid >> 4, ks = tid & 15;
-  constexpr int kper = KC * 8;
+struct HeadProj {
   Raw8<T> raw[NP][KC];
+  __device__ inline void load(const HeadProjP& hp, const int (&row0)[NP]) {
+    const int tid = threadIdx.x, o = tid >> 4, ks = tid & 15;
 #pragma unroll
-  for (int q = 0; q < NP; ++q) {
-    const T* wp = reinterpret_cast<const T*>(hp.W) + (long)(row0[q] + o) * hp.ldw + ks * kper;
+    for (int q = 0; q < NP; ++q) {
+      const T* wp = reinterpret_cast<const T*>(hp.W) + (long)(row0[q] + o) * hp.ldw + ks * (KC * 8);
 #pragma unroll
-    for (int c = 0; c < KC; ++c) raw[q][c].load(wp + c * 8);
-  }
-#pragma unroll
-  for (int q = 0; q < NP; ++q) {
-    float acc = 0.f;
-#pragma unroll
-    for (int c = 0; c < KC; ++c) {
-      float w[8];
-      raw[q][c].unpack(w);
-      const float4 x0 = *reinterpret_cast<const float4*>(xn + ks * kper + c * 8);
-      const float4 x1 = *reinterpret_cast<const float4*>(xn + ks * kper + c * 8 + 4);
-      acc += x0.x * w[0] + x0.y * w[1] + x0.z * w[2] + x0.w * w[3] + x1.x * w[4] + x1.y * w[5] + x1.z * w[6] + x1.w * w[7];
+      for (int c = 0; c < KC; ++c) raw[q][c].load(wp + c * 8);
     }
-    acc = group_sum<16>(acc);
-    if (ks == 0) out[q][o] = Elem<T>::to_f32(Elem<T>::from_f32(acc));
   }
-}
+  __device__ inline void apply(const float* xn, float (*out)[64]) const {
+    const int tid = threadIdx.x, o = tid >> 4, ks = tid & 15;
+    constexpr int kper = KC * 8;
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      float acc = 0.f;
+#pragma unroll
+      for (int c = 0; c < KC; ++c) {
+        float w[8];
+        raw[q][c].unpack(w);
+        const float4 x0 = *reinterpret_cast<const float4*>(xn + ks * kper + c * 8);
+        const float4 x1 = *reinterpret_cast<const float4*>(xn + ks * kper + c * 8 + 4);
+        acc += x0.x * w[0] + x0.y * w[1] + x0.z * w[2] + x0.w * w[3] + x1.x * w[4] + x1.y * w[5] + x1.z * w[6] + x1.w * w[7];
+      }
+      acc = group_sum<16>(acc);
+      if (ks == 0) out[q][o] = Elem<T>::to_f32(Elem<T>::from_f32(acc));
+    }
+  }
+};
 
 // cross-attention of one (b, h) with its own query projection; 16 waves, one key split (the default configuration
 // of dec_cross_attn_kernel, same key interleave and merge order)
@@ -688,23 +657,25 @@ void dec_cross_attn_q_kernel(CrossAttnP p, HeadProjP hp) {
   __shared__ float sm[NW][66];
   __shared__ __attribute__((aligned(16))) float xn[1024];
   __shared__ float qs[1][64];
-  __shared__ float stat;
+  __shared__ float red16[16];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int blk = blockIdx.x;
   int b, h;
-  if (p.kv_B > 0) {
-    const int q2 = blk >> 1;
-    b = (blk & 1) * p.kv_B + q2 / p.H;
-    h = q2 % p.H;
-  } else {
-    b = blk / p.H;
-    h = blk % p.H;
-  }
+  cross_pair_of_block(p, blockIdx.x, b, h);
+  MH_STAMP0();
+  unsigned long long t_start = 0;
+  if (p.tstamp && threadIdx.x == 0) t_start = (unsigned long long)wall_clock64();
   const int c8 = (lane & 7) * 8, g = lane >> 3;
-  norm_row_to_lds<T>(hp, b, xn, &stat);
   const int row0[1] = {h * 64};
-  head_proj<T, KC, 1>(hp, row0, xn, qs);
+  HeadProj<T, KC, 1> proj;
+  // this head's 64 x d slice of Wq does not depend on the activations: bf16 requests it before the row statistics are
+  // waited for (fp32 -- the parity path -- would not fit the 64-register budget of two workgroups per CU)
+  if (sizeof(T) == 2) proj.load(hp, row0);
+  norm_row_to_lds<T>(hp, b, xn, red16);
+  MH_STAMP(KID_CROSS, 0);   // row normalised
+  if (sizeof(T) != 2) proj.load(hp, row0);
+  proj.apply(xn, qs);
   __syncthreads();
+  MH_STAMP(KID_CROSS, 1);   // query projected
   float q[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) q[i] = qs[0][c8 + i];
@@ -714,11 +685,18 @@ void dec_cross_attn_q_kernel(CrossAttnP p, HeadProjP hp) {
   Partial st;
   partial_init(st);
   attend_keys<T, U>(st, q, kb, vb, wid * 8 + g, p.L, 8 * NW, nullptr, 0, nullptr, 0, 1.0f);
+  MH_STAMP(KID_CROSS, 2);   // keys streamed (this wave)
   partial_merge_groups<T>(st);
   float m, l, a;
   block_merge<T, NW>(st, sm, m, l, a);
+  MH_STAMP(KID_CROSS, 3);   // partials merged
   if (threadIdx.x < 64)
     reinterpret_cast<T*>(p.out)[(long)b * p.ldo + h * 64 + threadIdx.x] = Elem<T>::from_f32(l > 0.f ? a / l : 0.f);
+  if (p.tstamp && threadIdx.x == 0) {
+    unsigned long long* slot = p.tstamp + 2 * ((long)(*p.pos % p.ts_ring) * p.ts_layers + p.ts_layer);
+    atomicMin(slot, t_start);
+    atomicMax(slot + 1, (unsigned long long)wall_clock64());
+  }
 }
 
 // self-attention of one (b, h) with its own q / k / v projections: appends the new key / value row to the caches and
@@ -729,23 +707,32 @@ __global__ __launch_bounds__(1024) void dec_self_attn_qkv_kernel(SelfAttnP p, He
   __shared__ float sm[NW][66];
   __shared__ __attribute__((aligned(16))) float xn[1024];
   __shared__ float qkv[3][64];
-  __shared__ float stat;
+  __shared__ float red16[16];
+  MH_STAMP0();
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
   const int pos = *p.pos;
   const int c8 = (lane & 7) * 8, g = lane >> 3;
-  norm_row_to_lds<T>(hp, b, xn, &stat);
   if (sizeof(T) == 2) {
     const int row0[3] = {h * 64, inner + h * 64, 2 * inner + h * 64};
-    head_proj<T, KC, 3>(hp, row0, xn, qkv);
+    HeadProj<T, KC, 3> proj;
+    // (requesting the 3 x 64 x d weights ahead of the normalisation costs 117 registers = ONE workgroup per CU: the
+    // two decode chains then queue behind each other for CUs -- measured 14.1 vs 12.5 us per launch in situ)
+    norm_row_to_lds<T>(hp, b, xn, red16);
+    proj.load(hp, row0);
+    proj.apply(xn, qkv);
   } else {   // fp32 storage: one projection at a time (register budget of a 1024-thread workgroup)
+    norm_row_to_lds<T>(hp, b, xn, red16);
 #pragma unroll
     for (int q3 = 0; q3 < 3; ++q3) {
       const int row0[1] = {q3 * inner + h * 64};
-      head_proj<T, KC, 1>(hp, row0, xn, qkv + q3);
+      HeadProj<T, KC, 1> proj;
+      proj.load(hp, row0);
+      proj.apply(xn, qkv + q3);
     }
   }
   __syncthreads();
+  MH_STAMP(KID_SELF, 0);    // q / k / v projected
   T* kcache = reinterpret_cast<T*>(const_cast<void*>(p.kc)) + ((long)b * p.H + h) * p.tgt_len * 64;
   T* vcache = reinterpret_cast<T*>(const_cast<void*>(p.vc)) + ((long)b * p.H + h) * p.tgt_len * 64;
   if (threadIdx.x >= 64 && threadIdx.x < 128) kcache[(long)pos * 64 + (threadIdx.x - 64)] = Elem<T>::from_f32(qkv[1][threadIdx.x - 64]);
@@ -758,9 +745,11 @@ __global__ __launch_bounds__(1024) void dec_self_attn_qkv_kernel(SelfAttnP p, He
   Partial st;
   partial_init(st);
   attend_keys<T, 2>(st, q, kcache, vcache, wid * 8 + g, pos, 8 * NW, bias_row, pos, mask_row, p.P, 1.0f);
+  MH_STAMP(KID_SELF, 1);    // cached keys attended (this wave)
   partial_merge_groups<T>(st);
   float m, l, a;
   block_merge<T, NW>(st, sm, m, l, a);
+  MH_STAMP(KID_SELF, 2);    // partials merged
   if (threadIdx.x < 64) {
     const int d = threadIdx.x;
     float sn = wave_sum(qkv[0][d] * qkv[1][d]) + bias_row[0];
@@ -771,24 +760,6 @@ __global__ __launch_bounds__(1024) void dec_self_attn_qkv_kernel(SelfAttnP p, He
     a = a * fa + qkv[2][d] * fb;
     reinterpret_cast<T*>(p.out)[(long)b * p.ldo + h * 64 + d] = Elem<T>::from_f32(l > 0.f ? a / l : 0.f);
   }
-}
-
-template <typename T>
-__global__ __launch_bounds__(64) void dec_cross_merge_kernel(CrossAttnP p) {
-  const int pair = blockIdx.x, d = threadIdx.x;
-  const int b = pair / p.H, h = pair % p.H;
-  const float* pp = p.part + (long)pair * p.splits * 66;
-  float m = pp[0], l = pp[1], a = pp[2 + d];
-  for (int s = 1; s < p.splits; ++s) {
-    const float* ps = pp + s * 66;
-    const float m2 = ps[0], l2 = ps[1], a2 = ps[2 + d];
-    const float mn = fmaxf(m, m2);
-    const float fa = fexp<T>(m - mn), fb = fexp<T>(m2 - mn);
-    l = l * fa + l2 * fb;
-    a = a * fa + a2 * fb;
-    m = mn;
-  }
-  reinterpret_cast<T*>(p.out)[(long)b * p.ldo + h * 64 + d] = Elem<T>::from_f32(l > 0.f ? a / l : 0.f);
 }
 
 }  // namespace dec

@@ -147,7 +147,6 @@ struct SampleP {
   float* proc;                        // [R][V] processed scores of this step (read back by the sampling passes)
   float* hist_scores;                 // [2][R][V] scores entering LookbackBias at this / the previous step
   const void* dec_embed; float* h; int d;
-  float* ss;                          // [64] sum of squares of the embedded row (RMSNorm statistics, 1 part)
   MhSampling sp;
   DecState* st;
   int B, P;                           // B = rows of the WHOLE batch
@@ -196,17 +195,9 @@ __global__ __launch_bounds__(256) void dec_init_kernel(SampleP p, int chain_rows
     p.finish_col[b] = p.max_length - 1;
     if (lb == 0) { p.st->pos = start_pos; p.st->n_running = chain_rows; p.st->ticket = 0; }
   }
-  __shared__ float scratch[8];
   const int tok = p.tokens[(long)b * p.max_length + start_pos];
   const T* e = reinterpret_cast<const T*>(p.dec_embed) + (long)tok * p.d;
-  float sq = 0.f;
-  for (int i = threadIdx.x; i < p.d; i += 256) {
-    const float v = Elem<T>::to_f32(e[i]);
-    p.h[(long)lb * p.d + i] = v;
-    sq += v * v;
-  }
-  sq = block_sum(sq, scratch);
-  if (threadIdx.x == 0) p.ss[lb] = sq;
+  for (int i = threadIdx.x; i < p.d; i += 256) p.h[(long)lb * p.d + i] = Elem<T>::to_f32(e[i]);
 }
 
 // One workgroup per returned row (per CFG pair): processors -> selection -> bookkeeping -> next-token embedding.
@@ -446,14 +437,7 @@ __global__ __launch_bounds__(256) void dec_sample_kernel(SampleP p) {
   for (int j = 0; j < nrow; ++j) {
     const int lrow = j == 0 ? lb : lneg;
     const T* e = reinterpret_cast<const T*>(p.dec_embed) + (long)s_tok[j] * p.d;
-    float sq = 0.f;
-    for (int i = tid; i < p.d; i += 256) {
-      const float v = Elem<T>::to_f32(e[i]);
-      p.h[(long)lrow * p.d + i] = v;
-      sq += v * v;
-    }
-    sq = block_sum(sq, sf);
-    if (tid == 0) p.ss[lrow] = sq;   // RMSNorm statistics of the new residual row (one part)
+    for (int i = tid; i < p.d; i += 256) p.h[(long)lrow * p.d + i] = Elem<T>::to_f32(e[i]);
   }
   // Step bookkeeping without a launch of its own: every workgroup read `pos` when it started, so the one that arrives
   // last may advance it; it also recounts the running rows for the host's early-stop poll.  The `finished` flags are
@@ -481,99 +465,66 @@ __global__ void dec_finalize_kernel(const int32_t* finish_col, int B, int32_t* n
   }
 }
 
-template <typename T, int MF, int NS, int PRO, int EPI>
-int launch_skinny(const dec::SkinnyP& p, hipStream_t s) {
-  const int strips = ceil_div(p.N, 16);
-  const int kb = 4 * (16 / (int)sizeof(T));
-  MH_REQUIRE(p.K % kb == 0 && p.K / kb >= 1, "decode: K=%d must be a multiple of %d and >= %d", p.K, kb, 4 * kb);
-  MH_REQUIRE(PRO != dec::PRO_RMSNORM || (p.ss_in && p.ss_parts >= 1 && p.ss_parts <= 64), "decode: bad RMSNorm statistics");
-  MH_REQUIRE(EPI != dec::SK_RESID || (p.ss_out && p.N % 16 == 0 && p.N / 16 <= 64), "decode: RESID needs N %% 16 == 0, N <= 1024");
-  if (PRO == dec::PRO_PLAIN && p.K / kb > 32) {   // long K (wo): 8 waves so that a single pass covers it
-    hipLaunchKernelGGL((dec::skinny_gemm_kernel<T, MF, NS, dec::PRO_PLAIN, EPI, 8>), dim3(ceil_div(strips, NS)), dim3(512), 0, s, p);
-    return check_launch("skinny_gemm_kernel");
-  }
-  hipLaunchKernelGGL((dec::skinny_gemm_kernel<T, MF, NS, PRO, EPI>), dim3(ceil_div(strips, NS)), dim3(256), 0, s, p);
-  return check_launch("skinny_gemm_kernel");
+// real columns per 16-column tile of a decode GEMV: the largest of 16 / 8 / 4 that still yields >= 192 workgroups
+// (option decode_gemv_cols overrides; a result never depends on it: every column is an independent dot product)
+int gemv_cols(int N) {
+  const long o = option(OPT_DECODE_GEMV_COLS);
+  if (o == 4 || o == 8 || o == 16) return (int)o;
+  if (N / 16 >= 192) return 16;
+  if (N / 8 >= 192) return 8;
+  return 4;
 }
 
-template <typename T, int NS, int PRO, int EPI>
+template <typename T, int MF, int PRO, int EPI>
+int launch_skinny(dec::SkinnyP p, hipStream_t s) {
+  const int kb = 4 * (16 / (int)sizeof(T));
+  MH_REQUIRE(p.K % kb == 0 && p.K >= kb, "decode: K=%d must be a positive multiple of %d", p.K, kb);
+  const int nkb = p.K / kb;
+  // waves per workgroup: a function of K ONLY (batch invariance of the summation order)
+  const bool wide = nkb > 4 * dec::kGemvCH;
+  MH_REQUIRE(PRO != dec::PRO_RMSNORM || nkb <= 8 * dec::kGemvCH, "decode: RMSNorm prologue needs K <= %d", 8 * dec::kGemvCH * kb);
+  int tiles;
+  if (EPI == dec::SK_GEGLU) { p.nv = 8; tiles = ceil_div(p.N / 2, 8); }
+  else { p.nv = gemv_cols(p.N); tiles = ceil_div(p.N, p.nv); }
+  if (wide) {
+    if constexpr (PRO == dec::PRO_RMSNORM && sizeof(T) == 2) {   // d_model > 1024 in bf16: not a shape of this model family
+      set_error("decode: RMSNorm GEMV needs d_model <= 1024 in bf16 storage");
+      return MH_ERR_ARG;
+    } else {
+      hipLaunchKernelGGL((dec::gemv_kernel<T, MF, 8, PRO, EPI>), dim3(tiles), dim3(512), 0, s, p);
+    }
+  } else {
+    hipLaunchKernelGGL((dec::gemv_kernel<T, MF, 4, PRO, EPI>), dim3(tiles), dim3(256), 0, s, p);
+  }
+  return check_launch("gemv_kernel");
+}
+
+template <typename T, int PRO, int EPI>
 int skinny(const dec::SkinnyP& p, hipStream_t s) {
-  if (p.B <= 16) return launch_skinny<T, 1, NS, PRO, EPI>(p, s);
-  if (p.B <= 32) return launch_skinny<T, 2, NS, PRO, EPI>(p, s);
-  return launch_skinny<T, 4, NS, PRO, EPI>(p, s);
+  if (p.B <= 16) return launch_skinny<T, 1, PRO, EPI>(p, s);
+  if (p.B <= 32) return launch_skinny<T, 2, PRO, EPI>(p, s);
+  return launch_skinny<T, 4, PRO, EPI>(p, s);
 }
 
 constexpr int kMaxChains = 8;
 
 struct DecBuffers {
-  float* h; void* q; void* attn; void* ff; float* logits; float* part; float* ss; int* ticket;
+  float* h; void* q; void* attn; void* ff; float* logits; int chain;
   void* self_k; void* self_v;  // [n_dec][B][H][tgt][64]
   uint8_t* finished; int32_t* finish_col; int32_t* last_ts; DecState* st;
-  int splits;
 };
-
-// Key-range splits of the decode cross-attention.  A CONSTANT (not a function of the batch) so that a row's
-// reduction order -- and therefore its bf16 rounding and its greedy tokens -- does not depend on which other
-// chunks share its batch.  4 splits x 4 waves: B*H*4 workgroups (1536 at B=32, H=12) fill the 256 CUs.
-int cross_splits(int /*B*/, int /*H*/) {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("MH_CROSS_SPLITS");
-    v = e ? atoi(e) : 1;
-    if (v != 1 && v != 2 && v != 4) v = 1;
-  }
-  return v;   // 1: 16-wave workgroups, no merge;  2: 8-wave x 2 key splits;  4: 4-wave x 4 key splits (+ merge)
-}
-
-int cross_unroll() {   // keys in flight per 8-lane group; measured (B=32 base bf16): U=2 5.08, U=4 4.64, U=8 3.37 TB/s
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("MH_CROSS_U");
-    v = e ? atoi(e) : 2;
-    if (v != 1 && v != 2 && v != 4 && v != 8) v = 2;
-  }
-  return v;
-}
-
-template <typename T, int NW, int U>
-void launch_cross_one(const dec::CrossAttnP& ca, int blocks, hipStream_t s) {
-  hipLaunchKernelGGL((dec::dec_cross_attn_kernel<T, NW, U>), dim3(blocks), dim3(NW * 64), 0, s, ca);
-}
-template <typename T, int NW>
-void launch_cross_u(const dec::CrossAttnP& ca, int blocks, hipStream_t s) {
-  const int u = cross_unroll();
-  if (u == 1) launch_cross_one<T, NW, 1>(ca, blocks, s);
-  else if (u == 2) launch_cross_one<T, NW, 2>(ca, blocks, s);
-  else if (u == 8) launch_cross_one<T, NW, 8>(ca, blocks, s);
-  else launch_cross_one<T, NW, 4>(ca, blocks, s);
-}
 
 template <typename T>
 int launch_cross(const dec::CrossAttnP& ca, hipStream_t s) {
-  if (ca.splits == 1) {
-    launch_cross_u<T, 16>(ca, ca.B * ca.H, s);
-    return check_launch("dec_cross_attn_kernel");
-  }
-  if (ca.splits == 2) launch_cross_u<T, 8>(ca, ca.B * ca.H * 2, s);
-  else launch_cross_u<T, 4>(ca, ca.B * ca.H * ca.splits, s);
-  int rc = check_launch("dec_cross_attn_kernel");
-  if (rc == MH_OK && !ca.ticket) {
-    hipLaunchKernelGGL(dec::dec_cross_merge_kernel<T>, dim3(ca.B * ca.H), dim3(64), 0, s, ca);
-    rc = check_launch("dec_cross_merge_kernel");
-  }
-  return rc;
+  // two keys in flight per 8-lane group (measured stand-alone, B=32 base bf16: U=2 5.08, U=4 4.64, U=8 3.37 TB/s)
+  hipLaunchKernelGGL((dec::dec_cross_attn_kernel<T, 2>), dim3(ca.B * ca.H), dim3(1024), 0, s, ca);
+  return check_launch("dec_cross_attn_kernel");
 }
 
-// attention kernels that project their own q (/ k / v): see decode_kernels.hpp.  d_model = 128 KC, KC in {1, 4, 6, 8}
-// (tiny / small / base / large); MH_DECODE_FUSED_PROJ=0 restores the stand-alone QKV and cross-Q GEMV launches.
-bool fused_proj_enabled(int d) {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("MH_DECODE_FUSED_PROJ");
-    v = (e && atoi(e) == 0) ? 0 : 1;
-  }
-  return v == 1 && (d == 128 || d == 512 || d == 768 || d == 1024);
-}
+// attention kernels that project their own q (/ k / v): see decode_kernels.hpp.  d_model = 128 KC, KC in 1..8; option
+// decode_fused_proj = 0 runs the stand-alone QKV and cross-Q GEMV launches instead (same results up to fp32 summation
+// order of the projections; both forms are covered by the GPU tests).
+bool fused_proj_enabled(int d) { return option(OPT_DECODE_FUSED_PROJ) != 0 && d % 128 == 0 && d >= 128 && d <= 1024; }
 
 template <typename T, int KC>
 int launch_self_qkv(const dec::SelfAttnP& sa, const dec::HeadProjP& hp, int inner, hipStream_t s) {
@@ -584,8 +535,12 @@ template <typename T>
 int launch_self_qkv_d(const dec::SelfAttnP& sa, const dec::HeadProjP& hp, int inner, hipStream_t s) {
   switch (hp.d) {
     case 128: return launch_self_qkv<T, 1>(sa, hp, inner, s);
+    case 256: return launch_self_qkv<T, 2>(sa, hp, inner, s);
+    case 384: return launch_self_qkv<T, 3>(sa, hp, inner, s);
     case 512: return launch_self_qkv<T, 4>(sa, hp, inner, s);
+    case 640: return launch_self_qkv<T, 5>(sa, hp, inner, s);
     case 768: return launch_self_qkv<T, 6>(sa, hp, inner, s);
+    case 896: return launch_self_qkv<T, 7>(sa, hp, inner, s);
     default: return launch_self_qkv<T, 8>(sa, hp, inner, s);
   }
 }
@@ -600,11 +555,19 @@ template <typename T>
 int launch_cross_q_d(const dec::CrossAttnP& ca, const dec::HeadProjP& hp, hipStream_t s) {
   switch (hp.d) {
     case 128: return launch_cross_q<T, 1>(ca, hp, s);
+    case 256: return launch_cross_q<T, 2>(ca, hp, s);
+    case 384: return launch_cross_q<T, 3>(ca, hp, s);
     case 512: return launch_cross_q<T, 4>(ca, hp, s);
+    case 640: return launch_cross_q<T, 5>(ca, hp, s);
     case 768: return launch_cross_q<T, 6>(ca, hp, s);
+    case 896: return launch_cross_q<T, 7>(ca, hp, s);
     default: return launch_cross_q<T, 8>(ca, hp, s);
   }
 }
+
+// measurement hook (mh_t5_decode_timing): device buffer that receives per-launch timestamps of the dominant kernel
+struct DecodeTiming { unsigned long long* buf = nullptr; int ring = 0; };
+DecodeTiming g_timing;
 
 template <typename T>
 int enqueue_step(const MhT5Config* c, const MhT5Weights* w, const void* cross_kv, int B, int Bfull, int kvB,
@@ -626,59 +589,60 @@ int enqueue_step(const MhT5Config* c, const MhT5Weights* w, const void* cross_kv
     sa.P = P; sa.out = bf.attn; sa.ldo = inner; sa.B = B; sa.H = H; sa.tgt_len = tgt; sa.pos = posp;
     if (fused) {
       dec::HeadProjP hp{};
-      hp.h = bf.h; hp.ldh = d; hp.ln_w = w->dec_ln1[l]; hp.eps = c->eps; hp.ss_in = bf.ss;
-      hp.ss_parts = (l == 0) ? 1 : d / 16; hp.W = w->dec_qkv[l]; hp.ldw = d; hp.d = d;
+      hp.h = bf.h; hp.ldh = d; hp.ln_w = w->dec_ln1[l]; hp.eps = c->eps; hp.W = w->dec_qkv[l]; hp.ldw = d; hp.d = d;
       MH_TRY(launch_self_qkv_d<T>(sa, hp, inner, s));
     } else {
       sk = dec::SkinnyP{};
       sk.A = bf.h; sk.lda = d; sk.ln_w = w->dec_ln1[l]; sk.eps = c->eps; sk.W = w->dec_qkv[l]; sk.ldw = d; sk.B = B;
-      sk.ss_in = bf.ss; sk.ss_parts = (l == 0) ? 1 : d / 16;
       sk.N = 3 * inner; sk.K = d; sk.out = bf.q; sk.ldo = inner; sk.kc = (char*)bf.self_k + cache_off;
       sk.vc = (char*)bf.self_v + cache_off; sk.H = H; sk.tgt_len = tgt; sk.inner = inner; sk.pos = posp;
-      MH_TRY((skinny<T, 1, dec::PRO_RMSNORM, dec::SK_QKV>(sk, s)));
+      MH_TRY((skinny<T, dec::PRO_RMSNORM, dec::SK_QKV>(sk, s)));
       hipLaunchKernelGGL(dec::dec_self_attn_kernel<T>, dim3(B * H), dim3(256), 0, s, sa);
       MH_TRY(check_launch("dec_self_attn_kernel"));
     }
     sk = dec::SkinnyP{};
     sk.A = bf.attn; sk.lda = inner; sk.W = w->dec_o[l]; sk.ldw = inner; sk.B = B; sk.N = d; sk.K = inner; sk.h = bf.h;
-    sk.ldh = d; sk.ss_out = bf.ss;
-    MH_TRY((skinny<T, 1, dec::PRO_PLAIN, dec::SK_RESID>(sk, s)));
+    sk.ldh = d;
+    MH_TRY((skinny<T, dec::PRO_PLAIN, dec::SK_RESID>(sk, s)));
     // cross attention
     dec::CrossAttnP ca{};
     const long kv_layer = (long)kvB * H * L * 64 * es;
     ca.q = bf.q; ca.ldq = inner; ca.k = (const char*)cross_kv + (long)(l * 2 + 0) * kv_layer;
-    ca.v = (const char*)cross_kv + (long)(l * 2 + 1) * kv_layer; ca.out = bf.attn; ca.ldo = inner; ca.part = bf.part;
-    ca.B = B; ca.H = H; ca.L = L; ca.splits = bf.splits; ca.ticket = bf.ticket; ca.kv_B = kvB < Bfull ? kvB : 0;
-    if (fused && bf.splits == 1) {
+    ca.v = (const char*)cross_kv + (long)(l * 2 + 1) * kv_layer; ca.out = bf.attn; ca.ldo = inner;
+    ca.B = B; ca.H = H; ca.L = L; ca.kv_B = kvB < Bfull ? kvB : 0;
+    if (g_timing.buf) {   // one region of ring x layers slots per chain (chain index = first row / rows of a full chain)
+      ca.tstamp = g_timing.buf + 2L * bf.chain * g_timing.ring * c->n_dec_layers;
+      ca.pos = posp; ca.ts_ring = g_timing.ring; ca.ts_layers = c->n_dec_layers; ca.ts_layer = l;
+    }
+    if (fused) {
       dec::HeadProjP hp{};
-      hp.h = bf.h; hp.ldh = d; hp.ln_w = w->dec_ln2[l]; hp.eps = c->eps; hp.ss_in = bf.ss; hp.ss_parts = d / 16;
-      hp.W = w->dec_cq[l]; hp.ldw = d; hp.d = d;
+      hp.h = bf.h; hp.ldh = d; hp.ln_w = w->dec_ln2[l]; hp.eps = c->eps; hp.W = w->dec_cq[l]; hp.ldw = d; hp.d = d;
       MH_TRY(launch_cross_q_d<T>(ca, hp, s));
     } else {
       sk = dec::SkinnyP{};
       sk.A = bf.h; sk.lda = d; sk.ln_w = w->dec_ln2[l]; sk.eps = c->eps; sk.W = w->dec_cq[l]; sk.ldw = d; sk.B = B;
-      sk.N = inner; sk.K = d; sk.out = bf.q; sk.ldo = inner; sk.ss_in = bf.ss; sk.ss_parts = d / 16;
-      MH_TRY((skinny<T, 1, dec::PRO_RMSNORM, dec::SK_STORE>(sk, s)));
+      sk.N = inner; sk.K = d; sk.out = bf.q; sk.ldo = inner;
+      MH_TRY((skinny<T, dec::PRO_RMSNORM, dec::SK_STORE>(sk, s)));
       MH_TRY(launch_cross<T>(ca, s));
     }
     sk = dec::SkinnyP{};
     sk.A = bf.attn; sk.lda = inner; sk.W = w->dec_co[l]; sk.ldw = inner; sk.B = B; sk.N = d; sk.K = inner; sk.h = bf.h;
-    sk.ldh = d; sk.ss_out = bf.ss;
-    MH_TRY((skinny<T, 1, dec::PRO_PLAIN, dec::SK_RESID>(sk, s)));
+    sk.ldh = d;
+    MH_TRY((skinny<T, dec::PRO_PLAIN, dec::SK_RESID>(sk, s)));
     // feed forward
     sk = dec::SkinnyP{};
     sk.A = bf.h; sk.lda = d; sk.ln_w = w->dec_ln3[l]; sk.eps = c->eps; sk.W = w->dec_wi[l]; sk.ldw = d; sk.B = B;
-    sk.N = 2 * dff; sk.K = d; sk.out = bf.ff; sk.ldo = dff; sk.ss_in = bf.ss; sk.ss_parts = d / 16;
-    MH_TRY((skinny<T, 2, dec::PRO_RMSNORM, dec::SK_GEGLU>(sk, s)));
+    sk.N = 2 * dff; sk.K = d; sk.out = bf.ff; sk.ldo = dff;
+    MH_TRY((skinny<T, dec::PRO_RMSNORM, dec::SK_GEGLU>(sk, s)));
     sk = dec::SkinnyP{};
     sk.A = bf.ff; sk.lda = dff; sk.W = w->dec_wo[l]; sk.ldw = dff; sk.B = B; sk.N = d; sk.K = dff; sk.h = bf.h;
-    sk.ldh = d; sk.ss_out = bf.ss;
-    MH_TRY((skinny<T, 1, dec::PRO_PLAIN, dec::SK_RESID>(sk, s)));
+    sk.ldh = d;
+    MH_TRY((skinny<T, dec::PRO_PLAIN, dec::SK_RESID>(sk, s)));
   }
   dec::SkinnyP sk{};
   sk.A = bf.h; sk.lda = d; sk.ln_w = w->dec_final_ln; sk.eps = c->eps; sk.W = w->lm_head; sk.ldw = d; sk.B = B;
-  sk.N = c->vocab_out; sk.K = d; sk.out = bf.logits; sk.ldo = c->vocab_out; sk.ss_in = bf.ss; sk.ss_parts = d / 16;
-  MH_TRY((skinny<T, 1, dec::PRO_RMSNORM, dec::SK_LOGITS>(sk, s)));
+  sk.N = c->vocab_out; sk.K = d; sk.out = bf.logits; sk.ldo = c->vocab_out;
+  MH_TRY((skinny<T, dec::PRO_RMSNORM, dec::SK_LOGITS>(sk, s)));
   hipLaunchKernelGGL(dec_sample_kernel<T>, dim3(smp.pair > 0 ? smp.pair : B), dim3(256), 0, s, smp);
   MH_TRY(check_launch("dec_sample_kernel"));
   return MH_OK;
@@ -703,11 +667,8 @@ extern "C" int64_t mh_t5_decode_workspace_bytes(const MhT5Config* c, int B) {
   t += align256((int64_t)B * inner * es) * 2;                                     // q, attn
   t += align256((int64_t)B * c->d_ff * es);                                       // ff
   t += align256((int64_t)B * c->vocab_out * 4);                                   // logits
-  t += align256((int64_t)B * c->n_heads * 8 * 66 * 4);                            // cross partials
-  t += align256(64 * 64 * 4) * kMaxChains;                                        // RMSNorm partial sums of squares
   t += align256((int64_t)c->n_dec_layers * B * inner * c->tgt_len * es) * 2;      // self K, V caches
   t += align256(B) + align256((int64_t)B * 4) * 2 + align256(sizeof(DecState)) * kMaxChains;   // flags / state
-  t += align256((int64_t)B * c->n_heads * 4);                                     // cross-attention merge tickets
   t += align256((int64_t)B * c->vocab_out * 4) * 3;                               // processed scores + LookbackBias history
   t += prefill_layout(c, B, c->tgt_len - 1, nullptr, 0, nullptr);                  // batched prompt prefill
   return t;
@@ -845,6 +806,8 @@ int pick_chains(int B) {
 
 struct ChainPool {   // extra streams + fork/join events of ONE device, created on first use under that device
   hipStream_t streams[kMaxChains] = {};
+  hipStream_t part[2] = {};      // two streams bound to disjoint halves of the CUs (option decode_cu_split)
+  int part_mode = 0;
   hipEvent_t fork = nullptr, join[kMaxChains] = {};
   bool ready = false;
   int init() {
@@ -856,6 +819,23 @@ struct ChainPool {   // extra streams + fork/join events of ONE device, created 
         return check_launch("chain stream create");
     }
     ready = true;
+    return MH_OK;
+  }
+  // Two decode chains on disjoint CU sets: their kernels never queue behind each other for CU slots and (mode 1) never
+  // share an L2.  mode 1: XCD-interleaved numbering (CU bit i lives on XCD i % 8) -> chain 0 = XCDs 0-3, chain 1 = XCDs
+  // 4-7; mode 2: contiguous numbering (first / second 128 bits).
+  int init_partition(int mode) {
+    if (part_mode == mode) return MH_OK;
+    for (int i = 0; i < 2; ++i)
+      if (part[i]) { (void)hipStreamDestroy(part[i]); part[i] = nullptr; }
+    part_mode = 0;
+    for (int i = 0; i < 2; ++i) {
+      uint32_t mask[8];
+      for (int w = 0; w < 8; ++w)
+        mask[w] = mode == 1 ? (i == 0 ? 0x0F0F0F0Fu : 0xF0F0F0F0u) : ((w < 4) == (i == 0) ? 0xFFFFFFFFu : 0u);
+      if (hipExtStreamCreateWithCUMask(&part[i], 8, mask) != hipSuccess) return check_launch("hipExtStreamCreateWithCUMask");
+    }
+    part_mode = mode;
     return MH_OK;
   }
 };
@@ -907,25 +887,15 @@ extern "C" int mh_t5_generate(const MhT5Config* c, const MhT5Weights* w, const v
   all.attn = ar.take((int64_t)B * inner * es);
   all.ff = ar.take((int64_t)B * c->d_ff * es);
   all.logits = (float*)ar.take((int64_t)B * V * 4);
-  all.part = (float*)ar.take((int64_t)B * H * 8 * 66 * 4);
-  float* ss_all = (float*)ar.take((int64_t)64 * 64 * 4 * kMaxChains);
   all.self_k = ar.take((int64_t)c->n_dec_layers * B * inner * c->tgt_len * es);
   all.self_v = ar.take((int64_t)c->n_dec_layers * B * inner * c->tgt_len * es);
   all.finished = (uint8_t*)ar.take(B);
   all.finish_col = (int32_t*)ar.take((int64_t)B * 4);
   all.last_ts = (int32_t*)ar.take((int64_t)B * 4);
   DecState* st_all = (DecState*)ar.take((int64_t)align256(sizeof(DecState)) * kMaxChains);
-  int* ticket_all = (int*)ar.take((int64_t)B * H * 4);
   float* proc = (float*)ar.take((int64_t)B * V * 4);
   float* hist_scores = (float*)ar.take((int64_t)B * V * 4 * 2);
   MH_REQUIRE(ar.ok() && hist_scores, "mh_t5_generate: arena overflow");
-  // In-kernel merge of the cross-attention key splits (write-through partials + ticket, see dec_cross_attn_kernel);
-  // MH_DECODE_FUSED_MERGE=0 falls back to the separate merge launch.
-  const char* fm = getenv("MH_DECODE_FUSED_MERGE");
-  const bool fuse_merge = !(fm && atoi(fm) == 0);
-  if (hipMemsetAsync(ticket_all, 0, (size_t)B * H * 4, s) != hipSuccess) return check_launch("ticket memset");
-  all.splits = cross_splits(B, H);
-
   // a CFG pair spans both halves of the batch and the (batch-wide) conditional temperature reads row 0's history: one chain
   const int n_chains = (cfg || (sp->n_cond > 0 && !sp->cond_per_row)) ? 1 : pick_chains(B);
   const int rows_per = ceil_div(B, n_chains);
@@ -940,6 +910,10 @@ extern "C" int mh_t5_generate(const MhT5Config* c, const MhT5Weights* w, const v
   std::lock_guard<std::mutex> pool_guard(dp->mu);
   ChainPool& g_pool = dp->pool;
   MH_TRY(g_pool.init());
+  const int cu_split = (n_chains == 2) ? (int)option(OPT_DECODE_CU_SPLIT) : 0;
+  if (cu_split == 1 || cu_split == 2) MH_TRY(g_pool.init_partition(cu_split));
+  hipStream_t chain_stream[kMaxChains];
+  for (int i = 0; i < kMaxChains; ++i) chain_stream[i] = (g_pool.part_mode == cu_split && cu_split && i < 2) ? g_pool.part[i] : g_pool.streams[i];
 
   // tokens[:, :P] = prompt; the remainder is produced by the sampler
   if (hipMemcpy2DAsync(tokens, (size_t)sp->max_length * 4, prompt, (size_t)P * 4, (size_t)P * 4, B,
@@ -969,20 +943,18 @@ extern "C" int mh_t5_generate(const MhT5Config* c, const MhT5Weights* w, const v
     const int b0 = ci * rows_per;
     const int Bc = (b0 + rows_per <= B) ? rows_per : B - b0;
     if (Bc <= 0) break;
-    hipStream_t cs = g_pool.streams[ci];
+    hipStream_t cs = chain_stream[ci];
     if (hipStreamWaitEvent(cs, g_pool.fork, 0) != hipSuccess) { rc = check_launch("fork wait"); break; }
     DecBuffers bf = all;
+    bf.chain = ci;
     bf.h = all.h + (long)b0 * d;
     bf.q = (char*)all.q + (long)b0 * inner * es;
     bf.attn = (char*)all.attn + (long)b0 * inner * es;
     bf.ff = (char*)all.ff + (long)b0 * c->d_ff * es;
     bf.logits = all.logits + (long)b0 * V;
-    bf.part = all.part + (long)b0 * H * 8 * 66;
-    bf.ss = ss_all + (long)ci * 64 * 64;
     bf.self_k = (char*)all.self_k + (long)b0 * inner * c->tgt_len * es;
     bf.self_v = (char*)all.self_v + (long)b0 * inner * c->tgt_len * es;
     bf.finished = all.finished + b0;
-    bf.ticket = fuse_merge ? ticket_all + (long)b0 * H : nullptr;
     bf.st = (DecState*)((char*)st_all + (long)ci * align256(sizeof(DecState)));
     states[ci] = bf.st;
     const void* ckv = (const char*)cross_kv + (long)b0 * H * c->src_len * 64 * es;
@@ -992,7 +964,7 @@ extern "C" int mh_t5_generate(const MhT5Config* c, const MhT5Weights* w, const v
     smp.logits = bf.logits; smp.ldl = V; smp.V = V; smp.tokens = tokens; smp.max_length = sp->max_length;
     smp.forced = forced; smp.eos_table = eos_table; smp.finished = all.finished; smp.finish_col = all.finish_col;
     smp.last_ts_val = all.last_ts; smp.logits_dump = logits_dump; smp.dec_embed = w->dec_embed; smp.h = bf.h;
-    smp.d = d; smp.ss = bf.ss; smp.sp = *sp; smp.st = bf.st; smp.B = B; smp.P = P; smp.b0 = b0;
+    smp.d = d; smp.sp = *sp; smp.st = bf.st; smp.B = B; smp.P = P; smp.b0 = b0;
     smp.proc = proc; smp.hist_scores = hist_scores; smp.pair = cfg ? B / 2 : 0; smp.chain_rows = Bc;
 
     if (bf16) hipLaunchKernelGGL(dec_init_kernel<bf16_t>, dim3(Bc), dim3(256), 0, cs, smp, Bc, start_pos);
@@ -1020,12 +992,12 @@ extern "C" int mh_t5_generate(const MhT5Config* c, const MhT5Weights* w, const v
     while (step < total_steps) {
       const int burst = total_steps - step < poll_every ? total_steps - step : poll_every;
       for (int i = 0; i < burst; ++i)
-        if (hipGraphLaunch(execs[ci], g_pool.streams[ci]) != hipSuccess) return MH_ERR_LAUNCH;
+        if (hipGraphLaunch(execs[ci], chain_stream[ci]) != hipSuccess) return MH_ERR_LAUNCH;
       step += burst;
       if (step < total_steps && !forced) {
         int running = 1;
-        if (hipMemcpyAsync(&running, &states[ci]->n_running, 4, hipMemcpyDeviceToHost, g_pool.streams[ci]) != hipSuccess ||
-            hipStreamSynchronize(g_pool.streams[ci]) != hipSuccess)
+        if (hipMemcpyAsync(&running, &states[ci]->n_running, 4, hipMemcpyDeviceToHost, chain_stream[ci]) != hipSuccess ||
+            hipStreamSynchronize(chain_stream[ci]) != hipSuccess)
           return MH_ERR_LAUNCH;
         if (running == 0) break;
       }
@@ -1047,7 +1019,7 @@ extern "C" int mh_t5_generate(const MhT5Config* c, const MhT5Weights* w, const v
   }
   // join the chains back into the caller's stream
   for (int ci = 0; ci < used; ++ci) {
-    (void)hipEventRecord(g_pool.join[ci], g_pool.streams[ci]);
+    (void)hipEventRecord(g_pool.join[ci], chain_stream[ci]);
     (void)hipStreamWaitEvent(s, g_pool.join[ci], 0);
   }
   if (rc == MH_OK) {
@@ -1098,6 +1070,34 @@ extern "C" int mh_t5_decoder_forward(const MhT5Config* c, const MhT5Weights* w, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// In-situ timing of the dominant kernel.  `buf` (device, uint64 [n_chains][ring][n_dec_layers][2], pre-filled by the
+// caller with (UINT64_MAX, 0) pairs) makes every cross-attention launch of the following mh_t5_generate calls record its
+// earliest workgroup start and latest workgroup end in wall-clock ticks (hipDeviceAttributeWallClockRate kHz); slot =
+// decode position % ring.  buf = NULL switches it off.  Costs two atomics per workgroup: bench.py uses an EXTRA decode
+// pass for it, never the timed region.
+extern "C" int mh_t5_decode_timing(void* buf, int ring) {
+  MH_REQUIRE((buf == nullptr) == (ring <= 0), "mh_t5_decode_timing: buf and ring go together");
+  mh::g_timing.buf = (unsigned long long*)buf;
+  mh::g_timing.ring = ring;
+  return MH_OK;
+}
+
+#ifdef MH_PHASE_STAMPS
+// profiling build only: read (and optionally clear) the phase stamps; out = host uint64 [16][16][2]
+extern "C" int mh_debug_phase_stamps(unsigned long long* out, int reset) {
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(mh::dec::g_stamps), sizeof(mh::dec::g_stamps)) != hipSuccess)
+    return mh::check_launch("stamps read");
+  if (reset) {
+    static unsigned long long zero[16 * 16 * 2] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(mh::dec::g_stamps), zero, sizeof(zero)) != hipSuccess) return mh::check_launch("stamps reset");
+  }
+  return MH_OK;
+}
+#endif
+
+extern "C" int mh_t5_decode_chains(int B) { return B > 0 ? mh::pick_chains(B) : 0; }
+
+// ------------------------------------------------------------------------------------------------
 // Measurement hook for bench.py's roofline line: the dominant decode kernel (cross-attention over the
 // encoder keys) launched `reps` times back to back between two HIP events ON THE GIVEN STREAM, cycling
 // through the decoder layers exactly like a decode step does (so every launch streams a different layer's
@@ -1113,17 +1113,11 @@ extern "C" int mh_t5_cross_attn_probe(const MhT5Config* c, const MhT5Weights* w,
   float* h = (float*)ar.take((int64_t)B * d * 4);
   void* q = ar.take((int64_t)B * inner * es);
   void* attn = ar.take((int64_t)B * inner * es);
-  (void)ar.take((int64_t)B * c->d_ff * es);
-  (void)ar.take((int64_t)B * c->vocab_out * 4);
-  float* part = (float*)ar.take((int64_t)B * H * 8 * 66 * 4);
-  float* ss = (float*)ar.take((int64_t)64 * 64 * 4 * kMaxChains);
   if (hipMemsetAsync(q, 0, (size_t)B * inner * es, s) != hipSuccess) return check_launch("probe memset");
   if (hipMemsetAsync(h, 0, (size_t)B * d * 4, s) != hipSuccess) return check_launch("probe memset");
-  if (hipMemsetAsync(ss, 0, (size_t)64 * 64 * 4, s) != hipSuccess) return check_launch("probe memset");
-  const int splits = cross_splits(B, H);
   // the kernel the decode step launches: with weights given and the fused projections on, the cross-attention that
   // also projects its query (dec_cross_attn_q_kernel); otherwise the stand-alone dec_cross_attn_kernel
-  const bool with_q = w != nullptr && splits == 1 && fused_proj_enabled(d);
+  const bool with_q = w != nullptr && fused_proj_enabled(d);
   const long kv_layer = (long)B * H * L * 64 * es;
   hipEvent_t e0, e1;
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return check_launch("event create");
@@ -1134,12 +1128,11 @@ extern "C" int mh_t5_cross_attn_probe(const MhT5Config* c, const MhT5Weights* w,
       const int l = r % c->n_dec_layers;
       dec::CrossAttnP ca{};
       ca.q = q; ca.ldq = inner; ca.k = (const char*)cross_kv + (long)(l * 2 + 0) * kv_layer;
-      ca.v = (const char*)cross_kv + (long)(l * 2 + 1) * kv_layer; ca.out = attn; ca.ldo = inner; ca.part = part;
-      ca.B = B; ca.H = H; ca.L = L; ca.splits = splits; ca.ticket = nullptr;
+      ca.v = (const char*)cross_kv + (long)(l * 2 + 1) * kv_layer; ca.out = attn; ca.ldo = inner;
+      ca.B = B; ca.H = H; ca.L = L;
       if (with_q) {
         dec::HeadProjP hp{};
-        hp.h = h; hp.ldh = d; hp.ln_w = w->dec_ln2[l]; hp.eps = c->eps; hp.ss_in = ss; hp.ss_parts = d / 16;
-        hp.W = w->dec_cq[l]; hp.ldw = d; hp.d = d;
+        hp.h = h; hp.ldh = d; hp.ln_w = w->dec_ln2[l]; hp.eps = c->eps; hp.W = w->dec_cq[l]; hp.ldw = d; hp.d = d;
         rc = c->dtype == MH_BF16 ? launch_cross_q_d<bf16_t>(ca, hp, s) : launch_cross_q_d<float>(ca, hp, s);
       } else {
         rc = c->dtype == MH_BF16 ? launch_cross<bf16_t>(ca, s) : launch_cross<float>(ca, s);

@@ -145,6 +145,40 @@ int main() {
     t.join();
     printf("two concurrent graphs (%s): %6.2f / %6.2f us/kernel per stream\n", fn == f_chain ? "1-float chain" : "gemv 48 WG", r[0], r[1]);
   }
+  // four graphs from four host threads (why do 3-4 decode chains run slower than 2?)
+  {
+    hipStream_t ss[4] = {s, s2, nullptr, nullptr};
+    CHECK(hipStreamCreateWithFlags(&ss[2], hipStreamNonBlocking));
+    CHECK(hipStreamCreateWithFlags(&ss[3], hipStreamNonBlocking));
+    for (EnqueueFn fn : {f_chain, f_gemv48}) {
+      double r[4];
+      std::vector<std::thread> th;
+      for (int i = 1; i < 4; ++i) th.emplace_back([&, i] { r[i] = run_graph(fn, chain, reps, ss[i]); });
+      r[0] = run_graph(fn, chain, reps, ss[0]);
+      for (auto& t : th) t.join();
+      printf("four concurrent graphs (%s): %6.2f / %6.2f / %6.2f / %6.2f us/kernel per stream\n",
+             fn == f_chain ? "1-float chain" : "gemv 48 WG", r[0], r[1], r[2], r[3]);
+    }
+    // the same four streams fed from ONE host thread (round-robin graph launches)
+    for (EnqueueFn fn : {f_chain, f_gemv48}) {
+      hipGraph_t g[4]; hipGraphExec_t ge[4];
+      for (int i = 0; i < 4; ++i) {
+        CHECK(hipStreamBeginCapture(ss[i], hipStreamCaptureModeThreadLocal));
+        for (int k = 0; k < chain; ++k) fn(ss[i], k);
+        CHECK(hipStreamEndCapture(ss[i], &g[i]));
+        CHECK(hipGraphInstantiate(&ge[i], g[i], nullptr, nullptr, 0));
+      }
+      for (int i = 0; i < 4; ++i) CHECK(hipGraphLaunch(ge[i], ss[i]));
+      CHECK(hipDeviceSynchronize());
+      timespec t0, t1; clock_gettime(CLOCK_MONOTONIC, &t0);
+      for (int r2 = 0; r2 < reps; ++r2) for (int i = 0; i < 4; ++i) CHECK(hipGraphLaunch(ge[i], ss[i]));
+      CHECK(hipDeviceSynchronize());
+      clock_gettime(CLOCK_MONOTONIC, &t1);
+      const double us = (t1.tv_sec - t0.tv_sec) * 1e6 + (t1.tv_nsec - t0.tv_nsec) * 1e-3;
+      printf("four streams, one launcher thread (%s): %6.2f us per kernel per stream (%.2f us per kernel overall)\n",
+             fn == f_chain ? "1-float chain" : "gemv 48 WG", us / ((double)reps * chain), us / ((double)reps * chain * 4));
+    }
+  }
   // host cost of replaying a 72-node graph (launch call only, GPU idle wait excluded)
   {
     hipGraph_t g; hipGraphExec_t ge;
