@@ -1,14 +1,22 @@
 #!/usr/bin/env python
 """Headline benchmark: beatmap event-tokens/s of the audio->event hot path on N x MI355X
 (BASELINE.json configs[1]: osuT5-base, bf16 storage, batch = 32 ten-second chunks per GPU,
-mel + encoder + cross-KV + KV-cached greedy AR decode, all hand-written HIP kernels), plus the
-diffusion steps/s per song-chunk of the DiT-S + 100-step DDPM refinement stage (configs[2]) as an
-auxiliary figure.
+mel + encoder + cross-KV + KV-cached greedy AR decode, all hand-written HIP kernels).
 
 One "step" = one pass of the hot path over one batch of synthetic chunks that already sits in HBM:
   mh_mel -> mh_t5_encode -> mh_t5_cross_kv -> mh_t5_generate (new_tokens greedy tokens per row)
   [-> all_gather of the token streams over RCCL when N > 1].
 value = (non-pad generated tokens summed over ALL ranks) / (max over ranks of the timed region / steps).
+
+Besides the contract fields the JSON line carries
+  roofline      the dominant kernel (decode cross-attention) AS THE TIMED REGION LAUNCHES IT: rows per launch and
+                in-situ microseconds from device-side timestamps taken in an EXTRA decode pass (never the timed one),
+                next to the stand-alone full-batch probe and to the step-level figure (SURVEY 8d bytes per token step /
+                measured decode time per token step);
+  cpu_baseline  the CPU oracle (a port, kind "port") on a bounded sample of the same workload;
+  aux           config 1 (osuT5-small, 1 chunk, 128 tokens: GPU and CPU port), config 3 (T5 + DiT-S 100-step DDPM
+                refine of all 32 chunks as one denoiser batch: diffusion steps/s per chunk, end-to-end chunks/s), the
+                end-to-end rate through `model_generate` including H2D / D2H, per-stage milliseconds.
 
 Contract: python bench.py --gpus N --steps K --warmup W ; for N > 1 launched by torch.distributed.run,
 one rank per GPU.  Rank 0 prints ONE JSON line.
@@ -29,7 +37,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6.3 TB/s achievable
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6.3 TB/s achievable
+F32_MFMA_PEAK_TF = 157.3  # exact-f32 MFMA (= fp32 vector) peak, same guide
+SRC_FRAMES, N_SAMPLES = 1251, 160000
 
 
 def parse():
@@ -43,25 +53,34 @@ def parse():
     ap.add_argument("--new-tokens", type=int, default=384)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dit", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip config 1 / end-to-end / in-situ passes")
     return ap.parse_args()
 
 
+# ---------------------------------------------------------------------------------------------------------
+# CPU baselines (the ONLY places bench.py touches oracle/: the checker timed as the `port` baseline)
+# ---------------------------------------------------------------------------------------------------------
+def _cpu_threads():
+    # small-matrix decode work does not scale past a handful of threads (256 threads on the 2-socket host of the
+    # GPU box made it 100x SLOWER); use min(host cores, 16) threads and report that number
+    cores = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(cores)
+    return cores
+
+
 def cpu_baseline(size: str, vocab, seconds_budget: float = 25.0):
-    """The CPU oracle (a port of the reference's algorithm: oracle/t5.py, torch-CPU fp32, all host cores)
-    on a BOUNDED sample of the same workload.  This is the only place bench.py touches oracle/."""
+    """The CPU oracle (a port of the reference's algorithm: oracle/t5.py, torch-CPU fp32) on a BOUNDED sample of the
+    headline workload."""
     from mapperatorinator_amd.t5_engine import T5_PRESETS
     from mapperatorinator_amd.testing import random_t5_state_dict, synthetic_audio
     from oracle import t5 as ot5
-    # small-matrix decode work does not scale past a handful of threads (256 threads on the 2-socket host
-    # of the GPU box made it 100x SLOWER); use min(host cores, 16) threads and report that number
-    cores = min(os.cpu_count() or 1, 16)
-    torch.set_num_threads(cores)
+    cores = _cpu_threads()
     d = T5_PRESETS[size]
     vin, vout, ts0, ts1 = vocab
     sd = random_t5_state_dict(d, vin, vout, seed=0, lm_head_gain=6.0)
     o = ot5.T5Oracle(sd, d.d_model, d.d_ff, d.n_heads, d.n_enc_layers, d.n_dec_layers)
     Bc = 4
-    audio = synthetic_audio(Bc, 160000, seed=0)
+    audio = synthetic_audio(Bc, N_SAMPLES, seed=0)
     prompt = torch.tensor([[1]] * Bc)
     t0 = time.perf_counter()
     enc = o.encode_audio(audio)
@@ -76,7 +95,6 @@ def cpu_baseline(size: str, vocab, seconds_budget: float = 25.0):
         ids = o.generate(enc, prompt, None, [], 1 + new, ts0, ts1, [1])
         t_dec = time.perf_counter() - t1
     n_tok = int((ids[:, 1:] != 0).sum())
-    # whole-path rate for chunks that decode `full_new` tokens each: encoder cost amortised over them
     full_new = 384
     per_chunk = t_enc / Bc + full_new * (t_dec / n_tok)
     return {"value": full_new / per_chunk, "unit": "event-tokens/s", "cores": cores, "kind": "port",
@@ -85,13 +103,30 @@ def cpu_baseline(size: str, vocab, seconds_budget: float = 25.0):
                       f"({n_tok / t_dec:.1f} tok/s decode-only); value = 384 / (encoder s per chunk + 384 x decode s per token)"}
 
 
+def cpu_config1(vocab, new_tokens: int = 128):
+    """BASELINE configs[0] (osuT5-small, ONE 10 s chunk, greedy, 128 new tokens) through the CPU port."""
+    from mapperatorinator_amd.t5_engine import T5_PRESETS
+    from mapperatorinator_amd.testing import random_t5_state_dict, synthetic_audio
+    from oracle import t5 as ot5
+    cores = _cpu_threads()
+    d = T5_PRESETS["small"]
+    vin, vout, ts0, ts1 = vocab
+    o = ot5.T5Oracle(random_t5_state_dict(d, vin, vout, seed=0, lm_head_gain=6.0), d.d_model, d.d_ff, d.n_heads,
+                     d.n_enc_layers, d.n_dec_layers)
+    audio = synthetic_audio(1, N_SAMPLES, seed=0)
+    t0 = time.perf_counter()
+    enc = o.encode_audio(audio)
+    ids = o.generate(enc, torch.tensor([[1]]), None, [], 1 + new_tokens, ts0, ts1, [1])
+    dt = time.perf_counter() - t0
+    return {"value": round(int((ids[:, 1:] != 0).sum()) / dt, 1), "unit": "event-tokens/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/t5.py, osuT5-small fp32, 1 chunk, {new_tokens} greedy tokens, mel+encoder+decode in {dt:.2f} s"}
+
+
 def cpu_dit_baseline(n_steps: int = 6):
-    """The DiT-S denoiser of configs[2] through the CPU oracle (oracle/dit.py: the checker, timed here as the `port`
-    baseline of the diffusion metric): `n_steps` forward_with_cfg calls at Tq = 128, CFG batch 2."""
+    """The DiT-S denoiser of configs[2] through the CPU oracle: `n_steps` forward_with_cfg calls at Tq = 128, CFG batch 2."""
     from mapperatorinator_amd.testing import DIT_PRESETS, random_dit_state_dict, synthetic_dit_inputs
     from oracle import dit as odit
-    cores = min(os.cpu_count() or 1, 16)
-    torch.set_num_threads(cores)
+    cores = _cpu_threads()
     depth, hidden, heads = DIT_PRESETS["DiT-S"]
     orc = odit.DiTOracle(random_dit_state_dict(depth, hidden, seed=0), depth, hidden, heads)
     z, c, y = synthetic_dit_inputs(128, seed=0)
@@ -104,6 +139,23 @@ def cpu_dit_baseline(n_steps: int = 6):
     return {"value": round(1.0 / dt, 2), "unit": "diffusion steps/s per chunk", "cores": cores, "kind": "port",
             "sample": f"oracle/dit.py DiT-S fp32, Tq=128, CFG batch 2, {n_steps} denoiser calls ({dt * 1e3:.1f} ms each); the "
                       f"DDPM update itself is negligible"}
+
+
+# ---------------------------------------------------------------------------------------------------------
+def decode_step_bytes(dims, B: int, vocab_out: int, es: int, t_avg: float) -> float:
+    """SURVEY.md 8d algorithmic bytes of ONE token step: decoder weights + lm_head, read once per step, + per row the
+    cross-attention K/V of every layer and the self-attention K/V written so far (t_avg positions)."""
+    d, dff, inner, L = dims.d_model, dims.d_ff, dims.inner, dims.n_dec_layers
+    per_layer = (3 * inner * d + inner * d) + (inner * d + inner * d) + (2 * dff * d + d * dff)   # self qkv+o, cross q+o, ffn
+    weights = L * per_layer * es + d * vocab_out * es
+    cross = L * 2 * dims.n_heads * SRC_FRAMES * 64 * es
+    self_kv = L * 2 * dims.n_heads * t_avg * 64 * es
+    return weights + B * (cross + self_kv)
+
+
+def dit_flops_per_step(depth: int, D: int, N: int, T: int, band: int = 0) -> float:
+    """N * [depth * (2 T 12 D^2 + 4 T^2 D) + 2 T 528 D] (dense attention count)."""
+    return N * (depth * (2.0 * T * 12 * D * D + 4.0 * T * T * D) + 2.0 * T * 528 * D)
 
 
 def main():
@@ -124,38 +176,49 @@ def main():
 
     from mapperatorinator_amd import Tokenizer, _lib
     from mapperatorinator_amd.modeling import MapperatorinatorHIP
-    from mapperatorinator_amd.server import build_sampling
+    from mapperatorinator_amd.server import build_sampling, model_generate
     from mapperatorinator_amd.t5_engine import T5_PRESETS
     from mapperatorinator_amd.testing import random_t5_state_dict, synthetic_audio
 
     lib = _lib.load()
     tdtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    tok = Tokenizer.benchmark_vocab(src_seq_len=1251)
+    tok = Tokenizer.benchmark_vocab(src_seq_len=SRC_FRAMES)
     ts0 = [v for k, v in tok.event_start.items() if k.name == "TIME_SHIFT"][0]
     ts1 = [v for k, v in tok.event_end.items() if k.name == "TIME_SHIFT"][0]
+    vocab = (tok.vocab_size_in, tok.vocab_size_out, ts0, ts1)
     dims = T5_PRESETS[args.size]
     B, new = args.batch, args.new_tokens
     tgt_len = max(512, 1 + new)
     sd = random_t5_state_dict(dims, tok.vocab_size_in, tok.vocab_size_out, seed=0, lm_head_gain=6.0)
     model = MapperatorinatorHIP(sd, dims, vocab_size_in=tok.vocab_size_in, vocab_size_out=tok.vocab_size_out,
-                                src_seq_len=1251, tgt_seq_len=tgt_len, dtype=tdtype, device=dev)
+                                src_seq_len=SRC_FRAMES, tgt_seq_len=tgt_len, dtype=tdtype, device=dev)
     eng = model.engine
     del sd
-    audio = synthetic_audio(B, 160000, seed=rank).to(dev)            # resident in HBM before the timed region
+    audio_host = synthetic_audio(B, N_SAMPLES, seed=rank)
+    audio = audio_host.to(dev)                                             # resident in HBM before the timed region
     prompt = torch.full((B, 1), tok.sos_id, dtype=torch.int32, device=dev)
     gk = dict(do_sample=False, num_beams=1, max_length=1 + new, temperature=1.0, context_type="map", pad_token_id=0)
     sp, eos = build_sampling(tok, gk, tgt_len)
     eos_table = torch.zeros(tok.vocab_size_out, dtype=torch.uint8, device=dev)   # random-init: keep rows running
     gathered = torch.empty((world * B, 1 + new), dtype=torch.int32, device=dev) if use_dist else None
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
 
-    def one_step():
+    def one_step(record=False, gather=True):
         eng._enter()
         with torch.cuda.stream(eng.stream):
+            if record:
+                ev[0].record(eng.stream)
             enc = eng.encode_mel(eng.mel(audio))
+            if record:
+                ev[1].record(eng.stream)
             kv = eng.cross_kv(enc)
+            if record:
+                ev[2].record(eng.stream)
             tokens, n_out, _ = eng.decode(kv, prompt, None, eos_table, sp, poll_every=64)
+            if record:
+                ev[3].record(eng.stream)
         eng._leave()
-        if use_dist:
+        if use_dist and gather:
             dist.all_gather_into_tensor(gathered, tokens.contiguous())
         return tokens, kv
 
@@ -186,65 +249,172 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = n_tok_total / (elapsed / args.steps)
 
+    # ---- per-stage milliseconds (one extra pass with events on the engine's stream; not the timed region) --------
+    tokens, kv = one_step(record=True)
+    fence()
+    stage = {"mel_encoder_ms": round(ev[0].elapsed_time(ev[1]), 3), "cross_kv_ms": round(ev[1].elapsed_time(ev[2]), 3),
+             "decode_ms": round(ev[2].elapsed_time(ev[3]), 3)}
+    decode_us_per_step = stage["decode_ms"] * 1e3 / new
+
+    # ---- diffusion stage (configs[2] / [3]): every rank refines ITS chunks as one denoiser batch, coordinates are
+    # all-gathered next to the tokens -------------------------------------------------------------------
+    aux = {"stage_ms": stage}
+    if not args.no_dit:
+        from mapperatorinator_amd.dit import BandMask, DiTHIP, create_diffusion
+        from mapperatorinator_amd.testing import DIT_PRESETS, random_dit_state_dict, synthetic_dit_inputs
+        depth, hidden, heads = DIT_PRESETS["DiT-S"]
+        dit = DiTHIP(random_dit_state_dict(depth, hidden, seed=0), depth, hidden, heads, device=dev)
+        Tq = 128
+        parts = [synthetic_dit_inputs(Tq, seed=rank * B + b) for b in range(B)]
+        z = torch.cat([p[0][:1] for p in parts] + [p[0][1:] for p in parts]).to(dev)      # [cond rows | null rows]
+        c = torch.cat([p[1][:1] for p in parts] + [p[1][1:] for p in parts]).to(dev)
+        y = torch.cat([p[2][:1] for p in parts] + [p[2][1:] for p in parts]).to(dev)
+        diff = create_diffusion([100, 0, 0, 0, 0, 0, 0, 0, 0, 0], noise_schedule="squaredcos_cap_v2", diffusion_steps=1000)
+        coords_all = torch.empty((world * B, 2, Tq), dtype=torch.float32, device=dev) if use_dist else None
+
+        def dit_stage(zz, cc, yy, gather):
+            kw = dict(c=cc, y=yy, cfg_scale=1.0, attn_mask=BandMask(Tq, 128))
+            noise = torch.randn(100, *zz.shape, device=dev)
+            out = diff.p_sample_loop(dit.forward_with_cfg, zz.shape, zz, model_kwargs=kw, step_noise=noise)
+            coords = out[: zz.shape[0] // 2].contiguous()
+            if gather and use_dist:
+                dist.all_gather_into_tensor(coords_all, coords)
+            return coords
+
+        def timed(fn, reps):
+            fn()
+            fence()
+            t = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            fence()
+            return (time.perf_counter() - t) / reps
+
+        dt_one = timed(lambda: dit_stage(z[[0, B]], c[[0, B]], y[[0, B]], False), 3)     # the reference's shape: one chunk
+        dt_all = timed(lambda: dit_stage(z, c, y, True), 2)
+        if use_dist:
+            tt = torch.tensor([dt_all], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt_all = float(tt[0])
+        flops = dit_flops_per_step(depth, hidden, 2 * B, Tq) * 100
+        aux["diffusion"] = {
+            "dit": "DiT-S fp32 (exact-f32 MFMA), Tq=128, 100-step DDPM as one replayed hipGraph",
+            "one_chunk": {"ms_per_100_steps": round(dt_one * 1e3, 2), "steps_per_s_per_chunk": round(100 / dt_one, 1)},
+            "batched": {"chunks_per_gpu": B, "denoiser_batch": 2 * B, "ms_per_100_steps": round(dt_all * 1e3, 2),
+                        "steps_per_s_per_chunk": round(100 * B / dt_all, 1),
+                        "tflops": round(flops / dt_all / 1e12, 1), "frac_of_f32_mfma_peak": round(flops / dt_all / 1e12 / F32_MFMA_PEAK_TF, 3),
+                        "coords_all_gather": bool(use_dist)},
+        }
+        aux["diffusion_steps_per_s_per_chunk"] = aux["diffusion"]["batched"]["steps_per_s_per_chunk"]
+        # configs[2] end to end: T5 path + diffusion refine of the same chunks, whole job
+        aux["config3_end_to_end"] = {"chunks": world * B, "seconds": round(ms_per_step / 1e3 + dt_all, 4),
+                                     "chunks_per_s": round(world * B / (ms_per_step / 1e3 + dt_all), 2),
+                                     "t5_ms": round(ms_per_step, 2), "diffusion_ms": round(dt_all * 1e3, 2)}
+
     if rank != 0:
         if use_dist:
             dist.destroy_process_group()
         return
 
-    # ---- roofline of the dominant kernel (HBM-bound decode cross-attention), measured live -------------
+    # ---- roofline of the dominant kernel (HBM-bound decode cross-attention) ------------------------------------
     es = 2 if args.dtype == "bf16" else 4
-    alg_bytes = B * dims.n_heads * 1251 * 64 * 2 * es            # K and V of one layer, read once per launch
+    bytes_per_row = dims.n_heads * SRC_FRAMES * 64 * 2 * es                      # K and V of one layer, one chunk
+    # (a) in situ: device-side wall-clock stamps of every launch of one extra decode pass
+    n_chains = lib.mh_t5_decode_chains(B)
+    rows_per_launch = -(-B // n_chains)
+    ring, L = 64, dims.n_dec_layers
+    in_situ_us = None
+    if not args.no_extras:
+        tbuf = torch.zeros((n_chains, ring, L, 2), dtype=torch.int64, device=dev)
+        tbuf[..., 0] = -1                                                          # = UINT64_MAX for atomicMin
+        _lib.check(lib.mh_t5_decode_timing(tbuf.data_ptr(), ring), "mh_t5_decode_timing")
+        try:
+            one_step(gather=False)      # (rank 0 only: no collective in here)
+            torch.cuda.synchronize(dev)
+        finally:
+            _lib.check(lib.mh_t5_decode_timing(None, 0), "mh_t5_decode_timing")
+        t = tbuf.cpu().numpy().view("uint64")
+        okm = t[..., 1] > t[..., 0]
+        khz = lib.mh_wall_clock_khz() or 100000                                       # 100 MHz on gfx950
+        if okm.any():
+            in_situ_us = float((t[..., 1][okm] - t[..., 0][okm]).astype("float64").mean()) / (khz / 1e3)
+    # (b) stand-alone probe: the same kernel back to back at the full batch on the engine's stream (HIP events)
     ms = C.c_float(0.0)
     ws = eng._workspace("dec", lib.mh_t5_decode_workspace_bytes(C.byref(eng.packed.cfg), B))
-    reps = 20 * dims.n_dec_layers
-    rc = lib.mh_t5_cross_attn_probe(C.byref(eng.packed.cfg), C.byref(eng.packed.w), kv.data_ptr(), B, reps, C.byref(ms),
+    rc = lib.mh_t5_cross_attn_probe(C.byref(eng.packed.cfg), C.byref(eng.packed.w), kv.data_ptr(), B, 20 * L, C.byref(ms),
                                     ws.data_ptr(), ws.numel(), eng.stream.cuda_stream)
     _lib.check(rc, "mh_t5_cross_attn_probe")
-    achieved = alg_bytes / (ms.value * 1e-3) / 1e9
-    # HBM bytes per launch from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 passes, gfx950
-    # correction applied -- profiles/r01_pmc_hbm_traffic.txt); only quoted for the exact workload it was taken on
-    traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_cross_attn.json")
-    if os.path.exists(pmc_path) and args.size == "base" and args.dtype == "bf16" and B == 32:
-        with open(pmc_path) as f:
-            traffic = json.load(f).get("hbm_bytes_per_launch")
-    roofline = {"bound": "hbm", "kernel": "dec_cross_attn_q_kernel (cross-attention over the encoder K/V incl. its query projection)", "achieved": round(achieved, 1),
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "alg_bytes_per_launch": alg_bytes, "us_per_launch": round(ms.value * 1e3, 2),
-                "launches_per_token_step": dims.n_dec_layers}
+    probe_gbs = B * bytes_per_row / (ms.value * 1e-3) / 1e9
+    # (c) the whole token step against the bytes it must move
+    step_bytes = decode_step_bytes(dims, B, tok.vocab_size_out, es, t_avg=(1 + new) / 2.0)
+    step_gbs = step_bytes / (decode_us_per_step * 1e-6) / 1e9
+    use_us = in_situ_us if in_situ_us else ms.value * 1e3
+    use_rows = rows_per_launch if in_situ_us else B
+    achieved = use_rows * bytes_per_row / (use_us * 1e-6) / 1e9
+    roofline = {
+        "bound": "hbm", "kernel": "dec_cross_attn_q_kernel (decode cross-attention over the encoder K/V incl. its query projection)",
+        "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+        "traffic": None,   # PMC FETCH_SIZE/WRITE_SIZE need rocprofv3: profiles/r02_pmc_* hold the counter runs
+        "how": ("in situ: mean (last workgroup end - first workgroup start) over the launches of one extra decode pass, "
+                "device wall clock; the other chain's kernels run beside it" if in_situ_us else "stand-alone probe"),
+        "rows_per_launch": use_rows, "alg_bytes_per_launch": use_rows * bytes_per_row, "us_per_launch": round(use_us, 2),
+        "launches_per_token_step": L * n_chains, "decode_chains": n_chains,
+        "probe": {"rows_per_launch": B, "alg_bytes_per_launch": B * bytes_per_row, "us_per_launch": round(ms.value * 1e3, 2),
+                  "achieved": round(probe_gbs, 1), "frac": round(probe_gbs / HBM_PEAK_GBS, 4),
+                  "how": "the same kernel back to back at the full batch, HIP events on the engine's stream"},
+        "step": {"alg_bytes_per_token_step": int(step_bytes), "us_per_token_step": round(decode_us_per_step, 1),
+                 "achieved": round(step_gbs, 1), "frac": round(step_gbs / HBM_PEAK_GBS, 4),
+                 "how": "SURVEY 8d bytes (decoder weights + lm_head + B x (cross K/V + self K/V at the mean position)) / "
+                        "(decode stage time / new tokens)"},
+    }
 
-    # ---- auxiliary: DiT-S + 100-step DDPM, diffusion steps/s per song-chunk (configs[2]) ---------------
-    aux = {}
-    if not args.no_dit:
-        from mapperatorinator_amd.dit import DiTHIP, create_diffusion
-        from mapperatorinator_amd.testing import DIT_PRESETS, random_dit_state_dict, synthetic_dit_inputs
-        depth, hidden, heads = DIT_PRESETS["DiT-S"]
-        dit = DiTHIP(random_dit_state_dict(depth, hidden, seed=0), depth, hidden, heads, device=dev)
-        z, c, y = synthetic_dit_inputs(128, seed=0)
-        z, c, y = z.to(dev), c.to(dev), y.to(dev)
-        diff = create_diffusion([100, 0, 0, 0, 0, 0, 0, 0, 0, 0], noise_schedule="squaredcos_cap_v2",
-                                diffusion_steps=1000)
-        kw = dict(c=c, y=y, cfg_scale=1.0, attn_mask=None)
-        noise = torch.randn(100, *z.shape, device=dev)
-        diff.p_sample_loop(dit.forward_with_cfg, z.shape, z, model_kwargs=kw, step_noise=noise)
-        torch.cuda.synchronize(dev)
+    # ---- configs[0] on the GPU, and the end-to-end rate through the reference-shaped boundary ---------------------
+    if not args.no_extras:
+        e2e_audio = audio_host                                                       # HOST tensors, as server.py:86 receives them
+        mk = dict(inputs=e2e_audio, decoder_input_ids=torch.full((B, 1), tok.sos_id, dtype=torch.long))
+        # model_generate builds its EOS set from the tokenizer; random-init rows may stop early, so the rate is tokens / s
+        model_generate(model, tok, mk, gk)                                          # warm-up
         t0 = time.perf_counter()
-        reps_d = 5
-        for _ in range(reps_d):
-            diff.p_sample_loop(dit.forward_with_cfg, z.shape, z, model_kwargs=kw, step_noise=noise)
-        torch.cuda.synchronize(dev)
-        dt = (time.perf_counter() - t0) / reps_d
-        aux = {"diffusion_steps_per_s_per_chunk": round(100 / dt, 1), "dit": "DiT-S fp32, Tq=128, CFG batch 2, "
-               "100-step DDPM (fused hipGraph loop)", "ms_per_100_steps": round(dt * 1e3, 2)}
+        ids, st = model_generate(model, tok, mk, gk)
+        dt = time.perf_counter() - t0
+        aux["e2e_model_generate"] = {"tokens_per_s": round(st["generated_tokens"] / dt, 1), "seconds": round(dt, 4),
+                                     "generated_tokens": st["generated_tokens"],
+                                     "includes": "H2D of 32 x 640 KB audio, mel, encoder, cross-KV, decode, D2H of the ids, host "
+                                                 "bookkeeping of mapperatorinator_amd.server.model_generate (EOS set active)"}
+        d1 = T5_PRESETS["small"]
+        m1 = MapperatorinatorHIP(random_t5_state_dict(d1, tok.vocab_size_in, tok.vocab_size_out, seed=0, lm_head_gain=6.0), d1,
+                                 vocab_size_in=tok.vocab_size_in, vocab_size_out=tok.vocab_size_out, src_seq_len=SRC_FRAMES,
+                                 tgt_seq_len=512, dtype=torch.float32, device=dev)
+        a1 = synthetic_audio(1, N_SAMPLES, seed=0).to(dev)
+        p1 = torch.full((1, 1), tok.sos_id, dtype=torch.int32, device=dev)
+        sp1, _ = build_sampling(tok, dict(gk, max_length=129), 512)
+
+        def cfg1():
+            e1 = m1.engine
+            e1._enter()
+            with torch.cuda.stream(e1.stream):
+                e1.decode(e1.cross_kv(e1.encode_mel(e1.mel(a1))), p1, None, eos_table, sp1, poll_every=64)
+            e1._leave()
+            torch.cuda.synchronize(dev)
+        cfg1()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            cfg1()
+        dt1 = (time.perf_counter() - t0) / 3
+        aux["config1"] = {"workload": "osuT5-small fp32 (the bit-exact storage mode), 1 x 10 s chunk, 128 greedy tokens, "
+                                      "mel+encoder+decode (BASELINE configs[0])",
+                          "gpu_tokens_per_s": round(128 / dt1, 1), "gpu_ms": round(dt1 * 1e3, 2)}
+        del m1
 
     cpu = None
     if not args.no_cpu_baseline and world == 1:   # the CPU port is timed on rank 0 at N=1 only
-        cpu = cpu_baseline(args.size, (tok.vocab_size_in, tok.vocab_size_out, ts0, ts1))
-        if aux:
-            try:
-                aux["cpu_baseline"] = cpu_dit_baseline()
-            except Exception as e:   # the auxiliary figure must never cost the bench line
-                print(f"cpu_dit_baseline failed: {e!r}", file=sys.stderr)
+        cpu = cpu_baseline(args.size, vocab)
+        for key, fn in (("config1", lambda: cpu_config1(vocab)), ("diffusion", cpu_dit_baseline)):
+            if key in aux:
+                try:
+                    aux[key]["cpu_baseline"] = fn()
+                except Exception as e:   # an auxiliary figure must never cost the bench line
+                    print(f"cpu baseline for {key} failed: {e!r}", file=sys.stderr)
 
     line = {
         "metric": "beatmap event-tokens/sec (mel + osuT5 encoder + greedy AR decode), whole job",
@@ -253,8 +423,8 @@ def main():
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic 16 kHz audio (noise + tones), random-init weights",
         "config": {"workload": f"osuT5-{args.size} {args.dtype}, batch={B} x 10 s chunks per GPU, {new} greedy tokens "
                                f"per chunk, mel+encoder+cross-KV+AR decode (BASELINE configs[1])",
-                   "chunks_per_gpu": B, "new_tokens": new, "src_frames": 1251, "vocab": tok.vocab_size_out,
-                   "parallelism": f"chunk-sharded x{world}, all_gather of token streams"},
+                   "chunks_per_gpu": B, "new_tokens": new, "src_frames": SRC_FRAMES, "vocab": tok.vocab_size_out,
+                   "parallelism": f"chunk-sharded x{world}, all_gather of token streams (+ diffusion coordinates in aux)"},
         "roofline": roofline, "cpu_baseline": cpu, "aux": aux,
     }
     print(json.dumps(line))

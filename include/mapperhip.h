@@ -302,12 +302,13 @@ int mh_t5_cross_attn_probe(const MhT5Config* cfg, const MhT5Weights* w, const vo
 
 /* Measurement hook (bench.py `roofline`, in situ): with `buf` set, every cross-attention launch of the following
  * mh_t5_generate calls records (earliest workgroup start, latest workgroup end) in wall-clock ticks
- * (hipDeviceAttributeWallClockRate, kHz) into buf[chain][pos % ring][layer][2] (device uint64, pre-filled by the caller
- * with (UINT64_MAX, 0)): the duration of the kernel exactly as the decode step launches it -- rows of one chain per
+ * (hipDeviceAttributeWallClockRate, kHz) into buf[chain][pos][layer][2] for decode positions pos < ring (device uint64,
+ * pre-filled by the caller with (UINT64_MAX, 0)): the duration of the kernel exactly as the decode step launches it -- rows of one chain per
  * launch, the other chain's kernels running beside it.  Two atomics per workgroup: use an extra decode pass, not a
  * timed one.  buf == NULL (ring 0) switches it off.  mh_t5_decode_chains(B) = row chains mh_t5_generate uses for B. */
 int mh_t5_decode_timing(void* buf, int ring);
 int mh_t5_decode_chains(int B);
+int mh_wall_clock_khz(void);
 
 /* ------------------------------------------------------------------------------------------------
  * K7/K8/K9  osu_diffusion DiT + DDPM.  Replaces DiT.forward_with_cfg

@@ -103,6 +103,7 @@ SYMBOLS = {
     "mh_t5_cross_attn_probe": (I, [C.POINTER(MhT5Config), C.POINTER(MhT5Weights), VP, I, I, C.POINTER(C.c_float), VP, I64, VP]),
     "mh_t5_decode_timing": (I, [VP, I]),
     "mh_t5_decode_chains": (I, [I]),
+    "mh_wall_clock_khz": (I, []),
     "mh_dit_workspace_bytes": (I64, [C.POINTER(MhDiTConfig), I, I]),
     "mh_dit_forward_cfg": (I, [C.POINTER(MhDiTConfig), C.POINTER(MhDiTWeights), VP, VP, VP, VP, F, I, I, I,
                                VP, VP, I64, VP]),

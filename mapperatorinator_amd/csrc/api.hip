@@ -36,6 +36,8 @@ static OptionSlot g_options[OPT_COUNT] = {
     {"decode_gemv_cols", "MH_DECODE_GEMV_COLS", 0, false},       // valid weight rows per 16-column MFMA tile of the decode GEMVs (0 = automatic)
     {"decode_fused_proj", "MH_DECODE_FUSED_PROJ", 1, false},     // 1: attention kernels project their own q / k / v, 0: stand-alone GEMVs
     {"decode_cu_split", "MH_DECODE_CU_SPLIT", 0, false},         // two chains on disjoint CU halves: 1 = XCDs 0-3 / 4-7, 2 = first / second 128 CU bits
+    {"gemm_tile128_min", "MH_GEMM_TILE128_MIN", 192, false},     // the 128x128 GEMM tile is used from this many tiles on (else 64x64 / smaller)
+    {"attn_small_max_wgs", "MH_ATTN_SMALL_MAX_WGS", 1024, false}, // fp32 attention at L <= 256: key-split latency kernel up to this many workgroups, flash kernel beyond
 };
 
 long option(int id) {

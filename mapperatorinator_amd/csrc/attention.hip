@@ -375,15 +375,10 @@ __global__ __launch_bounds__(256) void attn_small_f32_kernel(SmallAttnP p) {
   }
 }
 
-// MH_ATTN_SMALL=0 routes the short fp32 sequences through the flash kernel again
-bool small_attn_enabled() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("MH_ATTN_SMALL");
-    v = (e && atoi(e) == 0) ? 0 : 1;
-  }
-  return v == 1;
-}
+// The key-split kernel is a LATENCY design (one CFG pair: 96 workgroups of 16 queries instead of 24 of 64); with many
+// chunks in one denoiser batch its per-lane operand loads (80 dword loads per lane, every workgroup re-reading its
+// head's K / V from L2) lose to the LDS-staged flash kernel: option attn_small_max_wgs (default 1024 workgroups).
+bool small_attn_ok(int B, int H, int L) { return (long)B * H * ceil_div(L, 16) <= option(OPT_ATTN_SMALL_MAX_WGS); }
 
 }  // namespace
 
@@ -392,7 +387,7 @@ int attention(const void* qk, int ld_qk, int k_col0, const void* vt, int Lpad, c
   MH_REQUIRE(qk && vt && out, "mh_attention: null operand");
   const int es = dtype == MH_BF16 ? 2 : 4;
   MH_REQUIRE((ld_qk * es) % 16 == 0 && (k_col0 * es) % 16 == 0, "mh_attention: rows must be 16-byte aligned");
-  if (dtype == MH_F32 && !bias && L <= 256 && ld_out % 4 == 0 && small_attn_enabled()) {
+  if (dtype == MH_F32 && !bias && L <= 256 && ld_out % 4 == 0 && small_attn_ok(B, H, L)) {
     SmallAttnP sp{};
     sp.q = (const float*)qk; sp.k = (const float*)qk + k_col0; sp.vt = (const float*)vt; sp.out = (float*)out;
     sp.ld_qk = ld_qk; sp.vt_hs = 64L * Lpad; sp.vt_bs = (long)H * 64 * Lpad; sp.ld_out = ld_out;

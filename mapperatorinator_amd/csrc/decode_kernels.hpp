@@ -522,7 +522,7 @@ struct CrossAttnP {
   int B, H, L;
   int kv_B;                 // > 0: row b reads K/V row b % kv_B (CFG pairs share the encoder output)
   // measurement only (mh_t5_decode_timing): [slots][2] = (earliest workgroup start, latest workgroup end) of THIS
-  // launch in wall-clock ticks, slot = (*pos % ts_ring) * ts_layers + ts_layer; NULL in production
+  // launch in wall-clock ticks, slot = *pos * ts_layers + ts_layer for the first ts_ring positions; NULL in production
   unsigned long long* tstamp; const int* pos; int ts_ring, ts_layers, ts_layer;
 };
 
@@ -692,8 +692,8 @@ void dec_cross_attn_q_kernel(CrossAttnP p, HeadProjP hp) {
   MH_STAMP(KID_CROSS, 3);   // partials merged
   if (threadIdx.x < 64)
     reinterpret_cast<T*>(p.out)[(long)b * p.ldo + h * 64 + threadIdx.x] = Elem<T>::from_f32(l > 0.f ? a / l : 0.f);
-  if (p.tstamp && threadIdx.x == 0) {
-    unsigned long long* slot = p.tstamp + 2 * ((long)(*p.pos % p.ts_ring) * p.ts_layers + p.ts_layer);
+  if (p.tstamp && threadIdx.x == 0 && *p.pos < p.ts_ring) {      // the first ts_ring positions of the call, one slot each
+    unsigned long long* slot = p.tstamp + 2 * ((long)(*p.pos) * p.ts_layers + p.ts_layer);
     atomicMin(slot, t_start);
     atomicMax(slot + 1, (unsigned long long)wall_clock64());
   }

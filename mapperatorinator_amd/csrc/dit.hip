@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void small_linear_kernel(const float* __restri
 }
 
 // final Linear(D -> 4) on the modulated activations, (N, T, 4) -> (N, 4, T), then CFG combine of the eps
-// channels (models.py:312-317).  One wave per sequence position, all n.
+// channels (models.py:312-317).  One wave per (sequence position, CFG pair).
 __global__ __launch_bounds__(256) void dit_final_kernel(const float* __restrict__ xm, const float* __restrict__ W,
                                                        int ldw, const float* __restrict__ b, int N, int T, int D,
                                                        float cfg_scale, float* __restrict__ out) {
@@ -106,7 +106,8 @@ __global__ __launch_bounds__(256) void dit_final_kernel(const float* __restrict_
   const int tp = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (tp >= T) return;
   const int hn = N / 2;
-  for (int n = 0; n < hn; ++n) {
+  {
+    const int n = blockIdx.y;   // one (position, CFG pair) per wave
     float v[2][4];
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
@@ -168,6 +169,12 @@ __global__ __launch_bounds__(256) void ddpm_step_kernel(const float* __restrict_
   if (pred) pred[idx] = x0;
 }
 #pragma clang fp contract(fast)
+
+// y = silu(x), elementwise (input of every adaLN projection: nn.Sequential(SiLU, Linear), models.py:124-127)
+__global__ void silu_kernel(const float* __restrict__ x, float* __restrict__ y, long n) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) { const float v = x[i]; y[i] = v / (1.0f + expf(-v)); }
+}
 
 __global__ void loop_dec_kernel(int* sel) {
   if (threadIdx.x == 0) *sel = *sel - 1;
@@ -254,11 +261,20 @@ int dit_conditioning(const MhDiTConfig* c, const MhDiTWeights* w, const int32_t*
   MH_TRY(check_launch("add_rows_bcast_kernel"));
   // row r = step*N + n of the output is [depth][6D] | [2D]; a step block is N consecutive rows
   const int ld_row = c->depth * 6 * D + 2 * D;   // per (step, n) row: [depth][6D] | [2D]
-  for (int l = 0; l < c->depth; ++l)
-    MH_TRY((small_linear<true, false>(bvec, D, w->ada_w[l], D, w->ada_b[l], cond_out + (long)l * 6 * D, ld_row, rows,
-                                      6 * D, D, 0, s)));
-  MH_TRY((small_linear<true, false>(bvec, D, w->fin_ada_w, D, w->fin_ada_b, cond_out + (long)c->depth * 6 * D, ld_row,
-                                    rows, 2 * D, D, 0, s)));
+  // SiLU once, then the depth + 1 adaLN projections on the MFMA GEMM (a sampling loop hoists ALL steps: rows = steps * N,
+  // 6400 x 2304 x 384 per block for 32 chunks -- one wave per output element took 5 ms per block there)
+  float* sb = temb1;   // (free again: bvec is complete)
+  hipLaunchKernelGGL(silu_kernel, dim3((unsigned)ceil_div(rows * D, 256)), dim3(256), 0, s, bvec, sb, (long)rows * D);
+  MH_TRY(check_launch("silu_kernel"));
+  MhGemm g;
+  for (int l = 0; l <= c->depth; ++l) {
+    const bool fin = l == c->depth;
+    g = MhGemm{};
+    g.A = sb; g.lda = D; g.W = fin ? w->fin_ada_w : w->ada_w[l]; g.ldw = D; g.C = cond_out + (long)l * 6 * D; g.ldc = ld_row;
+    g.M = rows; g.N = fin ? 2 * D : 6 * D; g.K = D; g.bias = fin ? w->fin_ada_b : w->ada_b[l]; g.dtype = MH_F32;
+    g.epilogue = MH_EPI_STORE_F32;
+    MH_TRY(gemm(g, s, /*ascending_k=*/true));   // same bits for 1 step or 100, 1 chunk or 32
+  }
   return MH_OK;
 }
 
@@ -321,7 +337,7 @@ int dit_body(const MhDiTConfig* c, const MhDiTWeights* w, const float* x, const 
   }
   const float* modf = b.cond_cur + (long)c->depth * 6 * D;
   MH_TRY(ln_modulate(b.xs, D, modf, modf + D, ld_row, T, b.xm, D, NT, D, 1e-6f, s));
-  hipLaunchKernelGGL(dit_final_kernel, dim3(ceil_div(T, 4)), dim3(256), 0, s, b.xm, w->fin_w, D, w->fin_b, N, T, D,
+  hipLaunchKernelGGL(dit_final_kernel, dim3(ceil_div(T, 4), N / 2), dim3(256), 0, s, b.xm, w->fin_w, D, w->fin_b, N, T, D,
                      cfg_scale, out);
   return check_launch("dit_final_kernel");
 }

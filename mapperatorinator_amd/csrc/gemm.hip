@@ -32,6 +32,7 @@ struct GemmP {
   float* stats_out;                                   // producer: [ceil(N/16)][M][2] row sums / sums of squares
   const float* ln_stats; int ln_strips;               // consumer: LayerNorm + modulate applied to the A operand (f32)
   const float* ln_shift; const float* ln_scale; int ln_ld; float ln_eps;
+  bool ascending_k;
 };
 
 // `v` already contains the bias; `old` = previous C value (RESID / GATE_RESID), `g` = gate value, `v2` = paired
@@ -437,13 +438,16 @@ int dispatch_tile(const GemmP& p, hipStream_t s) {
   // many small tiles (DiT: M = 256 rows) and big ones the 128x128 tile (encoder: M = 40k rows)
   const long tiles128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
   const long tiles64 = (long)((p.M + 63) / 64) * ((p.N + 63) / 64);
-  if (tiles128 >= 192) return launch_gemm<T, 128, 128, EPI>(p, s);
+  // exact-fp32 MFMA is 16x slower than bf16: an fp32 GEMM is compute-bound long before the big tile pays (measured on
+  // the batched DiT, M = 8192: 64x64 tiles 667 ms vs 128x128 827 ms per 100 steps) -> 8x the bf16 threshold
+  const long min128 = option(OPT_GEMM_TILE128_MIN) * (std::is_same<T, float>::value ? 8 : 1);
+  if (tiles128 >= min128) return launch_gemm<T, 128, 128, EPI>(p, s);
   if constexpr (EPI == MH_EPI_GEGLU) {
     return launch_gemm<T, 64, 64, EPI>(p, s);
   } else {
     if (tiles64 >= 192) return launch_gemm<T, 64, 64, EPI>(p, s);
     const long tiles32 = (long)((p.M + 31) / 32) * ((p.N + 31) / 32);
-    if (tiles32 >= splitk_threshold()) return launch_gemm<T, 32, 32, EPI>(p, s);
+    if (p.ascending_k || tiles32 >= splitk_threshold()) return launch_gemm<T, 32, 32, EPI>(p, s);
     return launch_gemm<T, 16, 16, EPI>(p, s);
   }
 }
@@ -479,7 +483,7 @@ int gemm_prepare() {
   return MH_OK;
 }
 
-int gemm(const MhGemm& g, hipStream_t s) {
+int gemm(const MhGemm& g, hipStream_t s, bool ascending_k) {
   MH_REQUIRE(g.A && g.W && g.C, "mh_gemm: null operand");
   MH_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0, "mh_gemm: bad shape M=%d N=%d K=%d", g.M, g.N, g.K);
   MH_REQUIRE(g.dtype == MH_F32 || g.dtype == MH_BF16, "mh_gemm: bad dtype %d", g.dtype);
@@ -505,6 +509,7 @@ int gemm(const MhGemm& g, hipStream_t s) {
                "mh_gemm: bad QKV_CACHE geometry");
   { int rc = gemm_prepare(); if (rc != MH_OK) return rc; }
   GemmP p;
+  p.ascending_k = ascending_k;
   p.C3 = g.C3; p.C4 = g.C4; p.cache_len = g.cache_len;
   p.C2 = g.C2; p.n_split = g.n_split; p.kv_Lpad = g.kv_Lpad;
   p.A = (const char*)g.A; p.lda_b = (long)g.lda * es;
@@ -529,5 +534,5 @@ int gemm(const MhGemm& g, hipStream_t s) {
 
 extern "C" int mh_gemm(const MhGemm* g, void* stream) {
   if (!g) { mh::set_error("mh_gemm: null descriptor"); return MH_ERR_ARG; }
-  return mh::gemm(*g, (hipStream_t)stream);
+  return mh::gemm(*g, (hipStream_t)stream, false);
 }

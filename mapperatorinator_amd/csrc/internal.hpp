@@ -5,7 +5,9 @@
 namespace mh {
 
 int gemm_prepare();  // one-time kernel attribute setup; call before any stream capture
-int gemm(const MhGemm& g, hipStream_t s);
+// ascending_k: never pick the 16x16 split-K tile, so the fp32 summation order (k ascending, one accumulator) and with it
+// every bit of the result is independent of M (the tile choice otherwise follows the grid size)
+int gemm(const MhGemm& g, hipStream_t s, bool ascending_k = false);
 int rmsnorm(const float* x, int ldx, const float* w, void* y, int ldy, int rows, int d, float eps, int out_dtype,
             hipStream_t s);
 int ln_modulate(const float* x, int ldx, const float* shift, const float* scale, int mod_ld, int rows_per_batch,

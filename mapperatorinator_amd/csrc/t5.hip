@@ -1095,6 +1095,15 @@ extern "C" int mh_debug_phase_stamps(unsigned long long* out, int reset) {
 }
 #endif
 
+extern "C" int mh_wall_clock_khz(void) {   // rate of the device wall clock the timing hook records (kHz); 0 if unknown
+  int dev = 0, khz = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return khz;
+}
+
 extern "C" int mh_t5_decode_chains(int B) { return B > 0 ? mh::pick_chains(B) : 0; }
 
 // ------------------------------------------------------------------------------------------------
