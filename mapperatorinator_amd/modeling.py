@@ -42,6 +42,7 @@ class MapperatorinatorHIP:
                  pad_token_id: int = 0, bos_token_id: int = 1, eos_token_id: int = 2):
         self.engine = T5Engine(state_dict, dims, vocab_size_in, vocab_size_out, n_mels, src_seq_len, tgt_seq_len,
                                dtype, device, sample_rate, n_fft, hop_length, f_min, f_max, spectrogram_log_scale)
+        self._source_state_dict = state_dict      # caller-owned tensors under the reference's parameter names (not copied)
         self.device = self.engine.device
         self.dtype = dtype
         self.spectrogram = self.engine.spectrogram
@@ -50,7 +51,12 @@ class MapperatorinatorHIP:
             max_source_positions=src_seq_len, max_target_positions=tgt_seq_len, vocab_size=vocab_size_out,
             vocab_size_in=vocab_size_in, n_mels=n_mels, hop_length=hop_length, sample_rate=sample_rate,
             pad_token_id=pad_token_id, bos_token_id=bos_token_id, eos_token_id=eos_token_id,
-            is_encoder_decoder=True, backbone_model_name="google/t5-v1_1(hip)")
+            is_encoder_decoder=True, backbone_model_name="google/t5-v1_1(hip)",
+            # the fields `get_cache` / `MapperatorinatorCache` read (inference/cache_utils.py:23-35): the engine owns its
+            # caches, they are here so that code inspecting the reference config finds them
+            num_hidden_layers_decoder=dims.n_dec_layers, d_model=dims.d_model, d_kv=dims.d_kv, num_heads=dims.n_heads,
+            num_layers=dims.n_enc_layers, num_decoder_layers=dims.n_dec_layers, d_ff=dims.d_ff,
+            torch_dtype=dtype, input_features=False, project_encoder_input=True, embed_decoder_input=True)
 
     # ---- construction from the reference object ---------------------------------------------------
     @classmethod
@@ -79,6 +85,53 @@ class MapperatorinatorHIP:
     # nn.Module-ish conveniences the reference callers use
     def eval(self):
         return self
+
+    def state_dict(self):
+        """The parameters under the reference's names (`Mapperatorinator.state_dict()` keys: encoder_embedder.*,
+        decoder_embedder.weight, transformer.*), i.e. what this object was built from -- the packed device copies are
+        derived data (t5_engine.PackedT5)."""
+        return dict(self._source_state_dict)
+
+    def get_encoder(self):
+        """`Mapperatorinator.get_encoder()` (modeling_mapperatorinator.py:333-353): a callable taking the raw audio
+        (`frames`) and returning an object with `.last_hidden_state` -- spectrogram, input projection and the T5 encoder
+        stack with its final RMSNorm, on the HIP engine."""
+        eng = self.engine
+
+        class _Encoder:
+            main_input_name = "frames"
+
+            def __call__(self_inner, frames=None, **unused):
+                if frames is None:
+                    raise ValueError("frames (raw audio, (B, samples)) is required")
+                enc = eng.encode(frames.to(eng.device, torch.float32))
+                return types.SimpleNamespace(last_hidden_state=enc, hidden_states=None, attentions=None)
+        return _Encoder()
+
+    def prepare_inputs_for_generation(self, decoder_input_ids, past_key_values=None, use_cache=None, encoder_outputs=None,
+                                      decoder_attention_mask=None, cache_position=None, negative_prompt=None,
+                                      negative_prompt_attention_mask=None, **kwargs):
+        """The batch layout the reference builds for classifier-free guidance (modeling_mapperatorinator.py:230-253):
+        the batch is doubled, the NEGATIVE prompt overwrites the first columns of the first half, masks and encoder
+        states follow.  `generate()` here applies exactly this layout inside the engine; the method exists so that code
+        written against the reference object (and the parity test) can see it."""
+        if negative_prompt is not None:
+            decoder_input_ids = decoder_input_ids.repeat((2, 1))
+            decoder_input_ids[:decoder_input_ids.shape[0] // 2, :negative_prompt.shape[1]] = negative_prompt
+            if decoder_attention_mask is not None:
+                decoder_attention_mask = decoder_attention_mask.repeat((2, 1))
+                if negative_prompt_attention_mask is not None:
+                    half = decoder_attention_mask.shape[0] // 2
+                    decoder_attention_mask[:half, :negative_prompt_attention_mask.shape[1]] = negative_prompt_attention_mask
+            if encoder_outputs is not None:
+                enc = getattr(encoder_outputs, "last_hidden_state", encoder_outputs)
+                encoder_outputs = types.SimpleNamespace(last_hidden_state=enc.repeat((2, 1, 1)))
+        out = dict(input_ids=decoder_input_ids, decoder_input_ids=decoder_input_ids, past_key_values=past_key_values,
+                   use_cache=use_cache, encoder_outputs=encoder_outputs, decoder_attention_mask=decoder_attention_mask,
+                   cache_position=cache_position)
+        for k, v in kwargs.items():
+            out.setdefault(k, v)
+        return out
 
     def to(self, *a, **k):
         return self
