@@ -120,6 +120,11 @@ typedef struct MhGemm {
   float* stats_out;
   const float* ln_stats; int ln_strips;
   const float* ln_shift; const float* ln_scale; int ln_ld; float ln_eps;
+  /* fp32 only -- "bf16 x 3": W is stored PRE-SPLIT, every 32-float block of a row as [32 x bf16 hi | 32 x bf16 lo]
+   * (hi = bf16(w), lo = bf16(w - hi); the same 128 bytes per block, ldw still counted in floats), A stays fp32 and is
+   * split on its way into LDS; a w ~= a_hi w_hi + a_hi w_lo + a_lo w_hi on the bf16 matrix cores with fp32 accumulation
+   * (relative error ~2^-16 per product instead of exact fp32 products).  K and ldw multiples of 32. */
+  int w_split3;
 } MhGemm;
 int mh_gemm(const MhGemm* g, void* stream);
 
@@ -337,6 +342,11 @@ typedef struct MhDiTWeights {       /* all fp32, matrices [N][Kpad]             
   const float* fc2_w[MH_MAX_LAYERS]; const float* fc2_b[MH_MAX_LAYERS];   /* mlp.fc2 [D, 4D]       */
   const float* fin_ada_w; const float* fin_ada_b;    /* final_layer.adaLN_modulation [2D, D]       */
   const float* fin_w; const float* fin_b;            /* final_layer.linear [4, D]                  */
+  /* optional pre-split copies (MhGemm.w_split3 layout) of the five big projections; NULL = exact fp32 only.  Used for
+   * denoiser batches of at least `dit_split3_min_rows` rows (option, default 2048 = 8 chunks of 128 points). */
+  const void* first_w3;
+  const void* qkv_w3[MH_MAX_LAYERS]; const void* out_w3[MH_MAX_LAYERS];
+  const void* fc1_w3[MH_MAX_LAYERS]; const void* fc2_w3[MH_MAX_LAYERS];
 } MhDiTWeights;
 
 int64_t mh_dit_workspace_bytes(const MhDiTConfig* cfg, int N, int T);

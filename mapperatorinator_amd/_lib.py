@@ -30,7 +30,7 @@ class MhGemm(C.Structure):
                 ("C3", VP), ("C4", VP), ("cache_len", C.c_int),
                 ("dtype", C.c_int), ("epilogue", C.c_int),
                 ("stats_out", VP), ("ln_stats", VP), ("ln_strips", C.c_int), ("ln_shift", VP), ("ln_scale", VP),
-                ("ln_ld", C.c_int), ("ln_eps", C.c_float)]
+                ("ln_ld", C.c_int), ("ln_eps", C.c_float), ("w_split3", C.c_int)]
 
 
 class MhT5Config(C.Structure):
@@ -73,7 +73,8 @@ class MhDiTWeights(C.Structure):
                 ("ada_w", _PTR_ARR), ("ada_b", _PTR_ARR), ("qkv_w", _PTR_ARR), ("qkv_b", _PTR_ARR),
                 ("out_w", _PTR_ARR), ("out_b", _PTR_ARR), ("fc1_w", _PTR_ARR), ("fc1_b", _PTR_ARR),
                 ("fc2_w", _PTR_ARR), ("fc2_b", _PTR_ARR), ("fin_ada_w", VP), ("fin_ada_b", VP),
-                ("fin_w", VP), ("fin_b", VP)]
+                ("fin_w", VP), ("fin_b", VP),
+                ("first_w3", VP), ("qkv_w3", _PTR_ARR), ("out_w3", _PTR_ARR), ("fc1_w3", _PTR_ARR), ("fc2_w3", _PTR_ARR)]
 
 
 ABI_VERSION = 3   # MH_ABI_VERSION of include/mapperhip.h

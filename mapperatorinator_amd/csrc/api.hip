@@ -38,6 +38,7 @@ static OptionSlot g_options[OPT_COUNT] = {
     {"decode_cu_split", "MH_DECODE_CU_SPLIT", 0, false},         // two chains on disjoint CU halves: 1 = XCDs 0-3 / 4-7, 2 = first / second 128 CU bits
     {"gemm_tile128_min", "MH_GEMM_TILE128_MIN", 192, false},     // the 128x128 GEMM tile is used from this many tiles on (else 64x64 / smaller)
     {"attn_small_max_wgs", "MH_ATTN_SMALL_MAX_WGS", 1024, false}, // fp32 attention at L <= 256: key-split latency kernel up to this many workgroups, flash kernel beyond
+    {"dit_split3_min_rows", "MH_DIT_SPLIT3_MIN_ROWS", 2048, false},   // DiT denoiser batches of >= this many rows (N*T) run their big GEMMs as bf16 x 3 (0 = never)
 };
 
 long option(int id) {

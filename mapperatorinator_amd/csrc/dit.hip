@@ -5,6 +5,8 @@
 //   GaussianDiffusion.p_mean_variance / p_sample      utils/diffusion/gaussian_diffusion.py:273-369,420-467
 // Dense layers run on the exact-f32 MFMA atom (gemm.hip), attention on the banded flash kernel
 // (attention.hip); this file holds the small glue kernels and the orchestration.
+#include <stdlib.h>
+
 #include "internal.hpp"
 
 namespace mh {
@@ -291,19 +293,32 @@ int dit_body(const MhDiTConfig* c, const MhDiTWeights* w, const float* x, const 
   // modulate(LN(xs)) normalises its A operand on the way into LDS (mh_gemm: stats_out / ln_stats).
   const bool fuse_ln = (D % 16 == 0);
   const int strips = D / 16;
+  // big denoiser batches (many chunks stacked): the five large projections run as bf16 x 3 on the bf16 matrix cores
+  // (MhGemm.w_split3); a single chunk keeps the exact-fp32 kernels.  The split path takes its LayerNorm + modulate from the
+  // stand-alone pass: the fused-in-the-A-load form gave non-repeatable rows on grids of > 1000 workgroups in combination
+  // with the split store (open issue, reproduced by tools at (2048, 2304, 768); every other combination is bit-stable)
+  const long s3min = option(OPT_DIT_SPLIT3_MIN_ROWS);
+  const bool s3 = s3min > 0 && NT >= s3min && w->first_w3 && D % 32 == 0 && c->first_k_pad % 32 == 0;
+  auto weights = [&](const float* exact, const void* split, MhGemm& gg) {
+    const bool use = s3 && split != nullptr;
+    gg.W = use ? split : (const void*)exact;
+    gg.w_split3 = use ? 1 : 0;
+  };
   MhGemm g = MhGemm{};
-  g.A = b.E; g.lda = c->first_k_pad; g.W = w->first_w; g.ldw = c->first_k_pad; g.C = b.xs; g.ldc = D; g.M = NT; g.N = D;
+  g.A = b.E; g.lda = c->first_k_pad; g.ldw = c->first_k_pad; g.C = b.xs; g.ldc = D; g.M = NT; g.N = D;
   g.K = c->first_k_pad; g.bias = w->first_b; g.dtype = MH_F32; g.epilogue = MH_EPI_STORE_F32;
+  weights(w->first_w, w->first_w3, g);
   g.stats_out = fuse_ln ? b.stats : nullptr;
   MH_TRY(gemm(g, s));
   for (int l = 0; l < c->depth; ++l) {
     const float* mod = b.cond_cur + (long)l * 6 * D;
     // attention branch
     g = MhGemm{};
-    g.A = b.xs; g.lda = D; g.W = w->qkv_w[l]; g.ldw = D; g.C = b.qk; g.ldc = 2 * D; g.M = NT; g.N = 3 * D; g.K = D;
+    g.A = b.xs; g.lda = D; g.ldw = D; g.C = b.qk; g.ldc = 2 * D; g.M = NT; g.N = 3 * D; g.K = D;
     g.bias = w->qkv_b[l]; g.dtype = MH_F32; g.epilogue = MH_EPI_QKV_VT; g.C2 = b.vt; g.n_split = 2 * D; g.kv_B = N;
     g.kv_H = H; g.kv_L = T; g.kv_Lpad = b.Tpad;
-    if (fuse_ln) {
+    weights(w->qkv_w[l], w->qkv_w3[l], g);
+    if (fuse_ln && !g.w_split3) {
       g.ln_stats = b.stats; g.ln_strips = strips; g.ln_shift = mod + 0 * D; g.ln_scale = mod + 1 * D; g.ln_ld = ld_row;
       g.ln_eps = 1e-6f; g.rows_per_batch = T;
     } else {
@@ -313,15 +328,17 @@ int dit_body(const MhDiTConfig* c, const MhDiTWeights* w, const float* x, const 
     MH_TRY(gemm(g, s));
     MH_TRY(attention(b.qk, 2 * D, D, b.vt, b.Tpad, nullptr, b.attn, D, N, T, H, 0.125f, band, MH_F32, s));
     g = MhGemm{};
-    g.A = b.attn; g.lda = D; g.W = w->out_w[l]; g.ldw = D; g.C = b.xs; g.ldc = D; g.M = NT; g.N = D; g.K = D;
+    g.A = b.attn; g.lda = D; g.ldw = D; g.C = b.xs; g.ldc = D; g.M = NT; g.N = D; g.K = D;
     g.bias = w->out_b[l]; g.gate = mod + 2 * D; g.gate_ld = ld_row; g.rows_per_batch = T; g.dtype = MH_F32;
     g.epilogue = MH_EPI_GATE_RESID; g.stats_out = fuse_ln ? b.stats : nullptr;
+    weights(w->out_w[l], w->out_w3[l], g);
     MH_TRY(gemm(g, s));
     // MLP branch
     g = MhGemm{};
-    g.A = b.xs; g.lda = D; g.W = w->fc1_w[l]; g.ldw = D; g.C = b.hid; g.ldc = 4 * D; g.M = NT; g.N = 4 * D; g.K = D;
+    g.A = b.xs; g.lda = D; g.ldw = D; g.C = b.hid; g.ldc = 4 * D; g.M = NT; g.N = 4 * D; g.K = D;
     g.bias = w->fc1_b[l]; g.dtype = MH_F32; g.epilogue = MH_EPI_BIAS_GELU;
-    if (fuse_ln) {
+    weights(w->fc1_w[l], w->fc1_w3[l], g);
+    if (fuse_ln && !g.w_split3) {
       g.ln_stats = b.stats; g.ln_strips = strips; g.ln_shift = mod + 3 * D; g.ln_scale = mod + 4 * D; g.ln_ld = ld_row;
       g.ln_eps = 1e-6f; g.rows_per_batch = T;
     } else {
@@ -330,9 +347,10 @@ int dit_body(const MhDiTConfig* c, const MhDiTWeights* w, const float* x, const 
     }
     MH_TRY(gemm(g, s));
     g = MhGemm{};
-    g.A = b.hid; g.lda = 4 * D; g.W = w->fc2_w[l]; g.ldw = 4 * D; g.C = b.xs; g.ldc = D; g.M = NT; g.N = D; g.K = 4 * D;
+    g.A = b.hid; g.lda = 4 * D; g.ldw = 4 * D; g.C = b.xs; g.ldc = D; g.M = NT; g.N = D; g.K = 4 * D;
     g.bias = w->fc2_b[l]; g.gate = mod + 5 * D; g.gate_ld = ld_row; g.rows_per_batch = T; g.dtype = MH_F32;
     g.epilogue = MH_EPI_GATE_RESID; g.stats_out = fuse_ln ? b.stats : nullptr;
+    weights(w->fc2_w[l], w->fc2_w3[l], g);
     MH_TRY(gemm(g, s));
   }
   const float* modf = b.cond_cur + (long)c->depth * 6 * D;

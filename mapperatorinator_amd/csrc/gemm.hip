@@ -33,6 +33,7 @@ struct GemmP {
   const float* ln_stats; int ln_strips;               // consumer: LayerNorm + modulate applied to the A operand (f32)
   const float* ln_shift; const float* ln_scale; int ln_ld; float ln_eps;
   bool ascending_k;
+  int split3;   // fp32 only: W holds [hi bf16 x32 | lo bf16 x32] per 32-float K block, A is split on the way into LDS
 };
 
 // `v` already contains the bias; `old` = previous C value (RESID / GATE_RESID), `g` = gate value, `v2` = paired
@@ -97,8 +98,14 @@ __device__ inline void epilogue_store(const GemmP& p, int row, int col, float v,
   }
 }
 
-template <typename T, int BM, int BN, int EPI>
+// S3 ("bf16 x 3"): an fp32 GEMM on the bf16 matrix cores.  a = a_hi + a_lo, w = w_hi + w_lo with hi = bf16(x),
+// lo = bf16(x - hi); a w ~= a_hi w_hi + a_hi w_lo + a_lo w_hi (the dropped a_lo w_lo and the 16-bit significands leave a
+// relative error of ~2^-16 per product, fp32 accumulation).  Three v_mfma_f32_16x16x32_bf16 replace eight exact
+// v_mfma_f32_16x16x4_f32: 1/5 of the matrix-core time at the SAME operand bytes (weights are stored pre-split, 128 B per
+// 32-float block either way; activations stay fp32 in HBM and are split while they are staged into LDS).
+template <typename T, int BM, int BN, int EPI, bool S3 = false>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmP p) {
+  static_assert(!S3 || (std::is_same<T, float>::value && BM == 64 && BN == 64), "split-3 path: fp32, 64x64 tile");
   constexpr int VEC = Elem<T>::kVec;          // elements per 16 B
   constexpr int kRowBytes = RowBytes<BM>::v;
   constexpr int kRowStride = kRowBytes + 16;  // padded LDS row stride in bytes
@@ -205,7 +212,18 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmP p) {
         v.z = __float_as_uint(m * ((__uint_as_float(v.z) - mu) * rs * (1.f + __uint_as_float(xsc[i].z)) + __uint_as_float(xsh[i].z)));
         v.w = __float_as_uint(m * ((__uint_as_float(v.w) - mu) * rs * (1.f + __uint_as_float(xsc[i].w)) + __uint_as_float(xsh[i].w)));
       }
-      *reinterpret_cast<uint4*>(smem + buf * kBufBytes + (crow + RPP * i) * kRowStride + cchunk * 16) = v;
+      if constexpr (S3) {
+        // 4 fp32 -> 4 hi + 4 lo bf16: hi half of the 128-byte row block at cchunk * 8, lo half 64 bytes further
+        const float f0 = __uint_as_float(v.x), f1 = __uint_as_float(v.y), f2 = __uint_as_float(v.z), f3 = __uint_as_float(v.w);
+        const uint32_t h01 = pack_bf16x2(f0, f1), h23 = pack_bf16x2(f2, f3);
+        const float r0 = f0 - __uint_as_float(h01 << 16), r1 = f1 - __uint_as_float(h01 & 0xffff0000u);
+        const float r2 = f2 - __uint_as_float(h23 << 16), r3 = f3 - __uint_as_float(h23 & 0xffff0000u);
+        char* rowp = smem + buf * kBufBytes + (crow + RPP * i) * kRowStride;
+        *reinterpret_cast<uint2*>(rowp + cchunk * 8) = make_uint2(h01, h23);
+        *reinterpret_cast<uint2*>(rowp + 64 + cchunk * 8) = make_uint2(pack_bf16x2(r0, r1), pack_bf16x2(r2, r3));
+      } else {
+        *reinterpret_cast<uint4*>(smem + buf * kBufBytes + (crow + RPP * i) * kRowStride + cchunk * 16) = v;
+      }
     }
 #pragma unroll
     for (int i = 0; i < B_CHUNKS; ++i)
@@ -296,6 +314,31 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmP p) {
       constexpr int kKs = BK / KM, kKsW = kSplitK ? kKs / 4 : kKs;
       static_assert(!kSplitK || kKs % 4 == 0, "K step not divisible among the 4 waves");
       const int ks0 = kSplitK ? wid * kKsW : 0;
+      if constexpr (S3) {
+        // one 32-deep bf16 k-step per 128-byte row block: fragments = 16 bytes at (lane >> 4) * 16 of the hi / lo half
+        const char* a3 = smem + cur * kBufBytes + (wr * WM + frow) * kRowStride + (lane >> 4) * 16;
+        const char* b3 = smem + cur * kBufBytes + (BM + wc * WN + frow) * kRowStride + (lane >> 4) * 16;
+        bf16x8_t ah[MI], al[MI], bh[NI], bl[NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          ah[i] = *reinterpret_cast<const bf16x8_t*>(a3 + i * 16 * kRowStride);
+          al[i] = *reinterpret_cast<const bf16x8_t*>(a3 + i * 16 * kRowStride + 64);
+        }
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          bh[j] = *reinterpret_cast<const bf16x8_t*>(b3 + j * 16 * kRowStride);
+          bl[j] = *reinterpret_cast<const bf16x8_t*>(b3 + j * 16 * kRowStride + 64);
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j) {
+            // small terms first, the dominant product last
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+          }
+      } else
 #pragma unroll
       for (int kq = 0; kq < kKsW; ++kq) {
         const int ks = ks0 + kq;
@@ -413,11 +456,11 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmP p) {
   }
 }
 
-template <typename T, int BM, int BN, int EPI>
+template <typename T, int BM, int BN, int EPI, bool S3 = false>
 int launch_gemm(const GemmP& p, hipStream_t s) {
   const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
   const size_t smem = 2 * (size_t)(BM + BN) * (RowBytes<BM>::v + 16) + BM * 8 + 2048;   // + LayerNorm statistics
-  hipLaunchKernelGGL((gemm_tn_kernel<T, BM, BN, EPI>), dim3(nbm * nbn), dim3(256), smem, s, p);
+  hipLaunchKernelGGL((gemm_tn_kernel<T, BM, BN, EPI, S3>), dim3(nbm * nbn), dim3(256), smem, s, p);
   return check_launch("gemm_tn_kernel");
 }
 
@@ -448,6 +491,10 @@ long splitk_threshold() { return option(OPT_GEMM_SPLITK_TILES); }
 
 template <typename T, int EPI>
 int dispatch_tile(const GemmP& p, hipStream_t s) {
+  if constexpr (std::is_same<T, float>::value && (EPI == MH_EPI_STORE_F32 || EPI == MH_EPI_QKV_VT ||
+                                                  EPI == MH_EPI_GATE_RESID || EPI == MH_EPI_BIAS_GELU)) {
+    if (p.split3) return launch_gemm<T, 64, 64, EPI, true>(p, s);
+  }
   // tile by grid size: the chip has 256 CUs; a K step of a wave costs MI*NI MFMAs, so small problems want
   // many small tiles (DiT: M = 256 rows) and big ones the 128x128 tile (encoder: M = 40k rows)
   const long tiles128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
@@ -524,6 +571,7 @@ int gemm(const MhGemm& g, hipStream_t s, bool ascending_k) {
   { int rc = gemm_prepare(); if (rc != MH_OK) return rc; }
   GemmP p;
   p.ascending_k = ascending_k;
+  p.split3 = g.w_split3;
   p.C3 = g.C3; p.C4 = g.C4; p.cache_len = g.cache_len;
   p.C2 = g.C2; p.n_split = g.n_split; p.kv_Lpad = g.kv_Lpad;
   p.A = (const char*)g.A; p.lda_b = (long)g.lda * es;
@@ -537,6 +585,11 @@ int gemm(const MhGemm& g, hipStream_t s, bool ascending_k) {
   if (g.stats_out)
     MH_REQUIRE((g.epilogue == MH_EPI_STORE_F32 || g.epilogue == MH_EPI_GATE_RESID) && g.N % 16 == 0,
                "mh_gemm: stats_out needs a fp32-output epilogue (STORE_F32 / GATE_RESID) and N %% 16 == 0");
+  if (g.w_split3)
+    MH_REQUIRE(g.dtype == MH_F32 && g.K % 32 == 0 && g.ldw % 32 == 0 &&
+                   (g.epilogue == MH_EPI_STORE_F32 || g.epilogue == MH_EPI_QKV_VT || g.epilogue == MH_EPI_GATE_RESID ||
+                    g.epilogue == MH_EPI_BIAS_GELU),
+               "mh_gemm: w_split3 is an fp32 path (K, ldw multiples of 32; STORE_F32 / QKV_VT / GATE_RESID / BIAS_GELU)");
   if (g.ln_stats)
     MH_REQUIRE(g.dtype == MH_F32 && g.ln_shift && g.ln_scale && g.ln_strips > 0 && g.rows_per_batch > 0 && g.ln_ld >= g.K,
                "mh_gemm: the fused LayerNorm-modulate prologue is fp32 only and needs shift / scale / strips / rows_per_batch");

@@ -53,6 +53,22 @@ class DiTHIP:
             self._keep.append(x)
             return x.data_ptr()
 
+        def t3(x, kpad=None):
+            """pre-split copy of a weight matrix for the bf16 x 3 GEMM path (MhGemm.w_split3): every 32-float block of
+            a row becomes [32 x bf16 hi | 32 x bf16 lo], hi = bf16(w), lo = bf16(w - hi)"""
+            x = x.detach().to(torch.float32)
+            if kpad is not None and x.shape[-1] != kpad:
+                x = torch.nn.functional.pad(x, (0, kpad - x.shape[-1]))
+            n, k = x.shape
+            if k % 32:
+                return None
+            hi = x.to(torch.bfloat16)
+            lo = (x - hi.to(torch.float32)).to(torch.bfloat16)
+            packed = torch.stack([hi.reshape(n, k // 32, 32), lo.reshape(n, k // 32, 32)], dim=2).reshape(n, 2 * k)
+            packed = packed.contiguous().to(dev)
+            self._keep.append(packed)
+            return packed.data_ptr()
+
         k1 = 2 * 128 + context_size
         cfg = _lib.MhDiTConfig(hidden, depth, num_heads, context_size, class_size, 2, 128, 256, _round_up(k1, 32),
                                class_size)
@@ -62,6 +78,7 @@ class DiTHIP:
         w.t_freqs = t(torch.exp(-math.log(10000) * torch.arange(0, 128, dtype=torch.float32) / 128))
         sd = state_dict
         w.first_w, w.first_b = t(sd["context_embedder.mlp.0.weight"], cfg.first_k_pad), t(sd["context_embedder.mlp.0.bias"])
+        w.first_w3 = t3(sd["context_embedder.mlp.0.weight"], cfg.first_k_pad)
         w.t_w0, w.t_b0 = t(sd["t_embedder.mlp.0.weight"]), t(sd["t_embedder.mlp.0.bias"])
         w.t_w1, w.t_b1 = t(sd["t_embedder.mlp.2.weight"]), t(sd["t_embedder.mlp.2.bias"])
         w.y_w0, w.y_b0 = t(sd["y_embedder.class_embedding.0.weight"]), t(sd["y_embedder.class_embedding.0.bias"])
@@ -73,6 +90,8 @@ class DiTHIP:
             w.out_w[l], w.out_b[l] = t(sd[b + "attn.out_proj.weight"]), t(sd[b + "attn.out_proj.bias"])
             w.fc1_w[l], w.fc1_b[l] = t(sd[b + "mlp.fc1.weight"]), t(sd[b + "mlp.fc1.bias"])
             w.fc2_w[l], w.fc2_b[l] = t(sd[b + "mlp.fc2.weight"]), t(sd[b + "mlp.fc2.bias"])
+            w.qkv_w3[l], w.out_w3[l] = t3(sd[b + "attn.in_proj_weight"]), t3(sd[b + "attn.out_proj.weight"])
+            w.fc1_w3[l], w.fc2_w3[l] = t3(sd[b + "mlp.fc1.weight"]), t3(sd[b + "mlp.fc2.weight"])
         w.fin_ada_w, w.fin_ada_b = t(sd["final_layer.adaLN_modulation.1.weight"]), t(sd["final_layer.adaLN_modulation.1.bias"])
         w.fin_w, w.fin_b = t(sd["final_layer.linear.weight"]), t(sd["final_layer.linear.bias"])
         self.cfg, self.w = cfg, w
