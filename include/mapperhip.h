@@ -68,6 +68,12 @@ int mh_abi_version(void);
  *   "decode_gemv_cols"   MH_DECODE_GEMV_COLS   0    valid columns per 16-column tile of the decode GEMVs (0 = automatic)
  *   "decode_fused_proj"  MH_DECODE_FUSED_PROJ  1    decode attention kernels project their own q / k / v (0: stand-alone
  *                                                   GEMV launches; fp32 summation order of the projections differs)
+ *   "decode_self_rows"   MH_DECODE_SELF_ROWS   1    rows of one head per decode self-attention workgroup (1, 2, 4): they share
+ *                                                   the head's q / k / v weight slice; a row's key interleave is 16 / rows
+ *                                                   waves wide (fp32 order of its softmax sums differs between settings,
+ *                                                   never with the batch)
+ * (further switches -- decode_cu_split, gemm_tile128_min, attn_small_max_wgs, dit_split3_min_rows -- are documented
+ * next to their definitions in csrc/api.hip.)
  * Unknown names return MH_ERR_ARG (set) / -1 (get). */
 int mh_set_option(const char* name, long value);
 long mh_get_option(const char* name);

@@ -94,6 +94,14 @@ template <> __device__ inline void store4<float>(float* p, float a, float b, flo
   *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
 }
 
+// Everything a decode kernel hands to the NEXT kernel is stored write-through ("agent scope", `global_store ... sc1`):
+// the release at the end of a kernel writes back the dirty lines of every XCD's L2, and with two decode chains on the
+// chip each chain's kernel boundaries also pay for the other chain's dirty lines.  With nothing dirty the boundary is
+// cheaper: tools/micro/gemv_probe, o-projection 3.53 -> 3.37 us alone, 4.60 -> 4.08 us beside a second chain; the
+// K = 2048 projection 6.35 -> 5.54 us (non-temporal stores: no gain).
+template <typename U>
+__device__ inline void store_wt(U* p, U v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 // ---- decode GEMV ("skinny GEMM": M = batch rows <= 64) ------------------------------------------------------------
 // out[b][n] = sum_k A[b][k] * W[n][k] on the 16x16 MFMA atoms.  One workgroup owns ONE 16-column tile of which `nv`
 // columns are real (nv = 16, 8 or 4: a 768-column projection becomes 48, 96 or 192 workgroups; the other tile columns
@@ -173,6 +181,13 @@ template <> struct VecOps<float> {
 
 constexpr int kGemvCH = 8;   // k-blocks per wave whose loads are in flight at once (one pass)
 
+// tools/micro/gemv_probe.hip compiles this kernel with parts switched OFF to price them (bit mask: 1 activation loads,
+// 2 weight loads, 4 old residual values, 8 cross-wave reduction, 16 stores; 32 / 64: residual stores as agent-scope atomic /
+// non-temporal stores); always 0 in the library
+#ifndef MH_GEMV_PROBE
+#define MH_GEMV_PROBE 0
+#endif
+
 // MF 16-row fragments (B <= 16 MF), NWV waves.  NWV depends on K only (never on the batch): a row's summation order,
 // hence its rounding and its greedy tokens, must not depend on which other rows share the launch.
 template <typename T, int MF, int NWV, int PRO, int EPI>
@@ -225,7 +240,8 @@ __global__ __launch_bounds__(NWV * 64) void gemv_kernel(SkinnyP p) {
   float oldh[UPW];
 #pragma unroll
   for (int u = 0; u < UPW; ++u) oldh[u] = 0.f;
-  if (EPI == SK_RESID && l15 < nv) {   // requested before anything is waited for
+  constexpr int PROBE = MH_GEMV_PROBE;
+  if (EPI == SK_RESID && l15 < nv && !(PROBE & 4)) {   // requested before anything is waited for
 #pragma unroll
     for (int u = 0; u < UPW; ++u) {
       const int unit = wid + u * NWV;
@@ -246,7 +262,7 @@ __global__ __launch_bounds__(NWV * 64) void gemv_kernel(SkinnyP p) {
     Raw hraw[PRO == PRO_RMSNORM ? CH : 1][PRO == PRO_RMSNORM ? MF : 1];
 #pragma unroll
     for (int c = 0; c < CH; ++c) wv[c] = make_uint4(0, 0, 0, 0);
-    if (wload) {     // ONE exec-masked region around all weight loads (a branch per load would serialise them)
+    if (wload && !(PROBE & 2)) {     // ONE exec-masked region around all weight loads (a branch per load would serialise them)
 #pragma unroll
       for (int c = 0; c < CH; ++c) {
         const int kb = kb0 + NWV * c;
@@ -257,7 +273,13 @@ __global__ __launch_bounds__(NWV * 64) void gemv_kernel(SkinnyP p) {
     for (int c = 0; c < CH; ++c) {
       const int kb = kb0 + NWV * c;
       const int kel = (kb < nkb ? kb : nkb - 1) * KB;
-      if (PRO == PRO_PLAIN) {
+      if (PROBE & 1) {
+#pragma unroll
+        for (int f = 0; f < MF; ++f) {
+          if (PRO == PRO_PLAIN) av[c][f] = make_uint4(kel, lane, c, f);
+          else hraw[c][f] = VecOps<T>::load_raw(lnw + ((kel + lane) & 1020));
+        }
+      } else if (PRO == PRO_PLAIN) {
 #pragma unroll
         for (int f = 0; f < MF; ++f)
           av[c][f] = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.A) + (long)arow[f] * p.lda + kel + lg * VEC);
@@ -306,10 +328,12 @@ __global__ __launch_bounds__(NWV * 64) void gemv_kernel(SkinnyP p) {
     kb0 += NWV * CH;
   } while (kb0 < nkb);
 
+  if (!(PROBE & 8)) {
 #pragma unroll
-  for (int f = 0; f < MF; ++f) red[(wid * MF + f) * 64 + lane] = acc[f];
+    for (int f = 0; f < MF; ++f) red[(wid * MF + f) * 64 + lane] = acc[f];
+  }
   MH_STAMP(KID, 1);     // operands arrived, products done
-  __syncthreads();
+  if (!(PROBE & 8)) __syncthreads();
   MH_STAMP(KID, 2);     // all waves done
 
   const int pos = (EPI == SK_QKV) ? *p.pos : 0;
@@ -320,28 +344,36 @@ __global__ __launch_bounds__(NWV * 64) void gemv_kernel(SkinnyP p) {
     if (unit >= MF * 4) break;
     const int ef = unit >> 2, r = unit & 3;
     float v = 0.f;
+    if (PROBE & 8) {
+      v = acc[0][0] + acc[MF - 1][3];
+    } else {
 #pragma unroll
-    for (int w = 0; w < NWV; ++w) v += redf[((w * MF + ef) * 64 + lane) * 4 + r];    // wave order: deterministic
+      for (int w = 0; w < NWV; ++w) v += redf[((w * MF + ef) * 64 + lane) * 4 + r];    // wave order: deterministic
+    }
     const int row = ef * 16 + lg * 4 + r;
-    const bool ok = col_ok && row < p.B;
+    const bool ok = col_ok && row < p.B && (!(PROBE & 16) || p.B < 0);
     if (EPI == SK_GEGLU) {
       const float lin = __shfl_down(v, 8, 16);   // the linear half of the pair sits 8 tile columns to the right
-      if (ok) reinterpret_cast<T*>(p.out)[(long)row * p.ldo + ocol] = Elem<T>::from_f32(gelu_tanh(v) * lin);
+      if (ok) store_wt(reinterpret_cast<T*>(p.out) + (long)row * p.ldo + ocol, Elem<T>::from_f32(gelu_tanh(v) * lin));
     } else if (EPI == SK_STORE) {
-      if (ok) reinterpret_cast<T*>(p.out)[(long)row * p.ldo + ocol] = Elem<T>::from_f32(v);
+      if (ok) store_wt(reinterpret_cast<T*>(p.out) + (long)row * p.ldo + ocol, Elem<T>::from_f32(v));
     } else if (EPI == SK_LOGITS) {
-      if (ok) reinterpret_cast<float*>(p.out)[(long)row * p.ldo + ocol] = v;
+      if (ok) store_wt(reinterpret_cast<float*>(p.out) + (long)row * p.ldo + ocol, v);
     } else if (EPI == SK_RESID) {
-      if (ok) p.h[(long)row * p.ldh + ocol] = oldh[u] + v;
+      if (ok) {
+        if (PROBE & 32) p.h[(long)row * p.ldh + ocol] = oldh[u] + v;     // (the plain store, for comparison)
+        else if (PROBE & 64) __builtin_nontemporal_store(oldh[u] + v, p.h + (long)row * p.ldh + ocol);
+        else store_wt(p.h + (long)row * p.ldh + ocol, oldh[u] + v);
+      }
     } else if (EPI == SK_QKV) {
       if (ok) {
         const int part = ocol / p.inner, c = ocol - part * p.inner;
         if (part == 0) {
-          reinterpret_cast<T*>(p.out)[(long)row * p.ldo + c] = Elem<T>::from_f32(v);
+          store_wt(reinterpret_cast<T*>(p.out) + (long)row * p.ldo + c, Elem<T>::from_f32(v));
         } else {
           const int hh = c >> 6, dd = c & 63;
           T* cache = reinterpret_cast<T*>(part == 1 ? p.kc : p.vc);
-          cache[(((long)row * p.H + hh) * p.tgt_len + pos) * 64 + dd] = Elem<T>::from_f32(v);
+          store_wt(cache + (((long)row * p.H + hh) * p.tgt_len + pos) * 64 + dd, Elem<T>::from_f32(v));
         }
       }
     }
@@ -512,7 +544,7 @@ __global__ __launch_bounds__(256) void dec_self_attn_kernel(SelfAttnP p) {
   float m, l, a;
   block_merge<T>(st, sm, m, l, a);
   if (threadIdx.x < 64)
-    reinterpret_cast<T*>(p.out)[(long)b * p.ldo + h * 64 + threadIdx.x] = Elem<T>::from_f32(l > 0.f ? a / l : 0.f);
+    store_wt(reinterpret_cast<T*>(p.out) + (long)b * p.ldo + h * 64 + threadIdx.x, Elem<T>::from_f32(l > 0.f ? a / l : 0.f));
 }
 
 struct CrossAttnP {
@@ -561,7 +593,7 @@ __global__ __launch_bounds__(1024) void dec_cross_attn_kernel(CrossAttnP p) {
   float m, l, a;
   block_merge<T, NW>(st, sm, m, l, a);
   if (threadIdx.x < 64)
-    reinterpret_cast<T*>(p.out)[(long)b * p.ldo + h * 64 + threadIdx.x] = Elem<T>::from_f32(l > 0.f ? a / l : 0.f);
+    store_wt(reinterpret_cast<T*>(p.out) + (long)b * p.ldo + h * 64 + threadIdx.x, Elem<T>::from_f32(l > 0.f ? a / l : 0.f));
 }
 
 // ---- attention kernels that project their own query (and the new self-attention key / value) --------------------
@@ -691,12 +723,42 @@ void dec_cross_attn_q_kernel(CrossAttnP p, HeadProjP hp) {
   block_merge<T, NW>(st, sm, m, l, a);
   MH_STAMP(KID_CROSS, 3);   // partials merged
   if (threadIdx.x < 64)
-    reinterpret_cast<T*>(p.out)[(long)b * p.ldo + h * 64 + threadIdx.x] = Elem<T>::from_f32(l > 0.f ? a / l : 0.f);
+    store_wt(reinterpret_cast<T*>(p.out) + (long)b * p.ldo + h * 64 + threadIdx.x, Elem<T>::from_f32(l > 0.f ? a / l : 0.f));
   if (p.tstamp && threadIdx.x == 0 && *p.pos < p.ts_ring) {      // the first ts_ring positions of the call, one slot each
     unsigned long long* slot = p.tstamp + 2 * ((long)(*p.pos) * p.ts_layers + p.ts_layer);
     atomicMin(slot, t_start);
     atomicMax(slot + 1, (unsigned long long)wall_clock64());
   }
+}
+
+// normalised rows b0 .. b0+R-1 (clamped to B-1) into LDS as T elements: xs[r][k] = T(ln_w[k] * (h[b][k] * rsqrt(mean(h[b]^2)
+// + eps))), one pass of loads, by a 1024-thread workgroup (d <= 1024); the statistics as in norm_row_to_lds
+template <typename T, int R>
+__device__ inline void norm_rows_to_lds(const HeadProjP& hp, int b0, int B, T (*xs)[1024], float (*red)[16]) {
+  const int tid = threadIdx.x;
+  const int kc = tid < hp.d ? tid : hp.d - 1;
+  float x[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int br = b0 + r < B ? b0 + r : B - 1;
+    x[r] = hp.h[(long)br * hp.ldh + kc];
+  }
+  const float g = hp.ln_w[kc];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const float sq = wave_sum(tid < hp.d ? x[r] * x[r] : 0.f);
+    if ((tid & 63) == 0) red[r][tid >> 6] = sq;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) tot += red[r][w];
+    const float rs = rsqrtf(tot / (float)hp.d + hp.eps);
+    if (tid < hp.d) xs[r][tid] = Elem<T>::from_f32(g * (x[r] * rs));
+  }
+  __syncthreads();
 }
 
 // self-attention of one (b, h) with its own q / k / v projections: appends the new key / value row to the caches and
@@ -735,8 +797,8 @@ __global__ __launch_bounds__(1024) void dec_self_attn_qkv_kernel(SelfAttnP p, He
   MH_STAMP(KID_SELF, 0);    // q / k / v projected
   T* kcache = reinterpret_cast<T*>(const_cast<void*>(p.kc)) + ((long)b * p.H + h) * p.tgt_len * 64;
   T* vcache = reinterpret_cast<T*>(const_cast<void*>(p.vc)) + ((long)b * p.H + h) * p.tgt_len * 64;
-  if (threadIdx.x >= 64 && threadIdx.x < 128) kcache[(long)pos * 64 + (threadIdx.x - 64)] = Elem<T>::from_f32(qkv[1][threadIdx.x - 64]);
-  if (threadIdx.x >= 128 && threadIdx.x < 192) vcache[(long)pos * 64 + (threadIdx.x - 128)] = Elem<T>::from_f32(qkv[2][threadIdx.x - 128]);
+  if (threadIdx.x >= 64 && threadIdx.x < 128) store_wt(kcache + (long)pos * 64 + (threadIdx.x - 64), Elem<T>::from_f32(qkv[1][threadIdx.x - 64]));
+  if (threadIdx.x >= 128 && threadIdx.x < 192) store_wt(vcache + (long)pos * 64 + (threadIdx.x - 128), Elem<T>::from_f32(qkv[2][threadIdx.x - 128]));
   float q[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) q[i] = qkv[0][c8 + i];
@@ -758,7 +820,114 @@ __global__ __launch_bounds__(1024) void dec_self_attn_qkv_kernel(SelfAttnP p, He
     const float fa = fexp<T>(m - mn), fb = fexp<T>(sn - mn);
     l = l * fa + fb;
     a = a * fa + qkv[2][d] * fb;
-    reinterpret_cast<T*>(p.out)[(long)b * p.ldo + h * 64 + d] = Elem<T>::from_f32(l > 0.f ? a / l : 0.f);
+    store_wt(reinterpret_cast<T*>(p.out) + (long)b * p.ldo + h * 64 + d, Elem<T>::from_f32(l > 0.f ? a / l : 0.f));
+  }
+}
+
+// The same for R = 2 or 4 rows of one head per workgroup (option decode_self_rows): rows b0 .. b0+R-1 share the head's
+// 3 x 64 x d weight slice, which is requested ONCE, at kernel entry (before the row statistics are waited for), straight
+// into MFMA fragments: wave w owns the 16-feature tile tg = w & 3 of each of q / k / v and the quarter ks = w >> 2 of K
+// (A operand = the R normalised rows from LDS, tile rows >= R repeat row 0 and are never read back); the 4 K-quarters are
+// added through LDS in fixed order.  R = 1 re-reads 295 KB of weights per (row, head) -- 57 MB of L2 reads per 16-row
+// launch at base dims -- and occupies 192 CUs with a 110-register 16-wave workgroup each (nothing of the other decode
+// chain fits beside it); R rows per workgroup divide both by R.  Then 16 / R waves per row attend over the cache.  A
+// row's arithmetic depends on R (projection on the MFMA atom, key interleave 16 / R waves wide), never on the batch.
+template <typename T, int KC, int R>
+__global__ __launch_bounds__(1024) void dec_self_attn_qkv_rows_kernel(SelfAttnP p, HeadProjP hp, int inner) {
+  constexpr int NW = 16, NWR = NW / R;   // waves per row
+  constexpr int U = 4;                   // keys in flight per 8-lane group (the weight fragments are dead by then)
+  constexpr int VEC = Elem<T>::kVec, KB = 4 * VEC;
+  constexpr int NF = KC * 128 / KB / 4;  // k-blocks per K-quarter: KC (bf16) or 2 KC (fp32)
+  constexpr int PPP = (sizeof(T) == 2 && KC <= 6) ? 3 : 1;   // projections per pass (register budget: <= 18 fragments)
+  __shared__ float sm[NW][66];
+  __shared__ __attribute__((aligned(16))) T xs[R][1024];
+  __shared__ float qkv[R][3][64];
+  __shared__ float red[R][16];
+  __shared__ f32x4_t part[3][NW][16];    // [projection][wave][feature of the tile]: accumulator rows 0..3 = batch rows
+  MH_STAMP0();
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int b0 = (blockIdx.x / p.H) * R, h = blockIdx.x % p.H;
+  const int tg = wid & 3, ks = wid >> 2;
+  const T* wbase = reinterpret_cast<const T*>(hp.W) + (long)(h * 64 + tg * 16 + l15) * hp.ldw + ks * NF * KB + lg * VEC;
+  const long wpart = (long)inner * hp.ldw;
+  uint4 wv[PPP][NF];
+#pragma unroll
+  for (int pp = 0; pp < PPP; ++pp)
+#pragma unroll
+    for (int c = 0; c < NF; ++c) wv[pp][c] = *reinterpret_cast<const uint4*>(wbase + pp * wpart + c * KB);
+  const int pos = *p.pos;
+  norm_rows_to_lds<T, R>(hp, b0, p.B, xs, red);
+  const T* xrow = xs[l15 < R ? l15 : 0] + ks * NF * KB + lg * VEC;
+#pragma unroll
+  for (int p0 = 0; p0 < 3; p0 += PPP) {
+    if (p0 > 0) {
+#pragma unroll
+      for (int c = 0; c < NF; ++c) wv[0][c] = *reinterpret_cast<const uint4*>(wbase + p0 * wpart + c * KB);
+    }
+#pragma unroll
+    for (int pp = 0; pp < PPP; ++pp) {
+      f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < NF; ++c) acc = VecOps<T>::mma(*reinterpret_cast<const uint4*>(xrow + c * KB), wv[pp][c], acc);
+      if (lg == 0) part[p0 + pp][wid][l15] = acc;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 3 * R * 64) {   // (projection, row, feature): the 4 K-quarters in fixed order
+    const int f = threadIdx.x & 63, rr = (threadIdx.x >> 6) % R, pj = threadIdx.x / (64 * R);
+    const float* pf = reinterpret_cast<const float*>(part);
+    float v = 0.f;
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) v += pf[(((pj * NW) + q4 * 4 + (f >> 4)) * 16 + (f & 15)) * 4 + rr];
+    qkv[rr][pj][f] = Elem<T>::to_f32(Elem<T>::from_f32(v));
+  }
+  __syncthreads();
+  MH_STAMP(KID_SELF, 0);    // q / k / v projected
+  const int c8 = (lane & 7) * 8, g = lane >> 3;
+  const int r = wid / NWR, wr = wid % NWR;            // this wave's row and its index among the row's waves
+  const bool live = b0 + r < p.B;
+  const int b = live ? b0 + r : p.B - 1;              // a dead row recomputes the last one and stores nothing
+  T* kcache = reinterpret_cast<T*>(const_cast<void*>(p.kc)) + ((long)b * p.H + h) * p.tgt_len * 64;
+  T* vcache = reinterpret_cast<T*>(const_cast<void*>(p.vc)) + ((long)b * p.H + h) * p.tgt_len * 64;
+  if (live && wr == 1) store_wt(kcache + (long)pos * 64 + lane, Elem<T>::from_f32(qkv[r][1][lane]));
+  if (live && wr == 2) store_wt(vcache + (long)pos * 64 + lane, Elem<T>::from_f32(qkv[r][2][lane]));
+  float q[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) q[i] = qkv[r][0][c8 + i];
+  const float* bias_row = p.bias + (long)h * p.tgt_len;
+  const uint8_t* mask_row = p.prompt_mask ? p.prompt_mask + (long)b * p.P : nullptr;
+  Partial st;
+  partial_init(st);
+  attend_keys<T, U>(st, q, kcache, vcache, wr * 8 + g, pos, 8 * NWR, bias_row, pos, mask_row, p.P, 1.0f);
+  MH_STAMP(KID_SELF, 1);    // cached keys attended (this wave)
+  partial_merge_groups<T>(st);
+  if (g == 0) {
+    if (lane == 0) { sm[wid][0] = st.m; sm[wid][1] = st.l; }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sm[wid][2 + c8 + i] = st.acc[i];
+  }
+  __syncthreads();
+  if (wr == 0) {   // the first wave of a row merges the row's NWR partials in wave order, then the new key
+    const int d = lane, w0 = r * NWR;
+    float m = sm[w0][0];
+#pragma unroll
+    for (int w = 1; w < NWR; ++w) m = fmaxf(m, sm[w0 + w][0]);
+    float l = 0.f, a = 0.f;
+#pragma unroll
+    for (int w = 0; w < NWR; ++w) {
+      const float f = fexp<T>(sm[w0 + w][0] - m);
+      l += sm[w0 + w][1] * f;
+      a += sm[w0 + w][2 + d] * f;
+    }
+    MH_STAMP(KID_SELF, 2);    // partials merged
+    float sn = wave_sum(qkv[r][0][d] * qkv[r][1][d]) + bias_row[0];
+    if (mask_row && pos < p.P && mask_row[pos < p.P ? pos : 0] == 0) sn = -INFINITY;
+    const float mn = fmaxf(m, sn);
+    const float fa = fexp<T>(m - mn), fb = fexp<T>(sn - mn);
+    l = l * fa + fb;
+    a = a * fa + qkv[r][2][d] * fb;
+    if (live) store_wt(reinterpret_cast<T*>(p.out) + (long)b * p.ldo + h * 64 + d, Elem<T>::from_f32(l > 0.f ? a / l : 0.f));
   }
 }
 

@@ -156,15 +156,13 @@ struct SampleP {
   int chain_rows;                     // rows of this chain (both halves under CFG)
 };
 
-__device__ inline void update_ts_state(const MhSampling& sp, int tok, int32_t* last_ts_val) {
+__device__ inline int32_t next_ts_state(const MhSampling& sp, int tok, int32_t cur) {
   // incremental form of MonotonicTimeShiftLogitsProcessor's "last TIME_SHIFT after the last SOS-type
-  // token" scan (osuT5/osuT5/inference/logit_processors.py:150-172)
-  if (tok >= sp.ts_start && tok < sp.ts_end) {
-    *last_ts_val = tok - sp.ts_start;
-  } else {
-    for (int i = 0; i < sp.n_sos; ++i)
-      if (tok == sp.sos_ids[i]) { *last_ts_val = -1; break; }
-  }
+  // token" scan (osuT5/osuT5/inference/logit_processors.py:150-172): the state after `tok`
+  if (tok >= sp.ts_start && tok < sp.ts_end) return tok - sp.ts_start;
+  for (int i = 0; i < sp.n_sos; ++i)
+    if (tok == sp.sos_ids[i]) return -1;
+  return cur;
 }
 
 // input_ids[row][i] as the reference's processors see it: the prompt, then the ids that were FED (the forced ids
@@ -189,7 +187,7 @@ __global__ __launch_bounds__(256) void dec_init_kernel(SampleP p, int chain_rows
   const int lb = blockIdx.x, b = p.b0 + lb;
   if (threadIdx.x == 0) {
     int32_t v = -1;
-    for (int i = 0; i <= start_pos; ++i) update_ts_state(p.sp, p.tokens[(long)b * p.max_length + i], &v);
+    for (int i = 0; i <= start_pos; ++i) v = next_ts_state(p.sp, p.tokens[(long)b * p.max_length + i], v);
     p.last_ts_val[b] = v;
     p.finished[b] = 0;
     p.finish_col[b] = p.max_length - 1;
@@ -229,7 +227,7 @@ __global__ __launch_bounds__(256) void dec_sample_kernel(SampleP p) {
     if (tid < nrow) {
       const int row = tid == 0 ? b : bneg;
       const int tok = p.tokens[(long)row * p.max_length + col];
-      if (tid == 0) update_ts_state(sp, tok, &p.last_ts_val[b]);
+      if (tid == 0) dec::store_wt(&p.last_ts_val[b], next_ts_state(sp, tok, p.last_ts_val[b]));
       s_tok[tid] = tok;
     }
     __syncthreads();
@@ -271,8 +269,9 @@ __global__ __launch_bounds__(256) void dec_sample_kernel(SampleP p) {
     float* fin = p.proc + (long)gr * p.V;
     float best = -INFINITY;
     int besti = 0x7fffffff;
+    const bool keep_scores = sp.do_sample != 0;   // only the sampling passes below read the processed scores back
     auto consider = [&](int v, float x) {
-      fin[v] = x;
+      if (keep_scores) fin[v] = x;
       if (dump) dump[v] = x;
       if (x > best) { best = x; besti = v; }   // strided scan keeps the smallest index per thread
     };
@@ -422,14 +421,14 @@ __global__ __launch_bounds__(256) void dec_sample_kernel(SampleP p) {
       const bool done = !forced && !was_finished && (p.eos_table[emit] || col + 1 >= sp.max_length);
       for (int j = 0; j < nrow; ++j) {   // the rows of a CFG pair receive the same id (decoder_input_ids.repeat)
         const int row = j == 0 ? b : bneg;
-        p.tokens[(long)row * p.max_length + col] = emit;
+        dec::store_wt(p.tokens + (long)row * p.max_length + col, (int32_t)emit);
         s_tok[j] = forced ? p.forced[(long)row * p.max_length + col] : emit;
         if (done) {
           __hip_atomic_store(&p.finished[row], (uint8_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // read by the last-arriving workgroup below
-          p.finish_col[row] = col;
+          dec::store_wt(p.finish_col + row, (int32_t)col);
         }
       }
-      update_ts_state(sp, s_tok[0], &p.last_ts_val[b]);
+      dec::store_wt(&p.last_ts_val[b], next_ts_state(sp, s_tok[0], ltv));
     }
     __syncthreads();
   }
@@ -437,7 +436,7 @@ __global__ __launch_bounds__(256) void dec_sample_kernel(SampleP p) {
   for (int j = 0; j < nrow; ++j) {
     const int lrow = j == 0 ? lb : lneg;
     const T* e = reinterpret_cast<const T*>(p.dec_embed) + (long)s_tok[j] * p.d;
-    for (int i = tid; i < p.d; i += 256) p.h[(long)lrow * p.d + i] = Elem<T>::to_f32(e[i]);
+    for (int i = tid; i < p.d; i += 256) dec::store_wt(p.h + (long)lrow * p.d + i, Elem<T>::to_f32(e[i]));   // write-through: see store_wt
   }
   // Step bookkeeping without a launch of its own: every workgroup read `pos` when it started, so the one that arrives
   // last may advance it; it also recounts the running rows for the host's early-stop poll.  The `finished` flags are
@@ -451,8 +450,8 @@ __global__ __launch_bounds__(256) void dec_sample_kernel(SampleP p) {
       int run = 0;
       for (int i = 0; i < p.chain_rows; ++i)
         run += __hip_atomic_load(&p.finished[p.b0 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 0 : 1;
-      p.st->n_running = run;
-      p.st->pos = pos + 1;
+      dec::store_wt(&p.st->n_running, run);
+      dec::store_wt(&p.st->pos, pos + 1);
     }
   }
 }
@@ -528,7 +527,14 @@ bool fused_proj_enabled(int d) { return option(OPT_DECODE_FUSED_PROJ) != 0 && d 
 
 template <typename T, int KC>
 int launch_self_qkv(const dec::SelfAttnP& sa, const dec::HeadProjP& hp, int inner, hipStream_t s) {
-  hipLaunchKernelGGL((dec::dec_self_attn_qkv_kernel<T, KC>), dim3(sa.B * sa.H), dim3(1024), 0, s, sa, hp, inner);
+  // option decode_self_rows: rows of one head per workgroup (1, 2 or 4) -- they share the head's weight slice
+  const long R = option(OPT_DECODE_SELF_ROWS);
+  if (R >= 4)
+    hipLaunchKernelGGL((dec::dec_self_attn_qkv_rows_kernel<T, KC, 4>), dim3((sa.B + 3) / 4 * sa.H), dim3(1024), 0, s, sa, hp, inner);
+  else if (R >= 2)
+    hipLaunchKernelGGL((dec::dec_self_attn_qkv_rows_kernel<T, KC, 2>), dim3((sa.B + 1) / 2 * sa.H), dim3(1024), 0, s, sa, hp, inner);
+  else
+    hipLaunchKernelGGL((dec::dec_self_attn_qkv_kernel<T, KC>), dim3(sa.B * sa.H), dim3(1024), 0, s, sa, hp, inner);
   return check_launch("dec_self_attn_qkv_kernel");
 }
 template <typename T>

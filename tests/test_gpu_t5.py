@@ -78,11 +78,12 @@ def test_fp32_matches_reference_golden(name):
 
 @pytest.mark.parametrize("opts", [dict(decode_fused_proj=0), dict(decode_gemv_cols=16), dict(decode_gemv_cols=8),
                                   dict(decode_gemv_cols=4), dict(decode_chains=1), dict(decode_chains=3),
-                                  dict(decode_prefill=0, decode_fused_proj=0)])
+                                  dict(decode_prefill=0, decode_fused_proj=0), dict(decode_self_rows=2),
+                                  dict(decode_self_rows=4)])
 def test_decode_kernel_variants_reproduce_the_reference_tokens(opts):
     """Every run-time selectable form of the decode step (mh_set_option: stand-alone QKV / cross-Q GEMVs instead of
     the attention kernels' own projections, 16 / 8 / 4 real columns per GEMV tile, 1 or 3 row chains, token-by-token
-    prompt feeding) must give the reference's greedy ids bit for bit in fp32 (golden t5_tiny: ragged prompts, 3 rows;
+    prompt feeding, 1 / 4 rows per self-attention workgroup) must give the reference's greedy ids bit for bit in fp32 (golden t5_tiny: ragged prompts, 3 rows;
     t5_small: base-like head count)."""
     from mapperatorinator_amd import _lib
     from mapperatorinator_amd.server import model_generate
