@@ -114,6 +114,11 @@ __device__ inline void store_wt(U* p, U v) { __hip_atomic_store(p, v, __ATOMIC_R
 //     once (single pass), so the RMSNorm statistics come from those registers (lane -> 16-lane shuffle -> LDS over the
 //     waves): no statistics buffers, no extra memory round trip, one barrier;
 //   * weights are read exactly once per workgroup straight into MFMA fragments (no LDS round trip for data used once).
+//   * the activation fragments are "fragment-shaped" loads (16 rows x 64 bytes per wave instruction), which cost the
+//     CU's load path about twice what whole lines cost (tools/micro/gemv_probe, mask 128: the same bytes as contiguous
+//     1 KB runs take 3.35 -> 2.70 us alone, 4.13 -> 2.92 us beside a second chain).  Staging them through LDS with
+//     whole-line loads was built and measured: the extra LDS write / barrier / read costs what the loads save (o-projection
+//     3.61 us alone, 4.12 beside a second chain; whole step 37.4 k vs 38.1 k tok/s without it) -- not kept.
 enum { PRO_PLAIN = 0, PRO_RMSNORM = 1 };
 enum { SK_STORE = 0, SK_QKV = 1, SK_GEGLU = 2, SK_RESID = 3, SK_LOGITS = 4 };
 
@@ -196,6 +201,22 @@ __global__ __launch_bounds__(NWV * 64) void gemv_kernel(SkinnyP p) {
   constexpr int KB = 4 * VEC;          // k elements per k-block (4 lane groups x 16 B)
   constexpr int CH = kGemvCH;
   typedef typename VecOps<T>::Raw Raw;
+  // PRO_PLAIN, 16 rows (MF == 1): the activations are loaded as whole 128-byte lines -- 8 rows x 128 bytes per wave
+  // instruction; wave w owns the k-block PAIRS w, w + NWV, ... -- and turned into MFMA fragments through a wave-private
+  // 2.3 KB LDS patch: no barrier (the LDS operations of one wave execute in order, so the patch is reused line after
+  // line), 2 ds_write_b128 + 2 ds_read_b128 per line.  Fragment-shaped global loads (16 rows x 64 bytes per instruction)
+  // cost the CU's load path twice as much: tools/micro/gemv_probe, o-projection 3.35 -> 2.80 us alone, 4.13 -> 3.09 us
+  // beside a second chain; K = 2048: 4.89 -> 3.66 / 5.54 -> 4.63; whole step 38.2 k -> 39.9 k tok/s.
+  // The same for the fp32 residual rows of PRO_RMSNORM (twice the lines per k-block) and for the 16-row weight tile of
+  // the gated-GELU GEMV was built and measured: 5.82 -> 6.90 us alone, 6.82 -> 8.69 beside a second chain (48 LDS
+  // operations per wave cost more than the load path saves) -- those keep fragment-shaped loads.
+#ifndef MH_GEMV_LINES
+#define MH_GEMV_LINES 1   // (0: A/B builds only)
+#endif
+  constexpr bool LINES = (MF == 1 && PRO == PRO_PLAIN && MH_GEMV_LINES);
+  constexpr int CP = CH / 2;                 // k-block pairs per wave and pass
+  constexpr int PATCH = 16 * 144;            // 16 rows x (128 + 16) bytes: rows 16 bytes apart in the bank row
+  __shared__ __attribute__((aligned(16))) unsigned char Lw[LINES ? NWV * PATCH : 16];
   __shared__ f32x4_t red[NWV * MF * 64];
   __shared__ float ssw[PRO == PRO_RMSNORM ? NWV : 1][MF * 16];
   __shared__ __attribute__((aligned(16))) float lnw[PRO == PRO_RMSNORM ? 1024 : 4];   // RMSNorm weight, staged once per workgroup
@@ -256,6 +277,46 @@ __global__ __launch_bounds__(NWV * 64) void gemv_kernel(SkinnyP p) {
   const int nkb = p.K / KB;
 
   int kb0 = wid;
+  if constexpr (LINES) {
+    const int npair = nkb >> 1;        // K is a multiple of 2 KB elements (checked on the host)
+    unsigned char* patch = Lw + wid * PATCH;
+    const int r8 = lane >> 3, c16 = (lane & 7) * 16;
+    const unsigned char* Ab = reinterpret_cast<const unsigned char*>(p.A) + c16;
+    const long rx = (long)(r8 < p.B ? r8 : p.B - 1) * p.lda * (long)sizeof(T);
+    const long ry = (long)(8 + r8 < p.B ? 8 + r8 : p.B - 1) * p.lda * (long)sizeof(T);
+    for (int pw0 = wid; pw0 < npair + wid; pw0 += NWV * CP) {
+      uint4 wv[CH], xa[CP], ya[CP];
+#pragma unroll
+      for (int c = 0; c < CH; ++c) wv[c] = make_uint4(0, 0, 0, 0);
+      if (wload && !(PROBE & 2)) {   // ONE exec-masked region around all weight loads
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          const int pw = pw0 + NWV * (c >> 1);
+          wv[c] = *reinterpret_cast<const uint4*>(Wp + (2 * (pw < npair ? pw : npair - 1) + (c & 1)) * KB);   // clamped address
+        }
+      }
+#pragma unroll
+      for (int cp = 0; cp < CP; ++cp) {
+        const int pw = pw0 + NWV * cp;
+        const long off = (long)(pw < npair ? pw : npair - 1) * 128;
+        xa[cp] = *reinterpret_cast<const uint4*>(Ab + rx + off);
+        ya[cp] = *reinterpret_cast<const uint4*>(Ab + ry + off);
+      }
+      MH_STAMP(KID, 0);   // loads issued
+#pragma unroll
+      for (int cp = 0; cp < CP; ++cp) {
+        const uint32_t keep = (pw0 + NWV * cp < npair) ? 0xffffffffu : 0u;   // pairs beyond K contribute zeros
+        *reinterpret_cast<uint4*>(patch + r8 * 144 + c16) = xa[cp];
+        *reinterpret_cast<uint4*>(patch + (8 + r8) * 144 + c16) = ya[cp];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {   // this lane's fragment (row l15, k group lg) of the pair's two k-blocks
+          uint4 a = *reinterpret_cast<const uint4*>(patch + l15 * 144 + (j * 4 + lg) * 16);
+          a = make_uint4(a.x & keep, a.y & keep, a.z & keep, a.w & keep);
+          acc[0] = VecOps<T>::mma(a, wv[cp * 2 + j], acc[0]);
+        }
+      }
+    }
+  } else
   do {   // ONE pass for every RMSNorm shape and for K <= NWV * CH * KB; every wave runs at least one (its barrier)
     uint4 wv[CH];
     uint4 av[PRO == PRO_PLAIN ? CH : 1][PRO == PRO_PLAIN ? MF : 1];
@@ -279,6 +340,10 @@ __global__ __launch_bounds__(NWV * 64) void gemv_kernel(SkinnyP p) {
           if (PRO == PRO_PLAIN) av[c][f] = make_uint4(kel, lane, c, f);
           else hraw[c][f] = VecOps<T>::load_raw(lnw + ((kel + lane) & 1020));
         }
+      } else if (PRO == PRO_PLAIN && (PROBE & 128)) {   // timing only: the same bytes as whole 1 KB runs per wave instruction
+#pragma unroll
+        for (int f = 0; f < MF; ++f)
+          av[c][f] = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.A) + ((long)((c * NWV + wid) % (p.K * 16 / (64 * VEC))) * 64 + lane) * VEC);
       } else if (PRO == PRO_PLAIN) {
 #pragma unroll
         for (int f = 0; f < MF; ++f)
@@ -646,8 +711,11 @@ __device__ inline void norm_row_to_lds(const HeadProjP& hp, int b, float* xn, fl
 }
 
 // NP projections of 64 outputs each: out[p][o] = T-rounded sum_k xn[k] * W[(row0[p] + o) * ldw + k].
-// 1024 threads: 16 consecutive lanes per output, KC 8-element chunks per lane (d = 128 KC).  The weight slice does not
-// depend on the activations: `load` is called at kernel entry, `apply` after the normalised row is in LDS.
+// 1024 threads: 16 consecutive lanes per output, KC 8-element chunks per lane (d = 128 KC), chunk c of lane ks = elements
+// [128 c + 8 ks, + 8): the 16 lanes of an output read 256 (bf16) / 512 (fp32) CONTIGUOUS bytes per load instruction, whole
+// 128-byte lines (lane-contiguous chunks -- 96-byte strides at d = 768 -- touch 12 lines per output row and instruction;
+// the CU's load path is charged per line and lane).  The weight slice does not depend on the activations: `load` is
+// called at kernel entry, `apply` after the normalised row is in LDS.
 template <typename T, int KC, int NP>
 struct HeadProj {
   Raw8<T> raw[NP][KC];
@@ -655,14 +723,13 @@ struct HeadProj {
     const int tid = threadIdx.x, o = tid >> 4, ks = tid & 15;
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
-      const T* wp = reinterpret_cast<const T*>(hp.W) + (long)(row0[q] + o) * hp.ldw + ks * (KC * 8);
+      const T* wp = reinterpret_cast<const T*>(hp.W) + (long)(row0[q] + o) * hp.ldw + ks * 8;
 #pragma unroll
-      for (int c = 0; c < KC; ++c) raw[q][c].load(wp + c * 8);
+      for (int c = 0; c < KC; ++c) raw[q][c].load(wp + c * 128);
     }
   }
   __device__ inline void apply(const float* xn, float (*out)[64]) const {
     const int tid = threadIdx.x, o = tid >> 4, ks = tid & 15;
-    constexpr int kper = KC * 8;
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
       float acc = 0.f;
@@ -670,8 +737,8 @@ struct HeadProj {
       for (int c = 0; c < KC; ++c) {
         float w[8];
         raw[q][c].unpack(w);
-        const float4 x0 = *reinterpret_cast<const float4*>(xn + ks * kper + c * 8);
-        const float4 x1 = *reinterpret_cast<const float4*>(xn + ks * kper + c * 8 + 4);
+        const float4 x0 = *reinterpret_cast<const float4*>(xn + c * 128 + ks * 8);
+        const float4 x1 = *reinterpret_cast<const float4*>(xn + c * 128 + ks * 8 + 4);
         acc += x0.x * w[0] + x0.y * w[1] + x0.z * w[2] + x0.w * w[3] + x1.x * w[4] + x1.y * w[5] + x1.z * w[6] + x1.w * w[7];
       }
       acc = group_sum<16>(acc);

@@ -479,6 +479,7 @@ int launch_skinny(dec::SkinnyP p, hipStream_t s) {
   const int kb = 4 * (16 / (int)sizeof(T));
   MH_REQUIRE(p.K % kb == 0 && p.K >= kb, "decode: K=%d must be a positive multiple of %d", p.K, kb);
   const int nkb = p.K / kb;
+  MH_REQUIRE(PRO != dec::PRO_PLAIN || MF != 1 || nkb % 2 == 0, "decode: K=%d must be a multiple of %d", p.K, 2 * kb);
   // waves per workgroup: a function of K ONLY (batch invariance of the summation order)
   const bool wide = nkb > 4 * dec::kGemvCH;
   MH_REQUIRE(PRO != dec::PRO_RMSNORM || nkb <= 8 * dec::kGemvCH, "decode: RMSNorm prologue needs K <= %d", 8 * dec::kGemvCH * kb);
