@@ -207,16 +207,21 @@ __global__ __launch_bounds__(NWV * 64) void gemv_kernel(SkinnyP p) {
   // line), 2 ds_write_b128 + 2 ds_read_b128 per line.  Fragment-shaped global loads (16 rows x 64 bytes per instruction)
   // cost the CU's load path twice as much: tools/micro/gemv_probe, o-projection 3.35 -> 2.80 us alone, 4.13 -> 3.09 us
   // beside a second chain; K = 2048: 4.89 -> 3.66 / 5.54 -> 4.63; whole step 38.2 k -> 39.9 k tok/s.
-  // The same for the fp32 residual rows of PRO_RMSNORM (twice the lines per k-block) and for the 16-row weight tile of
-  // the gated-GELU GEMV was built and measured: 5.82 -> 6.90 us alone, 6.82 -> 8.69 beside a second chain (48 LDS
-  // operations per wave cost more than the load path saves) -- those keep fragment-shaped loads.
+  // PRO_RMSNORM under bf16 storage (RLINES): the fp32 residual rows are one line per row and k-block; the same patch
+  // trick with the k-block -> wave assignment unchanged: RMSNorm + wi + gated GELU 5.80 -> 4.33 us alone, 6.80 -> 5.20 us
+  // beside a second chain.  Loading the 16-row WEIGHT tile of that GEMV as lines as well was measured and lost (6.90 /
+  // 8.69 us: 16 more LDS operations per wave than the load path saves) -- weights keep fragment-shaped loads.
 #ifndef MH_GEMV_LINES
 #define MH_GEMV_LINES 1   // (0: A/B builds only)
 #endif
   constexpr bool LINES = (MF == 1 && PRO == PRO_PLAIN && MH_GEMV_LINES);
   constexpr int CP = CH / 2;                 // k-block pairs per wave and pass
   constexpr int PATCH = 16 * 144;            // 16 rows x (128 + 16) bytes: rows 16 bytes apart in the bank row
-  __shared__ __attribute__((aligned(16))) unsigned char Lw[LINES ? NWV * PATCH : 16];
+#ifndef MH_GEMV_RLINES
+#define MH_GEMV_RLINES 1   // (0: A/B builds only)
+#endif
+  constexpr bool RLINES = (MF == 1 && PRO == PRO_RMSNORM && sizeof(T) == 2 && MH_GEMV_RLINES);
+  __shared__ __attribute__((aligned(16))) unsigned char Lw[(LINES || RLINES) ? NWV * PATCH : 16];
   __shared__ f32x4_t red[NWV * MF * 64];
   __shared__ float ssw[PRO == PRO_RMSNORM ? NWV : 1][MF * 16];
   __shared__ __attribute__((aligned(16))) float lnw[PRO == PRO_RMSNORM ? 1024 : 4];   // RMSNorm weight, staged once per workgroup
@@ -348,13 +353,36 @@ __global__ __launch_bounds__(NWV * 64) void gemv_kernel(SkinnyP p) {
 #pragma unroll
         for (int f = 0; f < MF; ++f)
           av[c][f] = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.A) + (long)arow[f] * p.lda + kel + lg * VEC);
-      } else {
+      } else if (!RLINES) {
 #pragma unroll
         for (int f = 0; f < MF; ++f)
           hraw[c][f] = VecOps<T>::load_raw(reinterpret_cast<const float*>(p.A) + (long)arow[f] * p.lda + kel + lg * VEC);
       }
     }
+    uint4 xr[RLINES ? CH : 1], yr[RLINES ? CH : 1];
+    if (RLINES) {   // one 128-byte line of fp32 per row and k-block: rows 0..7 / 8..15 of the block as two whole-line loads
+      const int r8 = lane >> 3;
+      const unsigned char* Ab = reinterpret_cast<const unsigned char*>(p.A) + (lane & 7) * 16;
+      const long rx = (long)(r8 < p.B ? r8 : p.B - 1) * p.lda * 4, ry = (long)(8 + r8 < p.B ? 8 + r8 : p.B - 1) * p.lda * 4;
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const int kb = kb0 + NWV * c;
+        const long off = (long)(kb < nkb ? kb : nkb - 1) * 128;
+        xr[c] = *reinterpret_cast<const uint4*>(Ab + rx + off);
+        yr[c] = *reinterpret_cast<const uint4*>(Ab + ry + off);
+      }
+    }
     MH_STAMP(KID, 0);   // loads issued
+    if (RLINES) {
+      unsigned char* patch = Lw + wid * PATCH;
+      const int r8 = lane >> 3, c16 = (lane & 7) * 16;
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        *reinterpret_cast<uint4*>(patch + r8 * 144 + c16) = xr[c];
+        *reinterpret_cast<uint4*>(patch + (8 + r8) * 144 + c16) = yr[c];
+        hraw[c][0] = VecOps<T>::load_raw(reinterpret_cast<const float*>(patch + l15 * 144 + lg * 32));
+      }
+    }
     float rsr[MF];
     if (PRO == PRO_RMSNORM) {
       // RMSNorm statistics of the rows from the registers: lane -> the 4 lane groups of the wave -> the NWV waves
