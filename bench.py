@@ -368,6 +368,29 @@ def main():
                         "(decode stage time / new tokens)"},
     }
 
+    # ---- the same batch with the token steps streaming the e4m3 copy of the cross K / V (BASELINE configs[4] direction) ----
+    if not args.no_extras and args.dtype == "bf16" and rank == 0:
+        def fp8_step():
+            eng._enter()
+            with torch.cuda.stream(eng.stream):
+                kv_ = eng.cross_kv(eng.encode_mel(eng.mel(audio)))
+                kv8 = eng.cross_kv_fp8(kv_)
+                t_, _, _ = eng.decode(kv_, prompt, None, eos_table, sp, poll_every=64, kv_fp8=kv8)
+            eng._leave()
+            return t_
+        fp8_step()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            t8 = fp8_step()
+        torch.cuda.synchronize(dev)
+        dt8 = (time.perf_counter() - t0) / args.steps
+        aux["fp8_cross_kv"] = {"tokens_per_s": round(int((t8[:, 1:] != 0).sum().item()) / dt8, 1), "ms_per_step": round(dt8 * 1e3, 2),
+                               "note": "same workload, the token steps stream an OCP e4m3 copy of the cross-attention K / V (one "
+                                       "scale per layer, k|v, row, head; quantisation pass inside the timed step); NOT the parity "
+                                       "mode and not `value`",
+                               "same_tokens_as_bf16_kv": round(float((t8 == tokens).float().mean().item()), 4)}
+
     # ---- configs[0] on the GPU, and the end-to-end rate through the reference-shaped boundary ---------------------
     if not args.no_extras:
         e2e_audio = audio_host                                                       # HOST tensors, as server.py:86 receives them

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MH_ABI_VERSION 3
+#define MH_ABI_VERSION 4
 #define MH_MAX_LAYERS 32
 
 typedef enum MhStatus {
@@ -270,9 +270,22 @@ typedef struct MhSampling {
                                processor.py:308-368): used when rows of different songs / shards share a batch */
   unsigned rng_row0;        /* do_sample: global index of this call's first returned row in the RNG key
                                (seed, row, column), so shards of one job do not replay each other's draws  */
+  /* --- ABI 4 ------------------------------------------------------------------------------------ */
+  const void* cross_kv_fp8; /* NULL: the token steps stream `cross_kv` (cfg.dtype).  Non-NULL (bf16 storage only): the
+                               packed OCP e4m3 copy written by mh_t5_quantize_cross_kv -- the token steps stream THAT
+                               (half the HBM bytes of the dominant kernel; BASELINE configs[4]); the prompt prefill
+                               still reads `cross_kv`.  Not a parity mode: K / V carry 3 mantissa bits.          */
 } MhSampling;
 
 int64_t mh_t5_decode_workspace_bytes(const MhT5Config* cfg, int B);
+
+/* fp8 form of the cross-attention K/V (no reference counterpart; BASELINE configs[4] "fp8 ... KV-cached decode").
+ * cross_kv  [n_dec][2][B][H][L][64] bf16 from mh_t5_cross_kv;
+ * out       mh_t5_cross_kv_fp8_bytes(cfg, B) bytes: the same layout in OCP e4m3, one byte per element, followed (256-
+ *           byte aligned) by fp32 scales [n_dec][2][B][H]: x ~ e4m3 * scale, scale = absmax of the (layer, k|v, row,
+ *           head) slab / 448. */
+int64_t mh_t5_cross_kv_fp8_bytes(const MhT5Config* cfg, int B);
+int mh_t5_quantize_cross_kv(const MhT5Config* cfg, const void* cross_kv, int B, void* out, void* stream);
 
 /* Runs prefill over the (left-padded) prompt and the AR loop until every row has emitted an id of
  * the EOS set or max_length is reached.

@@ -57,7 +57,8 @@ class MhSampling(C.Structure):
                 ("max_length", C.c_int), ("seed", C.c_uint64),
                 ("cfg_scale", C.c_float), ("n_cond", C.c_int), ("cond_temp", C.c_float * 3),
                 ("cond_offset", C.c_int * 3), ("lookback_types_first", C.c_int), ("tok_flags", VP),
-                ("cond_per_row", C.c_int), ("rng_row0", C.c_uint)]
+                ("cond_per_row", C.c_int), ("rng_row0", C.c_uint),
+                ("cross_kv_fp8", C.c_void_p)]
 
 
 class MhDiTConfig(C.Structure):
@@ -77,7 +78,7 @@ class MhDiTWeights(C.Structure):
                 ("first_w3", VP), ("qkv_w3", _PTR_ARR), ("out_w3", _PTR_ARR), ("fc1_w3", _PTR_ARR), ("fc2_w3", _PTR_ARR)]
 
 
-ABI_VERSION = 3   # MH_ABI_VERSION of include/mapperhip.h
+ABI_VERSION = 4   # MH_ABI_VERSION of include/mapperhip.h
 
 # every symbol include/mapperhip.h declares: (name, restype, argtypes)
 I, I64, F = C.c_int, C.c_int64, C.c_float
@@ -97,6 +98,8 @@ SYMBOLS = {
     "mh_t5_encode": (I, [C.POINTER(MhT5Config), C.POINTER(MhT5Weights), VP, I, VP, VP, VP, I64, VP]),
     "mh_t5_cross_kv": (I, [C.POINTER(MhT5Config), C.POINTER(MhT5Weights), VP, I, VP, VP]),
     "mh_t5_decode_workspace_bytes": (I64, [C.POINTER(MhT5Config), I]),
+    "mh_t5_cross_kv_fp8_bytes": (I64, [C.POINTER(MhT5Config), I]),
+    "mh_t5_quantize_cross_kv": (I, [C.POINTER(MhT5Config), VP, I, VP, VP]),
     "mh_t5_generate": (I, [C.POINTER(MhT5Config), C.POINTER(MhT5Weights), VP, I, VP, VP, I, VP,
                            C.POINTER(MhSampling), VP, VP, VP, VP, VP, I64, I, VP]),
     "mh_t5_forward_workspace_bytes": (I64, [C.POINTER(MhT5Config), I, I]),

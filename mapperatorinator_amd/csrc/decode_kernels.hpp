@@ -74,6 +74,19 @@ template <> __device__ inline void load8_stream<float>(const float* p, float (&o
 #pragma unroll
   for (int i = 0; i < 4; ++i) { o[i] = __uint_as_float(a[i]); o[4 + i] = __uint_as_float(b[i]); }
 }
+// OCP e4m3 rows (the fp8 copy of the cross-attention K / V): 8 elements = 8 bytes per lane
+struct fp8_t { uint8_t v; };
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+template <> __device__ inline void load8_stream<fp8_t>(const fp8_t* p, float (&o)[8]) {
+  const u32x2_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(p));
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const f32x2_t lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)v[i], false);
+    const f32x2_t hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)v[i], true);
+    o[4 * i] = lo[0]; o[4 * i + 1] = lo[1]; o[4 * i + 2] = hi[0]; o[4 * i + 3] = hi[1];
+  }
+}
 template <typename T> __device__ inline void store8(T* p, const float (&o)[8]);
 template <> __device__ inline void store8<bf16_t>(bf16_t* p, const float (&o)[8]) {
   uint32_t w[4];
@@ -506,8 +519,8 @@ __device__ inline void partial_merge_groups(Partial& s) {  // across the 8 key g
   s.m = mw;
 }
 
-template <typename T, int U>
-__device__ inline void attend_keys(Partial& st, const float (&q)[8], const T* kbase, const T* vbase, int j0,
+template <typename T, int U, typename E = T>
+__device__ inline void attend_keys(Partial& st, const float (&q)[8], const E* kbase, const E* vbase, int j0,
                                    int jend, int jstride, const float* bias_row, int pos, const uint8_t* mask_row,
                                    int P, float scale) {
   // processes keys j0, j0+jstride, ... < jend for this lane's key group, U at a time
@@ -519,14 +532,14 @@ __device__ inline void attend_keys(Partial& st, const float (&q)[8], const T* kb
     for (int u = 0; u < U; ++u) {
       const int jj = j + u * jstride;
       const int jc = jj < jend ? jj : j;
-      load8_stream<T>(kbase + (long)jc * 64 + c8, kv[u]);
+      load8_stream<E>(kbase + (long)jc * 64 + c8, kv[u]);
     }
     float vv[U][8];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int jj = j + u * jstride;
       const int jc = jj < jend ? jj : j;
-      load8_stream<T>(vbase + (long)jc * 64 + c8, vv[u]);
+      load8_stream<E>(vbase + (long)jc * 64 + c8, vv[u]);
     }
     // bias / mask values: wave-uniform branch on the pointers, unconditional loads from clamped indices
     float bv[U];
@@ -646,6 +659,7 @@ struct CrossAttnP {
   void* out; int ldo;       // T [B, inner]
   int B, H, L;
   int kv_B;                 // > 0: row b reads K/V row b % kv_B (CFG pairs share the encoder output)
+  const float* kscale; const float* vscale;   // fp8 rows (kernel template F8): this layer's [kv rows][H] scales, else NULL
   // measurement only (mh_t5_decode_timing): [slots][2] = (earliest workgroup start, latest workgroup end) of THIS
   // launch in wall-clock ticks, slot = *pos * ts_layers + ts_layer for the first ts_ring positions; NULL in production
   unsigned long long* tstamp; const int* pos; int ts_ring, ts_layers, ts_layer;
@@ -777,7 +791,8 @@ struct HeadProj {
 
 // cross-attention of one (b, h) with its own query projection; 16 waves, one key split (the default configuration
 // of dec_cross_attn_kernel, same key interleave and merge order)
-template <typename T, int KC, int U>
+// F8: K / V are the e4m3 copy (64-byte rows, 8 bytes per lane; the scales multiply the scores and the output)
+template <typename T, int KC, int U, bool F8 = false>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8)))   // <= 64 VGPRs: 2 workgroups per CU
 void dec_cross_attn_q_kernel(CrossAttnP p, HeadProjP hp) {
   constexpr int NW = 16;
@@ -807,18 +822,20 @@ void dec_cross_attn_q_kernel(CrossAttnP p, HeadProjP hp) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) q[i] = qs[0][c8 + i];
   const int kvb = p.kv_B > 0 ? b % p.kv_B : b;
-  const T* kb = reinterpret_cast<const T*>(p.k) + ((long)kvb * p.H + h) * p.L * 64;
-  const T* vb = reinterpret_cast<const T*>(p.v) + ((long)kvb * p.H + h) * p.L * 64;
+  typedef typename std::conditional<F8, fp8_t, T>::type E;
+  const E* kb = reinterpret_cast<const E*>(p.k) + ((long)kvb * p.H + h) * p.L * 64;
+  const E* vb = reinterpret_cast<const E*>(p.v) + ((long)kvb * p.H + h) * p.L * 64;
+  const float ks = F8 ? p.kscale[kvb * p.H + h] : 1.0f, vs = F8 ? p.vscale[kvb * p.H + h] : 1.0f;
   Partial st;
   partial_init(st);
-  attend_keys<T, U>(st, q, kb, vb, wid * 8 + g, p.L, 8 * NW, nullptr, 0, nullptr, 0, 1.0f);
+  attend_keys<T, U, E>(st, q, kb, vb, wid * 8 + g, p.L, 8 * NW, nullptr, 0, nullptr, 0, ks);
   MH_STAMP(KID_CROSS, 2);   // keys streamed (this wave)
   partial_merge_groups<T>(st);
   float m, l, a;
   block_merge<T, NW>(st, sm, m, l, a);
   MH_STAMP(KID_CROSS, 3);   // partials merged
   if (threadIdx.x < 64)
-    store_wt(reinterpret_cast<T*>(p.out) + (long)b * p.ldo + h * 64 + threadIdx.x, Elem<T>::from_f32(l > 0.f ? a / l : 0.f));
+    store_wt(reinterpret_cast<T*>(p.out) + (long)b * p.ldo + h * 64 + threadIdx.x, Elem<T>::from_f32(l > 0.f ? a / l * vs : 0.f));
   if (p.tstamp && threadIdx.x == 0 && *p.pos < p.ts_ring) {      // the first ts_ring positions of the call, one slot each
     unsigned long long* slot = p.tstamp + 2 * ((long)(*p.pos) * p.ts_layers + p.ts_layer);
     atomicMin(slot, t_start);

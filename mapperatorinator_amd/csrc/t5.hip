@@ -555,7 +555,13 @@ template <typename T, int KC>
 int launch_cross_q(const dec::CrossAttnP& ca, const dec::HeadProjP& hp, hipStream_t s) {
   // one key in flight per 8-lane group: 64 VGPRs without spills (two 16-wave workgroups per CU); U = 2 measured the
   // same bandwidth in the stand-alone kernel
-  hipLaunchKernelGGL((dec::dec_cross_attn_q_kernel<T, KC, 1>), dim3(ca.B * ca.H), dim3(1024), 0, s, ca, hp);
+  if (ca.kscale != nullptr) {
+    if constexpr (sizeof(T) == 2)
+      hipLaunchKernelGGL((dec::dec_cross_attn_q_kernel<T, KC, 1, true>), dim3(ca.B * ca.H), dim3(1024), 0, s, ca, hp);
+    else { set_error("decode: the fp8 cross K/V copy needs bf16 storage"); return MH_ERR_ARG; }
+  } else {
+    hipLaunchKernelGGL((dec::dec_cross_attn_q_kernel<T, KC, 1>), dim3(ca.B * ca.H), dim3(1024), 0, s, ca, hp);
+  }
   return check_launch("dec_cross_attn_q_kernel");
 }
 template <typename T>
@@ -578,7 +584,9 @@ DecodeTiming g_timing;
 
 template <typename T>
 int enqueue_step(const MhT5Config* c, const MhT5Weights* w, const void* cross_kv, int B, int Bfull, int kvB,
-                 const uint8_t* prompt_mask, int P, const DecBuffers& bf, const SampleP& smp, hipStream_t s) {
+                 const uint8_t* prompt_mask, int P, const DecBuffers& bf, const SampleP& smp, hipStream_t s,
+                 const void* kv8 = nullptr, const float* kv8_scales = nullptr) {
+  // kv8 / kv8_scales: the chain's first row of the e4m3 copy of cross_kv and of its scales (mh_t5_quantize_cross_kv)
   // B rows of one chain; every pointer in `bf` / `cross_kv` / `prompt_mask` already points at the chain's first
   // row, only the per-layer strides of the caches use the full batch size.  kvB = rows of cross_kv (B/2 under CFG:
   // a pair shares its encoder output, row b reads K/V row b % kvB).
@@ -617,6 +625,12 @@ int enqueue_step(const MhT5Config* c, const MhT5Weights* w, const void* cross_kv
     ca.q = bf.q; ca.ldq = inner; ca.k = (const char*)cross_kv + (long)(l * 2 + 0) * kv_layer;
     ca.v = (const char*)cross_kv + (long)(l * 2 + 1) * kv_layer; ca.out = bf.attn; ca.ldo = inner;
     ca.B = B; ca.H = H; ca.L = L; ca.kv_B = kvB < Bfull ? kvB : 0;
+    if (kv8) {
+      MH_REQUIRE(fused, "decode: the fp8 cross K/V copy needs decode_fused_proj = 1 and d_model a multiple of 128 <= 1024");
+      const long slab = (long)kvB * H * L * 64;
+      ca.k = (const char*)kv8 + (long)(l * 2 + 0) * slab; ca.v = (const char*)kv8 + (long)(l * 2 + 1) * slab;
+      ca.kscale = kv8_scales + (long)(l * 2 + 0) * kvB * H; ca.vscale = kv8_scales + (long)(l * 2 + 1) * kvB * H;
+    }
     if (g_timing.buf) {   // one region of ring x layers slots per chain (chain index = first row / rows of a full chain)
       ca.tstamp = g_timing.buf + 2L * bf.chain * g_timing.ring * c->n_dec_layers;
       ca.pos = posp; ca.ts_ring = g_timing.ring; ca.ts_layers = c->n_dec_layers; ca.ts_layer = l;
@@ -861,6 +875,63 @@ DevicePool* device_pool(int dev) {
 }  // namespace
 }  // namespace mh
 
+// ---- e4m3 copy of the cross-attention K / V -------------------------------------------------------------------------
+// one workgroup per (layer, k|v, row, head) slab of L x 64 bf16: absolute maximum, then x / scale -> OCP e4m3
+__global__ __launch_bounds__(256) void kv_quant_fp8_kernel(const bf16_t* src, uint8_t* dst, float* scales, int L) {
+  __shared__ float red[4];
+  const long slab = (long)blockIdx.x * L * 64;
+  const uint4* s16 = reinterpret_cast<const uint4*>(src + slab);
+  const int n16 = L * 8;   // 16-byte vectors (8 elements) in the slab
+  float mx = 0.f;
+  for (int i = threadIdx.x; i < n16; i += 256) {
+    const uint4 v = s16[i];
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      mx = fmaxf(mx, fabsf(__uint_as_float(w[j] << 16)));
+      mx = fmaxf(mx, fabsf(__uint_as_float(w[j] & 0xffff0000u)));
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  const float scale = mx > 0.f ? mx / 448.0f : 1.0f;   // 448 = largest finite e4m3 value
+  const float inv = 1.0f / scale;
+  if (threadIdx.x == 0) scales[blockIdx.x] = scale;
+  uint2* d8 = reinterpret_cast<uint2*>(dst + slab);
+  for (int i = threadIdx.x; i < n16; i += 256) {
+    const uint4 v = s16[i];
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    float f[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { f[2 * j] = __uint_as_float(w[j] << 16) * inv; f[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u) * inv; }
+    int o0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], 0, false);
+    o0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], o0, true);
+    int o1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], 0, false);
+    o1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], o1, true);
+    d8[i] = make_uint2((uint32_t)o0, (uint32_t)o1);
+  }
+}
+
+extern "C" int64_t mh_t5_cross_kv_fp8_bytes(const MhT5Config* c, int B) {
+  if (!c || B <= 0) return -1;
+  const int64_t data = (int64_t)c->n_dec_layers * 2 * B * c->n_heads * c->src_len * 64;
+  return align256(data) + align256((int64_t)c->n_dec_layers * 2 * B * c->n_heads * 4);
+}
+
+extern "C" int mh_t5_quantize_cross_kv(const MhT5Config* c, const void* cross_kv, int B, void* out, void* stream) {
+  MH_TRY(check_cfg(c, "mh_t5_quantize_cross_kv"));
+  MH_REQUIRE(cross_kv && out && B > 0, "mh_t5_quantize_cross_kv: null argument");
+  MH_REQUIRE(c->dtype == MH_BF16, "mh_t5_quantize_cross_kv: needs bf16 storage");
+  const int64_t data = (int64_t)c->n_dec_layers * 2 * B * c->n_heads * c->src_len * 64;
+  const int slabs = c->n_dec_layers * 2 * B * c->n_heads;
+  hipLaunchKernelGGL(kv_quant_fp8_kernel, dim3(slabs), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)cross_kv,
+                     (uint8_t*)out, reinterpret_cast<float*>((char*)out + align256(data)), c->src_len);
+  return check_launch("kv_quant_fp8_kernel");
+}
+
 extern "C" int mh_t5_generate(const MhT5Config* c, const MhT5Weights* w, const void* cross_kv, int B,
                               const int32_t* prompt, const uint8_t* prompt_mask, int P, const uint8_t* eos_table,
                               const MhSampling* sp, int32_t* tokens, int32_t* n_steps_out, float* logits_dump,
@@ -883,6 +954,7 @@ extern "C" int mh_t5_generate(const MhT5Config* c, const MhT5Weights* w, const v
   MH_REQUIRE(sp->tok_flags || (sp->n_cond == 0 && !sp->lookback_types_first),
              "mh_t5_generate: tok_flags is required by the conditional temperature / types_first lookback processors");
   const int kvB = cfg ? B / 2 : B;
+  MH_REQUIRE(!sp->cross_kv_fp8 || c->dtype == MH_BF16, "mh_t5_generate: cross_kv_fp8 needs bf16 storage");
   MH_REQUIRE(workspace_bytes >= mh_t5_decode_workspace_bytes(c, B), "mh_t5_generate: workspace too small");
   hipStream_t s = (hipStream_t)stream;
   const int es = es_of(c->dtype), H = c->n_heads, inner = H * 64, d = c->d_model, V = c->vocab_out;
@@ -980,8 +1052,15 @@ extern "C" int mh_t5_generate(const MhT5Config* c, const MhT5Weights* w, const v
     if (rc != MH_OK) break;
     // capture one step of this chain (every kernel reads the position from device memory) for replay
     if (hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) != hipSuccess) { rc = check_launch("begin capture"); break; }
-    int rce = bf16 ? enqueue_step<bf16_t>(c, w, ckv, Bc, B, kvB, pm, P, bf, smp, cs)
-                   : enqueue_step<float>(c, w, ckv, Bc, B, kvB, pm, P, bf, smp, cs);
+    const void* kv8 = nullptr;
+    const float* kv8_scales = nullptr;
+    if (sp->cross_kv_fp8) {   // packed e4m3 copy: data, then (256-byte aligned) the scales
+      const int64_t data_bytes = (int64_t)c->n_dec_layers * 2 * kvB * H * c->src_len * 64;
+      kv8 = (const char*)sp->cross_kv_fp8 + (long)b0 * H * c->src_len * 64;
+      kv8_scales = reinterpret_cast<const float*>((const char*)sp->cross_kv_fp8 + align256(data_bytes)) + (long)b0 * H;
+    }
+    int rce = bf16 ? enqueue_step<bf16_t>(c, w, ckv, Bc, B, kvB, pm, P, bf, smp, cs, kv8, kv8_scales)
+                   : enqueue_step<float>(c, w, ckv, Bc, B, kvB, pm, P, bf, smp, cs, kv8, kv8_scales);
     hipError_t ce = hipStreamEndCapture(cs, &graphs[ci]);
     ++used;
     if (rce != MH_OK) { rc = rce; break; }

@@ -295,7 +295,8 @@ def model_generate(model, tokenizer, model_kwargs, generate_kwargs):
         neg = neg_mask = None
 
     start = time.perf_counter()
-    out = model.engine.generate(audio, prompt, mask, eos, sp, negative_prompt=neg, negative_mask=neg_mask)
+    out = model.engine.generate(audio, prompt, mask, eos, sp, negative_prompt=neg, negative_mask=neg_mask,
+                                cross_kv_fp8=bool(generate_kwargs.get("cross_kv_fp8", False)))
     elapsed = time.perf_counter() - start
     result = out["tokens"]
     stats = _build_generation_stats(result, model_kwargs, pad_token_id, elapsed)

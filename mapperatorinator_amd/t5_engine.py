@@ -233,6 +233,19 @@ class T5Engine:
         _lib.check(rc, "mh_t5_cross_kv")
         return kv
 
+    def cross_kv_fp8(self, kv: torch.Tensor) -> torch.Tensor:
+        """The packed OCP e4m3 copy of `cross_kv(enc)` (one byte per element + one fp32 scale per (layer, k|v, row,
+        head)) that the token steps stream when `MhSampling.cross_kv_fp8` points at it: half the HBM bytes of the
+        dominant decode kernel (BASELINE configs[4]).  bf16 storage only; not a parity mode."""
+        if self.dtype != torch.bfloat16:
+            raise ValueError("the fp8 cross K/V copy needs bf16 storage")
+        p = self.packed
+        B = kv.shape[2]
+        out = torch.empty(self.lib.mh_t5_cross_kv_fp8_bytes(C.byref(p.cfg), B), dtype=torch.uint8, device=self.device)
+        rc = self.lib.mh_t5_quantize_cross_kv(C.byref(p.cfg), kv.data_ptr(), B, out.data_ptr(), self._s())
+        _lib.check(rc, "mh_t5_quantize_cross_kv")
+        return out
+
     def encode(self, audio: torch.Tensor, want_f32: bool = False):
         """audio (B, Ns) on the GPU -> encoder last_hidden_state (final RMSNorm applied)."""
         self._enter()
@@ -257,7 +270,7 @@ class T5Engine:
 
     def decode(self, cross_kv: torch.Tensor, prompt: torch.Tensor, prompt_mask: Optional[torch.Tensor],
                eos_table: torch.Tensor, sampling: _lib.MhSampling, forced: Optional[torch.Tensor] = None,
-               dump_logits: bool = False, poll_every: int = 16):
+               dump_logits: bool = False, poll_every: int = 16, kv_fp8: Optional[torch.Tensor] = None):
         """prompt int32 (B, P) on device.  Returns (tokens int32 (B, max_length) device, n_cols int, logits|None).
         Under CFG (sampling.cfg_scale > 1) the B rows are [negative-prompt rows | prompt rows], `cross_kv` holds
         B/2 rows and the logits dump has B/2 rows (the guided scores)."""
@@ -272,6 +285,7 @@ class T5Engine:
             sampling.tok_flags = flags_d.data_ptr()
         elif sampling.n_cond or sampling.lookback_types_first:
             raise ValueError("sampling needs tok_flags (build it with server.build_sampling)")
+        sampling.cross_kv_fp8 = kv_fp8.data_ptr() if kv_fp8 is not None else None
         need = self.lib.mh_t5_decode_workspace_bytes(C.byref(p.cfg), B)
         ws = self._workspace("dec", need)
         maxlen = sampling.max_length
@@ -289,8 +303,9 @@ class T5Engine:
     def generate(self, audio: torch.Tensor, prompt: torch.Tensor, prompt_mask: Optional[torch.Tensor],
                  eos_ids, sampling: _lib.MhSampling, forced: Optional[torch.Tensor] = None,
                  dump_logits: bool = False, poll_every: int = 16, negative_prompt: Optional[torch.Tensor] = None,
-                 negative_mask: Optional[torch.Tensor] = None):
-        """Full hot path for one batch of chunks.  Inputs may be CPU tensors (copied like
+                 negative_mask: Optional[torch.Tensor] = None, cross_kv_fp8: bool = False):
+        """Full hot path for one batch of chunks.  `cross_kv_fp8`: the token steps stream the e4m3 copy of the
+        cross-attention K / V (see `cross_kv_fp8()`).  Inputs may be CPU tensors (copied like
         server.py:86-87 does).  Returns dict(tokens=int64 CPU (B, n_cols), logits=..., n_cols=int).
         With `negative_prompt` (classifier-free guidance) the decode batch is doubled the way the reference's
         prepare_inputs_for_generation does it (modeling_mapperatorinator.py:243-254): the first half carries the
@@ -326,8 +341,9 @@ class T5Engine:
         with torch.cuda.stream(self.stream):
             enc = self.encode_mel(self.mel(audio))
             kv = self.cross_kv(enc)
+            kv8 = self.cross_kv_fp8(kv) if cross_kv_fp8 else None
             tokens, n_out, logits = self.decode(kv, prompt_d, mask_d, eos_table, sampling, forced_d, dump_logits,
-                                                poll_every)
+                                                poll_every, kv_fp8=kv8)
         self._leave()
         torch.cuda.current_stream(dev).synchronize()
         n_cols = int(n_out.item()) if forced is None else sampling.max_length

@@ -137,6 +137,50 @@ def test_bf16_teacher_forced_on_the_reference_bf16_run():
     assert rate_all >= 0.90
 
 
+def test_fp8_cross_kv_teacher_forced_vs_oracle_with_quantised_kv():
+    """The e4m3 copy of the cross-attention K / V (mh_t5_quantize_cross_kv, MhSampling.cross_kv_fp8; BASELINE
+    configs[4]) against the bf16-contract oracle whose cross K / V went through the same quantisation (absmax / 448 per
+    (layer, k|v, row, head), torch.float8_e4m3fn): teacher-forced on the t5_base golden ids with a 1-token prompt so that
+    every position is a token step.  Gate: the bf16 noise floor of the headline test (mean < 0.06, worst < 0.5); the
+    distance to the un-quantised bf16 run is printed (what the mode costs)."""
+    from mapperatorinator_amd.server import build_sampling
+    g, size, tok, sd, audio, src, tgt = golden_case("t5_base")
+    B = audio.shape[0]
+    ids = torch.from_numpy(g["ids"]).long()
+    T = ids.shape[1]
+    ids = ids.clone()
+    ids[:, 0] = tok.sos_id                                   # a 1-token prompt: column 0 only
+    prompt = ids[:, :1].clone()
+    forced = torch.zeros((B, tgt), dtype=torch.long)
+    forced[:, :T] = ids
+    model = build(size, tok, sd, src, tgt, torch.bfloat16)
+    sp, _ = build_sampling(tok, gen_kwargs(tgt), tgt)
+    lg8 = model.engine.generate(audio, prompt, None, [], sp, forced=forced, dump_logits=True, cross_kv_fp8=True)["logits"].float().cpu()
+    sp, _ = build_sampling(tok, gen_kwargs(tgt), tgt)
+    lg16 = model.engine.generate(audio, prompt, None, [], sp, forced=forced, dump_logits=True)["logits"].float().cpu()
+    o = oracle_for(size, sd, rounding="bf16")
+    ckv = o.cross_kv(o.encode_audio(audio))
+
+    def qdq(x):                                              # (B, H, L, 64): per (row, head) scale
+        scale = x.abs().amax(dim=(2, 3), keepdim=True) / 448.0
+        scale = torch.where(scale > 0, scale, torch.ones_like(scale))
+        return (x / scale).to(torch.float8_e4m3fn).float() * scale
+    ckv8 = [(qdq(k), qdq(v)) for k, v in ckv]
+    ts0, ts1 = ts_range(tok)
+    want = o.monotonic_scores(o.decoder_forward(ids[:, :-1], ckv8), ids[:, :-1], ts0, ts1, [tok.sos_id])   # (B, T-1, V)
+    hip8, hip16 = lg8[1:T].transpose(0, 1), lg16[1:T].transpose(0, 1)
+    fin = torch.isfinite(want)
+    assert torch.equal(fin, torch.isfinite(hip8))
+    d8 = (hip8[fin] - want[fin]).abs()
+    dmode = (hip8[fin] - hip16[fin]).abs()
+    agree = (hip8.argmax(-1) == hip16.argmax(-1)).float().mean().item()
+    print(f"fp8 cross K/V vs the oracle with quantised K/V: |dlogit| mean {d8.mean():.4f} worst {d8.max():.3f}; vs the bf16 "
+          f"K/V run of the same kernels: mean {dmode.mean():.4f} worst {dmode.max():.3f}, same top-1 on {agree:.3f} of the steps")
+    assert d8.mean().item() < 0.06 and d8.max().item() < 0.5
+    assert dmode.max().item() > 0          # the mode is really on
+    assert agree > 0.9
+
+
 def test_bf16_headline_batch_teacher_forced_vs_oracle():
     """BASELINE configs[1] at its own size: osuT5-base, bf16, B = 32 chunks x 384 new tokens.  The free-running HIP ids
     are fed back teacher-forced to the bf16-contract CPU oracle: every step the oracle decides by more than GAP_BF16
