@@ -40,6 +40,7 @@ static OptionSlot g_options[OPT_COUNT] = {
     {"attn_small_max_wgs", "MH_ATTN_SMALL_MAX_WGS", 1024, false}, // fp32 attention at L <= 256: key-split latency kernel up to this many workgroups, flash kernel beyond
     {"dit_split3_min_rows", "MH_DIT_SPLIT3_MIN_ROWS", 2048, false},   // DiT denoiser batches of >= this many rows (N*T) run their big GEMMs as bf16 x 3 (0 = never)
     {"decode_self_rows", "MH_DECODE_SELF_ROWS", 1, false},       // rows of one head per self-attention workgroup (1, 2, 4): they share the head's q / k / v weight slice
+    {"gemm_glds", "MH_GEMM_GLDS", 1, false},                     // bf16 128x128 GEMM tiles: operands by LDS-DMA (global_load_lds) instead of register staging
 };
 
 long option(int id) {

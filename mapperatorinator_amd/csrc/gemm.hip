@@ -103,12 +103,19 @@ __device__ inline void epilogue_store(const GemmP& p, int row, int col, float v,
 // relative error of ~2^-16 per product, fp32 accumulation).  Three v_mfma_f32_16x16x32_bf16 replace eight exact
 // v_mfma_f32_16x16x4_f32: 1/5 of the matrix-core time at the SAME operand bytes (weights are stored pre-split, 128 B per
 // 32-float block either way; activations stay fp32 in HBM and are split while they are staged into LDS).
-template <typename T, int BM, int BN, int EPI, bool S3 = false>
+// GL ("global_load_lds"): bf16, 128 x 128 tile, no operand transform -- the encoder GEMMs.  Both operand tiles go from
+// HBM / L2 straight into LDS (`global_load_lds_dwordx4`: no staging registers, no ds_write pass); an LDS-DMA writes
+// wave-uniform base + lane * 16, so the stage is lane-linear (128-byte rows, no padding) and the bank-conflict-free
+// layout comes from the SOURCE side: LDS chunk c of row r holds global chunk c ^ (r & 7) (still one whole line per row).
+__device__ __attribute__((aligned(16))) uint4 g_zero16 = {0, 0, 0, 0};   // source of K-tail chunks
+
+template <typename T, int BM, int BN, int EPI, bool S3 = false, bool GL = false>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmP p) {
   static_assert(!S3 || (std::is_same<T, float>::value && BM == 64 && BN == 64), "split-3 path: fp32, 64x64 tile");
+  static_assert(!GL || (sizeof(T) == 2 && BM == 128 && BN == 128 && !S3), "LDS-DMA path: bf16, 128x128 tile");
   constexpr int VEC = Elem<T>::kVec;          // elements per 16 B
   constexpr int kRowBytes = RowBytes<BM>::v;
-  constexpr int kRowStride = kRowBytes + 16;  // padded LDS row stride in bytes
+  constexpr int kRowStride = GL ? kRowBytes : kRowBytes + 16;  // LDS row stride in bytes (padded unless lane-linear)
   constexpr int CPR = kRowBytes / 16;         // 16-byte chunks per tile row
   constexpr int RPP = 256 / CPR;              // tile rows covered by one pass of the 256 threads
   constexpr int BK = kRowBytes / (int)sizeof(T);
@@ -236,9 +243,33 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmP p) {
 #pragma unroll
     for (int j = 0; j < NI; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
+  // GL: K tile kt of both operands -> LDS stage `buf`: 4 + 4 wave instructions of 8 rows x 128 bytes each
+  auto glds_tiles = [&](int buf, int kt) {
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const int r8 = lane >> 3;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = (i * 4 + wid) * 8 + r8;                  // tile row of this lane
+      const int k_el = kt * BK + (((lane & 7) ^ (r & 7)) * VEC);   // pre-swizzled source chunk (r & 7 == r8)
+      const bool kin = k_el < p.K;
+      int ra_ = m0 + r; ra_ = ra_ < p.M ? ra_ : p.M - 1;
+      int rb_ = n0 + r; rb_ = rb_ < p.N ? rb_ : p.N - 1;
+      const char* sa = kin ? p.A + (long)ra_ * p.lda_b + (long)k_el * sizeof(T) : reinterpret_cast<const char*>(&g_zero16);
+      const char* sb = kin ? p.W + (long)rb_ * p.ldw_b + (long)k_el * sizeof(T) : reinterpret_cast<const char*>(&g_zero16);
+      char* da = smem + buf * kBufBytes + (i * 4 + wid) * 1024;          // wave-uniform
+      char* db = da + BM * kRowStride;
+      __builtin_amdgcn_global_load_lds((gptr_t)sa, (lptr_t)da, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)sb, (lptr_t)db, 16, 0, 0);
+    }
+  };
+  if constexpr (GL) {
+    glds_tiles(0, 0);
+  } else {
 #pragma unroll
   for (int d = 0; d < D; ++d)
     if (d < nk) load_tiles(d, ra[d], rb[d], rsc[d], rsh[d]);
+  }
   // (the LayerNorm statistics below are requested after the first operand tiles: one round trip covers both)
   // small tile: the epilogue's old C / gate values do not depend on the product either -- requested here, not after it
   constexpr bool kReadsC = (EPI == MH_EPI_RESID || EPI == MH_EPI_GATE_RESID);
@@ -298,10 +329,38 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmP p) {
     }
     __syncthreads();
   }
-  store_tiles(0, 0, ra[0], rb[0], rsc[0], rsh[0]);
+  if constexpr (GL) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
+    store_tiles(0, 0, ra[0], rb[0], rsc[0], rsh[0]);
+  }
   __syncthreads();
 
   const int frow = lane & 15, fk = (lane >> 4) * KCH;
+  if constexpr (GL) {
+    const int sw = frow & 7, lgc = lane >> 4;
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      if (kt + 1 < nk) glds_tiles(cur ^ 1, kt + 1);   // the stage read two iterations ago (barrier below) is free
+      const char* a_row = smem + cur * kBufBytes + (wr * WM + frow) * kRowStride;
+      const char* b_row = smem + cur * kBufBytes + (BM + wc * WN + frow) * kRowStride;
+#pragma unroll
+      for (int ks = 0; ks < BK / KM; ++ks) {
+        const int coff = ((ks * 4 + lgc) ^ sw) * 16;
+        typename Atom<T>::frag_t af[MI], bf[NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) af[i] = Atom<T>::load(reinterpret_cast<const T*>(a_row + i * 16 * kRowStride + coff));
+#pragma unroll
+        for (int j = 0; j < NI; ++j) bf[j] = Atom<T>::load(reinterpret_cast<const T*>(b_row + j * 16 * kRowStride + coff));
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j) acc[i][j] = Atom<T>::mma(af[i], bf[j], acc[i][j]);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA of the next stage has landed
+      __syncthreads();
+    }
+  } else
   for (int kt0 = 0; kt0 < nk; kt0 += D) {
 #pragma unroll
     for (int d = 0; d < D; ++d) {
@@ -456,11 +515,11 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmP p) {
   }
 }
 
-template <typename T, int BM, int BN, int EPI, bool S3 = false>
+template <typename T, int BM, int BN, int EPI, bool S3 = false, bool GL = false>
 int launch_gemm(const GemmP& p, hipStream_t s) {
   const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
   const size_t smem = 2 * (size_t)(BM + BN) * (RowBytes<BM>::v + 16) + BM * 8 + 2048;   // + LayerNorm statistics
-  hipLaunchKernelGGL((gemm_tn_kernel<T, BM, BN, EPI, S3>), dim3(nbm * nbn), dim3(256), smem, s, p);
+  hipLaunchKernelGGL((gemm_tn_kernel<T, BM, BN, EPI, S3, GL>), dim3(nbm * nbn), dim3(256), smem, s, p);
   return check_launch("gemm_tn_kernel");
 }
 
@@ -469,8 +528,12 @@ int launch_gemm(const GemmP& p, hipStream_t s) {
 template <typename T, int BM, int BN, int EPI>
 bool prepare_one() {
   const size_t smem = 2 * (size_t)(BM + BN) * (RowBytes<BM>::v + 16) + BM * 8 + 2048;   // + LayerNorm statistics
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel<T, BM, BN, EPI>),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) == hipSuccess;
+  bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel<T, BM, BN, EPI>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) == hipSuccess;
+  if constexpr (sizeof(T) == 2 && BM == 128 && BN == 128)
+    ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel<T, BM, BN, EPI, false, true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) == hipSuccess;
+  return ok;
 }
 template <typename T, int EPI>
 bool prepare_epi() {
@@ -502,7 +565,12 @@ int dispatch_tile(const GemmP& p, hipStream_t s) {
   // exact-fp32 MFMA is 16x slower than bf16: an fp32 GEMM is compute-bound long before the big tile pays (measured on
   // the batched DiT, M = 8192: 64x64 tiles 667 ms vs 128x128 827 ms per 100 steps) -> 8x the bf16 threshold
   const long min128 = option(OPT_GEMM_TILE128_MIN) * (std::is_same<T, float>::value ? 8 : 1);
-  if (tiles128 >= min128) return launch_gemm<T, 128, 128, EPI>(p, s);
+  if (tiles128 >= min128) {
+    if constexpr (sizeof(T) == 2) {   // plain bf16 operands: the LDS-DMA form (option gemm_glds = 0: register staging)
+      if (option(OPT_GEMM_GLDS) != 0) return launch_gemm<T, 128, 128, EPI, false, true>(p, s);
+    }
+    return launch_gemm<T, 128, 128, EPI>(p, s);
+  }
   if constexpr (EPI == MH_EPI_GEGLU) {
     return launch_gemm<T, 64, 64, EPI>(p, s);
   } else {

@@ -99,6 +99,37 @@ def test_gemm_store_and_transpose_detecting(dtype_name, shape):
     assert ((out_t.double() - ref).abs() <= rel * ref.abs() + 1e-3).all()
 
 
+@pytest.mark.parametrize("shape", [(1251, 768, 416), (2600, 1100, 768), (700, 520, 2048)])
+def test_gemm_lds_dma_tile_equals_register_staged_tile(shape):
+    """The 128 x 128 bf16 tile fills its LDS stages by LDS-DMA (`global_load_lds`, option gemm_glds, the default) or by
+    register staging: the same products in the same order, so every epilogue's output must be BIT-equal between the two
+    and right against fp64.  Shapes with M / N / K tails (K = 416: half a K tile of zeros from the DMA's zero source)."""
+    import mapperatorinator_amd._lib as ML
+    L, _ = _lib()
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M + N + K)
+    A, W = _bf16r(torch.randn(M, K, generator=g)), _bf16r(torch.randn(N, K, generator=g) * torch.linspace(0.5, 2.0, N)[:, None])
+    bias = torch.randn(N, generator=g)
+    C0 = torch.randn(M, N, generator=g)
+    N2 = N // 32 * 32
+    old_min = ML.set_option("gemm_tile128_min", 1)
+    outs = {}
+    try:
+        for glds in (1, 0):
+            old = ML.set_option("gemm_glds", glds)
+            try:
+                outs[glds] = (run_gemm(A, W, L.EPI_STORE_F32, L.MH_BF16, bias=bias), run_gemm(A, W, L.EPI_RESID, L.MH_BF16, C0=C0),
+                              run_gemm(A, W[:N2], L.EPI_GEGLU, L.MH_BF16), run_gemm(A, W, L.EPI_STORE, L.MH_BF16))
+            finally:
+                ML.set_option("gemm_glds", old)
+    finally:
+        ML.set_option("gemm_tile128_min", old_min)
+    for a, b in zip(outs[1], outs[0]):
+        assert torch.equal(a, b)
+    ref = A.double() @ W.double().t() + bias.double()
+    assert (outs[1][0].double() - ref).abs().max().item() < 2e-5 * math.sqrt(K) * 4 + 1e-4
+
+
 def test_gemm_bf16x3_split_path():
     """MhGemm.w_split3 (fp32 GEMM as three bf16 MFMAs on pre-split weights, activations split on the way into LDS):
     ~2^-16 relative error per product -- two orders of magnitude tighter than bf16, one looser than exact fp32 -- on
