@@ -141,9 +141,11 @@ class SequentialWindowScheduler:
             kv = torch.stack([kvs[i][:, :, w] for i, _, _ in group], 2).contiguous()   # rows of this wave, gathered
             p_all = torch.cat([neg, prompts], 0) if cfg else prompts
             m_all = None if masks is None else (torch.cat([masks, masks], 0) if cfg else masks)
+            # generate_kwargs["cross_kv_fp8"]: the token steps stream an e4m3 copy of this wave's cross K / V
+            kv8 = eng.cross_kv_fp8(kv) if gk.get("cross_kv_fp8") else None
             tokens, n_out, _ = eng.decode(kv, p_all.to(dev, torch.int32).contiguous(),
                                           None if m_all is None else m_all.to(dev).contiguous(),
-                                          eos_table.to(dev), sp)
+                                          eos_table.to(dev), sp, kv_fp8=kv8)
         eng._leave()
         torch.cuda.current_stream(dev).synchronize()
         n_cols = int(n_out.item())

@@ -1,0 +1,79 @@
+"""BASELINE configs[4]-shaped measurement: KV-cached decode of whole songs (default: 32 songs x 18 windows of 10 s = 3 minutes
+each) through the window scheduler (mapperatorinator_amd/scheduler.py): every window of every song is encoded up front,
+its cross-attention K/V stays resident in HBM, wave w decodes window w of all songs as one batch; window w's prompt carries
+the last tokens window w-1 produced (the reference's sequential dependency, processor.py:308-368).
+Prints one JSON line.  Synthetic audio, random-init weights; greedy decoding; the tokenizer EOS set is active (a window ends when all its rows did).
+
+    python tools/long_song_bench.py [--size large] [--songs 32] [--windows 18] [--new-tokens 384] [--fp8-kv]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from mapperatorinator_amd import Tokenizer  # noqa: E402
+from mapperatorinator_amd.modeling import MapperatorinatorHIP  # noqa: E402
+from mapperatorinator_amd.scheduler import SequentialWindowScheduler, SongJob  # noqa: E402
+from mapperatorinator_amd.t5_engine import T5_PRESETS  # noqa: E402
+from mapperatorinator_amd.testing import random_t5_state_dict, synthetic_audio_varied  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--size", default="large", choices=list(T5_PRESETS))
+    ap.add_argument("--songs", type=int, default=32)
+    ap.add_argument("--windows", type=int, default=18)
+    ap.add_argument("--new-tokens", type=int, default=384)
+    ap.add_argument("--context-tokens", type=int, default=32, help="tokens of the previous window carried into the prompt")
+    ap.add_argument("--fp8-kv", action="store_true")
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    src, n_samples = 1251, 160000
+    tok = Tokenizer.benchmark_vocab(src_seq_len=src)
+    dims = T5_PRESETS[args.size]
+    tgt = 1 + args.context_tokens + args.new_tokens
+    model = MapperatorinatorHIP(random_t5_state_dict(dims, tok.vocab_size_in, tok.vocab_size_out, seed=0, lm_head_gain=6.0), dims,
+                                vocab_size_in=tok.vocab_size_in, vocab_size_out=tok.vocab_size_out, src_seq_len=src,
+                                tgt_seq_len=tgt, dtype=torch.bfloat16, device=dev)
+    audio = synthetic_audio_varied(args.songs * args.windows, n_samples, seed=3).view(args.songs, args.windows, n_samples)
+    gk = dict(max_length=tgt, do_sample=False, cross_kv_fp8=bool(args.fp8_kv))
+    last = [None] * args.songs
+    n_tok = [0]
+
+    def make_job(i):
+        def prompt_fn(w):
+            ctx = last[i][-args.context_tokens:] if last[i] is not None else torch.zeros(0, dtype=torch.long)
+            pad = torch.zeros(args.context_tokens - ctx.numel(), dtype=torch.long)          # fixed prompt width: one shape per wave
+            return dict(decoder_input_ids=torch.cat([pad, torch.tensor([tok.sos_id]), ctx])[None],
+                        decoder_attention_mask=torch.cat([pad, torch.ones(1 + ctx.numel(), dtype=torch.long)])[None])
+
+        def on_result(w, row, st):
+            last[i] = row[1 + args.context_tokens:]
+            n_tok[0] += int(row.numel() - 1 - args.context_tokens)
+        return SongJob(frames=audio[i], prompt_fn=prompt_fn, on_result=on_result, generate_kwargs=gk)
+
+    sched = SequentialWindowScheduler(model, tok, encode_batch=32, decode_batch=min(64, args.songs))
+    warm = SequentialWindowScheduler(model, tok, encode_batch=32, decode_batch=min(64, args.songs))
+    warm.run([SongJob(frames=audio[0, :1], prompt_fn=make_job(0).prompt_fn, on_result=lambda *a: None, generate_kwargs=gk)])
+    last[:] = [None] * args.songs
+    n_tok[0] = 0
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    stats = sched.run([make_job(i) for i in range(args.songs)])
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    print(json.dumps({"workload": f"osuT5-{args.size} bf16, {args.songs} songs x {args.windows} windows of 10 s, {args.new_tokens} new "
+                                  f"tokens per window, {args.context_tokens} context tokens, cross K/V {'e4m3' if args.fp8_kv else 'bf16'}",
+                      "event_tokens_per_s": round(n_tok[0] / dt, 1), "seconds": round(dt, 3), "tokens": n_tok[0],
+                      "song_seconds_per_s": round(args.songs * args.windows * 10.0 / dt, 1),
+                      "decode_calls": stats["decode_calls"], "encode_calls": stats["encode_calls"],
+                      "resident_cross_kv_gb": round(args.songs * args.windows * dims.n_dec_layers * 2 * dims.n_heads * src * 64 * 2 / 1e9, 2)}))
+
+
+if __name__ == "__main__":
+    main()
