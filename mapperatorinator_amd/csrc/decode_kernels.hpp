@@ -887,7 +887,7 @@ __global__ __launch_bounds__(1024) void dec_self_attn_qkv_kernel(SelfAttnP p, He
   const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
   const int pos = *p.pos;
   const int c8 = (lane & 7) * 8, g = lane >> 3;
-  if (sizeof(T) == 2) {
+  if (sizeof(T) == 2 && KC <= 7) {
     const int row0[3] = {h * 64, inner + h * 64, 2 * inner + h * 64};
     HeadProj<T, KC, 3> proj;
     // (requesting the 3 x 64 x d weights ahead of the normalisation costs 117 registers = ONE workgroup per CU: the
@@ -895,7 +895,7 @@ __global__ __launch_bounds__(1024) void dec_self_attn_qkv_kernel(SelfAttnP p, He
     norm_row_to_lds<T>(hp, b, xn, red16);
     proj.load(hp, row0);
     proj.apply(xn, qkv);
-  } else {   // fp32 storage: one projection at a time (register budget of a 1024-thread workgroup)
+  } else {   // fp32 storage, or d_model = 1024 in bf16: one projection at a time (register budget of a 1024-thread workgroup)
     norm_row_to_lds<T>(hp, b, xn, red16);
 #pragma unroll
     for (int q3 = 0; q3 < 3; ++q3) {

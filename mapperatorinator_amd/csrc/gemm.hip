@@ -34,6 +34,7 @@ struct GemmP {
   const float* ln_shift; const float* ln_scale; int ln_ld; float ln_eps;
   bool ascending_k;
   int split3;   // fp32 only: W holds [hi bf16 x32 | lo bf16 x32] per 32-float K block, A is split on the way into LDS
+  int debug;    // option gemm_lds_pad >> 20 (debugging aid)
 };
 
 // `v` already contains the bias; `old` = previous C value (RESID / GATE_RESID), `g` = gate value, `v2` = paired
@@ -212,12 +213,15 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmP p) {
       uint4 v = xa[i];
       if (kLnCapable && ln) {
         const bool kin = kt * BK + cchunk * VEC < p.K;   // K-tail columns stay zero
-        const float mu = lnst[2 * (crow + RPP * i)], rs = lnst[2 * (crow + RPP * i) + 1];
+        float mu = lnst[2 * (crow + RPP * i)], rs = lnst[2 * (crow + RPP * i) + 1];
+        if (p.debug & 1) { mu = 0.f; rs = 1.f; }
         const float m = kin ? 1.f : 0.f;
-        v.x = __float_as_uint(m * ((__uint_as_float(v.x) - mu) * rs * (1.f + __uint_as_float(xsc[i].x)) + __uint_as_float(xsh[i].x)));
-        v.y = __float_as_uint(m * ((__uint_as_float(v.y) - mu) * rs * (1.f + __uint_as_float(xsc[i].y)) + __uint_as_float(xsh[i].y)));
-        v.z = __float_as_uint(m * ((__uint_as_float(v.z) - mu) * rs * (1.f + __uint_as_float(xsc[i].z)) + __uint_as_float(xsh[i].z)));
-        v.w = __float_as_uint(m * ((__uint_as_float(v.w) - mu) * rs * (1.f + __uint_as_float(xsc[i].w)) + __uint_as_float(xsh[i].w)));
+        uint4 qsc = xsc[i], qsh = xsh[i];
+        if (p.debug & 2) { qsc = make_uint4(0, 0, 0, 0); qsh = make_uint4(0, 0, 0, 0); }
+        v.x = __float_as_uint(m * ((__uint_as_float(v.x) - mu) * rs * (1.f + __uint_as_float(qsc.x)) + __uint_as_float(qsh.x)));
+        v.y = __float_as_uint(m * ((__uint_as_float(v.y) - mu) * rs * (1.f + __uint_as_float(qsc.y)) + __uint_as_float(qsh.y)));
+        v.z = __float_as_uint(m * ((__uint_as_float(v.z) - mu) * rs * (1.f + __uint_as_float(qsc.z)) + __uint_as_float(qsh.z)));
+        v.w = __float_as_uint(m * ((__uint_as_float(v.w) - mu) * rs * (1.f + __uint_as_float(qsc.w)) + __uint_as_float(qsh.w)));
       }
       if constexpr (S3) {
         // 4 fp32 -> 4 hi + 4 lo bf16: hi half of the 128-byte row block at cchunk * 8, lo half 64 bytes further
@@ -518,7 +522,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmP p) {
 template <typename T, int BM, int BN, int EPI, bool S3 = false, bool GL = false>
 int launch_gemm(const GemmP& p, hipStream_t s) {
   const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
-  const size_t smem = 2 * (size_t)(BM + BN) * (RowBytes<BM>::v + 16) + BM * 8 + 2048;   // + LayerNorm statistics
+  size_t smem = 2 * (size_t)(BM + BN) * (RowBytes<BM>::v + 16) + BM * 8 + 2048;   // + LayerNorm statistics
+  if (BM <= 64) smem += (size_t)(option(OPT_GEMM_LDS_PAD) & 0xfffff);   // (debugging aid; <= 64 KB total without the opt-in attribute)
   hipLaunchKernelGGL((gemm_tn_kernel<T, BM, BN, EPI, S3, GL>), dim3(nbm * nbn), dim3(256), smem, s, p);
   return check_launch("gemm_tn_kernel");
 }
@@ -640,6 +645,7 @@ int gemm(const MhGemm& g, hipStream_t s, bool ascending_k) {
   GemmP p;
   p.ascending_k = ascending_k;
   p.split3 = g.w_split3;
+  p.debug = (int)(option(OPT_GEMM_LDS_PAD) >> 20);
   p.C3 = g.C3; p.C4 = g.C4; p.cache_len = g.cache_len;
   p.C2 = g.C2; p.n_split = g.n_split; p.kv_Lpad = g.kv_Lpad;
   p.A = (const char*)g.A; p.lda_b = (long)g.lda * es;
