@@ -42,7 +42,7 @@ static OptionSlot g_options[OPT_COUNT] = {
     {"decode_self_rows", "MH_DECODE_SELF_ROWS", 1, false},       // rows of one head per self-attention workgroup (1, 2, 4): they share the head's q / k / v weight slice
     {"gemm_glds", "MH_GEMM_GLDS", 1, false},                     // bf16 128x128 GEMM tiles: operands by LDS-DMA (global_load_lds) instead of register staging
     {"gemm_lds_pad", "MH_GEMM_LDS_PAD", 0, false},               // debugging: extra bytes of dynamic LDS per GEMM workgroup (fewer workgroups per CU)
-    {"dit_s3_fused_ln", "MH_DIT_S3_FUSED_LN", 1, false},         // bf16 x 3 DiT GEMMs take LayerNorm + modulate inside their A load (0: stand-alone pass before them)
+    {"dit_s3_fused_ln", "MH_DIT_S3_FUSED_LN", 0, false},         // 1: bf16 x 3 DiT GEMMs take LayerNorm + modulate inside their A load (default: stand-alone pass before them, measured faster)
 };
 
 long option(int id) {

@@ -294,11 +294,12 @@ int dit_body(const MhDiTConfig* c, const MhDiTWeights* w, const float* x, const 
   const bool fuse_ln = (D % 16 == 0);
   const int strips = D / 16;
   // big denoiser batches (many chunks stacked): the five large projections run as bf16 x 3 on the bf16 matrix cores
-  // (MhGemm.w_split3); a single chunk keeps the exact-fp32 kernels.  History: an earlier build of the split kernel with
-  // the LayerNorm + modulate fused into its A load returned non-repeatable rows (6, 7 mod 8) on grids of > 1000
-  // workgroups (tools/s3_ln_probe.py); the present code shape is repeatable and exact against the un-fused form
-  // (tests/test_gpu_kernels.py::test_gemm_bf16x3_with_fused_layernorm_is_repeatable), the cause was not isolated in the
-  // ISA -- option dit_s3_fused_ln = 0 brings the stand-alone pass back.
+  // (MhGemm.w_split3); a single chunk keeps the exact-fp32 kernels.  The split path takes its LayerNorm + modulate from
+  // the stand-alone pass by default: fusing it into the split kernel's A load (option dit_s3_fused_ln = 1) is slower
+  // (32 chunks x 100 steps: 303.7 vs 292.3 ms -- the modulate arithmetic sits in front of every split store).  History:
+  // an earlier build of that fused form returned non-repeatable rows (6, 7 mod 8) on grids of > 1000 workgroups
+  // (tools/s3_ln_probe.py); the present code shape is repeatable and exact against the un-fused form
+  // (tests/test_gpu_kernels.py::test_gemm_bf16x3_with_fused_layernorm_is_repeatable); the cause was not isolated in the ISA.
   const bool s3_fused_ln = option(OPT_DIT_S3_FUSED_LN) != 0;
   const long s3min = option(OPT_DIT_SPLIT3_MIN_ROWS);
   const bool s3 = s3min > 0 && NT >= s3min && w->first_w3 && D % 32 == 0 && c->first_k_pad % 32 == 0;
