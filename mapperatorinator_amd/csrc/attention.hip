@@ -81,8 +81,10 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(AttnArgs p) {
   for (int kt = t_lo; kt <= t_hi; ++kt) {
     const int kv0 = kt * 64;
     // ---- stage K tile [key][d] and V^T tile [d][key] ----
-    // (requesting the next tile into registers while this one is multiplied was measured and lost: 128 instead of 64
-    // VGPRs, the encoder's attention 9.8 -> ~12 ms per batch; the co-resident workgroups already overlap each other)
+    // (requesting the next tile into registers while this one is multiplied was measured and lost: the encoder's
+    // attention 9.8 -> ~12 ms per batch; so was a 128-query workgroup -- two 16-query fragments per wave, half the LDS
+    // reads and barriers per multiply, but 180 + 32 registers: mel + encoder 22.4 -> 24.1 ms per batch.  The co-resident
+    // workgroups already overlap each other's latencies; what this kernel lacks is MFMA work per wave instruction.)
 #pragma unroll
     for (int i = 0; i < CPT; ++i) {
       const int idx = tid + 256 * i;
