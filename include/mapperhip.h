@@ -67,7 +67,8 @@ int mh_abi_version(void);
  *   "decode_prefill"     MH_DECODE_PREFILL     1    batched prompt prefill (0: token by token)
  *   "decode_gemv_cols"   MH_DECODE_GEMV_COLS   0    valid columns per 16-column tile of the decode GEMVs (0 = automatic)
  *   "decode_fused_proj"  MH_DECODE_FUSED_PROJ  1    decode attention kernels project their own q / k / v (0: stand-alone
- *                                                   GEMV launches; fp32 summation order of the projections differs)
+ *                                                   GEMV launches; fp32 summation order of the projections differs;
+ *                                                   2: stand-alone QKV GEMV, cross-attention keeps its own projection)
  *   "decode_self_rows"   MH_DECODE_SELF_ROWS   1    rows of one head per decode self-attention workgroup (1, 2, 4): they share
  *                                                   the head's q / k / v weight slice; a row's key interleave is 16 / rows
  *                                                   waves wide (fp32 order of its softmax sums differs between settings,

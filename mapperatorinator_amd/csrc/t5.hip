@@ -597,12 +597,13 @@ int enqueue_step(const MhT5Config* c, const MhT5Weights* w, const void* cross_kv
     const long cache_off = (long)l * Bfull * H * tgt * 64 * es;
     dec::SkinnyP sk{};
     // self attention
-    const bool fused = fused_proj_enabled(d);
+    const bool fused = fused_proj_enabled(d);                                  // cross-attention projects its own query
+    const bool fused_self = fused && option(OPT_DECODE_FUSED_PROJ) == 1;       // (2: stand-alone QKV GEMV, fused cross-attention)
     dec::SelfAttnP sa{};
     sa.q = bf.q; sa.ldq = inner; sa.kc = (char*)bf.self_k + cache_off; sa.vc = (char*)bf.self_v + cache_off;
     sa.bias = w->dec_rel_bias; sa.prompt_mask = prompt_mask;
     sa.P = P; sa.out = bf.attn; sa.ldo = inner; sa.B = B; sa.H = H; sa.tgt_len = tgt; sa.pos = posp;
-    if (fused) {
+    if (fused_self) {
       dec::HeadProjP hp{};
       hp.h = bf.h; hp.ldh = d; hp.ln_w = w->dec_ln1[l]; hp.eps = c->eps; hp.W = w->dec_qkv[l]; hp.ldw = d; hp.d = d;
       MH_TRY(launch_self_qkv_d<T>(sa, hp, inner, s));

@@ -78,7 +78,7 @@ def test_fp32_matches_reference_golden(name):
 
 @pytest.mark.parametrize("opts", [dict(decode_fused_proj=0), dict(decode_gemv_cols=16), dict(decode_gemv_cols=8),
                                   dict(decode_gemv_cols=4), dict(decode_chains=1), dict(decode_chains=3),
-                                  dict(decode_prefill=0, decode_fused_proj=0), dict(decode_self_rows=2),
+                                  dict(decode_prefill=0, decode_fused_proj=0), dict(decode_fused_proj=2), dict(decode_self_rows=2),
                                   dict(decode_self_rows=4)])
 def test_decode_kernel_variants_reproduce_the_reference_tokens(opts):
     """Every run-time selectable form of the decode step (mh_set_option: stand-alone QKV / cross-Q GEMVs instead of
