@@ -66,7 +66,7 @@ class SequentialWindowScheduler:
         flat = torch.cat([j.frames for j in jobs], 0).to(eng.device, torch.float32)
         parts = []
         eng._enter()
-        with torch.cuda.stream(eng.stream):
+        with eng.on_stream():
             for a in range(0, flat.shape[0], self.encode_batch):
                 parts.append(eng.cross_kv(eng.encode_mel(eng.mel(flat[a:a + self.encode_batch]))))
                 self.stats["encode_calls"] += 1
@@ -137,7 +137,7 @@ class SequentialWindowScheduler:
         eos_ids = torch.as_tensor(sorted(set(int(e) for e in eos)), dtype=torch.int64)
         t0 = time.perf_counter()
         eng._enter()
-        with torch.cuda.stream(eng.stream):
+        with eng.on_stream():
             kv = torch.stack([kvs[i][:, :, w] for i, _, _ in group], 2).contiguous()   # rows of this wave, gathered
             p_all = torch.cat([neg, prompts], 0) if cfg else prompts
             m_all = None if masks is None else (torch.cat([masks, masks], 0) if cfg else masks)
@@ -147,7 +147,7 @@ class SequentialWindowScheduler:
                                           None if m_all is None else m_all.to(dev).contiguous(),
                                           eos_table.to(dev), sp, kv_fp8=kv8)
         eng._leave()
-        torch.cuda.current_stream(dev).synchronize()
+        eng.synchronize()
         n_cols = int(n_out.item())
         if cfg:
             tokens = tokens[len(group):]

@@ -204,6 +204,13 @@ class T5Engine:
     def _leave(self):
         torch.cuda.current_stream(self.device).wait_stream(self.stream)
 
+    def on_stream(self):
+        """Context manager: the engine's stream is current (what callers outside this module use around stage calls)."""
+        return torch.cuda.stream(self.stream)
+
+    def synchronize(self):
+        torch.cuda.current_stream(self.device).synchronize()
+
     def mel(self, audio: torch.Tensor) -> torch.Tensor:
         """(B, Ns) fp32 -> (B, L, n_mels_pad) storage dtype (K-padded GEMM operand)."""
         p = self.packed

@@ -237,3 +237,144 @@ def test_abi_header_is_plain_c():
         pytest.skip("no gcc")
     subprocess.run(["gcc", "-x", "c", "-std=c99", "-fsyntax-only", "-Wall", "-Werror", hdr], check=True)
     subprocess.run(["g++", "-x", "c++", "-std=c++17", "-fsyntax-only", hdr], check=True)
+
+
+class _StandInEngine:
+    """What SequentialWindowScheduler needs of an engine, on the CPU: per-window "cross K/V" = a fingerprint of the
+    window's audio, and a decode that is a deterministic function of (fingerprint, prompt without its left padding,
+    position) -- batch-invariant like the real engine, honouring EOS / max_length / pad-after-EOS and the guidance row
+    layout [negative rows | prompt rows]."""
+
+    def __init__(self, vocab_out, eos_every):
+        import contextlib
+        import types
+        self.device = torch.device("cpu")
+        self.packed = types.SimpleNamespace(vocab_out=vocab_out)
+        self.calls = []
+        self._ctx = contextlib.nullcontext
+        self.eos_every = eos_every
+
+    def _enter(self): pass
+    def _leave(self): pass
+    def synchronize(self): pass
+    def on_stream(self): return self._ctx()
+    def mel(self, audio): return audio
+    def encode_mel(self, mel): return mel
+
+    def cross_kv(self, enc):                                   # [layers=1][k|v=2][B][H=1][L=1][64]: the fingerprint
+        fp = (enc.abs().sum(-1) * 1000).round().long() % 997
+        return fp.view(1, 1, -1, 1, 1, 1).expand(1, 2, -1, 1, 1, 64).contiguous().float()
+
+    def decode(self, kv, prompt, prompt_mask, eos_table, sampling, forced=None, dump_logits=False, poll_every=16, kv_fp8=None):
+        B, P = prompt.shape
+        cfg = sampling.cfg_scale > 1.0
+        G = B // 2 if cfg else B
+        assert kv.shape[2] == G
+        self.calls.append(dict(B=B, P=P, cfg=cfg, max_length=sampling.max_length, masked=prompt_mask is not None))
+        maxlen = sampling.max_length
+        tokens = torch.full((B, maxlen), int(sampling.pad_id), dtype=torch.int32)
+        tokens[:, :P] = prompt
+        n_cols = P
+        for r in range(G):
+            row = r + (G if cfg else 0)
+            own = prompt[row][prompt_mask[row].bool()] if prompt_mask is not None else prompt[row]
+            seed = int(kv[0, 0, r, 0, 0, 0]) * 31 + int(own.sum()) * 7 + own.numel()
+            if cfg:
+                seed += int(prompt[r][prompt_mask[r].bool()].sum() if prompt_mask is not None else prompt[r].sum())
+            done = False
+            for c in range(P, maxlen):
+                if done:
+                    break
+                t = 3 + (seed + 13 * (c - P)) % (self.packed.vocab_out - 3)
+                if eos_table[t] or c + 1 >= maxlen:
+                    done = True
+                tokens[row, c] = t
+                n_cols = max(n_cols, c + 1)
+        return tokens, torch.tensor([n_cols], dtype=torch.int32), None
+
+
+@pytest.mark.parametrize("cfg_scale", [1.0, 2.0])
+def test_window_scheduler_waves_equal_the_sequential_loop_on_a_stand_in_engine(cfg_scale):
+    """SURVEY 8f rank 1 without a GPU: songs of 3 / 1 / 4 dependent windows through SequentialWindowScheduler (wave w =
+    window w of every song that has one, grouped by generate kwargs, ragged prompts left-padded and masked, guidance
+    rows doubled and halving the wave) must hand every `on_result` the row a batch-1 call for that window returns --
+    prompt included, cut after its own first EOS-set id -- in window order per song."""
+    import types
+    from mapperatorinator_amd import Tokenizer
+    from mapperatorinator_amd.scheduler import SequentialWindowScheduler, SongJob
+    from mapperatorinator_amd.server import build_sampling
+    tok = Tokenizer.benchmark_vocab(src_seq_len=251)
+    tgt = 40
+    eng = _StandInEngine(tok.vocab_size_out, eos_every=5)
+    model = types.SimpleNamespace(engine=eng, config=types.SimpleNamespace(max_target_positions=tgt))
+    n_windows = [3, 1, 4]
+    g = torch.Generator().manual_seed(5)
+    songs = [torch.randn(n, 64, generator=g) for n in n_windows]
+
+    def kwargs_for(w, n):
+        return dict(max_length=tgt, do_sample=False, cfg_scale=cfg_scale, lookback_time=400 if w != 0 else 0,
+                    lookahead_time=3000 if w != n - 1 else 0)
+
+    def prompt_from(prev):
+        carry = [] if prev is None else [t for t in prev.tolist() if t > 2][-3:]
+        return torch.tensor([[tok.sos_id] + carry])
+
+    neg = torch.tensor([[tok.sos_id]])
+
+    def batch1(k, w, prompt):
+        gk = dict(kwargs_for(w, n_windows[k]), conditional_temperature_per_row=True)
+        sp, eos = build_sampling(tok, gk, tgt)
+        table = torch.zeros(tok.vocab_size_out, dtype=torch.uint8)
+        table[[e for e in eos if 0 <= e < tok.vocab_size_out]] = 1
+        kv = eng.cross_kv(songs[k][w:w + 1])
+        p = prompt
+        if cfg_scale > 1:
+            negp = prompt.clone()
+            negp[:, :1] = neg
+            p = torch.cat([negp, prompt], 0)
+        tokens, n_out, _ = eng.decode(kv, p.int(), torch.ones_like(p, dtype=torch.uint8), table, sp)
+        row = tokens[-1, :int(n_out)].long()
+        body = row[prompt.shape[1]:]
+        hit = torch.isin(body, torch.tensor(sorted(eos))).nonzero()
+        return row[:prompt.shape[1] + int(hit[0]) + 1] if hit.numel() else row
+
+    want = []
+    for k, n in enumerate(n_windows):
+        prev, rows = None, []
+        for w in range(n):
+            prompt = prompt_from(prev)
+            row = batch1(k, w, prompt)
+            prev = row[prompt.shape[1]:]
+            rows.append(row)
+        want.append(rows)
+    eng.calls.clear()
+
+    got = [[None] * n for n in n_windows]
+    state = [None] * len(n_windows)
+    order = []
+
+    def make_job(k, n):
+        def prompt_fn(w):
+            ask = dict(decoder_input_ids=prompt_from(state[k]), generate_kwargs=kwargs_for(w, n))
+            if cfg_scale > 1:
+                ask["negative_prompt"] = neg
+            return ask
+
+        def on_result(w, row, st):
+            p = prompt_from(state[k]).shape[1]
+            got[k][w] = row
+            state[k] = row[p:]
+            order.append((k, w))
+            assert st["generated_tokens"] == int((row[p:] != 0).sum())
+        return SongJob(frames=songs[k], prompt_fn=prompt_fn, on_result=on_result)
+
+    sched = SequentialWindowScheduler(model, tok, encode_batch=4, decode_batch=4)
+    stats = sched.run([make_job(k, n) for k, n in enumerate(n_windows)])
+    assert stats["windows"] == sum(n_windows) and stats["encode_calls"] == 2          # 8 windows, 4 per encode batch
+    for k, n in enumerate(n_windows):
+        assert [w for kk, w in order if kk == k] == list(range(n))                     # per song in window order
+        for w in range(n):
+            assert torch.equal(got[k][w], want[k][w]), (k, w, got[k][w].tolist(), want[k][w].tolist())
+    assert stats["decode_calls"] < sum(n_windows)                                      # songs were interleaved
+    for c in eng.calls:
+        assert c["B"] <= 4 and c["cfg"] == (cfg_scale > 1) and (c["B"] % 2 == 0 or not c["cfg"])
