@@ -464,13 +464,15 @@ __global__ void dec_finalize_kernel(const int32_t* finish_col, int B, int32_t* n
   }
 }
 
-// real columns per 16-column tile of a decode GEMV: the largest of 16 / 8 / 4 that still yields >= 192 workgroups
-// (option decode_gemv_cols overrides; a result never depends on it: every column is an independent dot product)
+// real columns per 16-column tile of a decode GEMV: 16 when that still yields >= 192 workgroups, else 8 down to 96
+// workgroups, else 4 (every workgroup re-reads ALL activations through L2, the resource the two decode chains fight
+// over: at N = 768, 96 workgroups of 8 columns measured 42.9 k tok/s against 42.4 k for 192 of 4 and 42.1 k for 48 of
+// 16).  Option decode_gemv_cols overrides; a result never depends on it: every column is an independent dot product.
 int gemv_cols(int N) {
   const long o = option(OPT_DECODE_GEMV_COLS);
   if (o == 4 || o == 8 || o == 16) return (int)o;
   if (N / 16 >= 192) return 16;
-  if (N / 8 >= 192) return 8;
+  if (N / 8 >= 96) return 8;
   return 4;
 }
 
