@@ -222,6 +222,14 @@ int64_t mh_t5_encode_workspace_bytes(const MhT5Config* cfg, int B);
 int mh_t5_encode(const MhT5Config* cfg, const MhT5Weights* w, const void* mel, int B, void* enc_out,
                  float* enc_out_f32, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* The same with the wrapper's conditioning embedders (difficulty / mapper style / song position / style:
+ * modeling_mapperatorinator.py:395-414 -- per-row vectors repeated over the frames and concatenated to the mel frames in
+ * front of encoder_embedder).  A vector that is constant along the frames only adds a constant to every frame of its
+ * chunk: row_bias [B, d_model] fp32 = cond @ W[:, n_mels:]^T + b (computed by the caller; it REPLACES the bias of
+ * encoder_embedder), NULL = mh_t5_encode. */
+int mh_t5_encode_cond(const MhT5Config* cfg, const MhT5Weights* w, const void* mel, int B, const float* row_bias,
+                      void* enc_out, float* enc_out_f32, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* Cross-attention K/V projection of all decoder layers at once (HF T5Attention with
  * key_value_states, computed once per chunk and kept in the encoder-side StaticCache:
  * osuT5/osuT5/inference/cache_utils.py:32-35).

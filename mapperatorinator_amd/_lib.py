@@ -97,6 +97,7 @@ SYMBOLS = {
     "mh_t5_encode_workspace_bytes": (I64, [C.POINTER(MhT5Config), I]),
     "mh_t5_encode": (I, [C.POINTER(MhT5Config), C.POINTER(MhT5Weights), VP, I, VP, VP, VP, I64, VP]),
     "mh_t5_cross_kv": (I, [C.POINTER(MhT5Config), C.POINTER(MhT5Weights), VP, I, VP, VP]),
+    "mh_t5_encode_cond": (I, [C.POINTER(MhT5Config), C.POINTER(MhT5Weights), VP, I, VP, VP, VP, VP, I64, VP]),
     "mh_t5_decode_workspace_bytes": (I64, [C.POINTER(MhT5Config), I]),
     "mh_t5_cross_kv_fp8_bytes": (I64, [C.POINTER(MhT5Config), I]),
     "mh_t5_quantize_cross_kv": (I, [C.POINTER(MhT5Config), VP, I, VP, VP]),

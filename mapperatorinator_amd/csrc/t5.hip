@@ -58,8 +58,25 @@ extern "C" int64_t mh_t5_encode_workspace_bytes(const MhT5Config* c, int B) {
   return t;
 }
 
+namespace mh {
+namespace {
+// h[b * L + t][:] = row_bias[b][:]  (the conditioning embedders' contribution, constant along a chunk's frames)
+__global__ __launch_bounds__(256) void fill_rows_kernel(float* __restrict__ h, const float* __restrict__ row_bias, int L, int d) {
+  const long row = blockIdx.x;
+  const float4* src = reinterpret_cast<const float4*>(row_bias + (row / L) * d);
+  float4* dst = reinterpret_cast<float4*>(h + row * d);
+  for (int i = threadIdx.x; i < d / 4; i += 256) dst[i] = src[i];
+}
+}  // namespace
+}  // namespace mh
+
 extern "C" int mh_t5_encode(const MhT5Config* c, const MhT5Weights* w, const void* mel, int B, void* enc_out,
                             float* enc_out_f32, void* workspace, int64_t workspace_bytes, void* stream) {
+  return mh_t5_encode_cond(c, w, mel, B, nullptr, enc_out, enc_out_f32, workspace, workspace_bytes, stream);
+}
+
+extern "C" int mh_t5_encode_cond(const MhT5Config* c, const MhT5Weights* w, const void* mel, int B, const float* row_bias,
+                                 void* enc_out, float* enc_out_f32, void* workspace, int64_t workspace_bytes, void* stream) {
   MH_TRY(check_cfg(c, "mh_t5_encode"));
   MH_REQUIRE(w && mel && enc_out && workspace && B > 0, "mh_t5_encode: null argument");
   MH_REQUIRE(workspace_bytes >= mh_t5_encode_workspace_bytes(c, B), "mh_t5_encode: workspace too small");
@@ -81,6 +98,14 @@ extern "C" int mh_t5_encode(const MhT5Config* c, const MhT5Weights* w, const voi
   g = MhGemm{};
   g.A = mel; g.lda = c->n_mels_pad; g.W = w->enc_embed_w; g.ldw = c->n_mels_pad; g.C = h; g.ldc = d;
   g.M = rows; g.N = d; g.K = c->n_mels_pad; g.bias = w->enc_embed_b; g.dtype = c->dtype; g.epilogue = MH_EPI_STORE_F32;
+  if (row_bias) {
+    // conditioning: [mel | cond] @ W^T + b = mel @ W[:, :n_mels]^T + (cond @ W[:, n_mels:]^T + b); the bracket is the
+    // caller's per-chunk row_bias [B, d] (it already contains b), laid under the mel product
+    MH_REQUIRE(d % 4 == 0, "mh_t5_encode_cond: d_model must be a multiple of 4");
+    hipLaunchKernelGGL(mh::fill_rows_kernel, dim3(rows), dim3(256), 0, s, h, row_bias, L, d);
+    MH_TRY(check_launch("fill_rows_kernel"));
+    g.bias = nullptr; g.epilogue = MH_EPI_RESID;
+  }
   MH_TRY(gemm(g, s));
 
   for (int l = 0; l < c->n_enc_layers; ++l) {

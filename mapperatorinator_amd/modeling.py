@@ -17,6 +17,7 @@ from typing import Optional
 
 import torch
 
+from .conditioning import ConditioningEmbedders
 from .t5_engine import T5Dims, T5Engine, T5_PRESETS
 
 
@@ -43,6 +44,9 @@ class MapperatorinatorHIP:
         self.engine = T5Engine(state_dict, dims, vocab_size_in, vocab_size_out, n_mels, src_seq_len, tgt_seq_len,
                                dtype, device, sample_rate, n_fft, hop_length, f_min, f_max, spectrogram_log_scale)
         self._source_state_dict = state_dict      # caller-owned tensors under the reference's parameter names (not copied)
+        # difficulty / mapper / song-position / style embedders, if the state dict carries them (host side; their output
+        # reaches the device as a per-chunk row bias of the encoder input projection)
+        self.cond = ConditioningEmbedders(state_dict, n_mels)
         self.device = self.engine.device
         self.dtype = dtype
         self.spectrogram = self.engine.spectrogram
@@ -68,8 +72,6 @@ class MapperatorinatorHIP:
         if cfg.input_features or not cfg.project_encoder_input or not cfg.embed_decoder_input or cfg.input_raw_wave:
             raise NotImplementedError("HIP path implements input_features=False, project_encoder_input=True, "
                                       "embed_decoder_input=True")
-        if cfg.do_style_embed or cfg.do_difficulty_embed or cfg.do_mapper_embed or cfg.do_song_position_embed:
-            raise NotImplementedError("conditioning embedders are not part of the T5 north-star configs")
         bc = cfg.backbone_config
         return cls(model.state_dict(), dims_from_backbone_config(bc), vocab_size_in=cfg.vocab_size_in,
                    vocab_size_out=cfg.vocab_size, n_mels=cfg.n_mels, src_seq_len=cfg.max_source_positions,
@@ -101,10 +103,10 @@ class MapperatorinatorHIP:
         class _Encoder:
             main_input_name = "frames"
 
-            def __call__(self_inner, frames=None, **unused):
+            def __call__(self_inner, frames=None, **kw):
                 if frames is None:
                     raise ValueError("frames (raw audio, (B, samples)) is required")
-                enc = eng.encode(frames.to(eng.device, torch.float32))
+                enc = eng.encode(frames.to(eng.device, torch.float32), row_bias=self._row_bias(frames.shape[0], kw))
                 return types.SimpleNamespace(last_hidden_state=enc, hidden_states=None, attentions=None)
         return _Encoder()
 
@@ -136,8 +138,17 @@ class MapperatorinatorHIP:
     def to(self, *a, **k):
         return self
 
+    def _row_bias(self, batch, kw):
+        """The conditioning embedders' per-chunk bias of the encoder input projection (None without embedders); `kw` may
+        carry beatmap_idx / difficulty / mapper_idx / song_position as the reference's forward takes them."""
+        if not self.cond.active:
+            return None
+        vec = self.cond.vectors(batch, beatmap_idx=kw.get("beatmap_idx"), difficulty=kw.get("difficulty"),
+                                mapper_idx=kw.get("mapper_idx"), song_position=kw.get("song_position"))
+        return self.cond.row_bias(vec, self.dtype)
+
     # ---- B2: the two calls the reference makes on the model object -----------------------------------------
-    def _cross_kv(self, frames, encoder_outputs):
+    def _cross_kv(self, frames, encoder_outputs, row_bias=None):
         eng = self.engine
         if encoder_outputs is not None:
             enc = getattr(encoder_outputs, "last_hidden_state", encoder_outputs)
@@ -146,7 +157,7 @@ class MapperatorinatorHIP:
             return eng.cross_kv(enc.to(eng.device, eng.dtype).contiguous())
         if frames is None:
             raise ValueError("either frames (raw audio, (B, samples)) or encoder_outputs is required")
-        return eng.cross_kv(eng.encode_mel(eng.mel(frames.to(eng.device, torch.float32))))
+        return eng.cross_kv(eng.encode_mel(eng.mel(frames.to(eng.device, torch.float32)), row_bias=row_bias))
 
     @torch.no_grad()
     def forward(self, frames=None, decoder_input_ids=None, decoder_attention_mask=None, encoder_outputs=None, **unused):
@@ -162,9 +173,10 @@ class MapperatorinatorHIP:
         ids = decoder_input_ids.to(eng.device, torch.int32).contiguous()
         mask = (decoder_attention_mask.to(eng.device).to(torch.uint8).contiguous()
                 if decoder_attention_mask is not None else None)
+        row_bias = self._row_bias(ids.shape[0], unused) if encoder_outputs is None else None
         eng._enter()
         with torch.cuda.stream(eng.stream):
-            logits = eng.decoder_forward(self._cross_kv(frames, encoder_outputs), ids, mask)
+            logits = eng.decoder_forward(self._cross_kv(frames, encoder_outputs, row_bias), ids, mask)
         eng._leave()
         return types.SimpleNamespace(logits=logits, encoder_last_hidden_state=None, past_key_values=None, loss=None)
 
@@ -196,7 +208,9 @@ class MapperatorinatorHIP:
         eos = [eos] if isinstance(eos, int) else list(eos)
         if sp.cfg_scale > 1.0 and negative_prompt is None:
             raise ValueError("guidance needs negative_prompt (modeling_mapperatorinator.py:243-254)")
+        row_bias = self._row_bias(decoder_input_ids.shape[0], unused)
         out = self.engine.generate(audio, decoder_input_ids, decoder_attention_mask, eos, sp,
                                    negative_prompt=negative_prompt if sp.cfg_scale > 1.0 else None,
-                                   negative_mask=negative_prompt_attention_mask)
+                                   negative_mask=negative_prompt_attention_mask,
+                                   **({} if row_bias is None else dict(row_bias=row_bias)))
         return out["tokens"].to(self.device)

@@ -54,6 +54,9 @@ class SequentialWindowScheduler:
         if decode_batch > 64 or decode_batch < 1:
             raise ValueError("decode_batch must be in [1, 64] (32 at most when windows run under classifier-free guidance)")
         self.model, self.tokenizer = model, tokenizer
+        if getattr(getattr(model, "cond", None), "active", False):
+            raise NotImplementedError("the window scheduler does not carry per-window conditioning inputs yet "
+                                      "(song_position changes per window: processor.py:341-345)")
         self.engine = model.engine
         self.encode_batch, self.decode_batch = int(encode_batch), int(decode_batch)
         self.stats = dict(windows=0, decode_calls=0, encode_calls=0, generated_tokens=0, elapsed_seconds=0.0)

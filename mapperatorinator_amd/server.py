@@ -273,9 +273,15 @@ def sampling_from_processors(processors, vocab_size_out: int, *, do_sample=False
 def model_generate(model, tokenizer, model_kwargs, generate_kwargs):
     """See module docstring.  `model_kwargs['inputs']`: raw audio float32 (B, Ns)."""
     generate_kwargs = dict(generate_kwargs)
-    for k in ("beatmap_idx", "difficulty", "mapper_idx", "song_position"):
-        if model_kwargs.get(k) is not None:
-            raise NotImplementedError(f"conditioning input {k!r} is not part of the T5 north-star configs")
+    # conditioning inputs (modeling_mapperatorinator.py:174-228): used when the model carries the embedders, ignored
+    # otherwise -- exactly the reference's `if self.do_*_embed` switches
+    cond = getattr(model, "cond", None)
+    row_bias = None
+    if cond is not None and cond.active:
+        vec = cond.vectors(model_kwargs["inputs"].shape[0], beatmap_idx=model_kwargs.get("beatmap_idx"),
+                           difficulty=model_kwargs.get("difficulty"), mapper_idx=model_kwargs.get("mapper_idx"),
+                           song_position=model_kwargs.get("song_position"))
+        row_bias = cond.row_bias(vec, model.dtype)
     audio = model_kwargs["inputs"]
     prompt = model_kwargs["decoder_input_ids"]
     mask = model_kwargs.get("decoder_attention_mask")
@@ -295,8 +301,9 @@ def model_generate(model, tokenizer, model_kwargs, generate_kwargs):
         neg = neg_mask = None
 
     start = time.perf_counter()
+    extra = {} if row_bias is None else dict(row_bias=row_bias)
     out = model.engine.generate(audio, prompt, mask, eos, sp, negative_prompt=neg, negative_mask=neg_mask,
-                                cross_kv_fp8=bool(generate_kwargs.get("cross_kv_fp8", False)))
+                                cross_kv_fp8=bool(generate_kwargs.get("cross_kv_fp8", False)), **extra)
     elapsed = time.perf_counter() - start
     result = out["tokens"]
     stats = _build_generation_stats(result, model_kwargs, pad_token_id, elapsed)

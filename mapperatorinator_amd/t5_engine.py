@@ -122,7 +122,9 @@ class PackedT5:
                               vocab_in, vocab_out, n_mels, self.n_mels_pad, src_len, tgt_len,
                               _lib.MH_BF16 if dtype == torch.bfloat16 else _lib.MH_F32, dims.eps)
         w = _lib.MhT5Weights()
-        w.enc_embed_w = mat(sd["encoder_embedder.weight"], self.n_mels_pad).data_ptr()
+        # columns beyond n_mels belong to the conditioning vectors: they reach the device as a per-chunk row bias
+        # (conditioning.ConditioningEmbedders.row_bias, mh_t5_encode_cond)
+        w.enc_embed_w = mat(sd["encoder_embedder.weight"][:, :n_mels], self.n_mels_pad).data_ptr()
         w.enc_embed_b = vec(sd["encoder_embedder.bias"]).data_ptr()
         w.dec_embed = mat(sd["decoder_embedder.weight"]).data_ptr()
         enc_tab = sd[pe + "block.0.layer.0.SelfAttention.relative_attention_bias.weight"].detach().to(dtype).float().cpu()
@@ -219,16 +221,23 @@ class T5Engine:
                              f"this engine was built for src_len={p.src_len}")
         return self.spectrogram.forward_padded(audio, p.n_mels_pad, self.dtype)
 
-    def encode_mel(self, mel: torch.Tensor, want_f32: bool = False):
+    def encode_mel(self, mel: torch.Tensor, want_f32: bool = False, row_bias: Optional[torch.Tensor] = None):
+        """`row_bias` (B, d_model) fp32: the conditioning embedders' contribution incl. the bias of encoder_embedder
+        (conditioning.ConditioningEmbedders.row_bias); None = the plain projection."""
         p = self.packed
         B = mel.shape[0]
+        rb = None
+        if row_bias is not None:
+            rb = row_bias.to(self.device, torch.float32).contiguous()
+            if rb.shape != (B, self.dims.d_model):
+                raise ValueError(f"row_bias must be ({B}, {self.dims.d_model}), got {tuple(rb.shape)}")
         need = self.lib.mh_t5_encode_workspace_bytes(C.byref(p.cfg), B)
         ws = self._workspace("enc", need)
         enc = torch.empty((B, p.src_len, self.dims.d_model), dtype=self.dtype, device=self.device)
         enc32 = torch.empty((B, p.src_len, self.dims.d_model), dtype=torch.float32, device=self.device) if want_f32 else None
-        rc = self.lib.mh_t5_encode(C.byref(p.cfg), C.byref(p.w), mel.data_ptr(), B, enc.data_ptr(),
-                                   _lib.ptr(enc32), ws.data_ptr(), ws.numel(), self._s())
-        _lib.check(rc, "mh_t5_encode")
+        rc = self.lib.mh_t5_encode_cond(C.byref(p.cfg), C.byref(p.w), mel.data_ptr(), B, _lib.ptr(rb), enc.data_ptr(),
+                                        _lib.ptr(enc32), ws.data_ptr(), ws.numel(), self._s())
+        _lib.check(rc, "mh_t5_encode_cond")
         return (enc, enc32) if want_f32 else enc
 
     def cross_kv(self, enc: torch.Tensor) -> torch.Tensor:
@@ -253,11 +262,11 @@ class T5Engine:
         _lib.check(rc, "mh_t5_quantize_cross_kv")
         return out
 
-    def encode(self, audio: torch.Tensor, want_f32: bool = False):
+    def encode(self, audio: torch.Tensor, want_f32: bool = False, row_bias: Optional[torch.Tensor] = None):
         """audio (B, Ns) on the GPU -> encoder last_hidden_state (final RMSNorm applied)."""
         self._enter()
         with torch.cuda.stream(self.stream):
-            out = self.encode_mel(self.mel(audio), want_f32)
+            out = self.encode_mel(self.mel(audio), want_f32, row_bias)
         self._leave()
         return out
 
@@ -310,7 +319,8 @@ class T5Engine:
     def generate(self, audio: torch.Tensor, prompt: torch.Tensor, prompt_mask: Optional[torch.Tensor],
                  eos_ids, sampling: _lib.MhSampling, forced: Optional[torch.Tensor] = None,
                  dump_logits: bool = False, poll_every: int = 16, negative_prompt: Optional[torch.Tensor] = None,
-                 negative_mask: Optional[torch.Tensor] = None, cross_kv_fp8: bool = False):
+                 negative_mask: Optional[torch.Tensor] = None, cross_kv_fp8: bool = False,
+                 row_bias: Optional[torch.Tensor] = None):
         """Full hot path for one batch of chunks.  `cross_kv_fp8`: the token steps stream the e4m3 copy of the
         cross-attention K / V (see `cross_kv_fp8()`).  Inputs may be CPU tensors (copied like
         server.py:86-87 does).  Returns dict(tokens=int64 CPU (B, n_cols), logits=..., n_cols=int).
@@ -346,7 +356,7 @@ class T5Engine:
         eos_table = eos_table.to(dev)
         self._enter()
         with torch.cuda.stream(self.stream):
-            enc = self.encode_mel(self.mel(audio))
+            enc = self.encode_mel(self.mel(audio), row_bias=row_bias)
             kv = self.cross_kv(enc)
             kv8 = self.cross_kv_fp8(kv) if cross_kv_fp8 else None
             tokens, n_out, logits = self.decode(kv, prompt_d, mask_d, eos_table, sampling, forced_d, dump_logits,

@@ -78,6 +78,40 @@ def random_t5_state_dict(dims: T5Dims, vocab_in: int, vocab_out: int, n_mels: in
 DIVERSE_GAINS = {"decoder_embedder": 0.5, "EncDecAttention.q.weight": 2.0, "EncDecAttention.o.weight": 2.0}
 
 
+def add_random_conditioning(sd: dict, d_model: int, n_mels: int = 388, cond_dim: int = 16, num_mappers: int = 11, seed: int = 0) -> dict:
+    """Adds the parameters of the reference's difficulty / mapper / song-position embedders
+    (modeling_mapperatorinator.py:110-128,462-660) and widens `encoder_embedder.weight` by the 3 * cond_dim conditioning
+    columns, in place.  Scales are chosen so that the conditioning moves the encoder input by about as much as the mel
+    does (the reference's own initialisers -- xavier gain 0.1, zero bias -- would leave it invisible to a parity test)."""
+    rng = np.random.default_rng(5000 + seed)
+    C = cond_dim
+    sd["encoder_embedder.weight"] = torch.cat([sd["encoder_embedder.weight"], _normal(rng, (d_model, 3 * C), 0.5 / np.sqrt(3 * C))], 1)
+
+    def ln(prefix, n):
+        sd[prefix + ".weight"] = 1.0 + _normal(rng, (n,), 0.1)
+        sd[prefix + ".bias"] = _normal(rng, (n,), 0.1)
+
+    def lin(prefix, n_out, n_in):
+        sd[prefix + ".weight"] = _normal(rng, (n_out, n_in), n_in ** -0.5)
+        sd[prefix + ".bias"] = _normal(rng, (n_out,), 0.1)
+
+    sd["difficulty_embedder.basis_centers"] = torch.linspace(0, 1, 8) + _normal(rng, (8,), 0.02)
+    sd["difficulty_embedder.basis_widths"] = 0.1 + _normal(rng, (8,), 0.01).abs()
+    lin("difficulty_embedder.difficulty_proj.0", C, 8)
+    ln("difficulty_embedder.difficulty_proj.1", C)
+    lin("difficulty_embedder.difficulty_proj.4", C, C)
+    ln("difficulty_embedder.difficulty_proj.5", C)
+    sd["mapper_embedder.embedding.weight"] = _normal(rng, (num_mappers + 1, C), 0.5)
+    ln("mapper_embedder.layer_norm", C)
+    sd["song_pos_embedder.basis_centers"] = torch.linspace(0, 1, 10) + _normal(rng, (10,), 0.02)
+    sd["song_pos_embedder.basis_widths"] = 0.1 + _normal(rng, (10,), 0.01).abs()
+    lin("song_pos_embedder.position_proj.0", 2 * C, 20)
+    ln("song_pos_embedder.position_proj.1", 2 * C)
+    lin("song_pos_embedder.position_proj.4", C, 2 * C)
+    ln("song_pos_embedder.position_proj.5", C)
+    return sd
+
+
 def synthetic_audio(batch: int, n_samples: int = 160000, seed: int = 0) -> torch.Tensor:
     """N(0,1) noise plus two tones, peak-normalised to [-1, 1] per row (mirrors
     `normalize_audio_samples`, osuT5/osuT5/dataset/data_utils.py:132-137)."""

@@ -97,6 +97,42 @@ def t5_case(name):
           len(set(ids2.flatten().tolist())), "tok/s(ref,cpu)", stats["tokens_per_second"])
 
 
+COND_CASE = dict(size="tiny", ns=32000, src=251, tgt=40, wseed=3, gain=4.0, aseed=7, cond_dim=16, num_mappers=11, cseed=1,
+                 prompts=[[0, 1], [1, 40], [0, 1]], difficulty=[2.5, 6.1, 9.0], mapper_idx=[3, -1, 10],
+                 song_position=[[0.0, 0.1], [0.45, 0.5], [0.9, 1.0]])
+
+
+def t5_conditioning_case(name="t5_tiny_cond"):
+    """The wrapper's conditioning embedders (difficulty, mapper style, song position; modeling_mapperatorinator.py:104-128,
+    395-414) on the reference: the per-row conditioning vectors its own modules produce, the encoder states with them
+    concatenated to the mel frames, and the greedy ids -- plus the ids WITHOUT conditioning, to show it matters."""
+    from mapperatorinator_amd.testing import add_random_conditioning
+    c = COND_CASE
+    model, tok, _ = rh.build_reference_t5(c["size"], src_seq_len=c["src"], tgt_seq_len=c["tgt"],
+                                          cond=dict(cond_dim=c["cond_dim"], num_mappers=c["num_mappers"]))
+    sd = random_t5_state_dict(T5_PRESETS[c["size"]], tok.vocab_size_in, tok.vocab_size_out, seed=c["wseed"], lm_head_gain=c["gain"])
+    add_random_conditioning(sd, T5_PRESETS[c["size"]].d_model, 388, c["cond_dim"], c["num_mappers"], seed=c["cseed"])
+    res = model.load_state_dict(sd, strict=False)
+    assert not res.unexpected_keys and not [k for k in res.missing_keys if "embedder" in k], res
+    audio = synthetic_audio(len(c["prompts"]), c["ns"], seed=c["aseed"])
+    prompt = torch.tensor(c["prompts"])
+    diff, mp, sp = torch.tensor(c["difficulty"]), torch.tensor(c["mapper_idx"]), torch.tensor(c["song_position"])
+    cond = rh.reference_cond_vectors(model, diff, mp, sp)
+    enc = rh.reference_encode(model, audio, cond)
+    ids, _ = rh.reference_generate(model, tok, audio, prompt, rh.default_generate_kwargs(c["tgt"]), prompt.ne(0), cond=cond)
+    ids0, _ = rh.reference_generate(model, tok, audio, prompt, rh.default_generate_kwargs(c["tgt"]), prompt.ne(0),
+                                    cond=torch.zeros_like(cond))
+    np.savez_compressed(
+        os.path.join(OUT, name + ".npz"),
+        vocab_in=tok.vocab_size_in, vocab_out=tok.vocab_size_out, n_samples=c["ns"], src_len=c["src"], tgt_len=c["tgt"],
+        weight_seed=c["wseed"], lm_head_gain=c["gain"], audio_seed=c["aseed"], cond_dim=c["cond_dim"],
+        num_mappers=c["num_mappers"], cond_seed=c["cseed"], prompt=prompt.numpy(), difficulty=diff.numpy(),
+        mapper_idx=mp.numpy(), song_position=sp.numpy(), cond_vectors=cond.numpy(),
+        enc_slice=enc[:, ::13, ::7].numpy(), enc_abs_mean=enc.abs().double().mean().item(), ids=ids.numpy(), ids_zero_cond=ids0.numpy())
+    print(name, "ids", ids.shape, "positions that differ from the zero-conditioning run",
+          int((ids != ids0[:, :ids.shape[1]]).sum()) if ids0.shape == ids.shape else "shape differs", "cond |mean|", float(cond.abs().mean()))
+
+
 def t5_bf16_reference_case(name="t5_base"):
     """The reference itself in bfloat16 (`model.to(torch.bfloat16)`, the precision switch of
     osuT5/osuT5/utils/model_utils.py:375-376) on the weights / audio / prompts of `name`: free-running greedy ids,
@@ -345,6 +381,7 @@ def main():
     for name in T5_CASES:
         t5_case(name)
     t5_bf16_reference_case("t5_base")
+    t5_conditioning_case()
     types_first_case()
     dit_case("dit_xs", "DiT-XS", 96, 21, 5, 1.5)
     dit_case("dit_s", "DiT-S", 160, 1, 2, 2.0)

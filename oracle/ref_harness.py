@@ -71,7 +71,7 @@ TINY_OVERWRITE = {"d_model": 128, "d_ff": 256, "num_heads": 2, "num_layers": 2, 
 
 
 def build_reference_t5(size="small", src_seq_len=1251, tgt_seq_len=512, n_mels=388,
-                       dtype=torch.float32, seed=0, lm_head_gain=1.0, overwrite=None, types_first=False):
+                       dtype=torch.float32, seed=0, lm_head_gain=1.0, overwrite=None, types_first=False, cond=None):
     """reference `_get_model` (osuT5/osuT5/utils/model_utils.py:102-114) with the reference
     initialisers (HF `_init_weights`), seeded."""
     if size == "tiny":  # test-only size: t5-small backbone config with the dims overwritten
@@ -84,7 +84,12 @@ def build_reference_t5(size="small", src_seq_len=1251, tgt_seq_len=512, n_mels=3
         args.model.overwrite = dict(args.model.overwrite, **overwrite)
     from osuT5.osuT5.tokenizer import Tokenizer
     from osuT5.osuT5.utils.model_utils import _get_model
-    tok = Tokenizer(args)
+    tok = Tokenizer(args)   # (built before the conditioning switches: with do_mapper_embed the tokenizer wants a mapper table file)
+    if cond:   # difficulty + mapper + song-position embedders (modeling_mapperatorinator.py:104-128), cond_dim each
+        args.model.do_difficulty_embed = args.model.do_mapper_embed = args.model.do_song_position_embed = True
+        args.model.cond_dim = cond["cond_dim"]
+        args.model.cond_size = 3 * cond["cond_dim"]
+        tok.num_mapper_classes = cond["num_mappers"]     # what the mapper table would set (tokenizer.py:586); model_utils.py:56 reads it
     torch.manual_seed(seed)
     model = _get_model(args, tok, torch.float32, "eager").eval()
     if lm_head_gain != 1.0:
@@ -102,11 +107,28 @@ def ts_range(tok):
     return s, e
 
 
-def reference_encode(model, audio: torch.Tensor) -> torch.Tensor:
-    """mel -> encoder_embedder -> T5 encoder, called by hand (work-around for the positional
-    `inputs_embeds` bug at modeling_mapperatorinator.py:438-443; SURVEY.md headline finding 3)."""
+def reference_cond_vectors(model, difficulty=None, mapper_idx=None, song_position=None):
+    """The per-row conditioning vectors exactly as `Mapperatorinator.forward` builds them from its own embedder modules
+    (modeling_mapperatorinator.py:395-409): (B, cond_size), order difficulty | mapper | song position."""
+    with torch.no_grad():
+        conds = []
+        if model.do_difficulty_embed:
+            conds.append(model.difficulty_embedder(difficulty))
+        if model.do_mapper_embed:
+            conds.append(model.mapper_embedder(mapper_idx))
+        if model.do_song_position_embed:
+            conds.append(model.song_pos_embedder(song_position))
+        return torch.cat(conds, -1) if conds else None
+
+
+def reference_encode(model, audio: torch.Tensor, cond: torch.Tensor = None) -> torch.Tensor:
+    """mel (| conditioning vectors repeated over the frames) -> encoder_embedder -> T5 encoder, called by hand
+    (work-around for the positional `inputs_embeds` bug at modeling_mapperatorinator.py:438-443; SURVEY.md headline
+    finding 3); the concatenation is :411-412."""
     with torch.no_grad():
         mel = model.spectrogram(audio).to(model.transformer.dtype)
+        if cond is not None:
+            mel = torch.cat([mel, cond.to(mel.dtype).unsqueeze(1).expand(-1, mel.shape[1], -1)], -1)
         emb = model.encoder_embedder(mel)
         return model.transformer.encoder(inputs_embeds=emb).last_hidden_state
 
@@ -122,7 +144,7 @@ def default_generate_kwargs(max_length: int, **over):
 
 
 def reference_generate(model, tok, audio, prompt, generate_kwargs, attention_mask=None, negative_prompt=None,
-                       negative_mask=None, record_scores=None):
+                       negative_mask=None, record_scores=None, cond=None):
     """The reference's own `model_generate` (server.py:83-156) via the `encoder_outputs` route.
     `record_scores`: a list that receives the processed scores of every step (what the merged
     LogitsProcessorList returns inside HF `_sample`), observed without touching reference code."""
@@ -130,7 +152,7 @@ def reference_generate(model, tok, audio, prompt, generate_kwargs, attention_mas
     from osuT5.osuT5.inference.server import model_generate
     from transformers import LogitsProcessorList
     from transformers.modeling_outputs import BaseModelOutput
-    enc = reference_encode(model, audio)
+    enc = reference_encode(model, audio, cond)
     if attention_mask is None:
         attention_mask = prompt.ne(0)
     mk = dict(inputs=audio, encoder_outputs=BaseModelOutput(last_hidden_state=enc),

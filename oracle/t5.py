@@ -123,8 +123,12 @@ class T5Oracle:
         return tab[bucket(rel, False, self.nb, self.md)].permute(2, 0, 1)[None]  # (1,H,q,klen)
 
     # ---- encoder ---------------------------------------------------------------------------
-    def embed_mel(self, mel):
+    def embed_mel(self, mel, cond=None):
+        """`cond` (B, cond_size): the per-row conditioning vectors, repeated over the frames and concatenated to the mel
+        frames in front of encoder_embedder (modeling_mapperatorinator.py:411-414)."""
         r, sd = self.r, self.sd
+        if cond is not None:
+            mel = torch.cat([mel, cond.to(mel.dtype).unsqueeze(1).expand(-1, mel.shape[1], -1)], -1)
         return r(mel) @ sd["encoder_embedder.weight"].t() + sd["encoder_embedder.bias"]
 
     def encoder(self, h):
@@ -143,9 +147,9 @@ class T5Oracle:
             h = h + self._ffn(n, b + "layer.1.DenseReluDense.")
         return rms_norm(h, sd["transformer.encoder.final_layer_norm.weight"], self.eps)
 
-    def encode_audio(self, audio, n_mels=388):
+    def encode_audio(self, audio, n_mels=388, cond=None):
         mel = omel.mel_spectrogram(audio, n_mels=n_mels)
-        return self.encoder(self.embed_mel(mel))
+        return self.encoder(self.embed_mel(mel, cond))
 
     # ---- decoder ---------------------------------------------------------------------------
     def cross_kv(self, enc):

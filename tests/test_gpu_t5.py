@@ -645,3 +645,31 @@ def test_window_scheduler_matches_sequential_loop():
             assert a.shape == b.shape and torch.equal(a, b), (k, w, a.tolist(), b.tolist())
     # fewer decode calls than windows: songs were interleaved
     assert stats["decode_calls"] < sum(n_windows)
+
+
+def test_conditioning_embedders_fp32_match_reference_golden():
+    """tests/golden/t5_tiny_cond.npz: the reference wrapper with its difficulty / mapper-style / song-position embedders on
+    (modeling_mapperatorinator.py:104-128, 395-414).  `model_generate` with the same `difficulty` / `mapper_idx` /
+    `song_position` model kwargs must return the reference's greedy ids bit for bit (fp32 storage): the embedders run on
+    the host, their output reaches the device as the per-chunk row bias of the encoder input projection
+    (mh_t5_encode_cond).  The encoder states are held to the golden slice."""
+    from test_oracle_pinned import _cond_case
+    from mapperatorinator_amd.modeling import MapperatorinatorHIP
+    from mapperatorinator_amd.server import model_generate
+    from mapperatorinator_amd.t5_engine import T5_PRESETS
+    g, tok, sd, audio = _cond_case()
+    tgt = int(g["tgt_len"])
+    model = MapperatorinatorHIP(sd, T5_PRESETS["tiny"], vocab_size_in=tok.vocab_size_in, vocab_size_out=tok.vocab_size_out,
+                                src_seq_len=int(g["src_len"]), tgt_seq_len=tgt, dtype=torch.float32)
+    assert model.cond.active
+    prompt = torch.from_numpy(g["prompt"])
+    mk = dict(inputs=audio, decoder_input_ids=prompt, decoder_attention_mask=prompt.ne(0),
+              difficulty=torch.from_numpy(g["difficulty"]), mapper_idx=torch.from_numpy(g["mapper_idx"]),
+              song_position=torch.from_numpy(g["song_position"]))
+    ids, _ = model_generate(model, tok, mk, gen_kwargs(tgt))
+    assert ids.shape == g["ids"].shape and np.array_equal(ids.numpy(), g["ids"]), np.argwhere(ids.numpy() != g["ids"])[:3]
+    enc = model.get_encoder()(frames=audio, difficulty=mk["difficulty"], mapper_idx=mk["mapper_idx"],
+                              song_position=mk["song_position"]).last_hidden_state.float().cpu()
+    assert np.abs(enc[:, ::13, ::7].numpy() - g["enc_slice"]).max() < 2e-4
+    with pytest.raises(ValueError):
+        model_generate(model, tok, dict(inputs=audio, decoder_input_ids=prompt, decoder_attention_mask=prompt.ne(0)), gen_kwargs(tgt))
