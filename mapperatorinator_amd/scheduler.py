@@ -39,6 +39,9 @@ class SongJob:
     prompt_fn: Callable[[int], dict]
     on_result: Callable[[int, torch.Tensor, dict], None]
     generate_kwargs: dict = dataclasses.field(default_factory=dict)
+    # models with conditioning embedders: window index -> dict(difficulty=, mapper_idx=, song_position=, beatmap_idx=) of
+    # scalars / (2,) for THIS window (the reference sets song_position per window, processor.py:341-345)
+    conditioning_fn: Optional[Callable[[int], dict]] = None
 
 
 def _left_pad(rows, pad_id: int, dtype):
@@ -54,9 +57,6 @@ class SequentialWindowScheduler:
         if decode_batch > 64 or decode_batch < 1:
             raise ValueError("decode_batch must be in [1, 64] (32 at most when windows run under classifier-free guidance)")
         self.model, self.tokenizer = model, tokenizer
-        if getattr(getattr(model, "cond", None), "active", False):
-            raise NotImplementedError("the window scheduler does not carry per-window conditioning inputs yet "
-                                      "(song_position changes per window: processor.py:341-345)")
         self.engine = model.engine
         self.encode_batch, self.decode_batch = int(encode_batch), int(decode_batch)
         self.stats = dict(windows=0, decode_calls=0, encode_calls=0, generated_tokens=0, elapsed_seconds=0.0)
@@ -67,11 +67,13 @@ class SequentialWindowScheduler:
         """-> per job a tensor [n_dec_layers, 2, n_windows, H, L, 64] of resident cross-attention K/V."""
         eng = self.engine
         flat = torch.cat([j.frames for j in jobs], 0).to(eng.device, torch.float32)
+        row_bias = self._row_bias(jobs)
         parts = []
         eng._enter()
         with eng.on_stream():
             for a in range(0, flat.shape[0], self.encode_batch):
-                parts.append(eng.cross_kv(eng.encode_mel(eng.mel(flat[a:a + self.encode_batch]))))
+                rb = None if row_bias is None else row_bias[a:a + self.encode_batch]
+                parts.append(eng.cross_kv(eng.encode_mel(eng.mel(flat[a:a + self.encode_batch]), row_bias=rb)))
                 self.stats["encode_calls"] += 1
             kv = torch.cat(parts, 2) if len(parts) > 1 else parts[0]
         eng._leave()
@@ -80,6 +82,32 @@ class SequentialWindowScheduler:
             out.append(kv[:, :, a:a + j.frames.shape[0]])
             a += j.frames.shape[0]
         return out
+
+    def _row_bias(self, jobs):
+        """(total windows, d_model) fp32 for models with conditioning embedders (one row per window, in `frames` order),
+        None otherwise."""
+        cond = getattr(self.model, "cond", None)
+        if cond is None or not cond.active:
+            return None
+        keys = ("beatmap_idx", "difficulty", "mapper_idx", "song_position")
+        rows = {k: [] for k in keys}
+        for j in jobs:
+            if j.conditioning_fn is None:
+                raise ValueError("this model has conditioning embedders: every SongJob needs a conditioning_fn")
+            for w in range(j.frames.shape[0]):
+                kw = j.conditioning_fn(w)
+                for k in keys:
+                    rows[k].append(kw.get(k))
+        n = len(rows["difficulty"])
+        kw = {}
+        for k in keys:
+            if all(v is None for v in rows[k]):
+                continue
+            if any(v is None for v in rows[k]):
+                raise ValueError(f"conditioning input {k!r} is given for some windows only")
+            kw[k] = torch.stack([torch.as_tensor(v, dtype=torch.float32 if k in ("difficulty", "song_position") else torch.long)
+                                 for v in rows[k]])
+        return cond.row_bias(cond.vectors(n, **kw), self.model.dtype)
 
     # ---- stage 2: waves of dependent windows -----------------------------------------------------------------
     @torch.no_grad()

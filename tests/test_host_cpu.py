@@ -251,6 +251,7 @@ class _StandInEngine:
         self.device = torch.device("cpu")
         self.packed = types.SimpleNamespace(vocab_out=vocab_out)
         self.calls = []
+        self.row_bias_seen = []
         self._ctx = contextlib.nullcontext
         self.eos_every = eos_every
 
@@ -259,7 +260,9 @@ class _StandInEngine:
     def synchronize(self): pass
     def on_stream(self): return self._ctx()
     def mel(self, audio): return audio
-    def encode_mel(self, mel): return mel
+    def encode_mel(self, mel, row_bias=None):
+        self.row_bias_seen.append(None if row_bias is None else row_bias.clone())
+        return mel
 
     def cross_kv(self, enc):                                   # [layers=1][k|v=2][B][H=1][L=1][64]: the fingerprint
         fp = (enc.abs().sum(-1) * 1000).round().long() % 997
@@ -378,3 +381,39 @@ def test_window_scheduler_waves_equal_the_sequential_loop_on_a_stand_in_engine(c
     assert stats["decode_calls"] < sum(n_windows)                                      # songs were interleaved
     for c in eng.calls:
         assert c["B"] <= 4 and c["cfg"] == (cfg_scale > 1) and (c["B"] % 2 == 0 or not c["cfg"])
+
+
+def test_window_scheduler_hands_per_window_conditioning_to_the_encoder():
+    """Models with conditioning embedders: `SongJob.conditioning_fn(window)` -> one row of the encoder's row bias per window,
+    in the order the windows are encoded (song_position differs per window: processor.py:341-345)."""
+    import types
+    from mapperatorinator_amd import Tokenizer
+    from mapperatorinator_amd.conditioning import ConditioningEmbedders
+    from mapperatorinator_amd.scheduler import SequentialWindowScheduler, SongJob
+    from mapperatorinator_amd.t5_engine import T5_PRESETS
+    from mapperatorinator_amd.testing import add_random_conditioning, random_t5_state_dict
+    tok = Tokenizer.benchmark_vocab(src_seq_len=251)
+    sd = random_t5_state_dict(T5_PRESETS["tiny"], tok.vocab_size_in, tok.vocab_size_out, seed=3)
+    add_random_conditioning(sd, 128, 388, 16, 11, seed=1)
+    cond = ConditioningEmbedders(sd, 388)
+    eng = _StandInEngine(tok.vocab_size_out, eos_every=5)
+    model = types.SimpleNamespace(engine=eng, config=types.SimpleNamespace(max_target_positions=24), cond=cond, dtype=torch.float32)
+    g = torch.Generator().manual_seed(1)
+    n_windows = [2, 3]
+    songs = [torch.randn(n, 64, generator=g) for n in n_windows]
+
+    def cond_for(k, w):
+        return dict(difficulty=3.0 + k, mapper_idx=-1 if k == 0 else 4, song_position=[w / 3, (w + 1) / 3])
+    jobs = [SongJob(frames=songs[k], prompt_fn=lambda w: dict(decoder_input_ids=torch.tensor([[tok.sos_id]])),
+                    on_result=lambda *a: None, generate_kwargs=dict(max_length=24, do_sample=False),
+                    conditioning_fn=(lambda w, k=k: cond_for(k, w))) for k in range(2)]
+    SequentialWindowScheduler(model, tok, encode_batch=4, decode_batch=4).run(jobs)
+    seen = torch.cat([r for r in eng.row_bias_seen], 0)
+    flat = [cond_for(k, w) for k in range(2) for w in range(n_windows[k])]
+    want = cond.row_bias(cond.vectors(5, difficulty=torch.tensor([f["difficulty"] for f in flat]),
+                                      mapper_idx=torch.tensor([f["mapper_idx"] for f in flat]),
+                                      song_position=torch.tensor([f["song_position"] for f in flat])), torch.float32)
+    assert seen.shape == want.shape and torch.allclose(seen, want)
+    with pytest.raises(ValueError):
+        SequentialWindowScheduler(model, tok).run([SongJob(frames=songs[0], prompt_fn=jobs[0].prompt_fn, on_result=lambda *a: None,
+                                                             generate_kwargs=dict(max_length=24, do_sample=False))])
