@@ -82,7 +82,12 @@ class DiffusionPipelineHIP:
                  refine_model: Optional[DiTHIP] = None, refine_iters: int = 10, random_init: bool = False,
                  pad_sequence: bool = False, start_time: Optional[float] = None, end_time: Optional[float] = None):
         if pad_sequence:
-            raise NotImplementedError("pad_sequence=True pads the band mask with attendable columns; not on the HIP path")
+            # reference diffusion_pipeline.py:186-193 pads every window to max_seq_len, pads the band mask with "allowed" and
+            # builds a key_padding_mask -- which DiTBlock.forward never hands to its attention (models.py:133-150): every
+            # real query then attends all the zero-embedded pad tokens, so padding CHANGES the real positions
+            # (tests/test_oracle_pinned.py::test_reference_dit_padding_changes_real_positions).  That mask is no band;
+            # reproducing the quirk is not on the HIP path.
+            raise NotImplementedError("pad_sequence=True (band mask + attendable pad tokens) is not on the HIP path")
         if not 0 <= 2 * overlap_buffer < max_seq_len:
             raise ValueError("overlap_buffer must be less than half of max_seq_len")
         self.model, self.refine_model = model, refine_model
