@@ -223,6 +223,8 @@ __global__ __launch_bounds__(256) void dec_init_kernel(SampleP p, int chain_rows
   for (int i = threadIdx.x; i < p.d; i += 256) p.h[(long)lb * p.d + i] = Elem<T>::to_f32(e[i]);
 }
 
+constexpr int kSampleRegs = 16;   // the register sampling path holds up to 16 ids per thread: vocabularies of <= 4096 ids
+
 // One workgroup per returned row (per CFG pair): processors -> selection -> bookkeeping -> next-token embedding.
 // Processor order = server.py:106-134: CFG -> MonotonicTimeShift -> TimeshiftBias -> (Conditional)Temperature ->
 // LookbackBias, then HF's own top-k / top-p warpers and the multinomial draw.
@@ -230,6 +232,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void dec_sample_kernel(SampleP p) {
   __shared__ float sf[8];
   __shared__ int si[8];
+  __shared__ float s3[12];
+  __shared__ float s_e[256 * kSampleRegs];
   __shared__ int s_tok[2];
   __shared__ float s_sum, s_temp;
   __shared__ int s_timed;
@@ -366,9 +370,112 @@ __global__ __launch_bounds__(256) void dec_sample_kernel(SampleP p) {
     }
     __syncthreads();
     int tok = si[4];
-    if (sp.do_sample) {
-      // softmax sampling over the processed scores with optional top-k / top-p truncation.
-      // Threshold search instead of a sort: V is a few thousand, a wave-parallel bisection is cheap.
+    if (sp.do_sample && p.V <= 256 * kSampleRegs) {
+      // softmax sampling with optional top-k / top-p truncation, the processed scores of this row in REGISTERS (thread t
+      // holds ids t, t + 256, ...): both thresholds by 4-ary search (three candidate thresholds per block reduction),
+      // the draw by a block-wide prefix sum in id order.  The reference's default user settings sample (top_p 0.9,
+      // configs/inference/v32.yaml:12-13): the memory-bound bisection + serial scan below cost 350 us per token step.
+      const float mx = sf[4];
+      __syncthreads();   // sf / s3 are reduction scratch below
+      float xr[kSampleRegs];
+#pragma unroll
+      for (int i = 0; i < kSampleRegs; ++i) {
+        const int v = tid + 256 * i;
+        xr[i] = v < p.V ? fin[v] - mx : -INFINITY;     // this thread's own stores (consider)
+      }
+      auto reduce3 = [&](float a, float b, float c, float (&out)[3]) {
+        a = wave_sum(a); b = wave_sum(b); c = wave_sum(c);
+        __syncthreads();
+        if (lane == 0) { s3[wid * 3] = a; s3[wid * 3 + 1] = b; s3[wid * 3 + 2] = c; }
+        __syncthreads();
+        out[0] = s3[0] + s3[3] + s3[6] + s3[9];
+        out[1] = s3[1] + s3[4] + s3[7] + s3[10];
+        out[2] = s3[2] + s3[5] + s3[8] + s3[11];
+      };
+      float thr = -INFINITY;
+      if (sp.top_k > 0 && sp.top_k < p.V) {   // largest threshold (to 80 / 4^14) that still keeps >= top_k ids
+        float lo = -80.f, hi = 0.f;
+        for (int it = 0; it < 14; ++it) {
+          const float q = 0.25f * (hi - lo), t1 = lo + q, t2 = lo + 2.f * q, t3 = lo + 3.f * q;
+          float c1 = 0.f, c2 = 0.f, c3 = 0.f;
+#pragma unroll
+          for (int i = 0; i < kSampleRegs; ++i) { c1 += xr[i] >= t1 ? 1.f : 0.f; c2 += xr[i] >= t2 ? 1.f : 0.f; c3 += xr[i] >= t3 ? 1.f : 0.f; }
+          float r[3];
+          reduce3(c1, c2, c3, r);
+          const float k = (float)sp.top_k;
+          if (r[2] >= k) lo = t3; else if (r[1] >= k) { lo = t2; hi = t3; } else if (r[0] >= k) { lo = t1; hi = t2; } else hi = t1;
+        }
+        thr = lo;
+      }
+      float er[kSampleRegs];
+      float part = 0.f;
+#pragma unroll
+      for (int i = 0; i < kSampleRegs; ++i) { er[i] = xr[i] >= thr ? __expf(xr[i]) : 0.f; part += er[i]; }
+      const float total = block_sum(part, sf);
+      if (sp.top_p < 1.0f) {   // largest probability threshold whose kept mass still reaches top_p
+        float lo = 0.f, hi = 1.f;
+        const float inv = 1.0f / total;
+        for (int it = 0; it < 12; ++it) {
+          const float q = 0.25f * (hi - lo), t1 = lo + q, t2 = lo + 2.f * q, t3 = lo + 3.f * q;
+          float m1 = 0.f, m2 = 0.f, m3 = 0.f;
+#pragma unroll
+          for (int i = 0; i < kSampleRegs; ++i) {
+            const float pr = er[i] * inv;
+            m1 += pr >= t1 ? pr : 0.f; m2 += pr >= t2 ? pr : 0.f; m3 += pr >= t3 ? pr : 0.f;
+          }
+          float r[3];
+          reduce3(m1, m2, m3, r);
+          if (r[2] >= sp.top_p) lo = t3; else if (r[1] >= sp.top_p) { lo = t2; hi = t3; } else if (r[0] >= sp.top_p) { lo = t1; hi = t2; } else hi = t1;
+        }
+#pragma unroll
+        for (int i = 0; i < kSampleRegs; ++i) er[i] = (er[i] * inv >= lo) ? er[i] : 0.f;
+      }
+      // kept weights in id order -> contiguous ownership (thread t: ids [t C, t C + C)) -> inclusive prefix -> first id
+      // whose running sum reaches u (else the last kept id), as a sequential scan in id order would pick
+#pragma unroll
+      for (int i = 0; i < kSampleRegs; ++i) {
+        const int v = tid + 256 * i;
+        if (v < p.V) s_e[v] = er[i];
+      }
+      if (tid == 0) { si[5] = 0x7fffffff; si[6] = -1; }
+      __syncthreads();
+      const int Cn = (p.V + 255) / 256;
+      float loc[kSampleRegs];
+      float run = 0.f;
+#pragma unroll
+      for (int i = 0; i < kSampleRegs; ++i) {
+        const int v = tid * Cn + i;
+        const float e = (i < Cn && v < p.V) ? s_e[v] : 0.f;
+        run += e;
+        loc[i] = run;
+      }
+      float incl = run;                       // inclusive scan of the thread totals over the block
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const float up = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += up;
+      }
+      if (lane == 63) sf[wid] = incl;
+      __syncthreads();
+      float base = incl - run;
+      for (int w2 = 0; w2 < wid; ++w2) base += sf[w2];
+      const float mass = sf[0] + sf[1] + sf[2] + sf[3];
+      const float u = uniform01(sp.seed, (uint32_t)gr + sp.rng_row0, (uint32_t)col) * mass;
+      int first = 0x7fffffff, last = -1;
+      float prev = 0.f;
+#pragma unroll
+      for (int i = 0; i < kSampleRegs; ++i) {
+        const int v = tid * Cn + i;
+        const bool kept = i < Cn && v < p.V && loc[i] > prev;     // a kept id carries positive weight
+        if (kept) { last = v; if (base + loc[i] >= u && first == 0x7fffffff) first = v; }
+        prev = loc[i];
+      }
+      if (first != 0x7fffffff) atomicMin(&si[5], first);
+      if (last >= 0) atomicMax(&si[6], last);
+      __syncthreads();
+      tok = si[5] != 0x7fffffff ? si[5] : (si[6] >= 0 ? si[6] : tok);
+    } else if (sp.do_sample) {
+      // (vocabularies beyond 256 * kSampleRegs ids: the same search through memory)
       const float mx = sf[4];
       __syncthreads();   // sf[4] is reused as reduction scratch below
       float thr = -INFINITY;
