@@ -391,6 +391,28 @@ def main():
                                        "mode and not `value`",
                                "same_tokens_as_bf16_kv": round(float((t8 == tokens).float().mean().item()), 4)}
 
+    # ---- the reference's default USER settings: sampling with temperature 0.9 / top_p 0.9 (configs/inference/v32.yaml:12-13) ----
+    if not args.no_extras and rank == 0:
+        sp_s, _ = build_sampling(tok, dict(gk, do_sample=True, top_p=0.9, temperature=0.9, seed=1), tgt_len)
+
+        def sample_step():
+            eng._enter()
+            with torch.cuda.stream(eng.stream):
+                kv_ = eng.cross_kv(eng.encode_mel(eng.mel(audio)))
+                t_, _, _ = eng.decode(kv_, prompt, None, eos_table, sp_s, poll_every=64)
+            eng._leave()
+            return t_
+        sample_step()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            ts_ = sample_step()
+        torch.cuda.synchronize(dev)
+        dts = (time.perf_counter() - t0) / args.steps
+        aux["sampling_top_p"] = {"tokens_per_s": round(int((ts_[:, 1:] != 0).sum().item()) / dts, 1), "ms_per_step": round(dts * 1e3, 2),
+                                 "note": "same workload with do_sample, temperature 0.9, top_p 0.9 (the reference's default user settings); "
+                                         "thresholds and the draw on the device, per row"}
+
     # ---- configs[0] on the GPU, and the end-to-end rate through the reference-shaped boundary ---------------------
     if not args.no_extras:
         e2e_audio = audio_host                                                       # HOST tensors, as server.py:86 receives them
