@@ -93,6 +93,10 @@ int mh_struct_size(int which);
  * (mapperatorinator_amd/mel.py) and passed in:
  *   fb_start[n_mels], fb_len[n_mels], fb_off[n_mels] (int32), fb_w[sum(len)] fp32,
  *   window[n_fft] fp32 (periodic hann), twiddle[n_fft] (cos, sin) pairs fp32.
+ * log_scale: bit 0 = log1p of the mel energies (spectrogram.py:79-80); bit 1 = reflect instead of zero padding of the
+ *   n_fft/2 samples either side (the `torchaudio` parameterisation of the Whisper-family configs:
+ *   configs/model/whisper_base_v3.yaml:16-21 -- torch.stft(center=True, pad_mode="reflect"), HTK filterbank without
+ *   area normalisation; the filterbank is whatever the host passes in).
  * n_fft must be 1024 (the only size the reference configs use: configs/model/default.yaml:29-37). */
 int mh_mel(const float* audio, int B, int n_samples, int n_fft, int hop, int n_mels,
            const float* window, const float* twiddle, const int32_t* fb_start, const int32_t* fb_len,

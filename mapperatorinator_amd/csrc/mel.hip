@@ -19,7 +19,7 @@ struct MelP {
   const float* audio; int B, n_samples, hop, n_mels, n_frames;
   const float* window; const float2* tw;
   const int32_t* fb_start; const int32_t* fb_len; const int32_t* fb_off; const float* fb_w;
-  int log_scale; void* out; int ld_out;
+  int log_scale, reflect; void* out; int ld_out;
 };
 
 __device__ inline float2 cmul_conj_tw(float2 v, float2 w) {  // v * (w.x - i w.y)  == v * exp(-i theta)
@@ -43,8 +43,19 @@ __global__ __launch_bounds__(256) void mel_kernel(MelP p) {
     const float w = p.window[n];
     const int i0 = f0 * p.hop + n - NFFT / 2;
     const int i1 = i0 + p.hop;
-    const float a = (i0 >= 0 && i0 < p.n_samples) ? au[i0] : 0.f;
-    const float c = (has1 && i1 >= 0 && i1 < p.n_samples) ? au[i1] : 0.f;
+    float a, c;
+    if (p.reflect) {   // torch.stft center=True, pad_mode='reflect': sample -i for i < 0, 2 (Ns - 1) - i beyond the end
+      const int last = p.n_samples - 1;
+      int j0 = i0 < 0 ? -i0 : (i0 > last ? 2 * last - i0 : i0);
+      int j1 = i1 < 0 ? -i1 : (i1 > last ? 2 * last - i1 : i1);
+      j0 = j0 < 0 ? 0 : (j0 > last ? last : j0);
+      j1 = j1 < 0 ? 0 : (j1 > last ? last : j1);
+      a = au[j0];
+      c = has1 ? au[j1] : 0.f;
+    } else {
+      a = (i0 >= 0 && i0 < p.n_samples) ? au[i0] : 0.f;
+      c = (has1 && i1 >= 0 && i1 < p.n_samples) ? au[i1] : 0.f;
+    }
     v[r] = make_float2(a * w, c * w);
   }
   int cur = 0;
@@ -121,7 +132,7 @@ extern "C" int mh_mel(const float* audio, int B, int n_samples, int n_fft, int h
   p.n_frames = n_samples / hop + 1;
   p.window = window; p.tw = reinterpret_cast<const float2*>(twiddle);
   p.fb_start = fb_start; p.fb_len = fb_len; p.fb_off = fb_off; p.fb_w = fb_w;
-  p.log_scale = log_scale; p.out = out; p.ld_out = ld_out;
+  p.log_scale = log_scale & 1; p.reflect = (log_scale >> 1) & 1; p.out = out; p.ld_out = ld_out;
   dim3 grid((p.n_frames + 1) / 2, B), block(256);
   if (out_dtype == MH_BF16)
     hipLaunchKernelGGL(mel_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, p);

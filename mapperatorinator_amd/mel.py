@@ -1,8 +1,9 @@
 """Host side of K1: `MelSpectrogram` with the reference's constructor/forward contract
 (osuT5/osuT5/model/spectrogram.py:8-83), computed by `mh_mel` (csrc/mel.hip).
 
-Only the nnAudio parameterisation the T5 configs use is built (center=True, pad_mode='constant',
-hann, power 2, Slaney area-normalised filterbank; configs/model/default.yaml:29-37).  The
+Two parameterisations: the nnAudio one of the T5 configs (center=True, pad_mode='constant', hann, power 2, Slaney
+area-normalised filterbank; configs/model/default.yaml:29-37) and the torchaudio one of the Whisper-family configs
+(reflect padding, HTK filterbank without normalisation, log1p; configs/model/whisper_base_v3.yaml:16-21).  The
 host builds three small tables once (window, FFT twiddles, CSR filterbank) in float64 and hands
 fp32 copies to the kernel.
 """
@@ -51,21 +52,37 @@ def slaney_filterbank(sr: int, n_fft: int, n_mels: int, fmin: float, fmax: float
     return fb
 
 
+def htk_filterbank(sr: int, n_fft: int, n_mels: int, fmin: float, fmax: float) -> np.ndarray:
+    """[n_mels, n_fft//2+1] float32 triangular filters on the HTK mel scale, no area normalisation: what
+    `torchaudio.transforms.MelSpectrogram` builds by default (`melscale_fbanks(norm=None, mel_scale="htk")`: mel =
+    2595 log10(1 + f / 700), n_mels + 2 points equally spaced in mel, rising / falling slopes over the FFT bin centres)."""
+    n_bins = n_fft // 2 + 1
+    fft_f = np.linspace(0.0, sr // 2, n_bins)
+    m_lo, m_hi = 2595.0 * np.log10(1.0 + fmin / 700.0), 2595.0 * np.log10(1.0 + fmax / 700.0)
+    pts = 700.0 * (10.0 ** (np.linspace(m_lo, m_hi, n_mels + 2) / 2595.0) - 1.0)
+    width = np.diff(pts)
+    slopes = pts[None, :] - fft_f[:, None]                      # (bins, n_mels + 2)
+    down = -slopes[:, :-2] / width[:-1]
+    up = slopes[:, 2:] / width[1:]
+    return np.maximum(0.0, np.minimum(down, up)).T.astype(np.float32)
+
+
 class MelSpectrogram(torch.nn.Module):
-    """Same signature as the reference wrapper (`n_ftt` spelling included)."""
+    """Same signature as the reference wrapper (`n_ftt` spelling included).  implementation "nnAudio" (Slaney filterbank,
+    area-normalised) or "torchaudio" (HTK filterbank, no normalisation); pad_mode "constant" or "reflect"."""
 
     def __init__(self, implementation: str = "nnAudio", log_scale: bool = False, sample_rate: int = 16000,
                  n_ftt: int = 1024, n_mels: int = 388, hop_length: int = 128, f_min: int = 0,
                  f_max: int = 8000, pad_mode: str = "constant"):
         super().__init__()
-        if implementation != "nnAudio" or pad_mode != "constant":
-            raise NotImplementedError("the HIP mel frontend implements the nnAudio / constant-pad configuration "
-                                      "(torchaudio log-mel is a 'next' row, SURVEY.md 8f rank 2)")
+        if implementation not in ("nnAudio", "torchaudio") or pad_mode not in ("constant", "reflect"):
+            raise NotImplementedError(f"mel frontend: implementation {implementation!r} / pad_mode {pad_mode!r} is not built")
         if n_ftt != 1024:
             raise NotImplementedError("mh_mel is built for n_fft=1024")
         self.log_scale, self.sample_rate = bool(log_scale), sample_rate
         self.n_fft, self.n_mels, self.hop_length = n_ftt, n_mels, hop_length
-        fb = slaney_filterbank(sample_rate, n_ftt, n_mels, float(f_min), float(f_max))
+        self.reflect = pad_mode == "reflect"
+        fb = (slaney_filterbank if implementation == "nnAudio" else htk_filterbank)(sample_rate, n_ftt, n_mels, float(f_min), float(f_max))
         starts, lens, offs, ws = [], [], [], []
         off = 0
         for i in range(n_mels):
@@ -106,7 +123,7 @@ class MelSpectrogram(torch.nn.Module):
         lib = _lib.load()
         rc = lib.mh_mel(x.data_ptr(), B, ns, self.n_fft, self.hop_length, self.n_mels, self.window.data_ptr(),
                         self.twiddle.data_ptr(), self.fb_start.data_ptr(), self.fb_len.data_ptr(),
-                        self.fb_off.data_ptr(), self.fb_w.data_ptr(), int(self.log_scale), out.data_ptr(), ld_out,
+                        self.fb_off.data_ptr(), self.fb_w.data_ptr(), int(self.log_scale) | (2 if self.reflect else 0), out.data_ptr(), ld_out,
                         _lib.MH_BF16 if out_dtype == torch.bfloat16 else _lib.MH_F32,
                         torch.cuda.current_stream(x.device).cuda_stream)
         _lib.check(rc, "mh_mel")

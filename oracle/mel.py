@@ -143,3 +143,28 @@ def mel_spectrogram_f64(audio: np.ndarray, sr=16000, n_fft=1024, n_mels=388, hop
     spec = np.abs(np.fft.rfft(frames, axis=-1)) ** 2  # (B, L, bins)
     fb = mel_filterbank(sr, n_fft, n_mels, fmin, fmax).astype(np.float64)
     return spec @ fb.T
+
+
+def mel_spectrogram_torchaudio(audio, n_fft=1024, hop=128, n_mels=128, sr=16000, f_min=20.0, f_max=8000.0, pad_mode="reflect",
+                               log_scale=True):
+    """The `torchaudio` branch of the reference wrapper (osuT5/osuT5/model/spectrogram.py:38-49, 79-83) restated with
+    plain torch: torchaudio.transforms.MelSpectrogram = torch.stft (periodic hann, center=True, `pad_mode`, onesided,
+    power 2) followed by `melscale_fbanks(n_freqs, f_min, f_max, n_mels, sample_rate, norm=None, mel_scale="htk")`.
+    parity unpinned: torchaudio is not installed here; `torch.stft` is the routine it calls.
+    audio (B, Ns) -> (B, Ns // hop + 1, n_mels) float32."""
+    import math
+    x = audio.to(torch.float32)
+    win = torch.hann_window(n_fft, periodic=True, dtype=torch.float32)
+    spec = torch.stft(x, n_fft, hop_length=hop, win_length=n_fft, window=win, center=True, pad_mode=pad_mode,
+                      normalized=False, onesided=True, return_complex=True)
+    power = spec.real ** 2 + spec.imag ** 2                                   # (B, bins, frames)
+    n_bins = n_fft // 2 + 1
+    all_freqs = torch.linspace(0, sr // 2, n_bins, dtype=torch.float64)
+    m_min = 2595.0 * math.log10(1.0 + f_min / 700.0)
+    m_max = 2595.0 * math.log10(1.0 + f_max / 700.0)
+    f_pts = 700.0 * (10.0 ** (torch.linspace(m_min, m_max, n_mels + 2, dtype=torch.float64) / 2595.0) - 1.0)
+    f_diff = f_pts[1:] - f_pts[:-1]
+    slopes = f_pts.unsqueeze(0) - all_freqs.unsqueeze(1)
+    fb = torch.clamp(torch.minimum(-slopes[:, :-2] / f_diff[:-1], slopes[:, 2:] / f_diff[1:]), min=0.0).to(torch.float32)
+    mel = torch.matmul(power.transpose(1, 2), fb)                            # (B, frames, n_mels)
+    return torch.log1p(mel) if log_scale else mel

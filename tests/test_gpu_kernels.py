@@ -355,6 +355,29 @@ def test_mel_vs_oracle(B, ns):
     assert torch.allclose(pad[..., :388].float().cpu(), want, rtol=1e-2, atol=1e-4 * scale)
 
 
+@pytest.mark.parametrize("ns", [16000, 160000, 12345])
+def test_mel_torchaudio_parameterisation_vs_oracle(ns):
+    """The Whisper-family front-end settings (configs/model/whisper_base_v3.yaml:16-21: torchaudio, log-mel, 128 HTK mels
+    from 20 Hz, reflect padding) against the torch.stft restatement of that branch (oracle/mel.py; parity unpinned:
+    torchaudio itself is not installed).  The edge frames are the ones reflect padding changes."""
+    from mapperatorinator_amd.mel import MelSpectrogram
+    from mapperatorinator_amd.testing import synthetic_audio
+    from oracle import mel as omel
+    a = synthetic_audio(2, ns, seed=4)
+    m = MelSpectrogram(implementation="torchaudio", log_scale=True, n_mels=128, f_min=20, pad_mode="reflect").cuda()
+    got = m(a.cuda()).cpu()
+    want = omel.mel_spectrogram_torchaudio(a, n_mels=128, f_min=20.0, pad_mode="reflect", log_scale=True)
+    assert got.shape == want.shape == (2, ns // 128 + 1, 128)
+    err = (got - want).abs()
+    print(f"torchaudio-style log-mel: max |d| {err.max().item():.2e} (values up to {want.max().item():.2f}), "
+          f"first / last frame {err[:, 0].max().item():.2e} / {err[:, -1].max().item():.2e}")
+    assert err.max().item() < 2e-3                     # log1p domain
+    lin = MelSpectrogram(implementation="torchaudio", log_scale=False, n_mels=128, f_min=20, pad_mode="constant").cuda()(a.cuda()).cpu()
+    wl = omel.mel_spectrogram_torchaudio(a, n_mels=128, f_min=20.0, pad_mode="constant", log_scale=False)
+    assert (lin - wl).abs().max().item() < 1e-4 * wl.abs().max().item()
+    assert (got[:, 0] - torch.log1p(lin[:, 0])).abs().max().item() > 1e-3      # reflect padding really differs from zeros at the edge
+
+
 def test_mel_silence_and_tone():
     from mapperatorinator_amd.mel import MelSpectrogram
     m = MelSpectrogram().cuda()
