@@ -1,16 +1,22 @@
 // Device kernels of the KV-cached autoregressive T5 decode step (K5 / K6).
 //
-// One decode step of one layer is: [RMSNorm + QKV GEMV -> q, self-KV append] -> self-attention over the
-// cache -> [O GEMV + residual] -> [RMSNorm + cross-Q GEMV] -> cross-attention over the 1251 encoder
-// keys (THE HBM-bound kernel: B*H*L*64*2 elements per layer per step) -> [O GEMV + residual] ->
-// [RMSNorm + wi GEMV + gated GELU] -> [wo GEMV + residual]; then final RMSNorm + lm_head GEMV,
-// logits processors + token selection.  Every kernel reads the current position from device memory so
-// the whole step is one replayable hipGraph.
+// One token step of one layer is SIX dependent kernels per row chain (a chain = up to 16 rows; two chains run side by
+// side): [RMSNorm + this head's q / k / v projection + self-KV append + self-attention over the cache] -> [O GEMV +
+// residual] -> [RMSNorm + this head's query projection + cross-attention over the 1251 encoder keys: THE HBM-bound
+// kernel, B*H*L*64*2 elements per layer per step] -> [O GEMV + residual] -> [RMSNorm + wi GEMV + gated GELU] -> [wo GEMV
+// + residual]; then final RMSNorm + lm_head GEMV and the sampler (t5.hip).  Every kernel reads the current position
+// from device memory, so a chain's step is one replayable hipGraph.  (Option decode_fused_proj = 0 / 2 runs the q / k / v
+// and cross-query projections as stand-alone GEMVs in front of dec_self_attn_kernel / dec_cross_attn_kernel instead.)
 //
-// "Skinny" GEMVs (M = batch <= 64 rows) stream each weight row exactly once: a workgroup owns NS
-// 16-column strips of W, its 4 waves split K, MFMA 16x16 atoms do the (rows x 16) products with the
-// weight fragment loaded straight from HBM into registers (no LDS round trip for data used once), and
-// the 4 partial accumulators are combined through LDS in a fixed order (deterministic).
+// What shapes these kernels (measured): a dependent kernel costs ~3.3 us before it does anything (launch,
+// first-load latency, store flush), so each does its whole job in one or two memory round trips; the CU's load path is
+// charged per 128-byte line touched, so operands are loaded as whole lines (weights of the attention kernels' own
+// projections; the GEMVs' activations through a wave-private LDS patch) and only where that is impossible as MFMA-
+// fragment-shaped pieces; everything handed to the next kernel is stored write-through.
+//
+// GEMVs ("skinny GEMMs", M = rows of the chain): a workgroup owns one 16-column MFMA tile (4, 8 or 16 real columns),
+// its 4 or 8 waves split K, weight fragments go straight from L2 / HBM into registers (read once), the partial
+// accumulators are added through LDS in wave order (deterministic, independent of the batch).
 #pragma once
 #include <type_traits>
 
