@@ -189,7 +189,23 @@ def test_mel_host_tables():
     assert np.array_equal(dense, fb)
     assert m.n_frames(160000) == 1251
     with pytest.raises(NotImplementedError):
-        MelSpectrogram(implementation="torchaudio")
+        MelSpectrogram(implementation="librosa")
+    with pytest.raises(NotImplementedError):
+        MelSpectrogram(pad_mode="replicate")
+    # the torchaudio parameterisation of the Whisper-family configs: HTK triangles without area normalisation; the table
+    # the kernel receives equals what the torch.stft restatement multiplies by (recovered from an impulse power spectrum)
+    from mapperatorinator_amd.mel import htk_filterbank
+    t = MelSpectrogram(implementation="torchaudio", log_scale=True, n_mels=128, f_min=20, pad_mode="reflect")
+    assert t.reflect and t.log_scale and t.n_mels == 128
+    hfb = htk_filterbank(16000, 1024, 128, 20.0, 8000.0)
+    assert hfb.shape == (128, 513) and hfb.min() >= 0 and hfb.max() <= 1.0 + 1e-6
+    peaks = hfb.argmax(1)
+    assert (np.diff(peaks) >= 0).all() and hfb[:, :1].sum() == 0          # rising centre frequencies, nothing below 20 Hz
+    dense = np.zeros_like(hfb)
+    for i in range(128):
+        s_, ln, of = int(t.fb_start[i]), int(t.fb_len[i]), int(t.fb_off[i])
+        dense[i, s_:s_ + ln] = t.fb_w[of:of + ln].numpy()
+    assert np.array_equal(dense, hfb)
 
 
 def test_diffusion_pipeline_host_glue():
