@@ -7,7 +7,9 @@ LIB := mapperatorinator_amd/lib/libmapperhip.so
 SRCS := $(CSRC)/api.hip $(CSRC)/gemm.hip $(CSRC)/norm.hip $(CSRC)/attention.hip $(CSRC)/mel.hip $(CSRC)/conv.hip $(CSRC)/t5.hip $(CSRC)/dit.hip
 OBJS := $(patsubst $(CSRC)/%.hip,$(OBJDIR)/%.o,$(SRCS))
 HDRS := $(wildcard $(CSRC)/*.hpp) include/mapperhip.h
-HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wno-unused-value -Wno-pass-failed
+# -amdgpu-kernarg-preload-count: leading scalar kernel arguments arrive in SGPRs with the wave launch (gfx950 firmware)
+# instead of through an s_load from the kernarg segment -- one memory round trip off every small dependent kernel
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wno-unused-value -Wno-pass-failed -mllvm -amdgpu-kernarg-preload-count=14
 
 all: $(LIB)
 
@@ -34,7 +36,13 @@ $(PROF_LIB): $(PROF_OBJS)
 
 prof: $(PROF_LIB)
 
+# A/B builds: `make variant NAME=x DEFS="-DMH_..."` -> mapperatorinator_amd/lib/libmapperhip_x.so (select with MAPPERHIP_LIB)
+variant:
+	@mkdir -p build/var_$(NAME)
+	for f in $(SRCS); do $(HIPCC) $(HIPFLAGS) $(DEFS) -c $$f -o build/var_$(NAME)/$$(basename $$f .hip).o & done; wait
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC build/var_$(NAME)/*.o -o mapperatorinator_amd/lib/libmapperhip_$(NAME).so
+
 clean:
 	rm -rf build $(LIB) $(PROF_LIB)
 
-.PHONY: all clean prof
+.PHONY: all clean prof variant

@@ -192,7 +192,11 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(AttnArgs p) {
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         *reinterpret_cast<T*>(Pw + (lg * 4 + r) * RS + (j * 16 + l15) * ES) = Elem<T>::from_f32(s[j][r]);
-    // (no barrier: the patch is private to this wave and the LDS operations of one wave execute in order)
+    // (no workgroup barrier: the patch is private to this wave and the LDS operations of one wave execute in order; the
+    // wave-scope fence only stops the COMPILER from moving the cross-lane reads below above these stores -- no instruction)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
     // ---- O += P V ----
 #pragma unroll

@@ -65,6 +65,7 @@ template <> __device__ inline void load8<float>(const float* p, float (&o)[8]) {
 // `global_load_dwordx4 ... nt` keeps the 1.5 GB/step K/V stream from evicting the decoder weights (226 MB) out of
 // the 256 MB Infinity Cache between token steps.
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
 template <typename T> __device__ inline void load8_stream(const T* p, float (&o)[8]);
 template <> __device__ inline void load8_stream<bf16_t>(const bf16_t* p, float (&o)[8]) {
   const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
@@ -82,7 +83,6 @@ template <> __device__ inline void load8_stream<float>(const float* p, float (&o
 }
 // OCP e4m3 rows (the fp8 copy of the cross-attention K / V): 8 elements = 8 bytes per lane
 struct fp8_t { uint8_t v; };
-typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
 typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 template <> __device__ inline void load8_stream<fp8_t>(const fp8_t* p, float (&o)[8]) {
   const u32x2_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(p));
@@ -118,8 +118,75 @@ template <> __device__ inline void store4<float>(float* p, float a, float b, flo
 // chip each chain's kernel boundaries also pay for the other chain's dirty lines.  With nothing dirty the boundary is
 // cheaper: tools/micro/gemv_probe, o-projection 3.53 -> 3.37 us alone, 4.60 -> 4.08 us beside a second chain; the
 // K = 2048 projection 6.35 -> 5.54 us (non-temporal stores: no gain).
+// hipcc's scheduler sinks loads next to their first use when it believes registers are scarce (`load, s_waitcnt vmcnt(0),
+// use, load, ...`: one memory round trip PER LOAD instead of one per kernel -- found in the 8-wave GEMV and, after an
+// unrelated edit, in the 4-wave one: tools/isa_mem_signature.py shows it).  The cure is to tell it that registers are
+// not scarce (amdgpu_waves_per_eu on the kernels below); __builtin_amdgcn_sched_barrier at this marker was tried and is
+// worse: the kernel's private arrays are then promoted to LDS (a dispatch-packet read plus LDS round trips).
+#define MH_LOADS_ISSUED() do {} while (0)
+
+// (Naming the not-preloaded kernel arguments in an empty `asm volatile("" :: "s"(arg))` right after the vector loads, so
+// that their s_load overlaps the vector round trip, was measured: 677 -> 840 us per token step.  Not kept.)
+
 template <typename U>
 __device__ inline void store_wt(U* p, U v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// 16- / 8-byte write-through stores (`__hip_atomic_store` stops at 8 bytes).  A 2- or 4-byte write-through store is one
+// fabric write each (MI355X_MICROARCH.md: per byte, dword ~6x and short ~12.5x the dwordx4 time): the decode kernels stage
+// what they hand on through LDS and write whole 16-byte pieces of a row.
+__device__ inline void store16_wt(void* p, u32x4_t v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory"); }
+__device__ inline void store8_wt(void* p, u32x2_t v) { asm volatile("global_store_dwordx2 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory"); }
+// n consecutive fp32 values (n = 4 or 8) -> one write-through store of n T elements when the destination is aligned to
+// the piece, else element by element
+#ifndef MH_PACK_ATTN
+#define MH_PACK_ATTN 1     // (0: A/B builds only -- attention outputs / cache rows as 64 two-byte stores)
+#endif
+#ifndef MH_PACK_STORES
+#define MH_PACK_STORES 1   // (0: A/B builds only -- element-wise write-through stores)
+#endif
+template <typename TO>
+__device__ inline void store_piece_wt(TO* dst, const float* v, int n, int nvalid) {
+  const bool whole = MH_PACK_STORES && nvalid == n && (reinterpret_cast<uintptr_t>(dst) & (n * sizeof(TO) - 1)) == 0;
+  if (whole && sizeof(TO) == 4 && n == 4) {
+    store16_wt(dst, u32x4_t{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])});
+  } else if (whole && sizeof(TO) == 2 && n == 8) {
+    store16_wt(dst, u32x4_t{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])});
+  } else if (whole && sizeof(TO) == 2 && n == 4) {
+    store8_wt(dst, u32x2_t{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])});
+  } else {
+    for (int i = 0; i < nvalid; ++i) store_wt(dst + i, Elem<TO>::from_f32(v[i]));
+  }
+}
+
+// One wave holds the 64 values of a head row (lane = feature): through a wave-private 64-float LDS patch (one wave's LDS
+// operations execute in order: no barrier) to 16-byte pieces, written by the first 8 (bf16) / 16 (fp32) lanes.
+template <typename T>
+__device__ inline void store_head_row_wt(T* dst, float val, float* patch) {
+  const int lane = threadIdx.x & 63;
+  constexpr int N = 16 / (int)sizeof(T);
+  if (!MH_PACK_ATTN) { store_wt(dst + lane, Elem<T>::from_f32(val)); return; }
+  patch[lane] = val;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  if (lane < 64 / N) {
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = i < N ? patch[lane * N + i] : 0.f;
+    store_piece_wt<T>(dst + lane * N, v, N, N);
+  }
+}
+// the same from 64 floats that already sit in LDS (visible to the calling wave): lanes `lane0 .. lane0 + 64 / N` of the block
+template <typename T>
+__device__ inline void store_head_row_from_lds_wt(T* dst, const float* src, int t) {   // t = thread index relative to the first storing thread
+  constexpr int N = 16 / (int)sizeof(T);
+  if (!MH_PACK_ATTN) { if (t >= 0 && t < 64) store_wt(dst + t, Elem<T>::from_f32(src[t])); return; }
+  if (t >= 0 && t < 64 / N) {
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = i < N ? src[t * N + i] : 0.f;
+    store_piece_wt<T>(dst + t * N, v, N, N);
+  }
+}
 
 // ---- decode GEMV ("skinny GEMM": M = batch rows <= 64) ------------------------------------------------------------
 // out[b][n] = sum_k A[b][k] * W[n][k] on the 16x16 MFMA atoms.  One workgroup owns ONE 16-column tile of which `nv`
@@ -213,9 +280,32 @@ constexpr int kGemvCH = 8;   // k-blocks per wave whose loads are in flight at o
 #endif
 
 // MF 16-row fragments (B <= 16 MF), NWV waves.  NWV depends on K only (never on the batch): a row's summation order,
-// hence its rounding and its greedy tokens, must not depend on which other rows share the launch.
+// hence its rounding and its greedy tokens, must not depend on which other rows share the launch.  The k-block -> wave
+// assignment is likewise a function of the prologue only: PRO_PLAIN gives wave w the k-block PAIRS w, w + NWV, ... (two
+// consecutive k-blocks = one 128-byte line of a bf16 row) for every MF -- the whole-line path (MF == 1) and the
+// fragment-shaped path (MF >= 2: a chain of more than 16 rows, e.g. a guidance batch) add the same products in the same
+// order; PRO_RMSNORM gives wave w the single k-blocks w, w + NWV, ...
+// Kernel arguments: the operands a workgroup needs to issue its first loads are LEADING SCALAR arguments -- the library is
+// built with -amdgpu-kernarg-preload-count=14, so they arrive in SGPRs with the wave launch instead of through an s_load
+// from the (cold) kernarg segment: one memory round trip off every dependent kernel (tools/micro/kernarg_preload.hip: a
+// GEMV-like dependent kernel 2.49 -> 1.91 us alone, 3.58 -> 2.90 us beside a kernel that streams HBM).  The struct keeps
+// the rest; its copies of the leading arguments are never read (lda = ldw = K: checked on the host).
+// (12 dwords: the 13th and 14th preload slots do not arrive on this firmware -- the kernel body re-loads them)
+#define MH_GEMV_LEAD_PARAMS const void *A_, const void *W_, float *h_, const float *lnw_, int K_, int B_, int N_, int nv_
+#define MH_GEMV_LEAD_ARGS(p) (p).A, (p).W, (p).h, (p).ln_w, (p).K, (p).B, (p).N, (p).nv
 template <typename T, int MF, int NWV, int PRO, int EPI>
-__global__ __launch_bounds__(NWV * 64) void gemv_kernel(SkinnyP p) {
+#ifndef MH_GEMV_WPE
+#define MH_GEMV_WPE 4
+#endif
+#if MH_GEMV_WPE
+#define MH_GEMV_WPE_ATTR __attribute__((amdgpu_waves_per_eu(NWV / 4, MH_GEMV_WPE)))   // registers are free here: never trade a load for one
+#else
+#define MH_GEMV_WPE_ATTR
+#endif
+__global__ __launch_bounds__(NWV * 64) MH_GEMV_WPE_ATTR
+void gemv_kernel(MH_GEMV_LEAD_PARAMS, SkinnyP p) {
+  p.A = A_; p.W = W_; p.h = h_; p.ln_w = lnw_; p.K = K_; p.lda = K_; p.ldw = K_; p.B = B_; p.N = N_; p.nv = nv_;
+  if (EPI == SK_RESID) p.ldh = N_;   // the residual stream is dense [B, N] (checked on the host)
   constexpr int VEC = Elem<T>::kVec;   // elements per 16-byte vector (per lane per k-block)
   constexpr int KB = 4 * VEC;          // k elements per k-block (4 lane groups x 16 B)
   constexpr int CH = kGemvCH;
@@ -278,8 +368,6 @@ __global__ __launch_bounds__(NWV * 64) void gemv_kernel(SkinnyP p) {
 #pragma unroll
   for (int f = 0; f < MF; ++f) arow[f] = (f * 16 + l15) < p.B ? (f * 16 + l15) : p.B - 1;
 
-  // epilogue roles: the MF * 4 (fragment, accumulator register) units are dealt round-robin to the NWV waves -- one
-  // value per lane per unit (the gated-GELU epilogue is a tanh per value: on one wave it cost 0.9 us)
   constexpr int UPW = (MF * 4 + NWV - 1) / NWV;
   const bool col_ok = (EPI == SK_GEGLU) ? (l15 < 8 && ocol < p.N / 2) : (l15 < nv && ocol < p.N);
   float oldh[UPW];
@@ -300,6 +388,8 @@ __global__ __launch_bounds__(NWV * 64) void gemv_kernel(SkinnyP p) {
   for (int f = 0; f < MF; ++f) acc[f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   const int nkb = p.K / KB;
 
+  // k-block of slot c of a pass that starts at kb0 (PRO_PLAIN: kb0 counts k-block PAIRS, see the header comment)
+  auto kblock = [](int kb0, int c) -> int { return PRO == PRO_PLAIN ? 2 * (kb0 + NWV * (c >> 1)) + (c & 1) : kb0 + NWV * c; };
   int kb0 = wid;
   if constexpr (LINES) {
     const int npair = nkb >> 1;        // K is a multiple of 2 KB elements (checked on the host)
@@ -326,7 +416,9 @@ __global__ __launch_bounds__(NWV * 64) void gemv_kernel(SkinnyP p) {
         xa[cp] = *reinterpret_cast<const uint4*>(Ab + rx + off);
         ya[cp] = *reinterpret_cast<const uint4*>(Ab + ry + off);
       }
-      MH_STAMP(KID, 0);   // loads issued
+      MH_LOADS_ISSUED();
+      MH_LOADS_ISSUED();
+    MH_STAMP(KID, 0);   // loads issued
 #pragma unroll
       for (int cp = 0; cp < CP; ++cp) {
         const uint32_t keep = (pw0 + NWV * cp < npair) ? 0xffffffffu : 0u;   // pairs beyond K contribute zeros
@@ -350,13 +442,13 @@ __global__ __launch_bounds__(NWV * 64) void gemv_kernel(SkinnyP p) {
     if (wload && !(PROBE & 2)) {     // ONE exec-masked region around all weight loads (a branch per load would serialise them)
 #pragma unroll
       for (int c = 0; c < CH; ++c) {
-        const int kb = kb0 + NWV * c;
+        const int kb = kblock(kb0, c);
         wv[c] = *reinterpret_cast<const uint4*>(Wp + (kb < nkb ? kb : nkb - 1) * KB);   // clamped address
       }
     }
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
-      const int kb = kb0 + NWV * c;
+      const int kb = kblock(kb0, c);
       const int kel = (kb < nkb ? kb : nkb - 1) * KB;
       if (PROBE & 1) {
 #pragma unroll
@@ -391,6 +483,7 @@ __global__ __launch_bounds__(NWV * 64) void gemv_kernel(SkinnyP p) {
         yr[c] = *reinterpret_cast<const uint4*>(Ab + ry + off);
       }
     }
+    MH_LOADS_ISSUED();
     MH_STAMP(KID, 0);   // loads issued
     if (RLINES) {
       unsigned char* patch = Lw + wid * PATCH;
@@ -426,8 +519,9 @@ __global__ __launch_bounds__(NWV * 64) void gemv_kernel(SkinnyP p) {
     }
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
-      const uint32_t keep = (kb0 + NWV * c < nkb) ? 0xffffffffu : 0u;   // k-blocks beyond K contribute zeros
-      const int kc_el = ((kb0 + NWV * c < nkb) ? kb0 + NWV * c : nkb - 1) * KB + lg * VEC;
+      const int kbc = kblock(kb0, c);
+      const uint32_t keep = (kbc < nkb) ? 0xffffffffu : 0u;   // k-blocks beyond K contribute zeros
+      const int kc_el = ((kbc < nkb) ? kbc : nkb - 1) * KB + lg * VEC;
 #pragma unroll
       for (int f = 0; f < MF; ++f) {
         uint4 a;
@@ -437,8 +531,8 @@ __global__ __launch_bounds__(NWV * 64) void gemv_kernel(SkinnyP p) {
         acc[f] = VecOps<T>::mma(a, wv[c], acc[f]);
       }
     }
-    kb0 += NWV * CH;
-  } while (kb0 < nkb);
+    kb0 += NWV * (PRO == PRO_PLAIN ? CP : CH);
+  } while (kblock(kb0, 0) < nkb);
 
   if (!(PROBE & 8)) {
 #pragma unroll
@@ -472,11 +566,7 @@ __global__ __launch_bounds__(NWV * 64) void gemv_kernel(SkinnyP p) {
     } else if (EPI == SK_LOGITS) {
       if (ok) store_wt(reinterpret_cast<float*>(p.out) + (long)row * p.ldo + ocol, v);
     } else if (EPI == SK_RESID) {
-      if (ok) {
-        if (PROBE & 32) p.h[(long)row * p.ldh + ocol] = oldh[u] + v;     // (the plain store, for comparison)
-        else if (PROBE & 64) __builtin_nontemporal_store(oldh[u] + v, p.h + (long)row * p.ldh + ocol);
-        else store_wt(p.h + (long)row * p.ldh + ocol, oldh[u] + v);
-      }
+      if (ok) store_wt(p.h + (long)row * p.ldh + ocol, oldh[u] + v);
     } else if (EPI == SK_QKV) {
       if (ok) {
         const int part = ocol / p.inner, c = ocol - part * p.inner;
@@ -655,8 +745,8 @@ __global__ __launch_bounds__(256) void dec_self_attn_kernel(SelfAttnP p) {
   partial_merge_groups<T>(st);
   float m, l, a;
   block_merge<T>(st, sm, m, l, a);
-  if (threadIdx.x < 64)
-    store_wt(reinterpret_cast<T*>(p.out) + (long)b * p.ldo + h * 64 + threadIdx.x, Elem<T>::from_f32(l > 0.f ? a / l : 0.f));
+  if (threadIdx.x < 64)   // (sm[0] was last read by this very wave)
+    store_head_row_wt<T>(reinterpret_cast<T*>(p.out) + (long)b * p.ldo + h * 64, l > 0.f ? a / l : 0.f, &sm[0][0]);
 }
 
 struct CrossAttnP {
@@ -706,7 +796,7 @@ __global__ __launch_bounds__(1024) void dec_cross_attn_kernel(CrossAttnP p) {
   float m, l, a;
   block_merge<T, NW>(st, sm, m, l, a);
   if (threadIdx.x < 64)
-    store_wt(reinterpret_cast<T*>(p.out) + (long)b * p.ldo + h * 64 + threadIdx.x, Elem<T>::from_f32(l > 0.f ? a / l : 0.f));
+    store_head_row_wt<T>(reinterpret_cast<T*>(p.out) + (long)b * p.ldo + h * 64, l > 0.f ? a / l : 0.f, &sm[0][0]);
 }
 
 // ---- attention kernels that project their own query (and the new self-attention key / value) --------------------
@@ -741,22 +831,37 @@ template <> struct Raw8<float> {
 
 // xn[k] = T-rounded ln_w[k] * (h[b][k] * rsqrt(mean(h[b]^2) + eps)) for k < d, by a 1024-thread workgroup (d <= 1024).
 // The statistics come from the row itself (wave sums -> 16 LDS floats that every thread adds in the same order).
+// Two halves: `issue` only REQUESTS the row and the weight (it needs nothing but preloaded kernel arguments), `finish`
+// waits for them -- whatever else the kernel can request goes in between.
+template <typename T>
+struct NormRow {
+  float x, g;
+  __device__ inline void issue(const HeadProjP& hp, int b) {
+    const int tid = threadIdx.x;
+    const int kc = tid < hp.d ? tid : hp.d - 1;
+    x = hp.h[(long)b * hp.ldh + kc];
+    g = hp.ln_w[kc];
+  }
+  __device__ inline void finish(const HeadProjP& hp, float* xn, float* red16) const {
+    const int tid = threadIdx.x;
+    const float sq = wave_sum(tid < hp.d ? x * x : 0.f);
+    if ((tid & 63) == 0) red16[tid >> 6] = sq;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) tot += red16[w];
+    const float rs = rsqrtf(tot / (float)hp.d + hp.eps);
+    if (tid < hp.d) xn[tid] = Elem<T>::to_f32(Elem<T>::from_f32(g * (x * rs)));
+    __syncthreads();
+  }
+};
 template <typename T>
 __device__ inline void norm_row_to_lds(const HeadProjP& hp, int b, float* xn, float* red16) {
-  const int tid = threadIdx.x;
-  const int kc = tid < hp.d ? tid : hp.d - 1;
-  const float x = hp.h[(long)b * hp.ldh + kc];
-  const float g = hp.ln_w[kc];
-  const float sq = wave_sum(tid < hp.d ? x * x : 0.f);
-  if ((tid & 63) == 0) red16[tid >> 6] = sq;
-  __syncthreads();
-  float tot = 0.f;
-#pragma unroll
-  for (int w = 0; w < 16; ++w) tot += red16[w];
-  const float rs = rsqrtf(tot / (float)hp.d + hp.eps);
-  if (tid < hp.d) xn[tid] = Elem<T>::to_f32(Elem<T>::from_f32(g * (x * rs)));
-  __syncthreads();
+  NormRow<T> nr;
+  nr.issue(hp, b);
+  nr.finish(hp, xn, red16);
 }
+
 
 // NP projections of 64 outputs each: out[p][o] = T-rounded sum_k xn[k] * W[(row0[p] + o) * ldw + k].
 // 1024 threads: 16 consecutive lanes per output, KC 8-element chunks per lane (d = 128 KC), chunk c of lane ks = elements
@@ -771,6 +876,16 @@ struct HeadProj {
     const int tid = threadIdx.x, o = tid >> 4, ks = tid & 15;
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
+      const T* wp = reinterpret_cast<const T*>(hp.W) + (long)(row0[q] + o) * hp.ldw + ks * 8;
+#pragma unroll
+      for (int c = 0; c < KC; ++c) raw[q][c].load(wp + c * 128);
+    }
+    MH_LOADS_ISSUED();
+  }
+  __device__ inline void load3(const HeadProjP& hp, const int (&row0)[3]) {   // (NP == 3 instantiations only)
+    const int tid = threadIdx.x, o = tid >> 4, ks = tid & 15;
+#pragma unroll
+    for (int q = 0; q < (NP < 3 ? NP : 3); ++q) {
       const T* wp = reinterpret_cast<const T*>(hp.W) + (long)(row0[q] + o) * hp.ldw + ks * 8;
 #pragma unroll
       for (int c = 0; c < KC; ++c) raw[q][c].load(wp + c * 128);
@@ -800,7 +915,10 @@ struct HeadProj {
 // F8: K / V are the e4m3 copy (64-byte rows, 8 bytes per lane; the scales multiply the scores and the output)
 template <typename T, int KC, int U, bool F8 = false>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8)))   // <= 64 VGPRs: 2 workgroups per CU
-void dec_cross_attn_q_kernel(CrossAttnP p, HeadProjP hp) {
+void dec_cross_attn_q_kernel(const float* h_, const float* lnw_, const void* W_, const void* k_, const void* v_, int H_, int L_, int d_,
+                             int kvB_, CrossAttnP p, HeadProjP hp) {   // leading scalars: preloaded kernel arguments (see gemv_kernel)
+  hp.h = h_; hp.ln_w = lnw_; hp.W = W_; hp.ldh = d_; hp.ldw = d_; hp.d = d_;
+  p.k = k_; p.v = v_; p.H = H_; p.L = L_; p.kv_B = kvB_;
   constexpr int NW = 16;
   __shared__ float sm[NW][66];
   __shared__ __attribute__((aligned(16))) float xn[1024];
@@ -810,15 +928,25 @@ void dec_cross_attn_q_kernel(CrossAttnP p, HeadProjP hp) {
   int b, h;
   cross_pair_of_block(p, blockIdx.x, b, h);
   MH_STAMP0();
-  unsigned long long t_start = 0;
-  if (p.tstamp && threadIdx.x == 0) t_start = (unsigned long long)wall_clock64();
   const int c8 = (lane & 7) * 8, g = lane >> 3;
   const int row0[1] = {h * 64};
+  const int kvb = p.kv_B > 0 ? b % p.kv_B : b;
+  typedef typename std::conditional<F8, fp8_t, T>::type E;
+  const E* kb = reinterpret_cast<const E*>(p.k) + ((long)kvb * p.H + h) * p.L * 64;
+  const E* vb = reinterpret_cast<const E*>(p.v) + ((long)kvb * p.H + h) * p.L * 64;
   HeadProj<T, KC, 1> proj;
-  // this head's 64 x d slice of Wq does not depend on the activations: bf16 requests it before the row statistics are
-  // waited for (fp32 -- the parity path -- would not fit the 64-register budget of two workgroups per CU)
+  NormRow<T> nrow;
+  // everything the prologue needs is requested at once, from preloaded arguments only: the residual row, the RMSNorm
+  // weight and (bf16: fp32 -- the parity path -- would not fit the 64-register budget of two workgroups per CU) this
+  // head's 64 x d slice of Wq, which does not depend on the activations; then the remaining kernel arguments
+  nrow.issue(hp, b);
   if (sizeof(T) == 2) proj.load(hp, row0);
-  norm_row_to_lds<T>(hp, b, xn, red16);
+  // (LDS-DMA prefetch of every wave's first 1-3 key iterations during this prologue -- 32 KB of LDS per iteration, issued as
+  // inline asm behind shadow loads so that no wait of the prologue covers it -- was built and measured: 703 / 703 / 729 us
+  // per token step for 1 / 2 / 3 iterations against 679 without.  Not kept.)
+  unsigned long long t_start = 0;
+  if (p.tstamp && threadIdx.x == 0) t_start = (unsigned long long)wall_clock64();
+  nrow.finish(hp, xn, red16);
   MH_STAMP(KID_CROSS, 0);   // row normalised
   if (sizeof(T) != 2) proj.load(hp, row0);
   proj.apply(xn, qs);
@@ -827,10 +955,6 @@ void dec_cross_attn_q_kernel(CrossAttnP p, HeadProjP hp) {
   float q[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) q[i] = qs[0][c8 + i];
-  const int kvb = p.kv_B > 0 ? b % p.kv_B : b;
-  typedef typename std::conditional<F8, fp8_t, T>::type E;
-  const E* kb = reinterpret_cast<const E*>(p.k) + ((long)kvb * p.H + h) * p.L * 64;
-  const E* vb = reinterpret_cast<const E*>(p.v) + ((long)kvb * p.H + h) * p.L * 64;
   const float ks = F8 ? p.kscale[kvb * p.H + h] : 1.0f, vs = F8 ? p.vscale[kvb * p.H + h] : 1.0f;
   Partial st;
   partial_init(st);
@@ -841,7 +965,7 @@ void dec_cross_attn_q_kernel(CrossAttnP p, HeadProjP hp) {
   block_merge<T, NW>(st, sm, m, l, a);
   MH_STAMP(KID_CROSS, 3);   // partials merged
   if (threadIdx.x < 64)
-    store_wt(reinterpret_cast<T*>(p.out) + (long)b * p.ldo + h * 64 + threadIdx.x, Elem<T>::from_f32(l > 0.f ? a / l * vs : 0.f));
+    store_head_row_wt<T>(reinterpret_cast<T*>(p.out) + (long)b * p.ldo + h * 64, l > 0.f ? a / l * vs : 0.f, &sm[0][0]);
   if (p.tstamp && threadIdx.x == 0 && *p.pos < p.ts_ring) {      // the first ts_ring positions of the call, one slot each
     unsigned long long* slot = p.tstamp + 2 * ((long)(*p.pos) * p.ts_layers + p.ts_layer);
     atomicMin(slot, t_start);
@@ -882,7 +1006,13 @@ __device__ inline void norm_rows_to_lds(const HeadProjP& hp, int b0, int B, T (*
 // self-attention of one (b, h) with its own q / k / v projections: appends the new key / value row to the caches and
 // attends over keys 0 .. pos-1 from the cache plus the new key straight from LDS (merged last)
 template <typename T, int KC>
-__global__ __launch_bounds__(1024) void dec_self_attn_qkv_kernel(SelfAttnP p, HeadProjP hp, int inner) {
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4)))   // 16 waves = 4 per SIMD: the whole 128-register budget
+void dec_self_attn_qkv_kernel(const float* h_, const float* lnw_, const void* W_, const int* pos_,
+                                                                 const void* kc_, const void* vc_, int H_, int d_, SelfAttnP p,
+                                                                 HeadProjP hp) {   // leading scalars: preloaded kernel arguments
+  hp.h = h_; hp.ln_w = lnw_; hp.W = W_; hp.ldh = d_; hp.ldw = d_; hp.d = d_;
+  p.pos = pos_; p.kc = kc_; p.vc = vc_; p.H = H_;
+  const int inner = H_ * 64;
   constexpr int NW = 16;
   __shared__ float sm[NW][66];
   __shared__ __attribute__((aligned(16))) float xn[1024];
@@ -891,37 +1021,42 @@ __global__ __launch_bounds__(1024) void dec_self_attn_qkv_kernel(SelfAttnP p, He
   MH_STAMP0();
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
-  const int pos = *p.pos;
   const int c8 = (lane & 7) * 8, g = lane >> 3;
-  if (sizeof(T) == 2 && KC <= 7) {
-    const int row0[3] = {h * 64, inner + h * 64, 2 * inner + h * 64};
-    HeadProj<T, KC, 3> proj;
-    // (requesting the 3 x 64 x d weights ahead of the normalisation costs 117 registers = ONE workgroup per CU: the
-    // two decode chains then queue behind each other for CUs -- measured 14.1 vs 12.5 us per launch in situ)
-    norm_row_to_lds<T>(hp, b, xn, red16);
-    proj.load(hp, row0);
+  // the first round trip carries everything that does not depend on another load: the residual row + RMSNorm weight, the
+  // position, and the two loop-invariant values of the tail (the bias at distance 0 and the prompt mask of the new key:
+  // they used to be two serial round trips at the END of the kernel)
+  NormRow<T> nrow;
+  nrow.issue(hp, b);
+  const int pos = *p.pos;
+  constexpr bool kAllAtOnce = sizeof(T) == 2 && KC <= 7;
+  HeadProj<T, KC, kAllAtOnce ? 3 : 1> proj;
+  const int row03[3] = {h * 64, inner + h * 64, 2 * inner + h * 64};
+  const float* bias_row = p.bias + (long)h * p.tgt_len;
+  const uint8_t* mask_row = p.prompt_mask ? p.prompt_mask + (long)b * p.P : nullptr;
+  const float bias0 = bias_row[0];
+  const int new_key_mask = (mask_row && pos < p.P) ? (int)mask_row[pos < p.P ? pos : 0] : 1;
+  nrow.finish(hp, xn, red16);
+  if (kAllAtOnce) {
+    proj.load3(hp, row03);   // (requested AFTER the normalisation: holding the 18 vectors across it measured 688 vs 677 us per token step)
     proj.apply(xn, qkv);
   } else {   // fp32 storage, or d_model = 1024 in bf16: one projection at a time (register budget of a 1024-thread workgroup)
-    norm_row_to_lds<T>(hp, b, xn, red16);
 #pragma unroll
     for (int q3 = 0; q3 < 3; ++q3) {
       const int row0[1] = {q3 * inner + h * 64};
-      HeadProj<T, KC, 1> proj;
-      proj.load(hp, row0);
-      proj.apply(xn, qkv + q3);
+      HeadProj<T, KC, 1> proj1;
+      proj1.load(hp, row0);
+      proj1.apply(xn, qkv + q3);
     }
   }
   __syncthreads();
   MH_STAMP(KID_SELF, 0);    // q / k / v projected
   T* kcache = reinterpret_cast<T*>(const_cast<void*>(p.kc)) + ((long)b * p.H + h) * p.tgt_len * 64;
   T* vcache = reinterpret_cast<T*>(const_cast<void*>(p.vc)) + ((long)b * p.H + h) * p.tgt_len * 64;
-  if (threadIdx.x >= 64 && threadIdx.x < 128) store_wt(kcache + (long)pos * 64 + (threadIdx.x - 64), Elem<T>::from_f32(qkv[1][threadIdx.x - 64]));
-  if (threadIdx.x >= 128 && threadIdx.x < 192) store_wt(vcache + (long)pos * 64 + (threadIdx.x - 128), Elem<T>::from_f32(qkv[2][threadIdx.x - 128]));
+  store_head_row_from_lds_wt<T>(kcache + (long)pos * 64, qkv[1], (int)threadIdx.x - 64);     // waves 1 / 2: whole 16-byte pieces
+  store_head_row_from_lds_wt<T>(vcache + (long)pos * 64, qkv[2], (int)threadIdx.x - 128);
   float q[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) q[i] = qkv[0][c8 + i];
-  const float* bias_row = p.bias + (long)h * p.tgt_len;
-  const uint8_t* mask_row = p.prompt_mask ? p.prompt_mask + (long)b * p.P : nullptr;
   Partial st;
   partial_init(st);
   attend_keys<T, 2>(st, q, kcache, vcache, wid * 8 + g, pos, 8 * NW, bias_row, pos, mask_row, p.P, 1.0f);
@@ -932,13 +1067,13 @@ __global__ __launch_bounds__(1024) void dec_self_attn_qkv_kernel(SelfAttnP p, He
   MH_STAMP(KID_SELF, 2);    // partials merged
   if (threadIdx.x < 64) {
     const int d = threadIdx.x;
-    float sn = wave_sum(qkv[0][d] * qkv[1][d]) + bias_row[0];
-    if (mask_row && pos < p.P && mask_row[pos < p.P ? pos : 0] == 0) sn = -INFINITY;
+    float sn = wave_sum(qkv[0][d] * qkv[1][d]) + bias0;
+    if (new_key_mask == 0) sn = -INFINITY;
     const float mn = fmaxf(m, sn);
     const float fa = fexp<T>(m - mn), fb = fexp<T>(sn - mn);
     l = l * fa + fb;
     a = a * fa + qkv[2][d] * fb;
-    store_wt(reinterpret_cast<T*>(p.out) + (long)b * p.ldo + h * 64 + d, Elem<T>::from_f32(l > 0.f ? a / l : 0.f));
+    store_head_row_wt<T>(reinterpret_cast<T*>(p.out) + (long)b * p.ldo + h * 64, l > 0.f ? a / l : 0.f, &sm[0][0]);
   }
 }
 
@@ -951,7 +1086,12 @@ __global__ __launch_bounds__(1024) void dec_self_attn_qkv_kernel(SelfAttnP p, He
 // chain fits beside it); R rows per workgroup divide both by R.  Then 16 / R waves per row attend over the cache.  A
 // row's arithmetic depends on R (projection on the MFMA atom, key interleave 16 / R waves wide), never on the batch.
 template <typename T, int KC, int R>
-__global__ __launch_bounds__(1024) void dec_self_attn_qkv_rows_kernel(SelfAttnP p, HeadProjP hp, int inner) {
+__global__ __launch_bounds__(1024) void dec_self_attn_qkv_rows_kernel(const float* h_, const float* lnw_, const void* W_, const int* pos_,
+                                                                      const void* kc_, const void* vc_, int H_, int d_, SelfAttnP p,
+                                                                      HeadProjP hp) {   // leading scalars: preloaded kernel arguments
+  hp.h = h_; hp.ln_w = lnw_; hp.W = W_; hp.ldh = d_; hp.ldw = d_; hp.d = d_;
+  p.pos = pos_; p.kc = kc_; p.vc = vc_; p.H = H_;
+  const int inner = H_ * 64;
   constexpr int NW = 16, NWR = NW / R;   // waves per row
   constexpr int U = 4;                   // keys in flight per 8-lane group (the weight fragments are dead by then)
   constexpr int VEC = Elem<T>::kVec, KB = 4 * VEC;
@@ -1008,8 +1148,8 @@ __global__ __launch_bounds__(1024) void dec_self_attn_qkv_rows_kernel(SelfAttnP 
   const int b = live ? b0 + r : p.B - 1;              // a dead row recomputes the last one and stores nothing
   T* kcache = reinterpret_cast<T*>(const_cast<void*>(p.kc)) + ((long)b * p.H + h) * p.tgt_len * 64;
   T* vcache = reinterpret_cast<T*>(const_cast<void*>(p.vc)) + ((long)b * p.H + h) * p.tgt_len * 64;
-  if (live && wr == 1) store_wt(kcache + (long)pos * 64 + lane, Elem<T>::from_f32(qkv[r][1][lane]));
-  if (live && wr == 2) store_wt(vcache + (long)pos * 64 + lane, Elem<T>::from_f32(qkv[r][2][lane]));
+  if (live && wr == 1) store_head_row_from_lds_wt<T>(kcache + (long)pos * 64, qkv[r][1], lane);
+  if (live && wr == 2) store_head_row_from_lds_wt<T>(vcache + (long)pos * 64, qkv[r][2], lane);
   float q[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) q[i] = qkv[r][0][c8 + i];
@@ -1045,7 +1185,8 @@ __global__ __launch_bounds__(1024) void dec_self_attn_qkv_rows_kernel(SelfAttnP 
     const float fa = fexp<T>(m - mn), fb = fexp<T>(sn - mn);
     l = l * fa + fb;
     a = a * fa + qkv[r][2][d] * fb;
-    if (live) store_wt(reinterpret_cast<T*>(p.out) + (long)b * p.ldo + h * 64 + d, Elem<T>::from_f32(l > 0.f ? a / l : 0.f));
+    const float res = l > 0.f ? a / l : 0.f;
+    if (live) store_head_row_wt<T>(reinterpret_cast<T*>(p.out) + (long)b * p.ldo + h * 64, res, &sm[w0][0]);   // (this wave's own merge rows)
   }
 }
 

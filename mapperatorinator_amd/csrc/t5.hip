@@ -568,7 +568,12 @@ __global__ __launch_bounds__(256) void dec_sample_kernel(SampleP p) {
   for (int j = 0; j < nrow; ++j) {
     const int lrow = j == 0 ? lb : lneg;
     const T* e = reinterpret_cast<const T*>(p.dec_embed) + (long)s_tok[j] * p.d;
-    for (int i = tid; i < p.d; i += 256) dec::store_wt(p.h + (long)lrow * p.d + i, Elem<T>::to_f32(e[i]));   // write-through: see store_wt
+    for (int i = tid * 4; i < p.d; i += 1024) {   // 16-byte write-through pieces (d is a multiple of 4)
+      float v4[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v4[k] = Elem<T>::to_f32(e[i + k]);
+      dec::store_piece_wt<float>(p.h + (long)lrow * p.d + i, v4, 4, 4);
+    }
   }
   // Step bookkeeping without a launch of its own: every workgroup read `pos` when it started, so the one that arrives
   // last may advance it; it also recounts the running rows for the host's early-stop poll.  The `finished` flags are
@@ -613,10 +618,12 @@ int launch_skinny(dec::SkinnyP p, hipStream_t s) {
   const int kb = 4 * (16 / (int)sizeof(T));
   MH_REQUIRE(p.K % kb == 0 && p.K >= kb, "decode: K=%d must be a positive multiple of %d", p.K, kb);
   const int nkb = p.K / kb;
-  MH_REQUIRE(PRO != dec::PRO_PLAIN || MF != 1 || nkb % 2 == 0, "decode: K=%d must be a multiple of %d", p.K, 2 * kb);
+  MH_REQUIRE(PRO != dec::PRO_PLAIN || nkb % 2 == 0, "decode: K=%d must be a multiple of %d", p.K, 2 * kb);
   // waves per workgroup: a function of K ONLY (batch invariance of the summation order)
   const bool wide = nkb > 4 * dec::kGemvCH;
   MH_REQUIRE(PRO != dec::PRO_RMSNORM || nkb <= 8 * dec::kGemvCH, "decode: RMSNorm prologue needs K <= %d", 8 * dec::kGemvCH * kb);
+  MH_REQUIRE(p.lda == p.K && p.ldw == p.K, "decode: the GEMV operands must be dense (lda = ldw = K)");
+  MH_REQUIRE(EPI != dec::SK_RESID || (p.N % 4 == 0 && p.ldh == p.N), "decode: residual GEMV needs a dense [B, N] residual stream, N a multiple of 4");
   int tiles;
   if (EPI == dec::SK_GEGLU) { p.nv = 8; tiles = ceil_div(p.N / 2, 8); }
   else { p.nv = gemv_cols(p.N); tiles = ceil_div(p.N, p.nv); }
@@ -625,10 +632,10 @@ int launch_skinny(dec::SkinnyP p, hipStream_t s) {
       set_error("decode: RMSNorm GEMV needs d_model <= 1024 in bf16 storage");
       return MH_ERR_ARG;
     } else {
-      hipLaunchKernelGGL((dec::gemv_kernel<T, MF, 8, PRO, EPI>), dim3(tiles), dim3(512), 0, s, p);
+      hipLaunchKernelGGL((dec::gemv_kernel<T, MF, 8, PRO, EPI>), dim3(tiles), dim3(512), 0, s, MH_GEMV_LEAD_ARGS(p), p);
     }
   } else {
-    hipLaunchKernelGGL((dec::gemv_kernel<T, MF, 4, PRO, EPI>), dim3(tiles), dim3(256), 0, s, p);
+    hipLaunchKernelGGL((dec::gemv_kernel<T, MF, 4, PRO, EPI>), dim3(tiles), dim3(256), 0, s, MH_GEMV_LEAD_ARGS(p), p);
   }
   return check_launch("gemv_kernel");
 }
@@ -660,16 +667,19 @@ int launch_cross(const dec::CrossAttnP& ca, hipStream_t s) {
 // order of the projections; both forms are covered by the GPU tests).
 bool fused_proj_enabled(int d) { return option(OPT_DECODE_FUSED_PROJ) != 0 && d % 128 == 0 && d >= 128 && d <= 1024; }
 
+#define MH_SELF_LEAD_ARGS hp.h, hp.ln_w, hp.W, sa.pos, sa.kc, sa.vc, sa.H, hp.d
+#define MH_CROSS_LEAD_ARGS hp.h, hp.ln_w, hp.W, ca.k, ca.v, ca.H, ca.L, hp.d, ca.kv_B
 template <typename T, int KC>
 int launch_self_qkv(const dec::SelfAttnP& sa, const dec::HeadProjP& hp, int inner, hipStream_t s) {
+  MH_REQUIRE(hp.ldh == hp.d && hp.ldw == hp.d && inner == sa.H * 64, "decode: dense residual rows / projection weights expected");
   // option decode_self_rows: rows of one head per workgroup (1, 2 or 4) -- they share the head's weight slice
   const long R = option(OPT_DECODE_SELF_ROWS);
   if (R >= 4)
-    hipLaunchKernelGGL((dec::dec_self_attn_qkv_rows_kernel<T, KC, 4>), dim3((sa.B + 3) / 4 * sa.H), dim3(1024), 0, s, sa, hp, inner);
+    hipLaunchKernelGGL((dec::dec_self_attn_qkv_rows_kernel<T, KC, 4>), dim3((sa.B + 3) / 4 * sa.H), dim3(1024), 0, s, MH_SELF_LEAD_ARGS, sa, hp);
   else if (R >= 2)
-    hipLaunchKernelGGL((dec::dec_self_attn_qkv_rows_kernel<T, KC, 2>), dim3((sa.B + 1) / 2 * sa.H), dim3(1024), 0, s, sa, hp, inner);
+    hipLaunchKernelGGL((dec::dec_self_attn_qkv_rows_kernel<T, KC, 2>), dim3((sa.B + 1) / 2 * sa.H), dim3(1024), 0, s, MH_SELF_LEAD_ARGS, sa, hp);
   else
-    hipLaunchKernelGGL((dec::dec_self_attn_qkv_kernel<T, KC>), dim3(sa.B * sa.H), dim3(1024), 0, s, sa, hp, inner);
+    hipLaunchKernelGGL((dec::dec_self_attn_qkv_kernel<T, KC>), dim3(sa.B * sa.H), dim3(1024), 0, s, MH_SELF_LEAD_ARGS, sa, hp);
   return check_launch("dec_self_attn_qkv_kernel");
 }
 template <typename T>
@@ -687,14 +697,15 @@ int launch_self_qkv_d(const dec::SelfAttnP& sa, const dec::HeadProjP& hp, int in
 }
 template <typename T, int KC>
 int launch_cross_q(const dec::CrossAttnP& ca, const dec::HeadProjP& hp, hipStream_t s) {
+  MH_REQUIRE(hp.ldh == hp.d && hp.ldw == hp.d, "decode: dense residual rows / projection weights expected");
   // one key in flight per 8-lane group: 64 VGPRs without spills (two 16-wave workgroups per CU); U = 2 measured the
   // same bandwidth in the stand-alone kernel
   if (ca.kscale != nullptr) {
     if constexpr (sizeof(T) == 2)
-      hipLaunchKernelGGL((dec::dec_cross_attn_q_kernel<T, KC, 1, true>), dim3(ca.B * ca.H), dim3(1024), 0, s, ca, hp);
+      hipLaunchKernelGGL((dec::dec_cross_attn_q_kernel<T, KC, 1, true>), dim3(ca.B * ca.H), dim3(1024), 0, s, MH_CROSS_LEAD_ARGS, ca, hp);
     else { set_error("decode: the fp8 cross K/V copy needs bf16 storage"); return MH_ERR_ARG; }
   } else {
-    hipLaunchKernelGGL((dec::dec_cross_attn_q_kernel<T, KC, 1>), dim3(ca.B * ca.H), dim3(1024), 0, s, ca, hp);
+    hipLaunchKernelGGL((dec::dec_cross_attn_q_kernel<T, KC, 1>), dim3(ca.B * ca.H), dim3(1024), 0, s, MH_CROSS_LEAD_ARGS, ca, hp);
   }
   return check_launch("dec_cross_attn_q_kernel");
 }

@@ -72,31 +72,34 @@ def sharded_generate(generate_fn: Callable, model_kwargs: dict, pad_id: int, max
         toks, stats = torch.zeros((0, 1), dtype=torch.long), {"generated_tokens": 0}
     if toks.shape[1] > max_length:
         raise ValueError(f"generate_fn returned {toks.shape[1]} columns, max_length is {max_length}")
-    local = torch.full((hi - lo, max_length + 1), pad_id, dtype=torch.int32)
-    local[:, : toks.shape[1]] = toks.to(torch.int32)
+    # everything that travels is assembled ON the collective's device (RCCL: the GPU; gloo: the CPU): a generate_fn /
+    # refine_fn that returns device tensors is never bounced through the host before the gather
+    dev = _comm_device(group, comm_device) if world > 1 else toks.device
+    local = torch.full((hi - lo, max_length + 1), pad_id, dtype=torch.int32, device=dev)
+    local[:, : toks.shape[1]] = toks.to(device=dev, dtype=torch.int32)
     local[:, max_length] = toks.shape[1]          # column max_length carries the produced length
     n_coord = 0
     coord_shape = None
     if refine_fn is not None:
         coords = refine_fn(shard, toks) if hi > lo else None
         # every rank must agree on Tq even when its shard is empty: settle it with the first non-empty shard's shape
-        shape_t = torch.tensor(list(coords.shape[1:]) if coords is not None else [0, 0], dtype=torch.int64)
+        shape_t = torch.tensor(list(coords.shape[1:]) if coords is not None else [0, 0], dtype=torch.int64, device=dev)
         if world > 1:
-            shapes = [torch.zeros_like(shape_t) for _ in range(world)]
-            dist.all_gather(shapes, shape_t.to(_comm_device(group, comm_device)), group=group)
+            shapes = [torch.zeros_like(shape_t) for _ in range(world)]      # outputs live where the input lives
+            dist.all_gather(shapes, shape_t, group=group)
             shape_t = max((s_.cpu() for s_ in shapes), key=lambda s_: int(s_.prod()))
-        coord_shape = tuple(int(v) for v in shape_t)
+        coord_shape = tuple(int(v) for v in shape_t.cpu())
         n_coord = coord_shape[0] * coord_shape[1]
-        packed = torch.zeros((hi - lo, n_coord), dtype=torch.int32)
+        packed = torch.zeros((hi - lo, n_coord), dtype=torch.int32, device=dev)
         if coords is not None:
             if tuple(coords.shape[1:]) != coord_shape:
                 raise ValueError(f"refine_fn returned {tuple(coords.shape)}; every rank must use the same (2, Tq) = {coord_shape}")
-            packed = coords.to(torch.float32).contiguous().cpu().reshape(hi - lo, n_coord).view(torch.int32)
+            packed = coords.to(device=dev, dtype=torch.float32).contiguous().reshape(hi - lo, n_coord).view(torch.int32)
         local = torch.cat([local, packed], 1)
     if world == 1:
-        full = local
+        full = local.cpu()
     else:
-        full = all_gather_ragged(local.to(_comm_device(group, comm_device)), B, group).cpu()
+        full = all_gather_ragged(local, B, group).cpu()
     out = (full[:, :max_length].to(torch.int64), full[:, max_length].to(torch.int64), stats)
     if refine_fn is not None:
         c = full[:, max_length + 1:].contiguous().view(torch.float32).reshape((B,) + coord_shape)

@@ -445,6 +445,37 @@ def test_full_size_base_bf16_properties():
         assert torch.equal(one[0], ids[b, :n]) and (ids[b, n:] == 0).all(), f"row {b} depends on its batch"
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,chains", [(40, 0), (24, 1), (64, 0)])
+def test_rows_do_not_depend_on_the_rows_beside_them(dtype, B, chains):
+    """Chains of more than 16 rows use the 2- / 4-fragment GEMV (MF >= 2), chains of <= 16 rows the whole-line one
+    (MF == 1): both must add a row's products in the same order (k-block pairs per wave), so a chunk decodes to the same
+    ids alone (MF 1) and inside a batch of 24 (one chain, MF 2), 40 (two chains of 20, MF 2) or 64 rows (two chains of
+    32, MF 2)."""
+    from mapperatorinator_amd import Tokenizer, _lib
+    from mapperatorinator_amd.server import model_generate
+    from mapperatorinator_amd.t5_engine import T5_PRESETS
+    from mapperatorinator_amd.testing import random_t5_state_dict, synthetic_audio
+    src, tgt = 251, 48
+    tok = Tokenizer.benchmark_vocab(src_seq_len=src)
+    sd = random_t5_state_dict(T5_PRESETS["small"], tok.vocab_size_in, tok.vocab_size_out, seed=9, lm_head_gain=6.0)
+    model = build("small", tok, sd, src, tgt, dtype)
+    audio = synthetic_audio(B, 32000, seed=12)
+    prompt = torch.tensor([[1]] * B)
+    gk = gen_kwargs(tgt)
+    old = _lib.set_option("decode_chains", chains)
+    try:
+        ids, _ = model_generate(model, tok, dict(inputs=audio, decoder_input_ids=prompt, decoder_attention_mask=prompt.ne(0)), gk)
+    finally:
+        _lib.set_option("decode_chains", old)
+    for b in (0, 7, 17, B - 1):
+        one, _ = model_generate(model, tok, dict(inputs=audio[b:b + 1], decoder_input_ids=prompt[:1],
+                                                 decoder_attention_mask=prompt[:1].ne(0)), gk)
+        n = one.shape[1]
+        assert torch.equal(one[0], ids[b, :n]) and (ids[b, n:] == 0).all(), f"row {b} of {B} depends on its batch"
+
+
+
 def test_sampling_topk_topp_distribution():
     """do_sample path (row a9): sampling parity is RNG-bound, so it is checked distributionally --
     every sampled id lies inside the top-k / nucleus set of the processed scores of its step, identical rows
