@@ -186,6 +186,7 @@ class SequentialWindowScheduler:
         elapsed = time.perf_counter() - t0
         self.stats["decode_calls"] += 1
         P = prompts.shape[1]
+        redo = {}
         for r, (i, ask, _) in enumerate(group):
             own = ask["decoder_input_ids"].shape[-1]
             row = result[r, P - own:]                      # strip the padding this batch added on the left
@@ -195,8 +196,81 @@ class SequentialWindowScheduler:
             hit = torch.isin(body, eos_ids).nonzero()
             if hit.numel():
                 row = row[:own + int(hit[0]) + 1]
+            elif own < P and row.shape[0] < sp.max_length:
+                # no EOS and the row stopped at max_length COLUMNS, `P - own` of which were this batch's left padding: the
+                # reference's batch-1 call (no padding) would have gone on to max_length tokens.  Rare (windows end by
+                # EOS); such rows are decoded again among rows of their own prompt length, i.e. without padding.
+                redo.setdefault(own, []).append(group[r])
+                continue
             st = _build_generation_stats(row[None], dict(decoder_input_ids=ask["decoder_input_ids"].reshape(1, -1)),
                                          pad_id, elapsed)
             self.stats["windows"] += 1
             self.stats["generated_tokens"] += st["generated_tokens"]
             jobs[i].on_result(w, row, st)
+        for sub in redo.values():
+            self._decode_group(jobs, kvs, w, sub, pad_id)
+
+
+# ---- the reference's own sequential loop on the scheduler -------------------------------------------------------------
+def processor_generate_kwargs(proc, **window_kwargs) -> dict:
+    """The kwargs `Processor.model_generate` (osuT5/osuT5/inference/processor.py:155-170) hands to the module-level
+    `model_generate`: the window's own (lookback_time, lookahead_time, context_type) + the processor's sampling knobs."""
+    return dict(window_kwargs, precision=proc.precision, do_sample=proc.do_sample, num_beams=proc.num_beams, top_p=proc.top_p,
+                top_k=proc.top_k, max_length=proc.tgt_seq_len, cfg_scale=proc.cfg_scale, timeshift_bias=proc.timeshift_bias,
+                types_first=proc.types_first, temperature=proc.temperature, timing_temperature=proc.timing_temperature,
+                mania_column_temperature=proc.mania_column_temperature, taiko_hit_temperature=proc.taiko_hit_temperature)
+
+
+def processor_song_job(proc, *, sequences, in_context, out_context, context_index: int, req_special_tokens,
+                       model_kwargs: Optional[dict] = None) -> SongJob:
+    """ONE pass of the reference's `Processor.generate_sequential` (processor.py:308-368) over output context
+    `context_index` of one song, cut at its `self.model_generate(...)` call: everything in front of the call (the window's
+    prompts from the contexts as they stand -- `prepare_context_sequences`, `get_prompts`, `pad_prompts` -- the lookback /
+    lookahead EOS windows, the per-window song position) is `prompt_fn` / `conditioning_fn`, everything behind it
+    (`_record_generation_stats`, `result[0, max_len:]`, `add_predicted_tokens_to_context`) is `on_result`.  `proc` is the
+    reference's own `Processor` (duck-typed: its methods and attributes are used as they are -- the host logic stays the
+    reference's), so a song decoded through SequentialWindowScheduler leaves `out_context` exactly as the reference loop
+    does; many songs (one job each) share the scheduler's waves.  Several output contexts of a song = one scheduler run
+    per `context_index`, in order, as the reference's outer loop does."""
+    frames_all, frame_times, song_length = sequences
+    n = len(frames_all)
+    context = out_context[context_index]
+    pending = {}
+    pad_id = proc.tokenizer.pad_id
+    model_kwargs = dict(model_kwargs or {})
+
+    def prompt_fn(w: int) -> dict:
+        frame_time = frame_times[w].item()
+        trim_lookback = w != 0 and proc.lookback_time > 0
+        trim_lookahead = w != n - 1
+        cond_prompt, uncond_prompt = proc.get_prompts(
+            proc.prepare_context_sequences(in_context, frame_time, False, req_special_tokens),
+            proc.prepare_context_sequences(out_context[:context_index + 1], frame_time, True, req_special_tokens))
+        [prompt, uncond_prompt], max_len = proc.pad_prompts([cond_prompt, uncond_prompt])
+        pending[w] = (frame_time, max_len, trim_lookback, trim_lookahead)
+        ask = dict(decoder_input_ids=prompt, decoder_attention_mask=prompt.ne(pad_id),
+                   generate_kwargs=processor_generate_kwargs(
+                       proc, lookback_time=proc.lookback_time if trim_lookback else 0,
+                       lookahead_time=proc.lookahead_time if trim_lookahead else 0, context_type=context["context_type"].value))
+        if uncond_prompt is not None:
+            ask["negative_prompt"] = uncond_prompt
+        return ask
+
+    def on_result(w: int, row: torch.Tensor, stats: dict) -> None:
+        frame_time, max_len, trim_lookback, trim_lookahead = pending.pop(w)
+        proc._record_generation_stats(stats)
+        proc.add_predicted_tokens_to_context(context, row[max_len:].cpu(), frame_time, trim_lookback, trim_lookahead)
+
+    conditioning_fn = None
+    if getattr(proc, "do_song_position_embed", False) or any(k in model_kwargs for k in ("difficulty", "mapper_idx", "beatmap_idx")):
+        def conditioning_fn(w: int) -> dict:
+            kw = {k: (v[0] if isinstance(v, torch.Tensor) and v.dim() > 0 and v.shape[0] == 1 else v)
+                  for k, v in model_kwargs.items() if k in ("difficulty", "mapper_idx", "beatmap_idx")}
+            if getattr(proc, "do_song_position_embed", False):
+                ft = frame_times[w].item()
+                kw["song_position"] = torch.tensor([ft / song_length, (ft + proc.miliseconds_per_sequence) / song_length],
+                                                   dtype=torch.float32)
+            return kw
+
+    frames = torch.stack([proc.prepare_frames(f)[0] for f in frames_all])
+    return SongJob(frames=frames, prompt_fn=prompt_fn, on_result=on_result, conditioning_fn=conditioning_fn)

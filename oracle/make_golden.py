@@ -39,6 +39,9 @@ T5_CASES = {
     "t5_base": dict(size="base", ns=160000, src=1251, tgt=136, wseed=5, gain=4.0, aseed=2,
                     prompts=[[0, 0, 1], [1, 40, 700], [0, 1, 9], [1, 5, 1003]], audio="varied", gains="diverse",
                     scores=True),
+    # BASELINE configs[4] dims ("osuT5-large" = google/t5-v1_1-large through the same wrapper): 2 ragged rows, 69 new tokens
+    "t5_large": dict(size="large", ns=160000, src=1251, tgt=72, wseed=7, gain=4.0, aseed=3,
+                     prompts=[[0, 1, 40], [1, 9, 700]], audio="varied", gains="diverse", scores=True),
 }
 TOPK = 16   # per (step, row): the TOPK largest processed scores + their ids + the row's logsumexp
 
@@ -234,7 +237,9 @@ def tokenizer_case():
                         unidirectional=T5Attention._relative_position_bucket(rel, False, 32, 128).numpy())
 
 
-def dit_case(name, preset, T, wseed, iseed, cfg_scale):
+def dit_case(name, preset, T, wseed, iseed, cfg_scale, loop_steps=100):
+    """loop_steps < 100: the reference loop is run over that many injected draws only (the long DiT-B window: the
+    per-step arithmetic is what is pinned, a full 100-step trajectory of a random denoiser is chaotic anyway)"""
     depth, hidden, heads = DIT_PRESETS[preset]
     sd = random_dit_state_dict(depth, hidden, seed=wseed)
     rh.ref_shims.install()
@@ -259,10 +264,22 @@ def dit_case(name, preset, T, wseed, iseed, cfg_scale):
                                 model_kwargs=dict(c=c, y=y, cfg_scale=cfg_scale, attn_mask=mask, key_padding_mask=None))
     finally:
         gd.th.randn_like = orig
-    full = rh.reference_ddpm(ref, diff, z, c, y, cfg_scale, mask, list(noise))
+    if loop_steps >= 100:
+        full = rh.reference_ddpm(ref, diff, z, c, y, cfg_scale, mask, list(noise))
+    else:   # the last `loop_steps` iterations (indices loop_steps-1 .. 0) of the reference loop from z
+        full = z
+        gd.th.randn_like = lambda v: pending.pop(0)
+        pending = list(noise[:loop_steps])
+        try:
+            with torch.no_grad():
+                for i in range(loop_steps - 1, -1, -1):
+                    full = diff.p_sample(ref.forward_with_cfg, full, torch.full((2,), i, dtype=torch.long), clip_denoised=True,
+                                         model_kwargs=dict(c=c, y=y, cfg_scale=cfg_scale, attn_mask=mask, key_padding_mask=None))["sample"]
+        finally:
+            gd.th.randn_like = orig
     np.savez_compressed(
         os.path.join(OUT, name + ".npz"), preset=preset, T=T, weight_seed=wseed, input_seed=iseed, cfg_scale=cfg_scale,
-        eps_t99=eps[99].numpy(), eps_t50=eps[50].numpy(), eps_t0=eps[0].numpy(),
+        loop_steps=loop_steps, eps_t99=eps[99].numpy(), eps_t50=eps[50].numpy(), eps_t0=eps[0].numpy(),
         p_sample_i57=one["sample"].numpy(), p_sample_i57_x0=one["pred_xstart"].numpy(), sample_100=full.numpy(),
         timestep_map=np.array(diff.timestep_map), betas=diff.betas,
         posterior_log_variance_clipped=diff.posterior_log_variance_clipped,
@@ -372,21 +389,32 @@ def mel_case():
     np.savez_compressed(os.path.join(OUT, "mel_oracle.npz"), audio_seed=9, n_samples=16000, mel=m.numpy())
 
 
-def main():
+def main(only=None):
+    """`python -m oracle.make_golden` regenerates everything; `python -m oracle.make_golden NAME ...` only the named
+    fixtures (t5_tiny, t5_small, t5_base, t5_large, t5_base_bf16ref, t5_tiny_cond, t5_tiny_tf, dit_xs, dit_s, dit_b,
+    dit_b_1024, dit_pipeline, whisper_frontend, mel_oracle, tokenizer)."""
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(max(1, os.cpu_count() or 1))
-    tokenizer_case()
-    mel_case()
-    whisper_frontend_case()
+    cases = {"tokenizer": tokenizer_case, "mel_oracle": mel_case, "whisper_frontend": whisper_frontend_case}
     for name in T5_CASES:
-        t5_case(name)
-    t5_bf16_reference_case("t5_base")
-    t5_conditioning_case()
-    types_first_case()
-    dit_case("dit_xs", "DiT-XS", 96, 21, 5, 1.5)
-    dit_case("dit_s", "DiT-S", 160, 1, 2, 2.0)
-    pipeline_case()
+        cases[name] = (lambda n: (lambda: t5_case(n)))(name)
+    cases.update({
+        "t5_base_bf16ref": lambda: t5_bf16_reference_case("t5_base"),
+        "t5_tiny_cond": t5_conditioning_case,
+        "t5_tiny_tf": types_first_case,
+        "dit_xs": lambda: dit_case("dit_xs", "DiT-XS", 96, 21, 5, 1.5),
+        "dit_s": lambda: dit_case("dit_s", "DiT-S", 160, 1, 2, 2.0),
+        # BASELINE configs[4]: DiT-B (osu_diffusion/utils/models.py:392) at a chunk-sized and at a full 1024-point window
+        "dit_b": lambda: dit_case("dit_b", "DiT-B", 256, 4, 6, 1.5),
+        "dit_b_1024": lambda: dit_case("dit_b_1024", "DiT-B", 1024, 4, 8, 2.0, loop_steps=3),
+        "dit_pipeline": pipeline_case,
+    })
+    for name, fn in cases.items():
+        if only and name not in only:
+            continue
+        fn()
 
 
 if __name__ == "__main__":
-    main()
+    import sys
+    main(set(sys.argv[1:]) or None)

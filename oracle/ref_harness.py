@@ -281,3 +281,45 @@ def reference_pipeline_positions(model, seq_x, seq_o, seq_c, class_vector, unk_c
             return pipe.generate([], _Cfg(), None)
     finally:
         gd.th.randn_like = orig
+
+
+def make_reference_processor(tok, model, *, src_seq_len: int, tgt_seq_len: int, lookback: float = 0.5, lookahead: float = 0.4,
+                             train_lookahead: float = 0.0, cfg_scale: float = 1.0, types_first: bool = False,
+                             add_pre_tokens: bool = False, hop_length: int = 128, sample_rate: int = 16000):
+    """The reference's `Processor` (osuT5/osuT5/inference/processor.py:71-150) without its constructor -- that one wants a
+    whole InferenceConfig and an OsuParser (the absent `slider` package) -- with every attribute the sequential /
+    parallel generation loops read, computed by the constructor's own formulas."""
+    ref_shims.install()
+    from osuT5.osuT5.event import Event, EventType
+    from osuT5.osuT5.inference import processor as ref_proc
+    proc = object.__new__(ref_proc.Processor)
+    ms_step = ref_proc.MILISECONDS_PER_STEP
+    proc.model, proc.tokenizer, proc.precision, proc.device = model, tok, "fp32", "cpu"
+    proc.tgt_seq_len = tgt_seq_len
+    proc.frame_seq_len = src_seq_len - 1
+    proc.frame_size, proc.sample_rate = hop_length, sample_rate
+    proc.samples_per_sequence = proc.frame_seq_len * proc.frame_size
+    proc.miliseconds_per_sequence = proc.samples_per_sequence * ref_proc.MILISECONDS_PER_SECOND / proc.sample_rate
+    proc.lookback_time = lookback * proc.miliseconds_per_sequence
+    proc.lookback_time_range = range(tok.event_start[EventType.TIME_SHIFT],
+                                     tok.encode(Event(EventType.TIME_SHIFT, int(proc.lookback_time / ms_step))))
+    proc.lookahead_max_time = (1 - lookahead) * proc.miliseconds_per_sequence
+    proc.lookahead_time = lookahead * proc.miliseconds_per_sequence
+    proc.lookahead_time_range = range(tok.encode(Event(EventType.TIME_SHIFT, int(proc.lookahead_max_time / ms_step))),
+                                      tok.event_end[EventType.TIME_SHIFT])
+    proc.eos_time = (1 - train_lookahead) * proc.miliseconds_per_sequence
+    proc.center_pad_decoder = False
+    for name in ("add_out_context_types", "add_gamemode_token", "add_style_token", "add_diff_token", "add_mapper_token",
+                 "add_year_token", "add_hitsounded_token", "add_song_length_token", "add_global_sv_token", "add_cs_token",
+                 "add_keycount_token", "add_hold_note_ratio_token", "add_scroll_speed_ratio_token", "add_descriptors",
+                 "add_sv_special_token", "add_kiai_special_token", "add_song_position_token", "add_kiai", "add_gd_context",
+                 "add_timing", "do_style_embed", "do_difficulty_embed", "do_mapper_embed", "do_song_position_embed",
+                 "add_positions", "add_sv", "add_mania_sv", "add_to_beatmap"):
+        setattr(proc, name, False)
+    proc.max_pre_token_len, proc.add_pre_tokens = -1, add_pre_tokens
+    proc.start_time = proc.end_time = None
+    proc.cfg_scale, proc.top_p, proc.top_k, proc.temperature = cfg_scale, 0.9, 0, 0.9
+    proc.timing_temperature, proc.mania_column_temperature, proc.taiko_hit_temperature = 0.9, 0.9, 0.9
+    proc.do_sample, proc.num_beams, proc.parallel, proc.max_batch_size = False, 1, False, 4
+    proc.timeshift_bias, proc.types_first, proc.last_generation_stats = 0.0, types_first, None
+    return proc

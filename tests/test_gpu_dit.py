@@ -27,8 +27,10 @@ def setup(name):
     return g, dit, orc, z, c, y, odit.band_mask(T, 128), float(g["cfg_scale"])
 
 
-@pytest.mark.parametrize("name", ["dit_xs", "dit_s"])
+@pytest.mark.parametrize("name", ["dit_xs", "dit_s", "dit_b", "dit_b_1024"])
 def test_eps_matches_reference_golden(name):
+    """dit_b / dit_b_1024: BASELINE configs[4]'s DiT-B (osu_diffusion/utils/models.py:392) at 256 and at 1024 points --
+    the eps the REFERENCE module produced (oracle/make_golden.py), same gate as the small presets."""
     g, dit, orc, z, c, y, mask, cfg = setup(name)
     for tv in (99, 50, 0):
         t = torch.full((2,), tv, dtype=torch.long)
@@ -106,6 +108,51 @@ def test_single_p_sample_and_loop(name):
     out3 = diff.p_sample_loop(dit.forward_with_cfg, z.shape, zt, denoised_fn=lambda v: spec(v), model_kwargs=dict(
         c=c.cuda(), y=y.cuda(), cfg_scale=cfg, attn_mask=mask), step_noise=noise).cpu()
     assert (out3 - out2).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("name", ["dit_b", "dit_b_1024"])
+def test_dit_b_p_sample_and_loop_vs_reference_golden(name):
+    """DiT-B against the reference's own `p_sample` (one step at loop index 57) and its sampling loop (100 steps at 256
+    points; the last 3 loop iterations at 1024 points) with the golden's injected draws."""
+    from mapperatorinator_amd import _lib
+    from mapperatorinator_amd.dit import create_diffusion
+    g, dit, orc, z, c, y, mask, cfg = setup(name)
+    diff = create_diffusion([100, 0, 0, 0, 0, 0, 0, 0, 0, 0], noise_schedule="squaredcos_cap_v2", diffusion_steps=1000)
+    noise = torch.from_numpy(np.random.default_rng(500 + int(g["input_seed"])).standard_normal((100, *z.shape)).astype(np.float32))
+    lib = _lib.load()
+    N, _, T = z.shape
+    zt = z.cuda()
+    t = torch.full((2,), diff.timestep_map[57], dtype=torch.long)
+    mo = dit.forward_with_cfg(zt, t.cuda(), c.cuda(), y.cuda(), cfg, attn_mask=mask)
+    coefs = diff.coef_table().cuda()
+    xo, pr = torch.empty_like(zt), torch.empty_like(zt)
+    _lib.check(lib.mh_ddpm_step(mo.data_ptr(), zt.data_ptr(), noise[0].cuda().contiguous().data_ptr(), coefs[57].contiguous().data_ptr(),
+                                None, None, None, 0, N, T, xo.data_ptr(), pr.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    e1 = (xo.cpu() - torch.from_numpy(g["p_sample_i57"])).abs().max().item()
+    e2 = (pr.cpu() - torch.from_numpy(g["p_sample_i57_x0"])).abs().max().item()
+    print(name, "one p_sample vs reference: sample", e1, "pred_xstart", e2)
+    assert e1 < 2e-4 and e2 < 2e-4
+    steps = int(g["loop_steps"])
+    kw = dict(c=c.cuda(), y=y.cuda(), cfg_scale=cfg, attn_mask=mask, key_padding_mask=None)
+    if steps >= 100:
+        out = diff.p_sample_loop(dit.forward_with_cfg, z.shape, zt, model_kwargs=kw, step_noise=noise).cpu()
+        tol = 5e-2          # a 100-step trajectory amplifies rounding (module docstring)
+    else:                   # the reference ran loop indices steps-1 .. 0 from z with the first `steps` draws
+        x = zt
+        for k, i in enumerate(range(steps - 1, -1, -1)):
+            tt = torch.full((2,), diff.timestep_map[i], dtype=torch.long).cuda()
+            mo = dit.forward_with_cfg(x, tt, c.cuda(), y.cuda(), cfg, attn_mask=mask)
+            nxt = torch.empty_like(x)
+            _lib.check(lib.mh_ddpm_step(mo.data_ptr(), x.contiguous().data_ptr(), noise[k].cuda().contiguous().data_ptr(),
+                                        coefs[i].contiguous().data_ptr(), None, None, None, 0, N, T, nxt.data_ptr(), None,
+                                        torch.cuda.current_stream().cuda_stream))
+            torch.cuda.synchronize()
+            x = nxt
+        out, tol = x.cpu(), 1e-3
+    e = (out - torch.from_numpy(g["sample_100"])).abs().max().item()
+    print(name, f"{steps}-step loop vs reference: max abs", e)
+    assert torch.isfinite(out).all() and e < tol
 
 
 def test_dit_rng_consumption_matches_reference_pattern():
@@ -289,10 +336,11 @@ def test_batched_chunks_equal_independent_runs(variant):
     assert (batched[1] - batched[0]).abs().mean().item() > 1.0, "chunks must differ"
 
 
-def test_batched_denoiser_eps_vs_oracle_per_chunk():
-    """B = 8 chunks in one denoiser batch (2 B T = 2048 rows: the bf16 x 3 GEMM path + flash attention + 64x64 tiles):
-    every chunk's CFG-combined eps within 2e-4 of the CPU oracle run on that chunk alone -- the same gate as the
-    single-chunk golden tests."""
+@pytest.mark.parametrize("B", [8, 32])
+def test_batched_denoiser_eps_vs_oracle_per_chunk(B):
+    """B chunks in one denoiser batch (B = 8: 2 B T = 2048 rows, where the bf16 x 3 GEMM path + flash attention + 64x64
+    tiles start; B = 32: 8192 rows = the shape bench.py's config 3 runs): every chunk's CFG-combined eps within 2e-4 of
+    the CPU oracle run on that chunk alone -- the same gate as the single-chunk golden tests."""
     from mapperatorinator_amd.dit import BandMask, DiTHIP
     from mapperatorinator_amd.testing import DIT_PRESETS, random_dit_state_dict, synthetic_dit_inputs
     from oracle import dit as odit
@@ -300,7 +348,7 @@ def test_batched_denoiser_eps_vs_oracle_per_chunk():
     sd = random_dit_state_dict(depth, hidden, seed=4)
     dit = DiTHIP(sd, depth, hidden, heads, device="cuda")
     orc = odit.DiTOracle(sd, depth, hidden, heads)
-    B, T, cfg = 8, 128, 2.0
+    T, cfg = 128, 2.0
     parts = [synthetic_dit_inputs(T, seed=30 + b) for b in range(B)]
     z = torch.cat([p[0][:1] for p in parts] + [p[0][1:] for p in parts])
     c = torch.cat([p[1][:1] for p in parts] + [p[1][1:] for p in parts])
