@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MH_ABI_VERSION 4
+#define MH_ABI_VERSION 5
 #define MH_MAX_LAYERS 32
 
 typedef enum MhStatus {
@@ -183,7 +183,19 @@ typedef struct MhT5Config {
   int src_len;              /* L: mel frames per chunk (encoder positions)             */
   int tgt_len;              /* max_target_positions = StaticCache length                */
   int dtype;                /* MhDtype                                                  */
-  float eps;                /* RMSNorm epsilon (1e-6)                                   */
+  float eps;                /* RMSNorm epsilon (T5: 1e-6; Whisper family: nn.RMSNorm(eps=None) = finfo(dtype).eps) */
+  /* --- ABI 5: the Whisper-family backbone of the released V30-V32 checkpoints ('OliBomby/varwhisper-*',
+   * osuT5/osuT5/model/custom_transformers/modeling_varwhisper.py) behind the same entry points ------------------------ */
+  int arch;                 /* 0 = T5-v1.1 (relative bias, unscaled scores, gated-GELU FFN); 1 = VarWhisper: conv front-end,
+                               pre-norm RMSNorm blocks, fused Wqkv / Wo and fc1 -> gelu(erf) -> fc2 with optional biases,
+                               rotate-half RoPE on q / k of the self-attentions, scores * attn_scale, untied head        */
+  float attn_scale;         /* arch 1: 1 / sqrt(64)                                                                      */
+  int in_frames;            /* arch 1: log-mel frames per chunk entering the front-end (`mel` rows per chunk); src_len is
+                               then the number of ENCODER positions = (in_frames - 1) / 2 + 1 (conv2 stride 2), which is
+                               what the cross-attention streams.  arch 0: unused (= src_len)                             */
+  int local_every;          /* arch 1: global_attn_every_n_layers -- layer l is LOCAL iff l % local_every != 0; <= 1: none */
+  int local_window;         /* arch 1: local_attention // 2 keys either side for local layers (the reference applies the
+                               window on its flash-attention path only, modeling_varwhisper.py:330)                      */
 } MhT5Config;
 
 typedef struct MhT5Weights {
@@ -213,6 +225,23 @@ typedef struct MhT5Weights {
   const void* dec_wo[MH_MAX_LAYERS];
   const float* dec_final_ln;
   const void* lm_head;                   /* [vocab_out, d]                                            */
+  /* --- ABI 5, arch 1 only (all NULL for T5).  Matrix slots above are reused: *_qkv = fused Wqkv [3 d, d], *_o = Wo,
+   * dec_cq = cross Wq, dec_ckv_all = the layers' cross Wkv stacked [n_dec * 2 d, d] (rows k | v per layer, head-major:
+   * `kv.view(bs, -1, 2, H, 64)`, :544), dec_co = cross Wo, *_wi = fc1 [d_ff, d] (NOT interleaved), *_wo = fc2 [d, d_ff],
+   * dec_embed = the wrapper's decoder_embedder, lm_head = proj_out, enc_ln1 / enc_ln2 = self_attn_layer_norm /
+   * final_layer_norm, dec_ln1 / dec_ln2 / dec_ln3 = self_attn_ / cross_attn_ / final_layer_norm. ------------------- */
+  const void* conv1_w; const float* conv1_b;      /* front-end, mh_whisper_frontend layout ([d, Kpad] tap-major)      */
+  const void* conv2_w; const float* conv2_b;
+  const float* enc_qkv_b[MH_MAX_LAYERS]; const float* enc_o_b[MH_MAX_LAYERS];     /* fp32, NULL = attention_bias false */
+  const float* enc_fc1_b[MH_MAX_LAYERS]; const float* enc_fc2_b[MH_MAX_LAYERS];
+  const float* dec_qkv_b[MH_MAX_LAYERS]; const float* dec_o_b[MH_MAX_LAYERS];
+  const float* dec_cq_b[MH_MAX_LAYERS]; const float* dec_ckv_b_all;               /* [n_dec * 2 d]                     */
+  const float* dec_co_b[MH_MAX_LAYERS];
+  const float* dec_fc1_b[MH_MAX_LAYERS]; const float* dec_fc2_b[MH_MAX_LAYERS];
+  /* rotary tables, fp32 [positions][64] = cos(32) | sin(32), built on the host by VarWhisperRotaryEmbedding's formulas
+   * (:212-226) and rounded to the storage type there: encoder positions 0 .. src_len-1, decoder 0 .. tgt_len-1;
+   * *_local = the same with local_rope_theta for local layers (may alias the global ones)                           */
+  const float* enc_rope; const float* enc_rope_local; const float* dec_rope; const float* dec_rope_local;
 } MhT5Weights;
 
 /* bytes of scratch needed by mh_t5_encode for a batch of B chunks */
@@ -225,6 +254,10 @@ int64_t mh_t5_encode_workspace_bytes(const MhT5Config* cfg, int B);
  * enc_out_f32 optional fp32 copy [B*L, d] (NULL to skip) for parity checks. */
 int mh_t5_encode(const MhT5Config* cfg, const MhT5Weights* w, const void* mel, int B, void* enc_out,
                  float* enc_out_f32, void* workspace, int64_t workspace_bytes, void* stream);
+/* arch 1 (VarWhisperEncoder.forward, modeling_varwhisper.py:779-852): `mel` is [B * in_frames, n_mels_pad] log-mel
+ * frames (mh_mel with the torchaudio parameterisation, log1p) -- the time-major transpose of HF's input_features --
+ * and the same call runs conv1 + GELU, conv2 (stride 2) + GELU, the encoder layers (RMSNorm -> Wqkv -> RoPE ->
+ * softmax(q k^T / 8) v -> Wo -> + ; RMSNorm -> fc1 -> GELU -> fc2 -> +) and the final RMSNorm; enc_out [B * src_len, d]. */
 
 /* The same with the wrapper's conditioning embedders (difficulty / mapper style / song position / style:
  * modeling_mapperatorinator.py:395-414 -- per-row vectors repeated over the frames and concatenated to the mel frames in

@@ -37,7 +37,10 @@ class MhT5Config(C.Structure):
     _fields_ = [("d_model", C.c_int), ("d_kv", C.c_int), ("d_ff", C.c_int), ("n_heads", C.c_int),
                 ("n_enc_layers", C.c_int), ("n_dec_layers", C.c_int), ("vocab_in", C.c_int),
                 ("vocab_out", C.c_int), ("n_mels", C.c_int), ("n_mels_pad", C.c_int), ("src_len", C.c_int),
-                ("tgt_len", C.c_int), ("dtype", C.c_int), ("eps", C.c_float)]
+                ("tgt_len", C.c_int), ("dtype", C.c_int), ("eps", C.c_float),
+                # ABI 5: the Whisper-family backbone (arch 1)
+                ("arch", C.c_int), ("attn_scale", C.c_float), ("in_frames", C.c_int), ("local_every", C.c_int),
+                ("local_window", C.c_int)]
 
 
 class MhT5Weights(C.Structure):
@@ -47,7 +50,13 @@ class MhT5Weights(C.Structure):
                 ("enc_wi", _PTR_ARR), ("enc_wo", _PTR_ARR), ("enc_final_ln", VP),
                 ("dec_ln1", _PTR_ARR), ("dec_qkv", _PTR_ARR), ("dec_o", _PTR_ARR), ("dec_ln2", _PTR_ARR),
                 ("dec_cq", _PTR_ARR), ("dec_ckv_all", VP), ("dec_co", _PTR_ARR), ("dec_ln3", _PTR_ARR),
-                ("dec_wi", _PTR_ARR), ("dec_wo", _PTR_ARR), ("dec_final_ln", VP), ("lm_head", VP)]
+                ("dec_wi", _PTR_ARR), ("dec_wo", _PTR_ARR), ("dec_final_ln", VP), ("lm_head", VP),
+                # ABI 5, arch 1 only
+                ("conv1_w", VP), ("conv1_b", VP), ("conv2_w", VP), ("conv2_b", VP),
+                ("enc_qkv_b", _PTR_ARR), ("enc_o_b", _PTR_ARR), ("enc_fc1_b", _PTR_ARR), ("enc_fc2_b", _PTR_ARR),
+                ("dec_qkv_b", _PTR_ARR), ("dec_o_b", _PTR_ARR), ("dec_cq_b", _PTR_ARR), ("dec_ckv_b_all", VP),
+                ("dec_co_b", _PTR_ARR), ("dec_fc1_b", _PTR_ARR), ("dec_fc2_b", _PTR_ARR),
+                ("enc_rope", VP), ("enc_rope_local", VP), ("dec_rope", VP), ("dec_rope_local", VP)]
 
 
 class MhSampling(C.Structure):
@@ -78,7 +87,7 @@ class MhDiTWeights(C.Structure):
                 ("first_w3", VP), ("qkv_w3", _PTR_ARR), ("out_w3", _PTR_ARR), ("fc1_w3", _PTR_ARR), ("fc2_w3", _PTR_ARR)]
 
 
-ABI_VERSION = 4   # MH_ABI_VERSION of include/mapperhip.h
+ABI_VERSION = 5   # MH_ABI_VERSION of include/mapperhip.h
 
 # every symbol include/mapperhip.h declares: (name, restype, argtypes)
 I, I64, F = C.c_int, C.c_int64, C.c_float

@@ -46,6 +46,11 @@ class ConditioningEmbedders:
         self.has_difficulty = "difficulty_embedder.basis_centers" in sd
         self.has_mapper = "mapper_embedder.embedding.weight" in sd
         self.has_song_position = "song_pos_embedder.basis_centers" in sd
+        if "encoder_embedder.weight" not in state_dict:        # project_encoder_input = false (the Whisper-family configs)
+            if sd:
+                raise NotImplementedError("conditioning embedders without encoder_embedder (project_encoder_input=false)")
+            self.w_cond, self.bias, self.cond_size = torch.zeros(0, 0), torch.zeros(0), 0
+            return
         w = state_dict["encoder_embedder.weight"].detach().to(torch.float32).cpu()
         self.w_cond = w[:, self.n_mels:].contiguous()          # (d_model, cond_size)
         self.bias = state_dict["encoder_embedder.bias"].detach().to(torch.float32).cpu()

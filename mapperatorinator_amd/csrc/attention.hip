@@ -58,10 +58,14 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(AttnArgs p) {
 
   // key tiles this query block can see
   int t_lo = 0, t_hi = (Lk - 1) / 64;
-  if (p.band > 0) {
-    int klo = qb0 - (p.band - 1);
+  // band > 0: -(band - 1) <= k - q <= band (the DiT's banded mask); band < 0: |k - q| <= -band (the symmetric window of
+  // the Whisper family's local layers: flash-attention `window_size = (w, w)`)
+  const int rel_lo = p.band > 0 ? -(p.band - 1) : (p.band < 0 ? p.band : -(1 << 30));
+  const int rel_hi = p.band > 0 ? p.band : (p.band < 0 ? -p.band : (1 << 30));
+  if (p.band != 0) {
+    int klo = qb0 + rel_lo;
     klo = klo < 0 ? 0 : klo;
-    int khi = qb0 + 63 + p.band;
+    int khi = qb0 + 63 + rel_hi;
     khi = khi > Lk - 1 ? Lk - 1 : khi;
     t_lo = klo / 64;
     t_hi = khi / 64;
@@ -157,7 +161,7 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(AttnArgs p) {
         float v = s[j][r] * p.scale + bv[r][j];
         const int rel = kg - qpos;
         bool ok = (kg < Lk) && (kmv[j] != 0);
-        if (p.band > 0) ok = ok && (rel >= -(p.band - 1)) && (rel <= p.band);
+        if (p.band != 0) ok = ok && (rel >= rel_lo) && (rel <= rel_hi);
         if (p.causal) ok = ok && (rel <= 0);
         v = ok ? v : -INFINITY;
         s[j][r] = v;
@@ -308,7 +312,8 @@ __global__ __launch_bounds__(256) void attn_small_f32_kernel(SmallAttnP p) {
       vf[db][kk] = vtb[(long)(db * 16 + l15) * p.Lpad + (key < L ? key : L - 1)];   // never a pad column (P is 0 there)
     }
   // S = scale * Q K^T with the band mask; C layout: col = l15 (key in block), row = lg*4 + r (query)
-  const int rel_lo = p.band > 0 ? -(p.band - 1) : -(1 << 30), rel_hi = p.band > 0 ? p.band : (1 << 30);   // band 0 = open
+  const int rel_lo = p.band > 0 ? -(p.band - 1) : (p.band < 0 ? p.band : -(1 << 30));          // band 0 = open, < 0 = |k - q| <= -band
+  const int rel_hi = p.band > 0 ? p.band : (p.band < 0 ? -p.band : (1 << 30));
   f32x4_t sc[KBW];
   float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll

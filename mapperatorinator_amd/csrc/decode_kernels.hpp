@@ -206,7 +206,7 @@ __device__ inline void store_head_row_from_lds_wt(T* dst, const float* src, int 
 //     whole-line loads was built and measured: the extra LDS write / barrier / read costs what the loads save (o-projection
 //     3.61 us alone, 4.12 beside a second chain; whole step 37.4 k vs 38.1 k tok/s without it) -- not kept.
 enum { PRO_PLAIN = 0, PRO_RMSNORM = 1 };
-enum { SK_STORE = 0, SK_QKV = 1, SK_GEGLU = 2, SK_RESID = 3, SK_LOGITS = 4 };
+enum { SK_STORE = 0, SK_QKV = 1, SK_GEGLU = 2, SK_RESID = 3, SK_LOGITS = 4, SK_GELU_ERF = 5 };   // (GELU_ERF: the Whisper family's fc1)
 
 struct SkinnyP {
   const void* A; int lda;      // PRO_PLAIN: T [B, lda];  PRO_RMSNORM: fp32 residual stream [B, lda]
@@ -219,6 +219,7 @@ struct SkinnyP {
   void* kc; void* vc;          // QKV: this layer's self-attention caches [B][H][tgt_len][64]
   int H, tgt_len, inner;
   const int* pos;
+  const float* bias;           // kernel template BIAS (the Whisper family's biased projections): fp32 [N], else unused
 };
 
 template <typename T> struct VecOps;
@@ -293,7 +294,6 @@ constexpr int kGemvCH = 8;   // k-blocks per wave whose loads are in flight at o
 // (12 dwords: the 13th and 14th preload slots do not arrive on this firmware -- the kernel body re-loads them)
 #define MH_GEMV_LEAD_PARAMS const void *A_, const void *W_, float *h_, const float *lnw_, int K_, int B_, int N_, int nv_
 #define MH_GEMV_LEAD_ARGS(p) (p).A, (p).W, (p).h, (p).ln_w, (p).K, (p).B, (p).N, (p).nv
-template <typename T, int MF, int NWV, int PRO, int EPI>
 #ifndef MH_GEMV_WPE
 #define MH_GEMV_WPE 4
 #endif
@@ -302,6 +302,7 @@ template <typename T, int MF, int NWV, int PRO, int EPI>
 #else
 #define MH_GEMV_WPE_ATTR
 #endif
+template <typename T, int MF, int NWV, int PRO, int EPI, bool BIAS = false>
 __global__ __launch_bounds__(NWV * 64) MH_GEMV_WPE_ATTR
 void gemv_kernel(MH_GEMV_LEAD_PARAMS, SkinnyP p) {
   p.A = A_; p.W = W_; p.h = h_; p.ln_w = lnw_; p.K = K_; p.lda = K_; p.ldw = K_; p.B = B_; p.N = N_; p.nv = nv_;
@@ -374,6 +375,8 @@ void gemv_kernel(MH_GEMV_LEAD_PARAMS, SkinnyP p) {
 #pragma unroll
   for (int u = 0; u < UPW; ++u) oldh[u] = 0.f;
   constexpr int PROBE = MH_GEMV_PROBE;
+  float bias_v = 0.f;
+  if (BIAS) bias_v = p.bias[ocol < p.N ? ocol : p.N - 1];
   if (EPI == SK_RESID && l15 < nv && !(PROBE & 4)) {   // requested before anything is waited for
 #pragma unroll
     for (int u = 0; u < UPW; ++u) {
@@ -558,7 +561,10 @@ void gemv_kernel(MH_GEMV_LEAD_PARAMS, SkinnyP p) {
     }
     const int row = ef * 16 + lg * 4 + r;
     const bool ok = col_ok && row < p.B && (!(PROBE & 16) || p.B < 0);
-    if (EPI == SK_GEGLU) {
+    if (BIAS) v += bias_v;
+    if (EPI == SK_GELU_ERF) {
+      if (ok) store_wt(reinterpret_cast<T*>(p.out) + (long)row * p.ldo + ocol, Elem<T>::from_f32(0.5f * v * (1.0f + erff(v * 0.70710678118654752f))));
+    } else if (EPI == SK_GEGLU) {
       const float lin = __shfl_down(v, 8, 16);   // the linear half of the pair sits 8 tile columns to the right
       if (ok) store_wt(reinterpret_cast<T*>(p.out) + (long)row * p.ldo + ocol, Elem<T>::from_f32(gelu_tanh(v) * lin));
     } else if (EPI == SK_STORE) {
@@ -618,7 +624,7 @@ __device__ inline void partial_merge_groups(Partial& s) {  // across the 8 key g
 template <typename T, int U, typename E = T>
 __device__ inline void attend_keys(Partial& st, const float (&q)[8], const E* kbase, const E* vbase, int j0,
                                    int jend, int jstride, const float* bias_row, int pos, const uint8_t* mask_row,
-                                   int P, float scale) {
+                                   int P, float scale, int jmin = 0) {   // keys below jmin are masked (sliding window)
   // processes keys j0, j0+jstride, ... < jend for this lane's key group, U at a time
   const int c8 = (threadIdx.x & 7) * 8;
   for (int j = j0; j < jend; j += jstride * U) {
@@ -666,7 +672,7 @@ __device__ inline void attend_keys(Partial& st, const float (&q)[8], const E* kb
 #pragma unroll
       for (int i = 0; i < 8; ++i) d += q[i] * kv[u][i];
       d = group_sum<8>(d) * scale + bv[u];
-      const bool ok = (jj < jend) && (mv[u] != 0);
+      const bool ok = (jj < jend) && (jj >= jmin) && (mv[u] != 0);
       d = ok ? d : -INFINITY;
       s[u] = d;
       cmax = fmaxf(cmax, d);
@@ -695,6 +701,11 @@ struct SelfAttnP {
   void* out; int ldo;             // T [B, inner]
   int B, H, tgt_len;
   const int* pos;
+  // the Whisper family (kernel template WH; modeling_varwhisper.py:229-258,381-568): fp32 bias of this layer's fused
+  // Wqkv [3 inner] or NULL; rotary table fp32 [tgt_len][64] = cos(32) | sin(32) of every position (built on the host with
+  // the reference's formulas, already rounded to the storage type); score scale; window > 0: keys older than
+  // pos - window are not attended (local layers under the flash-attention path, :330)
+  const float* qkv_bias; const float* rope; float scale; int window;
 };
 
 // merge the 4 waves' partial (m, l, acc[64]) through LDS; threads 0..63 return the merged (m, l, a[d])
@@ -759,6 +770,8 @@ struct CrossAttnP {
   // measurement only (mh_t5_decode_timing): [slots][2] = (earliest workgroup start, latest workgroup end) of THIS
   // launch in wall-clock ticks, slot = *pos * ts_layers + ts_layer for the first ts_ring positions; NULL in production
   unsigned long long* tstamp; const int* pos; int ts_ring, ts_layers, ts_layer;
+  // the Whisper family (kernel template WH): fp32 bias of this layer's query projection [inner] or NULL, and the score scale
+  const float* q_bias; float scale;
 };
 
 // (b, h) of workgroup `blk`; under CFG (B == 2 kv_B) the two rows that share K/V sit in adjacent workgroups
@@ -891,7 +904,8 @@ struct HeadProj {
       for (int c = 0; c < KC; ++c) raw[q][c].load(wp + c * 128);
     }
   }
-  __device__ inline void apply(const float* xn, float (*out)[64]) const {
+  // bias (fp32, indexed like the weight rows) or NULL: out = T-rounded (acc + bias[row0 + o]) -- nn.Linear with bias
+  __device__ inline void apply(const float* xn, float (*out)[64], const float* bias = nullptr, const int* row0 = nullptr) const {
     const int tid = threadIdx.x, o = tid >> 4, ks = tid & 15;
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
@@ -905,6 +919,7 @@ struct HeadProj {
         acc += x0.x * w[0] + x0.y * w[1] + x0.z * w[2] + x0.w * w[3] + x1.x * w[4] + x1.y * w[5] + x1.z * w[6] + x1.w * w[7];
       }
       acc = group_sum<16>(acc);
+      if (bias) acc += bias[row0[q] + o];
       if (ks == 0) out[q][o] = Elem<T>::to_f32(Elem<T>::from_f32(acc));
     }
   }
@@ -913,7 +928,7 @@ struct HeadProj {
 // cross-attention of one (b, h) with its own query projection; 16 waves, one key split (the default configuration
 // of dec_cross_attn_kernel, same key interleave and merge order)
 // F8: K / V are the e4m3 copy (64-byte rows, 8 bytes per lane; the scales multiply the scores and the output)
-template <typename T, int KC, int U, bool F8 = false>
+template <typename T, int KC, int U, bool F8 = false, bool WH = false>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8)))   // <= 64 VGPRs: 2 workgroups per CU
 void dec_cross_attn_q_kernel(const float* h_, const float* lnw_, const void* W_, const void* k_, const void* v_, int H_, int L_, int d_,
                              int kvB_, CrossAttnP p, HeadProjP hp) {   // leading scalars: preloaded kernel arguments (see gemv_kernel)
@@ -949,13 +964,13 @@ void dec_cross_attn_q_kernel(const float* h_, const float* lnw_, const void* W_,
   nrow.finish(hp, xn, red16);
   MH_STAMP(KID_CROSS, 0);   // row normalised
   if (sizeof(T) != 2) proj.load(hp, row0);
-  proj.apply(xn, qs);
+  proj.apply(xn, qs, WH ? p.q_bias : nullptr, row0);
   __syncthreads();
   MH_STAMP(KID_CROSS, 1);   // query projected
   float q[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) q[i] = qs[0][c8 + i];
-  const float ks = F8 ? p.kscale[kvb * p.H + h] : 1.0f, vs = F8 ? p.vscale[kvb * p.H + h] : 1.0f;
+  const float ks = (F8 ? p.kscale[kvb * p.H + h] : 1.0f) * (WH ? p.scale : 1.0f), vs = F8 ? p.vscale[kvb * p.H + h] : 1.0f;
   Partial st;
   partial_init(st);
   attend_keys<T, U, E>(st, q, kb, vb, wid * 8 + g, p.L, 8 * NW, nullptr, 0, nullptr, 0, ks);
@@ -1005,7 +1020,7 @@ __device__ inline void norm_rows_to_lds(const HeadProjP& hp, int b0, int B, T (*
 
 // self-attention of one (b, h) with its own q / k / v projections: appends the new key / value row to the caches and
 // attends over keys 0 .. pos-1 from the cache plus the new key straight from LDS (merged last)
-template <typename T, int KC>
+template <typename T, int KC, bool WH = false>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4)))   // 16 waves = 4 per SIMD: the whole 128-register budget
 void dec_self_attn_qkv_kernel(const float* h_, const float* lnw_, const void* W_, const int* pos_,
                                                                  const void* kc_, const void* vc_, int H_, int d_, SelfAttnP p,
@@ -1031,24 +1046,45 @@ void dec_self_attn_qkv_kernel(const float* h_, const float* lnw_, const void* W_
   constexpr bool kAllAtOnce = sizeof(T) == 2 && KC <= 7;
   HeadProj<T, KC, kAllAtOnce ? 3 : 1> proj;
   const int row03[3] = {h * 64, inner + h * 64, 2 * inner + h * 64};
-  const float* bias_row = p.bias + (long)h * p.tgt_len;
+  const float* bias_row = WH ? nullptr : p.bias + (long)h * p.tgt_len;       // (the Whisper family has no additive bias)
   const uint8_t* mask_row = p.prompt_mask ? p.prompt_mask + (long)b * p.P : nullptr;
-  const float bias0 = bias_row[0];
+  const float bias0 = WH ? 0.f : bias_row[0];
+  float rope_c = 1.f, rope_s = 0.f;
+  if (WH) {   // cos / sin of this position for rotary pair (threadIdx.x & 31)
+    rope_c = p.rope[(long)pos * 64 + (threadIdx.x & 31)];
+    rope_s = p.rope[(long)pos * 64 + 32 + (threadIdx.x & 31)];
+  }
   const int new_key_mask = (mask_row && pos < p.P) ? (int)mask_row[pos < p.P ? pos : 0] : 1;
   nrow.finish(hp, xn, red16);
+  const float* qb = WH ? p.qkv_bias : nullptr;
   if (kAllAtOnce) {
     proj.load3(hp, row03);   // (requested AFTER the normalisation: holding the 18 vectors across it measured 688 vs 677 us per token step)
-    proj.apply(xn, qkv);
+    proj.apply(xn, qkv, qb, row03);
   } else {   // fp32 storage, or d_model = 1024 in bf16: one projection at a time (register budget of a 1024-thread workgroup)
 #pragma unroll
     for (int q3 = 0; q3 < 3; ++q3) {
       const int row0[1] = {q3 * inner + h * 64};
       HeadProj<T, KC, 1> proj1;
       proj1.load(hp, row0);
-      proj1.apply(xn, qkv + q3);
+      proj1.apply(xn, qkv + q3, qb, row0);
     }
   }
   __syncthreads();
+  if (WH) {
+    // rotate-half RoPE on q and k (apply_rotary_pos_emb, modeling_varwhisper.py:236-258): pair (i, i + 32) of a head ->
+    // (x1 cos - x2 sin, x2 cos + x1 sin), T-rounded; threads 0..63 = q, 64..127 = k
+    float rot = 0.f;
+    const int t = threadIdx.x;
+    if (t < 128) {
+      const float* x = qkv[t >> 6];
+      const int i = t & 31;
+      const float x1 = x[i], x2 = x[i + 32];
+      rot = (t & 32) ? x2 * rope_c + x1 * rope_s : x1 * rope_c - x2 * rope_s;
+    }
+    __syncthreads();
+    if (t < 128) qkv[t >> 6][t & 63] = Elem<T>::to_f32(Elem<T>::from_f32(rot));
+    __syncthreads();
+  }
   MH_STAMP(KID_SELF, 0);    // q / k / v projected
   T* kcache = reinterpret_cast<T*>(const_cast<void*>(p.kc)) + ((long)b * p.H + h) * p.tgt_len * 64;
   T* vcache = reinterpret_cast<T*>(const_cast<void*>(p.vc)) + ((long)b * p.H + h) * p.tgt_len * 64;
@@ -1059,7 +1095,11 @@ void dec_self_attn_qkv_kernel(const float* h_, const float* lnw_, const void* W_
   for (int i = 0; i < 8; ++i) q[i] = qkv[0][c8 + i];
   Partial st;
   partial_init(st);
-  attend_keys<T, 2>(st, q, kcache, vcache, wid * 8 + g, pos, 8 * NW, bias_row, pos, mask_row, p.P, 1.0f);
+  const float sc = WH ? p.scale : 1.0f;
+  int j_first = 0;
+  if (WH && p.window > 0 && pos - p.window > 0) j_first = (pos - p.window) & ~(8 * NW - 1);   // whole key iterations below the window are skipped
+  attend_keys<T, 2>(st, q, kcache, vcache, j_first + wid * 8 + g, pos, 8 * NW, bias_row, pos, mask_row, p.P, sc,
+                    (WH && p.window > 0) ? pos - p.window : 0);
   MH_STAMP(KID_SELF, 1);    // cached keys attended (this wave)
   partial_merge_groups<T>(st);
   float m, l, a;
@@ -1067,7 +1107,7 @@ void dec_self_attn_qkv_kernel(const float* h_, const float* lnw_, const void* W_
   MH_STAMP(KID_SELF, 2);    // partials merged
   if (threadIdx.x < 64) {
     const int d = threadIdx.x;
-    float sn = wave_sum(qkv[0][d] * qkv[1][d]) + bias0;
+    float sn = wave_sum(qkv[0][d] * qkv[1][d]) * sc + bias0;
     if (new_key_mask == 0) sn = -INFINITY;
     const float mn = fmaxf(m, sn);
     const float fa = fexp<T>(m - mn), fb = fexp<T>(sn - mn);

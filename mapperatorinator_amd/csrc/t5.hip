@@ -27,8 +27,15 @@ int check_cfg(const MhT5Config* c, const char* who) {
   MH_REQUIRE(c->d_model % 32 == 0 && c->d_ff % 32 == 0, "%s: d_model/d_ff must be multiples of 32", who);
   MH_REQUIRE(c->n_mels_pad % 32 == 0 && c->n_mels_pad >= c->n_mels, "%s: bad n_mels_pad", who);
   MH_REQUIRE(c->dtype == MH_F32 || c->dtype == MH_BF16, "%s: bad dtype", who);
+  MH_REQUIRE(c->arch == 0 || c->arch == 1, "%s: arch %d is neither 0 (T5) nor 1 (VarWhisper)", who, c->arch);
+  if (c->arch == 1) {
+    MH_REQUIRE(c->d_model == c->n_heads * 64, "%s: the Whisper family needs d_model = 64 heads", who);
+    MH_REQUIRE(c->in_frames >= 1 && c->src_len == (c->in_frames - 1) / 2 + 1, "%s: src_len must be the conv-strided in_frames", who);
+    MH_REQUIRE(c->attn_scale > 0.f, "%s: attn_scale must be positive", who);
+  }
   return MH_OK;
 }
+inline bool is_local_layer(const MhT5Config* c, int l) { return c->arch == 1 && c->local_every > 1 && c->local_window > 0 && l % c->local_every != 0; }
 
 #define MH_TRY(expr)              \
   do {                            \
@@ -49,6 +56,8 @@ extern "C" int64_t mh_t5_encode_workspace_bytes(const MhT5Config* c, int B) {
   const int64_t rows = (int64_t)B * c->src_len, es = es_of(c->dtype);
   const int inner = c->n_heads * 64, Lpad = round_up(c->src_len, 64);
   int64_t t = 0;
+  if (c->arch == 1)   // front-end scratch + its output (storage type) in front of the layer buffers
+    t += align256(mh_whisper_frontend_workspace_bytes(B, c->in_frames, c->n_mels_pad, c->d_model, c->dtype)) + align256(rows * c->d_model * es);
   t += align256(rows * c->d_model * 4);                    // h
   t += align256(rows * c->d_model * es);                   // n
   t += align256(rows * 2 * inner * es);                    // qk
@@ -60,6 +69,44 @@ extern "C" int64_t mh_t5_encode_workspace_bytes(const MhT5Config* c, int B) {
 
 namespace mh {
 namespace {
+// fp32 residual stream <- storage-typed rows (the conv front-end's output)
+template <typename T>
+__global__ __launch_bounds__(256) void rows_to_f32_kernel(const T* __restrict__ x, float* __restrict__ h, long n) {
+  const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i + 3 < n) {
+    *reinterpret_cast<float4*>(h + i) = make_float4(Elem<T>::to_f32(x[i]), Elem<T>::to_f32(x[i + 1]), Elem<T>::to_f32(x[i + 2]), Elem<T>::to_f32(x[i + 3]));
+  } else {
+    for (long j = i; j < n; ++j) h[j] = Elem<T>::to_f32(x[j]);
+  }
+}
+// rotate-half RoPE in place on the q | k block of a QKV GEMM output (apply_rotary_pos_emb,
+// osuT5/osuT5/model/custom_transformers/modeling_varwhisper.py:229-258): row r = b * L + position, 2H head slots of 64
+// columns; one thread rotates 8 pairs (i, i + 32): two 16-byte (bf16) / four (fp32) accesses each way.
+// rope fp32 [L][64] = cos(32) | sin(32).
+template <typename T>
+__global__ __launch_bounds__(256) void rope_qk_kernel(T* __restrict__ qk, int ld, long rows, int L, int slots, const float* __restrict__ rope) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;       // (row, slot, chunk of 8 pairs)
+  const long total = rows * slots * 4;
+  if (idx >= total) return;
+  const int c = (int)(idx & 3);
+  const long rs = idx >> 2;
+  const int slot = (int)(rs % slots);
+  const long row = rs / slots;
+  const int pos = (int)(row % L);
+  T* x1 = qk + row * ld + slot * 64 + c * 8;
+  T* x2 = x1 + 32;
+  const float* cs = rope + (long)pos * 64 + c * 8;
+  float a[8], b[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { a[i] = Elem<T>::to_f32(x1[i]); b[i] = Elem<T>::to_f32(x2[i]); }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float co = cs[i], si = cs[32 + i];
+    x1[i] = Elem<T>::from_f32(a[i] * co - b[i] * si);
+    x2[i] = Elem<T>::from_f32(b[i] * co + a[i] * si);
+  }
+}
+
 // h[b * L + t][:] = row_bias[b][:]  (the conditioning embedders' contribution, constant along a chunk's frames)
 __global__ __launch_bounds__(256) void fill_rows_kernel(float* __restrict__ h, const float* __restrict__ row_bias, int L, int d) {
   const long row = blockIdx.x;
@@ -84,6 +131,61 @@ extern "C" int mh_t5_encode_cond(const MhT5Config* c, const MhT5Weights* w, cons
   const int L = c->src_len, d = c->d_model, H = c->n_heads, inner = H * 64, dff = c->d_ff;
   const int rows = B * L, es = es_of(c->dtype), Lpad = round_up(L, 64);
   Arena ar(workspace, workspace_bytes);
+  if (c->arch == 1) {
+    // ---- VarWhisperEncoder.forward (modeling_varwhisper.py:779-852) --------------------------------------------------
+    MH_REQUIRE(!row_bias, "mh_t5_encode: the Whisper-family configs carry no conditioning embedders");
+    MH_REQUIRE(w->conv1_w && w->conv1_b && w->conv2_w && w->conv2_b && w->enc_rope, "mh_t5_encode: arch 1 needs the conv front-end weights and the rotary table");
+    const int64_t fe_bytes = mh_whisper_frontend_workspace_bytes(B, c->in_frames, c->n_mels_pad, d, c->dtype);
+    void* fe_ws = ar.take(fe_bytes);
+    void* x0 = ar.take((int64_t)rows * d * es);
+    float* h = (float*)ar.take((int64_t)rows * d * 4);
+    void* n = ar.take((int64_t)rows * d * es);
+    void* qk = ar.take((int64_t)rows * 2 * inner * es);
+    void* vt = ar.take((int64_t)B * inner * Lpad * es);
+    void* attn = ar.take((int64_t)rows * inner * es);
+    void* ff = ar.take((int64_t)rows * dff * es);
+    MH_REQUIRE(ar.ok() && ff, "mh_t5_encode: arena overflow");
+    MH_TRY(mh_whisper_frontend(mel, B, c->in_frames, c->n_mels_pad, w->conv1_w, w->conv1_b, w->conv2_w, w->conv2_b, nullptr, d, x0,
+                               fe_ws, fe_bytes, c->dtype, stream));
+    const long nel = (long)rows * d;
+    if (c->dtype == MH_BF16) hipLaunchKernelGGL(mh::rows_to_f32_kernel<bf16_t>, dim3((unsigned)((nel / 4 + 255) / 256 + 1)), dim3(256), 0, s, (const bf16_t*)x0, h, nel);
+    else hipLaunchKernelGGL(mh::rows_to_f32_kernel<float>, dim3((unsigned)((nel / 4 + 255) / 256 + 1)), dim3(256), 0, s, (const float*)x0, h, nel);
+    MH_TRY(check_launch("rows_to_f32_kernel"));
+    if (hipMemsetAsync(vt, 0, (size_t)B * inner * Lpad * es, s) != hipSuccess) return check_launch("memset vt");
+    MhGemm g;
+    for (int l = 0; l < c->n_enc_layers; ++l) {
+      const bool local = is_local_layer(c, l);
+      MH_TRY(rmsnorm(h, d, w->enc_ln1[l], n, d, rows, d, c->eps, c->dtype, s));
+      g = MhGemm{};
+      g.A = n; g.lda = d; g.W = w->enc_qkv[l]; g.ldw = d; g.C = qk; g.ldc = 2 * inner; g.M = rows; g.N = 3 * inner;
+      g.K = d; g.bias = w->enc_qkv_b[l]; g.dtype = c->dtype; g.epilogue = MH_EPI_QKV_VT; g.C2 = vt; g.n_split = 2 * inner;
+      g.kv_B = B; g.kv_H = H; g.kv_L = L; g.kv_Lpad = Lpad;
+      MH_TRY(gemm(g, s));
+      const float* rope = (local && w->enc_rope_local) ? w->enc_rope_local : w->enc_rope;
+      const long work = (long)rows * 2 * H * 4;
+      if (c->dtype == MH_BF16) hipLaunchKernelGGL(mh::rope_qk_kernel<bf16_t>, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, (bf16_t*)qk, 2 * inner, (long)rows, L, 2 * H, rope);
+      else hipLaunchKernelGGL(mh::rope_qk_kernel<float>, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, (float*)qk, 2 * inner, (long)rows, L, 2 * H, rope);
+      MH_TRY(check_launch("rope_qk_kernel"));
+      MH_TRY(attention(qk, 2 * inner, inner, vt, Lpad, nullptr, attn, inner, B, L, H, c->attn_scale, local ? -c->local_window : 0, c->dtype, s));
+      g = MhGemm{};
+      g.A = attn; g.lda = inner; g.W = w->enc_o[l]; g.ldw = inner; g.C = h; g.ldc = d; g.M = rows; g.N = d; g.K = inner;
+      g.bias = w->enc_o_b[l]; g.dtype = c->dtype; g.epilogue = MH_EPI_RESID;
+      MH_TRY(gemm(g, s));
+      MH_TRY(rmsnorm(h, d, w->enc_ln2[l], n, d, rows, d, c->eps, c->dtype, s));
+      MH_REQUIRE(w->enc_fc1_b[l] && w->enc_fc2_b[l], "mh_t5_encode: fc1 / fc2 carry biases in the Whisper family");
+      g = MhGemm{};
+      g.A = n; g.lda = d; g.W = w->enc_wi[l]; g.ldw = d; g.C = ff; g.ldc = dff; g.M = rows; g.N = dff; g.K = d;
+      g.bias = w->enc_fc1_b[l]; g.dtype = c->dtype; g.epilogue = MH_EPI_BIAS_GELU_ERF;
+      MH_TRY(gemm(g, s));
+      g = MhGemm{};
+      g.A = ff; g.lda = dff; g.W = w->enc_wo[l]; g.ldw = dff; g.C = h; g.ldc = d; g.M = rows; g.N = d; g.K = dff;
+      g.bias = w->enc_fc2_b[l]; g.dtype = c->dtype; g.epilogue = MH_EPI_RESID;
+      MH_TRY(gemm(g, s));
+    }
+    MH_TRY(rmsnorm(h, d, w->enc_final_ln, enc_out, d, rows, d, c->eps, c->dtype, s));
+    if (enc_out_f32) MH_TRY(rmsnorm(h, d, w->enc_final_ln, enc_out_f32, d, rows, d, c->eps, MH_F32, s));
+    return MH_OK;
+  }
   float* h = (float*)ar.take((int64_t)rows * d * 4);
   void* n = ar.take((int64_t)rows * d * es);
   void* qk = ar.take((int64_t)rows * 2 * inner * es);
@@ -143,6 +245,7 @@ extern "C" int mh_t5_cross_kv(const MhT5Config* c, const MhT5Weights* w, const v
   MhGemm g = MhGemm{};
   g.A = enc_out; g.lda = c->d_model; g.W = w->dec_ckv_all; g.ldw = c->d_model; g.C = cross_kv; g.ldc = 0;
   g.M = B * c->src_len; g.N = c->n_dec_layers * 2 * inner; g.K = c->d_model; g.dtype = c->dtype;
+  g.bias = c->arch == 1 ? w->dec_ckv_b_all : nullptr;
   g.epilogue = MH_EPI_KV_SCATTER; g.kv_B = B; g.kv_H = c->n_heads; g.kv_L = c->src_len;
   return gemm(g, (hipStream_t)stream);
 }
@@ -613,7 +716,7 @@ int gemv_cols(int N) {
   return 4;
 }
 
-template <typename T, int MF, int PRO, int EPI>
+template <typename T, int MF, int PRO, int EPI, bool BIAS = false>
 int launch_skinny(dec::SkinnyP p, hipStream_t s) {
   const int kb = 4 * (16 / (int)sizeof(T));
   MH_REQUIRE(p.K % kb == 0 && p.K >= kb, "decode: K=%d must be a positive multiple of %d", p.K, kb);
@@ -632,19 +735,25 @@ int launch_skinny(dec::SkinnyP p, hipStream_t s) {
       set_error("decode: RMSNorm GEMV needs d_model <= 1024 in bf16 storage");
       return MH_ERR_ARG;
     } else {
-      hipLaunchKernelGGL((dec::gemv_kernel<T, MF, 8, PRO, EPI>), dim3(tiles), dim3(512), 0, s, MH_GEMV_LEAD_ARGS(p), p);
+      hipLaunchKernelGGL((dec::gemv_kernel<T, MF, 8, PRO, EPI, BIAS>), dim3(tiles), dim3(512), 0, s, MH_GEMV_LEAD_ARGS(p), p);
     }
   } else {
-    hipLaunchKernelGGL((dec::gemv_kernel<T, MF, 4, PRO, EPI>), dim3(tiles), dim3(256), 0, s, MH_GEMV_LEAD_ARGS(p), p);
+    hipLaunchKernelGGL((dec::gemv_kernel<T, MF, 4, PRO, EPI, BIAS>), dim3(tiles), dim3(256), 0, s, MH_GEMV_LEAD_ARGS(p), p);
   }
   return check_launch("gemv_kernel");
 }
 
-template <typename T, int PRO, int EPI>
+template <typename T, int PRO, int EPI, bool BIAS = false>
 int skinny(const dec::SkinnyP& p, hipStream_t s) {
-  if (p.B <= 16) return launch_skinny<T, 1, PRO, EPI>(p, s);
-  if (p.B <= 32) return launch_skinny<T, 2, PRO, EPI>(p, s);
-  return launch_skinny<T, 4, PRO, EPI>(p, s);
+  MH_REQUIRE(!BIAS || p.bias, "decode: biased GEMV without a bias");
+  if (p.B <= 16) return launch_skinny<T, 1, PRO, EPI, BIAS>(p, s);
+  if (p.B <= 32) return launch_skinny<T, 2, PRO, EPI, BIAS>(p, s);
+  return launch_skinny<T, 4, PRO, EPI, BIAS>(p, s);
+}
+// residual GEMV with an optional bias (the Whisper family's Wo / fc2)
+template <typename T>
+int skinny_resid(const dec::SkinnyP& p, hipStream_t s) {
+  return p.bias ? skinny<T, dec::PRO_PLAIN, dec::SK_RESID, true>(p, s) : skinny<T, dec::PRO_PLAIN, dec::SK_RESID>(p, s);
 }
 
 constexpr int kMaxChains = 8;
@@ -672,6 +781,10 @@ bool fused_proj_enabled(int d) { return option(OPT_DECODE_FUSED_PROJ) != 0 && d 
 template <typename T, int KC>
 int launch_self_qkv(const dec::SelfAttnP& sa, const dec::HeadProjP& hp, int inner, hipStream_t s) {
   MH_REQUIRE(hp.ldh == hp.d && hp.ldw == hp.d && inner == sa.H * 64, "decode: dense residual rows / projection weights expected");
+  if (sa.rope) {   // the Whisper family: biased fused Wqkv, RoPE, scaled scores, optional window
+    hipLaunchKernelGGL((dec::dec_self_attn_qkv_kernel<T, KC, true>), dim3(sa.B * sa.H), dim3(1024), 0, s, MH_SELF_LEAD_ARGS, sa, hp);
+    return check_launch("dec_self_attn_qkv_kernel");
+  }
   // option decode_self_rows: rows of one head per workgroup (1, 2 or 4) -- they share the head's weight slice
   const long R = option(OPT_DECODE_SELF_ROWS);
   if (R >= 4)
@@ -700,7 +813,10 @@ int launch_cross_q(const dec::CrossAttnP& ca, const dec::HeadProjP& hp, hipStrea
   MH_REQUIRE(hp.ldh == hp.d && hp.ldw == hp.d, "decode: dense residual rows / projection weights expected");
   // one key in flight per 8-lane group: 64 VGPRs without spills (two 16-wave workgroups per CU); U = 2 measured the
   // same bandwidth in the stand-alone kernel
-  if (ca.kscale != nullptr) {
+  if (ca.scale != 0.f) {   // the Whisper family: biased Wq, scaled scores
+    MH_REQUIRE(ca.kscale == nullptr, "decode: the fp8 cross K/V copy is not wired for the Whisper family");
+    hipLaunchKernelGGL((dec::dec_cross_attn_q_kernel<T, KC, 1, false, true>), dim3(ca.B * ca.H), dim3(1024), 0, s, MH_CROSS_LEAD_ARGS, ca, hp);
+  } else if (ca.kscale != nullptr) {
     if constexpr (sizeof(T) == 2)
       hipLaunchKernelGGL((dec::dec_cross_attn_q_kernel<T, KC, 1, true>), dim3(ca.B * ca.H), dim3(1024), 0, s, MH_CROSS_LEAD_ARGS, ca, hp);
     else { set_error("decode: the fp8 cross K/V copy needs bf16 storage"); return MH_ERR_ARG; }
@@ -738,9 +854,54 @@ int enqueue_step(const MhT5Config* c, const MhT5Weights* w, const void* cross_kv
   const int d = c->d_model, H = c->n_heads, inner = H * 64, dff = c->d_ff, L = c->src_len, tgt = c->tgt_len;
   const int es = (int)sizeof(T);
   const int* posp = &bf.st->pos;
+  const bool wh = c->arch == 1;
+  if (wh) MH_REQUIRE(fused_proj_enabled(d) && option(OPT_DECODE_FUSED_PROJ) == 1 && option(OPT_DECODE_SELF_ROWS) <= 1 && w->dec_rope,
+                     "decode: the Whisper family runs on the fused attention kernels (d_model a multiple of 128 <= 1024) and needs its rotary table");
   for (int l = 0; l < c->n_dec_layers; ++l) {
     const long cache_off = (long)l * Bfull * H * tgt * 64 * es;
     dec::SkinnyP sk{};
+    if (wh) {
+      // ---- VarWhisperDecoderLayer (modeling_varwhisper.py:633-741), one token: the same six dependent kernels -------
+      const bool local = is_local_layer(c, l);
+      dec::SelfAttnP sa{};
+      sa.kc = (char*)bf.self_k + cache_off; sa.vc = (char*)bf.self_v + cache_off; sa.prompt_mask = prompt_mask; sa.P = P;
+      sa.out = bf.attn; sa.ldo = inner; sa.B = B; sa.H = H; sa.tgt_len = tgt; sa.pos = posp;
+      sa.qkv_bias = w->dec_qkv_b[l]; sa.rope = (local && w->dec_rope_local) ? w->dec_rope_local : w->dec_rope;
+      sa.scale = c->attn_scale; sa.window = local ? c->local_window : 0;
+      dec::HeadProjP hp{};
+      hp.h = bf.h; hp.ldh = d; hp.ln_w = w->dec_ln1[l]; hp.eps = c->eps; hp.W = w->dec_qkv[l]; hp.ldw = d; hp.d = d;
+      MH_TRY(launch_self_qkv_d<T>(sa, hp, inner, s));
+      sk = dec::SkinnyP{};
+      sk.A = bf.attn; sk.lda = inner; sk.W = w->dec_o[l]; sk.ldw = inner; sk.B = B; sk.N = d; sk.K = inner; sk.h = bf.h; sk.ldh = d;
+      sk.bias = w->dec_o_b[l];
+      MH_TRY(skinny_resid<T>(sk, s));
+      dec::CrossAttnP ca{};
+      const long kv_layer = (long)kvB * H * L * 64 * es;
+      ca.k = (const char*)cross_kv + (long)(l * 2 + 0) * kv_layer; ca.v = (const char*)cross_kv + (long)(l * 2 + 1) * kv_layer;
+      ca.out = bf.attn; ca.ldo = inner; ca.B = B; ca.H = H; ca.L = L; ca.kv_B = kvB < Bfull ? kvB : 0;
+      ca.q_bias = w->dec_cq_b[l]; ca.scale = c->attn_scale;
+      MH_REQUIRE(!kv8, "decode: the fp8 cross K/V copy is not wired for the Whisper family");
+      if (g_timing.buf) {
+        ca.tstamp = g_timing.buf + 2L * bf.chain * g_timing.ring * c->n_dec_layers;
+        ca.pos = posp; ca.ts_ring = g_timing.ring; ca.ts_layers = c->n_dec_layers; ca.ts_layer = l;
+      }
+      hp = dec::HeadProjP{};
+      hp.h = bf.h; hp.ldh = d; hp.ln_w = w->dec_ln2[l]; hp.eps = c->eps; hp.W = w->dec_cq[l]; hp.ldw = d; hp.d = d;
+      MH_TRY(launch_cross_q_d<T>(ca, hp, s));
+      sk = dec::SkinnyP{};
+      sk.A = bf.attn; sk.lda = inner; sk.W = w->dec_co[l]; sk.ldw = inner; sk.B = B; sk.N = d; sk.K = inner; sk.h = bf.h; sk.ldh = d;
+      sk.bias = w->dec_co_b[l];
+      MH_TRY(skinny_resid<T>(sk, s));
+      sk = dec::SkinnyP{};
+      sk.A = bf.h; sk.lda = d; sk.ln_w = w->dec_ln3[l]; sk.eps = c->eps; sk.W = w->dec_wi[l]; sk.ldw = d; sk.B = B;
+      sk.N = dff; sk.K = d; sk.out = bf.ff; sk.ldo = dff; sk.bias = w->dec_fc1_b[l];
+      MH_TRY((skinny<T, dec::PRO_RMSNORM, dec::SK_GELU_ERF, true>(sk, s)));
+      sk = dec::SkinnyP{};
+      sk.A = bf.ff; sk.lda = dff; sk.W = w->dec_wo[l]; sk.ldw = dff; sk.B = B; sk.N = d; sk.K = dff; sk.h = bf.h; sk.ldh = d;
+      sk.bias = w->dec_fc2_b[l];
+      MH_TRY(skinny_resid<T>(sk, s));
+      continue;
+    }
     // self attention
     const bool fused = fused_proj_enabled(d);                                  // cross-attention projects its own query
     const bool fused_self = fused && option(OPT_DECODE_FUSED_PROJ) == 1;       // (2: stand-alone QKV GEMV, fused cross-attention)
@@ -1147,7 +1308,7 @@ extern "C" int mh_t5_generate(const MhT5Config* c, const MhT5Weights* w, const v
   // batched prompt prefill (positions 0..P-2); MH_DECODE_PREFILL=0 feeds the prompt token by token instead
   int start_pos = 0;
   {
-    if (P > 1 && option(OPT_DECODE_PREFILL) != 0) {
+    if (P > 1 && option(OPT_DECODE_PREFILL) != 0 && c->arch == 0) {   // (the Whisper family feeds its prompt token by token)
       PrefillBuf pb;
       const int64_t used_dec = ar.off;
       prefill_layout(c, B, P - 1, (char*)workspace + used_dec, workspace_bytes - used_dec, &pb);
@@ -1282,6 +1443,7 @@ extern "C" int mh_t5_decoder_forward(const MhT5Config* c, const MhT5Weights* w, 
                                      const int32_t* ids, const uint8_t* mask, int T, float* logits, void* workspace,
                                      int64_t workspace_bytes, void* stream) {
   MH_TRY(check_cfg(c, "mh_t5_decoder_forward"));
+  MH_REQUIRE(c->arch == 0, "mh_t5_decoder_forward: arch 1 has no batched prompt path yet -- use mh_t5_generate with `forced` and `logits_dump`");
   MH_REQUIRE(w && cross_kv && ids && logits && workspace, "mh_t5_decoder_forward: null argument");
   MH_REQUIRE(B > 0 && T >= 1 && T <= c->tgt_len, "mh_t5_decoder_forward: T=%d not in [1, tgt_len=%d]", T, c->tgt_len);
   MH_REQUIRE(workspace_bytes >= mh_t5_forward_workspace_bytes(c, B, T), "mh_t5_decoder_forward: workspace too small");

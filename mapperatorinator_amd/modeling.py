@@ -5,10 +5,11 @@ stands for the *generate* path: same attributes the callers read (`.device`, `.d
 `.config.{max_target_positions, max_source_positions, hidden_size, vocab_size, ...}`,
 `.spectrogram`, `.generate(**kwargs)`), but the arithmetic underneath is libmapperhip.
 
-Only the T5-backbone configuration of the north star is wired (input_features=False,
-project_encoder_input=True, embed_decoder_input=True, no conditioning embedders:
-configs/model/default.yaml:1-4 + t5_small_v9.yaml:5); anything else raises NotImplementedError
-instead of silently running something different.
+Two backbones are wired: the T5 configuration of the north star (input_features=False, project_encoder_input=True,
+embed_decoder_input=True: configs/model/default.yaml:1-4 + t5_small_v9.yaml:5) and the Whisper-family one of the released
+V30-V32 checkpoints ('OliBomby/varwhisper-*': input_features=True, project_encoder_input=False, torchaudio log-mel --
+configs/model/varwhisper_{small,base}_v3.yaml; whisper_engine.py); anything else raises NotImplementedError instead of
+silently running something different.
 """
 from __future__ import annotations
 
@@ -19,6 +20,7 @@ import torch
 
 from .conditioning import ConditioningEmbedders
 from .t5_engine import T5Dims, T5Engine, T5_PRESETS
+from .whisper_engine import VARWHISPER_PRESETS, VarWhisperDims, VarWhisperEngine
 
 
 def dims_from_backbone_config(bc) -> T5Dims:
@@ -40,9 +42,17 @@ class MapperatorinatorHIP:
                  n_mels: int = 388, src_seq_len: int = 1251, tgt_seq_len: int = 512,
                  dtype: torch.dtype = torch.bfloat16, device="cuda", sample_rate: int = 16000, n_fft: int = 1024,
                  hop_length: int = 128, f_min: int = 0, f_max: int = 8000, spectrogram_log_scale: bool = False,
-                 pad_token_id: int = 0, bos_token_id: int = 1, eos_token_id: int = 2):
-        self.engine = T5Engine(state_dict, dims, vocab_size_in, vocab_size_out, n_mels, src_seq_len, tgt_seq_len,
-                               dtype, device, sample_rate, n_fft, hop_length, f_min, f_max, spectrogram_log_scale)
+                 pad_token_id: int = 0, bos_token_id: int = 1, eos_token_id: int = 2, backbone_options: Optional[dict] = None):
+        """`dims`: T5Dims (google/t5-v1_1-*) or VarWhisperDims (OliBomby/varwhisper-*; `src_seq_len` then counts log-mel
+        frames as the reference's data.src_seq_len does, `backbone_options` = global_rope_theta / local_rope_theta /
+        global_attn_every_n_layers / local_attention)."""
+        self.is_whisper = isinstance(dims, VarWhisperDims)
+        if self.is_whisper:
+            self.engine = VarWhisperEngine(state_dict, dims, vocab_size_in, vocab_size_out, n_mels, src_seq_len, tgt_seq_len,
+                                           dtype, device, sample_rate, n_fft, hop_length, f_min, f_max, **(backbone_options or {}))
+        else:
+            self.engine = T5Engine(state_dict, dims, vocab_size_in, vocab_size_out, n_mels, src_seq_len, tgt_seq_len,
+                                   dtype, device, sample_rate, n_fft, hop_length, f_min, f_max, spectrogram_log_scale)
         self._source_state_dict = state_dict      # caller-owned tensors under the reference's parameter names (not copied)
         # difficulty / mapper / song-position / style embedders, if the state dict carries them (host side; their output
         # reaches the device as a per-chunk row bias of the encoder input projection)
@@ -52,23 +62,41 @@ class MapperatorinatorHIP:
         self.spectrogram = self.engine.spectrogram
         self.config = types.SimpleNamespace(
             hidden_size=dims.d_model, num_attention_heads=dims.n_heads, num_hidden_layers=dims.n_enc_layers,
-            max_source_positions=src_seq_len, max_target_positions=tgt_seq_len, vocab_size=vocab_size_out,
+            # (Whisper family: config.max_source_positions = src_seq_len // 2, configuration_mapperatorinator.py:107)
+            max_source_positions=src_seq_len // 2 if self.is_whisper else src_seq_len, max_target_positions=tgt_seq_len, vocab_size=vocab_size_out,
             vocab_size_in=vocab_size_in, n_mels=n_mels, hop_length=hop_length, sample_rate=sample_rate,
             pad_token_id=pad_token_id, bos_token_id=bos_token_id, eos_token_id=eos_token_id,
-            is_encoder_decoder=True, backbone_model_name="google/t5-v1_1(hip)",
+            is_encoder_decoder=True, backbone_model_name="OliBomby/varwhisper(hip)" if self.is_whisper else "google/t5-v1_1(hip)",
             # the fields `get_cache` / `MapperatorinatorCache` read (inference/cache_utils.py:23-35): the engine owns its
             # caches, they are here so that code inspecting the reference config finds them
             num_hidden_layers_decoder=dims.n_dec_layers, d_model=dims.d_model, d_kv=dims.d_kv, num_heads=dims.n_heads,
             num_layers=dims.n_enc_layers, num_decoder_layers=dims.n_dec_layers, d_ff=dims.d_ff,
-            torch_dtype=dtype, input_features=False, project_encoder_input=True, embed_decoder_input=True)
+            torch_dtype=dtype, input_features=self.is_whisper, project_encoder_input=not self.is_whisper, embed_decoder_input=True)
 
     # ---- construction from the reference object ---------------------------------------------------
     @classmethod
     def from_reference(cls, model, dtype: Optional[torch.dtype] = None, device="cuda"):
         """`model`: a reference `Mapperatorinator` with a google/t5 backbone (possibly on the CPU)."""
         cfg = model.config
+        if str(cfg.backbone_model_name).startswith("OliBomby/varwhisper"):
+            if not cfg.input_features or cfg.project_encoder_input or not cfg.embed_decoder_input or cfg.input_raw_wave:
+                raise NotImplementedError("HIP path of the Whisper family implements input_features=True, project_encoder_input="
+                                          "False, embed_decoder_input=True (configs/model/varwhisper_*_v3.yaml)")
+            if cfg.spectrogram_implementation != "torchaudio" or not cfg.spectrogram_log_scale or cfg.pad_mode != "reflect":
+                raise NotImplementedError("the Whisper-family configs use the torchaudio log-mel front-end with reflect padding")
+            bc = cfg.backbone_config
+            dims = VarWhisperDims(bc.d_model, bc.encoder_attention_heads, bc.encoder_layers, bc.decoder_layers, bc.encoder_ffn_dim)
+            if bc.decoder_attention_heads != bc.encoder_attention_heads or bc.decoder_ffn_dim != bc.encoder_ffn_dim or bc.activation_function != "gelu":
+                raise NotImplementedError("encoder and decoder of the HIP Whisper path share heads / ffn width; activation gelu")
+            return cls(model.state_dict(), dims, vocab_size_in=cfg.vocab_size_in, vocab_size_out=cfg.vocab_size, n_mels=cfg.n_mels,
+                       src_seq_len=2 * cfg.max_source_positions, tgt_seq_len=cfg.max_target_positions, dtype=dtype or model.dtype,
+                       device=device, sample_rate=cfg.sample_rate, n_fft=cfg.n_fft, hop_length=cfg.hop_length, f_min=cfg.f_min,
+                       f_max=cfg.f_max, spectrogram_log_scale=True, pad_token_id=cfg.pad_token_id, bos_token_id=cfg.bos_token_id,
+                       eos_token_id=cfg.eos_token_id,
+                       backbone_options=dict(global_rope_theta=bc.global_rope_theta, local_rope_theta=bc.local_rope_theta,
+                                             global_attn_every_n_layers=bc.global_attn_every_n_layers, local_attention=bc.local_attention))
         if not str(cfg.backbone_model_name).startswith("google/t5"):
-            raise NotImplementedError("only T5 backbones run on the HIP path (Whisper-family: SURVEY.md 8f rank 2)")
+            raise NotImplementedError("only google/t5 and OliBomby/varwhisper backbones run on the HIP path")
         if cfg.input_features or not cfg.project_encoder_input or not cfg.embed_decoder_input or cfg.input_raw_wave:
             raise NotImplementedError("HIP path implements input_features=False, project_encoder_input=True, "
                                       "embed_decoder_input=True")
@@ -82,6 +110,9 @@ class MapperatorinatorHIP:
 
     @classmethod
     def from_preset(cls, name: str, state_dict: dict, **kw):
+        """name: a T5 preset (tiny / small / base / large) or "varwhisper-<test|tiny|base|small>"."""
+        if name.startswith("varwhisper-"):
+            return cls(state_dict, VARWHISPER_PRESETS[name[len("varwhisper-"):]], **kw)
         return cls(state_dict, T5_PRESETS[name], **kw)
 
     # nn.Module-ish conveniences the reference callers use
@@ -174,6 +205,27 @@ class MapperatorinatorHIP:
         mask = (decoder_attention_mask.to(eng.device).to(torch.uint8).contiguous()
                 if decoder_attention_mask is not None else None)
         row_bias = self._row_bias(ids.shape[0], unused) if encoder_outputs is None else None
+        if self.is_whisper:
+            # no batched teacher-forced path for this family yet: the token loop with the ids forced and its scores dumped
+            # (no processors: an empty sampling struct leaves the logits as they are)
+            from .server import Sampling
+            sp = Sampling()
+            sp.temperature, sp.cfg_scale, sp.max_length, sp.pad_id = 1.0, 1.0, ids.shape[1] + 1, int(self.config.pad_token_id)
+            if sp.max_length > self.config.max_target_positions:
+                raise ValueError("forward(): sequence longer than max_target_positions - 1")
+            forced = torch.zeros((ids.shape[0], sp.max_length), dtype=torch.int32, device=eng.device)
+            forced[:, :ids.shape[1]] = ids
+            eos_table = torch.zeros(self.config.vocab_size, dtype=torch.uint8, device=eng.device)
+            eng._enter()
+            with torch.cuda.stream(eng.stream):
+                kv = self._cross_kv(frames, encoder_outputs, None)
+                m1 = None if mask is None else mask[:, :1].contiguous()
+                _, _, dump = eng.decode(kv, ids[:, :1].contiguous(), m1, eos_table, sp, forced=forced, dump_logits=True)
+                logits = dump[1:ids.shape[1] + 1].transpose(0, 1).contiguous()
+            eng._leave()
+            if mask is not None and not bool(mask.all()):
+                raise NotImplementedError("forward() of the Whisper family with padded decoder_input_ids")
+            return types.SimpleNamespace(logits=logits, encoder_last_hidden_state=None, past_key_values=None, loss=None)
         eng._enter()
         with torch.cuda.stream(eng.stream):
             logits = eng.decoder_forward(self._cross_kv(frames, encoder_outputs, row_bias), ids, mask)

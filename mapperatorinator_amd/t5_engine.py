@@ -120,7 +120,8 @@ class PackedT5:
         pe, pd = "transformer.encoder.", "transformer.decoder."
         cfg = _lib.MhT5Config(dims.d_model, dims.d_kv, dims.d_ff, dims.n_heads, dims.n_enc_layers, dims.n_dec_layers,
                               vocab_in, vocab_out, n_mels, self.n_mels_pad, src_len, tgt_len,
-                              _lib.MH_BF16 if dtype == torch.bfloat16 else _lib.MH_F32, dims.eps)
+                              _lib.MH_BF16 if dtype == torch.bfloat16 else _lib.MH_F32, dims.eps,
+                              0, 1.0, src_len, 0, 0)      # arch 0 = T5
         w = _lib.MhT5Weights()
         # columns beyond n_mels belong to the conditioning vectors: they reach the device as a per-chunk row bias
         # (conditioning.ConditioningEmbedders.row_bias, mh_t5_encode_cond)

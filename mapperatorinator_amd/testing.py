@@ -71,6 +71,65 @@ def random_t5_state_dict(dims: T5Dims, vocab_in: int, vocab_out: int, n_mels: in
     return sd
 
 
+def random_varwhisper_state_dict(d_model: int, n_heads: int, n_enc: int, n_dec: int, ffn: int, vocab_in: int, vocab_out: int,
+                                 n_mels: int = 128, seed: int = 0, head_gain: float = 1.0, attention_bias: bool = True,
+                                 ln_jitter: float = 0.1, gains: dict | None = None) -> dict:
+    """Reference-named parameters of `Mapperatorinator` over the VarWhisper backbone
+    (custom_transformers/modeling_varwhisper.py; configs/model/varwhisper_*_v3.yaml: input_features, no encoder
+    projection, wrapper-side decoder embedding, untied head).  Scales keep the residual stream O(1); `attention_bias`
+    adds the Wqkv / Wq / Wkv / Wo biases of `config.attention_bias`."""
+    rng = np.random.default_rng(7000 + seed)
+    d = d_model
+    sd = {}
+    sd["decoder_embedder.weight"] = _normal(rng, (vocab_in, d), 1.0)
+    sd["transformer.model.decoder.embed_tokens.weight"] = _normal(rng, (vocab_out, d), 0.02)      # (unused: embed_decoder_input)
+    sd["transformer.proj_out.weight"] = _normal(rng, (vocab_out, d), head_gain * d ** -0.5)
+    e = "transformer.model.encoder."
+    sd[e + "conv1.weight"] = _normal(rng, (d, n_mels, 3), (3 * n_mels) ** -0.5)
+    sd[e + "conv1.bias"] = _normal(rng, (d,), 0.05)
+    sd[e + "conv2.weight"] = _normal(rng, (d, d, 3), 1.7 * (3 * d) ** -0.5)
+    sd[e + "conv2.bias"] = _normal(rng, (d,), 0.05)
+
+    def lin(name, n_out, n_in, bias, std=None):
+        sd[name + ".weight"] = _normal(rng, (n_out, n_in), std if std is not None else n_in ** -0.5)
+        if bias:
+            sd[name + ".bias"] = _normal(rng, (n_out,), 0.05)
+
+    def ln(name):
+        sd[name] = 1.0 + _normal(rng, (d,), ln_jitter)
+
+    def mlp(b):
+        lin(b + "fc1", ffn, d, True)
+        lin(b + "fc2", d, ffn, True)
+
+    for l in range(n_enc):
+        b = e + f"layers.{l}."
+        lin(b + "self_attn.Wqkv", 3 * d, d, attention_bias, 1.5 * d ** -0.5)
+        lin(b + "self_attn.Wo", d, d, attention_bias)
+        ln(b + "self_attn_layer_norm.weight")
+        mlp(b)
+        ln(b + "final_layer_norm.weight")
+    ln(e + "layer_norm.weight")
+    dd = "transformer.model.decoder."
+    for l in range(n_dec):
+        b = dd + f"layers.{l}."
+        lin(b + "self_attn.Wqkv", 3 * d, d, attention_bias, 1.5 * d ** -0.5)
+        lin(b + "self_attn.Wo", d, d, attention_bias)
+        ln(b + "self_attn_layer_norm.weight")
+        lin(b + "cross_attn.Wq", d, d, attention_bias, 2.0 * d ** -0.5)
+        lin(b + "cross_attn.Wkv", 2 * d, d, attention_bias, 1.5 * d ** -0.5)
+        lin(b + "cross_attn.Wo", d, d, attention_bias, 2.0 * d ** -0.5)
+        ln(b + "cross_attn_layer_norm.weight")
+        mlp(b)
+        ln(b + "final_layer_norm.weight")
+    ln(dd + "layer_norm.weight")
+    for pat, g in (gains or {}).items():
+        for k in sd:
+            if pat in k:
+                sd[k] = sd[k] * g
+    return sd
+
+
 # weaker token embedding + sharper / stronger cross-attention: the next token depends on WHICH encoder frames the
 # query selects, not only on the previous token (random-init greedy decoding otherwise repeats a handful of ids).
 # Kept mild on purpose: at (0.3, 6, 3) the REFERENCE itself in bfloat16 agrees with its fp32 self on only 73 % of

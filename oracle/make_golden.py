@@ -225,6 +225,55 @@ def types_first_case():
     np.savez_compressed(os.path.join(OUT, "t5_tiny_tf.npz"), **out)
 
 
+VW_CASES = {
+    # name: backbone dims (mapperatorinator_amd.whisper_engine.VARWHISPER_PRESETS), log-mel frames per chunk, tgt_len, ...
+    "vw_test": dict(size="test", frames=250, tgt=48, wseed=3, gain=5.0, aseed=4, prompts=[[0, 0, 1], [1, 40, 700], [0, 1, 9]],
+                    bias=True),
+    "vw_test_nobias": dict(size="test", frames=250, tgt=40, wseed=5, gain=5.0, aseed=6, prompts=[[0, 1], [1, 9]], bias=False),
+    # the released V32 backbone: 'OliBomby/varwhisper-small' (whisper-small dims) at its own chunk size, data.src_seq_len 2048
+    "vw_small": dict(size="small", frames=2048, tgt=72, wseed=9, gain=4.0, aseed=7, prompts=[[0, 1, 40], [1, 9, 700]], bias=True),
+}
+
+
+def vw_case(name):
+    """The Whisper-family backbone on the REFERENCE: `Mapperatorinator` over VarWhisperForConditionalGeneration
+    (custom_transformers/modeling_varwhisper.py) as configs/model/varwhisper_*_v3.yaml wire it, through the reference's own
+    `model_generate`: log-mel slice, encoder states, greedy ids, the 16 best processed scores of every step."""
+    from mapperatorinator_amd.testing import random_varwhisper_state_dict
+    from mapperatorinator_amd.whisper_engine import VARWHISPER_PRESETS
+    c = VW_CASES[name]
+    d = VARWHISPER_PRESETS[c["size"]]
+    over = dict(d_model=d.d_model, encoder_layers=d.n_enc_layers, decoder_layers=d.n_dec_layers, encoder_attention_heads=d.n_heads,
+                decoder_attention_heads=d.n_heads, encoder_ffn_dim=d.d_ff, decoder_ffn_dim=d.d_ff)
+    model, tok, _ = rh.build_reference_varwhisper("small", src_seq_len=c["frames"], tgt_seq_len=c["tgt"], overwrite=over,
+                                                  attention_bias=c["bias"])
+    sd = random_varwhisper_state_dict(d.d_model, d.n_heads, d.n_enc_layers, d.n_dec_layers, d.d_ff, tok.vocab_size_in,
+                                      tok.vocab_size_out, seed=c["wseed"], head_gain=c["gain"], attention_bias=c["bias"],
+                                      gains={"decoder_embedder": 0.5})
+    res = model.load_state_dict(sd, strict=False)
+    assert not res.unexpected_keys and not [k for k in res.missing_keys if "loss_fn" not in k], res
+    ns = (c["frames"] - 1) * 128
+    audio = synthetic_audio_varied(len(c["prompts"]), ns, seed=c["aseed"])
+    prompt = torch.tensor(c["prompts"])
+    with torch.no_grad():
+        mel = model.spectrogram(audio)
+    enc = rh.reference_encode_whisper(model, audio)
+    rec = []
+    ids, stats = rh.reference_generate_whisper(model, tok, audio, prompt, rh.default_generate_kwargs(c["tgt"]), record_scores=rec)
+    ids2, _ = rh.reference_generate_whisper(model, tok, audio, prompt,
+                                            rh.default_generate_kwargs(c["tgt"], temperature=0.7, timeshift_bias=0.35, lookahead_time=3000))
+    v, i, lse = topk_scores(rec)
+    gap = v[..., 0] - v[..., 1]
+    np.savez_compressed(
+        os.path.join(OUT, name + ".npz"), size=c["size"], vocab_in=tok.vocab_size_in, vocab_out=tok.vocab_size_out, n_samples=ns,
+        in_frames=c["frames"], tgt_len=c["tgt"], weight_seed=c["wseed"], head_gain=c["gain"], audio_seed=c["aseed"],
+        attention_bias=c["bias"], prompt=prompt.numpy(), mel_slice=mel[:, ::37, ::11].numpy(), mel_sum=mel.double().sum().item(),
+        enc_slice=enc[:, ::29, ::17].numpy(), enc_abs_mean=enc.abs().double().mean().item(), ids=ids.numpy(),
+        ids_processors=ids2.numpy(), top_vals=v, top_ids=i, lse=lse)
+    print(name, "ids", tuple(ids.shape), "distinct", len(set(ids.flatten().tolist())), "top-2 gap min / median", float(gap.min()),
+          float(np.median(gap)), "tok/s(ref,cpu)", stats["tokens_per_second"])
+
+
 def tokenizer_case():
     _, tok, _ = rh.build_reference_t5("small", src_seq_len=1251, tgt_seq_len=64)
     with open(os.path.join(OUT, "tokenizer_benchmark_vocab.json"), "w") as f:
@@ -391,13 +440,15 @@ def mel_case():
 
 def main(only=None):
     """`python -m oracle.make_golden` regenerates everything; `python -m oracle.make_golden NAME ...` only the named
-    fixtures (t5_tiny, t5_small, t5_base, t5_large, t5_base_bf16ref, t5_tiny_cond, t5_tiny_tf, dit_xs, dit_s, dit_b,
-    dit_b_1024, dit_pipeline, whisper_frontend, mel_oracle, tokenizer)."""
+    fixtures (t5_tiny, t5_small, t5_base, t5_large, vw_test, vw_test_nobias, vw_small, t5_base_bf16ref, t5_tiny_cond,
+    t5_tiny_tf, dit_xs, dit_s, dit_b, dit_b_1024, dit_pipeline, whisper_frontend, mel_oracle, tokenizer)."""
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(max(1, os.cpu_count() or 1))
     cases = {"tokenizer": tokenizer_case, "mel_oracle": mel_case, "whisper_frontend": whisper_frontend_case}
     for name in T5_CASES:
         cases[name] = (lambda n: (lambda: t5_case(n)))(name)
+    for name in VW_CASES:
+        cases[name] = (lambda n: (lambda: vw_case(n)))(name)
     cases.update({
         "t5_base_bf16ref": lambda: t5_bf16_reference_case("t5_base"),
         "t5_tiny_cond": t5_conditioning_case,

@@ -323,3 +323,73 @@ def make_reference_processor(tok, model, *, src_seq_len: int, tgt_seq_len: int, 
     proc.do_sample, proc.num_beams, proc.parallel, proc.max_batch_size = False, 1, False, 4
     proc.timeshift_bias, proc.types_first, proc.last_generation_stats = 0.0, types_first, None
     return proc
+
+
+# ---- the Whisper-family backbone the released V30-V32 checkpoints use ---------------------------------
+VARWHISPER_TINY_OVERWRITE = {"d_model": 128, "encoder_layers": 2, "decoder_layers": 2, "encoder_attention_heads": 2,
+                             "decoder_attention_heads": 2, "encoder_ffn_dim": 256, "decoder_ffn_dim": 256}
+
+
+def build_reference_varwhisper(size="small", src_seq_len=1024, tgt_seq_len=256, n_mels=128, seed=0, head_gain=1.0,
+                               overwrite=None, attn_implementation="sdpa", attention_bias=True, global_attn_every_n_layers=1,
+                               local_attention=128):
+    """reference `_get_model` on configs/model/varwhisper_{small,base}_v3.yaml: backbone 'OliBomby/varwhisper-<size>'
+    (custom_transformers/modeling_varwhisper.py), input_features = true, project_encoder_input = false, the torchaudio
+    log-mel front-end (128 mels, f_min 20, reflect padding, log1p), untied head.  size "tiny": test-only dims."""
+    ref_shims.varwhisper_module()
+    if size == "tiny":
+        size, overwrite = "tiny", dict(VARWHISPER_TINY_OVERWRITE, **(overwrite or {}))
+    args = _train_config("small", src_seq_len, tgt_seq_len, n_mels)
+    args.model.name = f"OliBomby/varwhisper-{size}"
+    args.model.input_features = True
+    args.model.project_encoder_input = False
+    args.model.overwrite = dict({"tie_word_embeddings": False}, **(overwrite or {}))
+    args.model.attention_bias = attention_bias                        # configs/model/default.yaml:23 (true in the released configs)
+    args.model.global_attn_every_n_layers = global_attn_every_n_layers
+    args.model.local_attention = local_attention
+    sp = args.model.spectrogram
+    sp.implementation, sp.log_scale, sp.n_mels, sp.f_min, sp.pad_mode = "torchaudio", True, n_mels, 20, "reflect"
+    from osuT5.osuT5.tokenizer import Tokenizer
+    from osuT5.osuT5.utils.model_utils import _get_model
+    tok = Tokenizer(args)
+    torch.manual_seed(seed)
+    model = _get_model(args, tok, torch.float32, attn_implementation).eval()
+    if head_gain != 1.0:
+        with torch.no_grad():
+            model.transformer.proj_out.weight.mul_(head_gain)
+    return model, tok, args
+
+
+def reference_encode_whisper(model, audio: torch.Tensor) -> torch.Tensor:
+    """log-mel -> (B, n_mels, L) input_features -> the backbone's own encoder (conv front-end + layers + final norm): what
+    `OsuTEncoder.forward` does for input_features = true (modeling_mapperatorinator.py:395-443), called by hand for the
+    same reason as `reference_encode`."""
+    with torch.no_grad():
+        mel = model.spectrogram(audio).to(model.transformer.dtype)
+        return model.transformer.get_encoder()(torch.swapaxes(mel, 1, 2)).last_hidden_state
+
+
+def reference_generate_whisper(model, tok, audio, prompt, generate_kwargs, attention_mask=None, negative_prompt=None,
+                               record_scores=None):
+    """`reference_generate` for a Whisper-family backbone: the reference's own `model_generate` with the encoder states
+    of `reference_encode_whisper` handed over as `encoder_outputs`."""
+    ref_shims.varwhisper_module()
+    from osuT5.osuT5.inference.server import model_generate
+    from transformers import LogitsProcessorList
+    from transformers.modeling_outputs import BaseModelOutput
+    enc = reference_encode_whisper(model, audio)
+    mk = dict(inputs=audio, encoder_outputs=BaseModelOutput(last_hidden_state=enc), decoder_input_ids=prompt,
+              decoder_attention_mask=prompt.ne(0) if attention_mask is None else attention_mask)
+    if negative_prompt is not None:
+        mk.update(negative_prompt=negative_prompt, negative_prompt_attention_mask=negative_prompt.ne(0))
+    orig = LogitsProcessorList.__call__
+    if record_scores is not None:
+        def spy(self, input_ids, scores, **kw):
+            out = orig(self, input_ids, scores, **kw)
+            record_scores.append(out.detach().float().cpu().clone())
+            return out
+        LogitsProcessorList.__call__ = spy
+    try:
+        return model_generate(model, tok, mk, dict(generate_kwargs))
+    finally:
+        LogitsProcessorList.__call__ = orig

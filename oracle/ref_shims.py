@@ -139,8 +139,78 @@ def install():
         return local_t5_config(str(name))
 
     def _whisper_from_pretrained(cls, name, *a, **k):
-        return WhisperConfig()
+        # openai/whisper-{tiny,base,small} dims without the hub; `cls` is WhisperConfig or one of the reference's forks
+        # (VarWhisperConfig.from_pretrained("openai/whisper" + suffix), configuration_mapperatorinator.py:73-78)
+        for suffix, (d, layers, heads) in _WHISPER_DIMS.items():
+            if str(name).endswith(suffix):
+                return cls(d_model=d, encoder_layers=layers, decoder_layers=layers, encoder_attention_heads=heads,
+                           decoder_attention_heads=heads, encoder_ffn_dim=4 * d, decoder_ffn_dim=4 * d)
+        return cls()
 
     T5Config.from_pretrained = classmethod(_t5_from_pretrained)
     WhisperConfig.from_pretrained = classmethod(_whisper_from_pretrained)
+
+    # ---- third-party API drift between the reference's pin (transformers 4.57) and the installed 5.x, Whisper forks only ----
+    # (1) ROPE_INIT_FUNCTIONS["default"] (modeling_varwhisper.py:207) left the table: the published default RoPE
+    #     initialiser restated -- inv_freq[i] = theta^(-2i / head_dim), attention factor 1
+    import torch
+    from transformers import modeling_rope_utils as mru
+
+    def _default_rope(config, device=None, seq_len=None, **kw):
+        head_dim = getattr(config, "head_dim", None) or config.hidden_size // config.num_attention_heads
+        dim = int(head_dim * getattr(config, "partial_rotary_factor", 1.0))
+        inv_freq = 1.0 / (config.rope_theta ** (torch.arange(0, dim, 2, dtype=torch.int64).to(device=device, dtype=torch.float) / dim))
+        return inv_freq, 1.0
+
+    mru.ROPE_INIT_FUNCTIONS.setdefault("default", _default_rope)
+    # (2) torchaudio is not installed: spectrogram.py:38-49 builds torchaudio.transforms.MelSpectrogram -> the torch.stft
+    #     restatement of oracle/mel.py (parity unpinned for that one stage, like nnAudio)
+    from oracle import mel as omel
+
+    class _TorchaudioMel(torch.nn.Module):
+        def __init__(self, sample_rate=16000, n_fft=1024, n_mels=128, hop_length=128, center=True, f_min=0.0, f_max=None,
+                     pad_mode="reflect", **kw):
+            super().__init__()
+            self.kw = dict(n_fft=n_fft, hop=hop_length, n_mels=n_mels, sr=sample_rate, f_min=float(f_min), f_max=float(f_max),
+                           pad_mode=pad_mode)
+
+        def forward(self, x):   # torchaudio returns (B, n_mels, frames), power spectrogram (the wrapper applies log1p itself)
+            return omel.mel_spectrogram_torchaudio(x, log_scale=False, **self.kw).permute(0, 2, 1)
+
+    ta, tat = types.ModuleType("torchaudio"), types.ModuleType("torchaudio.transforms")
+    tat.MelSpectrogram = _TorchaudioMel
+    ta.transforms = tat
+    sys.modules.setdefault("torchaudio", ta)
+    sys.modules.setdefault("torchaudio.transforms", tat)
     _installed = True
+
+
+_WHISPER_DIMS = {"tiny": (384, 4, 6), "base": (512, 6, 8), "small": (768, 12, 12)}
+
+
+def varwhisper_module():
+    """The reference's VarWhisper fork, importable under transformers 5.x: `_tied_weights_keys` is a list there and a dict
+    here (the fork unties its head anyway: configs/model/varwhisper_*_v3.yaml `tie_word_embeddings: false`)."""
+    install()
+    from osuT5.osuT5.model.custom_transformers import modeling_varwhisper as mv
+    cls = mv.VarWhisperForConditionalGeneration
+    cls._tied_weights_keys = {}
+    if not getattr(cls, "_mh_kwargs_filtered", False):
+        # transformers 5.x `generate` hands its own bookkeeping kwargs (`next_sequence_length`, ...) to
+        # prepare_inputs_for_generation, and the wrapper forwards every kwarg it does not know
+        # (modeling_mapperatorinator.py:265-268) into a forward with a closed signature: drop what that signature lacks
+        import inspect
+        orig = cls.forward
+        known = set(inspect.signature(orig).parameters)
+
+        def forward(self, *a, **k):
+            return orig(self, *a, **{kk: v for kk, v in k.items() if kk in known})
+
+        cls.forward = forward
+        cls._mh_kwargs_filtered = True
+        # `cache[layer_idx] -> (keys, values)` (modeling_varwhisper.py:538, the cross-attention cache after the first step)
+        # existed on the pinned 4.57 Cache classes; 5.x keeps the tensors on per-layer objects
+        from transformers.cache_utils import Cache
+        if not hasattr(Cache, "__getitem__"):
+            Cache.__getitem__ = lambda self, i: (self.layers[i].keys, self.layers[i].values)
+    return mv

@@ -47,6 +47,25 @@ def t5_golden_case(name):
     return g, size, tok, sd, audio, src, tgt
 
 
+def vw_golden_case(name):
+    """tests/golden/vw_*.npz (oracle/make_golden.py:vw_case) -> (golden, dims, tok, state_dict, audio): the Whisper-family
+    backbone on the reference; weights and audio regenerated from the recorded seeds."""
+    import numpy as np
+
+    from mapperatorinator_amd import Tokenizer
+    from mapperatorinator_amd.testing import random_varwhisper_state_dict, synthetic_audio_varied
+    from mapperatorinator_amd.whisper_engine import VARWHISPER_PRESETS
+    g = np.load(f"{GOLDEN}/{name}.npz")
+    d = VARWHISPER_PRESETS[str(g["size"])]
+    tok = Tokenizer.benchmark_vocab(src_seq_len=int(g["in_frames"]))
+    assert tok.vocab_size_out == int(g["vocab_out"]) and tok.vocab_size_in == int(g["vocab_in"])
+    sd = random_varwhisper_state_dict(d.d_model, d.n_heads, d.n_enc_layers, d.n_dec_layers, d.d_ff, tok.vocab_size_in,
+                                      tok.vocab_size_out, seed=int(g["weight_seed"]), head_gain=float(g["head_gain"]),
+                                      attention_bias=bool(g["attention_bias"]), gains={"decoder_embedder": 0.5})
+    audio = synthetic_audio_varied(g["prompt"].shape[0], int(g["n_samples"]), seed=int(g["audio_seed"]))
+    return g, d, tok, sd, audio
+
+
 def assert_topk_scores_match(dumped, g, P, tol):
     """dumped: fp32 (cols, B, V) processed scores of a run (index = produced column); g: a fixture holding the
     reference's per-step `top_vals` / `top_ids` (steps, B, K) and `lse` (steps, B).  The K best ids of every step must
