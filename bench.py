@@ -313,7 +313,8 @@ def main():
 
     if rank != 0:
         if use_dist:
-            dist.destroy_process_group()
+            dist.barrier()                  # rank 0 prints its line (its single-rank extras take a few seconds), then every
+            dist.destroy_process_group()    # rank leaves the group together
         return
 
     # ---- roofline of the dominant kernel (HBM-bound decode cross-attention) ------------------------------------
@@ -472,8 +473,9 @@ def main():
                    "parallelism": f"chunk-sharded x{world}, all_gather of token streams (+ diffusion coordinates in aux)"},
         "roofline": roofline, "cpu_baseline": cpu, "aux": aux,
     }
-    print(json.dumps(line))
+    print(json.dumps(line), flush=True)
     if use_dist:
+        dist.barrier()
         dist.destroy_process_group()
 
 

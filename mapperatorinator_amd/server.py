@@ -111,14 +111,31 @@ def _build_generation_stats(result, model_kwargs, pad_token_id, elapsed_seconds)
             "tokens_per_second": total / elapsed_seconds if elapsed_seconds > 0 else 0.0}
 
 
+_SEED_CALLS: dict = {}
+
+
 def fresh_seed(seed=None) -> int:
     """Seed of one generate call.  The reference samples with `torch.multinomial`, which ADVANCES the global generator
     on every draw, so two calls never replay the same uniforms; the in-kernel RNG is keyed by (seed, row, column), so
-    the call's seed must move instead: one 63-bit draw from torch's default generator per call (still a deterministic
-    function of `torch.manual_seed`).  An explicit `seed` is used as is."""
-    if seed is not None:
-        return int(seed) & 0xFFFFFFFFFFFFFFFF
-    return int(torch.randint(0, 2 ** 63 - 1, (1,), dtype=torch.int64).item())
+    the call's seed must move instead.  Without an explicit seed: one 63-bit draw from torch's default generator per call
+    (still a deterministic function of `torch.manual_seed`).  With an explicit `seed` (a caller that wants reproducible
+    runs): the n-th call made with that seed gets splitmix64(seed, n) -- the windows and waves of a song, or consecutive
+    `model_generate` calls, draw from different streams, and the same sequence of calls reproduces the same tokens
+    (`reset_seed_calls()` restarts the count)."""
+    if seed is None:
+        return int(torch.randint(0, 2 ** 63 - 1, (1,), dtype=torch.int64).item())
+    seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    n = _SEED_CALLS.get(seed, 0)
+    _SEED_CALLS[seed] = n + 1
+    z = (seed + 0x9E3779B97F4A7C15 * (n + 1)) & 0xFFFFFFFFFFFFFFFF
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+    return z ^ (z >> 31)
+
+
+def reset_seed_calls() -> None:
+    """Forget how many calls were made with each explicit seed (see `fresh_seed`)."""
+    _SEED_CALLS.clear()
 
 
 def build_sampling(tokenizer, generate_kwargs: dict, max_target_positions: int):

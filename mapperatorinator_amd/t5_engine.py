@@ -125,6 +125,7 @@ class PackedT5:
         w = _lib.MhT5Weights()
         # columns beyond n_mels belong to the conditioning vectors: they reach the device as a per-chunk row bias
         # (conditioning.ConditioningEmbedders.row_bias, mh_t5_encode_cond)
+        self.cond_cols = int(sd["encoder_embedder.weight"].shape[1]) - n_mels     # > 0: the model carries conditioning embedders
         w.enc_embed_w = mat(sd["encoder_embedder.weight"][:, :n_mels], self.n_mels_pad).data_ptr()
         w.enc_embed_b = vec(sd["encoder_embedder.bias"]).data_ptr()
         w.dec_embed = mat(sd["decoder_embedder.weight"]).data_ptr()
@@ -228,6 +229,10 @@ class T5Engine:
         p = self.packed
         B = mel.shape[0]
         rb = None
+        if row_bias is None and getattr(p, "cond_cols", 0) > 0:
+            # a conditioned model without its conditioning would neither raise nor reproduce the reference: refuse
+            raise ValueError(f"this model's encoder_embedder has {p.cond_cols} conditioning columns: pass row_bias "
+                             "(conditioning.ConditioningEmbedders.row_bias; model_generate / MapperatorinatorHIP do)")
         if row_bias is not None:
             rb = row_bias.to(self.device, torch.float32).contiguous()
             if rb.shape != (B, self.dims.d_model):

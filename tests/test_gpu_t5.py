@@ -531,10 +531,14 @@ def test_sampling_topk_topp_distribution():
         out = model.engine.generate(audio, prompt, None, [], sp, dump_logits=True)
         return out["tokens"], out["logits"].cpu()
 
+    from mapperatorinator_amd.server import reset_seed_calls
+    reset_seed_calls()
     toks, lg = run(top_k=5, temperature=0.8, seed=1234)
-    toks2, _ = run(top_k=5, temperature=0.8, seed=1234)
+    toks_next, _ = run(top_k=5, temperature=0.8, seed=1234)       # the SECOND call with a seed draws a different stream ...
+    reset_seed_calls()
+    toks2, _ = run(top_k=5, temperature=0.8, seed=1234)           # ... and the same sequence of calls reproduces itself
     toks3, _ = run(top_k=5, temperature=0.8, seed=99)
-    assert torch.equal(toks, toks2) and not torch.equal(toks, toks3)
+    assert torch.equal(toks, toks2) and not torch.equal(toks, toks3) and not torch.equal(toks, toks_next)
     for col in range(1, toks.shape[1]):
         top = lg[col].topk(5, dim=-1)
         assert (toks[:, col, None] == top.indices).any(-1).all(), f"column {col}: id outside the top-k set"
