@@ -352,6 +352,23 @@ int mh_t5_generate(const MhT5Config* cfg, const MhT5Weights* w, const void* cros
                    const int32_t* forced, void* workspace, int64_t workspace_bytes, int poll_every,
                    void* stream);
 
+/* Step-wise decode for host-driven search.  Replaces the per-position `self(**model_inputs)` of HF
+ * `GenerationMixin._beam_search` (num_beams > 1: osuT5/osuT5/inference/processor.py:147,159; server.py:137) and
+ * `MapperatorinatorCache.reorder_cache` (osuT5/osuT5/inference/cache_utils.py:16-20).
+ *   mh_t5_step: feeds ids[b] (device int32 [B]) at position `pos` to the decoder (self K/V appended at `pos`) and writes the
+ *     RAW logits fp32 [B, vocab_out] -- no processors, no selection.  Rows are (chunk, beam) pairs, kv_group beams per
+ *     chunk: row b reads cross K/V row b / kv_group (cross_kv holds B / kv_group rows).  prompt_mask uint8 [B, P] as in
+ *     mh_t5_generate (NULL = ones).  `workspace` = mh_t5_decode_workspace_bytes(cfg, B) bytes, owned by the caller and kept
+ *     between calls: it holds the self-attention caches.
+ *   mh_t5_reorder_cache: cache rows b <- src[b] (device int32 [B]) for positions 0 .. n_pos-1 of every layer;
+ *     scratch = mh_t5_reorder_cache_scratch_bytes(cfg, B, n_pos) bytes. */
+int mh_t5_step(const MhT5Config* cfg, const MhT5Weights* w, const void* cross_kv, int B, int kv_group, const int32_t* ids,
+               int pos, const uint8_t* prompt_mask, int P, float* logits, void* workspace, int64_t workspace_bytes,
+               void* stream);
+int64_t mh_t5_reorder_cache_scratch_bytes(const MhT5Config* cfg, int B, int n_pos);
+int mh_t5_reorder_cache(const MhT5Config* cfg, int B, const int32_t* src, int n_pos, void* workspace, int64_t workspace_bytes,
+                        void* scratch, int64_t scratch_bytes, void* stream);
+
 /* Teacher-forced decoder forward over whole sequences: `Mapperatorinator.forward` with `encoder_outputs` given
  * (seam B2, osuT5/osuT5/model/modeling_mapperatorinator.py:174-228; used by server.py:160-181 `model_forward`).
  *   ids  int32 [B, T] decoder_input_ids, mask uint8 [B, T] decoder_attention_mask (NULL = ones), T <= tgt_len

@@ -112,6 +112,9 @@ SYMBOLS = {
     "mh_t5_quantize_cross_kv": (I, [C.POINTER(MhT5Config), VP, I, VP, VP]),
     "mh_t5_generate": (I, [C.POINTER(MhT5Config), C.POINTER(MhT5Weights), VP, I, VP, VP, I, VP,
                            C.POINTER(MhSampling), VP, VP, VP, VP, VP, I64, I, VP]),
+    "mh_t5_step": (I, [C.POINTER(MhT5Config), C.POINTER(MhT5Weights), VP, I, I, VP, I, VP, I, VP, VP, I64, VP]),
+    "mh_t5_reorder_cache_scratch_bytes": (I64, [C.POINTER(MhT5Config), I, I]),
+    "mh_t5_reorder_cache": (I, [C.POINTER(MhT5Config), I, VP, I, VP, I64, VP, I64, VP]),
     "mh_t5_forward_workspace_bytes": (I64, [C.POINTER(MhT5Config), I, I]),
     "mh_t5_decoder_forward": (I, [C.POINTER(MhT5Config), C.POINTER(MhT5Weights), VP, I, VP, VP, I, VP, VP, I64, VP]),
     "mh_t5_cross_attn_probe": (I, [C.POINTER(MhT5Config), C.POINTER(MhT5Weights), VP, I, I, C.POINTER(C.c_float), VP, I64, VP]),

@@ -1,0 +1,197 @@
+"""Beam search on the HIP engine (`num_beams > 1`).
+
+The reference hands `num_beams` to HF `generate` (osuT5/osuT5/inference/processor.py:147,159; its timing generator decodes
+with two beams, config.py:71) and reorders its static caches per step (`MapperatorinatorCache.reorder_cache`,
+inference/cache_utils.py:16-20).  The selection logic is HF's (third-party; the algorithm below restates the published,
+vectorised `GenerationMixin._beam_search` -- transformers >= 4.50; line references are to the installed 5.x
+`generation/utils.py`): per step
+
+    log_probs = processors(sequences, log_softmax(logits))            (b: processors act on LOG-PROBABILITIES here)
+    accumulated = log_probs + running_beam_scores                      -> top K = max(2, 1 + #eos) * num_beams continuations
+    candidates that hit an EOS id / max_length leave the running set   (e), the next `num_beams` others keep running
+    finished hypotheses among the TOP num_beams candidates are merged into the finished set by score / length ** penalty   (f)
+    the cache rows follow the surviving beams                           (g)
+    stop when no running beam can still beat the worst finished one (early_stopping = False heuristic)
+
+The device side is the step-wise entry of the library (`mh_t5_step`: one decoder position for all (chunk, beam) rows, raw
+logits out; `mh_t5_reorder_cache`); the bookkeeping above runs as torch ops on the same GPU.  The logits processors of
+server.py:106-134 are applied here with torch ops (the in-kernel sampler of the greedy / sampling path selects per row and
+cannot rank across beams): MonotonicTimeShift, TimeshiftBias, (Conditional)Temperature and the lookback mask; guidance
+(cfg_scale > 1) and the types_first lookback renormalisation are refused in beam mode.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+
+def _gather(t: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    while idx.dim() < t.dim():
+        idx = idx.unsqueeze(-1)
+    return torch.take_along_dim(t, idx, dim=1)
+
+
+class BeamProcessors:
+    """The reference's processor list (server.py:106-134) on (rows, V) LOG-PROBABILITIES, from an MhSampling struct."""
+
+    def __init__(self, sp, device):
+        if sp.cfg_scale > 1.0:
+            raise NotImplementedError("beam search under classifier-free guidance is not on the HIP path")
+        if sp.lookback_types_first and sp.lookback_mask_end > sp.ts_start:
+            raise NotImplementedError("beam search with the types_first lookback renormalisation is not on the HIP path")
+        self.sp = sp
+        self.sos = torch.tensor([sp.sos_ids[i] for i in range(sp.n_sos)], dtype=torch.long, device=device)
+        flags = getattr(sp, "host_tok_flags", None)
+        self.flags = None if flags is None else torch.as_tensor(flags, dtype=torch.uint8, device=device)
+
+    def __call__(self, ids: torch.Tensor, scores: torch.Tensor) -> torch.Tensor:
+        sp = self.sp
+        scores = scores.clone()
+        R, T = ids.shape
+        # MonotonicTimeShiftLogitsProcessor (logit_processors.py:136-183)
+        if sp.ts_end > sp.ts_start:
+            idx = torch.arange(T, device=ids.device).expand(R, -1)
+            is_ts = (ids >= sp.ts_start) & (ids < sp.ts_end)
+            is_sos = torch.isin(ids, self.sos)
+            last_ts = torch.where(is_ts, idx, -1).max(1).values
+            last_sos = torch.where(is_sos, idx, -1).max(1).values
+            val = torch.where(last_ts != -1, ids[torch.arange(R, device=ids.device), last_ts.clamp(min=0)] - sp.ts_start, 0)
+            apply = (last_ts != -1) & (last_ts > last_sos)
+            vocab = torch.arange(sp.ts_start, sp.ts_end, device=ids.device)
+            bad = apply[:, None] & (vocab[None, :] < (sp.ts_start + val)[:, None])
+            scores[:, sp.ts_start:sp.ts_end] = scores[:, sp.ts_start:sp.ts_end].masked_fill(bad, float("-inf"))
+            if sp.timeshift_bias != 0.0:                                     # TimeshiftBias (:36-44)
+                scores[:, sp.ts_start:sp.ts_end] += sp.timeshift_bias
+        # (Conditional)TemperatureLogitsWarper (:47-82): row 0's history picks the temperature of the whole call
+        temp = torch.full((R,), float(sp.temperature), device=ids.device)
+        if sp.n_cond > 0:
+            if self.flags is None:
+                raise ValueError("conditional temperature needs tok_flags")
+            rows = ids if sp.cond_per_row else ids[:1].expand(R, -1)
+            chosen = torch.zeros(R, dtype=torch.bool, device=ids.device)
+            for j in range(sp.n_cond):
+                off = int(sp.cond_offset[j])
+                if T >= off:
+                    hit = ((self.flags[rows[:, T - off]] & (2 << j)) != 0) & ~chosen
+                    temp = torch.where(hit, torch.full_like(temp, float(sp.cond_temp[j])), temp)
+                    chosen |= hit
+        scores = scores / temp[:, None]
+        if sp.lookback_mask_end > sp.ts_start:                                # LookbackBiasLogitsWarper, types_first False (:111-114)
+            scores[:, sp.ts_start:sp.lookback_mask_end] = float("-inf")
+        return scores
+
+
+@torch.no_grad()
+def beam_search(engine, cross_kv: torch.Tensor, prompt: torch.Tensor, prompt_mask: Optional[torch.Tensor], eos_ids, sp,
+                num_beams: int, length_penalty: float = 1.0, early_stopping=False) -> torch.Tensor:
+    """cross_kv: the G chunks' cross K/V (engine.cross_kv); prompt int (G, P) left-padded, prompt_mask (G, P) or None.
+    Returns int64 (G, P + new) on the engine's device: the best hypothesis per chunk, shorter ones filled the way HF does
+    (`pad_token_id or eos_token_id[0]`: with pad id 0 that is the FIRST EOS id)."""
+    dev, lib, p = engine.device, engine.lib, engine.packed
+    G, P = prompt.shape
+    nb = int(num_beams)
+    R = G * nb
+    if R > 64:
+        raise ValueError(f"{G} chunks x {nb} beams exceed the engine's 64-row decode batch")
+    V = p.vocab_out
+    max_length = int(sp.max_length)
+    if not (1 <= P < max_length <= p.tgt_len):
+        raise ValueError("prompt / max_length do not fit the cache")
+    procs = BeamProcessors(sp, dev)
+    eos_list = [int(e) for e in eos_ids]
+    eos_t = torch.tensor(sorted(set(eos_list)), dtype=torch.long, device=dev)
+    n_eos = len(eos_list)
+    K = max(2, 1 + n_eos) * nb
+    K = min(K, nb * V)
+    top_mask = torch.zeros(K, dtype=torch.bool, device=dev)
+    top_mask[:nb] = True
+    fill = int(sp.pad_id) or (eos_list[0] if eos_list else -1)
+    ids0 = prompt.to(dev, torch.int64).repeat_interleave(nb, 0)                       # (R, P): rows (chunk, beam)
+    mask = None if prompt_mask is None else prompt_mask.to(dev).to(torch.uint8).repeat_interleave(nb, 0).contiguous()
+    running = torch.full((G, nb, max_length), fill, dtype=torch.int64, device=dev)
+    running[:, :, :P] = ids0.view(G, nb, P)
+    sequences = running.clone()
+    running_scores = torch.zeros((G, nb), dtype=torch.float32, device=dev)
+    running_scores[:, 1:] = -1e9
+    beam_scores = torch.full((G, nb), -1e9, dtype=torch.float32, device=dev)
+    finished = torch.zeros((G, nb), dtype=torch.bool, device=dev)
+    heuristic_open = torch.ones((G, 1), dtype=torch.bool, device=dev)
+    n_new = max_length - P
+    running_bidx = torch.full((G, nb, n_new), -1, dtype=torch.int32, device=dev)
+    beam_bidx = running_bidx.clone()
+
+    need = lib.mh_t5_decode_workspace_bytes(C.byref(p.cfg), R)
+    ws = torch.empty(int(need), dtype=torch.uint8, device=dev)                        # owned by this call: holds the caches
+    scratch = torch.empty(int(lib.mh_t5_reorder_cache_scratch_bytes(C.byref(p.cfg), R, max_length)), dtype=torch.uint8, device=dev)
+    logits = torch.empty((R, V), dtype=torch.float32, device=dev)
+    stream = engine._s()
+
+    def step(tokens: torch.Tensor, pos: int):
+        t32 = tokens.to(torch.int32).contiguous()
+        rc = lib.mh_t5_step(C.byref(p.cfg), C.byref(p.w), cross_kv.data_ptr(), R, nb, t32.data_ptr(), pos, _lib.ptr(mask), P,
+                            logits.data_ptr(), ws.data_ptr(), ws.numel(), stream)
+        _lib.check(rc, "mh_t5_step")
+
+    engine._enter()
+    with torch.cuda.stream(engine.stream):
+        for pos in range(P - 1):                                                      # the prompt, token by token
+            step(ids0[:, pos], pos)
+        cur_len = P
+        first = True
+        while True:
+            flat = running[:, :, :cur_len].reshape(R, cur_len)
+            step(flat[:, cur_len - 1], cur_len - 1)
+            log_probs = procs(flat, torch.log_softmax(logits, dim=-1))
+            acc = (log_probs.view(G, nb, V) + running_scores[:, :, None]).reshape(G, nb * V)
+            topk_lp, topk_idx = torch.topk(acc, k=K)
+            src_beam = topk_idx // V
+            topk_bidx = _gather(running_bidx, src_beam)
+            topk_seq = _gather(running, src_beam)
+            topk_seq[:, :, cur_len] = topk_idx % V
+            topk_bidx[:, :, cur_len - P] = (src_beam + torch.arange(G, device=dev).view(-1, 1) * nb).to(torch.int32)
+            # d. stopping criteria on the K candidates: EOS id as the new last token, or max_length reached
+            hits = torch.isin(topk_seq[:, :, cur_len], eos_t) | (cur_len + 1 >= max_length)
+            # e. the running beams of the next step: best num_beams candidates that did not just finish
+            run_lp = topk_lp + hits.to(torch.float32) * -1.0e9
+            nxt = torch.topk(run_lp, k=nb)[1]
+            running, running_scores, running_bidx = _gather(topk_seq, nxt), _gather(run_lp, nxt), _gather(topk_bidx, nxt)
+            # f. finished hypotheses: only candidates inside the top num_beams count
+            just = hits & top_mask[None, :]
+            fin_lp = topk_lp / ((cur_len + 1 - P) ** length_penalty)
+            full = torch.all(finished, dim=-1, keepdim=True) & (early_stopping is True)
+            fin_lp = fin_lp + full.to(torch.float32) * -1.0e9
+            fin_lp = fin_lp + (~heuristic_open).to(torch.float32) * -1.0e9
+            fin_lp = fin_lp + (~just) * -1.0e9
+            m_seq = torch.cat((sequences, topk_seq), dim=1)
+            m_sc = torch.cat((beam_scores, fin_lp), dim=1)
+            m_bi = torch.cat((beam_bidx, topk_bidx), dim=1)
+            m_fin = torch.cat((finished, just), dim=1)
+            sel = torch.topk(m_sc, k=nb)[1]
+            sequences, beam_scores, beam_bidx, finished = _gather(m_seq, sel), _gather(m_sc, sel), _gather(m_bi, sel), _gather(m_fin, sel)
+            # g. the caches follow the beams that keep running
+            src = running_bidx[..., cur_len - P].reshape(R).to(torch.int32).contiguous()
+            rc = lib.mh_t5_reorder_cache(C.byref(p.cfg), R, src.data_ptr(), cur_len, ws.data_ptr(), ws.numel(), scratch.data_ptr(),
+                                         scratch.numel(), stream)
+            _lib.check(rc, "mh_t5_reorder_cache")
+            cur_len += 1
+            if early_stopping == "never" and length_penalty > 0.0:
+                hyp_len = max_length - P
+            else:
+                hyp_len = cur_len - P
+            best_running = running_scores[:, :1] / (hyp_len ** length_penalty)
+            worst_fin = torch.where(finished, torch.min(beam_scores, dim=1, keepdim=True)[0], -1.0e9)
+            heuristic_open = heuristic_open & torch.any(best_running > worst_fin, dim=-1, keepdim=True)
+            go_on = torch.any(heuristic_open) & ~(torch.all(finished) & (early_stopping is True)) & ~torch.all(hits)
+            first = False
+            if not bool(go_on):
+                break
+        best = sequences[:, 0, :]
+        n_gen = int(((beam_bidx[:, 0, :] + 1).bool()).sum(dim=1).max())
+        out = best[:, :P + n_gen].clone()
+    engine._leave()
+    engine.synchronize()
+    return out

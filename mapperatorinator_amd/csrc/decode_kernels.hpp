@@ -765,7 +765,8 @@ struct CrossAttnP {
   const void* k; const void* v;  // this layer's [B][H][L][64]
   void* out; int ldo;       // T [B, inner]
   int B, H, L;
-  int kv_B;                 // > 0: row b reads K/V row b % kv_B (CFG pairs share the encoder output)
+  int kv_B;                 // > 0: row b reads K/V row b % kv_B (CFG pairs share the encoder output);
+                            // < 0: row b reads K/V row b / -kv_B (the beams of a chunk share it: rows are (chunk, beam))
   const float* kscale; const float* vscale;   // fp8 rows (kernel template F8): this layer's [kv rows][H] scales, else NULL
   // measurement only (mh_t5_decode_timing): [slots][2] = (earliest workgroup start, latest workgroup end) of THIS
   // launch in wall-clock ticks, slot = *pos * ts_layers + ts_layer for the first ts_ring positions; NULL in production
@@ -799,7 +800,7 @@ __global__ __launch_bounds__(1024) void dec_cross_attn_kernel(CrossAttnP p) {
   const int c8 = (lane & 7) * 8, g = lane >> 3;
   float q[8];
   load8<T>(reinterpret_cast<const T*>(p.q) + (long)b * p.ldq + h * 64 + c8, q);
-  const int kvb = p.kv_B > 0 ? b % p.kv_B : b;   // row b reads K/V row b % kv_B
+  const int kvb = p.kv_B > 0 ? b % p.kv_B : (p.kv_B < 0 ? b / -p.kv_B : b);
   const T* kb = reinterpret_cast<const T*>(p.k) + ((long)kvb * p.H + h) * p.L * 64;
   const T* vb = reinterpret_cast<const T*>(p.v) + ((long)kvb * p.H + h) * p.L * 64;
   Partial st;
@@ -945,7 +946,7 @@ void dec_cross_attn_q_kernel(const float* h_, const float* lnw_, const void* W_,
   MH_STAMP0();
   const int c8 = (lane & 7) * 8, g = lane >> 3;
   const int row0[1] = {h * 64};
-  const int kvb = p.kv_B > 0 ? b % p.kv_B : b;
+  const int kvb = p.kv_B > 0 ? b % p.kv_B : (p.kv_B < 0 ? b / -p.kv_B : b);
   typedef typename std::conditional<F8, fp8_t, T>::type E;
   const E* kb = reinterpret_cast<const E*>(p.k) + ((long)kvb * p.H + h) * p.L * 64;
   const E* vb = reinterpret_cast<const E*>(p.v) + ((long)kvb * p.H + h) * p.L * 64;

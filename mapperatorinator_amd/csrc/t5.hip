@@ -846,7 +846,9 @@ DecodeTiming g_timing;
 template <typename T>
 int enqueue_step(const MhT5Config* c, const MhT5Weights* w, const void* cross_kv, int B, int Bfull, int kvB,
                  const uint8_t* prompt_mask, int P, const DecBuffers& bf, const SampleP& smp, hipStream_t s,
-                 const void* kv8 = nullptr, const float* kv8_scales = nullptr) {
+                 const void* kv8 = nullptr, const float* kv8_scales = nullptr, bool with_sampler = true, int kv_group = 0) {
+  // with_sampler = false: the step ends with the logits (mh_t5_step: the host selects); kv_group > 1: rows are (chunk, beam)
+  // pairs and row b reads cross K/V row b / kv_group
   // kv8 / kv8_scales: the chain's first row of the e4m3 copy of cross_kv and of its scales (mh_t5_quantize_cross_kv)
   // B rows of one chain; every pointer in `bf` / `cross_kv` / `prompt_mask` already points at the chain's first
   // row, only the per-layer strides of the caches use the full batch size.  kvB = rows of cross_kv (B/2 under CFG:
@@ -878,7 +880,7 @@ int enqueue_step(const MhT5Config* c, const MhT5Weights* w, const void* cross_kv
       dec::CrossAttnP ca{};
       const long kv_layer = (long)kvB * H * L * 64 * es;
       ca.k = (const char*)cross_kv + (long)(l * 2 + 0) * kv_layer; ca.v = (const char*)cross_kv + (long)(l * 2 + 1) * kv_layer;
-      ca.out = bf.attn; ca.ldo = inner; ca.B = B; ca.H = H; ca.L = L; ca.kv_B = kvB < Bfull ? kvB : 0;
+      ca.out = bf.attn; ca.ldo = inner; ca.B = B; ca.H = H; ca.L = L; ca.kv_B = kv_group > 1 ? -kv_group : (kvB < Bfull ? kvB : 0);
       ca.q_bias = w->dec_cq_b[l]; ca.scale = c->attn_scale;
       MH_REQUIRE(!kv8, "decode: the fp8 cross K/V copy is not wired for the Whisper family");
       if (g_timing.buf) {
@@ -931,7 +933,7 @@ int enqueue_step(const MhT5Config* c, const MhT5Weights* w, const void* cross_kv
     const long kv_layer = (long)kvB * H * L * 64 * es;
     ca.q = bf.q; ca.ldq = inner; ca.k = (const char*)cross_kv + (long)(l * 2 + 0) * kv_layer;
     ca.v = (const char*)cross_kv + (long)(l * 2 + 1) * kv_layer; ca.out = bf.attn; ca.ldo = inner;
-    ca.B = B; ca.H = H; ca.L = L; ca.kv_B = kvB < Bfull ? kvB : 0;
+    ca.B = B; ca.H = H; ca.L = L; ca.kv_B = kv_group > 1 ? -kv_group : (kvB < Bfull ? kvB : 0);
     if (kv8) {
       MH_REQUIRE(fused, "decode: the fp8 cross K/V copy needs decode_fused_proj = 1 and d_model a multiple of 128 <= 1024");
       const long slab = (long)kvB * H * L * 64;
@@ -971,9 +973,44 @@ int enqueue_step(const MhT5Config* c, const MhT5Weights* w, const void* cross_kv
   sk.A = bf.h; sk.lda = d; sk.ln_w = w->dec_final_ln; sk.eps = c->eps; sk.W = w->lm_head; sk.ldw = d; sk.B = B;
   sk.N = c->vocab_out; sk.K = d; sk.out = bf.logits; sk.ldo = c->vocab_out;
   MH_TRY((skinny<T, dec::PRO_RMSNORM, dec::SK_LOGITS>(sk, s)));
+  if (!with_sampler) return MH_OK;
   hipLaunchKernelGGL(dec_sample_kernel<T>, dim3(smp.pair > 0 ? smp.pair : B), dim3(256), 0, s, smp);
   MH_TRY(check_launch("dec_sample_kernel"));
   return MH_OK;
+}
+
+// ---- step-wise decode (beam search) ----------------------------------------------------------------------------------
+// h[b][:] = dec_embed[ids[b]] and the position word of the step
+template <typename T>
+__global__ __launch_bounds__(256) void step_embed_kernel(const int32_t* ids, const T* emb, int d, float* h, DecState* st, int pos) {
+  const int b = blockIdx.x;
+  if (b == 0 && threadIdx.x == 0) { st->pos = pos; st->n_running = 0; st->ticket = 0; }
+  const T* e = emb + (long)ids[b] * d;
+  for (int i = threadIdx.x; i < d; i += 256) h[(long)b * d + i] = Elem<T>::to_f32(e[i]);
+}
+// cache rows [l][b][h][0 .. n_pos) <- [l][src[b]][h][..]: gather into `tmp`, then copy back (in place would read rows that
+// were already overwritten); one workgroup per (k|v, layer, row, head)
+template <typename T>
+__global__ __launch_bounds__(256) void cache_gather_kernel(const T* kc, const T* vc, T* tmp, const int32_t* src, int B, int H, int tgt,
+                                                          int n_pos, long layer_stride) {
+  const int h = blockIdx.x % H, b = (blockIdx.x / H) % B, l = (blockIdx.x / H / B) % (int)gridDim.y, kv = blockIdx.z;
+  const T* from = (kv ? vc : kc) + (long)blockIdx.y * layer_stride + ((long)src[b] * H + h) * tgt * 64;
+  T* to = tmp + ((((long)kv * gridDim.y + blockIdx.y) * B + b) * H + h) * (long)n_pos * 64;
+  (void)l;
+  const uint4* f4 = reinterpret_cast<const uint4*>(from);
+  uint4* t4 = reinterpret_cast<uint4*>(to);
+  const int n16 = n_pos * 64 * (int)sizeof(T) / 16;
+  for (int i = threadIdx.x; i < n16; i += 256) t4[i] = f4[i];
+}
+template <typename T>
+__global__ __launch_bounds__(256) void cache_scatter_kernel(T* kc, T* vc, const T* tmp, int B, int H, int tgt, int n_pos, long layer_stride) {
+  const int h = blockIdx.x % H, b = (blockIdx.x / H) % B, kv = blockIdx.z;
+  T* to = (kv ? vc : kc) + (long)blockIdx.y * layer_stride + ((long)b * H + h) * tgt * 64;
+  const T* from = tmp + ((((long)kv * gridDim.y + blockIdx.y) * B + b) * H + h) * (long)n_pos * 64;
+  const uint4* f4 = reinterpret_cast<const uint4*>(from);
+  uint4* t4 = reinterpret_cast<uint4*>(to);
+  const int n16 = n_pos * 64 * (int)sizeof(T) / 16;
+  for (int i = threadIdx.x; i < n16; i += 256) t4[i] = f4[i];
 }
 
 }  // namespace
@@ -1553,4 +1590,77 @@ extern "C" int mh_t5_cross_attn_probe(const MhT5Config* c, const MhT5Weights* w,
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   return rc;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Step-wise decode for host-driven search (beam search: HF `GenerationMixin._beam_search` drives the model one position at a
+// time and reorders its cache, osuT5/osuT5/inference/cache_utils.py:16-20).  The workspace is the one of mh_t5_generate
+// (mh_t5_decode_workspace_bytes) and holds the self-attention K/V caches between calls.
+extern "C" int mh_t5_step(const MhT5Config* c, const MhT5Weights* w, const void* cross_kv, int B, int kv_group, const int32_t* ids,
+                          int pos, const uint8_t* prompt_mask, int P, float* logits, void* workspace, int64_t workspace_bytes,
+                          void* stream) {
+  MH_TRY(check_cfg(c, "mh_t5_step"));
+  MH_REQUIRE(w && cross_kv && ids && logits && workspace, "mh_t5_step: null argument");
+  MH_REQUIRE(B > 0 && B <= 64, "mh_t5_step: batch %d not in [1, 64]", B);
+  MH_REQUIRE(kv_group >= 1 && B % kv_group == 0, "mh_t5_step: %d rows are not whole groups of %d", B, kv_group);
+  MH_REQUIRE(pos >= 0 && pos < c->tgt_len, "mh_t5_step: position %d outside the cache (tgt_len %d)", pos, c->tgt_len);
+  MH_REQUIRE(workspace_bytes >= mh_t5_decode_workspace_bytes(c, B), "mh_t5_step: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  const int es = es_of(c->dtype), H = c->n_heads, inner = H * 64, d = c->d_model, V = c->vocab_out;
+  Arena ar(workspace, workspace_bytes);
+  DecBuffers bf{};
+  bf.h = (float*)ar.take((int64_t)B * d * 4);
+  bf.q = ar.take((int64_t)B * inner * es);
+  bf.attn = ar.take((int64_t)B * inner * es);
+  bf.ff = ar.take((int64_t)B * c->d_ff * es);
+  float* ws_logits = (float*)ar.take((int64_t)B * V * 4);
+  (void)ws_logits;
+  bf.logits = logits;
+  bf.self_k = ar.take((int64_t)c->n_dec_layers * B * inner * c->tgt_len * es);
+  bf.self_v = ar.take((int64_t)c->n_dec_layers * B * inner * c->tgt_len * es);
+  bf.finished = (uint8_t*)ar.take(B);
+  bf.finish_col = (int32_t*)ar.take((int64_t)B * 4);
+  bf.last_ts = (int32_t*)ar.take((int64_t)B * 4);
+  bf.st = (DecState*)ar.take((int64_t)align256(sizeof(DecState)) * kMaxChains);
+  bf.chain = 0;
+  MH_REQUIRE(ar.ok(), "mh_t5_step: arena overflow");
+  if (c->dtype == MH_BF16) hipLaunchKernelGGL(step_embed_kernel<bf16_t>, dim3(B), dim3(256), 0, s, ids, (const bf16_t*)w->dec_embed, d, bf.h, bf.st, pos);
+  else hipLaunchKernelGGL(step_embed_kernel<float>, dim3(B), dim3(256), 0, s, ids, (const float*)w->dec_embed, d, bf.h, bf.st, pos);
+  MH_TRY(check_launch("step_embed_kernel"));
+  SampleP smp{};
+  const int kvB = B / kv_group;
+  return c->dtype == MH_BF16 ? enqueue_step<bf16_t>(c, w, cross_kv, B, B, kvB, prompt_mask, P, bf, smp, s, nullptr, nullptr, false, kv_group)
+                             : enqueue_step<float>(c, w, cross_kv, B, B, kvB, prompt_mask, P, bf, smp, s, nullptr, nullptr, false, kv_group);
+}
+
+// self-attention cache rows of every layer: row b <- row src[b] for positions 0 .. n_pos-1 (`cache.reorder_cache(beam_idx)`).
+// scratch: 2 * n_dec * B * inner * n_pos elements of the storage type (mh_t5_reorder_cache_scratch_bytes).
+extern "C" int64_t mh_t5_reorder_cache_scratch_bytes(const MhT5Config* c, int B, int n_pos) {
+  if (!c || B <= 0 || n_pos <= 0) return -1;
+  return align256(2LL * c->n_dec_layers * B * c->n_heads * 64 * n_pos * es_of(c->dtype));
+}
+extern "C" int mh_t5_reorder_cache(const MhT5Config* c, int B, const int32_t* src, int n_pos, void* workspace, int64_t workspace_bytes,
+                                   void* scratch, int64_t scratch_bytes, void* stream) {
+  MH_TRY(check_cfg(c, "mh_t5_reorder_cache"));
+  MH_REQUIRE(src && workspace && scratch && B > 0 && B <= 64 && n_pos > 0 && n_pos <= c->tgt_len, "mh_t5_reorder_cache: bad argument");
+  MH_REQUIRE(workspace_bytes >= mh_t5_decode_workspace_bytes(c, B) && scratch_bytes >= mh_t5_reorder_cache_scratch_bytes(c, B, n_pos),
+             "mh_t5_reorder_cache: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  const int es = es_of(c->dtype), H = c->n_heads, inner = H * 64, d = c->d_model, V = c->vocab_out;
+  Arena ar(workspace, workspace_bytes);
+  ar.take((int64_t)B * d * 4); ar.take((int64_t)B * inner * es); ar.take((int64_t)B * inner * es); ar.take((int64_t)B * c->d_ff * es);
+  ar.take((int64_t)B * V * 4);
+  void* self_k = ar.take((int64_t)c->n_dec_layers * B * inner * c->tgt_len * es);
+  void* self_v = ar.take((int64_t)c->n_dec_layers * B * inner * c->tgt_len * es);
+  const long layer_stride = (long)B * H * c->tgt_len * 64;
+  const dim3 grid(B * H, c->n_dec_layers, 2);
+  if (c->dtype == MH_BF16) {
+    hipLaunchKernelGGL(cache_gather_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)self_k, (const bf16_t*)self_v, (bf16_t*)scratch, src, B, H, c->tgt_len, n_pos, layer_stride);
+    hipLaunchKernelGGL(cache_scatter_kernel<bf16_t>, grid, dim3(256), 0, s, (bf16_t*)self_k, (bf16_t*)self_v, (const bf16_t*)scratch, B, H, c->tgt_len, n_pos, layer_stride);
+  } else {
+    hipLaunchKernelGGL(cache_gather_kernel<float>, grid, dim3(256), 0, s, (const float*)self_k, (const float*)self_v, (float*)scratch, src, B, H, c->tgt_len, n_pos, layer_stride);
+    hipLaunchKernelGGL(cache_scatter_kernel<float>, grid, dim3(256), 0, s, (float*)self_k, (float*)self_v, (const float*)scratch, B, H, c->tgt_len, n_pos, layer_stride);
+  }
+  return check_launch("cache reorder");
 }

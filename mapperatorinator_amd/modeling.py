@@ -244,8 +244,8 @@ class MapperatorinatorHIP:
         (server.sampling_from_processors), `past_key_values` / `use_cache` are accepted and unused (the engine owns
         its caches).  Returns int64 (B, prompt + new) on the model's device, pad_token_id after each row's EOS."""
         from .server import sampling_from_processors
-        if num_beams != 1:
-            raise NotImplementedError("beam search is not on the HIP path (num_beams must be 1)")
+        if num_beams != 1 and do_sample:
+            raise NotImplementedError("beam-sample (num_beams > 1 with do_sample) is not on the HIP path")
         audio = inputs if inputs is not None else frames
         if decoder_input_ids is None:
             raise ValueError("decoder_input_ids is required (the reference always passes the prompt)")
@@ -261,6 +261,10 @@ class MapperatorinatorHIP:
         if sp.cfg_scale > 1.0 and negative_prompt is None:
             raise ValueError("guidance needs negative_prompt (modeling_mapperatorinator.py:243-254)")
         row_bias = self._row_bias(decoder_input_ids.shape[0], unused)
+        if num_beams != 1:
+            out = self.engine.generate_beam(audio, decoder_input_ids, decoder_attention_mask, eos, sp, int(num_beams),
+                                            **({} if row_bias is None else dict(row_bias=row_bias)))
+            return out["tokens"].to(self.device)
         out = self.engine.generate(audio, decoder_input_ids, decoder_attention_mask, eos, sp,
                                    negative_prompt=negative_prompt if sp.cfg_scale > 1.0 else None,
                                    negative_mask=negative_prompt_attention_mask,

@@ -154,8 +154,9 @@ def build_sampling(tokenizer, generate_kwargs: dict, max_target_positions: int):
     context_type = gk.pop("context_type", None)
     if context_type is not None:
         context_type = ContextType(getattr(context_type, "value", context_type))
-    if gk.get("num_beams", 1) != 1:
-        raise NotImplementedError("beam search is not on the HIP path (num_beams must be 1)")
+    num_beams = int(gk.get("num_beams", 1) or 1)
+    if num_beams > 1 and gk.get("do_sample", False):
+        raise NotImplementedError("beam-sample (num_beams > 1 with do_sample) is not on the HIP path")
 
     ts0, ts1 = _ev(tokenizer.event_start, "TIME_SHIFT"), _ev(tokenizer.event_end, "TIME_SHIFT")
     sp = Sampling()
@@ -206,6 +207,7 @@ def build_sampling(tokenizer, generate_kwargs: dict, max_target_positions: int):
                     flags[_ev(tokenizer.event_start, name):_ev(tokenizer.event_end, name)] |= FLAG_TIMED
             need_flags = True
     sp.host_tok_flags = flags if need_flags else None
+    sp.num_beams = num_beams               # (host attribute: beam search runs through mapperatorinator_amd.beam)
     sp.pad_id = int(gk.get("pad_token_id", getattr(tokenizer, "pad_id", 0)) or 0)
     sp.max_length = int(gk.get("max_length", max_target_positions))
     sp.seed = fresh_seed(gk.get("seed")) if sp.do_sample else 0     # greedy decoding leaves the global generator alone
@@ -319,8 +321,12 @@ def model_generate(model, tokenizer, model_kwargs, generate_kwargs):
 
     start = time.perf_counter()
     extra = {} if row_bias is None else dict(row_bias=row_bias)
-    out = model.engine.generate(audio, prompt, mask, eos, sp, negative_prompt=neg, negative_mask=neg_mask,
-                                cross_kv_fp8=bool(generate_kwargs.get("cross_kv_fp8", False)), **extra)
+    if getattr(sp, "num_beams", 1) > 1:
+        # HF beam search (processor.py:159 `num_beams`; the timing generator uses two beams): mapperatorinator_amd/beam.py
+        out = model.engine.generate_beam(audio, prompt, mask, eos, sp, sp.num_beams, **extra)
+    else:
+        out = model.engine.generate(audio, prompt, mask, eos, sp, negative_prompt=neg, negative_mask=neg_mask,
+                                    cross_kv_fp8=bool(generate_kwargs.get("cross_kv_fp8", False)), **extra)
     elapsed = time.perf_counter() - start
     result = out["tokens"]
     stats = _build_generation_stats(result, model_kwargs, pad_token_id, elapsed)

@@ -322,6 +322,20 @@ class T5Engine:
         _lib.check(rc, "mh_t5_generate")
         return tokens, n_out, logits
 
+    def generate_beam(self, audio: torch.Tensor, prompt: torch.Tensor, prompt_mask: Optional[torch.Tensor], eos_ids,
+                      sampling: _lib.MhSampling, num_beams: int, row_bias: Optional[torch.Tensor] = None,
+                      length_penalty: float = 1.0, early_stopping=False):
+        """mel -> encoder -> cross K/V, then HF-style beam search over the step-wise decode entry (beam.py).  Returns
+        dict(tokens=int64 CPU (B, n_cols), n_cols, logits=None) like `generate`."""
+        from .beam import beam_search
+        audio = audio.to(self.device, torch.float32)
+        self._enter()
+        with torch.cuda.stream(self.stream):
+            kv = self.cross_kv(self.encode_mel(self.mel(audio), row_bias=row_bias))
+        self._leave()
+        out = beam_search(self, kv, prompt, prompt_mask, eos_ids, sampling, num_beams, length_penalty, early_stopping)
+        return dict(tokens=out.cpu(), n_cols=int(out.shape[1]), logits=None)
+
     def generate(self, audio: torch.Tensor, prompt: torch.Tensor, prompt_mask: Optional[torch.Tensor],
                  eos_ids, sampling: _lib.MhSampling, forced: Optional[torch.Tensor] = None,
                  dump_logits: bool = False, poll_every: int = 16, negative_prompt: Optional[torch.Tensor] = None,

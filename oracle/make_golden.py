@@ -274,6 +274,35 @@ def vw_case(name):
           float(np.median(gap)), "tok/s(ref,cpu)", stats["tokens_per_second"])
 
 
+BEAM_CASE = dict(src=251, tgt=40, ns=32000, wseed=13, gain=1.5, aseed=6, prompts=[[0, 0, 1], [1, 40, 700], [0, 1, 9]],
+                 runs={"b2": dict(num_beams=2), "b3": dict(num_beams=3),
+                       "b2p": dict(num_beams=2, lookahead_time=500, temperature=0.8, timeshift_bias=0.3),
+                       "b3p": dict(num_beams=3, lookahead_time=700, lookback_time=300, temperature=1.3)})
+
+
+def beam_case(name="t5_tiny_beam"):
+    """`num_beams > 1` on the reference: its `model_generate` -> HF beam search with `MapperatorinatorCache.reorder_cache`
+    (inference/cache_utils.py:16-20), 2 and 3 beams, with and without processors / EOS windows (hypotheses of different
+    lengths), next to the greedy ids of the same inputs."""
+    c = BEAM_CASE
+    model, tok, _ = rh.build_reference_t5("tiny", src_seq_len=c["src"], tgt_seq_len=c["tgt"])
+    sd = random_t5_state_dict(T5_PRESETS["tiny"], tok.vocab_size_in, tok.vocab_size_out, seed=c["wseed"], lm_head_gain=c["gain"],
+                              gains=DIVERSE_GAINS)
+    model.load_state_dict(sd, strict=False)
+    audio = synthetic_audio_varied(len(c["prompts"]), c["ns"], seed=c["aseed"])
+    prompt = torch.tensor(c["prompts"])
+    out = dict(vocab_in=tok.vocab_size_in, vocab_out=tok.vocab_size_out, prompt=prompt.numpy(), runs=json.dumps(c["runs"]),
+               **{k: v for k, v in c.items() if k not in ("prompts", "runs")})
+    for tag, kw in c["runs"].items():
+        ids, _ = rh.reference_generate(model, tok, audio, prompt, rh.default_generate_kwargs(c["tgt"], **kw), prompt.ne(0))
+        greedy, _ = rh.reference_generate(model, tok, audio, prompt, rh.default_generate_kwargs(c["tgt"], **dict(kw, num_beams=1)), prompt.ne(0))
+        out["ids_" + tag], out["greedy_" + tag] = ids.numpy(), greedy.numpy()
+        w = min(ids.shape[1], greedy.shape[1])
+        print(name, tag, tuple(ids.shape), "greedy", tuple(greedy.shape), "positions where beams and greedy differ",
+              int((ids[:, :w] != greedy[:, :w]).sum()))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+
+
 def tokenizer_case():
     _, tok, _ = rh.build_reference_t5("small", src_seq_len=1251, tgt_seq_len=64)
     with open(os.path.join(OUT, "tokenizer_benchmark_vocab.json"), "w") as f:
@@ -459,6 +488,7 @@ def main(only=None):
         "dit_b": lambda: dit_case("dit_b", "DiT-B", 256, 4, 6, 1.5),
         "dit_b_1024": lambda: dit_case("dit_b_1024", "DiT-B", 1024, 4, 8, 2.0, loop_steps=3),
         "dit_pipeline": pipeline_case,
+        "t5_tiny_beam": beam_case,
     })
     for name, fn in cases.items():
         if only and name not in only:

@@ -332,3 +332,107 @@ class T5Oracle:
                 if not unfinished.any():
                     break
         return (ids, all_scores) if return_logits else ids
+
+
+    # ---- beam search ---------------------------------------------------------------------------------
+    def _processed_log_probs(self, logits, hist, ts_start, ts_end, sos_ids, temperature, timeshift_bias, lookback_mask_end):
+        """HF beam search hands the processors LOG-PROBABILITIES (generation/utils.py `_beam_search` step b)."""
+        scores = torch.log_softmax(logits.float(), dim=-1)
+        sos = set(int(v) for v in sos_ids)
+        for r in range(hist.shape[0]):
+            row = hist[r].tolist()
+            last_ts = max((i for i, t in enumerate(row) if ts_start <= t < ts_end), default=-1)
+            last_sos = max((i for i, t in enumerate(row) if t in sos), default=-1)
+            if last_ts != -1 and last_ts > last_sos:
+                scores[r, ts_start:ts_start + (row[last_ts] - ts_start)] = float("-inf")
+        if timeshift_bias != 0:
+            scores[:, ts_start:ts_end] += timeshift_bias
+        scores = scores / temperature
+        if lookback_mask_end > ts_start:
+            scores[:, ts_start:lookback_mask_end] = float("-inf")
+        return scores
+
+    def generate_beam(self, enc, prompt, prompt_mask, eos_ids, max_length, ts_start, ts_end, sos_ids, num_beams, pad_id=0,
+                      temperature=1.0, timeshift_bias=0.0, lookback_mask_end=0, length_penalty=1.0):
+        """HF `GenerationMixin._beam_search` (third-party; the vectorised form of transformers >= 4.50, early_stopping =
+        False, num_return_sequences = 1) as `model_generate` reaches it with `num_beams > 1` (processor.py:159), restated
+        chunk by chunk with explicit candidate lists; the self-attention cache rows are re-gathered per step as
+        `MapperatorinatorCache.reorder_cache` does (inference/cache_utils.py:16-20).  Returns ids (B, n_cols): the best
+        hypothesis per chunk, shorter rows filled with `pad_token_id or eos_token_id[0]` (HF's `output_fill_value`)."""
+        B, P = prompt.shape
+        nb, V = int(num_beams), self.sd[[k for k in self.sd if k.endswith("lm_head.weight") or k.endswith("proj_out.weight")][0]].shape[0]
+        R = B * nb
+        ckv = self.cross_kv(enc.repeat_interleave(nb, 0))
+        cache = [(torch.zeros(R, self.H, max_length, 64), torch.zeros(R, self.H, max_length, 64)) for _ in range(self.nd)]
+        key_mask = torch.ones(R, max_length, dtype=torch.bool)
+        if prompt_mask is not None:
+            key_mask[:, :P] = prompt_mask.bool().repeat_interleave(nb, 0)
+        eos_list = [int(e) for e in eos_ids]
+        eos = set(eos_list)
+        K = max(2, 1 + len(eos_list)) * nb
+        fill = pad_id or (eos_list[0] if eos_list else -1)
+        f32 = lambda v: torch.tensor(v, dtype=torch.float32)
+        run_seq = [[prompt[b].tolist() for _ in range(nb)] for b in range(B)]
+        run_score = [[f32(0.0)] + [f32(-1e9)] * (nb - 1) for _ in range(B)]
+        run_hist = [[[] for _ in range(nb)] for _ in range(B)]                     # beam indices per generated position
+        fin = [[(f32(-1e9), None, [], False) for _ in range(nb)] for _ in range(B)]  # (score, seq, beam-index history, finished)
+        open_h = [True] * B
+        for pos in range(P - 1):
+            self.decoder_step(prompt[:, pos].repeat_interleave(nb), pos, cache, ckv, key_mask)
+        cur = P
+        while True:
+            flat = torch.tensor([run_seq[b][k] for b in range(B) for k in range(nb)])
+            logits = self.decoder_step(flat[:, cur - 1], cur - 1, cache, ckv, key_mask)
+            lp = self._processed_log_probs(logits, flat, ts_start, ts_end, sos_ids, temperature, timeshift_bias, lookback_mask_end)
+            src_rows = []
+            all_hit = True
+            for b in range(B):
+                acc = torch.stack([lp[b * nb + k] + run_score[b][k] for k in range(nb)]).reshape(-1)
+                top_lp, top_idx = torch.topk(acc, k=min(K, acc.numel()))
+                cand = []
+                for lpv, ix in zip(top_lp, top_idx.tolist()):
+                    k0, tok = ix // V, ix % V
+                    seq = run_seq[b][k0] + [tok]
+                    hit = (tok in eos) or (len(seq) >= max_length)
+                    cand.append((lpv, seq, run_hist[b][k0] + [b * nb + k0], hit))
+                all_hit = all_hit and all(c[3] for c in cand)
+                # e. running beams: the best nb candidates after pushing the just-finished ones down by 1e9
+                run_lp = torch.stack([c[0] + (f32(-1e9) if c[3] else f32(0.0)) for c in cand])
+                nxt = torch.topk(run_lp, k=nb)[1].tolist()
+                new_seq, new_score, new_hist = [cand[i][1] for i in nxt], [run_lp[i] for i in nxt], [cand[i][2] for i in nxt]
+                # f. finished hypotheses, from the top nb candidates only
+                all_fin = all(f[3] for f in fin[b])
+                merged = list(fin[b])
+                for j, c in enumerate(cand):
+                    sc = c[0] / f32(float((cur + 1 - P) ** length_penalty))
+                    if not open_h[b]:
+                        sc = sc + f32(-1e9)
+                    just = c[3] and j < nb
+                    if not just:
+                        sc = sc + f32(-1e9)
+                    merged.append((sc, c[1], c[2], just))
+                order = torch.topk(torch.stack([m[0] for m in merged]), k=nb)[1].tolist()
+                fin[b] = [merged[i] for i in order]
+                run_seq[b], run_score[b], run_hist[b] = new_seq, new_score, new_hist
+                src_rows += [h[-1] for h in new_hist]
+            src = torch.tensor(src_rows)
+            for l in range(self.nd):                                               # reorder_cache(beam_idx)
+                Kc, Vc = cache[l]
+                cache[l] = (Kc[src].clone(), Vc[src].clone())
+            cur += 1
+            any_open = False
+            for b in range(B):
+                best_running = run_score[b][0] / f32(float((cur - P) ** length_penalty))
+                worst = min(f[0] for f in fin[b])
+                improv = any(bool(best_running > (worst if f[3] else f32(-1e9))) for f in fin[b])
+                open_h[b] = open_h[b] and improv
+                any_open = any_open or open_h[b]
+            if not any_open or all_hit:
+                break
+        n_gen = max(len(fin[b][0][2]) for b in range(B))
+        out = torch.full((B, P + n_gen), fill, dtype=torch.long)
+        for b in range(B):
+            seq = fin[b][0][1] if fin[b][0][1] is not None else prompt[b].tolist()
+            seq = seq[:P + n_gen]
+            out[b, :len(seq)] = torch.tensor(seq)
+        return out

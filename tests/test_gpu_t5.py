@@ -633,7 +633,7 @@ def test_model_object_generate_and_forward_seam_b2():
     assert ids.device.type == "cuda" and ids.dtype == torch.int64
     assert np.array_equal(ids.cpu().numpy(), g["ids_processors"])       # = the reference's own output for these kwargs
     with pytest.raises(NotImplementedError):
-        model.generate(inputs=audio, decoder_input_ids=prompt, num_beams=2)
+        model.generate(inputs=audio, decoder_input_ids=prompt, num_beams=2, do_sample=True)     # beam-sample is not built
 
     # forward: teacher-forced on the reference's greedy ids
     seq = torch.from_numpy(g["ids"])[:, :-1]
@@ -743,3 +743,29 @@ def test_conditioning_embedders_fp32_match_reference_golden():
     assert np.abs(enc[:, ::13, ::7].numpy() - g["enc_slice"]).max() < 2e-4
     with pytest.raises(ValueError):
         model_generate(model, tok, dict(inputs=audio, decoder_input_ids=prompt, decoder_attention_mask=prompt.ne(0)), gen_kwargs(tgt))
+
+
+@pytest.mark.parametrize("run", ["b2", "b3", "b2p", "b3p"])
+def test_fp32_beam_search_matches_reference_golden(run):
+    """`num_beams` 2 / 3 through `model_generate` on the HIP path (mapperatorinator_amd/beam.py over mh_t5_step /
+    mh_t5_reorder_cache): the ids the REFERENCE returned for the same inputs through HF beam search and its cache reorder
+    (tests/golden/t5_tiny_beam.npz), bit for bit -- hypotheses of different lengths, processors and EOS windows included."""
+    import json
+    from mapperatorinator_amd import Tokenizer
+    from mapperatorinator_amd.server import model_generate
+    from mapperatorinator_amd.t5_engine import T5_PRESETS
+    from mapperatorinator_amd.testing import DIVERSE_GAINS, random_t5_state_dict, synthetic_audio_varied
+    g = np.load(f"{GOLDEN}/t5_tiny_beam.npz")
+    src, tgt = int(g["src"]), int(g["tgt"])
+    tok = Tokenizer.benchmark_vocab(src_seq_len=src)
+    sd = random_t5_state_dict(T5_PRESETS["tiny"], tok.vocab_size_in, tok.vocab_size_out, seed=int(g["wseed"]),
+                              lm_head_gain=float(g["gain"]), gains=DIVERSE_GAINS)
+    audio = synthetic_audio_varied(g["prompt"].shape[0], int(g["ns"]), seed=int(g["aseed"]))
+    model = build("tiny", tok, sd, src, tgt, torch.float32)
+    prompt = torch.from_numpy(g["prompt"])
+    kw = json.loads(str(g["runs"]))[run]
+    ids, stats = model_generate(model, tok, dict(inputs=audio, decoder_input_ids=prompt, decoder_attention_mask=prompt.ne(0)),
+                                gen_kwargs(tgt, **kw))
+    want = g["ids_" + run]
+    assert ids.shape == want.shape and np.array_equal(ids.numpy(), want), (ids.tolist(), want.tolist())
+    assert ids.dtype == torch.int64 and ids.device.type == "cpu" and stats["generated_tokens"] > 0

@@ -112,8 +112,9 @@ def test_eos_set_and_sampling_translation():
     assert sp.lookback_mask_end == ts0 + 12
     assert eos[:2] == [2, 4]
     assert sp.cfg_scale == 1.0 and sp.n_cond == 0 and sp.lookback_types_first == 0 and sp.host_tok_flags is None
+    assert build_sampling(tok, dict(num_beams=2), 512)[0].num_beams == 2       # beam search: mapperatorinator_amd/beam.py
     with pytest.raises(NotImplementedError):
-        build_sampling(tok, dict(num_beams=2), 512)
+        build_sampling(tok, dict(num_beams=2, do_sample=True), 512)            # beam-sample is not built
 
 
 def test_types_first_sampling_translation():
