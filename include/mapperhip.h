@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MH_ABI_VERSION 5
+#define MH_ABI_VERSION 6
 #define MH_MAX_LAYERS 32
 
 typedef enum MhStatus {
@@ -79,7 +79,8 @@ int mh_abi_version(void);
 int mh_set_option(const char* name, long value);
 long mh_get_option(const char* name);
 /* sizeof() of the ABI structs as this library was compiled, so that a binding can verify its own layout:
- * which = 0 MhGemm, 1 MhT5Config, 2 MhT5Weights, 3 MhSampling, 4 MhDiTConfig, 5 MhDiTWeights; -1 otherwise. */
+ * which = 0 MhGemm, 1 MhT5Config, 2 MhT5Weights, 3 MhSampling, 4 MhDiTConfig, 5 MhDiTWeights,
+ * 6 MhSliderSet; -1 otherwise. */
 int mh_struct_size(int which);
 
 /* ------------------------------------------------------------------------------------------------
@@ -459,19 +460,51 @@ int mh_ddpm_step(const float* model_out, const float* x, const float* noise, con
                  const uint8_t* inpaint_mask, const float* inpaint_ref, const float* x0_override,
                  int raw_pred, int N, int T, float* x_out, float* pred_xstart, void* stream);
 
+/* Sliders whose END point `denoised_fn` re-projects onto the slider's own path every denoising step (reference
+ * diffusion_pipeline.py:208-220; DiffusionSlider :30-35; SliderPath osuT5/osuT5/inference/slider_path.py:26-230 and
+ * path_approximator.py).  All arrays live in DEVICE memory; indices are relative to the window (column of x0).
+ *   chunk b owns rows b and b + pair_stride of x0 (the CFG pair layout [cond_0..cond_{B-1} | null_0..null_{B-1}] of
+ *   mh_dit_forward_cfg: pair_stride = B = n_chunks, N = 2 B), or just row b when pair_stride = 0 (n_chunks = N).
+ *   chunk_active[b] != 0: the song of chunk b has sliders at all -- its positions then take the reference's pixel round
+ *   trip ((x + 1) / 2 * (512, 384)) / (512, 384) * 2 - 1 and row b is broadcast over its pair, exactly as
+ *   `x[:, :, :] = ...` (:220) does, even when no slider of the song lies inside this window.
+ *   Sliders chunk_off[b] .. chunk_off[b+1] belong to chunk b; slider s has control points cp_idx[cp_off[s] .. cp_off[s+1]),
+ *   curve type[s] (0 Linear, 1 PerfectCurve, 2 Catmull, 3 Bezier), end point end_idx[s] and length[s] (playfield pixels).
+ *   The caller leaves out sliders that are not entirely inside the window (:210-212) and guarantees that no end_idx is
+ *   another slider's control point or end (true for event streams: a SLIDER_END is its own point).  One Bezier span
+ *   (control points between repeated points) holds at most 32 points; a longer one yields NaN positions. */
+typedef struct MhSliderSet {
+  int32_t n_chunks, pair_stride, n_sliders;
+  const uint8_t* chunk_active; /* [n_chunks] */
+  const int32_t* chunk_off;    /* [n_chunks + 1] */
+  const int32_t* type;         /* [n_sliders] */
+  const int32_t* cp_off;       /* [n_sliders + 1] */
+  const int32_t* cp_idx;       /* [cp_off[n_sliders]] */
+  const int32_t* end_idx;      /* [n_sliders] */
+  const double* length;        /* [n_sliders] */
+} MhSliderSet;
+
+/* `denoised_fn` of the pipeline on x0 [N,2,T] in place: x0 = where(mask, x0, ref) (mask / ref may be NULL), then the
+ * slider end re-projection above.  The path arithmetic follows the reference's numpy dtype flow (float32 Linear /
+ * Catmull / circular-arc paths, float64 Bezier subdivision). */
+int mh_slider_project(float* x0, const uint8_t* inpaint_mask, const float* inpaint_ref, int N, int T,
+                      const MhSliderSet* sliders, void* stream);
+
 /* Whole p_sample_loop on device (gaussian_diffusion.py:469-561): `n_steps` iterations of
  * mh_dit_forward_cfg + mh_ddpm_step captured once into a hipGraph and replayed.
  *   t_map int32 [n_steps] : timestep_map[i] for loop index i (SpacedDiffusion, respace.py:72-86)
  *   coefs fp32 [n_steps][7]; noise fp32 [n_steps][N,2,T], both indexed by loop index i
  *   (the loop runs i = n_steps-1 ... 0).  x_io [N,2,T] is updated in place.
  *   Everything that depends only on (t, y) -- timestep/label embedders and every block's adaLN modulation --
- *   is computed for all steps before the loop; workspace size from mh_ddpm_loop_workspace_bytes. */
+ *   is computed for all steps before the loop; workspace size from mh_ddpm_loop_workspace_bytes.
+ *   sliders (NULL = none): the step becomes eps -> x0, mh_slider_project (in-paint + slider ends), posterior + noise --
+ *   still inside the one captured graph. */
 int64_t mh_ddpm_loop_workspace_bytes(const MhDiTConfig* cfg, int N, int T, int n_steps);
 int mh_ddpm_sample_loop(const MhDiTConfig* cfg, const MhDiTWeights* w, float* x_io, const float* c,
                         const float* y, float cfg_scale, int band, int N, int T, int n_steps,
                         const int32_t* t_map, const float* coefs, const float* noise,
-                        const uint8_t* inpaint_mask, const float* inpaint_ref, void* workspace,
-                        int64_t workspace_bytes, void* stream);
+                        const uint8_t* inpaint_mask, const float* inpaint_ref, const MhSliderSet* sliders,
+                        void* workspace, int64_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

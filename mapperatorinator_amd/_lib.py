@@ -87,7 +87,13 @@ class MhDiTWeights(C.Structure):
                 ("first_w3", VP), ("qkv_w3", _PTR_ARR), ("out_w3", _PTR_ARR), ("fc1_w3", _PTR_ARR), ("fc2_w3", _PTR_ARR)]
 
 
-ABI_VERSION = 5   # MH_ABI_VERSION of include/mapperhip.h
+class MhSliderSet(C.Structure):
+    _fields_ = [("n_chunks", C.c_int32), ("pair_stride", C.c_int32), ("n_sliders", C.c_int32),
+                ("chunk_active", VP), ("chunk_off", VP), ("type", VP), ("cp_off", VP), ("cp_idx", VP),
+                ("end_idx", VP), ("length", VP)]
+
+
+ABI_VERSION = 6   # MH_ABI_VERSION of include/mapperhip.h
 
 # every symbol include/mapperhip.h declares: (name, restype, argtypes)
 I, I64, F = C.c_int, C.c_int64, C.c_float
@@ -127,7 +133,8 @@ SYMBOLS = {
     "mh_ddpm_step": (I, [VP, VP, VP, VP, VP, VP, VP, I, I, I, VP, VP, VP]),
     "mh_ddpm_loop_workspace_bytes": (I64, [C.POINTER(MhDiTConfig), I, I, I]),
     "mh_ddpm_sample_loop": (I, [C.POINTER(MhDiTConfig), C.POINTER(MhDiTWeights), VP, VP, VP, F, I, I, I, I,
-                                VP, VP, VP, VP, VP, VP, I64, VP]),
+                                VP, VP, VP, VP, VP, C.POINTER(MhSliderSet), VP, I64, VP]),
+    "mh_slider_project": (I, [VP, VP, VP, I, I, C.POINTER(MhSliderSet), VP]),
 }
 
 _lib = None
@@ -156,7 +163,7 @@ def load():
         fn.argtypes = args
     if lib.mh_abi_version() != ABI_VERSION:
         raise RuntimeError("libmapperhip.so ABI version mismatch")
-    for which, st in enumerate((MhGemm, MhT5Config, MhT5Weights, MhSampling, MhDiTConfig, MhDiTWeights)):
+    for which, st in enumerate((MhGemm, MhT5Config, MhT5Weights, MhSampling, MhDiTConfig, MhDiTWeights, MhSliderSet)):
         if lib.mh_struct_size(which) != C.sizeof(st):
             raise RuntimeError(f"libmapperhip.so: layout of {st.__name__} differs from the binding "
                                f"({lib.mh_struct_size(which)} vs {C.sizeof(st)} bytes)")

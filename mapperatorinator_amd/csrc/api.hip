@@ -86,6 +86,7 @@ extern "C" int mh_struct_size(int which) {
     case 3: return (int)sizeof(MhSampling);
     case 4: return (int)sizeof(MhDiTConfig);
     case 5: return (int)sizeof(MhDiTWeights);
+    case 6: return (int)sizeof(MhSliderSet);
   }
   return -1;
 }

@@ -385,7 +385,8 @@ extern "C" int64_t mh_dit_workspace_bytes(const MhDiTConfig* c, int N, int T) {
 extern "C" int64_t mh_ddpm_loop_workspace_bytes(const MhDiTConfig* c, int N, int T, int n_steps) {
   if (!c || N <= 0 || T <= 0 || n_steps <= 0) return -1;
   return dit_ws_layout(c, N, T, nullptr, 0, nullptr) + align256((int64_t)N * 4 * T * 4) +
-         cond_scratch_bytes(c, n_steps * N) + align256(cond_floats(c, N) * 4 * (int64_t)n_steps);
+         cond_scratch_bytes(c, n_steps * N) + align256(cond_floats(c, N) * 4 * (int64_t)n_steps) +
+         align256((int64_t)N * 2 * T * 4);   // x0 between the two halves of a step with sliders
 }
 
 extern "C" int mh_dit_forward_cfg(const MhDiTConfig* c, const MhDiTWeights* w, const float* x, const int32_t* t,
@@ -416,11 +417,12 @@ extern "C" int mh_ddpm_step(const float* model_out, const float* x, const float*
 extern "C" int mh_ddpm_sample_loop(const MhDiTConfig* c, const MhDiTWeights* w, float* x_io, const float* cc,
                                    const float* y, float cfg_scale, int band, int N, int T, int n_steps,
                                    const int32_t* t_map, const float* coefs, const float* noise,
-                                   const uint8_t* inpaint_mask, const float* inpaint_ref, void* workspace,
-                                   int64_t workspace_bytes, void* stream) {
+                                   const uint8_t* inpaint_mask, const float* inpaint_ref, const MhSliderSet* sliders,
+                                   void* workspace, int64_t workspace_bytes, void* stream) {
   MH_TRY(check_dit(c, N, T));
   MH_REQUIRE(w && x_io && cc && y && t_map && coefs && noise && workspace && n_steps > 0,
              "mh_ddpm_sample_loop: null argument");
+  if (sliders) MH_TRY(check_slider_set(sliders, N));
   MH_REQUIRE(stream != nullptr, "mh_ddpm_sample_loop: needs a non-default stream (hipGraph capture)");
   MH_REQUIRE(workspace_bytes >= mh_ddpm_loop_workspace_bytes(c, N, T, n_steps), "mh_ddpm_sample_loop: workspace too small");
   MH_REQUIRE((inpaint_mask == nullptr) == (inpaint_ref == nullptr), "mh_ddpm_sample_loop: inpaint mask/ref mismatch");
@@ -430,6 +432,7 @@ extern "C" int mh_ddpm_sample_loop(const MhDiTConfig* c, const MhDiTWeights* w, 
   float* mout = (float*)((char*)workspace + used);
   void* scratch = (char*)mout + align256((int64_t)N * 4 * T * 4);
   float* cond_all = (float*)((char*)scratch + cond_scratch_bytes(c, n_steps * N));
+  float* x0buf = (float*)((char*)cond_all + align256(cond_floats(c, N) * 4 * (int64_t)n_steps));
   MH_TRY(gemm_prepare());
   // hoisted out of the per-step graph: V^T padding, the conditioning of EVERY step, the loop counter
   if (hipMemsetAsync(b.vt, 0, (size_t)N * c->hidden * b.Tpad * 4, s) != hipSuccess) return check_launch("memset vt");
@@ -445,9 +448,15 @@ extern "C" int mh_ddpm_sample_loop(const MhDiTConfig* c, const MhDiTWeights* w, 
                      per_step, b.cond_cur);
   int rc = check_launch("select_step_kernel");
   if (rc == MH_OK) rc = dit_body(c, w, x_io, cc, cfg_scale, band, N, T, mout, b, s);
-  if (rc == MH_OK)
+  if (rc == MH_OK && !sliders)
     rc = ddpm_step(mout, x_io, noise, coefs, b.sel, (long)N * 2 * T, inpaint_mask, inpaint_ref, nullptr, 0, N, T, x_io,
                    nullptr, s);
+  if (rc == MH_OK && sliders) {   // eps -> x0 | in-paint + slider ends | clamp, posterior mean, noise
+    rc = ddpm_step(mout, x_io, noise, coefs, b.sel, (long)N * 2 * T, nullptr, nullptr, nullptr, 1, N, T, x_io, x0buf, s);
+    if (rc == MH_OK) rc = slider_project(x0buf, inpaint_mask, inpaint_ref, N, T, *sliders, s);
+    if (rc == MH_OK)
+      rc = ddpm_step(mout, x_io, noise, coefs, b.sel, (long)N * 2 * T, nullptr, nullptr, x0buf, 0, N, T, x_io, nullptr, s);
+  }
   if (rc == MH_OK) {
     hipLaunchKernelGGL(loop_dec_kernel, dim3(1), dim3(64), 0, s, b.sel);
     rc = check_launch("loop_dec_kernel");

@@ -33,6 +33,9 @@ int attention_general(const AttnArgs& a, int B, int H, int dtype, hipStream_t s)
 int transpose_v(const void* v, long v_bs_el, long v_hs_el, int Lk, void* vt, int Lkpad, int B, int H, int dtype,
                 hipStream_t s);
 
+int slider_project(float* x0, const uint8_t* imask, const float* iref, int N, int T, const MhSliderSet& ss, hipStream_t s);
+int check_slider_set(const MhSliderSet* ss, int N);
+
 inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 inline int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
 

@@ -11,18 +11,32 @@ loop (K7-K9).  Integer / indexing logic on the host, every float of the hot loop
                        `p_sample_loop` (:243-252), the refine iterations (:254-267) and `to_positions` (:171-176)
 
 Grouping Events into hit-object points (`get_groups`, `update_event_times`) and writing positions back into Events
-(`events_with_pos`) is the reference's own integer host code either side of this seam and stays there.  Not built:
-slider end re-projection inside `denoised_fn` (:208-220) -- pass `denoised_fn_factory` to
-supply it from the host -- and `pad_sequence=True` (the padded mask is no longer a band).
+(`events_with_pos`) is the reference's own integer host code either side of this seam and stays there; the
+`DiffusionSlider` list it builds (:389-437) is handed in as `sliders` and the slider end re-projection of `denoised_fn`
+(:208-220) runs on the device inside the DDPM graph (csrc/slider.hip).  Not built: `pad_sequence=True` (the padded
+mask is no longer a band).
 """
 from __future__ import annotations
 
 import math
-from typing import Callable, Optional
+from dataclasses import dataclass
+from typing import Callable, Optional, Sequence
 
+import numpy as np
 import torch
 
-from .dit import BandMask, DiTHIP, InpaintSpec, create_diffusion
+from .dit import BandMask, DiTHIP, InpaintSpec, SliderInpaintSpec, create_diffusion
+
+
+@dataclass
+class DiffusionSlider:
+    """(diffusion_pipeline.py:30-35) sequence points of the head and anchors, the point of the slider end, the curve
+    type of the first anchor ('Bezier' | 'PerfectCurve' | 'Catmull') and the length in playfield pixels"""
+    seq_indices: np.ndarray
+    end_index: int
+    curve_type: Optional[str]
+    length: Optional[float]
+
 
 # one-hot row of each hit-object type inside the 16 type rows (diffusion_pipeline.py:304-315); +1 for a new combo on
 # CIRCLE / SLIDER_HEAD (:339-340), + repeat_type(repeats) on SLIDER_END (:343-347)
@@ -109,10 +123,13 @@ class DiffusionPipelineHIP:
     def generate_positions(self, seq_x: torch.Tensor, seq_o: torch.Tensor, seq_c: torch.Tensor,
                            class_vector: torch.Tensor, unk_class_vector: torch.Tensor,
                            noise_source: Optional[Callable] = None,
-                           denoised_fn_factory: Optional[Callable] = None) -> torch.Tensor:
+                           denoised_fn_factory: Optional[Callable] = None,
+                           sliders: Optional[Sequence] = None) -> torch.Tensor:
         """seq_* as returned by `events_to_sequence`; class vectors (C,) multi-hot.  Returns positions (1, 2, T) on the
         CPU, what the reference hands to `events_with_pos`.  (= generate_positions_batch with one chunk.)
 
+        sliders: the DiffusionSlider list `events_to_sequence` returns (its 6th value); their end points are
+            re-projected onto the slider paths every denoising step, on the device.
         noise_source(n, shape) -> fp32 [n, *shape]: the gaussian noise of n consecutive p_sample calls (parity tests
             inject the reference's draws); default: torch.randn on the device, one draw per call like `th.randn_like`.
         denoised_fn_factory(mask, z_part, start, end) -> callable: replaces the in-paint-only `denoised_fn` (e.g. with
@@ -120,15 +137,18 @@ class DiffusionPipelineHIP:
         if seq_x.shape[1] == 0:
             return torch.zeros(1, 2, 0)
         return self.generate_positions_batch(seq_x[None], seq_o[None], seq_c[None], class_vector[None],
-                                             unk_class_vector[None], noise_source, denoised_fn_factory)
+                                             unk_class_vector[None], noise_source, denoised_fn_factory,
+                                             None if sliders is None else [list(sliders)])
 
     @torch.no_grad()
     def generate_positions_batch(self, seq_x: torch.Tensor, seq_o: torch.Tensor, seq_c: torch.Tensor,
                                  class_vectors: torch.Tensor, unk_class_vectors: torch.Tensor,
                                  noise_source: Optional[Callable] = None,
-                                 denoised_fn_factory: Optional[Callable] = None) -> torch.Tensor:
+                                 denoised_fn_factory: Optional[Callable] = None,
+                                 sliders: Optional[Sequence[Sequence]] = None) -> torch.Tensor:
         """B song-chunks with the SAME number of points T through the diffusion stage as ONE denoiser batch:
         seq_x (B, 2, T), seq_o (B, T), seq_c (B, 272, T), class vectors (B, C).  Returns positions (B, 2, T) on the CPU.
+        `sliders`: one DiffusionSlider list per chunk (indices count the chunk's own points).
 
         The reference runs its pipeline once per beatmap with `n = 1` (diffusion_pipeline.py:157-166): a CFG batch of
         2 rows, i.e. M = 2 T rows per GEMM -- 67 latency-bound launches per step at T = 128.  Chunks are independent,
@@ -141,6 +161,8 @@ class DiffusionPipelineHIP:
         B, _, seq_len = seq_x.shape
         if seq_len == 0:
             return torch.zeros(B, 2, 0)
+        if sliders is not None and len(sliders) != B:
+            raise ValueError(f"{len(sliders)} slider lists for {B} chunks")
         diffusion = create_diffusion(timestep_respacing=self.timesteps, diffusion_steps=self.diffusion_steps,
                                      noise_schedule=self.noise_schedule)
         z = seq_x.to(dev, torch.float32)
@@ -178,6 +200,8 @@ class DiffusionPipelineHIP:
                 return z_part
             if denoised_fn_factory is not None:
                 denoised_fn = denoised_fn_factory(mask, z_part, start, end)
+            elif sliders is not None and any(len(sl) > 0 for sl in sliders):
+                denoised_fn = SliderInpaintSpec(mask, z_part, sliders, start, end)
             else:
                 denoised_fn = InpaintSpec(mask, z_part)
             z_part = denoised_fn(z_part)

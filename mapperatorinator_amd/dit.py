@@ -202,6 +202,77 @@ class InpaintSpec:
         return torch.where(self.mask.to(x.device), x, self.ref.to(x.device))
 
 
+CURVE_CODE = {"Linear": 0, "PerfectCurve": 1, "Catmull": 2, "Bezier": 3}
+MAX_BEZIER_SPAN = 32     # SL_MAXCP of csrc/slider.hip
+
+
+class SliderInpaintSpec(InpaintSpec):
+    """`denoised_fn` of the reference pipeline WITH sliders (diffusion_pipeline.py:201-222): the in-paint `where`, then
+    every slider that lies entirely inside the window [start, end) gets its end point moved to
+    `SliderPath(curve_type, control points).position_at(length / get_distance())`.  Runs on the device
+    (mh_slider_project); SpacedDiffusionHIP recognises it and keeps the whole loop one replayed hipGraph.
+
+    sliders_per_chunk: one list per song chunk (row b and row B + b of the CFG batch) of objects with the fields of
+    the reference's DiffusionSlider (:30-35): seq_indices, end_index, curve_type, length -- indices count points of
+    the whole song, `start` is the window's first point."""
+
+    def __init__(self, mask: torch.Tensor, ref: torch.Tensor, sliders_per_chunk, start: int, end: int):
+        super().__init__(mask, ref)
+        dev = ref.device
+        if dev.type != "cuda":
+            raise RuntimeError("SliderInpaintSpec lives on the GPU; there is no CPU path")
+        N, _, T = ref.shape
+        B = len(sliders_per_chunk)
+        if N != 2 * B or T != end - start:
+            raise ValueError(f"slider lists for {B} chunks / window {start}:{end} do not match x0 {tuple(ref.shape)}")
+        active, chunk_off, types, cp_off, cp_idx, end_idx, length = [], [0], [], [0], [], [], []
+        for sl in sliders_per_chunk:
+            active.append(1 if len(sl) > 0 else 0)
+            used = set()
+            for s in sl:
+                idx = np.asarray(s.seq_indices, dtype=np.int64)
+                if np.any((idx < start) | (idx >= end)) or s.end_index < start or s.end_index >= end:
+                    continue                                       # (:210-212)
+                run = longest = 1
+                for a, b in zip(idx[:-1], idx[1:]):                # spans only ever split further (equal positions)
+                    run = 1 if a == b else run + 1
+                    longest = max(longest, run)
+                if longest > MAX_BEZIER_SPAN:
+                    raise NotImplementedError(f"slider with a {longest}-point curve span (device limit {MAX_BEZIER_SPAN})")
+                pts = set(int(i) for i in idx) | {int(s.end_index)}
+                if int(s.end_index) in set(int(i) for i in idx) or (used & pts):
+                    raise NotImplementedError("sliders sharing sequence points are re-projected in order by the reference; "
+                                              "the device kernel needs them disjoint")
+                used |= pts
+                types.append(CURVE_CODE.get(s.curve_type, 3))      # calculate_subpath: anything else is a Bezier
+                cp_idx.extend(int(i) - start for i in idx)
+                cp_off.append(len(cp_idx))
+                end_idx.append(int(s.end_index) - start)
+                length.append(float(s.length))
+            chunk_off.append(len(types))
+        self.n_sliders = len(types)
+
+        def dv(a, dt):
+            return torch.tensor(a if len(a) else [0], dtype=dt).to(dev)
+
+        self._t = [dv(active, torch.uint8), dv(chunk_off, torch.int32), dv(types, torch.int32), dv(cp_off, torch.int32),
+                   dv(cp_idx, torch.int32), dv(end_idx, torch.int32), dv(length, torch.float64)]
+        self.cset = _lib.MhSliderSet(B, B, self.n_sliders, *[t.data_ptr() for t in self._t])
+        self._mask8 = self.mask.to(dev).to(torch.uint8).contiguous()
+        self._ref = self.ref.to(dev, torch.float32).contiguous()
+
+    def project_(self, x0: torch.Tensor, stream: int) -> torch.Tensor:
+        """in place on a contiguous fp32 device tensor [2B, 2, T]"""
+        N, _, T = x0.shape
+        _lib.check(_lib.load().mh_slider_project(x0.data_ptr(), self._mask8.data_ptr(), self._ref.data_ptr(), N, T,
+                                                 C.byref(self.cset), stream), "mh_slider_project")
+        return x0
+
+    def __call__(self, x):
+        x0 = x.to(self._ref.device, torch.float32).contiguous().clone()
+        return self.project_(x0, torch.cuda.current_stream(x0.device).cuda_stream)
+
+
 # ---- schedule (host, float64) --------------------------------------------------------------------
 def named_beta_schedule(name: str, n: int) -> np.ndarray:
     if name == "linear":
@@ -300,16 +371,18 @@ class SpacedDiffusionHIP:
         ws = dit.workspace(N, T, n)
 
         if denoised_fn is None or isinstance(denoised_fn, InpaintSpec):
-            imask = iref = None
+            imask = iref = sset = None
             if denoised_fn is not None:
                 imask = denoised_fn.mask.to(dev).to(torch.uint8).contiguous()
                 iref = denoised_fn.ref.to(dev, torch.float32).contiguous()
+            if isinstance(denoised_fn, SliderInpaintSpec):
+                sset = C.byref(denoised_fn.cset)
             dit.stream.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(dit.stream):
                 rc = lib.mh_ddpm_sample_loop(C.byref(dit.cfg), C.byref(dit.w), x.data_ptr(), c.data_ptr(),
                                              y.data_ptr(), cfg_scale, band, N, T, n, t_map.data_ptr(),
                                              coefs.data_ptr(), noise_by_i.data_ptr(), _lib.ptr(imask), _lib.ptr(iref),
-                                             ws.data_ptr(), ws.numel(), dit.stream.cuda_stream)
+                                             sset, ws.data_ptr(), ws.numel(), dit.stream.cuda_stream)
             _lib.check(rc, "mh_ddpm_sample_loop")
             torch.cuda.current_stream(dev).wait_stream(dit.stream)
             return x
@@ -365,7 +438,13 @@ class SpacedDiffusionHIP:
         _lib.check(lib.mh_dit_forward_cfg(C.byref(dit.cfg), C.byref(dit.w), x.data_ptr(), t32.data_ptr(), c.data_ptr(),
                                           y.data_ptr(), float(mk.get("cfg_scale", 1.0)), band, N, T, mout.data_ptr(),
                                           ws.data_ptr(), ws.numel(), s), "mh_dit_forward_cfg")
-        if denoised_fn is None or isinstance(denoised_fn, InpaintSpec):
+        if isinstance(denoised_fn, SliderInpaintSpec):     # eps -> x0 | in-paint + slider ends | posterior, all on the device
+            _lib.check(lib.mh_ddpm_step(mout.data_ptr(), x.data_ptr(), noise.data_ptr(), coef.data_ptr(), None, None,
+                                        None, 1, N, T, out.data_ptr(), x0.data_ptr(), s), "mh_ddpm_step")
+            denoised_fn.project_(x0, s)
+            _lib.check(lib.mh_ddpm_step(mout.data_ptr(), x.data_ptr(), noise.data_ptr(), coef.data_ptr(), None, None,
+                                        x0.data_ptr(), 0, N, T, out.data_ptr(), x0.data_ptr(), s), "mh_ddpm_step")
+        elif denoised_fn is None or isinstance(denoised_fn, InpaintSpec):
             imask = iref = None
             if denoised_fn is not None:
                 imask = denoised_fn.mask.to(dev).to(torch.uint8).contiguous()

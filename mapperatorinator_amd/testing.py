@@ -280,6 +280,29 @@ def synthetic_hit_objects(T: int, seed: int, span_ms: float = 60000.0):
     return x, y, times, dist, typ
 
 
+def synthetic_sliders(T: int, seed: int, every: int = 9):
+    """DiffusionSlider lists over the points of `synthetic_hit_objects`: head, 1-6 anchors (a red anchor = the same point
+    twice, as `events_to_sequence` emits it), last anchor, and the slider end as the next point; curve types cycle through
+    Bezier / PerfectCurve / Catmull.  Consecutive sliders use disjoint points, like a real event stream."""
+    from .diffusion_pipeline import DiffusionSlider
+    rng = np.random.default_rng(seed)
+    out, i, k = [], 2, 0
+    while i + 9 < T:
+        curve = ("Bezier", "PerfectCurve", "Catmull", "Bezier")[k % 4]
+        n_anchor = 1 if (curve == "PerfectCurve" and k % 8 == 1) else int(rng.integers(1, 6))
+        idx = [i]
+        for a in range(n_anchor):
+            idx.append(i + 1 + a)
+            if curve == "Bezier" and k % 4 == 3 and a == n_anchor // 2:
+                idx.append(i + 1 + a)                      # red anchor
+        idx.append(i + 1 + n_anchor)                       # last anchor
+        end = i + 2 + n_anchor
+        out.append(DiffusionSlider(np.array(idx), end, curve, float(rng.uniform(20, 500))))
+        i = end + 1 + int(rng.integers(0, every))
+        k += 1
+    return out
+
+
 def pipeline_windows(seq_len: int, max_seq_len: int, overlap_buffer: int):
     """(start, end) of every diffusion window (reference diffusion_pipeline.py:277-278)."""
     return [(i, min(i + max_seq_len, seq_len))

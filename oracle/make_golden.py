@@ -378,7 +378,7 @@ def pipeline_case():
     """Reference `DiffisionPipeline.generate` (window loop, in-paint masks with start/end time, refine steps) on
     synthetic hit objects, gaussian draws injected from a numpy stream (one draw per p_sample call, in call order)."""
     from mapperatorinator_amd.diffusion_pipeline import points_to_sequence
-    from mapperatorinator_amd.testing import pipeline_windows, synthetic_hit_objects
+    from mapperatorinator_amd.testing import pipeline_windows, synthetic_hit_objects, synthetic_sliders
     c = PIPE_CASE
     depth, hidden, heads = DIT_PRESETS[c["preset"]]
     sd = random_dit_state_dict(depth, hidden, seed=c["weight_seed"])
@@ -398,15 +398,20 @@ def pipeline_case():
     start_time, end_time = float(times[20]), float(times[280])
     out = {}
     # "short": 2 DDPM steps + 1 refine step per window -- errors cannot compound, pins the window / mask logic tightly
+    # "sliders": the slider end re-projection of `denoised_fn` on synthetic sliders (mapperatorinator_amd.testing)
+    sliders = synthetic_sliders(c["T"], c["point_seed"] + 1)
     for tag, kk, seed in (("", k, c["noise_seed"]),
-                          ("_short", dict(k, timesteps=[2] + [0] * 9, refine_iters=1), c["noise_seed"] + 1)):
+                          ("_short", dict(k, timesteps=[2] + [0] * 9, refine_iters=1), c["noise_seed"] + 1),
+                          ("_sliders", k, c["noise_seed"] + 2),
+                          ("_sliders_short", dict(k, timesteps=[2] + [0] * 9, refine_iters=1), c["noise_seed"] + 3)):
         rng = np.random.default_rng(seed)
         noise = []
         for (a, b) in pipeline_windows(c["T"], kk["max_seq_len"], kk["overlap_buffer"]):
             for _ in range(kk["timesteps"][0] + kk["refine_iters"]):
                 noise.append(torch.from_numpy(rng.standard_normal((2, 2, b - a)).astype(np.float32)))
         out["positions" + tag] = rh.reference_pipeline_positions(ref, seq_x, seq_o, seq_c, cv, ucv, noise,
-                                                                 start_time=start_time, end_time=end_time, **kk).numpy()
+                                                                 start_time=start_time, end_time=end_time,
+                                                                 sliders=sliders if "sliders" in tag else (), **kk).numpy()
     pos = torch.from_numpy(out["positions"])
     np.savez_compressed(os.path.join(OUT, "dit_pipeline.npz"), case=json.dumps(c), start_time=start_time,
                         end_time=end_time, seq_c_slice=seq_c[:, ::37].numpy(), **out)
@@ -467,10 +472,59 @@ def mel_case():
     np.savez_compressed(os.path.join(OUT, "mel_oracle.npz"), audio_seed=9, n_samples=16000, mel=m.numpy())
 
 
+def random_slider_cases(n_cases: int, seed: int):
+    """(curve code, float32 control points, length) triples covering every curve type, repeated points (red anchors),
+    degenerate (all points equal) and nearly collinear perfect curves"""
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n_cases):
+        ct = int(rng.integers(0, 4))
+        ncp = 3 if (ct == 1 and rng.random() < 0.7) else int(rng.integers(2, 10))
+        base = rng.uniform(50, 450, 2)
+        cps = (base + rng.normal(0, rng.uniform(5, 150), (ncp, 2))).astype(np.float32)
+        if rng.random() < 0.3 and ncp > 3:
+            k = int(rng.integers(1, ncp - 1))
+            cps[k + 1] = cps[k]
+        if rng.random() < 0.04:
+            cps[:] = cps[0]
+        if ct == 1 and ncp == 3 and rng.random() < 0.2:
+            cps[1] = (cps[0] + cps[2]) / 2 + rng.normal(0, 1e-3, 2).astype(np.float32)
+        # what `to_positions` makes of normalised coordinates, so that a run from the normalised values sees THESE points
+        v = torch.from_numpy(cps) / torch.tensor((512, 384)) * 2 - 1
+        cps = (((v + 1) / 2) * torch.tensor((512, 384))).numpy()
+        out.append((ct, cps, float(rng.uniform(0, 600)), v.numpy()))
+    return out
+
+
+def sliders_case():
+    """End points of the reference's own SliderPath (slider_path.py) on random sliders: what `denoised_fn` writes into
+    x2[slider.end_index] (diffusion_pipeline.py:213-219), float32 like x2."""
+    rh.ref_shims.install()
+    from osuT5.osuT5.inference.slider_path import SliderPath
+    names = ["Linear", "PerfectCurve", "Catmull", "Bezier"]
+    cases = random_slider_cases(800, 20240)
+    types, cp_off, cps_all, v_all, lengths, ends, moved = [], [0], [], [], [], [], []
+    for ct, cps, length, v in cases:
+        path = SliderPath(names[ct], cps)
+        total = path.get_distance()
+        end = None if total == 0 else np.asarray(path.position_at(length / total))
+        types.append(ct)
+        cps_all.append(cps)
+        v_all.append(v)
+        cp_off.append(cp_off[-1] + len(cps))
+        lengths.append(length)
+        moved.append(end is not None)
+        ends.append(np.zeros(2, np.float32) if end is None else end.astype(np.float32))
+    np.savez_compressed(os.path.join(OUT, "sliders.npz"), type=np.array(types, np.int32), cp_off=np.array(cp_off, np.int32),
+                        cps=np.concatenate(cps_all), v=np.concatenate(v_all), length=np.array(lengths, np.float64), end=np.stack(ends),
+                        moved=np.array(moved))
+    print("sliders", len(cases), "cases, moved", int(np.sum(moved)), "by type", np.bincount(types))
+
+
 def main(only=None):
     """`python -m oracle.make_golden` regenerates everything; `python -m oracle.make_golden NAME ...` only the named
     fixtures (t5_tiny, t5_small, t5_base, t5_large, vw_test, vw_test_nobias, vw_small, t5_base_bf16ref, t5_tiny_cond,
-    t5_tiny_tf, dit_xs, dit_s, dit_b, dit_b_1024, dit_pipeline, whisper_frontend, mel_oracle, tokenizer)."""
+    t5_tiny_tf, dit_xs, dit_s, dit_b, dit_b_1024, dit_pipeline, sliders, whisper_frontend, mel_oracle, tokenizer)."""
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(max(1, os.cpu_count() or 1))
     cases = {"tokenizer": tokenizer_case, "mel_oracle": mel_case, "whisper_frontend": whisper_frontend_case}
@@ -489,6 +543,7 @@ def main(only=None):
         "dit_b_1024": lambda: dit_case("dit_b_1024", "DiT-B", 1024, 4, 8, 2.0, loop_steps=3),
         "dit_pipeline": pipeline_case,
         "t5_tiny_beam": beam_case,
+        "sliders": sliders_case,
     })
     for name, fn in cases.items():
         if only and name not in only:

@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import copy
 
+import numpy as np
 import torch
 
 from . import ref_shims
@@ -241,12 +242,14 @@ def reference_ddpm(model, diffusion, z, c, y, cfg_scale, attn_mask, noise_list):
 
 def reference_pipeline_positions(model, seq_x, seq_o, seq_c, class_vector, unk_class_vector, noise_list, *, timesteps,
                                  seq_len, max_seq_len, overlap_buffer, cfg_scale, refine_iters=0, start_time=None,
-                                 end_time=None, diffusion_steps=1000, noise_schedule="squaredcos_cap_v2"):
+                                 end_time=None, diffusion_steps=1000, noise_schedule="squaredcos_cap_v2", sliders=()):
     """The reference's own `DiffisionPipeline.generate` (diffusion_pipeline.py:111-287) driven from the tensors that
     `events_to_sequence` returns: the object is built without its constructor, `events_to_sequence`,
     `get_class_vector` and `events_with_pos` are replaced by stand-ins that hand the given tensors through (Event
     grouping needs the `slider` package, absent here), everything in between is unmodified reference code.  The
-    gaussian draws are popped from `noise_list` in call order (one per p_sample call, refine steps included)."""
+    gaussian draws are popped from `noise_list` in call order (one per p_sample call, refine steps included).
+    `sliders`: DiffusionSlider-like objects handed through as the 6th value of `events_to_sequence` (their end points are
+    then re-projected by the reference's own `denoised_fn` / SliderPath code)."""
     ref_shims.install()
     import diffusion_pipeline as dp
     from osu_diffusion.utils.diffusion import gaussian_diffusion as gd
@@ -266,7 +269,9 @@ def reference_pipeline_positions(model, seq_x, seq_o, seq_c, class_vector, unk_c
         calls.append(1)
         return (class_vector if len(calls) == 1 else unk_class_vector).clone()
 
-    pipe.events_to_sequence = lambda events, timing, sm: (seq_x, seq_o, seq_c, seq_x.shape[1], {}, [])
+    ref_sliders = [dp.DiffusionSlider(np.asarray(s.seq_indices), int(s.end_index), s.curve_type, float(s.length))
+                   for s in sliders]
+    pipe.events_to_sequence = lambda events, timing, sm: (seq_x, seq_o, seq_c, seq_x.shape[1], {}, ref_sliders)
     pipe.get_class_vector = get_class_vector
     pipe.events_with_pos = lambda events, positions, seq_indices: positions
 

@@ -192,7 +192,7 @@ def test_dit_b_full_size_properties():
     assert not torch.equal(a[:, :, 990:], b[:, :, 990:])
 
 
-@pytest.mark.parametrize("variant", ["short", "full"])
+@pytest.mark.parametrize("variant", ["short", "full", "sliders_short", "sliders"])
 def test_window_pipeline_matches_reference_golden(variant):
     """Row a14: the reference's `DiffisionPipeline.generate` between `events_to_sequence` and `events_with_pos`
     (3 overlapping windows, in-paint masks incl. start / end time, DDPM steps + refine steps per window, CFG) vs
@@ -201,12 +201,14 @@ def test_window_pipeline_matches_reference_golden(variant):
       full : 12 steps + 2 refine steps.  The random DiT amplifies fp32 rounding at a few points (two CPU fp32
              implementations -- reference DiT vs oracle/dit.py inside the reference pipeline -- already differ by up to
              1.7 px there): median < 0.1 px, 90 % < 1 px, max inside the 5e-2 (12.8 px) bound of the 100-step loop test.
+      sliders_short / sliders: the same two runs with ~25 synthetic sliders whose end points `denoised_fn` re-projects
+             onto their paths every step (diffusion_pipeline.py:208-220) -- on the device here, inside the DDPM graph.
     Points outside [start_time, end_time] keep the given positions."""
     import json
 
     from mapperatorinator_amd.diffusion_pipeline import DiffusionPipelineHIP, points_to_sequence
     from mapperatorinator_amd.dit import DiTHIP
-    from mapperatorinator_amd.testing import DIT_PRESETS, random_dit_state_dict, synthetic_hit_objects
+    from mapperatorinator_amd.testing import DIT_PRESETS, random_dit_state_dict, synthetic_hit_objects, synthetic_sliders
     g = np.load(f"{GOLDEN}/dit_pipeline.npz")
     c = json.loads(str(g["case"]))
     depth, hidden, heads = DIT_PRESETS[c["preset"]]
@@ -217,10 +219,11 @@ def test_window_pipeline_matches_reference_golden(variant):
     cv[c["classes"]] = 1
     ucv[c["null_classes"]] = 1
     k = dict(c["knobs"])
-    seed, key = c["noise_seed"], "positions"
-    if variant == "short":
+    seed, key = c["noise_seed"] + {"full": 0, "short": 1, "sliders": 2, "sliders_short": 3}[variant], "positions"
+    key = "positions" if variant == "full" else "positions_" + variant
+    sliders = synthetic_sliders(c["T"], c["point_seed"] + 1) if "sliders" in variant else None
+    if "short" in variant:
         k.update(timesteps=[2] + [0] * 9, refine_iters=1)
-        seed, key = seed + 1, "positions_short"
     pipe = DiffusionPipelineHIP(dit, timesteps=k["timesteps"], seq_len=k["seq_len"], max_seq_len=k["max_seq_len"],
                                 overlap_buffer=k["overlap_buffer"], cfg_scale=k["cfg_scale"], refine_model=dit,
                                 refine_iters=k["refine_iters"], start_time=float(g["start_time"]),
@@ -230,19 +233,27 @@ def test_window_pipeline_matches_reference_golden(variant):
     def noise_source(n, shape):
         return torch.from_numpy(np.stack([rng.standard_normal(shape).astype(np.float32) for _ in range(n)]))
 
-    pos = pipe.generate_positions(seq_x, seq_o, seq_c, cv, ucv, noise_source=noise_source)
+    pos = pipe.generate_positions(seq_x, seq_o, seq_c, cv, ucv, noise_source=noise_source, sliders=sliders)
     assert pos.shape == (1, 2, c["T"]) and pos.device.type == "cpu"
     want = torch.from_numpy(g[key])
     err = (pos[0] - want).abs().max(0).values
     print(f"pipeline[{variant}] position error px: max {err.max().item():.4f} median {err.median().item():.4f} "
           f"p90 {err.quantile(0.9).item():.4f}")
-    if variant == "short":
+    if sliders is not None:
+        # the re-projection really moved the slider ends: the run without sliders leaves them somewhere else
+        ends = [s.end_index for s in sliders]
+        plain = torch.from_numpy(g["positions_short" if "short" in variant else "positions"])
+        assert (want[:, ends] - plain[:, ends]).abs().max(0).values.median().item() > 5
+        print(f"   slider ends: max err {err[ends].max().item():.4f} px over {len(ends)} sliders")
+    if "short" in variant:
         assert err.max().item() < 0.05
     else:
         assert err.median().item() < 0.1 and err.quantile(0.9).item() < 1.0 and err.max().item() < 12.8
     # points outside [start_time, end_time] are never generated: they keep the given positions
     given = torch.stack([torch.from_numpy(x), torch.from_numpy(y)])
     frozen = (torch.from_numpy(times) < float(g["start_time"])) | (torch.from_numpy(times) > float(g["end_time"]))
+    if sliders is not None:
+        frozen[[s.end_index for s in sliders]] = False     # slider ends are re-projected even where nothing is generated
     assert int(frozen.sum()) >= 30
     assert (pos[0][:, frozen] - given[:, frozen]).abs().max().item() < 1e-3
     assert (want[:, frozen] - given[:, frozen]).abs().max().item() < 1e-3
@@ -361,3 +372,80 @@ def test_batched_denoiser_eps_vs_oracle_per_chunk(B):
         worst = max(worst, (got[[b, B + b]] - want).abs().max().item())
     print("batched (bf16 x 3) eps vs per-chunk oracle: max abs", worst, "eps scale", got.abs().max().item())
     assert worst < 2e-4
+
+
+def test_slider_end_projection_matches_reference_golden():
+    """mh_slider_project (csrc/slider.hip) against the reference's own SliderPath on 800 random sliders of every curve
+    type (tests/golden/sliders.npz: Linear / PerfectCurve / Catmull / Bezier, red anchors, degenerate and nearly
+    collinear cases).  The kernel restates the reference's numpy dtype flow (float32 vs float64 per operation), so the
+    end points are expected BIT-equal except where a float32 transcendental of the circular arc (atan2 / acos / cos /
+    sin: device libm vs numpy's) differs in its last ulp -- an angle ulp times the radius, which is large for the nearly
+    collinear cases the reference itself resolves only to float32.  Tolerances: 2e-4 px for every Linear / Catmull /
+    Bezier slider, 5e-2 px for three-point perfect curves, and >= 95 % of all end points bit-equal."""
+    import ctypes as C
+
+    from mapperatorinator_amd import _lib
+    from oracle import slider as osl
+    g = np.load(f"{GOLDEN}/sliders.npz")
+    lib = _lib.load()
+    n = len(g["type"])
+    B = 4
+    per = (n + B - 1) // B
+    cp_off = g["cp_off"].astype(np.int64)
+    cols = [[] for _ in range(B)]           # per chunk: normalised coordinates, column by column
+    types, offs, idx, ends, chunk_off = [], [0], [], [], [0]
+    for b in range(B):
+        for s in range(b * per, min(n, (b + 1) * per)):
+            v = g["v"][cp_off[s]:cp_off[s + 1]]
+            first = len(cols[b])
+            cols[b].extend(v.tolist())
+            cols[b].append([0.25, -0.5])     # the slider end before the projection
+            types.append(int(g["type"][s]))
+            idx.extend(range(first, first + len(v)))
+            offs.append(len(idx))
+            ends.append(first + len(v))
+        chunk_off.append(len(types))
+    T = max(len(c) for c in cols)
+    x = torch.zeros(2 * B, 2, T)
+    for b in range(B):
+        x[b, :, :len(cols[b])] = torch.tensor(cols[b], dtype=torch.float32).T
+    x[B:] = 7.0                              # the null rows are overwritten with the chunk's row (the `x[:, :, :] =` broadcast)
+    dev = torch.device("cuda")
+    t = [torch.ones(B, dtype=torch.uint8), torch.tensor(chunk_off, dtype=torch.int32), torch.tensor(types, dtype=torch.int32),
+         torch.tensor(offs, dtype=torch.int32), torch.tensor(idx, dtype=torch.int32), torch.tensor(ends, dtype=torch.int32),
+         torch.from_numpy(g["length"])]
+    t = [a.to(dev) for a in t]
+    sset = _lib.MhSliderSet(B, B, n, *[a.data_ptr() for a in t])
+    xd = x.to(dev).contiguous()
+    _lib.check(lib.mh_slider_project(xd.data_ptr(), None, None, 2 * B, T, C.byref(sset), None), "mh_slider_project")
+    torch.cuda.synchronize()
+    out = xd.cpu()
+    assert torch.equal(out[:B], out[B:]), "row b must be broadcast over its CFG pair"
+    size = torch.tensor(osl.PLAYFIELD, dtype=torch.float32)
+    px = ((out[:B] + 1) / 2 * size[None, :, None])
+    roundtrip = (((x[:B] + 1) / 2) * size[None, :, None]) / size[None, :, None] * 2 - 1
+    exact = 0
+    worst = {False: 0.0, True: 0.0}          # [is a three-point perfect curve]
+    k = 0
+    for b in range(B):
+        for s in range(b * per, min(n, (b + 1) * per)):
+            e = ends[k]
+            k += 1
+            if not g["moved"][s]:
+                assert torch.equal(out[b, :, e], roundtrip[b, :, e]), "a slider without length must stay where it was"
+                exact += 1
+                continue
+            want = torch.from_numpy(g["end"][s]) / size * 2 - 1
+            exact += int(torch.equal(out[b, :, e], want))
+            err = (px[b, :, e] - torch.from_numpy(g["end"][s])).abs().max().item()
+            if err > 2e-4:
+                print(f"   slider {s}: type {int(g['type'][s])} points {int(cp_off[s + 1] - cp_off[s])} length "
+                      f"{float(g['length'][s]):.1f} off by {err:.2e} px")
+            arc = int(g["type"][s]) == 1 and cp_off[s + 1] - cp_off[s] == 3
+            worst[arc] = max(worst[arc], err)
+        # everything that is not a slider end only takes the pixel round trip
+        keep = torch.ones(T, dtype=torch.bool)
+        keep[[ends[i] for i in range(chunk_off[b], chunk_off[b + 1])]] = False
+        assert torch.equal(out[b][:, keep], roundtrip[b][:, keep])
+    print(f"slider ends: {exact}/{n} bit-equal to the reference, worst {worst[False]:.2e} px (arcs {worst[True]:.2e} px)")
+    assert worst[False] < 2e-4 and worst[True] < 5e-2 and exact >= 0.95 * n
