@@ -331,3 +331,108 @@ def model_generate(model, tokenizer, model_kwargs, generate_kwargs):
     result = out["tokens"]
     stats = _build_generation_stats(result, model_kwargs, pad_token_id, elapsed)
     return result, stats
+
+
+# ---- request batching (second half) ---------------------------------------------------------------
+class RequestBatcher:
+    """The batching policy of the reference's `InferenceServer._batch_thread` (osuT5/osuT5/inference/server.py:343-424)
+    in front of `model_generate`, without its control plane (unix socket, listener / client threads, idle monitor stay
+    the reference's: its `InferenceServer` works unchanged once its module-level `model_generate` is this module's --
+    INTEGRATION.md, tests/test_oracle_pinned.py::test_reference_inference_server_batches_into_our_model_generate).
+
+    Same policy: requests are grouped by their generate kwargs; one batch takes whole or PARTIAL requests of the first
+    group until `max_batch_size // batch_multiplier` rows are filled (2 x beams under guidance, server.py:353-355); every
+    tensor with more than one dimension is left-padded to the widest request, `decoder_input_ids` decides how many pad
+    columns are cut from each request's result again (:377-399); a request is answered when all its rows are done, with
+    the summed token and time statistics (:401-417).
+
+    `max_batch_size` defaults to 32 rows: the decode engine runs two 16-row chains and its step time does not drop
+    below 32 rows (decode), so smaller batches only lose throughput."""
+
+    def __init__(self, model, tokenizer, max_batch_size: int = 32, generate_fn=None):
+        self.model, self.tokenizer, self.max_batch_size = model, tokenizer, int(max_batch_size)
+        self.generate_fn = generate_fn or model_generate
+        self.grouped_requests: dict = {}
+
+    def submit(self, model_kwargs: dict, generate_kwargs: dict) -> dict:
+        """Queue one request (what `_client_handler` does on `conn.recv()`, :297-322); returns its record, whose
+        'result' is filled by `step` once 'work_done' == 'total_work'."""
+        record = dict(model_kwargs=model_kwargs, total_work=int(model_kwargs["inputs"].shape[0]), work_done=0, result=None,
+                      generated_tokens=0, elapsed_seconds=0.0, done=False)
+        self.grouped_requests.setdefault(frozenset(generate_kwargs.items()), []).append(record)
+        return record
+
+    @property
+    def pending(self) -> bool:
+        return bool(self.grouped_requests)
+
+    @staticmethod
+    def _cut(model_kwargs: dict, start: int, length: int) -> dict:
+        return {k: v[start:start + length] if isinstance(v, torch.Tensor) else v for k, v in model_kwargs.items()}
+
+    def step(self) -> int:
+        """One batch of the first group through `model_generate`; returns the number of rows it held (0: nothing queued)."""
+        if not self.grouped_requests:
+            return 0
+        key = next(iter(self.grouped_requests))
+        requests = self.grouped_requests[key]
+        generate_kwargs = dict(key)
+        cfg_scale, num_beams = generate_kwargs.get("cfg_scale", 1.0), generate_kwargs.get("num_beams", 1)
+        multiplier = 2 * num_beams if cfg_scale > 1 else num_beams
+        room = self.max_batch_size // multiplier
+        if room <= 0:
+            raise ValueError(f"max_batch_size {self.max_batch_size} holds no row at batch multiplier {multiplier}")
+        batch = []
+        while room > 0 and requests:
+            req = requests.pop(0)
+            left = req["total_work"] - req["work_done"]
+            work = min(left, room)
+            batch.append((self._cut(req["model_kwargs"], req["work_done"], work), req, work))
+            room -= work
+            if left > work:
+                requests.insert(0, req)            # the rest of it leads the next batch
+        if not requests:
+            del self.grouped_requests[key]
+
+        keys = [k for k, v in batch[0][0].items() if v is not None]
+        paddings = [0] * len(batch)
+        collated = {}
+        for k in keys:
+            parts = [b[0][k] for b in batch]
+            if isinstance(parts[0], torch.Tensor) and parts[0].dim() > 1:
+                width = max(t.size(-1) for t in parts)
+                if k == "decoder_input_ids":
+                    paddings = [width - t.size(-1) for t in parts]
+                parts = [torch.nn.functional.pad(t, (width - t.size(-1), 0)) for t in parts]
+            collated[k] = torch.cat(parts, dim=0)
+        outputs, stats = self.generate_fn(self.model, self.tokenizer, collated, generate_kwargs)
+        per_row = stats.get("generated_tokens_per_sample", [])
+        row = 0
+        for (_, req, work), pad in zip(batch, paddings):
+            out = outputs[row:row + work, pad:]
+            req["generated_tokens"] += sum(per_row[row:row + work])
+            row += work
+            if req["result"] is not None and req["result"].shape[1] != out.shape[1]:
+                # parts of one request decoded in different batches can stop at different lengths; the reference's
+                # torch.cat raises here (and its client retries): widen with the pad id finished rows already carry
+                width = max(req["result"].shape[1], out.shape[1])
+                fill = generate_kwargs.get("pad_token_id", getattr(self.tokenizer, "pad_id", 0))
+                req["result"] = torch.nn.functional.pad(req["result"], (0, width - req["result"].shape[1]), value=fill)
+                out = torch.nn.functional.pad(out, (0, width - out.shape[1]), value=fill)
+            req["result"] = out if req["result"] is None else torch.cat((req["result"], out), dim=0)
+            req["work_done"] += work
+            req["elapsed_seconds"] += stats.get("elapsed_seconds", 0.0)
+            if req["work_done"] >= req["total_work"]:
+                secs, toks = req["elapsed_seconds"], req["generated_tokens"]
+                req["result"] = {"output": req["result"],
+                                 "stats": {"generated_tokens": toks, "elapsed_seconds": secs,
+                                           "tokens_per_second": toks / secs if secs > 0 else 0.0}}
+                req["done"] = True
+        return row
+
+    def drain(self) -> int:
+        """Run batches until nothing is queued; returns how many batches ran."""
+        n = 0
+        while self.step():
+            n += 1
+        return n
