@@ -15,8 +15,9 @@ Besides the contract fields the JSON line carries
                 measured decode time per token step);
   cpu_baseline  the CPU oracle (a port, kind "port") on a bounded sample of the same workload;
   aux           config 1 (osuT5-small, 1 chunk, 128 tokens: GPU and CPU port), config 3 (T5 + DiT-S 100-step DDPM
-                refine of all 32 chunks as one denoiser batch: diffusion steps/s per chunk, end-to-end chunks/s), the
-                end-to-end rate through `model_generate` including H2D / D2H, per-stage milliseconds.
+                refine of all 32 chunks as one denoiser batch: diffusion steps/s per chunk, end-to-end chunks/s), config 5
+                (osuT5-large / base over 32 three-minute songs with resident cross K/V, bf16 and e4m3; DiT-B), each with
+                its own roofline_step, the end-to-end rate through `model_generate` including H2D / D2H, per-stage ms.
 
 Contract: python bench.py --gpus N --steps K --warmup W ; for N > 1 launched by torch.distributed.run,
 one rank per GPU.  Rank 0 prints ONE JSON line.
@@ -39,6 +40,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6.3 TB/s achievable
 F32_MFMA_PEAK_TF = 157.3  # exact-f32 MFMA (= fp32 vector) peak, same guide
+BF16_MFMA_PEAK_TF = 2500.0  # dense bf16 MFMA peak, same guide
 SRC_FRAMES, N_SAMPLES = 1251, 160000
 
 
@@ -54,6 +56,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dit", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip config 1 / end-to-end / in-situ passes")
+    ap.add_argument("--no-config5", action="store_true", help="skip the long-song (osuT5-large, 3 min songs) and DiT-B aux lines")
     return ap.parse_args()
 
 
@@ -303,9 +306,31 @@ def main():
             "batched": {"chunks_per_gpu": B, "denoiser_batch": 2 * B, "ms_per_100_steps": round(dt_all * 1e3, 2),
                         "steps_per_s_per_chunk": round(100 * B / dt_all, 1),
                         "tflops": round(flops / dt_all / 1e12, 1), "frac_of_f32_mfma_peak": round(flops / dt_all / 1e12 / F32_MFMA_PEAK_TF, 3),
+                        "frac_of_bf16_pipe": round(3 * flops / dt_all / 1e12 / BF16_MFMA_PEAK_TF, 4),
+                        "frac_note": "the big GEMMs run as three bf16 MFMA passes (bf16 x 3): the pipe they occupy is the bf16 "
+                                     "one, so the honest fraction is 3 x fp32-equivalent flops / 2500 TFLOP/s",
                         "coords_all_gather": bool(use_dist)},
         }
         aux["diffusion_steps_per_s_per_chunk"] = aux["diffusion"]["batched"]["steps_per_s_per_chunk"]
+        if not args.no_config5 and rank == 0:
+            # BASELINE configs[4]: DiT-B (osu_diffusion/utils/models.py:392), the same 32 chunks as one denoiser batch
+            db, hb, nb = DIT_PRESETS["DiT-B"]
+            dit_b = DiTHIP(random_dit_state_dict(db, hb, seed=0), db, hb, nb, device=dev)
+
+            def dit_b_stage():
+                kw = dict(c=c, y=y, cfg_scale=1.0, attn_mask=BandMask(Tq, 128))
+                return diff.p_sample_loop(dit_b.forward_with_cfg, z.shape, z, model_kwargs=kw, step_noise=torch.randn(100, *z.shape, device=dev))
+            dt_b = timed(dit_b_stage, 1)
+            fl_b = dit_flops_per_step(db, hb, 2 * B, Tq) * 100
+            aux["config5_dit_b"] = {
+                "dit": "DiT-B fp32 semantics (big GEMMs bf16 x 3 on the matrix cores), Tq=128, 100-step DDPM, one replayed hipGraph",
+                "chunks": B, "denoiser_batch": 2 * B, "ms_per_100_steps": round(dt_b * 1e3, 2),
+                "steps_per_s_per_chunk": round(100 * B / dt_b, 1),
+                "roofline_step": {"bound": "mfma", "alg_flops_per_step": fl_b / 100, "achieved": round(fl_b / dt_b / 1e12, 1),
+                                  "unit": "TFLOP/s", "peak": BF16_MFMA_PEAK_TF,
+                                  "frac": round(3 * fl_b / dt_b / 1e12 / BF16_MFMA_PEAK_TF, 4),
+                                  "how": "fp32-equivalent flops x 3 (three bf16 MFMA passes per product) / dense bf16 peak"}}
+            del dit_b
         # configs[2] end to end: T5 path + diffusion refine of the same chunks, whole job
         aux["config3_end_to_end"] = {"chunks": world * B, "seconds": round(ms_per_step / 1e3 + dt_all, 4),
                                      "chunks_per_s": round(world * B / (ms_per_step / 1e3 + dt_all), 2),
@@ -355,7 +380,9 @@ def main():
     roofline = {
         "bound": "hbm", "kernel": "dec_cross_attn_q_kernel (decode cross-attention over the encoder K/V incl. its query projection)",
         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-        "traffic": None,   # PMC FETCH_SIZE/WRITE_SIZE need rocprofv3: profiles/r02_pmc_* hold the counter runs
+        "traffic": None,   # PMC FETCH_SIZE/WRITE_SIZE need rocprofv3 around the process: not measurable from inside this run
+        "traffic_source": "profiles/r03_pmc_hbm_traffic.txt (rocprofv3 --pmc pass of this command, builder-run): fetch / "
+                          "algorithmic bytes of this kernel ~1.0",
         "how": ("in situ: mean (last workgroup end - first workgroup start) over the launches of one extra decode pass, "
                 "device wall clock; the other chain's kernels run beside it" if in_situ_us else "stand-alone probe"),
         "rows_per_launch": use_rows, "alg_bytes_per_launch": use_rows * bytes_per_row, "us_per_launch": round(use_us, 2),
@@ -451,6 +478,21 @@ def main():
                                       "mel+encoder+decode (BASELINE configs[0])",
                           "gpu_tokens_per_s": round(128 / dt1, 1), "gpu_ms": round(dt1 * 1e3, 2)}
         del m1
+
+    # ---- BASELINE configs[4]: whole 3-minute songs, KV-cached, through the window scheduler (tools/long_song_bench.py) ----
+    if not args.no_extras and not args.no_config5:
+        try:
+            import importlib.util
+            spec = importlib.util.spec_from_file_location("long_song_bench", os.path.join(ROOT, "tools", "long_song_bench.py"))
+            lsb = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(lsb)
+            aux["config5_long_songs"] = {
+                "large": lsb.run("large", songs=32, windows=18, fp8_kv=(False, True), device=str(dev)),
+                "base": lsb.run("base", songs=32, windows=18, fp8_kv=(False,), device=str(dev)),
+                "note": "32 songs x 18 windows (3 min each): every window encoded up front, its cross K/V resident in HBM, wave w "
+                        "decodes window w of all songs; window w's prompt carries the last 32 tokens of window w-1"}
+        except Exception as e:   # an auxiliary figure must never cost the bench line
+            print(f"config 5 long-song pass failed: {e!r}", file=sys.stderr)
 
     cpu = None
     if not args.no_cpu_baseline and world == 1:   # the CPU port is timed on rank 0 at N=1 only
