@@ -27,6 +27,7 @@ from typing import Callable, Optional
 import torch
 
 from .server import _build_generation_stats, build_sampling
+from .t5_engine import HostStager
 
 
 @dataclasses.dataclass
@@ -66,14 +67,29 @@ class SequentialWindowScheduler:
     def encode_all(self, jobs: list[SongJob]):
         """-> per job a tensor [n_dec_layers, 2, n_windows, H, L, 64] of resident cross-attention K/V."""
         eng = self.engine
-        flat = torch.cat([j.frames for j in jobs], 0).to(eng.device, torch.float32)
+        flat = torch.cat([j.frames for j in jobs], 0)
         row_bias = self._row_bias(jobs)
         parts = []
+        on_gpu = torch.device(eng.device).type == "cuda"     # (CPU stand-in engines of the host tests take the plain path)
+        stager = HostStager(eng.device) if on_gpu else None
+        eb = self.encode_batch
+
+        def stage(a):
+            part = flat[a:a + eb]
+            return stager.stage(part, torch.float32) if on_gpu else (part.to(eng.device, torch.float32), None)
+        nxt = stage(0)                                        # batch a + 1 crosses PCIe while batch a is encoded
         eng._enter()
         with eng.on_stream():
-            for a in range(0, flat.shape[0], self.encode_batch):
-                rb = None if row_bias is None else row_bias[a:a + self.encode_batch]
-                parts.append(eng.cross_kv(eng.encode_mel(eng.mel(flat[a:a + self.encode_batch]), row_bias=rb)))
+            for a in range(0, flat.shape[0], eb):
+                cur, ev = nxt
+                if a + eb < flat.shape[0]:
+                    nxt = stage(a + eb)
+                if ev is not None:
+                    eng.stream.wait_event(ev)
+                rb = None if row_bias is None else row_bias[a:a + eb]
+                parts.append(eng.cross_kv(eng.encode_mel(eng.mel(cur), row_bias=rb)))
+                if on_gpu:
+                    cur.record_stream(eng.stream)
                 self.stats["encode_calls"] += 1
             kv = torch.cat(parts, 2) if len(parts) > 1 else parts[0]
         eng._leave()

@@ -353,27 +353,29 @@ class RequestBatcher:
         self.model, self.tokenizer, self.max_batch_size = model, tokenizer, int(max_batch_size)
         self.generate_fn = generate_fn or model_generate
         self.grouped_requests: dict = {}
+        self.prefetch = True          # start the next batch's H2D before this batch decodes (HIP engine only)
+        self._staged, self._stager = None, None
 
     def submit(self, model_kwargs: dict, generate_kwargs: dict) -> dict:
         """Queue one request (what `_client_handler` does on `conn.recv()`, :297-322); returns its record, whose
         'result' is filled by `step` once 'work_done' == 'total_work'."""
-        record = dict(model_kwargs=model_kwargs, total_work=int(model_kwargs["inputs"].shape[0]), work_done=0, result=None,
+        record = dict(model_kwargs=model_kwargs, total_work=int(model_kwargs["inputs"].shape[0]), work_done=0, work_taken=0, result=None,
                       generated_tokens=0, elapsed_seconds=0.0, done=False)
         self.grouped_requests.setdefault(frozenset(generate_kwargs.items()), []).append(record)
         return record
 
     @property
     def pending(self) -> bool:
-        return bool(self.grouped_requests)
+        return bool(self.grouped_requests) or self._staged is not None
 
     @staticmethod
     def _cut(model_kwargs: dict, start: int, length: int) -> dict:
         return {k: v[start:start + length] if isinstance(v, torch.Tensor) else v for k, v in model_kwargs.items()}
 
-    def step(self) -> int:
-        """One batch of the first group through `model_generate`; returns the number of rows it held (0: nothing queued)."""
+    def _take_batch(self):
+        """-> (generate kwargs, [(cut model_kwargs, request, rows)]) of the next batch, or None"""
         if not self.grouped_requests:
-            return 0
+            return None
         key = next(iter(self.grouped_requests))
         requests = self.grouped_requests[key]
         generate_kwargs = dict(key)
@@ -385,15 +387,18 @@ class RequestBatcher:
         batch = []
         while room > 0 and requests:
             req = requests.pop(0)
-            left = req["total_work"] - req["work_done"]
-            work = min(left, room)
-            batch.append((self._cut(req["model_kwargs"], req["work_done"], work), req, work))
+            left = req["total_work"] - req["work_taken"]       # rows not yet handed to a batch (the batch before this one
+            work = min(left, room)                              # may still be decoding: `work_done` lags behind)
+            batch.append((self._cut(req["model_kwargs"], req["work_taken"], work), req, work))
+            req["work_taken"] += work
             room -= work
             if left > work:
                 requests.insert(0, req)            # the rest of it leads the next batch
         if not requests:
             del self.grouped_requests[key]
+        return generate_kwargs, batch
 
+    def _collate(self, batch):
         keys = [k for k, v in batch[0][0].items() if v is not None]
         paddings = [0] * len(batch)
         collated = {}
@@ -405,6 +410,36 @@ class RequestBatcher:
                     paddings = [width - t.size(-1) for t in parts]
                 parts = [torch.nn.functional.pad(t, (width - t.size(-1), 0)) for t in parts]
             collated[k] = torch.cat(parts, dim=0)
+        return collated, paddings
+
+    def _stage(self, taken):
+        """collate a taken batch and start the H2D copy of its audio (pinned buffer, copy stream): by the time the batch
+        before it has decoded, the audio sits in HBM"""
+        if taken is None:
+            return None
+        generate_kwargs, batch = taken
+        collated, paddings = self._collate(batch)
+        ev = None
+        engine = getattr(self.model, "engine", None)
+        if self.prefetch and engine is not None and isinstance(getattr(engine, "device", None), torch.device) \
+                and engine.device.type == "cuda":
+            if self._stager is None:
+                from .t5_engine import HostStager
+                self._stager = HostStager(engine.device)
+            collated["inputs"], ev = self._stager.stage(collated["inputs"], torch.float32)
+        return generate_kwargs, batch, collated, paddings, ev
+
+    def step(self) -> int:
+        """One batch of the first group through `model_generate`; returns the number of rows it held (0: nothing queued).
+        The batch AFTER it is taken and its audio sent towards the device before this one starts decoding."""
+        cur = self._staged if self._staged is not None else self._stage(self._take_batch())
+        self._staged = None
+        if cur is None:
+            return 0
+        generate_kwargs, batch, collated, paddings, ev = cur
+        self._staged = self._stage(self._take_batch())
+        if ev is not None:
+            torch.cuda.current_stream(collated["inputs"].device).wait_event(ev)
         outputs, stats = self.generate_fn(self.model, self.tokenizer, collated, generate_kwargs)
         per_row = stats.get("generated_tokens_per_sample", [])
         row = 0

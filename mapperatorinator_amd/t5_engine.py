@@ -171,6 +171,31 @@ class PackedT5:
         return sum(t.numel() * t.element_size() for t in self._keep)
 
 
+class HostStager:
+    """Host -> HBM copies that overlap the kernels of the batch before: the host tensor goes through a pinned buffer and
+    a copy stream of its own, the consumer's stream waits on the returned event (nothing overlapped the H2D
+    of batch i + 1 with the decode of batch i).  Used by the window scheduler's encode loop and by RequestBatcher."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.stream = torch.cuda.Stream(self.device)
+        self._live = []                               # (event, pinned buffer): the buffer outlives its copy
+
+    def stage(self, t: torch.Tensor, dtype=None):
+        """-> (device tensor, event or None).  Returns at once; device tensors pass through."""
+        if t.device.type == "cuda":
+            return (t if dtype is None else t.to(dtype)), None
+        self._live = [(e, b) for e, b in self._live if not e.query()]
+        pin = torch.empty(t.shape, dtype=dtype or t.dtype, pin_memory=True)
+        pin.copy_(t)
+        with torch.cuda.stream(self.stream):
+            d = pin.to(self.device, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        self._live.append((ev, pin))
+        return d, ev
+
+
 class T5Engine:
     """mel -> encoder -> cross-KV -> KV-cached AR decode on one GPU."""
 
