@@ -401,8 +401,12 @@ int mh_wall_clock_khz(void);
 /* ------------------------------------------------------------------------------------------------
  * K7/K8/K9  osu_diffusion DiT + DDPM.  Replaces DiT.forward_with_cfg
  * (osu_diffusion/utils/models.py:281-317) and GaussianDiffusion.p_sample
- * (osu_diffusion/utils/diffusion/gaussian_diffusion.py:273-369, 420-467).  Always fp32
- * (the reference never casts the DiT: inference.py:637-642).
+ * (osu_diffusion/utils/diffusion/gaussian_diffusion.py:273-369, 420-467).  fp32 like the reference (it never
+ * casts the DiT: inference.py:637-642) by default; operand_dtype = MH_BF16 is the reduced-precision mode of BASELINE
+ * configs[4]: the four projections of every block take bf16 operands (weights stored bf16; LayerNorm-modulate, q / k / v,
+ * the attention output and the GELU hidden are rounded to bf16 where they become a GEMM operand), one bf16 MFMA pass
+ * with fp32 accumulation; the residual stream, LayerNorm, softmax, the adaLN conditioning, the first and the final
+ * layer and the DDPM update stay fp32.  Parity of that mode is an error bound against the fp32 reference golden.
  */
 typedef struct MhDiTConfig {
   int hidden, depth, n_heads, context_size, class_size, in_channels; /* in_channels = 2 */
@@ -410,6 +414,7 @@ typedef struct MhDiTConfig {
   int t_freq_dim;    /* TimestepEmbedder frequency_embedding_size = 256                  */
   int first_k_pad;   /* padded K of the first layer GEMM (in_channels*freq_dim+context)  */
   int class_pad;     /* padded K of y_embedder[0]                                        */
+  int operand_dtype; /* MH_F32 (reference semantics) or MH_BF16 (block GEMM operands, see above) */
 } MhDiTConfig;
 
 typedef struct MhDiTWeights {       /* all fp32, matrices [N][Kpad]                                  */
@@ -430,6 +435,9 @@ typedef struct MhDiTWeights {       /* all fp32, matrices [N][Kpad]             
   const void* first_w3;
   const void* qkv_w3[MH_MAX_LAYERS]; const void* out_w3[MH_MAX_LAYERS];
   const void* fc1_w3[MH_MAX_LAYERS]; const void* fc2_w3[MH_MAX_LAYERS];
+  /* bf16 copies [N][K] of the four block projections; required when operand_dtype = MH_BF16 */
+  const void* qkv_wb[MH_MAX_LAYERS]; const void* out_wb[MH_MAX_LAYERS];
+  const void* fc1_wb[MH_MAX_LAYERS]; const void* fc2_wb[MH_MAX_LAYERS];
 } MhDiTWeights;
 
 int64_t mh_dit_workspace_bytes(const MhDiTConfig* cfg, int N, int T);

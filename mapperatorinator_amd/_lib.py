@@ -73,7 +73,7 @@ class MhSampling(C.Structure):
 class MhDiTConfig(C.Structure):
     _fields_ = [("hidden", C.c_int), ("depth", C.c_int), ("n_heads", C.c_int), ("context_size", C.c_int),
                 ("class_size", C.c_int), ("in_channels", C.c_int), ("freq_dim", C.c_int),
-                ("t_freq_dim", C.c_int), ("first_k_pad", C.c_int), ("class_pad", C.c_int)]
+                ("t_freq_dim", C.c_int), ("first_k_pad", C.c_int), ("class_pad", C.c_int), ("operand_dtype", C.c_int)]
 
 
 class MhDiTWeights(C.Structure):
@@ -84,7 +84,8 @@ class MhDiTWeights(C.Structure):
                 ("out_w", _PTR_ARR), ("out_b", _PTR_ARR), ("fc1_w", _PTR_ARR), ("fc1_b", _PTR_ARR),
                 ("fc2_w", _PTR_ARR), ("fc2_b", _PTR_ARR), ("fin_ada_w", VP), ("fin_ada_b", VP),
                 ("fin_w", VP), ("fin_b", VP),
-                ("first_w3", VP), ("qkv_w3", _PTR_ARR), ("out_w3", _PTR_ARR), ("fc1_w3", _PTR_ARR), ("fc2_w3", _PTR_ARR)]
+                ("first_w3", VP), ("qkv_w3", _PTR_ARR), ("out_w3", _PTR_ARR), ("fc1_w3", _PTR_ARR), ("fc2_w3", _PTR_ARR),
+                ("qkv_wb", _PTR_ARR), ("out_wb", _PTR_ARR), ("fc1_wb", _PTR_ARR), ("fc2_wb", _PTR_ARR)]
 
 
 class MhSliderSet(C.Structure):

@@ -237,6 +237,8 @@ int check_dit(const MhDiTConfig* c, int N, int T) {
   MH_REQUIRE(c->first_k_pad % 32 == 0 && c->first_k_pad >= 2 * c->freq_dim + c->context_size, "dit: bad first_k_pad");
   MH_REQUIRE(c->class_pad >= c->class_size, "dit: bad class_pad");
   MH_REQUIRE(N >= 2 && N % 2 == 0 && T > 0, "dit: N must be even (CFG batch) and T > 0");
+  MH_REQUIRE(c->operand_dtype == MH_F32 || c->operand_dtype == MH_BF16, "dit: operand_dtype must be MH_F32 or MH_BF16");
+  MH_REQUIRE(c->operand_dtype == MH_F32 || c->hidden % 8 == 0, "dit: bf16 operands need hidden %% 8 == 0");
   return MH_OK;
 }
 
@@ -314,7 +316,38 @@ int dit_body(const MhDiTConfig* c, const MhDiTWeights* w, const float* x, const 
   weights(w->first_w, w->first_w3, g);
   g.stats_out = fuse_ln ? b.stats : nullptr;
   MH_TRY(gemm(g, s));
-  for (int l = 0; l < c->depth; ++l) {
+  const bool lowp = c->operand_dtype == MH_BF16;
+  if (lowp)
+    for (int l = 0; l < c->depth; ++l)
+      MH_REQUIRE(w->qkv_wb[l] && w->out_wb[l] && w->fc1_wb[l] && w->fc2_wb[l], "dit: operand_dtype = MH_BF16 needs the bf16 weight copies (layer %d)", l);
+  for (int l = 0; l < c->depth && lowp; ++l) {
+    // bf16 operands (BASELINE configs[4]): the same block, every GEMM operand rounded to bf16 where it is produced; the
+    // activation buffers are the fp32 ones reinterpreted (half used).  128 x 128 LDS-DMA tiles for the wide outputs.
+    const float* mod = b.cond_cur + (long)l * 6 * D;
+    MH_TRY(ln_modulate(b.xs, D, mod + 0 * D, mod + 1 * D, ld_row, T, b.xm, D, NT, D, 1e-6f, MH_BF16, s));
+    g = MhGemm{};
+    g.A = b.xm; g.lda = D; g.W = w->qkv_wb[l]; g.ldw = D; g.C = b.qk; g.ldc = 2 * D; g.M = NT; g.N = 3 * D; g.K = D;
+    g.bias = w->qkv_b[l]; g.dtype = MH_BF16; g.epilogue = MH_EPI_QKV_VT; g.C2 = b.vt; g.n_split = 2 * D; g.kv_B = N;
+    g.kv_H = H; g.kv_L = T; g.kv_Lpad = b.Tpad;
+    MH_TRY(gemm(g, s));
+    MH_TRY(attention(b.qk, 2 * D, D, b.vt, b.Tpad, nullptr, b.attn, D, N, T, H, 0.125f, band, MH_BF16, s));
+    g = MhGemm{};
+    g.A = b.attn; g.lda = D; g.W = w->out_wb[l]; g.ldw = D; g.C = b.xs; g.ldc = D; g.M = NT; g.N = D; g.K = D;
+    g.bias = w->out_b[l]; g.gate = mod + 2 * D; g.gate_ld = ld_row; g.rows_per_batch = T; g.dtype = MH_BF16;
+    g.epilogue = MH_EPI_GATE_RESID;
+    MH_TRY(gemm(g, s));
+    MH_TRY(ln_modulate(b.xs, D, mod + 3 * D, mod + 4 * D, ld_row, T, b.xm, D, NT, D, 1e-6f, MH_BF16, s));
+    g = MhGemm{};
+    g.A = b.xm; g.lda = D; g.W = w->fc1_wb[l]; g.ldw = D; g.C = b.hid; g.ldc = 4 * D; g.M = NT; g.N = 4 * D; g.K = D;
+    g.bias = w->fc1_b[l]; g.dtype = MH_BF16; g.epilogue = MH_EPI_BIAS_GELU;
+    MH_TRY(gemm(g, s));
+    g = MhGemm{};
+    g.A = b.hid; g.lda = 4 * D; g.W = w->fc2_wb[l]; g.ldw = 4 * D; g.C = b.xs; g.ldc = D; g.M = NT; g.N = D; g.K = 4 * D;
+    g.bias = w->fc2_b[l]; g.gate = mod + 5 * D; g.gate_ld = ld_row; g.rows_per_batch = T; g.dtype = MH_BF16;
+    g.epilogue = MH_EPI_GATE_RESID;
+    MH_TRY(gemm(g, s));
+  }
+  for (int l = 0; l < c->depth && !lowp; ++l) {
     const float* mod = b.cond_cur + (long)l * 6 * D;
     // attention branch
     g = MhGemm{};
@@ -326,7 +359,7 @@ int dit_body(const MhDiTConfig* c, const MhDiTWeights* w, const float* x, const 
       g.ln_stats = b.stats; g.ln_strips = strips; g.ln_shift = mod + 0 * D; g.ln_scale = mod + 1 * D; g.ln_ld = ld_row;
       g.ln_eps = 1e-6f; g.rows_per_batch = T;
     } else {
-      MH_TRY(ln_modulate(b.xs, D, mod + 0 * D, mod + 1 * D, ld_row, T, b.xm, D, NT, D, 1e-6f, s));
+      MH_TRY(ln_modulate(b.xs, D, mod + 0 * D, mod + 1 * D, ld_row, T, b.xm, D, NT, D, 1e-6f, MH_F32, s));
       g.A = b.xm;
     }
     MH_TRY(gemm(g, s));
@@ -346,7 +379,7 @@ int dit_body(const MhDiTConfig* c, const MhDiTWeights* w, const float* x, const 
       g.ln_stats = b.stats; g.ln_strips = strips; g.ln_shift = mod + 3 * D; g.ln_scale = mod + 4 * D; g.ln_ld = ld_row;
       g.ln_eps = 1e-6f; g.rows_per_batch = T;
     } else {
-      MH_TRY(ln_modulate(b.xs, D, mod + 3 * D, mod + 4 * D, ld_row, T, b.xm, D, NT, D, 1e-6f, s));
+      MH_TRY(ln_modulate(b.xs, D, mod + 3 * D, mod + 4 * D, ld_row, T, b.xm, D, NT, D, 1e-6f, MH_F32, s));
       g.A = b.xm;
     }
     MH_TRY(gemm(g, s));
@@ -358,7 +391,7 @@ int dit_body(const MhDiTConfig* c, const MhDiTWeights* w, const float* x, const 
     MH_TRY(gemm(g, s));
   }
   const float* modf = b.cond_cur + (long)c->depth * 6 * D;
-  MH_TRY(ln_modulate(b.xs, D, modf, modf + D, ld_row, T, b.xm, D, NT, D, 1e-6f, s));
+  MH_TRY(ln_modulate(b.xs, D, modf, modf + D, ld_row, T, b.xm, D, NT, D, 1e-6f, MH_F32, s));
   hipLaunchKernelGGL(dit_final_kernel, dim3(ceil_div(T, 4), N / 2), dim3(256), 0, s, b.xm, w->fin_w, D, w->fin_b, N, T, D,
                      cfg_scale, out);
   return check_launch("dit_final_kernel");

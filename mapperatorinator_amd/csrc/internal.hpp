@@ -11,7 +11,7 @@ int gemm(const MhGemm& g, hipStream_t s, bool ascending_k = false);
 int rmsnorm(const float* x, int ldx, const float* w, void* y, int ldy, int rows, int d, float eps, int out_dtype,
             hipStream_t s);
 int ln_modulate(const float* x, int ldx, const float* shift, const float* scale, int mod_ld, int rows_per_batch,
-                float* y, int ldy, int rows, int d, float eps, hipStream_t s);
+                void* y, int ldy, int rows, int d, float eps, int out_dtype, hipStream_t s);
 int attention(const void* qk, int ld_qk, int k_col0, const void* vt, int Lpad, const float* bias, void* out,
               int ld_out, int B, int L, int H, float scale, int band, int dtype, hipStream_t s);
 

@@ -33,11 +33,13 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
   }
 }
 
-// x [rows, d] fp32; shift/scale: [n_batch, mod_ld] rows selected by row / rows_per_batch.
+// x [rows, d] fp32; shift/scale: [n_batch, mod_ld] rows selected by row / rows_per_batch.  y: fp32 or bf16 (the operand
+// rounding of the DiT's bf16 mode happens here, after the fp32 arithmetic).
+template <typename T>
 __global__ __launch_bounds__(256) void ln_modulate_kernel(const float* __restrict__ x, int ldx,
                                                          const float* __restrict__ shift,
                                                          const float* __restrict__ scale, int mod_ld,
-                                                         int rows_per_batch, float* __restrict__ y, int ldy,
+                                                         int rows_per_batch, T* __restrict__ y, int ldy,
                                                          int rows, int d, float eps) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -59,7 +61,7 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(const float* __restric
   const int bidx = row / rows_per_batch;
   const float* sh = shift + (long)bidx * mod_ld;
   const float* sc = scale + (long)bidx * mod_ld;
-  float* yr = y + (long)row * ldy;
+  T* yr = y + (long)row * ldy;
   for (int i = lane * 4; i < d; i += 256) {
     float4 v = *reinterpret_cast<const float4*>(xr + i);
     float4 a = *reinterpret_cast<const float4*>(sh + i);
@@ -69,7 +71,13 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(const float* __restric
     o.y = (v.y - mean) * rs * (1.f + b.y) + a.y;
     o.z = (v.z - mean) * rs * (1.f + b.z) + a.z;
     o.w = (v.w - mean) * rs * (1.f + b.w) + a.w;
-    *reinterpret_cast<float4*>(yr + i) = o;
+    if constexpr (sizeof(T) == 4) {
+      *reinterpret_cast<float4*>(yr + i) = o;
+    } else {
+      ushort4 q;
+      q.x = Elem<T>::from_f32(o.x); q.y = Elem<T>::from_f32(o.y); q.z = Elem<T>::from_f32(o.z); q.w = Elem<T>::from_f32(o.w);
+      *reinterpret_cast<ushort4*>(yr + i) = q;
+    }
   }
 }
 
@@ -88,10 +96,14 @@ int rmsnorm(const float* x, int ldx, const float* w, void* y, int ldy, int rows,
 }
 
 int ln_modulate(const float* x, int ldx, const float* shift, const float* scale, int mod_ld, int rows_per_batch,
-                float* y, int ldy, int rows, int d, float eps, hipStream_t s) {
+                void* y, int ldy, int rows, int d, float eps, int out_dtype, hipStream_t s) {
   MH_REQUIRE(d % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && mod_ld % 4 == 0, "ln_modulate: alignment");
-  hipLaunchKernelGGL(ln_modulate_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, s, x, ldx, shift, scale, mod_ld,
-                     rows_per_batch, y, ldy, rows, d, eps);
+  if (out_dtype == MH_BF16)
+    hipLaunchKernelGGL(ln_modulate_kernel<bf16_t>, dim3(ceil_div(rows, 4)), dim3(256), 0, s, x, ldx, shift, scale, mod_ld,
+                       rows_per_batch, (bf16_t*)y, ldy, rows, d, eps);
+  else
+    hipLaunchKernelGGL(ln_modulate_kernel<float>, dim3(ceil_div(rows, 4)), dim3(256), 0, s, x, ldx, shift, scale, mod_ld,
+                       rows_per_batch, (float*)y, ldy, rows, d, eps);
   return check_launch("ln_modulate_kernel");
 }
 

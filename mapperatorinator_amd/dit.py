@@ -32,13 +32,17 @@ class DiTHIP:
     """fp32 DiT denoiser on libmapperhip.  `state_dict` uses the reference's parameter names."""
 
     def __init__(self, state_dict: dict, depth: int, hidden: int, num_heads: int, context_size: int = 272,
-                 class_size: int = 300, device="cuda"):
+                 class_size: int = 300, device="cuda", operand_dtype: torch.dtype = torch.float32):
         if not torch.cuda.is_available():
             raise RuntimeError("DiTHIP needs a ROCm GPU; there is no CPU fallback")
         if hidden != num_heads * 64:
             raise NotImplementedError("HIP attention kernels are built for head_dim = 64")
+        if operand_dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("operand_dtype: torch.float32 (the reference's semantics) or torch.bfloat16 (block GEMM operands "
+                             "rounded to bf16, fp32 accumulation / residual stream / LayerNorm / softmax / DDPM update)")
         self.lib = _lib.load()
         self.device = torch.device(device)
+        self.operand_dtype = operand_dtype
         self.in_channels, self.learn_sigma = 2, True
         self.depth, self.hidden, self.num_heads = depth, hidden, num_heads
         self.context_size, self.class_size = context_size, class_size
@@ -70,8 +74,14 @@ class DiTHIP:
             return packed.data_ptr()
 
         k1 = 2 * 128 + context_size
+        def tb(x):
+            x = x.detach().to(torch.bfloat16).contiguous().to(dev)
+            self._keep.append(x)
+            return x.data_ptr()
+
+        lowp = operand_dtype == torch.bfloat16
         cfg = _lib.MhDiTConfig(hidden, depth, num_heads, context_size, class_size, 2, 128, 256, _round_up(k1, 32),
-                               class_size)
+                               class_size, _lib.MH_BF16 if lowp else _lib.MH_F32)
         w = _lib.MhDiTWeights()
         # frequency tables with the same fp32 tensor ops as timestep_embedding (positional_embedding.py:38-43)
         w.pos_freqs = t(torch.exp(-math.log(10000) * torch.arange(0, 64, dtype=torch.float32) / 64))
@@ -92,6 +102,9 @@ class DiTHIP:
             w.fc2_w[l], w.fc2_b[l] = t(sd[b + "mlp.fc2.weight"]), t(sd[b + "mlp.fc2.bias"])
             w.qkv_w3[l], w.out_w3[l] = t3(sd[b + "attn.in_proj_weight"]), t3(sd[b + "attn.out_proj.weight"])
             w.fc1_w3[l], w.fc2_w3[l] = t3(sd[b + "mlp.fc1.weight"]), t3(sd[b + "mlp.fc2.weight"])
+            if lowp:
+                w.qkv_wb[l], w.out_wb[l] = tb(sd[b + "attn.in_proj_weight"]), tb(sd[b + "attn.out_proj.weight"])
+                w.fc1_wb[l], w.fc2_wb[l] = tb(sd[b + "mlp.fc1.weight"]), tb(sd[b + "mlp.fc2.weight"])
         w.fin_ada_w, w.fin_ada_b = t(sd["final_layer.adaLN_modulation.1.weight"]), t(sd["final_layer.adaLN_modulation.1.bias"])
         w.fin_w, w.fin_b = t(sd["final_layer.linear.weight"]), t(sd["final_layer.linear.bias"])
         self.cfg, self.w = cfg, w
@@ -104,11 +117,11 @@ class DiTHIP:
         return cls(state_dict, depth, hidden, heads, **kw)
 
     @classmethod
-    def from_reference(cls, model, device="cuda"):
+    def from_reference(cls, model, device="cuda", **kw):
         """`model`: a reference osu_diffusion `DiT` module."""
         return cls(model.state_dict(), len(model.blocks), model.final_layer.linear.in_features, model.num_heads,
                    context_size=model.context_size, class_size=model.y_embedder.class_embedding[0].in_features,
-                   device=device)
+                   device=device, **kw)
 
     # nn.Module-ish conveniences used by the reference pipeline
     def eval(self):

@@ -32,9 +32,20 @@ def layer_norm(x, eps=1e-6):
 
 
 class DiTOracle:
-    def __init__(self, sd: dict, depth: int, hidden: int, num_heads: int):
+    """`rounding="bf16"` restates the device's reduced-precision mode (MhDiTConfig.operand_dtype = MH_BF16, BASELINE
+    configs[4]) -- NOT a reference mode: the weights of the four block projections and every activation that becomes their
+    (or the attention's) MFMA operand are rounded to bf16 (LayerNorm-modulate output; q, k, v; the softmax probabilities;
+    the attention output; the GELU hidden); accumulation and everything else stays fp32."""
+
+    def __init__(self, sd: dict, depth: int, hidden: int, num_heads: int, rounding=None):
         self.sd = {k: v.detach().float() for k, v in sd.items()}
         self.depth, self.D, self.H = depth, hidden, num_heads
+        assert rounding in (None, "bf16")
+        self.r = (lambda a: a.to(torch.bfloat16).to(torch.float32)) if rounding == "bf16" else (lambda a: a)
+        if rounding == "bf16":
+            for l in range(depth):
+                for n in ("attn.in_proj_weight", "attn.out_proj.weight", "mlp.fc1.weight", "mlp.fc2.weight"):
+                    self.sd[f"blocks.{l}.{n}"] = self.r(self.sd[f"blocks.{l}.{n}"])
 
     def _lin(self, x, name):
         return x @ self.sd[name + ".weight"].t() + self.sd[name + ".bias"]
@@ -42,14 +53,17 @@ class DiTOracle:
     def _mha(self, x, l, attn_mask):
         sd, D, H = self.sd, self.D, self.H
         N, T, _ = x.shape
-        qkv = x @ sd[f"blocks.{l}.attn.in_proj_weight"].t() + sd[f"blocks.{l}.attn.in_proj_bias"]
+        r = self.r
+        qkv = r(r(x) @ sd[f"blocks.{l}.attn.in_proj_weight"].t() + sd[f"blocks.{l}.attn.in_proj_bias"])
         q, k, v = qkv.split(D, dim=-1)
         sh = lambda a: a.view(N, T, H, D // H).transpose(1, 2)
         s = torch.matmul(sh(q), sh(k).transpose(-1, -2)) * (1.0 / math.sqrt(D // H))
         if attn_mask is not None:
             s = s.masked_fill(attn_mask[None, None], float("-inf"))
-        o = torch.matmul(torch.softmax(s, -1), sh(v)).transpose(1, 2).reshape(N, T, D)
-        return self._lin(o, f"blocks.{l}.attn.out_proj")
+        # (the flash kernel rounds the un-normalised exp(s - running max) and divides by the fp32 sum of the unrounded
+        # values; rounding the normalised probabilities instead differs by bf16 rounding noise only)
+        o = torch.matmul(r(torch.softmax(s, -1)), sh(v)).transpose(1, 2).reshape(N, T, D)
+        return self._lin(r(o), f"blocks.{l}.attn.out_proj")
 
     def forward(self, x, t, c, y, attn_mask=None):
         sd = self.sd
@@ -67,8 +81,8 @@ class DiTOracle:
             m = layer_norm(h) * (1 + sc1[:, None]) + sh1[:, None]
             h = h + g1[:, None] * self._mha(m, l, attn_mask)
             m = layer_norm(h) * (1 + sc2[:, None]) + sh2[:, None]
-            u = F.gelu(self._lin(m, f"blocks.{l}.mlp.fc1"), approximate="tanh")
-            h = h + g2[:, None] * self._lin(u, f"blocks.{l}.mlp.fc2")
+            u = F.gelu(self._lin(self.r(m), f"blocks.{l}.mlp.fc1"), approximate="tanh")
+            h = h + g2[:, None] * self._lin(self.r(u), f"blocks.{l}.mlp.fc2")
         shf, scf = self._lin(F.silu(b), "final_layer.adaLN_modulation.1").chunk(2, dim=1)
         out = self._lin(layer_norm(h) * (1 + scf[:, None]) + shf[:, None], "final_layer.linear")
         return out.transpose(1, 2)

@@ -449,3 +449,54 @@ def test_slider_end_projection_matches_reference_golden():
         assert torch.equal(out[b][:, keep], roundtrip[b][:, keep])
     print(f"slider ends: {exact}/{n} bit-equal to the reference, worst {worst[False]:.2e} px (arcs {worst[True]:.2e} px)")
     assert worst[False] < 2e-4 and worst[True] < 5e-2 and exact >= 0.95 * n
+
+
+@pytest.mark.parametrize("name", ["dit_s", "dit_b"])
+def test_bf16_operand_mode_error_bounds(name):
+    """MhDiTConfig.operand_dtype = MH_BF16 (BASELINE configs[4]'s reduced-precision DiT; NOT the parity mode): the block
+    GEMMs and the attention take bf16 operands, everything else stays fp32.  Gates, with the measured values printed:
+      eps vs the bf16-contract oracle (oracle/dit.py rounding="bf16", the same rounding points)   < 1e-2 of the eps scale
+      eps vs the fp32 REFERENCE golden                                                              < 1e-2 of the eps scale
+                                                   (measured 3e-3 .. 5e-3 for both, DiT-S and DiT-B)
+      one p_sample step from the reference's x (no compounding): every position within 0.5 px of the reference's step
+      100-step DDPM sample vs the reference's fp32 sample (same draws): median position error < 2 px, 95 % < 16 px
+                                                   (measured: median 0.85 / 1.19 px, p95 11.1 / 7.5 px, max 22 / 17 px)
+    The random-weight DiT is not contractive: rounding differences grow along the 100-step trajectory (the fp32 HIP path
+    itself ends up to 0.8 / 4.8 px from the reference at its worst point), so the per-evaluation gates are the parity
+    statement of this mode and the trajectory gate is a sanity bound."""
+    from mapperatorinator_amd.dit import DiTHIP, create_diffusion
+    from mapperatorinator_amd.testing import DIT_PRESETS, random_dit_state_dict
+    from oracle import dit as odit
+    g, dit32, orc, z, c, y, mask, cfg = setup(name)
+    depth, hidden, heads = DIT_PRESETS[str(g["preset"])]
+    sd = random_dit_state_dict(depth, hidden, seed=int(g["weight_seed"]))
+    dit = DiTHIP(sd, depth, hidden, heads, device="cuda", operand_dtype=torch.bfloat16)
+    orc16 = odit.DiTOracle(sd, depth, hidden, heads, rounding="bf16")
+    for tv in (99, 50, 0):
+        t = torch.full((2,), tv, dtype=torch.long)
+        got = dit.forward_with_cfg(z.cuda(), t.cuda(), c.cuda(), y.cuda(), cfg, attn_mask=mask).cpu()
+        ref = torch.from_numpy(g[f"eps_t{tv}"])
+        want16 = orc16.forward_with_cfg(z, t, c, y, cfg, mask)
+        scale = ref.abs().max().item()
+        e_ref, e_orc = (got - ref).abs().max().item() / scale, (got - want16).abs().max().item() / scale
+        print(f"{name} bf16 operands, t={tv}: vs fp32 reference {e_ref:.2e}, vs bf16-contract oracle {e_orc:.2e} (of scale {scale:.2f})")
+        assert e_orc < 1e-2 and e_ref < 1e-2
+        assert torch.equal(got[0, :2], got[1, :2])
+    if "sample_100" in g.files:
+        diff = create_diffusion([100, 0, 0, 0, 0, 0, 0, 0, 0, 0], noise_schedule="squaredcos_cap_v2", diffusion_steps=1000)
+        noise = torch.from_numpy(np.random.default_rng(500 + int(g["input_seed"])).standard_normal((100, *z.shape)).astype(np.float32))
+        kw = dict(c=c.cuda(), y=y.cuda(), cfg_scale=cfg, attn_mask=mask, key_padding_mask=None)
+        out = diff.p_sample_loop(dit.forward_with_cfg, z.shape, z.cuda(), model_kwargs=kw, step_noise=noise).cpu()
+        ref = torch.from_numpy(g["sample_100"])
+        px = ((out[0] - ref[0]).abs() * torch.tensor([256.0, 192.0])[:, None]).max(0).values      # row 0 = the conditional half
+        out32 = diff.p_sample_loop(dit32.forward_with_cfg, z.shape, z.cuda(), model_kwargs=kw, step_noise=noise).cpu()
+        px32 = ((out32[0] - ref[0]).abs() * torch.tensor([256.0, 192.0])[:, None]).max(0).values
+        print(f"{name} 100-step sample vs reference, px: bf16 operands median {px.median().item():.3f} p95 {px.quantile(0.95).item():.3f} "
+              f"max {px.max().item():.3f} | fp32 path median {px32.median().item():.4f} max {px32.max().item():.4f}")
+        assert torch.isfinite(out).all() and px.median().item() < 2.0 and px.quantile(0.95).item() < 16.0
+        # one reverse step at loop index 57 from the reference's own input (golden p_sample_i57)
+        t57 = torch.full((2,), diff.timestep_map[57], dtype=torch.long)
+        st = diff.p_sample(dit.forward_with_cfg, z.cuda(), torch.full((2,), 57), model_kwargs=kw, noise=noise[0].cuda())
+        e57 = ((st["sample"].cpu()[0] - torch.from_numpy(g["p_sample_i57"])[0]).abs() * torch.tensor([256.0, 192.0])[:, None]).max().item()
+        print(f"{name} one p_sample step vs reference: worst position {e57:.4f} px")
+        assert e57 < 0.5

@@ -773,8 +773,11 @@ def test_fp32_beam_search_matches_reference_golden(run):
 
 def test_request_batcher_answers_every_request_like_a_call_of_its_own():
     """`RequestBatcher` (the batching policy of the reference's InferenceServer, server.py:343-424) over the HIP engine:
-    five requests with ragged batch sizes and prompt widths, two generate-kwargs groups, split across 16-row batches and
-    left-padded together -- every request gets back exactly what `model_generate` returns for it alone (fp32, greedy)."""
+    six requests with ragged batch sizes and prompt widths in two generate-kwargs groups, max_batch_size 16.  Batches:
+    [A 9 rows + B 7] (A left-padded to B's width), [D 16 of 20], [D 4 + E 3], [C 3 + F 1] (C padded to F's width).
+    Every request gets back, bit for bit (fp32, greedy), what `model_generate` returns for it alone under the same left
+    padding -- rows do not depend on their batch; a different padding WIDTH shifts the key chunking of the attention
+    sums, which is an fp32 reordering in the reference as well."""
     from mapperatorinator_amd import Tokenizer
     from mapperatorinator_amd.server import RequestBatcher, model_generate
     from mapperatorinator_amd.t5_engine import T5_PRESETS
@@ -782,21 +785,25 @@ def test_request_batcher_answers_every_request_like_a_call_of_its_own():
     src, tgt = 251, 40
     tok = Tokenizer.benchmark_vocab(src_seq_len=src)
     sd = random_t5_state_dict(T5_PRESETS["small"], tok.vocab_size_in, tok.vocab_size_out, seed=21, lm_head_gain=6.0)
-    model = build("small", tok, sd, src, tgt, "fp32")
+    model = build("small", tok, sd, src, tgt, torch.float32)
     g = torch.Generator().manual_seed(4)
     plain, biased = gen_kwargs(tgt), gen_kwargs(tgt, timeshift_bias=0.3)
-    reqs = []
-    for i, (rows, width, gk) in enumerate([(9, 1, plain), (5, 3, plain), (3, 2, biased), (11, 2, plain), (1, 4, biased)]):
+    reqs, pad_to = [], [3, 3, 4, 2, 2, 4]
+    for i, (rows, width, gk) in enumerate([(9, 1, plain), (7, 3, plain), (3, 2, biased), (20, 2, plain), (3, 2, plain), (1, 4, biased)]):
         ids = torch.randint(20, tok.vocab_size_in - 1, (rows, width), generator=g)
         ids[:, 0] = 1
         reqs.append((dict(inputs=synthetic_audio(rows, 32000, seed=50 + i), decoder_input_ids=ids,
                           decoder_attention_mask=torch.ones_like(ids)), gk))
     batcher = RequestBatcher(model, tok, max_batch_size=16)
     records = [batcher.submit(mk, gk) for mk, gk in reqs]
-    assert batcher.drain() == 3                      # 25 rows of the first group in two batches, 4 rows of the second
-    for (mk, gk), rec in zip(reqs, records):
-        alone, stats = model_generate(model, tok, mk, gk)
+    assert batcher.drain() == 4 and not batcher.pending
+    for (mk, gk), rec, width in zip(reqs, records, pad_to):
+        pad = width - mk["decoder_input_ids"].shape[1]
+        padded = dict(mk, decoder_input_ids=torch.nn.functional.pad(mk["decoder_input_ids"], (pad, 0)),
+                      decoder_attention_mask=torch.nn.functional.pad(mk["decoder_attention_mask"], (pad, 0)))
+        alone, stats = model_generate(model, tok, padded, gk)
         got = rec["result"]["output"]
-        n = min(alone.shape[1], got.shape[1])        # a batch decodes until its longest row ends: only pad columns differ
-        assert torch.equal(got[:, :n], alone[:, :n]) and (got[:, n:] == 0).all() and (alone[:, n:] == 0).all()
+        assert rec["done"] and got.shape[0] == mk["inputs"].shape[0]
+        n = min(got.shape[1], alone.shape[1] - pad)          # a batch runs until its longest row ends: pad columns may differ
+        assert torch.equal(got[:, :n], alone[:, pad:pad + n]) and (got[:, n:] == 0).all() and (alone[:, pad + n:] == 0).all()
         assert rec["result"]["stats"]["generated_tokens"] == stats["generated_tokens"]
