@@ -331,6 +331,24 @@ def main():
                                   "frac": round(3 * fl_b / dt_b / 1e12 / BF16_MFMA_PEAK_TF, 4),
                                   "how": "fp32-equivalent flops x 3 (three bf16 MFMA passes per product) / dense bf16 peak"}}
             del dit_b
+            # the reduced-precision mode configs[4] names (MhDiTConfig.operand_dtype = MH_BF16): block GEMMs and attention on
+            # bf16 operands, one MFMA pass; parity = error bounds vs the fp32 reference golden (tests/test_gpu_dit.py)
+            lowp = {}
+            for pname in ("DiT-S", "DiT-B"):
+                dd, hh, nn = DIT_PRESETS[pname]
+                dl = DiTHIP(random_dit_state_dict(dd, hh, seed=0), dd, hh, nn, device=dev, operand_dtype=torch.bfloat16)
+
+                def lowp_stage():
+                    kw = dict(c=c, y=y, cfg_scale=1.0, attn_mask=BandMask(Tq, 128))
+                    return diff.p_sample_loop(dl.forward_with_cfg, z.shape, z, model_kwargs=kw, step_noise=torch.randn(100, *z.shape, device=dev))
+                dtl = timed(lowp_stage, 2)
+                fl = dit_flops_per_step(dd, hh, 2 * B, Tq) * 100
+                lowp[pname] = {"ms_per_100_steps": round(dtl * 1e3, 2), "steps_per_s_per_chunk": round(100 * B / dtl, 1),
+                               "tflops": round(fl / dtl / 1e12, 1), "frac_of_bf16_mfma_peak": round(fl / dtl / 1e12 / BF16_MFMA_PEAK_TF, 4)}
+                del dl
+            aux["config5_dit_bf16_operands"] = dict(lowp, chunks=B, note="32 chunks x 100 DDPM steps, block GEMMs + attention on bf16 operands "
+                                                    "(fp32 residual stream / LayerNorm / softmax / DDPM update); NOT the parity mode: eps within "
+                                                    "5e-3 of scale and one p_sample step within 0.03 px of the fp32 reference golden")
         # configs[2] end to end: T5 path + diffusion refine of the same chunks, whole job
         aux["config3_end_to_end"] = {"chunks": world * B, "seconds": round(ms_per_step / 1e3 + dt_all, 4),
                                      "chunks_per_s": round(world * B / (ms_per_step / 1e3 + dt_all), 2),

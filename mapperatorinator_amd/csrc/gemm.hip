@@ -447,6 +447,17 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmP p) {
       bias_v[j] = p.bias[c < p.N ? c : p.N - 1];
     }
   }
+  // The bias goes into the accumulators HERE and the result is pinned: left inside the guarded per-element stores below,
+  // hipcc sinks the add -- and with it the wait for the bias load -- behind the stores, and since the load counter also
+  // counts stores every element then waits for the store before it (one write round trip per element: 64 per lane on
+  // the 128 x 128 tile).  The same holds for the old C / gate values of a row block.
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      acc[i][j][0] += bias_v[j]; acc[i][j][1] += bias_v[j]; acc[i][j][2] += bias_v[j]; acc[i][j][3] += bias_v[j];
+      asm volatile("" : "+v"(acc[i][j]));
+    }
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
     f32x4_t oldv[NI], gv[NI];
@@ -484,6 +495,13 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmP p) {
         }
       }
     }
+    if constexpr (kReadsC) {
+#pragma unroll
+      for (int j = 0; j < NI; ++j) asm volatile("" : "+v"(oldv[j]), "+v"(gv[j]));   // loaded before the first store of the block
+    } else if constexpr (kPos) {
+#pragma unroll
+      for (int j = 0; j < NI; ++j) asm volatile("" : "+v"(gv[j]));
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = erow0 + i * 16 + r;
@@ -497,13 +515,13 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmP p) {
       } else {
 #pragma unroll
         for (int j = 0; j < NI; ++j)
-          epilogue_store<T, EPI>(p, row, ecol0 + j * 16, acc[i][j][r] + bias_v[j], 0.f, kReadsC ? oldv[j][r] : 0.f,
+          epilogue_store<T, EPI>(p, row, ecol0 + j * 16, acc[i][j][r], 0.f, kReadsC ? oldv[j][r] : 0.f,
                                  (kReadsC || kPos) ? gv[j][r] : 0.f);
         if constexpr (EPI == MH_EPI_STORE_F32 || EPI == MH_EPI_GATE_RESID) {
           if (p.stats_out) {   // block-uniform: row sums of the values just stored, one (sum, sum of squares) per 16 columns
 #pragma unroll
             for (int j = 0; j < NI; ++j) {
-              const float lin = acc[i][j][r] + bias_v[j];
+              const float lin = acc[i][j][r];
               float o = (EPI == MH_EPI_GATE_RESID) ? oldv[j][r] + gv[j][r] * lin : lin;
               o = (row < p.M && ecol0 + j * 16 < p.N) ? o : 0.f;
               const float s1 = group_sum<16>(o), s2 = group_sum<16>(o * o);
@@ -517,6 +535,306 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmP p) {
       }
     }
   }
+}
+
+// ---- G3: bf16, 256 x 128 tile, 8 waves as 4(M) x 2(N), THREE LDS stages filled by LDS-DMA two K steps ahead --------------
+// The two-stage kernel above waits for the whole next stage at the end of every K step (vmcnt(0) + barrier): with the
+// 0.2 us of MFMA work a step holds, a step costs one loaded memory round trip (~2.2 us measured on the encoder GEMMs, two
+// workgroups per CU: MfmaUtil 17-28 %).  Here the DMA of step kt + 2 is issued before step kt is multiplied and the wait
+// at the end of step kt only covers step kt + 1 (counted vmcnt: the 6 newest DMA instructions of this wave stay in
+// flight), so two stages (96 KB) are always on their way.  One workgroup per CU (144 KB of LDS), two waves per SIMD:
+// one wave's ds_reads run under the other's MFMAs.  Same XOR-swizzled 128-byte rows, same fragment reads, same
+// epilogues as the 128 x 128 LDS-DMA form.
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_glds3_kernel(GemmP p) {
+  using T = bf16_t;
+  constexpr int BM = 256, BN = 128, BK = 64, KM = 32, NST = 3;
+  constexpr int kRowStride = 128, kStage = (BM + BN) * kRowStride;
+  constexpr int WM = 64, WN = 64, MI = 4, NI = 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wr = wid >> 1, wc = wid & 1;
+
+  const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
+  const int nwg = nbm * nbn;
+  int bid = blockIdx.x;
+  {   // block b runs on XCD b % 8: give every XCD a contiguous range of the work list (bijective)
+    const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  int bm, bn;
+  {   // groups of GM row panels (<= ~2.5 MB of A), inside a group the row panel runs fastest: W panels are fetched once per group
+    const long panel_bytes = (long)BM * p.K * (long)sizeof(T);
+    int GM = (int)((5L << 19) / (panel_bytes > 0 ? panel_bytes : 1));
+    GM = GM < 2 ? 2 : (GM > 16 ? 16 : GM);
+    const int per_group = GM * nbn;
+    const int grp = bid / per_group, rem = bid - grp * per_group;
+    const int gm = (nbm - grp * GM) < GM ? (nbm - grp * GM) : GM;
+    bn = rem / gm;
+    bm = grp * GM + (rem - bn * gm);
+  }
+  const int m0 = bm * BM, n0 = bn * BN;
+  const int nk = (p.K + BK - 1) / BK;
+
+  // K tile kt of both operands -> stage st: 4 (A) + 2 (B) wave instructions of 8 rows x 128 bytes.  K % 64 == 0 (dispatch
+  // condition): no K tail, so a step is six loads from six per-lane pointers that advance by 128 bytes -- no scalar
+  // loads and no branches inside the K loop (either would make hipcc's counter bookkeeping fall back to lgkmcnt(0) waits
+  // in front of the MFMAs, serialising the fragment reads below with them).
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  const char* srcp[6];
+  {
+    const int r8 = lane >> 3;
+    const long k_off = (long)(((lane & 7) ^ r8) * 8) * sizeof(T);     // pre-swizzled source chunk (tile row & 7 == r8)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int ra_ = m0 + (i * 8 + wid) * 8 + r8; ra_ = ra_ < p.M ? ra_ : p.M - 1;
+      srcp[i] = p.A + (long)ra_ * p.lda_b + k_off;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int rb_ = n0 + (i * 8 + wid) * 8 + r8; rb_ = rb_ < p.N ? rb_ : p.N - 1;
+      srcp[4 + i] = p.W + (long)rb_ * p.ldw_b + k_off;
+    }
+  }
+  auto issue = [&](int st) {          // the NEXT K tile (the pointers advance)
+    char* base = smem + st * kStage;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_global_load_lds((gptr_t)srcp[i], (lptr_t)(base + (i * 8 + wid) * 1024), 16, 0, 0);
+      srcp[i] += BK * sizeof(T);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      __builtin_amdgcn_global_load_lds((gptr_t)srcp[4 + i], (lptr_t)(base + BM * kRowStride + (i * 8 + wid) * 1024), 16, 0, 0);
+      srcp[4 + i] += BK * sizeof(T);
+    }
+  };
+
+  // The product is accumulated TRANSPOSED (W fragment as the MFMA's A operand): acc[j][i][r] =
+  // C[row m0 + wr*64 + i*16 + (lane & 15)][col n0 + wc*64 + j*16 + (lane >> 4)*4 + r] -- a lane owns 4 CONSECUTIVE
+  // columns of one row, so the epilogue writes 8-byte (bf16) / 16-byte (fp32) pieces, 16 stores per lane instead of 64.
+  f32x4_t acc[NI][MI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j)
+#pragma unroll
+    for (int i = 0; i < MI; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  issue(0);
+  if (nk > 1) {
+    issue(1);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");    // stage 0 of this wave has landed, stage 1 may still fly
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  // raw s_barrier: __syncthreads() carries a workgroup fence, and hipcc waits for EVERY outstanding LDS-DMA (vmcnt(0)) in
+  // front of it -- the very wait this kernel exists to avoid.  The volatile asm statements keep the LDS reads below it.
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  const int frow = lane & 15, sw = frow & 7, lgc = lane >> 4;
+  // fragments of K sub-step `ks` (32 of the 64 columns of a stage) for this wave's 64 x 64 tile.  The reads are inline
+  // asm on purpose: hipcc's own counter bookkeeping puts lgkmcnt(0) in front of the first MFMA of a phase (it does not
+  // count across the loop edge), which would make the 8 reads just issued for the NEXT phase finish before the MFMAs
+  // of this one start.  With the reads invisible to it, the waits below are the only ones: lgkmcnt(8) = "everything but
+  // the 8 newest reads has arrived" (LDS reads return in order).
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
+  const uint32_t a_off = (uint32_t)((wr * WM + frow) * kRowStride), b_off = (uint32_t)((BM + wc * WN + frow) * kRowStride);
+  auto ldfrag = [&](int st, int ks, bf16x8_t (&af)[MI], bf16x8_t (&bf)[NI]) {
+    const uint32_t coff = (uint32_t)(((ks * 4 + lgc) ^ sw) * 16);
+    const uint32_t pa = lds0 + st * kStage + a_off + coff, pb = lds0 + st * kStage + b_off + coff;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(af[0]) : "v"(pa));
+    asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(af[1]) : "v"(pa));
+    asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(af[2]) : "v"(pa));
+    asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(af[3]) : "v"(pa));
+    asm volatile("ds_read_b128 %0, %1" : "=v"(bf[0]) : "v"(pb));
+    asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(bf[1]) : "v"(pb));
+    asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(bf[2]) : "v"(pb));
+    asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(bf[3]) : "v"(pb));
+  };
+  auto mma = [&](const bf16x8_t (&af)[MI], const bf16x8_t (&bf)[NI]) {
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int i = 0; i < MI; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], acc[j][i], 0, 0, 0);
+  };
+  // Two phases per K step, each = 8 fragment reads in flight under 16 MFMAs of the fragments read one phase earlier:
+  //   phase A: DMA of step kt + 2 | reads of (stage kt, ks 1) | MFMAs of (stage kt, ks 0) | lgkmcnt(0), vmcnt(6), barrier
+  //   phase B: reads of (stage kt + 1, ks 0)                  | MFMAs of (stage kt, ks 1)
+  // The lgkmcnt(0) in front of the barrier retires this wave's last reads of stage kt, so the DMA that the fastest wave
+  // issues into that buffer two phases later (step kt + 1's phase A, stage kt + 3) cannot overtake them.
+  bf16x8_t a0[MI], b0[NI], a1[MI], b1[NI];
+  ldfrag(0, 0, a0, b0);
+  int cur = 0, nxt2 = 2;
+  // every wait of the loop is written out; a sched_barrier after each keeps hipcc from moving MFMAs (register-only, so a
+  // "memory" clobber does not hold them) above the wait that makes their operands valid
+#define G3_WAIT(str) do { asm volatile(str ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+  for (int kt = 0; kt + 2 < nk; ++kt) {            // steady state: a DMA every step
+    issue(nxt2);
+    ldfrag(cur, 1, a1, b1);
+    G3_WAIT("s_waitcnt lgkmcnt(8)");               // a0 / b0 (read one phase ago) are in
+    mma(a0, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    G3_WAIT("s_waitcnt vmcnt(6) lgkmcnt(0)");      // a1 / b1 are in; stage kt + 1 of this wave has landed
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    cur = cur == NST - 1 ? 0 : cur + 1;
+    nxt2 = nxt2 == NST - 1 ? 0 : nxt2 + 1;
+    ldfrag(cur, 0, a0, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(a1, b1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (nk > 1) {                                    // step nk - 2: nothing left to request, step nk - 1 must have landed
+    ldfrag(cur, 1, a1, b1);
+    G3_WAIT("s_waitcnt lgkmcnt(8)");
+    mma(a0, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    G3_WAIT("s_waitcnt vmcnt(0) lgkmcnt(0)");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    cur = cur == NST - 1 ? 0 : cur + 1;
+    ldfrag(cur, 0, a0, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(a1, b1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  ldfrag(cur, 1, a1, b1);                          // last step
+  G3_WAIT("s_waitcnt lgkmcnt(8)");
+  mma(a0, b0);
+  __builtin_amdgcn_sched_barrier(0);
+  G3_WAIT("s_waitcnt lgkmcnt(0)");
+  mma(a1, b1);
+#undef G3_WAIT
+
+  // ---- epilogue: 4 consecutive columns per lane; every load it needs is in flight before the first store of its row
+  // block (a load consumed behind a store makes hipcc wait for that store: one write round trip per element) ----------
+  constexpr bool kReadsC = (EPI == MH_EPI_RESID || EPI == MH_EPI_GATE_RESID);
+  constexpr bool kPos = (EPI == MH_EPI_BIAS_GELU_ERF);
+  const int l15 = lane & 15;
+  const int ecol_base = n0 + wc * WN + lgc * 4;     // + j * 16
+  const int erow_base = m0 + wr * WM + l15;         // + i * 16
+  auto f4 = [](const float* q) { return *reinterpret_cast<const float4*>(q); };
+  auto st_bf16x4 = [](void* base, long idx, const float (&v)[4]) {
+    *reinterpret_cast<uint2*>(reinterpret_cast<T*>(base) + idx) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+  };
+  auto st_f32x4 = [](void* base, long idx, const float (&v)[4]) {
+    *reinterpret_cast<float4*>(reinterpret_cast<float*>(base) + idx) = make_float4(v[0], v[1], v[2], v[3]);
+  };
+  float4 bias4[NI];
+#pragma unroll
+  for (int jj = 0; jj < NI; ++jj) {
+    int c = ecol_base + jj * 16;
+    c = c < p.N ? c : p.N - 4;
+    bias4[jj] = (EPI != MH_EPI_GEGLU && p.bias) ? f4(p.bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+#pragma unroll
+  for (int jj = 0; jj < NI; ++jj)
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      acc[jj][i][0] += bias4[jj].x; acc[jj][i][1] += bias4[jj].y; acc[jj][i][2] += bias4[jj].z; acc[jj][i][3] += bias4[jj].w;
+      asm volatile("" : "+v"(acc[jj][i]));   // materialised HERE: hipcc otherwise sinks the add (and the wait for the bias
+    }                                        // load) behind the stores, and every store then waits for the one before it
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int row = erow_base + i * 16;
+    const bool rok = row < p.M;
+    const int rowc = rok ? row : p.M - 1;
+    float4 old4[NI], g4[NI];
+    if constexpr (kReadsC || kPos) {
+#pragma unroll
+      for (int jj = 0; jj < NI; ++jj) {
+        int c = ecol_base + jj * 16;
+        c = c < p.N ? c : p.N - 4;
+        old4[jj] = kReadsC ? f4(reinterpret_cast<const float*>(p.C) + (long)rowc * p.ldc + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (EPI == MH_EPI_GATE_RESID) g4[jj] = f4(p.gate + (long)(rowc / p.rows_per_batch) * p.gate_ld + c);
+        else if (kPos && p.gate) g4[jj] = f4(p.gate + (long)(rowc % p.rows_per_batch) * p.gate_ld + c);
+        else g4[jj] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    // all values of this row block first (pinned: nothing that depends on a load may sink behind a store), then the stores
+    f32x4_t vv[NI];
+#pragma unroll
+    for (int jj = 0; jj < NI; ++jj) {
+      f32x4_t v = acc[jj][i];
+      if constexpr (EPI == MH_EPI_GEGLU) {
+        if (!(jj & 1)) {                             // 16-row weight blocks alternate wi_0 / wi_1: jj the gate, jj + 1 the linear half
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = gelu_tanh(v[r]) * acc[jj + 1][i][r];
+        }
+      } else if constexpr (EPI == MH_EPI_RESID) {
+        v[0] += old4[jj].x; v[1] += old4[jj].y; v[2] += old4[jj].z; v[3] += old4[jj].w;
+      } else if constexpr (EPI == MH_EPI_GATE_RESID) {
+        v[0] = old4[jj].x + g4[jj].x * v[0]; v[1] = old4[jj].y + g4[jj].y * v[1];
+        v[2] = old4[jj].z + g4[jj].z * v[2]; v[3] = old4[jj].w + g4[jj].w * v[3];
+      } else if constexpr (EPI == MH_EPI_BIAS_GELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_tanh(v[r]);
+      } else if constexpr (EPI == MH_EPI_BIAS_GELU_ERF) {
+        const float gq[4] = {g4[jj].x, g4[jj].y, g4[jj].z, g4[jj].w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = 0.5f * v[r] * (1.0f + erff(v[r] * 0.70710678118654752f)) + gq[r];
+      }
+      asm volatile("" : "+v"(v));
+      vv[jj] = v;
+    }
+#pragma unroll
+    for (int jj = 0; jj < NI; ++jj) {
+      const int c = ecol_base + jj * 16;
+      const float v[4] = {vv[jj][0], vv[jj][1], vv[jj][2], vv[jj][3]};
+      if constexpr (EPI == MH_EPI_GEGLU) {
+        if (jj & 1) continue;
+        const int oc = (n0 + wc * WN) / 2 + (jj / 2) * 16 + lgc * 4;
+        if (rok && oc < p.N / 2) st_bf16x4(p.C, (long)row * p.ldc + oc, v);
+        continue;
+      }
+      if (!rok || c >= p.N) continue;
+      if constexpr (EPI == MH_EPI_STORE || EPI == MH_EPI_BIAS_GELU || EPI == MH_EPI_BIAS_GELU_ERF) {
+        st_bf16x4(p.C, (long)row * p.ldc + c, v);
+      } else if constexpr (EPI == MH_EPI_STORE_F32 || EPI == MH_EPI_RESID || EPI == MH_EPI_GATE_RESID) {
+        st_f32x4(p.C, (long)row * p.ldc + c, v);
+      } else if constexpr (EPI == MH_EPI_KV_SCATTER) {
+        const int dd = c & 63, h = (c >> 6) % p.kv_H, lk = (c >> 6) / p.kv_H;
+        const int b = row / p.kv_L, key = row - b * p.kv_L;
+        st_bf16x4(p.C, ((((long)lk * p.kv_B + b) * p.kv_H + h) * p.kv_L + key) * 64 + dd, v);
+      } else if constexpr (EPI == MH_EPI_QKV_VT) {
+        if (c < p.n_split) {
+          st_bf16x4(p.C, (long)row * p.ldc + c, v);
+        } else {
+          const int c2 = c - p.n_split;
+          const int b = row / p.kv_L, key = row - b * p.kv_L;
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            reinterpret_cast<T*>(p.C2)[((long)b * p.kv_H * 64 + c2 + r) * p.kv_Lpad + key] = Elem<T>::from_f32(v[r]);
+        }
+      } else if constexpr (EPI == MH_EPI_QKV_CACHE) {
+        if (c < p.n_split) {
+          st_bf16x4(p.C, (long)row * p.ldc + c, v);
+        } else {
+          const int inner = p.kv_H * 64;
+          const int c2 = c - p.n_split;
+          const int kv = c2 / inner, cc = c2 - kv * inner;
+          const int b = row / p.kv_L, ip = row - b * p.kv_L;
+          const long dst = (((long)b * p.kv_H + (cc >> 6)) * p.cache_len + ip) * 64 + (cc & 63);
+          if (kv == 0) {
+            st_bf16x4(p.C2, dst, v);
+          } else {
+            st_bf16x4(p.C3, dst, v);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              reinterpret_cast<T*>(p.C4)[((long)b * p.kv_H * 64 + cc + r) * p.kv_Lpad + ip] = Elem<T>::from_f32(v[r]);
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int EPI>
+int launch_glds3(const GemmP& p, hipStream_t s) {
+  const int nbm = (p.M + 255) / 256, nbn = (p.N + 127) / 128;
+  hipLaunchKernelGGL((gemm_glds3_kernel<EPI>), dim3(nbm * nbn), dim3(512), 3 * (256 + 128) * 128, s, p);
+  return check_launch("gemm_glds3_kernel");
 }
 
 template <typename T, int BM, int BN, int EPI, bool S3 = false, bool GL = false>
@@ -543,6 +861,9 @@ bool prepare_one() {
 template <typename T, int EPI>
 bool prepare_epi() {
   bool ok = prepare_one<T, 128, 128, EPI>() && prepare_one<T, 64, 64, EPI>();
+  if constexpr (sizeof(T) == 2)
+    ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds3_kernel<EPI>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (256 + 128) * 128) == hipSuccess;
   if constexpr (EPI != MH_EPI_GEGLU) ok = ok && prepare_one<T, 32, 32, EPI>() && prepare_one<T, 16, 16, EPI>();   // GEGLU pairs two 16-col blocks per wave
   return ok;
 }
@@ -571,7 +892,12 @@ int dispatch_tile(const GemmP& p, hipStream_t s) {
   // the batched DiT, M = 8192: 64x64 tiles 667 ms vs 128x128 827 ms per 100 steps) -> 8x the bf16 threshold
   const long min128 = option(OPT_GEMM_TILE128_MIN) * (std::is_same<T, float>::value ? 8 : 1);
   if (tiles128 >= min128) {
-    if constexpr (sizeof(T) == 2) {   // plain bf16 operands: the LDS-DMA form (option gemm_glds = 0: register staging)
+    if constexpr (sizeof(T) == 2) {   // plain bf16 operands: the LDS-DMA forms (option gemm_glds = 0: register staging)
+      const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + 127) / 128);
+      const bool vec_ok = p.N % 4 == 0 && p.ldc % 4 == 0 && (p.gate == nullptr || p.gate_ld % 4 == 0) &&
+                          (EPI != MH_EPI_GEGLU || p.N % 8 == 0) && p.K % 64 == 0;
+      if (option(OPT_GEMM_GLDS) >= 2 && tiles256 >= option(OPT_GEMM_TILE256_MIN) && !p.stats_out && vec_ok)
+        return launch_glds3<EPI>(p, s);
       if (option(OPT_GEMM_GLDS) != 0) return launch_gemm<T, 128, 128, EPI, false, true>(p, s);
     }
     return launch_gemm<T, 128, 128, EPI>(p, s);
