@@ -497,6 +497,43 @@ def main():
                           "gpu_tokens_per_s": round(128 / dt1, 1), "gpu_ms": round(dt1 * 1e3, 2)}
         del m1
 
+    # ---- the Whisper-family backbone of the released V30-V32 checkpoints (varwhisper small: d 768, 12 + 12 layers, 1024 frames) ----
+    if not args.no_extras and not args.no_config5:
+        try:
+            from mapperatorinator_amd.testing import random_varwhisper_state_dict
+            from mapperatorinator_amd.whisper_engine import VARWHISPER_PRESETS
+            dv, fr = VARWHISPER_PRESETS["small"], 2048
+            tokw = Tokenizer.benchmark_vocab(src_seq_len=fr // 2)
+            sdw = random_varwhisper_state_dict(dv.d_model, dv.n_heads, dv.n_enc_layers, dv.n_dec_layers, dv.d_ff, tokw.vocab_size_in,
+                                               tokw.vocab_size_out, seed=0, head_gain=5.0, gains={"decoder_embedder": 0.5})
+            mw = MapperatorinatorHIP(sdw, dv, vocab_size_in=tokw.vocab_size_in, vocab_size_out=tokw.vocab_size_out, n_mels=128,
+                                     src_seq_len=fr, tgt_seq_len=tgt_len, dtype=torch.bfloat16, device=dev, f_min=20)
+            aw = synthetic_audio(B, (fr - 1) * 128, seed=5).to(dev)
+            pw = torch.full((B, 1), tokw.sos_id, dtype=torch.int32, device=dev)
+            spw, _ = build_sampling(tokw, dict(gk), tgt_len)
+            ew = mw.engine
+            eos_w = torch.zeros(tokw.vocab_size_out, dtype=torch.uint8, device=dev)
+
+            def vw_step():
+                ew._enter()
+                with torch.cuda.stream(ew.stream):
+                    t_, _, _ = ew.decode(ew.cross_kv(ew.encode_mel(ew.mel(aw))), pw, None, eos_w, spw, poll_every=64)
+                ew._leave()
+                return t_
+            vw_step()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                tw = vw_step()
+            torch.cuda.synchronize(dev)
+            dtw = (time.perf_counter() - t0) / args.steps
+            aux["whisper_family"] = {"workload": f"varwhisper-small bf16 (d 768, 12 + 12 layers, 2048 log-mel frames -> 1024 encoder "
+                                                 f"positions per 16.4 s chunk), batch={B}, {new} greedy tokens per chunk",
+                                     "tokens_per_s": round(int((tw[:, 1:] != 0).sum().item()) / dtw, 1), "ms_per_step": round(dtw * 1e3, 2)}
+            del mw, ew
+        except Exception as e:   # an auxiliary figure must never cost the bench line
+            print(f"whisper-family pass failed: {e!r}", file=sys.stderr)
+
     # ---- BASELINE configs[4]: whole 3-minute songs, KV-cached, through the window scheduler (tools/long_song_bench.py) ----
     if not args.no_extras and not args.no_config5:
         try:
