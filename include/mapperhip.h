@@ -447,10 +447,13 @@ int64_t mh_dit_workspace_bytes(const MhDiTConfig* cfg, int N, int T);
  *   t [N] int32 original-scale timesteps (already mapped by _WrappedModel, respace.py:127-132)
  *   c [N,context,T] fp32;  y [N,class] fp32;  band: |i-j| < band attends (banded bool mask of
  *   diffusion_pipeline.py:146-148), band <= 0 = full attention
+ *   open_from: with `pad_sequence` (diffusion_pipeline.py:186-193) the window is padded to max_seq_len and the band mask
+ *   is padded with "allowed" -- positions >= open_from attend and are attended by everything (the reference builds a
+ *   key_padding_mask for them but DiTBlock.forward never hands it to the attention, models.py:133-150); 0 = no padding
  *   out [N,4,T] fp32: CFG-combined eps (duplicated) ++ variance channels (models.py:312-317). */
 int mh_dit_forward_cfg(const MhDiTConfig* cfg, const MhDiTWeights* w, const float* x, const int32_t* t,
-                       const float* c, const float* y, float cfg_scale, int band, int N, int T, float* out,
-                       void* workspace, int64_t workspace_bytes, void* stream);
+                       const float* c, const float* y, float cfg_scale, int band, int open_from, int N, int T,
+                       float* out, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* One p_sample update (learned-range variance, epsilon prediction, clip_denoised -> clamp(-2,2)):
  *   coef fp32[7] for this step, extracted on the host from the float64 schedule exactly as
@@ -509,7 +512,7 @@ int mh_slider_project(float* x0, const uint8_t* inpaint_mask, const float* inpai
  *   still inside the one captured graph. */
 int64_t mh_ddpm_loop_workspace_bytes(const MhDiTConfig* cfg, int N, int T, int n_steps);
 int mh_ddpm_sample_loop(const MhDiTConfig* cfg, const MhDiTWeights* w, float* x_io, const float* c,
-                        const float* y, float cfg_scale, int band, int N, int T, int n_steps,
+                        const float* y, float cfg_scale, int band, int open_from, int N, int T, int n_steps,
                         const int32_t* t_map, const float* coefs, const float* noise,
                         const uint8_t* inpaint_mask, const float* inpaint_ref, const MhSliderSet* sliders,
                         void* workspace, int64_t workspace_bytes, void* stream);

@@ -129,11 +129,11 @@ SYMBOLS = {
     "mh_t5_decode_chains": (I, [I]),
     "mh_wall_clock_khz": (I, []),
     "mh_dit_workspace_bytes": (I64, [C.POINTER(MhDiTConfig), I, I]),
-    "mh_dit_forward_cfg": (I, [C.POINTER(MhDiTConfig), C.POINTER(MhDiTWeights), VP, VP, VP, VP, F, I, I, I,
+    "mh_dit_forward_cfg": (I, [C.POINTER(MhDiTConfig), C.POINTER(MhDiTWeights), VP, VP, VP, VP, F, I, I, I, I,
                                VP, VP, I64, VP]),
     "mh_ddpm_step": (I, [VP, VP, VP, VP, VP, VP, VP, I, I, I, VP, VP, VP]),
     "mh_ddpm_loop_workspace_bytes": (I64, [C.POINTER(MhDiTConfig), I, I, I]),
-    "mh_ddpm_sample_loop": (I, [C.POINTER(MhDiTConfig), C.POINTER(MhDiTWeights), VP, VP, VP, F, I, I, I, I,
+    "mh_ddpm_sample_loop": (I, [C.POINTER(MhDiTConfig), C.POINTER(MhDiTWeights), VP, VP, VP, F, I, I, I, I, I,
                                 VP, VP, VP, VP, VP, C.POINTER(MhSliderSet), VP, I64, VP]),
     "mh_slider_project": (I, [VP, VP, VP, I, I, C.POINTER(MhSliderSet), VP]),
 }

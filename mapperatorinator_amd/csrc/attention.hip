@@ -75,6 +75,15 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(AttnArgs p) {
     khi = khi > Lk - 1 ? Lk - 1 : khi;
     t_hi = khi / 64;
   }
+  // open_from > 0 (the DiT pipeline's pad_sequence, diffusion_pipeline.py:186-193): positions >= open_from are padding that
+  // the reference leaves attendable -- key k is visible from query q iff in-band OR k >= open_from OR q >= open_from
+  const int open_from = (p.band != 0 && p.open_from > 0) ? p.open_from : (1 << 30);
+  int t_last = t_hi, t_open = 1 << 30;
+  if (open_from < Lk) {
+    t_last = (Lk - 1) / 64;
+    if (qb0 + 63 >= open_from) { t_lo = 0; t_hi = t_last; }     // a pad query in the block: every key tile
+    else t_open = open_from / 64;                                 // band tiles, then the tiles holding pad keys
+  }
 
   const char* kbase = (const char*)p.k + (long)b * p.k_bs + (long)h * p.k_hs;
   const char* vbase = (const char*)p.vt + (long)b * p.vt_bs + (long)h * p.vt_hs;
@@ -82,7 +91,8 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(AttnArgs p) {
   const uint8_t* mrow = p.key_mask ? p.key_mask + (long)b * p.mask_ld : nullptr;
   char* Pw = Ps + wid * 16 * RS;
 
-  for (int kt = t_lo; kt <= t_hi; ++kt) {
+  for (int kt = t_lo; kt <= t_last; ++kt) {
+    if (kt > t_hi && kt < t_open) continue;      // (block-uniform) between the band and the pad columns
     const int kv0 = kt * 64;
     // ---- stage K tile [key][d] and V^T tile [d][key] ----
     // (requesting the next tile into registers while this one is multiplied was measured and lost: the encoder's
@@ -161,7 +171,7 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(AttnArgs p) {
         float v = s[j][r] * p.scale + bv[r][j];
         const int rel = kg - qpos;
         bool ok = (kg < Lk) && (kmv[j] != 0);
-        if (p.band != 0) ok = ok && (rel >= rel_lo) && (rel <= rel_hi);
+        if (p.band != 0) ok = ok && (((rel >= rel_lo) && (rel <= rel_hi)) || kg >= open_from || qpos >= open_from);
         if (p.causal) ok = ok && (rel <= 0);
         v = ok ? v : -INFINITY;
         s[j][r] = v;
@@ -276,7 +286,7 @@ namespace {
 struct SmallAttnP {
   const float* q; const float* k; const float* vt; float* out;
   long ld_qk, vt_hs, vt_bs; int ld_out;
-  int L, Lpad, H, band;
+  int L, Lpad, H, band, open_from;
   float scale;
 };
 
@@ -314,6 +324,7 @@ __global__ __launch_bounds__(256) void attn_small_f32_kernel(SmallAttnP p) {
   // S = scale * Q K^T with the band mask; C layout: col = l15 (key in block), row = lg*4 + r (query)
   const int rel_lo = p.band > 0 ? -(p.band - 1) : (p.band < 0 ? p.band : -(1 << 30));          // band 0 = open, < 0 = |k - q| <= -band
   const int rel_hi = p.band > 0 ? p.band : (p.band < 0 ? -p.band : (1 << 30));
+  const int open_from = (p.band != 0 && p.open_from > 0) ? p.open_from : (1 << 30);   // pad_sequence: see flash_attn_kernel
   f32x4_t sc[KBW];
   float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
@@ -324,8 +335,9 @@ __global__ __launch_bounds__(256) void attn_small_f32_kernel(SmallAttnP p) {
     const int key = kbase + kb * 16 + l15;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int rel = key - (q0 + lg * 4 + r);
-      const bool ok = (key < L) && (rel >= rel_lo) && (rel <= rel_hi);
+      const int qq = q0 + lg * 4 + r;
+      const int rel = key - qq;
+      const bool ok = (key < L) && (((rel >= rel_lo) && (rel <= rel_hi)) || key >= open_from || qq >= open_from);
       a[r] = ok ? a[r] * p.scale : -INFINITY;
       m[r] = fmaxf(m[r], a[r]);
     }
@@ -396,7 +408,7 @@ bool small_attn_ok(int B, int H, int L) { return (long)B * H * ceil_div(L, 16) <
 }  // namespace
 
 int attention(const void* qk, int ld_qk, int k_col0, const void* vt, int Lpad, const float* bias, void* out,
-              int ld_out, int B, int L, int H, float scale, int band, int dtype, hipStream_t s) {
+              int ld_out, int B, int L, int H, float scale, int band, int dtype, hipStream_t s, int open_from) {
   MH_REQUIRE(qk && vt && out, "mh_attention: null operand");
   const int es = dtype == MH_BF16 ? 2 : 4;
   MH_REQUIRE((ld_qk * es) % 16 == 0 && (k_col0 * es) % 16 == 0, "mh_attention: rows must be 16-byte aligned");
@@ -404,7 +416,7 @@ int attention(const void* qk, int ld_qk, int k_col0, const void* vt, int Lpad, c
     SmallAttnP sp{};
     sp.q = (const float*)qk; sp.k = (const float*)qk + k_col0; sp.vt = (const float*)vt; sp.out = (float*)out;
     sp.ld_qk = ld_qk; sp.vt_hs = 64L * Lpad; sp.vt_bs = (long)H * 64 * Lpad; sp.ld_out = ld_out;
-    sp.L = L; sp.Lpad = Lpad; sp.H = H; sp.band = band; sp.scale = scale;
+    sp.L = L; sp.Lpad = Lpad; sp.H = H; sp.band = band; sp.open_from = open_from; sp.scale = scale;
     dim3 grid(ceil_div(L, 16), H, B), block(256);
     if (L <= 128) hipLaunchKernelGGL(attn_small_f32_kernel<2>, grid, block, 0, s, sp);
     else hipLaunchKernelGGL(attn_small_f32_kernel<4>, grid, block, 0, s, sp);
@@ -417,7 +429,7 @@ int attention(const void* qk, int ld_qk, int k_col0, const void* vt, int Lpad, c
   a.bias = bias; a.bias_hs = 2L * L - 1; a.bias_center = L - 1; a.bias_sign = 1; a.bias_min = -(L - 1); a.bias_max = L - 1;
   a.key_mask = nullptr; a.mask_ld = 0; a.mask_len = 0;
   a.out = out; a.out_rs = (long)ld_out * es; a.out_bs = (long)L * ld_out * es;
-  a.Lq = L; a.Lk = L; a.scale = scale; a.band = band; a.causal = 0; a.q_pos0 = 0;
+  a.Lq = L; a.Lk = L; a.scale = scale; a.band = band; a.open_from = open_from; a.causal = 0; a.q_pos0 = 0;
   return attention_general(a, B, H, dtype, s);
 }
 

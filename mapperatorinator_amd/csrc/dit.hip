@@ -284,7 +284,7 @@ int dit_conditioning(const MhDiTConfig* c, const MhDiTWeights* w, const int32_t*
 
 // x-dependent part of the denoiser; the conditioning of this step is in b.cond_cur ([n][depth*6D + 2D])
 int dit_body(const MhDiTConfig* c, const MhDiTWeights* w, const float* x, const float* cc, float cfg_scale, int band,
-             int N, int T, float* out, const DiTBuf& b, hipStream_t s) {
+             int open_from, int N, int T, float* out, const DiTBuf& b, hipStream_t s) {
   const int D = c->hidden, H = c->n_heads, NT = N * T;
   const int ld_row = c->depth * 6 * D + 2 * D;
   hipLaunchKernelGGL(dit_embed_kernel, dim3(NT), dim3(256), 0, s, x, cc, w->pos_freqs, N, T, c->freq_dim,
@@ -330,7 +330,7 @@ int dit_body(const MhDiTConfig* c, const MhDiTWeights* w, const float* x, const 
     g.bias = w->qkv_b[l]; g.dtype = MH_BF16; g.epilogue = MH_EPI_QKV_VT; g.C2 = b.vt; g.n_split = 2 * D; g.kv_B = N;
     g.kv_H = H; g.kv_L = T; g.kv_Lpad = b.Tpad;
     MH_TRY(gemm(g, s));
-    MH_TRY(attention(b.qk, 2 * D, D, b.vt, b.Tpad, nullptr, b.attn, D, N, T, H, 0.125f, band, MH_BF16, s));
+    MH_TRY(attention(b.qk, 2 * D, D, b.vt, b.Tpad, nullptr, b.attn, D, N, T, H, 0.125f, band, MH_BF16, s, open_from));
     g = MhGemm{};
     g.A = b.attn; g.lda = D; g.W = w->out_wb[l]; g.ldw = D; g.C = b.xs; g.ldc = D; g.M = NT; g.N = D; g.K = D;
     g.bias = w->out_b[l]; g.gate = mod + 2 * D; g.gate_ld = ld_row; g.rows_per_batch = T; g.dtype = MH_BF16;
@@ -363,7 +363,7 @@ int dit_body(const MhDiTConfig* c, const MhDiTWeights* w, const float* x, const 
       g.A = b.xm;
     }
     MH_TRY(gemm(g, s));
-    MH_TRY(attention(b.qk, 2 * D, D, b.vt, b.Tpad, nullptr, b.attn, D, N, T, H, 0.125f, band, MH_F32, s));
+    MH_TRY(attention(b.qk, 2 * D, D, b.vt, b.Tpad, nullptr, b.attn, D, N, T, H, 0.125f, band, MH_F32, s, open_from));
     g = MhGemm{};
     g.A = b.attn; g.lda = D; g.ldw = D; g.C = b.xs; g.ldc = D; g.M = NT; g.N = D; g.K = D;
     g.bias = w->out_b[l]; g.gate = mod + 2 * D; g.gate_ld = ld_row; g.rows_per_batch = T; g.dtype = MH_F32;
@@ -423,8 +423,8 @@ extern "C" int64_t mh_ddpm_loop_workspace_bytes(const MhDiTConfig* c, int N, int
 }
 
 extern "C" int mh_dit_forward_cfg(const MhDiTConfig* c, const MhDiTWeights* w, const float* x, const int32_t* t,
-                                  const float* cc, const float* y, float cfg_scale, int band, int N, int T, float* out,
-                                  void* workspace, int64_t workspace_bytes, void* stream) {
+                                  const float* cc, const float* y, float cfg_scale, int band, int open_from, int N, int T,
+                                  float* out, void* workspace, int64_t workspace_bytes, void* stream) {
   MH_TRY(check_dit(c, N, T));
   MH_REQUIRE(w && x && t && cc && y && out && workspace, "mh_dit_forward_cfg: null argument");
   MH_REQUIRE(workspace_bytes >= mh_dit_workspace_bytes(c, N, T), "mh_dit_forward_cfg: workspace too small");
@@ -434,7 +434,8 @@ extern "C" int mh_dit_forward_cfg(const MhDiTConfig* c, const MhDiTWeights* w, c
   void* scratch = (char*)workspace + used + align256((int64_t)N * 4 * T * 4);
   if (hipMemsetAsync(b.vt, 0, (size_t)N * c->hidden * b.Tpad * 4, s) != hipSuccess) return check_launch("memset vt");
   MH_TRY(dit_conditioning(c, w, t, 1, y, N, 1, b.cond_cur, b, scratch, s));
-  return dit_body(c, w, x, cc, cfg_scale, band, N, T, out, b, s);
+  MH_REQUIRE(open_from >= 0 && open_from <= T, "mh_dit_forward_cfg: open_from outside [0, T]");
+  return dit_body(c, w, x, cc, cfg_scale, band, open_from, N, T, out, b, s);
 }
 
 extern "C" int mh_ddpm_step(const float* model_out, const float* x, const float* noise, const float* coef,
@@ -448,7 +449,7 @@ extern "C" int mh_ddpm_step(const float* model_out, const float* x, const float*
 }
 
 extern "C" int mh_ddpm_sample_loop(const MhDiTConfig* c, const MhDiTWeights* w, float* x_io, const float* cc,
-                                   const float* y, float cfg_scale, int band, int N, int T, int n_steps,
+                                   const float* y, float cfg_scale, int band, int open_from, int N, int T, int n_steps,
                                    const int32_t* t_map, const float* coefs, const float* noise,
                                    const uint8_t* inpaint_mask, const float* inpaint_ref, const MhSliderSet* sliders,
                                    void* workspace, int64_t workspace_bytes, void* stream) {
@@ -456,6 +457,7 @@ extern "C" int mh_ddpm_sample_loop(const MhDiTConfig* c, const MhDiTWeights* w, 
   MH_REQUIRE(w && x_io && cc && y && t_map && coefs && noise && workspace && n_steps > 0,
              "mh_ddpm_sample_loop: null argument");
   if (sliders) MH_TRY(check_slider_set(sliders, N));
+  MH_REQUIRE(open_from >= 0 && open_from <= T, "mh_ddpm_sample_loop: open_from outside [0, T]");
   MH_REQUIRE(stream != nullptr, "mh_ddpm_sample_loop: needs a non-default stream (hipGraph capture)");
   MH_REQUIRE(workspace_bytes >= mh_ddpm_loop_workspace_bytes(c, N, T, n_steps), "mh_ddpm_sample_loop: workspace too small");
   MH_REQUIRE((inpaint_mask == nullptr) == (inpaint_ref == nullptr), "mh_ddpm_sample_loop: inpaint mask/ref mismatch");
@@ -480,7 +482,7 @@ extern "C" int mh_ddpm_sample_loop(const MhDiTConfig* c, const MhDiTWeights* w, 
   hipLaunchKernelGGL(select_step_kernel, dim3((unsigned)ceil_div((int)per_step, 256)), dim3(256), 0, s, cond_all, b.sel,
                      per_step, b.cond_cur);
   int rc = check_launch("select_step_kernel");
-  if (rc == MH_OK) rc = dit_body(c, w, x_io, cc, cfg_scale, band, N, T, mout, b, s);
+  if (rc == MH_OK) rc = dit_body(c, w, x_io, cc, cfg_scale, band, open_from, N, T, mout, b, s);
   if (rc == MH_OK && !sliders)
     rc = ddpm_step(mout, x_io, noise, coefs, b.sel, (long)N * 2 * T, inpaint_mask, inpaint_ref, nullptr, 0, N, T, x_io,
                    nullptr, s);

@@ -13,7 +13,7 @@ int rmsnorm(const float* x, int ldx, const float* w, void* y, int ldy, int rows,
 int ln_modulate(const float* x, int ldx, const float* shift, const float* scale, int mod_ld, int rows_per_batch,
                 void* y, int ldy, int rows, int d, float eps, int out_dtype, hipStream_t s);
 int attention(const void* qk, int ld_qk, int k_col0, const void* vt, int Lpad, const float* bias, void* out,
-              int ld_out, int B, int L, int H, float scale, int band, int dtype, hipStream_t s);
+              int ld_out, int B, int L, int H, float scale, int band, int dtype, hipStream_t s, int open_from = 0);
 
 // strided description of one attention problem (all byte strides; see attention.hip)
 struct AttnArgs {
@@ -25,6 +25,7 @@ struct AttnArgs {
   void* out; long out_rs, out_bs;
   int Lq, Lk;
   float scale;
+  int open_from = 0;   // with a band: positions >= open_from (padding) attend and are attended by everything (0 = none)
   int band;        // > 0: attend iff -(band-1) <= k - q <= band
   int causal;      // attend iff key position <= q_pos0 + query index
   int q_pos0;

@@ -13,8 +13,8 @@ loop (K7-K9).  Integer / indexing logic on the host, every float of the hot loop
 Grouping Events into hit-object points (`get_groups`, `update_event_times`) and writing positions back into Events
 (`events_with_pos`) is the reference's own integer host code either side of this seam and stays there; the
 `DiffusionSlider` list it builds (:389-437) is handed in as `sliders` and the slider end re-projection of `denoised_fn`
-(:208-220) runs on the device inside the DDPM graph (csrc/slider.hip).  Not built: `pad_sequence=True` (the padded
-mask is no longer a band).
+(:208-220) runs on the device inside the DDPM graph (csrc/slider.hip).  `pad_sequence=True` (:186-193) is reproduced with
+the reference's own quirk: the pad positions stay attendable (the attention kernels' `open_from`).
 """
 from __future__ import annotations
 
@@ -95,13 +95,11 @@ class DiffusionPipelineHIP:
                  seq_len: int = 128, max_seq_len: int = 1024, overlap_buffer: int = 128, cfg_scale: float = 1.0,
                  refine_model: Optional[DiTHIP] = None, refine_iters: int = 10, random_init: bool = False,
                  pad_sequence: bool = False, start_time: Optional[float] = None, end_time: Optional[float] = None):
-        if pad_sequence:
-            # reference diffusion_pipeline.py:186-193 pads every window to max_seq_len, pads the band mask with "allowed" and
-            # builds a key_padding_mask -- which DiTBlock.forward never hands to its attention (models.py:133-150): every
-            # real query then attends all the zero-embedded pad tokens, so padding CHANGES the real positions
-            # (tests/test_oracle_pinned.py::test_reference_dit_padding_changes_real_positions).  That mask is no band;
-            # reproducing the quirk is not on the HIP path.
-            raise NotImplementedError("pad_sequence=True (band mask + attendable pad tokens) is not on the HIP path")
+        # pad_sequence (reference diffusion_pipeline.py:186-193) pads every window to max_seq_len with zero positions and zero
+        # context, pads the band mask with "allowed" and builds a key_padding_mask -- which DiTBlock.forward never hands to
+        # its attention (models.py:133-150): every real query then attends all the pad tokens, so padding CHANGES the real
+        # positions (tests/test_oracle_pinned.py::test_reference_dit_padding_changes_real_positions).  Reproduced as it is:
+        # BandMask(open_from=) / the attention kernels' `open_from`.
         if not 0 <= 2 * overlap_buffer < max_seq_len:
             raise ValueError("overlap_buffer must be less than half of max_seq_len")
         self.model, self.refine_model = model, refine_model
@@ -109,7 +107,7 @@ class DiffusionPipelineHIP:
         self.timesteps, self.diffusion_steps, self.noise_schedule = timesteps, diffusion_steps, noise_schedule
         self.seq_len, self.max_seq_len, self.overlap_buffer = seq_len, max_seq_len, overlap_buffer
         self.cfg_scale, self.refine_iters, self.random_init = cfg_scale, refine_iters, random_init
-        self.start_time, self.end_time = start_time, end_time
+        self.start_time, self.end_time, self.pad_sequence = start_time, end_time, bool(pad_sequence)
 
     def to_positions(self, samples: torch.Tensor) -> torch.Tensor:
         """(:171-176) drop the null-class half, [-1, 1] -> playfield pixels, to the CPU.  (2B, 2, T) -> (B, 2, T)"""
@@ -182,7 +180,12 @@ class DiffusionPipelineHIP:
         def sample_part(zfull, start, end, start_mask_size=0):
             z_part = zfull[:, :, start:end].contiguous()
             c_part = c[:, :, start:end].contiguous()
-            T = end - start
+            real = end - start
+            pad = self.max_seq_len - real if self.pad_sequence else 0          # (:186-193)
+            if pad > 0:
+                z_part = torch.nn.functional.pad(z_part, (0, pad)).contiguous()
+                c_part = torch.nn.functional.pad(c_part, (0, pad)).contiguous()
+            T = real + max(pad, 0)
             # True means it will be generated (:223-234); per chunk, the pair of a chunk shares its mask
             mask = torch.full(z_part.shape, False, dtype=torch.bool, device=dev)
             mask[:, :, start_mask_size:] = True
@@ -197,7 +200,7 @@ class DiffusionPipelineHIP:
                     mask[b, :, k1:] = False
                     mask[B + b, :, k1:] = False
             if not bool(mask.any()):
-                return z_part
+                return z_part[:, :, :real]
             if denoised_fn_factory is not None:
                 denoised_fn = denoised_fn_factory(mask, z_part, start, end)
             elif sliders is not None and any(len(sl) > 0 for sl in sliders):
@@ -205,8 +208,8 @@ class DiffusionPipelineHIP:
             else:
                 denoised_fn = InpaintSpec(mask, z_part)
             z_part = denoised_fn(z_part)
-            model_kwargs = dict(c=c_part, y=y, cfg_scale=self.cfg_scale, attn_mask=BandMask(T, self.seq_len),
-                                key_padding_mask=None)
+            model_kwargs = dict(c=c_part, y=y, cfg_scale=self.cfg_scale,
+                                attn_mask=BandMask(T, self.seq_len, open_from=real if pad > 0 else 0), key_padding_mask=None)
             samples = diffusion.p_sample_loop(self.model.forward_with_cfg, z_part.shape, z_part, denoised_fn=denoised_fn,
                                               clip_denoised=True, model_kwargs=model_kwargs, device=dev,
                                               step_noise=noise_source(diffusion.num_timesteps, tuple(z_part.shape)))
@@ -218,7 +221,7 @@ class DiffusionPipelineHIP:
                                              clip_denoised=True, model_kwargs=model_kwargs,
                                              noise=noise_source(1, tuple(samples.shape))[0])
                     samples = out["sample"]
-            return samples
+            return samples[:, :, :real] if pad > 0 else samples
 
         full = z.clone()
         ob = self.overlap_buffer

@@ -138,30 +138,32 @@ class DiTHIP:
             self._ws = torch.empty(int(need), dtype=torch.uint8, device=self.device)
         return self._ws
 
-    def band_from_mask(self, attn_mask: Optional[torch.Tensor], T: int) -> int:
+    def band_from_mask(self, attn_mask: Optional[torch.Tensor], T: int):
         """The reference passes a (T, T) bool mask, True = masked, built as a band
-        (diffusion_pipeline.py:146-148): query q may attend key k iff -(band-1) <= k - q <= band.
-        Recover `band` and verify the mask really is that band (anything else is refused)."""
+        (diffusion_pipeline.py:146-148): query q may attend key k iff -(band-1) <= k - q <= band; with `pad_sequence` it is
+        padded with "allowed" rows and columns (:190).  Recover (band, open_from) and verify the mask really has that
+        structure (anything else is refused)."""
         if attn_mask is None:
-            return 0
+            return 0, 0
         if isinstance(attn_mask, BandMask):      # our own pipeline: the band is known, nothing to analyse
             if attn_mask.T != T:
                 raise ValueError(f"band mask built for T={attn_mask.T}, sequence has T={T}")
-            return attn_mask.band
+            return attn_mask.band, attn_mask.open_from
         m = attn_mask.to("cpu")
         if m.dtype != torch.bool or m.shape != (T, T):
             raise NotImplementedError("attn_mask must be a (T, T) bool band mask")
-        allowed0 = int((~m[0]).sum().item())  # keys 0..band visible from query 0
-        band = 0 if allowed0 >= T and not bool(m.any()) else allowed0 - 1
-        if band > 0:
-            q = torch.arange(T)[:, None]
-            k = torch.arange(T)[None, :]
-            expect = ~(((k - q) >= -(band - 1)) & ((k - q) <= band))
-            if not torch.equal(expect, m):
-                raise NotImplementedError("attn_mask is not the banded mask of diffusion_pipeline.py:146-148")
-        elif bool(m.any()):
-            raise NotImplementedError("attn_mask is not the banded mask of diffusion_pipeline.py:146-148")
-        return band
+        if not bool(m.any()):
+            return 0, 0
+        # trailing rows AND columns that mask nothing = padding; the band is among the positions before them
+        real = T
+        while real > 0 and not bool(m[real - 1].any()) and not bool(m[:, real - 1].any()):
+            real -= 1
+        allowed0 = int((~m[0, :real]).sum().item())      # keys 0..band visible from query 0
+        band = allowed0 - 1
+        expect = BandMask(T, band, open_from=real if real < T else 0).to_tensor()
+        if band <= 0 or not torch.equal(expect, m):
+            raise NotImplementedError("attn_mask is not the banded mask of diffusion_pipeline.py:146-148 (optionally padded, :190)")
+        return band, (real if real < T else 0)
 
     # ---- B3 ------------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -170,7 +172,7 @@ class DiTHIP:
         (models.py:132,145-151 never forwards it)."""
         dev = self.device
         N, _, T = x.shape
-        band = self.band_from_mask(attn_mask, T)
+        band, open_from = self.band_from_mask(attn_mask, T)
         x = x.to(dev, torch.float32).contiguous()
         c = c.to(dev, torch.float32).contiguous()
         y = y.to(dev, torch.float32).contiguous()
@@ -179,7 +181,7 @@ class DiTHIP:
         ws = self.workspace(N, T)
         s = torch.cuda.current_stream(dev).cuda_stream
         rc = self.lib.mh_dit_forward_cfg(C.byref(self.cfg), C.byref(self.w), x.data_ptr(), t32.data_ptr(),
-                                         c.data_ptr(), y.data_ptr(), float(cfg_scale), band, N, T, out.data_ptr(),
+                                         c.data_ptr(), y.data_ptr(), float(cfg_scale), band, open_from, N, T, out.data_ptr(),
                                          ws.data_ptr(), ws.numel(), s)
         _lib.check(rc, "mh_dit_forward_cfg")
         return out
@@ -190,17 +192,25 @@ class DiTHIP:
 class BandMask:
     """The banded attention mask of diffusion_pipeline.py:145-148 as a description instead of a (T, T) tensor: query q
     may attend key k iff -(band-1) <= k - q <= band (band = the pipeline's `seq_len`).  What DiffusionPipelineHIP
-    passes as `attn_mask`; a foreign caller's bool tensor is analysed (and verified to be a band) on every call."""
+    passes as `attn_mask`; a foreign caller's bool tensor is analysed (and verified to be a band) on every call.
 
-    def __init__(self, T: int, seq_len: int):
-        self.T, self.band = int(T), (int(seq_len) if seq_len < T else 0)   # band >= T masks nothing
+    `open_from` (pad_sequence, :186-193): the window was padded to T positions, the mask padded with "allowed" -- positions
+    >= open_from attend and are attended by everything; the band lives among the first open_from positions."""
+
+    def __init__(self, T: int, seq_len: int, open_from: int = 0):
+        real = open_from if open_from else T
+        self.T, self.band = int(T), (int(seq_len) if seq_len < real else 0)   # band >= the real length masks nothing
+        self.open_from = int(open_from) if (open_from and open_from < T and self.band) else 0
 
     def to_tensor(self, device="cpu") -> torch.Tensor:
         q = torch.arange(self.T, device=device)[:, None]
         k = torch.arange(self.T, device=device)[None, :]
         if self.band == 0:
             return torch.zeros(self.T, self.T, dtype=torch.bool, device=device)
-        return ~((q >= k - self.band) & (q < k + self.band))
+        m = ~((q >= k - self.band) & (q < k + self.band))
+        if self.open_from:
+            m = m & (q < self.open_from) & (k < self.open_from)
+        return m
 
 
 class InpaintSpec:
@@ -236,7 +246,7 @@ class SliderInpaintSpec(InpaintSpec):
             raise RuntimeError("SliderInpaintSpec lives on the GPU; there is no CPU path")
         N, _, T = ref.shape
         B = len(sliders_per_chunk)
-        if N != 2 * B or T != end - start:
+        if N != 2 * B or T < end - start:        # (T > end - start: the window was padded, pad_sequence)
             raise ValueError(f"slider lists for {B} chunks / window {start}:{end} do not match x0 {tuple(ref.shape)}")
         active, chunk_off, types, cp_off, cp_idx, end_idx, length = [], [0], [], [0], [], [], []
         for sl in sliders_per_chunk:
@@ -372,7 +382,7 @@ class SpacedDiffusionHIP:
         c = mk["c"].to(dev, torch.float32).contiguous()
         y = mk["y"].to(dev, torch.float32).contiguous()
         cfg_scale = float(mk.get("cfg_scale", 1.0))
-        band = dit.band_from_mask(mk.get("attn_mask"), T)
+        band, open_from = dit.band_from_mask(mk.get("attn_mask"), T)
         n = self.num_timesteps
         if step_noise is None:
             step_noise = torch.stack([torch.randn_like(x) for _ in range(n)])
@@ -393,7 +403,7 @@ class SpacedDiffusionHIP:
             dit.stream.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(dit.stream):
                 rc = lib.mh_ddpm_sample_loop(C.byref(dit.cfg), C.byref(dit.w), x.data_ptr(), c.data_ptr(),
-                                             y.data_ptr(), cfg_scale, band, N, T, n, t_map.data_ptr(),
+                                             y.data_ptr(), cfg_scale, band, open_from, N, T, n, t_map.data_ptr(),
                                              coefs.data_ptr(), noise_by_i.data_ptr(), _lib.ptr(imask), _lib.ptr(iref),
                                              sset, ws.data_ptr(), ws.numel(), dit.stream.cuda_stream)
             _lib.check(rc, "mh_ddpm_sample_loop")
@@ -407,7 +417,7 @@ class SpacedDiffusionHIP:
         for i in reversed(range(n)):
             t32 = torch.full((N,), self.timestep_map[i], dtype=torch.int32, device=dev)
             _lib.check(lib.mh_dit_forward_cfg(C.byref(dit.cfg), C.byref(dit.w), x.data_ptr(), t32.data_ptr(),
-                                              c.data_ptr(), y.data_ptr(), cfg_scale, band, N, T, mout.data_ptr(),
+                                              c.data_ptr(), y.data_ptr(), cfg_scale, band, open_from, N, T, mout.data_ptr(),
                                               ws.data_ptr(), ws.numel(), s), "mh_dit_forward_cfg")
             _lib.check(lib.mh_ddpm_step(mout.data_ptr(), x.data_ptr(), noise_by_i[i].data_ptr(), coefs[i].data_ptr(),
                                         None, None, None, 1, N, T, x.data_ptr(), x0.data_ptr(), s), "mh_ddpm_step")
@@ -439,7 +449,7 @@ class SpacedDiffusionHIP:
         i = int(ti[0])
         c = mk["c"].to(dev, torch.float32).contiguous()
         y = mk["y"].to(dev, torch.float32).contiguous()
-        band = dit.band_from_mask(mk.get("attn_mask"), T)
+        band, open_from = dit.band_from_mask(mk.get("attn_mask"), T)
         noise = (torch.randn_like(x) if noise is None else noise.to(dev, torch.float32)).contiguous()
         coef = self.coef_table()[i].to(dev).contiguous()
         t32 = torch.full((N,), self.timestep_map[i], dtype=torch.int32, device=dev)
@@ -449,7 +459,7 @@ class SpacedDiffusionHIP:
         s = torch.cuda.current_stream(dev).cuda_stream
         lib = dit.lib
         _lib.check(lib.mh_dit_forward_cfg(C.byref(dit.cfg), C.byref(dit.w), x.data_ptr(), t32.data_ptr(), c.data_ptr(),
-                                          y.data_ptr(), float(mk.get("cfg_scale", 1.0)), band, N, T, mout.data_ptr(),
+                                          y.data_ptr(), float(mk.get("cfg_scale", 1.0)), band, open_from, N, T, mout.data_ptr(),
                                           ws.data_ptr(), ws.numel(), s), "mh_dit_forward_cfg")
         if isinstance(denoised_fn, SliderInpaintSpec):     # eps -> x0 | in-paint + slider ends | posterior, all on the device
             _lib.check(lib.mh_ddpm_step(mout.data_ptr(), x.data_ptr(), noise.data_ptr(), coef.data_ptr(), None, None,

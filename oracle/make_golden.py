@@ -403,12 +403,16 @@ def pipeline_case():
     for tag, kk, seed in (("", k, c["noise_seed"]),
                           ("_short", dict(k, timesteps=[2] + [0] * 9, refine_iters=1), c["noise_seed"] + 1),
                           ("_sliders", k, c["noise_seed"] + 2),
-                          ("_sliders_short", dict(k, timesteps=[2] + [0] * 9, refine_iters=1), c["noise_seed"] + 3)):
+                          ("_sliders_short", dict(k, timesteps=[2] + [0] * 9, refine_iters=1), c["noise_seed"] + 3),
+                          # pad_sequence: every window padded to max_seq_len, the pad positions attendable (:186-193)
+                          ("_pad_short", dict(k, timesteps=[2] + [0] * 9, refine_iters=1, pad_sequence=True), c["noise_seed"] + 4),
+                          ("_pad_sliders", dict(k, pad_sequence=True), c["noise_seed"] + 5)):
         rng = np.random.default_rng(seed)
         noise = []
         for (a, b) in pipeline_windows(c["T"], kk["max_seq_len"], kk["overlap_buffer"]):
+            width = kk["max_seq_len"] if kk.get("pad_sequence") else b - a
             for _ in range(kk["timesteps"][0] + kk["refine_iters"]):
-                noise.append(torch.from_numpy(rng.standard_normal((2, 2, b - a)).astype(np.float32)))
+                noise.append(torch.from_numpy(rng.standard_normal((2, 2, width)).astype(np.float32)))
         out["positions" + tag] = rh.reference_pipeline_positions(ref, seq_x, seq_o, seq_c, cv, ucv, noise,
                                                                  start_time=start_time, end_time=end_time,
                                                                  sliders=sliders if "sliders" in tag else (), **kk).numpy()

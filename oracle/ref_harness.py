@@ -242,7 +242,8 @@ def reference_ddpm(model, diffusion, z, c, y, cfg_scale, attn_mask, noise_list):
 
 def reference_pipeline_positions(model, seq_x, seq_o, seq_c, class_vector, unk_class_vector, noise_list, *, timesteps,
                                  seq_len, max_seq_len, overlap_buffer, cfg_scale, refine_iters=0, start_time=None,
-                                 end_time=None, diffusion_steps=1000, noise_schedule="squaredcos_cap_v2", sliders=()):
+                                 end_time=None, diffusion_steps=1000, noise_schedule="squaredcos_cap_v2", sliders=(),
+                                 pad_sequence=False):
     """The reference's own `DiffisionPipeline.generate` (diffusion_pipeline.py:111-287) driven from the tensors that
     `events_to_sequence` returns: the object is built without its constructor, `events_to_sequence`,
     `get_class_vector` and `events_with_pos` are replaced by stand-ins that hand the given tensors through (Event
@@ -261,7 +262,7 @@ def reference_pipeline_positions(model, seq_x, seq_o, seq_c, class_vector, unk_c
     pipe.diffusion_steps, pipe.noise_schedule = diffusion_steps, noise_schedule
     pipe.seq_len, pipe.max_seq_len, pipe.overlap_buffer = seq_len, max_seq_len, overlap_buffer
     pipe.timesteps, pipe.cfg_scale, pipe.refine_iters = list(timesteps), cfg_scale, refine_iters
-    pipe.random_init, pipe.types_first, pipe.pad_sequence = False, False, False
+    pipe.random_init, pipe.types_first, pipe.pad_sequence = False, False, bool(pad_sequence)
     pipe.start_time, pipe.end_time = start_time, end_time
     calls = []
 

@@ -192,7 +192,7 @@ def test_dit_b_full_size_properties():
     assert not torch.equal(a[:, :, 990:], b[:, :, 990:])
 
 
-@pytest.mark.parametrize("variant", ["short", "full", "sliders_short", "sliders"])
+@pytest.mark.parametrize("variant", ["short", "full", "sliders_short", "sliders", "pad_short", "pad_sliders"])
 def test_window_pipeline_matches_reference_golden(variant):
     """Row a14: the reference's `DiffisionPipeline.generate` between `events_to_sequence` and `events_with_pos`
     (3 overlapping windows, in-paint masks incl. start / end time, DDPM steps + refine steps per window, CFG) vs
@@ -203,6 +203,8 @@ def test_window_pipeline_matches_reference_golden(variant):
              1.7 px there): median < 0.1 px, 90 % < 1 px, max inside the 5e-2 (12.8 px) bound of the 100-step loop test.
       sliders_short / sliders: the same two runs with ~25 synthetic sliders whose end points `denoised_fn` re-projects
              onto their paths every step (diffusion_pipeline.py:208-220) -- on the device here, inside the DDPM graph.
+      pad_short / pad_sliders: `pad_sequence=True` (:186-193): the last window (44 real points) is padded to 160 and the pad
+             positions stay attendable, as in the reference (its key_padding_mask never reaches the attention).
     Points outside [start_time, end_time] keep the given positions."""
     import json
 
@@ -219,7 +221,7 @@ def test_window_pipeline_matches_reference_golden(variant):
     cv[c["classes"]] = 1
     ucv[c["null_classes"]] = 1
     k = dict(c["knobs"])
-    seed, key = c["noise_seed"] + {"full": 0, "short": 1, "sliders": 2, "sliders_short": 3}[variant], "positions"
+    seed, key = c["noise_seed"] + {"full": 0, "short": 1, "sliders": 2, "sliders_short": 3, "pad_short": 4, "pad_sliders": 5}[variant], "positions"
     key = "positions" if variant == "full" else "positions_" + variant
     sliders = synthetic_sliders(c["T"], c["point_seed"] + 1) if "sliders" in variant else None
     if "short" in variant:
@@ -227,7 +229,7 @@ def test_window_pipeline_matches_reference_golden(variant):
     pipe = DiffusionPipelineHIP(dit, timesteps=k["timesteps"], seq_len=k["seq_len"], max_seq_len=k["max_seq_len"],
                                 overlap_buffer=k["overlap_buffer"], cfg_scale=k["cfg_scale"], refine_model=dit,
                                 refine_iters=k["refine_iters"], start_time=float(g["start_time"]),
-                                end_time=float(g["end_time"]))
+                                end_time=float(g["end_time"]), pad_sequence="pad" in variant)
     rng = np.random.default_rng(seed)
 
     def noise_source(n, shape):
@@ -242,8 +244,9 @@ def test_window_pipeline_matches_reference_golden(variant):
     if sliders is not None:
         # the re-projection really moved the slider ends: the run without sliders leaves them somewhere else
         ends = [s.end_index for s in sliders]
-        plain = torch.from_numpy(g["positions_short" if "short" in variant else "positions"])
-        assert (want[:, ends] - plain[:, ends]).abs().max(0).values.median().item() > 5
+        if "pad" not in variant:
+            plain = torch.from_numpy(g["positions_short" if "short" in variant else "positions"])
+            assert (want[:, ends] - plain[:, ends]).abs().max(0).values.median().item() > 5
         print(f"   slider ends: max err {err[ends].max().item():.4f} px over {len(ends)} sliders")
     if "short" in variant:
         assert err.max().item() < 0.05

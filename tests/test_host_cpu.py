@@ -165,10 +165,10 @@ def test_band_mask_recovery_and_inpaint():
     from oracle.dit import band_mask
     f = DiTHIP.band_from_mask
     self = type("X", (), {"_band_cache": {}})()
-    assert f(self, None, 10) == 0
-    assert f(self, band_mask(300, 128), 300) == 128
-    assert f(self, band_mask(96, 128), 96) == 0
-    assert f(self, band_mask(200, 7), 200) == 7
+    assert f(self, None, 10) == (0, 0)
+    assert f(self, band_mask(300, 128), 300) == (128, 0)
+    assert f(self, band_mask(96, 128), 96) == (0, 0)
+    assert f(self, band_mask(200, 7), 200) == (7, 0)
     bad = band_mask(200, 7)
     bad[100, 100] = True
     with pytest.raises(NotImplementedError):
@@ -434,3 +434,24 @@ def test_window_scheduler_hands_per_window_conditioning_to_the_encoder():
     with pytest.raises(ValueError):
         SequentialWindowScheduler(model, tok).run([SongJob(frames=songs[0], prompt_fn=jobs[0].prompt_fn, on_result=lambda *a: None,
                                                              generate_kwargs=dict(max_length=24, do_sample=False))])
+
+
+def test_band_mask_with_padding_round_trips_through_the_mask_analysis():
+    """BandMask(open_from=) builds exactly the mask the reference pads (diffusion_pipeline.py:146-148 + :190), and the
+    analysis of a foreign (T, T) tensor recovers (band, open_from) from it or refuses."""
+    from mapperatorinator_amd.dit import BandMask, DiTHIP
+    T, real, band = 96, 70, 16
+    idx = torch.arange(real)
+    inner = ~((idx[:, None] >= idx[None, :] - band) & (idx[:, None] < idx[None, :] + band))     # the reference's band, True = masked
+    ref = torch.nn.functional.pad(inner, (0, T - real, 0, T - real), value=False)
+    ours = BandMask(T, band, open_from=real)
+    assert torch.equal(ours.to_tensor(), ref) and (ours.band, ours.open_from) == (band, real)
+    analyse = DiTHIP.band_from_mask
+    assert analyse(None, ref, T) == (band, real)
+    assert analyse(None, inner, real) == (band, 0)
+    assert analyse(None, torch.zeros(T, T, dtype=torch.bool), T) == (0, 0)
+    assert analyse(None, BandMask(T, 200), T) == (0, 0)               # a band wider than the window masks nothing
+    broken = ref.clone()
+    broken[3, 60] = False
+    with pytest.raises(NotImplementedError):
+        analyse(None, broken, T)
