@@ -239,6 +239,227 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(AttnArgs p) {
   }
 }
 
+// ---- flash2: bf16, 128 queries per workgroup (32 per wave), S computed TRANSPOSED ----------------------------------------
+// The kernel above multiplies 16 queries per wave: every 16 MFMAs read 16 K / V fragments from LDS and push P through a
+// wave-private LDS patch (2 KB written with 2-byte stores, 2 KB read) -- LDS and VALU, not the matrix cores, bound it
+// (MfmaUtil 7-9 % on the encoder).  Here
+//   S^T = K Q^T   (K fragment = the MFMA's A operand, Q fragment = B): lane (l15, lg) holds, for QUERY l15 of a 16-query
+//                 block, the scores of KEYS kb*16 + lg*4 + r -- 16 keys per lane and query block: the row maximum / sum are
+//                 in-lane reductions plus 2 shuffles (xor 16, 32) instead of 4, and the sum is only reduced once at the end;
+//   O^T = V^T P^T (V^T fragment = A, P = B): those very registers, packed to bf16, ARE the B fragment of the PV product --
+//                 an MFMA does not care in which order its 32 k-slots enumerate the keys as long as both operands agree,
+//                 so slot lg*8 + j stands for key (2s + j/4)*16 + lg*4 + j%4 and the V^T fragment is two 8-byte reads at
+//                 those keys.  No P patch, no barrier, and the result lane (l15 = query) owns the same query as the
+//                 softmax statistics: the rescale needs no shuffle.
+// Two query blocks per wave share every K and V^T fragment: per 64-key tile 32 MFMAs on 16 KB of fragment reads (was 16 on
+// 20 KB).  Scores are kept in the log2 domain (one FMA applies scale and bias), a tile that needs no masking skips it.
+template <int QB>
+__global__ __launch_bounds__(256) void flash2_bf16_kernel(AttnArgs p) {
+  using T = bf16_t;
+  constexpr int RS = 64 * 2 + 16;           // padded LDS row stride (bytes)
+  constexpr int WQ = QB * 16;               // queries per wave
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Ks = smem;                           // [64 keys][64 d]
+  char* Vts = smem + 64 * RS;                // [64 d][64 keys]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int Lq = p.Lq, Lk = p.Lk;
+  const int qb0 = qt * 4 * WQ;
+  const int q0w = qb0 + wid * WQ;
+  const int l15 = lane & 15, lg = lane >> 4;
+  constexpr float kLog2e = 1.4426950408889634f;
+
+  // Q fragments (B operand: row = query l15, k chunk = lg) straight from global memory
+  bf16x8_t qf[QB][2];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    int qr = q0w + qb * 16 + l15;
+    qr = qr < Lq ? qr : Lq - 1;
+    const char* qp = (const char*)p.q + (long)b * p.q_bs + (long)qr * p.q_rs + (long)(h * 64 + lg * 8) * 2;
+    qf[qb][0] = *reinterpret_cast<const bf16x8_t*>(qp);
+    qf[qb][1] = *reinterpret_cast<const bf16x8_t*>(qp + 64);
+  }
+  f32x4_t o[QB][4];                          // O^T: o[qb][db][r] = O[query qb*16 + l15][d = db*16 + lg*4 + r]
+  float m[QB], lsum[QB];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    m[qb] = -INFINITY; lsum[qb] = 0.f;
+#pragma unroll
+    for (int db = 0; db < 4; ++db) o[qb][db] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
+
+  // key tiles this query block can see (same rules as flash_attn_kernel)
+  int t_lo = 0, t_hi = (Lk - 1) / 64;
+  const int rel_lo = p.band > 0 ? -(p.band - 1) : (p.band < 0 ? p.band : -(1 << 30));
+  const int rel_hi = p.band > 0 ? p.band : (p.band < 0 ? -p.band : (1 << 30));
+  if (p.band != 0) {
+    int klo = qb0 + rel_lo;
+    klo = klo < 0 ? 0 : klo;
+    int khi = qb0 + 4 * WQ - 1 + rel_hi;
+    khi = khi > Lk - 1 ? Lk - 1 : khi;
+    t_lo = klo / 64;
+    t_hi = khi / 64;
+  }
+  if (p.causal) {
+    int khi = p.q_pos0 + qb0 + 4 * WQ - 1;
+    khi = khi > Lk - 1 ? Lk - 1 : khi;
+    t_hi = khi / 64;
+  }
+  const int open_from = (p.band != 0 && p.open_from > 0) ? p.open_from : (1 << 30);
+  int t_last = t_hi, t_open = 1 << 30;
+  if (open_from < Lk) {
+    t_last = (Lk - 1) / 64;
+    if (qb0 + 4 * WQ - 1 >= open_from) { t_lo = 0; t_hi = t_last; }
+    else t_open = open_from / 64;
+  }
+
+  const char* kbase = (const char*)p.k + (long)b * p.k_bs + (long)h * p.k_hs;
+  const char* vbase = (const char*)p.vt + (long)b * p.vt_bs + (long)h * p.vt_hs;
+  const float* bh = p.bias ? p.bias + (long)h * p.bias_hs + p.bias_center : nullptr;
+  const uint8_t* mrow = p.key_mask ? p.key_mask + (long)b * p.mask_ld : nullptr;
+  const float c2 = p.scale * kLog2e;
+
+  for (int kt = t_lo; kt <= t_last; ++kt) {
+    if (kt > t_hi && kt < t_open) continue;      // (block-uniform) between the band and the pad columns
+    const int kv0 = kt * 64;
+    // ---- stage K tile [key][d] and V^T tile [d][key]: 2 + 2 16-byte chunks per thread ----
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + 256 * i;
+      const int row = idx >> 3, ch = idx & 7;
+      int kr = kv0 + row;
+      kr = kr < Lk ? kr : Lk - 1;
+      const uint4 kv = *reinterpret_cast<const uint4*>(kbase + (long)kr * p.k_rs + ch * 16);
+      const uint4 vv = *reinterpret_cast<const uint4*>(vbase + ((long)row * p.Lkpad + kv0) * 2 + ch * 16);
+      *reinterpret_cast<uint4*>(Ks + row * RS + ch * 16) = kv;
+      *reinterpret_cast<uint4*>(Vts + row * RS + ch * 16) = vv;
+    }
+    __syncthreads();
+
+    // ---- S^T = K Q^T: st[kb][qb][r] = score(key kv0 + kb*16 + lg*4 + r, query q0w + qb*16 + l15) ----
+    f32x4_t st[4][QB];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) st[kb][qb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(Ks + (kb * 16 + l15) * RS + (ks * 32 + lg * 8) * 2);
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) st[kb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qb][ks], st[kb][qb], 0, 0, 0);
+      }
+
+    // ---- log2-domain scores: s2 = s * scale * log2(e) + bias * log2(e); masks only where this tile needs them ----
+    const int qlo = p.q_pos0 + q0w, qhi = qlo + WQ - 1;                       // positions of this wave's queries
+    bool need_mask = (kv0 + 63 >= Lk) || mrow != nullptr;
+    if (p.band != 0) need_mask = need_mask || (kv0 - qhi < rel_lo) || (kv0 + 63 - qlo > rel_hi);
+    if (p.causal) need_mask = need_mask || (kv0 + 63 > qlo);
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      const int qg = q0w + qb * 16 + l15;
+      const int qpos = p.q_pos0 + (qg < Lq ? qg : Lq - 1);
+      if (bh) {
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int kg = kv0 + kb * 16 + lg * 4 + r;
+            int idx = p.bias_sign * ((kg < Lk ? kg : Lk - 1) - qpos);
+            idx = idx < p.bias_min ? p.bias_min : (idx > p.bias_max ? p.bias_max : idx);
+            st[kb][qb][r] = st[kb][qb][r] * c2 + bh[idx] * kLog2e;
+          }
+      } else {
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) st[kb][qb][r] *= c2;
+      }
+      if (need_mask) {                                                          // wave-uniform
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int kg = kv0 + kb * 16 + lg * 4 + r;
+            const int rel = kg - qpos;
+            bool ok = kg < Lk;
+            if (mrow) ok = ok && (kg >= p.mask_len || mrow[kg < p.mask_len ? kg : p.mask_len - 1] != 0);
+            if (p.band != 0) ok = ok && (((rel >= rel_lo) && (rel <= rel_hi)) || kg >= open_from || qpos >= open_from);
+            if (p.causal) ok = ok && (rel <= 0);
+            st[kb][qb][r] = ok ? st[kb][qb][r] : -INFINITY;
+          }
+      }
+      // ---- online softmax of query (qb, l15): 16 keys in this lane, the other 48 in lanes l15 + 16 / 32 / 48 ----
+      float mx = -INFINITY;
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[kb][qb][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mn = fmaxf(m[qb], mx);
+      const float mu = mn == -INFINITY ? 0.f : mn;          // a fully masked row so far: keep exp2(-inf - 0) = 0, not NaN
+      const float alpha = __builtin_amdgcn_exp2f(m[qb] - mu);     // raw v_exp_f32 (exp2f() adds a denormal path: 11 more instructions each)
+      m[qb] = mn;
+      float sum = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pv = __builtin_amdgcn_exp2f(st[kb][qb][r] - mu);
+          st[kb][qb][r] = pv;
+          sum += pv;
+        }
+      lsum[qb] = lsum[qb] * alpha + sum;                    // this lane's keys only: reduced over lg once, at the end
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        o[qb][db][0] *= alpha; o[qb][db][1] *= alpha; o[qb][db][2] *= alpha; o[qb][db][3] *= alpha;
+      }
+    }
+
+    // ---- O^T += V^T P^T: k-slot lg*8 + j of step s <-> key (2s + j/4)*16 + lg*4 + j%4 (both operands) ----
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      bf16x8_t pf[QB];
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) {
+        const uint32_t w0 = pack_bf16x2(st[2 * s2][qb][0], st[2 * s2][qb][1]), w1 = pack_bf16x2(st[2 * s2][qb][2], st[2 * s2][qb][3]);
+        const uint32_t w2 = pack_bf16x2(st[2 * s2 + 1][qb][0], st[2 * s2 + 1][qb][1]), w3 = pack_bf16x2(st[2 * s2 + 1][qb][2], st[2 * s2 + 1][qb][3]);
+        const uint4 pk = make_uint4(w0, w1, w2, w3);
+        pf[qb] = __builtin_bit_cast(bf16x8_t, pk);
+      }
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        const char* vr = Vts + (db * 16 + l15) * RS + (2 * s2 * 16 + lg * 4) * 2;
+        const uint2 v0 = *reinterpret_cast<const uint2*>(vr);
+        const uint2 v1 = *reinterpret_cast<const uint2*>(vr + 32);
+        const uint4 vk = make_uint4(v0.x, v0.y, v1.x, v1.y);
+        const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, vk);
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) o[qb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qb], o[qb][db], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- normalise and store: 4 consecutive d per lane (a fully masked query row -- a left-pad position -- yields zeros) ----
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    float l = lsum[qb];
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const int qg = q0w + qb * 16 + l15;
+    if (qg >= Lq) continue;
+    const float inv = l > 0.f ? 1.0f / l : 0.f;
+    T* op = reinterpret_cast<T*>((char*)p.out + (long)b * p.out_bs + (long)qg * p.out_rs) + h * 64 + lg * 4;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+      *reinterpret_cast<uint2*>(op + db * 16) = make_uint2(pack_bf16x2(o[qb][db][0] * inv, o[qb][db][1] * inv),
+                                                           pack_bf16x2(o[qb][db][2] * inv, o[qb][db][3] * inv));
+  }
+}
+
 // V [B][H][Lk][64] (row stride 64) -> V^T [B][H][64][Lkpad]; pad columns are left untouched (zeroed once by the caller)
 template <typename T>
 __global__ __launch_bounds__(256) void transpose_v_kernel(const T* __restrict__ v, long v_bs, long v_hs, int Lk, T* __restrict__ vt,
@@ -268,6 +489,11 @@ int attention_general(const AttnArgs& a, int B, int H, int dtype, hipStream_t s)
                  a.vt_bs % 16 == 0 && a.vt_hs % 16 == 0,
              "attention: strides must be multiples of 16 bytes");
   const int es = dtype == MH_BF16 ? 2 : 4;
+  if (dtype == MH_BF16 && option(OPT_ATTN_FLASH2) != 0 && a.out_rs % 8 == 0 && a.out_bs % 8 == 0) {
+    // bf16: transposed-S kernel, 128 queries per workgroup (option attn_flash2 = 0: the 64-query kernel below)
+    hipLaunchKernelGGL(flash2_bf16_kernel<2>, dim3(ceil_div(a.Lq, 128), H, B), dim3(256), (size_t)128 * (64 * 2 + 16), s, a);
+    return check_launch("flash2_bf16_kernel");
+  }
   dim3 grid(ceil_div(a.Lq, 64), H, B), block(256);
   const size_t smem = (size_t)(128 + 64) * (64 * es + 16);
   if (dtype == MH_BF16)
