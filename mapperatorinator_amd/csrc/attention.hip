@@ -356,11 +356,32 @@ __global__ __launch_bounds__(256) void flash2_bf16_kernel(AttnArgs p) {
     bool need_mask = (kv0 + 63 >= Lk) || mrow != nullptr;
     if (p.band != 0) need_mask = need_mask || (kv0 - qhi < rel_lo) || (kv0 + 63 - qlo > rel_hi);
     if (p.causal) need_mask = need_mask || (kv0 + 63 > qlo);
+    // Relative bias, fast path (bias_sign = +1, tile away from the table's ends): rel = key - query of element (kb, qb, r) is
+    // rel0 + 16 (kb - qb) + r with rel0 = kv0 + lg*4 - (q_pos0 + q0w + l15): the 4 r values are CONSECUTIVE table entries and
+    // query block qb's key block kb + 1 reads what block qb + 1's kb + ... -- 4 + QB - 1 unaligned 16-byte loads per lane
+    // instead of 16 QB scalar gathers with their index arithmetic (the kernel is VALU-bound: VALUBusy 88 %).
+    const int rel0 = kv0 + lg * 4 - (p.q_pos0 + q0w + l15);
+    const bool bias_fast = bh && p.bias_sign == 1 && !need_mask && (rel0 - 16 * (QB - 1) >= p.bias_min) && (rel0 + 51 <= p.bias_max);
+    float4 bq[4 + QB - 1];
+    if (bias_fast) {
+#pragma unroll
+      for (int g = 0; g < 4 + QB - 1; ++g) {
+        const float4 t = *reinterpret_cast<const float4*>(bh + rel0 + 16 * (g - (QB - 1)));      // group g <-> kb - qb = g - (QB - 1)
+        bq[g] = make_float4(t.x * kLog2e, t.y * kLog2e, t.z * kLog2e, t.w * kLog2e);
+      }
+    }
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
       const int qg = q0w + qb * 16 + l15;
       const int qpos = p.q_pos0 + (qg < Lq ? qg : Lq - 1);
-      if (bh) {
+      if (bias_fast) {
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+          const float4 t = bq[kb - qb + QB - 1];
+          st[kb][qb][0] = st[kb][qb][0] * c2 + t.x; st[kb][qb][1] = st[kb][qb][1] * c2 + t.y;
+          st[kb][qb][2] = st[kb][qb][2] * c2 + t.z; st[kb][qb][3] = st[kb][qb][3] * c2 + t.w;
+        }
+      } else if (bh) {
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
