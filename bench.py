@@ -312,7 +312,7 @@ def main():
                         "coords_all_gather": bool(use_dist)},
         }
         aux["diffusion_steps_per_s_per_chunk"] = aux["diffusion"]["batched"]["steps_per_s_per_chunk"]
-        if not args.no_config5 and rank == 0:
+        if not args.no_config5 and rank == 0 and world == 1:   # (single-GPU extras: the other ranks of a multi-GPU run would only wait)
             # BASELINE configs[4]: DiT-B (osu_diffusion/utils/models.py:392), the same 32 chunks as one denoiser batch
             db, hb, nb = DIT_PRESETS["DiT-B"]
             dit_b = DiTHIP(random_dit_state_dict(db, hb, seed=0), db, hb, nb, device=dev)
@@ -498,7 +498,7 @@ def main():
         del m1
 
     # ---- the Whisper-family backbone of the released V30-V32 checkpoints (varwhisper small: d 768, 12 + 12 layers, 1024 frames) ----
-    if not args.no_extras and not args.no_config5:
+    if not args.no_extras and not args.no_config5 and world == 1:
         try:
             from mapperatorinator_amd.testing import random_varwhisper_state_dict
             from mapperatorinator_amd.whisper_engine import VARWHISPER_PRESETS
@@ -535,7 +535,7 @@ def main():
             print(f"whisper-family pass failed: {e!r}", file=sys.stderr)
 
     # ---- BASELINE configs[4]: whole 3-minute songs, KV-cached, through the window scheduler (tools/long_song_bench.py) ----
-    if not args.no_extras and not args.no_config5:
+    if not args.no_extras and not args.no_config5 and world == 1:
         try:
             import importlib.util
             spec = importlib.util.spec_from_file_location("long_song_bench", os.path.join(ROOT, "tools", "long_song_bench.py"))
