@@ -399,8 +399,9 @@ def main():
         "bound": "hbm", "kernel": "dec_cross_attn_q_kernel (decode cross-attention over the encoder K/V incl. its query projection)",
         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
         "traffic": None,   # PMC FETCH_SIZE/WRITE_SIZE need rocprofv3 around the process: not measurable from inside this run
-        "traffic_source": "profiles/r03_pmc_hbm_traffic.txt (rocprofv3 --pmc pass of this command, builder-run): fetch / "
-                          "algorithmic bytes of this kernel ~1.0",
+        "traffic_source": "profiles/r03_pmc_hbm_traffic.txt / r03_pmc_cross_attn.json (rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE passes of this "
+                          "command, builder-run, one 32-row chain: 126.24 MB fetched + 0.05 MB written per 122.98 MB launch = 1.027 x "
+                          "algorithmic; the counter passes cannot run inside this process)",
         "how": ("in situ: mean (last workgroup end - first workgroup start) over the launches of one extra decode pass, "
                 "device wall clock; the other chain's kernels run beside it" if in_situ_us else "stand-alone probe"),
         "rows_per_launch": use_rows, "alg_bytes_per_launch": use_rows * bytes_per_row, "us_per_launch": round(use_us, 2),
