@@ -40,7 +40,7 @@ static OptionSlot g_options[OPT_COUNT] = {
     {"attn_small_max_wgs", "MH_ATTN_SMALL_MAX_WGS", 1024, false}, // fp32 attention at L <= 256: key-split latency kernel up to this many workgroups, flash kernel beyond
     {"dit_split3_min_rows", "MH_DIT_SPLIT3_MIN_ROWS", 2048, false},   // DiT denoiser batches of >= this many rows (N*T) run their big GEMMs as bf16 x 3 (0 = never)
     {"decode_self_rows", "MH_DECODE_SELF_ROWS", 1, false},       // rows of one head per self-attention workgroup (1, 2, 4): they share the head's q / k / v weight slice
-    {"gemm_glds", "MH_GEMM_GLDS", 2, false},                     // bf16 GEMM operands by LDS-DMA (global_load_lds): 2 = three-stage 256x128 tiles where the grid is big enough, 1 = two-stage 128x128 only, 0 = register staging
+    {"gemm_glds", "MH_GEMM_GLDS", 3, false},                     // bf16 GEMM operands by LDS-DMA (global_load_lds): 3 = three-stage kernel, 256x128 tiles or 128x128 where fewer than 128 of the big ones exist; 2 = 256x128 only; 1 = two-stage 128x128 only; 0 = register staging
     {"gemm_lds_pad", "MH_GEMM_LDS_PAD", 0, false},               // debugging: extra bytes of dynamic LDS per GEMM workgroup (fewer workgroups per CU)
     {"dit_s3_fused_ln", "MH_DIT_S3_FUSED_LN", 0, false},         // 1: bf16 x 3 DiT GEMMs take LayerNorm + modulate inside their A load (default: stand-alone pass before them, measured faster)
     {"gemm_tile256_min", "MH_GEMM_TILE256_MIN", 96, false},      // the three-stage 256x128 bf16 tile (one workgroup per CU) is used from this many tiles on (batched DiT-S bf16: 171.6 ms at 192, 167.4 at 96, 168.6 at 48)

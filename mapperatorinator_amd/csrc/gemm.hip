@@ -545,12 +545,15 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmP p) {
 // flight), so two stages (96 KB) are always on their way.  One workgroup per CU (144 KB of LDS), two waves per SIMD:
 // one wave's ds_reads run under the other's MFMAs.  Same XOR-swizzled 128-byte rows, same fragment reads, same
 // epilogues as the 128 x 128 LDS-DMA form.
-template <int EPI>
+// MI = 4: 256 x 128 tile (wave tile 64 x 64); MI = 2: 128 x 128 tile (wave tile 32 x 64) for grids that would leave most CUs
+// idle at 256 rows per tile (the DiT's N = 384 projections: 96 -> 192 workgroups).
+template <int EPI, int MI>
 __global__ __launch_bounds__(512) void gemm_glds3_kernel(GemmP p) {
   using T = bf16_t;
-  constexpr int BM = 256, BN = 128, BK = 64, KM = 32, NST = 3;
+  constexpr int BM = 64 * MI, BN = 128, BK = 64, KM = 32, NST = 3;
   constexpr int kRowStride = 128, kStage = (BM + BN) * kRowStride;
-  constexpr int WM = 64, WN = 64, MI = 4, NI = 4;
+  constexpr int WM = 16 * MI, WN = 64, NI = 4;
+  constexpr int NA = MI;                     // A-tile DMA instructions per wave and stage (BM / 8 row groups over 8 waves)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wr = wid >> 1, wc = wid & 1;
@@ -582,32 +585,32 @@ __global__ __launch_bounds__(512) void gemm_glds3_kernel(GemmP p) {
   // in front of the MFMAs, serialising the fragment reads below with them).
   typedef const __attribute__((address_space(1))) void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
-  const char* srcp[6];
+  const char* srcp[NA + 2];
   {
     const int r8 = lane >> 3;
     const long k_off = (long)(((lane & 7) ^ r8) * 8) * sizeof(T);     // pre-swizzled source chunk (tile row & 7 == r8)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NA; ++i) {
       int ra_ = m0 + (i * 8 + wid) * 8 + r8; ra_ = ra_ < p.M ? ra_ : p.M - 1;
       srcp[i] = p.A + (long)ra_ * p.lda_b + k_off;
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       int rb_ = n0 + (i * 8 + wid) * 8 + r8; rb_ = rb_ < p.N ? rb_ : p.N - 1;
-      srcp[4 + i] = p.W + (long)rb_ * p.ldw_b + k_off;
+      srcp[NA + i] = p.W + (long)rb_ * p.ldw_b + k_off;
     }
   }
   auto issue = [&](int st) {          // the NEXT K tile (the pointers advance)
     char* base = smem + st * kStage;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NA; ++i) {
       __builtin_amdgcn_global_load_lds((gptr_t)srcp[i], (lptr_t)(base + (i * 8 + wid) * 1024), 16, 0, 0);
       srcp[i] += BK * sizeof(T);
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      __builtin_amdgcn_global_load_lds((gptr_t)srcp[4 + i], (lptr_t)(base + BM * kRowStride + (i * 8 + wid) * 1024), 16, 0, 0);
-      srcp[4 + i] += BK * sizeof(T);
+      __builtin_amdgcn_global_load_lds((gptr_t)srcp[NA + i], (lptr_t)(base + BM * kRowStride + (i * 8 + wid) * 1024), 16, 0, 0);
+      srcp[NA + i] += BK * sizeof(T);
     }
   };
 
@@ -623,7 +626,8 @@ __global__ __launch_bounds__(512) void gemm_glds3_kernel(GemmP p) {
   issue(0);
   if (nk > 1) {
     issue(1);
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");    // stage 0 of this wave has landed, stage 1 may still fly
+    if constexpr (MI == 4) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");    // stage 0 of this wave has landed, stage 1 may still fly
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   } else {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
@@ -645,8 +649,10 @@ __global__ __launch_bounds__(512) void gemm_glds3_kernel(GemmP p) {
     const uint32_t pa = lds0 + st * kStage + a_off + coff, pb = lds0 + st * kStage + b_off + coff;
     asm volatile("ds_read_b128 %0, %1" : "=v"(af[0]) : "v"(pa));
     asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(af[1]) : "v"(pa));
-    asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(af[2]) : "v"(pa));
-    asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(af[3]) : "v"(pa));
+    if constexpr (MI == 4) {
+      asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(af[2]) : "v"(pa));
+      asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(af[3]) : "v"(pa));
+    }
     asm volatile("ds_read_b128 %0, %1" : "=v"(bf[0]) : "v"(pb));
     asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(bf[1]) : "v"(pb));
     asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(bf[2]) : "v"(pb));
@@ -672,10 +678,12 @@ __global__ __launch_bounds__(512) void gemm_glds3_kernel(GemmP p) {
   for (int kt = 0; kt + 2 < nk; ++kt) {            // steady state: a DMA every step
     issue(nxt2);
     ldfrag(cur, 1, a1, b1);
-    G3_WAIT("s_waitcnt lgkmcnt(8)");               // a0 / b0 (read one phase ago) are in
+    if constexpr (MI == 4) G3_WAIT("s_waitcnt lgkmcnt(8)");               // a0 / b0 (read one phase ago) are in
+    else G3_WAIT("s_waitcnt lgkmcnt(6)");
     mma(a0, b0);
     __builtin_amdgcn_sched_barrier(0);
-    G3_WAIT("s_waitcnt vmcnt(6) lgkmcnt(0)");      // a1 / b1 are in; stage kt + 1 of this wave has landed
+    if constexpr (MI == 4) G3_WAIT("s_waitcnt vmcnt(6) lgkmcnt(0)");      // a1 / b1 are in; stage kt + 1 of this wave has landed
+    else G3_WAIT("s_waitcnt vmcnt(4) lgkmcnt(0)");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     cur = cur == NST - 1 ? 0 : cur + 1;
@@ -687,7 +695,8 @@ __global__ __launch_bounds__(512) void gemm_glds3_kernel(GemmP p) {
   }
   if (nk > 1) {                                    // step nk - 2: nothing left to request, step nk - 1 must have landed
     ldfrag(cur, 1, a1, b1);
-    G3_WAIT("s_waitcnt lgkmcnt(8)");
+    if constexpr (MI == 4) G3_WAIT("s_waitcnt lgkmcnt(8)");
+    else G3_WAIT("s_waitcnt lgkmcnt(6)");
     mma(a0, b0);
     __builtin_amdgcn_sched_barrier(0);
     G3_WAIT("s_waitcnt vmcnt(0) lgkmcnt(0)");
@@ -700,7 +709,8 @@ __global__ __launch_bounds__(512) void gemm_glds3_kernel(GemmP p) {
     __builtin_amdgcn_sched_barrier(0);
   }
   ldfrag(cur, 1, a1, b1);                          // last step
-  G3_WAIT("s_waitcnt lgkmcnt(8)");
+  if constexpr (MI == 4) G3_WAIT("s_waitcnt lgkmcnt(8)");
+  else G3_WAIT("s_waitcnt lgkmcnt(6)");
   mma(a0, b0);
   __builtin_amdgcn_sched_barrier(0);
   G3_WAIT("s_waitcnt lgkmcnt(0)");
@@ -830,10 +840,11 @@ __global__ __launch_bounds__(512) void gemm_glds3_kernel(GemmP p) {
   }
 }
 
-template <int EPI>
+template <int EPI, int MI>
 int launch_glds3(const GemmP& p, hipStream_t s) {
-  const int nbm = (p.M + 255) / 256, nbn = (p.N + 127) / 128;
-  hipLaunchKernelGGL((gemm_glds3_kernel<EPI>), dim3(nbm * nbn), dim3(512), 3 * (256 + 128) * 128, s, p);
+  constexpr int BM = 64 * MI;
+  const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + 127) / 128;
+  hipLaunchKernelGGL((gemm_glds3_kernel<EPI, MI>), dim3(nbm * nbn), dim3(512), 3 * (BM + 128) * 128, s, p);
   return check_launch("gemm_glds3_kernel");
 }
 
@@ -862,8 +873,10 @@ template <typename T, int EPI>
 bool prepare_epi() {
   bool ok = prepare_one<T, 128, 128, EPI>() && prepare_one<T, 64, 64, EPI>();
   if constexpr (sizeof(T) == 2)
-    ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds3_kernel<EPI>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (256 + 128) * 128) == hipSuccess;
+    ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds3_kernel<EPI, 4>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (256 + 128) * 128) == hipSuccess &&
+         hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds3_kernel<EPI, 2>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (128 + 128) * 128) == hipSuccess;
   if constexpr (EPI != MH_EPI_GEGLU) ok = ok && prepare_one<T, 32, 32, EPI>() && prepare_one<T, 16, 16, EPI>();   // GEGLU pairs two 16-col blocks per wave
   return ok;
 }
@@ -896,8 +909,12 @@ int dispatch_tile(const GemmP& p, hipStream_t s) {
       const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + 127) / 128);
       const bool vec_ok = p.N % 4 == 0 && p.ldc % 4 == 0 && (p.gate == nullptr || p.gate_ld % 4 == 0) &&
                           (EPI != MH_EPI_GEGLU || p.N % 8 == 0) && p.K % 64 == 0;
-      if (option(OPT_GEMM_GLDS) >= 2 && tiles256 >= option(OPT_GEMM_TILE256_MIN) && !p.stats_out && vec_ok)
-        return launch_glds3<EPI>(p, s);
+      if (option(OPT_GEMM_GLDS) >= 2 && tiles256 >= option(OPT_GEMM_TILE256_MIN) && !p.stats_out && vec_ok) {
+        // fewer 256-row tiles than half the CUs: the 128-row form of the same kernel doubles the workgroups (batched DiT-S bf16,
+        // N = 384: 96 -> 192 workgroups, 153 -> 137 ms per 100 steps; at 192 tiles -- DiT-B, N = 768 -- it loses, 294 -> 308)
+        if (tiles256 < 128 && option(OPT_GEMM_GLDS) >= 3) return launch_glds3<EPI, 2>(p, s);
+        return launch_glds3<EPI, 4>(p, s);
+      }
       if (option(OPT_GEMM_GLDS) != 0) return launch_gemm<T, 128, 128, EPI, false, true>(p, s);
     }
     return launch_gemm<T, 128, 128, EPI>(p, s);

@@ -34,8 +34,10 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
 }
 
 // x [rows, d] fp32; shift/scale: [n_batch, mod_ld] rows selected by row / rows_per_batch.  y: fp32 or bf16 (the operand
-// rounding of the DiT's bf16 mode happens here, after the fp32 arithmetic).
-template <typename T>
+// rounding of the DiT's bf16 mode happens here, after the fp32 arithmetic).  One wave per row; the row (d <= 256 * NC floats)
+// is read ONCE into registers -- mean, the centred sum of squares (same two-pass arithmetic as before, on the registers) and
+// the modulated output all come from that copy; the shift / scale vectors are requested with the row.
+template <typename T, int NC>
 __global__ __launch_bounds__(256) void ln_modulate_kernel(const float* __restrict__ x, int ldx,
                                                          const float* __restrict__ shift,
                                                          const float* __restrict__ scale, int mod_ld,
@@ -45,32 +47,41 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(const float* __restric
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const float* xr = x + (long)row * ldx;
-  float s = 0.f;
-  for (int i = lane * 4; i < d; i += 256) {
-    float4 v = *reinterpret_cast<const float4*>(xr + i);
-    s += v.x + v.y + v.z + v.w;
-  }
-  const float mean = wave_sum(s) / (float)d;
-  float ss = 0.f;
-  for (int i = lane * 4; i < d; i += 256) {
-    float4 v = *reinterpret_cast<const float4*>(xr + i);
-    float a = v.x - mean, b = v.y - mean, c = v.z - mean, e = v.w - mean;
-    ss += a * a + b * b + c * c + e * e;
-  }
-  const float rs = rsqrtf(wave_sum(ss) / (float)d + eps);
   const int bidx = row / rows_per_batch;
   const float* sh = shift + (long)bidx * mod_ld;
   const float* sc = scale + (long)bidx * mod_ld;
+  float4 v[NC], a[NC], b[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int i = lane * 4 + c * 256;
+    const int ic = i < d ? i : 0;                      // clamped address, value masked below
+    v[c] = *reinterpret_cast<const float4*>(xr + ic);
+    a[c] = *reinterpret_cast<const float4*>(sh + ic);
+    b[c] = *reinterpret_cast<const float4*>(sc + ic);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < NC; ++c)
+    if (lane * 4 + c * 256 < d) s += v[c].x + v[c].y + v[c].z + v[c].w;
+  const float mean = wave_sum(s) / (float)d;
+  float ss = 0.f;
+#pragma unroll
+  for (int c = 0; c < NC; ++c)
+    if (lane * 4 + c * 256 < d) {
+      const float p = v[c].x - mean, q = v[c].y - mean, r = v[c].z - mean, t = v[c].w - mean;
+      ss += p * p + q * q + r * r + t * t;
+    }
+  const float rs = rsqrtf(wave_sum(ss) / (float)d + eps);
   T* yr = y + (long)row * ldy;
-  for (int i = lane * 4; i < d; i += 256) {
-    float4 v = *reinterpret_cast<const float4*>(xr + i);
-    float4 a = *reinterpret_cast<const float4*>(sh + i);
-    float4 b = *reinterpret_cast<const float4*>(sc + i);
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int i = lane * 4 + c * 256;
+    if (i >= d) continue;
     float4 o;
-    o.x = (v.x - mean) * rs * (1.f + b.x) + a.x;
-    o.y = (v.y - mean) * rs * (1.f + b.y) + a.y;
-    o.z = (v.z - mean) * rs * (1.f + b.z) + a.z;
-    o.w = (v.w - mean) * rs * (1.f + b.w) + a.w;
+    o.x = (v[c].x - mean) * rs * (1.f + b[c].x) + a[c].x;
+    o.y = (v[c].y - mean) * rs * (1.f + b[c].y) + a[c].y;
+    o.z = (v[c].z - mean) * rs * (1.f + b[c].z) + a[c].z;
+    o.w = (v[c].w - mean) * rs * (1.f + b[c].w) + a[c].w;
     if constexpr (sizeof(T) == 4) {
       *reinterpret_cast<float4*>(yr + i) = o;
     } else {
@@ -95,15 +106,23 @@ int rmsnorm(const float* x, int ldx, const float* w, void* y, int ldy, int rows,
   return check_launch("rmsnorm_kernel");
 }
 
+template <typename T, int NC>
+static void launch_ln_modulate(const float* x, int ldx, const float* shift, const float* scale, int mod_ld, int rows_per_batch,
+                               void* y, int ldy, int rows, int d, float eps, hipStream_t s) {
+  hipLaunchKernelGGL((ln_modulate_kernel<T, NC>), dim3(ceil_div(rows, 4)), dim3(256), 0, s, x, ldx, shift, scale, mod_ld,
+                     rows_per_batch, (T*)y, ldy, rows, d, eps);
+}
+
 int ln_modulate(const float* x, int ldx, const float* shift, const float* scale, int mod_ld, int rows_per_batch,
                 void* y, int ldy, int rows, int d, float eps, int out_dtype, hipStream_t s) {
   MH_REQUIRE(d % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && mod_ld % 4 == 0, "ln_modulate: alignment");
-  if (out_dtype == MH_BF16)
-    hipLaunchKernelGGL(ln_modulate_kernel<bf16_t>, dim3(ceil_div(rows, 4)), dim3(256), 0, s, x, ldx, shift, scale, mod_ld,
-                       rows_per_batch, (bf16_t*)y, ldy, rows, d, eps);
-  else
-    hipLaunchKernelGGL(ln_modulate_kernel<float>, dim3(ceil_div(rows, 4)), dim3(256), 0, s, x, ldx, shift, scale, mod_ld,
-                       rows_per_batch, (float*)y, ldy, rows, d, eps);
+  MH_REQUIRE(d <= 1536, "ln_modulate: d = %d > 1536 (the row lives in registers)", d);
+  const int nc = ceil_div(d, 256);
+  const bool lo = out_dtype == MH_BF16;
+#define MH_LN_CASE(NC) case NC: if (lo) launch_ln_modulate<bf16_t, NC>(x, ldx, shift, scale, mod_ld, rows_per_batch, y, ldy, rows, d, eps, s); \
+                                else launch_ln_modulate<float, NC>(x, ldx, shift, scale, mod_ld, rows_per_batch, y, ldy, rows, d, eps, s); break;
+  switch (nc) { MH_LN_CASE(1) MH_LN_CASE(2) MH_LN_CASE(3) MH_LN_CASE(4) MH_LN_CASE(5) MH_LN_CASE(6) }
+#undef MH_LN_CASE
   return check_launch("ln_modulate_kernel");
 }
 
