@@ -135,7 +135,11 @@ typedef struct MhGemm {
   /* fp32 only -- "bf16 x 3": W is stored PRE-SPLIT, every 32-float block of a row as [32 x bf16 hi | 32 x bf16 lo]
    * (hi = bf16(w), lo = bf16(w - hi); the same 128 bytes per block, ldw still counted in floats), A stays fp32 and is
    * split on its way into LDS; a w ~= a_hi w_hi + a_hi w_lo + a_lo w_hi on the bf16 matrix cores with fp32 accumulation
-   * (relative error ~2^-16 per product instead of exact fp32 products).  K and ldw multiples of 32. */
+   * (relative error ~2^-16 per product instead of exact fp32 products).  K and ldw multiples of 32.
+   * Bit flags: 1 = W pre-split (above); | 2 = A is stored pre-split in the same layout by its producer (lda counted in
+   * floats, multiple of 32): the three-stage LDS-DMA form, no conversion work inside the GEMM (STORE_F32, QKV_VT,
+   * GATE_RESID, BIAS_GELU; N, ldc multiples of 4); | 4 = with 2 and MH_EPI_BIAS_GELU: C is written pre-split as well
+   * (it is the next GEMM's A operand; ldc multiple of 32). */
   int w_split3;
 } MhGemm;
 int mh_gemm(const MhGemm* g, void* stream);

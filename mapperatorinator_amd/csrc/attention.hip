@@ -233,6 +233,22 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(AttnArgs p) {
     const int qg = q0w + lg * 4 + r;
     if (qg >= Lq) continue;
     const float inv = l[r] > 0.f ? 1.0f / l[r] : 0.f;
+    if constexpr (sizeof(T) == 4) {
+      if (p.out_split3) {   // the out-projection's A operand, pre-split for gemm_s3g_kernel: [32 x bf16 hi | 32 x bf16 lo] per 32 values
+        char* orow = (char*)p.out + (long)b * p.out_bs + (long)qg * p.out_rs;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int c = h * 64 + j * 16 + l15;
+          const float v = o[j][r] * inv;
+          const bf16_t hi = f32_to_bf16(v);
+          const bf16_t lo = f32_to_bf16(v - bf16_to_f32(hi));
+          bf16_t* blk = reinterpret_cast<bf16_t*>(orow + (long)(c >> 5) * 128);
+          blk[c & 31] = hi;
+          blk[32 + (c & 31)] = lo;
+        }
+        continue;
+      }
+    }
     T* op = reinterpret_cast<T*>((char*)p.out + (long)b * p.out_bs + (long)qg * p.out_rs) + h * 64 + l15;
 #pragma unroll
     for (int j = 0; j < 4; ++j) op[j * 16] = Elem<T>::from_f32(o[j][r] * inv);
@@ -533,7 +549,7 @@ namespace {
 struct SmallAttnP {
   const float* q; const float* k; const float* vt; float* out;
   long ld_qk, vt_hs, vt_bs; int ld_out;
-  int L, Lpad, H, band, open_from;
+  int L, Lpad, H, band, open_from, out_split3;
   float scale;
 };
 
@@ -642,8 +658,19 @@ __global__ __launch_bounds__(256) void attn_small_f32_kernel(SmallAttnP p) {
   }
   if (q0 + row < L) {
     const float inv = Ls > 0.f ? 1.f / Ls : 0.f;
-    *reinterpret_cast<float4*>(p.out + ((long)b * L + q0 + row) * p.ld_out + h * 64 + d0) =
-        make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+    float* orow = p.out + ((long)b * L + q0 + row) * p.ld_out;
+    if (p.out_split3) {   // pre-split for gemm_s3g_kernel (see flash_attn_kernel)
+      const int c = h * 64 + d0;
+      const float v0 = acc.x * inv, v1 = acc.y * inv, v2 = acc.z * inv, v3 = acc.w * inv;
+      const uint32_t h01 = pack_bf16x2(v0, v1), h23 = pack_bf16x2(v2, v3);
+      const float r0 = v0 - __uint_as_float(h01 << 16), r1 = v1 - __uint_as_float(h01 & 0xffff0000u);
+      const float r2 = v2 - __uint_as_float(h23 << 16), r3 = v3 - __uint_as_float(h23 & 0xffff0000u);
+      char* dst = reinterpret_cast<char*>(orow) + (long)(c >> 5) * 128 + (c & 31) * 2;
+      *reinterpret_cast<uint2*>(dst) = make_uint2(h01, h23);
+      *reinterpret_cast<uint2*>(dst + 64) = make_uint2(pack_bf16x2(r0, r1), pack_bf16x2(r2, r3));
+    } else {
+      *reinterpret_cast<float4*>(orow + h * 64 + d0) = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+    }
   }
 }
 
@@ -655,7 +682,8 @@ bool small_attn_ok(int B, int H, int L) { return (long)B * H * ceil_div(L, 16) <
 }  // namespace
 
 int attention(const void* qk, int ld_qk, int k_col0, const void* vt, int Lpad, const float* bias, void* out,
-              int ld_out, int B, int L, int H, float scale, int band, int dtype, hipStream_t s, int open_from) {
+              int ld_out, int B, int L, int H, float scale, int band, int dtype, hipStream_t s, int open_from, int out_split3) {
+  MH_REQUIRE(!out_split3 || (dtype == MH_F32 && ld_out % 32 == 0), "attention: out_split3 is an fp32 path (ld_out %% 32 == 0)");
   MH_REQUIRE(qk && vt && out, "mh_attention: null operand");
   const int es = dtype == MH_BF16 ? 2 : 4;
   MH_REQUIRE((ld_qk * es) % 16 == 0 && (k_col0 * es) % 16 == 0, "mh_attention: rows must be 16-byte aligned");
@@ -663,7 +691,7 @@ int attention(const void* qk, int ld_qk, int k_col0, const void* vt, int Lpad, c
     SmallAttnP sp{};
     sp.q = (const float*)qk; sp.k = (const float*)qk + k_col0; sp.vt = (const float*)vt; sp.out = (float*)out;
     sp.ld_qk = ld_qk; sp.vt_hs = 64L * Lpad; sp.vt_bs = (long)H * 64 * Lpad; sp.ld_out = ld_out;
-    sp.L = L; sp.Lpad = Lpad; sp.H = H; sp.band = band; sp.open_from = open_from; sp.scale = scale;
+    sp.L = L; sp.Lpad = Lpad; sp.H = H; sp.band = band; sp.open_from = open_from; sp.out_split3 = out_split3; sp.scale = scale;
     dim3 grid(ceil_div(L, 16), H, B), block(256);
     if (L <= 128) hipLaunchKernelGGL(attn_small_f32_kernel<2>, grid, block, 0, s, sp);
     else hipLaunchKernelGGL(attn_small_f32_kernel<4>, grid, block, 0, s, sp);
@@ -676,7 +704,7 @@ int attention(const void* qk, int ld_qk, int k_col0, const void* vt, int Lpad, c
   a.bias = bias; a.bias_hs = 2L * L - 1; a.bias_center = L - 1; a.bias_sign = 1; a.bias_min = -(L - 1); a.bias_max = L - 1;
   a.key_mask = nullptr; a.mask_ld = 0; a.mask_len = 0;
   a.out = out; a.out_rs = (long)ld_out * es; a.out_bs = (long)L * ld_out * es;
-  a.Lq = L; a.Lk = L; a.scale = scale; a.band = band; a.open_from = open_from; a.causal = 0; a.q_pos0 = 0;
+  a.Lq = L; a.Lk = L; a.scale = scale; a.band = band; a.open_from = open_from; a.out_split3 = out_split3; a.causal = 0; a.q_pos0 = 0;
   return attention_general(a, B, H, dtype, s);
 }
 

@@ -347,7 +347,37 @@ int dit_body(const MhDiTConfig* c, const MhDiTWeights* w, const float* x, const 
     g.epilogue = MH_EPI_GATE_RESID;
     MH_TRY(gemm(g, s));
   }
-  for (int l = 0; l < c->depth && !lowp; ++l) {
+  // fp32 semantics, big batches: the bf16 x 3 GEMMs with BOTH operands pre-split (gemm_s3g_kernel: three-stage LDS-DMA,
+  // no conversion work inside the GEMM) -- LayerNorm-modulate, the attention and the GELU epilogue write their outputs as
+  // [32 x bf16 hi | 32 x bf16 lo] per 32 values straight away (the same bytes as fp32, the same buffers).  Option
+  // dit_s3_presplit = 0: the 64 x 64 kernel that splits A while staging it.
+  const bool s3g = !lowp && s3 && option(OPT_DIT_S3_PRESPLIT) != 0 && D % 32 == 0;
+  for (int l = 0; l < c->depth && s3g; ++l) {
+    const float* mod = b.cond_cur + (long)l * 6 * D;
+    MH_TRY(ln_modulate(b.xs, D, mod + 0 * D, mod + 1 * D, ld_row, T, b.xm, D, NT, D, 1e-6f, MH_LN_SPLIT3, s));
+    g = MhGemm{};
+    g.A = b.xm; g.lda = D; g.W = w->qkv_w3[l]; g.ldw = D; g.C = b.qk; g.ldc = 2 * D; g.M = NT; g.N = 3 * D; g.K = D;
+    g.bias = w->qkv_b[l]; g.dtype = MH_F32; g.epilogue = MH_EPI_QKV_VT; g.C2 = b.vt; g.n_split = 2 * D; g.kv_B = N;
+    g.kv_H = H; g.kv_L = T; g.kv_Lpad = b.Tpad; g.w_split3 = 3;
+    MH_TRY(gemm(g, s));
+    MH_TRY(attention(b.qk, 2 * D, D, b.vt, b.Tpad, nullptr, b.attn, D, N, T, H, 0.125f, band, MH_F32, s, open_from, /*out_split3=*/1));
+    g = MhGemm{};
+    g.A = b.attn; g.lda = D; g.W = w->out_w3[l]; g.ldw = D; g.C = b.xs; g.ldc = D; g.M = NT; g.N = D; g.K = D;
+    g.bias = w->out_b[l]; g.gate = mod + 2 * D; g.gate_ld = ld_row; g.rows_per_batch = T; g.dtype = MH_F32;
+    g.epilogue = MH_EPI_GATE_RESID; g.w_split3 = 3;
+    MH_TRY(gemm(g, s));
+    MH_TRY(ln_modulate(b.xs, D, mod + 3 * D, mod + 4 * D, ld_row, T, b.xm, D, NT, D, 1e-6f, MH_LN_SPLIT3, s));
+    g = MhGemm{};
+    g.A = b.xm; g.lda = D; g.W = w->fc1_w3[l]; g.ldw = D; g.C = b.hid; g.ldc = 4 * D; g.M = NT; g.N = 4 * D; g.K = D;
+    g.bias = w->fc1_b[l]; g.dtype = MH_F32; g.epilogue = MH_EPI_BIAS_GELU; g.w_split3 = 7;
+    MH_TRY(gemm(g, s));
+    g = MhGemm{};
+    g.A = b.hid; g.lda = 4 * D; g.W = w->fc2_w3[l]; g.ldw = 4 * D; g.C = b.xs; g.ldc = D; g.M = NT; g.N = D; g.K = 4 * D;
+    g.bias = w->fc2_b[l]; g.gate = mod + 5 * D; g.gate_ld = ld_row; g.rows_per_batch = T; g.dtype = MH_F32;
+    g.epilogue = MH_EPI_GATE_RESID; g.w_split3 = 3;
+    MH_TRY(gemm(g, s));
+  }
+  for (int l = 0; l < c->depth && !lowp && !s3g; ++l) {
     const float* mod = b.cond_cur + (long)l * 6 * D;
     // attention branch
     g = MhGemm{};

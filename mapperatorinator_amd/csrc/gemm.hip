@@ -840,6 +840,238 @@ __global__ __launch_bounds__(512) void gemm_glds3_kernel(GemmP p) {
   }
 }
 
+// ---- S3G: the bf16 x 3 fp32 GEMM on the three-stage LDS-DMA structure, BOTH operands pre-split -----------------------
+// The 64 x 64 split-3 tile above converts its fp32 A operand into [hi | lo] while staging it (registers, VALU, LDS
+// writes), one stage ahead: 41-57 us per GEMM of the batched DiT.  When the PRODUCER of the activations writes them
+// pre-split -- the same [32 x bf16 hi | 32 x bf16 lo] per 32 values as the weights, the same bytes as fp32 -- a K step is
+// one 128-byte row per operand row, i.e. exactly what gemm_glds3_kernel moves by LDS-DMA: its "ks = 0 / 1" fragment reads
+// are the hi / lo halves.  Per 32-k step and wave: 2 (MI + 4) fragment reads, 3 * 4 * MI MFMAs (lo.hi, hi.lo, hi.hi -- the
+// order of the 64 x 64 kernel), reads of step kt + 1 issued before the MFMAs of step kt into a second register set.
+// Epilogues: QKV_VT and GATE_RESID write fp32 (attention operands, residual stream), BIAS_GELU writes the next GEMM's A
+// operand pre-split again (p.split3 & 4).
+template <int EPI, int MI>
+__global__ __launch_bounds__(512) void gemm_s3g_kernel(GemmP p) {
+  static_assert(MI == 2, "MI = 4 spills fragment registers that inline-asm LDS reads are still filling");
+  constexpr int BM = 64 * MI, BN = 128, NST = 3;
+  constexpr int kRowStride = 128, kStage = (BM + BN) * kRowStride;
+  constexpr int WM = 16 * MI, WN = 64, NI = 4, NA = MI;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wr = wid >> 1, wc = wid & 1;
+  const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
+  const int nwg = nbm * nbn;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  int bm, bn;
+  {
+    const long panel_bytes = (long)BM * p.K * 4L;
+    int GM = (int)((5L << 19) / (panel_bytes > 0 ? panel_bytes : 1));
+    GM = GM < 2 ? 2 : (GM > 16 ? 16 : GM);
+    const int per_group = GM * nbn;
+    const int grp = bid / per_group, rem = bid - grp * per_group;
+    const int gm = (nbm - grp * GM) < GM ? (nbm - grp * GM) : GM;
+    bn = rem / gm;
+    bm = grp * GM + (rem - bn * gm);
+  }
+  const int m0 = bm * BM, n0 = bn * BN;
+  const int nk = p.K / 32;                       // one 128-byte block (32 values as hi | lo) per K step
+
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  const char* srcp[NA + 2];
+  {
+    const int r8 = lane >> 3;
+    const long k_off = (long)(((lane & 7) ^ r8) * 16);               // pre-swizzled 16-byte chunk of the 128-byte block
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      int ra_ = m0 + (i * 8 + wid) * 8 + r8; ra_ = ra_ < p.M ? ra_ : p.M - 1;
+      srcp[i] = p.A + (long)ra_ * p.lda_b + k_off;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int rb_ = n0 + (i * 8 + wid) * 8 + r8; rb_ = rb_ < p.N ? rb_ : p.N - 1;
+      srcp[NA + i] = p.W + (long)rb_ * p.ldw_b + k_off;
+    }
+  }
+  auto issue = [&](int st) {
+    char* base = smem + st * kStage;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      __builtin_amdgcn_global_load_lds((gptr_t)srcp[i], (lptr_t)(base + (i * 8 + wid) * 1024), 16, 0, 0);
+      srcp[i] += 128;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      __builtin_amdgcn_global_load_lds((gptr_t)srcp[NA + i], (lptr_t)(base + BM * kRowStride + (i * 8 + wid) * 1024), 16, 0, 0);
+      srcp[NA + i] += 128;
+    }
+  };
+
+  f32x4_t acc[NI][MI];                           // transposed product, as in gemm_glds3_kernel
+#pragma unroll
+  for (int j = 0; j < NI; ++j)
+#pragma unroll
+    for (int i = 0; i < MI; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, sw = frow & 7, lgc = lane >> 4;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
+  const uint32_t a_off = (uint32_t)((wr * WM + frow) * kRowStride), b_off = (uint32_t)((BM + wc * WN + frow) * kRowStride);
+  struct Frags { bf16x8_t ah[MI], al[MI], bh[NI], bl[NI]; };
+  auto rd = [&](int st, Frags& f) {              // hi halves = chunks 0..3, lo halves = chunks 4..7 of the (swizzled) block
+    const uint32_t ch = (uint32_t)((lgc ^ sw) * 16), cl = (uint32_t)(((4 + lgc) ^ sw) * 16);
+    const uint32_t pa = lds0 + st * kStage + a_off, pb = lds0 + st * kStage + b_off;
+    const uint32_t pah = pa + ch, pal = pa + cl, pbh = pb + ch, pbl = pb + cl;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(f.ah[0]) : "v"(pah));
+    asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(f.ah[1]) : "v"(pah));
+    asm volatile("ds_read_b128 %0, %1" : "=v"(f.al[0]) : "v"(pal));
+    asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(f.al[1]) : "v"(pal));
+    if constexpr (MI == 4) {
+      asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(f.ah[2]) : "v"(pah));
+      asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(f.ah[3]) : "v"(pah));
+      asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(f.al[2]) : "v"(pal));
+      asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(f.al[3]) : "v"(pal));
+    }
+    asm volatile("ds_read_b128 %0, %1" : "=v"(f.bh[0]) : "v"(pbh));
+    asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(f.bh[1]) : "v"(pbh));
+    asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(f.bh[2]) : "v"(pbh));
+    asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(f.bh[3]) : "v"(pbh));
+    asm volatile("ds_read_b128 %0, %1" : "=v"(f.bl[0]) : "v"(pbl));
+    asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(f.bl[1]) : "v"(pbl));
+    asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(f.bl[2]) : "v"(pbl));
+    asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(f.bl[3]) : "v"(pbl));
+  };
+  auto mma3 = [&](const Frags& f) {              // small terms first, the dominant product last
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.bh[j], f.al[i], acc[j][i], 0, 0, 0);
+        acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.bl[j], f.ah[i], acc[j][i], 0, 0, 0);
+        acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.bh[j], f.ah[i], acc[j][i], 0, 0, 0);
+      }
+  };
+#define S3G_WAIT(str) do { asm volatile(str ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+  // step kt: [DMA of stage kt + 2] wait: stage kt + 1 landed, own LDS reads retired | barrier | reads of stage kt + 1 into
+  // the OTHER register set | MFMAs on this set (read one step ago, retired by the wait above)
+  Frags f0, f1;
+  issue(0);
+  if (nk > 1) {
+    issue(1);
+    if constexpr (MI == 4) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  rd(0, f0);
+  int nxt = 1, nxt2 = 2;
+  auto step = [&](Frags& cur, Frags& other, bool dma, bool more) {
+    if (dma) {
+      issue(nxt2);
+      if constexpr (MI == 4) S3G_WAIT("s_waitcnt vmcnt(6) lgkmcnt(0)"); else S3G_WAIT("s_waitcnt vmcnt(4) lgkmcnt(0)");
+    } else {
+      S3G_WAIT("s_waitcnt vmcnt(0) lgkmcnt(0)");
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (more) rd(nxt, other);
+    __builtin_amdgcn_sched_barrier(0);
+    mma3(cur);
+    __builtin_amdgcn_sched_barrier(0);
+    nxt = nxt == NST - 1 ? 0 : nxt + 1;
+    nxt2 = nxt2 == NST - 1 ? 0 : nxt2 + 1;
+  };
+  int kt = 0;
+  for (; kt + 3 < nk; kt += 2) {                 // pairs of steps with a DMA each (register sets alternate)
+    step(f0, f1, true, true);
+    step(f1, f0, true, true);
+  }
+  for (; kt < nk; ++kt) {                        // the last <= 3 steps
+    const bool dma = kt + 2 < nk, more = kt + 1 < nk;
+    if ((kt & 1) == 0) step(f0, f1, dma, more); else step(f1, f0, dma, more);
+  }
+#undef S3G_WAIT
+
+  // ---- epilogue (4 consecutive columns per lane; loads pinned before the first store of a row block) ----
+  const int l15 = lane & 15;
+  const int ecol_base = n0 + wc * WN + lgc * 4, erow_base = m0 + wr * WM + l15;
+  auto f4 = [](const float* q) { return *reinterpret_cast<const float4*>(q); };
+  float4 bias4[NI];
+#pragma unroll
+  for (int jj = 0; jj < NI; ++jj) {
+    int c = ecol_base + jj * 16;
+    c = c < p.N ? c : p.N - 4;
+    bias4[jj] = p.bias ? f4(p.bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+#pragma unroll
+  for (int jj = 0; jj < NI; ++jj)
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      acc[jj][i][0] += bias4[jj].x; acc[jj][i][1] += bias4[jj].y; acc[jj][i][2] += bias4[jj].z; acc[jj][i][3] += bias4[jj].w;
+      asm volatile("" : "+v"(acc[jj][i]));
+    }
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int row = erow_base + i * 16;
+    const bool rok = row < p.M;
+    const int rowc = rok ? row : p.M - 1;
+    f32x4_t vv[NI];
+#pragma unroll
+    for (int jj = 0; jj < NI; ++jj) {
+      f32x4_t v = acc[jj][i];
+      if constexpr (EPI == MH_EPI_GATE_RESID) {
+        int c = ecol_base + jj * 16;
+        c = c < p.N ? c : p.N - 4;
+        const float4 o4 = f4(reinterpret_cast<const float*>(p.C) + (long)rowc * p.ldc + c);
+        const float4 g4 = f4(p.gate + (long)(rowc / p.rows_per_batch) * p.gate_ld + c);
+        v[0] = o4.x + g4.x * v[0]; v[1] = o4.y + g4.y * v[1]; v[2] = o4.z + g4.z * v[2]; v[3] = o4.w + g4.w * v[3];
+      } else if constexpr (EPI == MH_EPI_BIAS_GELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_tanh(v[r]);
+      }
+      asm volatile("" : "+v"(v));
+      vv[jj] = v;
+    }
+#pragma unroll
+    for (int jj = 0; jj < NI; ++jj) {
+      const int c = ecol_base + jj * 16;
+      if (!rok || c >= p.N) continue;
+      const f32x4_t v = vv[jj];
+      if constexpr (EPI == MH_EPI_BIAS_GELU) {
+        // the next GEMM's A operand, pre-split: column c of row `row` -> block c / 32, hi at (c % 32) * 2, lo 64 bytes on
+        char* dst = reinterpret_cast<char*>(p.C) + ((long)row * p.ldc + (c & ~31)) * 4 + (c & 31) * 2;
+        const uint32_t h01 = pack_bf16x2(v[0], v[1]), h23 = pack_bf16x2(v[2], v[3]);
+        const float r0 = v[0] - __uint_as_float(h01 << 16), r1 = v[1] - __uint_as_float(h01 & 0xffff0000u);
+        const float r2 = v[2] - __uint_as_float(h23 << 16), r3 = v[3] - __uint_as_float(h23 & 0xffff0000u);
+        *reinterpret_cast<uint2*>(dst) = make_uint2(h01, h23);
+        *reinterpret_cast<uint2*>(dst + 64) = make_uint2(pack_bf16x2(r0, r1), pack_bf16x2(r2, r3));
+      } else if constexpr (EPI == MH_EPI_GATE_RESID || EPI == MH_EPI_STORE_F32) {
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + (long)row * p.ldc + c) = make_float4(v[0], v[1], v[2], v[3]);
+      } else if constexpr (EPI == MH_EPI_QKV_VT) {
+        if (c < p.n_split) {
+          *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + (long)row * p.ldc + c) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+          const int c2 = c - p.n_split;
+          const int b = row / p.kv_L, key = row - b * p.kv_L;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) reinterpret_cast<float*>(p.C2)[((long)b * p.kv_H * 64 + c2 + r) * p.kv_Lpad + key] = v[r];
+        }
+      }
+    }
+  }
+}
+
+template <int EPI, int MI>
+int launch_s3g(const GemmP& p, hipStream_t s) {
+  constexpr int BM = 64 * MI;
+  const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + 127) / 128;
+  hipLaunchKernelGGL((gemm_s3g_kernel<EPI, MI>), dim3(nbm * nbn), dim3(512), 3 * (BM + 128) * 128, s, p);
+  return check_launch("gemm_s3g_kernel");
+}
+
 template <int EPI, int MI>
 int launch_glds3(const GemmP& p, hipStream_t s) {
   constexpr int BM = 64 * MI;
@@ -880,6 +1112,12 @@ bool prepare_epi() {
   if constexpr (EPI != MH_EPI_GEGLU) ok = ok && prepare_one<T, 32, 32, EPI>() && prepare_one<T, 16, 16, EPI>();   // GEGLU pairs two 16-col blocks per wave
   return ok;
 }
+template <int EPI>
+bool prepare_s3g() {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_s3g_kernel<EPI, 2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             3 * (128 + 128) * 128) == hipSuccess;
+}
+
 template <typename T>
 bool prepare_type() {
   return prepare_epi<T, MH_EPI_STORE>() && prepare_epi<T, MH_EPI_STORE_F32>() && prepare_epi<T, MH_EPI_RESID>() &&
@@ -895,6 +1133,10 @@ template <typename T, int EPI>
 int dispatch_tile(const GemmP& p, hipStream_t s) {
   if constexpr (std::is_same<T, float>::value && (EPI == MH_EPI_STORE_F32 || EPI == MH_EPI_QKV_VT ||
                                                   EPI == MH_EPI_GATE_RESID || EPI == MH_EPI_BIAS_GELU)) {
+    // A pre-split as well: the three-stage LDS-DMA form.  128-row tiles only: the 256-row form needs two fragment sets of
+    // 128 VGPRs beside 64 accumulators and hipcc spills fragments -- registers written by the inline-asm LDS reads, which it
+    // believes valid and stores to scratch BEFORE the data has arrived (wrong results, found by the DiT-B 1024-point golden).
+    if (p.split3 & 2) return launch_s3g<EPI, 2>(p, s);
     if (p.split3) return launch_gemm<T, 64, 64, EPI, true>(p, s);
   }
   // tile by grid size: the chip has 256 CUs; a K step of a wave costs MI*NI MFMAs, so small problems want
@@ -952,7 +1194,8 @@ int dispatch_epi(const GemmP& p, int epi, hipStream_t s) {
 int gemm_prepare() {
   static bool done = false;
   if (done) return MH_OK;
-  if (!(prepare_type<bf16_t>() && prepare_type<float>())) {
+  if (!(prepare_type<bf16_t>() && prepare_type<float>() && prepare_s3g<MH_EPI_QKV_VT>() && prepare_s3g<MH_EPI_GATE_RESID>() &&
+        prepare_s3g<MH_EPI_BIAS_GELU>() && prepare_s3g<MH_EPI_STORE_F32>())) {
     set_error("gemm_prepare: hipFuncSetAttribute failed: %s", hipGetErrorString(hipGetLastError()));
     return MH_ERR_LAUNCH;
   }
@@ -1002,6 +1245,12 @@ int gemm(const MhGemm& g, hipStream_t s, bool ascending_k) {
   if (g.stats_out)
     MH_REQUIRE((g.epilogue == MH_EPI_STORE_F32 || g.epilogue == MH_EPI_GATE_RESID) && g.N % 16 == 0,
                "mh_gemm: stats_out needs a fp32-output epilogue (STORE_F32 / GATE_RESID) and N %% 16 == 0");
+  if (g.w_split3 & 2)
+    MH_REQUIRE((g.w_split3 & 1) && g.lda % 32 == 0 && g.N % 4 == 0 && g.ldc % 4 == 0 && !g.stats_out && !g.ln_stats &&
+                   (g.gate == nullptr || g.gate_ld % 4 == 0) && ((g.w_split3 & 4) == 0 || (g.epilogue == MH_EPI_BIAS_GELU && g.ldc % 32 == 0)),
+               "mh_gemm: w_split3 & 2 (A pre-split) needs w_split3 & 1, lda %% 32 == 0, N and ldc multiples of 4, no LayerNorm fusion");
+  if ((g.w_split3 & 2) == 0) MH_REQUIRE((g.w_split3 & 4) == 0, "mh_gemm: w_split3 & 4 (pre-split output) only with w_split3 & 2");
+  if ((g.w_split3 & 2) && g.epilogue == MH_EPI_BIAS_GELU) MH_REQUIRE(g.w_split3 & 4, "mh_gemm: the A-pre-split BIAS_GELU form writes its output pre-split (w_split3 & 4)");
   if (g.w_split3)
     MH_REQUIRE(g.dtype == MH_F32 && g.K % 32 == 0 && g.ldw % 32 == 0 &&
                    (g.epilogue == MH_EPI_STORE_F32 || g.epilogue == MH_EPI_QKV_VT || g.epilogue == MH_EPI_GATE_RESID ||

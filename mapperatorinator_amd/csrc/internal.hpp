@@ -10,10 +10,12 @@ int gemm_prepare();  // one-time kernel attribute setup; call before any stream 
 int gemm(const MhGemm& g, hipStream_t s, bool ascending_k = false);
 int rmsnorm(const float* x, int ldx, const float* w, void* y, int ldy, int rows, int d, float eps, int out_dtype,
             hipStream_t s);
+constexpr int MH_LN_SPLIT3 = 2;   // ln_modulate out_dtype: fp32 values stored pre-split for gemm_s3g_kernel
 int ln_modulate(const float* x, int ldx, const float* shift, const float* scale, int mod_ld, int rows_per_batch,
                 void* y, int ldy, int rows, int d, float eps, int out_dtype, hipStream_t s);
 int attention(const void* qk, int ld_qk, int k_col0, const void* vt, int Lpad, const float* bias, void* out,
-              int ld_out, int B, int L, int H, float scale, int band, int dtype, hipStream_t s, int open_from = 0);
+              int ld_out, int B, int L, int H, float scale, int band, int dtype, hipStream_t s, int open_from = 0,
+              int out_split3 = 0);
 
 // strided description of one attention problem (all byte strides; see attention.hip)
 struct AttnArgs {
@@ -26,6 +28,7 @@ struct AttnArgs {
   int Lq, Lk;
   float scale;
   int open_from = 0;   // with a band: positions >= open_from (padding) attend and are attended by everything (0 = none)
+  int out_split3 = 0;  // fp32 only: the output is written pre-split ([32 x bf16 hi | 32 x bf16 lo] per 32 values), MhGemm.w_split3 & 2
   int band;        // > 0: attend iff -(band-1) <= k - q <= band
   int causal;      // attend iff key position <= q_pos0 + query index
   int q_pos0;

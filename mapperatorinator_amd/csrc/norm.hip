@@ -2,7 +2,7 @@
 //   rmsnorm      : T5LayerNorm  (HF modeling_t5 T5LayerNorm; restated custom_transformers/t5.py:50-62)
 //   ln_modulate  : LayerNorm(no affine, eps) followed by adaLN modulate x*(1+scale)+shift
 //                  (osu_diffusion/utils/models.py:11-12,110,117,140-155)
-#include "common.hpp"
+#include "internal.hpp"
 
 namespace mh {
 namespace {
@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
 // rounding of the DiT's bf16 mode happens here, after the fp32 arithmetic).  One wave per row; the row (d <= 256 * NC floats)
 // is read ONCE into registers -- mean, the centred sum of squares (same two-pass arithmetic as before, on the registers) and
 // the modulated output all come from that copy; the shift / scale vectors are requested with the row.
-template <typename T, int NC>
+template <typename T, int NC, bool SPLIT = false>
 __global__ __launch_bounds__(256) void ln_modulate_kernel(const float* __restrict__ x, int ldx,
                                                          const float* __restrict__ shift,
                                                          const float* __restrict__ scale, int mod_ld,
@@ -82,7 +82,14 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(const float* __restric
     o.y = (v[c].y - mean) * rs * (1.f + b[c].y) + a[c].y;
     o.z = (v[c].z - mean) * rs * (1.f + b[c].z) + a[c].z;
     o.w = (v[c].w - mean) * rs * (1.f + b[c].w) + a[c].w;
-    if constexpr (sizeof(T) == 4) {
+    if constexpr (SPLIT) {   // fp32 values as [32 x bf16 hi | 32 x bf16 lo] per 32 (the pre-split A operand of gemm_s3g_kernel)
+      const uint32_t h01 = pack_bf16x2(o.x, o.y), h23 = pack_bf16x2(o.z, o.w);
+      const float r0 = o.x - __uint_as_float(h01 << 16), r1 = o.y - __uint_as_float(h01 & 0xffff0000u);
+      const float r2 = o.z - __uint_as_float(h23 << 16), r3 = o.w - __uint_as_float(h23 & 0xffff0000u);
+      char* dst = reinterpret_cast<char*>(yr) + (long)(i >> 5) * 128 + (i & 31) * 2;
+      *reinterpret_cast<uint2*>(dst) = make_uint2(h01, h23);
+      *reinterpret_cast<uint2*>(dst + 64) = make_uint2(pack_bf16x2(r0, r1), pack_bf16x2(r2, r3));
+    } else if constexpr (sizeof(T) == 4) {
       *reinterpret_cast<float4*>(yr + i) = o;
     } else {
       ushort4 q;
@@ -106,10 +113,10 @@ int rmsnorm(const float* x, int ldx, const float* w, void* y, int ldy, int rows,
   return check_launch("rmsnorm_kernel");
 }
 
-template <typename T, int NC>
+template <typename T, int NC, bool SPLIT = false>
 static void launch_ln_modulate(const float* x, int ldx, const float* shift, const float* scale, int mod_ld, int rows_per_batch,
                                void* y, int ldy, int rows, int d, float eps, hipStream_t s) {
-  hipLaunchKernelGGL((ln_modulate_kernel<T, NC>), dim3(ceil_div(rows, 4)), dim3(256), 0, s, x, ldx, shift, scale, mod_ld,
+  hipLaunchKernelGGL((ln_modulate_kernel<T, NC, SPLIT>), dim3(ceil_div(rows, 4)), dim3(256), 0, s, x, ldx, shift, scale, mod_ld,
                      rows_per_batch, (T*)y, ldy, rows, d, eps);
 }
 
@@ -119,7 +126,9 @@ int ln_modulate(const float* x, int ldx, const float* shift, const float* scale,
   MH_REQUIRE(d <= 1536, "ln_modulate: d = %d > 1536 (the row lives in registers)", d);
   const int nc = ceil_div(d, 256);
   const bool lo = out_dtype == MH_BF16;
-#define MH_LN_CASE(NC) case NC: if (lo) launch_ln_modulate<bf16_t, NC>(x, ldx, shift, scale, mod_ld, rows_per_batch, y, ldy, rows, d, eps, s); \
+  MH_REQUIRE(out_dtype != MH_LN_SPLIT3 || (ldy % 32 == 0 && d % 32 == 0), "ln_modulate: the pre-split output needs d, ldy %% 32 == 0");
+#define MH_LN_CASE(NC) case NC: if (out_dtype == MH_LN_SPLIT3) launch_ln_modulate<float, NC, true>(x, ldx, shift, scale, mod_ld, rows_per_batch, y, ldy, rows, d, eps, s); \
+                                else if (lo) launch_ln_modulate<bf16_t, NC>(x, ldx, shift, scale, mod_ld, rows_per_batch, y, ldy, rows, d, eps, s); \
                                 else launch_ln_modulate<float, NC>(x, ldx, shift, scale, mod_ld, rows_per_batch, y, ldy, rows, d, eps, s); break;
   switch (nc) { MH_LN_CASE(1) MH_LN_CASE(2) MH_LN_CASE(3) MH_LN_CASE(4) MH_LN_CASE(5) MH_LN_CASE(6) }
 #undef MH_LN_CASE

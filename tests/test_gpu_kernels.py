@@ -31,6 +31,13 @@ def split3_pack(W):
     return torch.stack([hi.reshape(n, k // 32, 32), lo.reshape(n, k // 32, 32)], dim=2).reshape(n, 2 * k).contiguous()
 
 
+def split3_unpack(P):
+    """inverse of split3_pack (rows of [hi 32 | lo 32] bf16 blocks, viewed from an fp32-sized buffer) -> fp32 values hi + lo"""
+    n = P.shape[0]
+    b = P.contiguous().view(torch.bfloat16).reshape(n, -1, 2, 32).float()
+    return (b[:, :, 0] + b[:, :, 1]).reshape(n, -1)
+
+
 def run_gemm(A, W, epi, dtype, bias=None, C0=None, gate=None, rows_per_batch=0, kv=None, n_split=0, Lpad=0, out_cols=None,
              split3=False):
     L, lib = _lib()
@@ -39,8 +46,10 @@ def run_gemm(A, W, epi, dtype, bias=None, C0=None, gate=None, rows_per_batch=0, 
     M, K = A.shape
     N = W.shape[0]
     Ad, Wd = A.to(dev, td).contiguous(), (split3_pack(W).to(dev) if split3 else W.to(dev, td).contiguous())
+    if split3 and int(split3) & 2:          # A pre-split by its producer (the three-stage gemm_s3g_kernel)
+        Ad = split3_pack(A).to(dev)
     g = L.MhGemm()
-    g.w_split3 = 1 if split3 else 0
+    g.w_split3 = int(split3) if split3 else 0
     g.A, g.lda, g.W, g.ldw = Ad.data_ptr(), K, Wd.data_ptr(), K
     g.M, g.N, g.K, g.dtype, g.epilogue = M, N, K, dtype, epi
     keep = [Ad, Wd]
@@ -194,6 +203,34 @@ def test_gemm_bf16x3_split_path():
     gate = torch.randn(3, N, generator=g)
     out = run_gemm(A, W, L.EPI_GATE_RESID, L.MH_F32, bias=bias, C0=C0, gate=gate, rows_per_batch=111, split3=True)
     assert torch.allclose(out, C0 + gate.repeat_interleave(111, dim=0) * ref.float(), atol=3e-3, rtol=1e-4)
+
+
+def test_gemm_bf16x3_presplit_three_stage_path():
+    """MhGemm.w_split3 = 3 / 7: both operands pre-split, the three-stage LDS-DMA kernel (gemm_s3g_kernel).  Same products
+    and the same summation order per 32-k block as the 64 x 64 split kernel, so the two agree to fp32 rounding; ragged M
+    (clamped rows), small and large grids, the pre-split BIAS_GELU output."""
+    L, _ = _lib()
+    g = torch.Generator().manual_seed(18)
+    for M, N, K in ((700, 384, 416), (2300, 1536, 384), (4100, 1152, 768)):
+        A = torch.randn(M, K, generator=g)
+        W = torch.randn(N, K, generator=g) * torch.linspace(0.5, 2.0, N)[:, None]
+        bias = torch.randn(N, generator=g)
+        ref = A.double() @ W.double().t() + bias.double()
+        scale = (A.abs().double() @ W.abs().double().t()).max().item()
+        old = run_gemm(A, W, L.EPI_STORE_F32, L.MH_F32, bias=bias, split3=1)
+        new = run_gemm(A, W, L.EPI_STORE_F32, L.MH_F32, bias=bias, split3=3)
+        e_new, d_on = (new.double() - ref).abs().max().item() / scale, (new - old).abs().max().item() / scale
+        print(f"M={M} N={N} K={K}: pre-split path vs fp64 {e_new:.2e}, vs the 64x64 split kernel {d_on:.2e} (of sum|a||w|)")
+        assert e_new < 3e-5 and d_on < 2e-7
+        C0 = torch.randn(M, N, generator=g)
+        gate = torch.randn(-(-M // 100), N, generator=g)
+        out = run_gemm(A, W, L.EPI_GATE_RESID, L.MH_F32, bias=bias, C0=C0, gate=gate, rows_per_batch=100, split3=3)
+        assert torch.allclose(out, C0 + gate.repeat_interleave(100, dim=0)[:M] * ref.float(), atol=3e-3, rtol=1e-4)
+        out = run_gemm(A, W, L.EPI_BIAS_GELU, L.MH_F32, bias=bias, split3=7)          # fp32-sized buffer holding [hi | lo] blocks
+        got = split3_unpack(out)
+        want = gelu_tanh(ref.float())
+        assert torch.allclose(got, want, atol=2e-3, rtol=1e-4)
+        assert (got - want).abs().max().item() < 2e-3 and (got - _bf16r(want)).abs().max().item() > 0      # hi + lo, not bf16
 
 
 @pytest.mark.parametrize("dtype_name", ["f32", "bf16"])
