@@ -779,7 +779,7 @@ __global__ __launch_bounds__(512) void gemm_glds3_kernel(GemmP p) {
         v[2] = old4[jj].z + g4[jj].z * v[2]; v[3] = old4[jj].w + g4[jj].w * v[3];
       } else if constexpr (EPI == MH_EPI_BIAS_GELU) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = gelu_tanh(v[r]);
+        for (int r = 0; r < 4; ++r) v[r] = gelu_tanh_fast(v[r]);
       } else if constexpr (EPI == MH_EPI_BIAS_GELU_ERF) {
         const float gq[4] = {g4[jj].x, g4[jj].y, g4[jj].z, g4[jj].w};
 #pragma unroll
@@ -1030,7 +1030,7 @@ __global__ __launch_bounds__(512) void gemm_s3g_kernel(GemmP p) {
         v[0] = o4.x + g4.x * v[0]; v[1] = o4.y + g4.y * v[1]; v[2] = o4.z + g4.z * v[2]; v[3] = o4.w + g4.w * v[3];
       } else if constexpr (EPI == MH_EPI_BIAS_GELU) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = gelu_tanh(v[r]);
+        for (int r = 0; r < 4; ++r) v[r] = gelu_tanh_fast(v[r]);
       }
       asm volatile("" : "+v"(v));
       vv[jj] = v;
