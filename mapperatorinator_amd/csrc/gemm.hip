@@ -860,42 +860,44 @@ __global__ __launch_bounds__(512) void gemm_s3g_kernel(GemmP p) {
   const int wr = wid >> 1, wc = wid & 1;
   const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
   const int nwg = nbm * nbn;
-  int bid = blockIdx.x;
-  {
+  // PERSISTENT over tiles: workgroup w takes tiles w, w + gridDim.x, ... of the XCD-aware work list (gridDim.x is a multiple of
+  // 8 or the whole list, so tile t still runs on XCD t % 8).  With one workgroup per CU the DMA latency of a tile's first two
+  // stages and its epilogue were dead time (9 of 17 us per tile at K = 384): the NEXT tile's first two stages are requested
+  // once the K loop is over (its last barrier retired every read of the stage buffers) and the epilogue has its OWN loads in
+  // registers (the load counter is in-order: a bias load issued after the DMAs would wait for them), before the stores.
+  auto coords = [&](int t, int& m0_, int& n0_) {
+    int bid = t;
     const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  int bm, bn;
-  {
     const long panel_bytes = (long)BM * p.K * 4L;
     int GM = (int)((5L << 19) / (panel_bytes > 0 ? panel_bytes : 1));
     GM = GM < 2 ? 2 : (GM > 16 ? 16 : GM);
     const int per_group = GM * nbn;
     const int grp = bid / per_group, rem = bid - grp * per_group;
     const int gm = (nbm - grp * GM) < GM ? (nbm - grp * GM) : GM;
-    bn = rem / gm;
-    bm = grp * GM + (rem - bn * gm);
-  }
-  const int m0 = bm * BM, n0 = bn * BN;
+    const int bn = rem / gm;
+    m0_ = (grp * GM + (rem - bn * gm)) * BM;
+    n0_ = bn * BN;
+  };
   const int nk = p.K / 32;                       // one 128-byte block (32 values as hi | lo) per K step
 
   typedef const __attribute__((address_space(1))) void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
   const char* srcp[NA + 2];
-  {
+  auto setup = [&](int m0_, int n0_) {
     const int r8 = lane >> 3;
     const long k_off = (long)(((lane & 7) ^ r8) * 16);               // pre-swizzled 16-byte chunk of the 128-byte block
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      int ra_ = m0 + (i * 8 + wid) * 8 + r8; ra_ = ra_ < p.M ? ra_ : p.M - 1;
+      int ra_ = m0_ + (i * 8 + wid) * 8 + r8; ra_ = ra_ < p.M ? ra_ : p.M - 1;
       srcp[i] = p.A + (long)ra_ * p.lda_b + k_off;
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      int rb_ = n0 + (i * 8 + wid) * 8 + r8; rb_ = rb_ < p.N ? rb_ : p.N - 1;
+      int rb_ = n0_ + (i * 8 + wid) * 8 + r8; rb_ = rb_ < p.N ? rb_ : p.N - 1;
       srcp[NA + i] = p.W + (long)rb_ * p.ldw_b + k_off;
     }
-  }
+  };
   auto issue = [&](int st) {
     char* base = smem + st * kStage;
 #pragma unroll
@@ -911,11 +913,6 @@ __global__ __launch_bounds__(512) void gemm_s3g_kernel(GemmP p) {
   };
 
   f32x4_t acc[NI][MI];                           // transposed product, as in gemm_glds3_kernel
-#pragma unroll
-  for (int j = 0; j < NI; ++j)
-#pragma unroll
-    for (int i = 0; i < MI; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
   const int frow = lane & 15, sw = frow & 7, lgc = lane >> 4;
   const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
   const uint32_t a_off = (uint32_t)((wr * WM + frow) * kRowStride), b_off = (uint32_t)((BM + wc * WN + frow) * kRowStride);
@@ -957,17 +954,15 @@ __global__ __launch_bounds__(512) void gemm_s3g_kernel(GemmP p) {
   // step kt: [DMA of stage kt + 2] wait: stage kt + 1 landed, own LDS reads retired | barrier | reads of stage kt + 1 into
   // the OTHER register set | MFMAs on this set (read one step ago, retired by the wait above)
   Frags f0, f1;
+  int t = blockIdx.x;
+  int m0, n0;
+  coords(t, m0, n0);
+  setup(m0, n0);
   issue(0);
-  if (nk > 1) {
-    issue(1);
-    if constexpr (MI == 4) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  rd(0, f0);
+  if (nk > 1) issue(1);
+  bool first = true;
   int nxt = 1, nxt2 = 2;
+  int m0n = 0, n0n = 0;                          // the next tile's origin (set by the last K step)
   auto step = [&](Frags& cur, Frags& other, bool dma, bool more) {
     if (dma) {
       issue(nxt2);
@@ -984,6 +979,22 @@ __global__ __launch_bounds__(512) void gemm_s3g_kernel(GemmP p) {
     nxt = nxt == NST - 1 ? 0 : nxt + 1;
     nxt2 = nxt2 == NST - 1 ? 0 : nxt2 + 1;
   };
+  for (; t < nwg; t += (int)gridDim.x) {
+#pragma unroll
+  for (int j = 0; j < NI; ++j)
+#pragma unroll
+    for (int i = 0; i < MI; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  // stage 0 has landed (the first tile may keep stage 1 in flight; later tiles also wait for their predecessor's stores)
+  if (first && nk > 1) {
+    if constexpr (MI == 4) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  first = false;
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  rd(0, f0);
+  nxt = 1; nxt2 = 2;
   int kt = 0;
   for (; kt + 3 < nk; kt += 2) {                 // pairs of steps with a DMA each (register sets alternate)
     step(f0, f1, true, true);
@@ -1013,26 +1024,47 @@ __global__ __launch_bounds__(512) void gemm_s3g_kernel(GemmP p) {
       acc[jj][i][0] += bias4[jj].x; acc[jj][i][1] += bias4[jj].y; acc[jj][i][2] += bias4[jj].z; acc[jj][i][3] += bias4[jj].w;
       asm volatile("" : "+v"(acc[jj][i]));
     }
+  float4 old4[MI][NI], g4[MI][NI];
+  if constexpr (EPI == MH_EPI_GATE_RESID) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int row = erow_base + i * 16;
+      const int rowc = row < p.M ? row : p.M - 1;
+#pragma unroll
+      for (int jj = 0; jj < NI; ++jj) {
+        int c = ecol_base + jj * 16;
+        c = c < p.N ? c : p.N - 4;
+        old4[i][jj] = f4(reinterpret_cast<const float*>(p.C) + (long)rowc * p.ldc + c);
+        g4[i][jj] = f4(p.gate + (long)(rowc / p.rows_per_batch) * p.gate_ld + c);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int jj = 0; jj < NI; ++jj) asm volatile("" : "+v"(old4[i][jj].x), "+v"(old4[i][jj].y), "+v"(old4[i][jj].z), "+v"(old4[i][jj].w),
+                                                        "+v"(g4[i][jj].x), "+v"(g4[i][jj].y), "+v"(g4[i][jj].z), "+v"(g4[i][jj].w));
+  }
+  if (t + (int)gridDim.x < nwg) {                // every load this epilogue needs has arrived: the next tile's first K tiles start flying
+    coords(t + (int)gridDim.x, m0n, n0n);
+    setup(m0n, n0n);
+    issue(0);
+    if (nk > 1) issue(1);
+  }
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
     const int row = erow_base + i * 16;
     const bool rok = row < p.M;
-    const int rowc = rok ? row : p.M - 1;
     f32x4_t vv[NI];
 #pragma unroll
     for (int jj = 0; jj < NI; ++jj) {
       f32x4_t v = acc[jj][i];
       if constexpr (EPI == MH_EPI_GATE_RESID) {
-        int c = ecol_base + jj * 16;
-        c = c < p.N ? c : p.N - 4;
-        const float4 o4 = f4(reinterpret_cast<const float*>(p.C) + (long)rowc * p.ldc + c);
-        const float4 g4 = f4(p.gate + (long)(rowc / p.rows_per_batch) * p.gate_ld + c);
-        v[0] = o4.x + g4.x * v[0]; v[1] = o4.y + g4.y * v[1]; v[2] = o4.z + g4.z * v[2]; v[3] = o4.w + g4.w * v[3];
+        const float4 o4 = old4[i][jj], q4 = g4[i][jj];
+        v[0] = o4.x + q4.x * v[0]; v[1] = o4.y + q4.y * v[1]; v[2] = o4.z + q4.z * v[2]; v[3] = o4.w + q4.w * v[3];
       } else if constexpr (EPI == MH_EPI_BIAS_GELU) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = gelu_tanh_fast(v[r]);
       }
-      asm volatile("" : "+v"(v));
       vv[jj] = v;
     }
 #pragma unroll
@@ -1062,13 +1094,16 @@ __global__ __launch_bounds__(512) void gemm_s3g_kernel(GemmP p) {
       }
     }
   }
+  m0 = m0n; n0 = n0n;
+  }   // tile loop
 }
 
 template <int EPI, int MI>
 int launch_s3g(const GemmP& p, hipStream_t s) {
   constexpr int BM = 64 * MI;
   const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + 127) / 128;
-  hipLaunchKernelGGL((gemm_s3g_kernel<EPI, MI>), dim3(nbm * nbn), dim3(512), 3 * (BM + 128) * 128, s, p);
+  const int tiles = nbm * nbn;
+  hipLaunchKernelGGL((gemm_s3g_kernel<EPI, MI>), dim3(tiles < 256 ? tiles : 256), dim3(512), 3 * (BM + 128) * 128, s, p);
   return check_launch("gemm_s3g_kernel");
 }
 
