@@ -6,8 +6,10 @@ Same kwargs, same EOS-set construction (server.py:72-80), same processor order
 (CFG -> MonotonicTimeShift -> TimeshiftBias -> Temperature | ConditionalTemperature -> LookbackBias,
 server.py:106-134), same stats dict (server.py:50-69).  Classifier-free guidance follows the reference's
 batch layout: the negative prompt rows first, the prompt rows second, one shared encoder output per pair
-(modeling_mapperatorinator.py:243-254).  Beam search is the one option the HIP path does not implement:
-it raises NotImplementedError -- never a silent approximation.
+(modeling_mapperatorinator.py:243-254).  `num_beams > 1` runs HF's beam search over the step-wise decode entry
+(mapperatorinator_amd/beam.py); beam-sample is the one combination that is not built and raises NotImplementedError --
+never a silent approximation.  `RequestBatcher` at the end of the file is the batching policy of the reference's
+InferenceServer (server.py:343-424) in front of this function.
 """
 from __future__ import annotations
 
