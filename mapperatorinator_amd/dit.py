@@ -229,6 +229,40 @@ CURVE_CODE = {"Linear": 0, "PerfectCurve": 1, "Catmull": 2, "Bezier": 3}
 MAX_BEZIER_SPAN = 32     # SL_MAXCP of csrc/slider.hip
 
 
+def pack_slider_set(sliders_per_chunk, start: int, end: int):
+    """Host side of MhSliderSet for the window [start, end): per chunk the sliders that lie entirely inside it
+    (diffusion_pipeline.py:210-212), indices made window-relative.  Returns the seven flat lists of the struct
+    (chunk_active, chunk_off, type, cp_off, cp_idx, end_idx, length).  Refuses what the kernel cannot reproduce: a curve
+    span of more than MAX_BEZIER_SPAN points, and sliders that share sequence points (the reference re-projects in order,
+    the kernel in parallel)."""
+    active, chunk_off, types, cp_off, cp_idx, end_idx, length = [], [0], [], [0], [], [], []
+    for sl in sliders_per_chunk:
+        active.append(1 if len(sl) > 0 else 0)
+        used = set()
+        for s in sl:
+            idx = np.asarray(s.seq_indices, dtype=np.int64)
+            if np.any((idx < start) | (idx >= end)) or s.end_index < start or s.end_index >= end:
+                continue                                       # (:210-212)
+            run = longest = 1
+            for a, b in zip(idx[:-1], idx[1:]):                # spans only ever split further (equal positions)
+                run = 1 if a == b else run + 1
+                longest = max(longest, run)
+            if longest > MAX_BEZIER_SPAN:
+                raise NotImplementedError(f"slider with a {longest}-point curve span (device limit {MAX_BEZIER_SPAN})")
+            pts = set(int(i) for i in idx) | {int(s.end_index)}
+            if int(s.end_index) in set(int(i) for i in idx) or (used & pts):
+                raise NotImplementedError("sliders sharing sequence points are re-projected in order by the reference; "
+                                          "the device kernel needs them disjoint")
+            used |= pts
+            types.append(CURVE_CODE.get(s.curve_type, 3))      # calculate_subpath: anything else is a Bezier
+            cp_idx.extend(int(i) - start for i in idx)
+            cp_off.append(len(cp_idx))
+            end_idx.append(int(s.end_index) - start)
+            length.append(float(s.length))
+        chunk_off.append(len(types))
+    return active, chunk_off, types, cp_off, cp_idx, end_idx, length
+
+
 class SliderInpaintSpec(InpaintSpec):
     """`denoised_fn` of the reference pipeline WITH sliders (diffusion_pipeline.py:201-222): the in-paint `where`, then
     every slider that lies entirely inside the window [start, end) gets its end point moved to
@@ -248,31 +282,7 @@ class SliderInpaintSpec(InpaintSpec):
         B = len(sliders_per_chunk)
         if N != 2 * B or T < end - start:        # (T > end - start: the window was padded, pad_sequence)
             raise ValueError(f"slider lists for {B} chunks / window {start}:{end} do not match x0 {tuple(ref.shape)}")
-        active, chunk_off, types, cp_off, cp_idx, end_idx, length = [], [0], [], [0], [], [], []
-        for sl in sliders_per_chunk:
-            active.append(1 if len(sl) > 0 else 0)
-            used = set()
-            for s in sl:
-                idx = np.asarray(s.seq_indices, dtype=np.int64)
-                if np.any((idx < start) | (idx >= end)) or s.end_index < start or s.end_index >= end:
-                    continue                                       # (:210-212)
-                run = longest = 1
-                for a, b in zip(idx[:-1], idx[1:]):                # spans only ever split further (equal positions)
-                    run = 1 if a == b else run + 1
-                    longest = max(longest, run)
-                if longest > MAX_BEZIER_SPAN:
-                    raise NotImplementedError(f"slider with a {longest}-point curve span (device limit {MAX_BEZIER_SPAN})")
-                pts = set(int(i) for i in idx) | {int(s.end_index)}
-                if int(s.end_index) in set(int(i) for i in idx) or (used & pts):
-                    raise NotImplementedError("sliders sharing sequence points are re-projected in order by the reference; "
-                                              "the device kernel needs them disjoint")
-                used |= pts
-                types.append(CURVE_CODE.get(s.curve_type, 3))      # calculate_subpath: anything else is a Bezier
-                cp_idx.extend(int(i) - start for i in idx)
-                cp_off.append(len(cp_idx))
-                end_idx.append(int(s.end_index) - start)
-                length.append(float(s.length))
-            chunk_off.append(len(types))
+        active, chunk_off, types, cp_off, cp_idx, end_idx, length = pack_slider_set(sliders_per_chunk, start, end)
         self.n_sliders = len(types)
 
         def dv(a, dt):

@@ -455,3 +455,25 @@ def test_band_mask_with_padding_round_trips_through_the_mask_analysis():
     broken[3, 60] = False
     with pytest.raises(NotImplementedError):
         analyse(None, broken, T)
+
+
+def test_slider_set_packing_filters_windows_and_refuses_what_the_kernel_cannot_do():
+    """pack_slider_set: the host side of MhSliderSet (reference filter diffusion_pipeline.py:210-212)."""
+    from mapperatorinator_amd.diffusion_pipeline import DiffusionSlider
+    from mapperatorinator_amd.dit import MAX_BEZIER_SPAN, pack_slider_set
+    S = DiffusionSlider
+    inside = S(np.array([12, 13, 13, 14]), 15, "Bezier", 120.0)         # red anchor = the same point twice
+    crosses = S(np.array([28, 29, 30]), 31, "PerfectCurve", 50.0)       # end outside [10, 30)
+    before = S(np.array([3, 4]), 5, "Catmull", 10.0)
+    odd = S(np.array([20, 21]), 22, None, 33.0)                         # unknown curve type -> Bezier (calculate_subpath's else)
+    active, chunk_off, types, cp_off, cp_idx, end_idx, length = pack_slider_set([[before, inside, crosses, odd], []], 10, 30)
+    assert active == [1, 0] and chunk_off == [0, 2, 2]
+    assert types == [3, 3] and cp_off == [0, 4, 6] and cp_idx == [2, 3, 3, 4, 10, 11] and end_idx == [5, 12] and length == [120.0, 33.0]
+    # a song whose sliders all fall outside the window still counts as "has sliders" (the pixel round trip, :208)
+    assert pack_slider_set([[before]], 10, 30)[:2] == ([1], [0, 0])
+    with pytest.raises(NotImplementedError, match="sharing"):
+        pack_slider_set([[inside, S(np.array([15, 16]), 17, "Bezier", 5.0)]], 10, 30)      # starts on the other's end point
+    with pytest.raises(NotImplementedError, match="curve span"):
+        pack_slider_set([[S(np.arange(40, 40 + MAX_BEZIER_SPAN + 1), 90, "Bezier", 5.0)]], 0, 100)
+    long_but_split = S(np.concatenate([np.arange(40, 60), [59], np.arange(60, 80)]), 90, "Bezier", 5.0)   # 41 points, spans of 20 + 21
+    assert pack_slider_set([[long_but_split]], 0, 100)[2] == [3]
