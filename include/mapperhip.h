@@ -73,8 +73,16 @@ int mh_abi_version(void);
  *                                                   the head's q / k / v weight slice; a row's key interleave is 16 / rows
  *                                                   waves wide (fp32 order of its softmax sums differs between settings,
  *                                                   never with the batch)
- * (further switches -- decode_cu_split, gemm_tile128_min, attn_small_max_wgs, dit_split3_min_rows -- are documented
- * next to their definitions in csrc/api.hip.)
+ *   "gemm_glds"          MH_GEMM_GLDS          3    bf16 GEMM operands by LDS-DMA: 3 = three-stage kernel (256x128 tiles, 128x128
+ *                                                   below half a wave of them), 2 = 256x128 only, 1 = two-stage 128x128,
+ *                                                   0 = register staging
+ *   "attn_flash2"        MH_ATTN_FLASH2        1    bf16 attention: transposed-S kernel (probabilities stay in registers);
+ *                                                   0 = the 64-query kernel with the LDS P patch (different fp32 order)
+ *   "dit_s3_presplit"    MH_DIT_S3_PRESPLIT    1    batched fp32-semantics DiT: activations written pre-split by their
+ *                                                   producers + three-stage bf16 x 3 GEMM; 0 = the 64x64 kernel that splits A
+ *                                                   while staging it (bit-identical GEMM results; the fc1 GELU differs)
+ * (further switches -- decode_cu_split, gemm_tile128_min, gemm_tile256_min, attn_small_max_wgs, dit_split3_min_rows,
+ * dit_s3_fused_ln -- are documented next to their definitions in csrc/api.hip.)
  * Unknown names return MH_ERR_ARG (set) / -1 (get). */
 int mh_set_option(const char* name, long value);
 long mh_get_option(const char* name);
