@@ -107,6 +107,29 @@ __global__ __launch_bounds__(256) void rope_qk_kernel(T* __restrict__ qk, int ld
   }
 }
 
+// rotate-half RoPE in place on the cached keys of positions 0 .. np-1: kc [BH][tgt][64], one thread per (bh, pos, 8 pairs)
+template <typename T>
+__global__ __launch_bounds__(256) void rope_cache_kernel(T* __restrict__ kc, long BH, int tgt, int np, const float* __restrict__ rope) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= BH * np * 4) return;
+  const int c = (int)(idx & 3);
+  const long rp = idx >> 2;
+  const int pos = (int)(rp % np);
+  const long bh = rp / np;
+  T* x1 = kc + (bh * tgt + pos) * 64 + c * 8;
+  T* x2 = x1 + 32;
+  const float* cs = rope + (long)pos * 64 + c * 8;
+  float a[8], b[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { a[i] = Elem<T>::to_f32(x1[i]); b[i] = Elem<T>::to_f32(x2[i]); }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float co = cs[i], si = cs[32 + i];
+    x1[i] = Elem<T>::from_f32(a[i] * co - b[i] * si);
+    x2[i] = Elem<T>::from_f32(b[i] * co + a[i] * si);
+  }
+}
+
 // h[b * L + t][:] = row_bias[b][:]  (the conditioning embedders' contribution, constant along a chunk's frames)
 __global__ __launch_bounds__(256) void fill_rows_kernel(float* __restrict__ h, const float* __restrict__ row_bias, int L, int d) {
   const long row = blockIdx.x;
@@ -1084,6 +1107,11 @@ int prefill_prompt(const MhT5Config* c, const MhT5Weights* w, const void* cross_
   const int d = c->d_model, H = c->n_heads, inner = H * 64, dff = c->d_ff, L = c->src_len, tgt = c->tgt_len;
   const int es = es_of(c->dtype);
   const int np_pad = round_up(np, 64);
+  // arch 1 (VarWhisperDecoderLayer, modeling_varwhisper.py:633-741) through the same batched form: biased projections,
+  // rotate-half RoPE on q and on the cached keys, scores / 8 without a relative bias, fc1 -> gelu(erf) -> fc2.  Global layers
+  // only: the caller keeps the token-by-token path when the model has local (windowed) layers.
+  const bool wh = c->arch == 1;
+  if (wh) MH_REQUIRE(w->dec_rope != nullptr, "prefill: the Whisper family needs its rotary table");
   if (c->dtype == MH_BF16)
     hipLaunchKernelGGL(prefill_embed_kernel<bf16_t>, dim3(rows), dim3(256), 0, s, prompt, P, np, (const bf16_t*)w->dec_embed, d, pb.h);
   else
@@ -1106,25 +1134,39 @@ int prefill_prompt(const MhT5Config* c, const MhT5Weights* w, const void* cross_
     g.A = pb.n; g.lda = d; g.W = w->dec_qkv[l]; g.ldw = d; g.C = pb.q; g.ldc = inner; g.M = rows; g.N = 3 * inner; g.K = d;
     g.dtype = c->dtype; g.epilogue = MH_EPI_QKV_CACHE; g.n_split = inner; g.C2 = kc; g.C3 = vc; g.C4 = pb.vt; g.kv_B = B;
     g.kv_H = H; g.kv_L = np; g.kv_Lpad = np_pad; g.cache_len = tgt;
+    if (wh) g.bias = w->dec_qkv_b[l];
     MH_TRY(gemm(g, s));
+    if (wh) {   // rotate-half RoPE on q (all prompt positions) and on the keys just cached; position = column of the padded prompt
+      const long wq = (long)rows * H * 4, wk = (long)B * H * np * 4;
+      if (c->dtype == MH_BF16) {
+        hipLaunchKernelGGL(mh::rope_qk_kernel<bf16_t>, dim3((unsigned)((wq + 255) / 256)), dim3(256), 0, s, (bf16_t*)pb.q, inner, (long)rows, np, H, w->dec_rope);
+        hipLaunchKernelGGL(mh::rope_cache_kernel<bf16_t>, dim3((unsigned)((wk + 255) / 256)), dim3(256), 0, s, (bf16_t*)kc, (long)B * H, tgt, np, w->dec_rope);
+      } else {
+        hipLaunchKernelGGL(mh::rope_qk_kernel<float>, dim3((unsigned)((wq + 255) / 256)), dim3(256), 0, s, (float*)pb.q, inner, (long)rows, np, H, w->dec_rope);
+        hipLaunchKernelGGL(mh::rope_cache_kernel<float>, dim3((unsigned)((wk + 255) / 256)), dim3(256), 0, s, (float*)kc, (long)B * H, tgt, np, w->dec_rope);
+      }
+      MH_TRY(check_launch("rope (prefill)"));
+    }
     AttnArgs a{};
     a.q = pb.q; a.q_rs = (long)inner * es; a.q_bs = (long)np * inner * es;
     a.k = kc; a.k_rs = 64L * es; a.k_hs = (long)tgt * 64 * es; a.k_bs = (long)H * tgt * 64 * es;
     a.vt = pb.vt; a.Lkpad = np_pad; a.vt_hs = 64L * np_pad * es; a.vt_bs = (long)H * 64 * np_pad * es;
-    a.bias = w->dec_rel_bias; a.bias_hs = tgt; a.bias_center = 0; a.bias_sign = -1; a.bias_min = 0; a.bias_max = tgt - 1;
+    if (!wh) { a.bias = w->dec_rel_bias; a.bias_hs = tgt; a.bias_center = 0; a.bias_sign = -1; a.bias_min = 0; a.bias_max = tgt - 1; }
     a.key_mask = prompt_mask; a.mask_ld = P; a.mask_len = np;
     a.out = pb.attn; a.out_rs = (long)inner * es; a.out_bs = (long)np * inner * es;
-    a.Lq = np; a.Lk = np; a.scale = 1.0f; a.band = 0; a.causal = 1; a.q_pos0 = 0;
+    a.Lq = np; a.Lk = np; a.scale = wh ? c->attn_scale : 1.0f; a.band = 0; a.causal = 1; a.q_pos0 = 0;
     MH_TRY(attention_general(a, B, H, c->dtype, s));
     g = MhGemm{};
     g.A = pb.attn; g.lda = inner; g.W = w->dec_o[l]; g.ldw = inner; g.C = pb.h; g.ldc = d; g.M = rows; g.N = d; g.K = inner;
     g.dtype = c->dtype; g.epilogue = MH_EPI_RESID;
+    if (wh) g.bias = w->dec_o_b[l];
     MH_TRY(gemm(g, s));
     // cross attention of every prompt position over the encoder keys
     MH_TRY(rmsnorm(pb.h, d, w->dec_ln2[l], pb.n, d, rows, d, c->eps, c->dtype, s));
     g = MhGemm{};
     g.A = pb.n; g.lda = d; g.W = w->dec_cq[l]; g.ldw = d; g.C = pb.q; g.ldc = inner; g.M = rows; g.N = inner; g.K = d;
     g.dtype = c->dtype; g.epilogue = MH_EPI_STORE;
+    if (wh) g.bias = w->dec_cq_b[l];
     MH_TRY(gemm(g, s));
     for (int b0 = 0; b0 < B; b0 += kvB) {   // under CFG both halves of the batch attend to the same kvB encoder rows
       a = AttnArgs{};
@@ -1134,22 +1176,26 @@ int prefill_prompt(const MhT5Config* c, const MhT5Weights* w, const void* cross_
       a.vt = (char*)pb.cross_vt + (long)l * kvB * inner * pb.Lpad * es; a.Lkpad = pb.Lpad; a.vt_hs = 64L * pb.Lpad * es;
       a.vt_bs = (long)H * 64 * pb.Lpad * es;
       a.out = (char*)pb.attn + (long)b0 * np * inner * es; a.out_rs = (long)inner * es; a.out_bs = (long)np * inner * es;
-      a.Lq = np; a.Lk = L; a.scale = 1.0f;
+      a.Lq = np; a.Lk = L; a.scale = wh ? c->attn_scale : 1.0f;
       MH_TRY(attention_general(a, kvB, H, c->dtype, s));
     }
     g = MhGemm{};
     g.A = pb.attn; g.lda = inner; g.W = w->dec_co[l]; g.ldw = inner; g.C = pb.h; g.ldc = d; g.M = rows; g.N = d; g.K = inner;
     g.dtype = c->dtype; g.epilogue = MH_EPI_RESID;
+    if (wh) g.bias = w->dec_co_b[l];
     MH_TRY(gemm(g, s));
     // feed forward
     MH_TRY(rmsnorm(pb.h, d, w->dec_ln3[l], pb.n, d, rows, d, c->eps, c->dtype, s));
     g = MhGemm{};
-    g.A = pb.n; g.lda = d; g.W = w->dec_wi[l]; g.ldw = d; g.C = pb.ff; g.ldc = dff; g.M = rows; g.N = 2 * dff; g.K = d;
-    g.dtype = c->dtype; g.epilogue = MH_EPI_GEGLU;
+    g.A = pb.n; g.lda = d; g.W = w->dec_wi[l]; g.ldw = d; g.C = pb.ff; g.ldc = dff; g.M = rows; g.K = d;
+    g.dtype = c->dtype;
+    if (wh) { g.N = dff; g.epilogue = MH_EPI_BIAS_GELU_ERF; g.bias = w->dec_fc1_b[l]; }     // fc1 -> gelu(erf) (modeling_varwhisper.py:633-741)
+    else { g.N = 2 * dff; g.epilogue = MH_EPI_GEGLU; }
     MH_TRY(gemm(g, s));
     g = MhGemm{};
     g.A = pb.ff; g.lda = dff; g.W = w->dec_wo[l]; g.ldw = dff; g.C = pb.h; g.ldc = d; g.M = rows; g.N = d; g.K = dff;
     g.dtype = c->dtype; g.epilogue = MH_EPI_RESID;
+    if (wh) g.bias = w->dec_fc2_b[l];
     MH_TRY(gemm(g, s));
   }
   return MH_OK;
@@ -1345,7 +1391,9 @@ extern "C" int mh_t5_generate(const MhT5Config* c, const MhT5Weights* w, const v
   // batched prompt prefill (positions 0..P-2); MH_DECODE_PREFILL=0 feeds the prompt token by token instead
   int start_pos = 0;
   {
-    if (P > 1 && option(OPT_DECODE_PREFILL) != 0 && c->arch == 0) {   // (the Whisper family feeds its prompt token by token)
+    bool has_local = false;
+    for (int l = 0; l < c->n_dec_layers; ++l) has_local = has_local || is_local_layer(c, l);
+    if (P > 1 && option(OPT_DECODE_PREFILL) != 0 && !has_local) {   // (a Whisper-family model with local layers feeds its prompt token by token)
       PrefillBuf pb;
       const int64_t used_dec = ar.off;
       prefill_layout(c, B, P - 1, (char*)workspace + used_dec, workspace_bytes - used_dec, &pb);

@@ -16,7 +16,8 @@ reference applies on its flash-attention path (:330); its eager / sdpa paths ign
 every layer global (configs/model/default.yaml:24).
 
 Numerics contract: as t5_engine.py (bf16 storage = bf16 parameters and GEMM operands, fp32 accumulation / residual
-stream / norms / softmax / GELU / logits).  The prompt is fed token by token (no batched prefill for this family yet).
+stream / norms / softmax / GELU / logits).  The prompt goes through the batched prefill (RoPE on q and on the cached keys, biased GEMMs); a model with local (windowed)
+layers feeds it token by token.
 """
 from __future__ import annotations
 

@@ -52,6 +52,14 @@ def test_fp32_matches_reference_golden(name):
     mk = dict(inputs=audio, decoder_input_ids=prompt, decoder_attention_mask=prompt.ne(0))
     ids, stats = model_generate(model, tok, mk, gen_kwargs(tgt))
     assert ids.shape == g["ids"].shape and np.array_equal(ids.numpy(), g["ids"]), np.argwhere(ids.numpy() != g["ids"])[:3]
+    if name == "vw_test":      # the ragged prompts went through the batched prefill (RoPE on q and on the cached keys, biased
+        from mapperatorinator_amd import _lib      # GEMMs): the token-by-token prompt path gives the reference's ids too
+        old = _lib.set_option("decode_prefill", 0)
+        try:
+            ids_tok, _ = model_generate(model, tok, mk, gen_kwargs(tgt))
+        finally:
+            _lib.set_option("decode_prefill", old)
+        assert np.array_equal(ids_tok.numpy(), g["ids"])
     ids2, _ = model_generate(model, tok, mk, gen_kwargs(tgt, temperature=0.7, timeshift_bias=0.35, lookahead_time=3000))
     assert ids2.shape == g["ids_processors"].shape and np.array_equal(ids2.numpy(), g["ids_processors"])
     sp, eos = build_sampling(tok, gen_kwargs(tgt), tgt)
