@@ -1528,7 +1528,8 @@ extern "C" int mh_t5_decoder_forward(const MhT5Config* c, const MhT5Weights* w, 
                                      const int32_t* ids, const uint8_t* mask, int T, float* logits, void* workspace,
                                      int64_t workspace_bytes, void* stream) {
   MH_TRY(check_cfg(c, "mh_t5_decoder_forward"));
-  MH_REQUIRE(c->arch == 0, "mh_t5_decoder_forward: arch 1 has no batched prompt path yet -- use mh_t5_generate with `forced` and `logits_dump`");
+  for (int l = 0; l < c->n_dec_layers; ++l)
+    MH_REQUIRE(!is_local_layer(c, l), "mh_t5_decoder_forward: local (windowed) layers have no batched prompt path -- use mh_t5_generate with `forced` and `logits_dump`");
   MH_REQUIRE(w && cross_kv && ids && logits && workspace, "mh_t5_decoder_forward: null argument");
   MH_REQUIRE(B > 0 && T >= 1 && T <= c->tgt_len, "mh_t5_decoder_forward: T=%d not in [1, tgt_len=%d]", T, c->tgt_len);
   MH_REQUIRE(workspace_bytes >= mh_t5_forward_workspace_bytes(c, B, T), "mh_t5_decoder_forward: workspace too small");

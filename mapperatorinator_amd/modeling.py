@@ -205,9 +205,9 @@ class MapperatorinatorHIP:
         mask = (decoder_attention_mask.to(eng.device).to(torch.uint8).contiguous()
                 if decoder_attention_mask is not None else None)
         row_bias = self._row_bias(ids.shape[0], unused) if encoder_outputs is None else None
-        if self.is_whisper:
-            # no batched teacher-forced path for this family yet: the token loop with the ids forced and its scores dumped
-            # (no processors: an empty sampling struct leaves the logits as they are)
+        if self.is_whisper and self._has_local_layers():
+            # local (windowed) layers have no batched teacher-forced path: the token loop with the ids forced and its scores
+            # dumped (no processors: an empty sampling struct leaves the logits as they are)
             from .server import Sampling
             sp = Sampling()
             sp.temperature, sp.cfg_scale, sp.max_length, sp.pad_id = 1.0, 1.0, ids.shape[1] + 1, int(self.config.pad_token_id)
@@ -233,6 +233,10 @@ class MapperatorinatorHIP:
         return types.SimpleNamespace(logits=logits, encoder_last_hidden_state=None, past_key_values=None, loss=None)
 
     __call__ = forward
+
+    def _has_local_layers(self) -> bool:
+        cfg = self.engine.packed.cfg
+        return bool(cfg.arch == 1 and cfg.local_every > 1 and cfg.local_window > 0 and cfg.n_dec_layers > 1)
 
     @torch.no_grad()
     def generate(self, inputs=None, frames=None, decoder_input_ids=None, decoder_attention_mask=None,

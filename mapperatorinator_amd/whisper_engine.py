@@ -197,4 +197,9 @@ class VarWhisperEngine(T5Engine):
         return self.spectrogram.forward_padded(audio, p.n_mels_pad, self.dtype)
 
     def decoder_forward(self, cross_kv, ids, mask=None):
-        raise NotImplementedError("teacher-forced forward of the Whisper family: use generate(..., forced=ids, dump_logits=True)")
+        """Batched teacher-forced logits (the prompt-prefill form over all positions); a model with local (windowed) layers
+        has no such path -- use generate(..., forced=ids, dump_logits=True)."""
+        cfg = self.packed.cfg
+        if cfg.local_every > 1 and cfg.local_window > 0 and cfg.n_dec_layers > 1:
+            raise NotImplementedError("teacher-forced forward with local layers: use generate(..., forced=ids, dump_logits=True)")
+        return super().decoder_forward(cross_kv, ids, mask)
