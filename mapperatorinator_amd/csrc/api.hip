@@ -4,6 +4,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+
 #include "common.hpp"
 
 namespace mh {
@@ -28,7 +30,9 @@ int check_launch(const char* what) {
 
 // ---- tuning options: a default, an environment override read at first use, and mh_set_option() at run time --------
 // (process-wide, not per call: they select between kernels that compute the same results)
-struct OptionSlot { const char* name; const char* env; long value; bool resolved; };
+// (atomics: the decode chains' launcher threads read options while a caller's thread may set one -- a torn or stale read is
+// excluded; two engines that want DIFFERENT variants in one process still share the switch: options are process-wide)
+struct OptionSlot { const char* name; const char* env; std::atomic<long> value; std::atomic<bool> resolved; };
 static OptionSlot g_options[OPT_COUNT] = {
     {"gemm_splitk_tiles", "MH_GEMM_SPLITK_TILES", 192, false},   // below this many 32x32 tiles the 16x16 split-K tile is used (0 = never)
     {"decode_chains", "MH_DECODE_CHAINS", 0, false},             // independent row chains of the decode step (0 = automatic)
@@ -50,12 +54,12 @@ static OptionSlot g_options[OPT_COUNT] = {
 
 long option(int id) {
   OptionSlot& o = g_options[id];
-  if (!o.resolved) {
+  if (!o.resolved.load(std::memory_order_acquire)) {
     const char* e = getenv(o.env);
-    if (e && *e) o.value = atol(e);
-    o.resolved = true;
+    if (e && *e) o.value.store(atol(e), std::memory_order_relaxed);
+    o.resolved.store(true, std::memory_order_release);
   }
-  return o.value;
+  return o.value.load(std::memory_order_relaxed);
 }
 
 }  // namespace mh
@@ -63,8 +67,8 @@ long option(int id) {
 extern "C" int mh_set_option(const char* name, long value) {
   for (int i = 0; name && i < mh::OPT_COUNT; ++i)
     if (strcmp(mh::g_options[i].name, name) == 0) {
-      mh::g_options[i].value = value;
-      mh::g_options[i].resolved = true;
+      mh::g_options[i].value.store(value, std::memory_order_relaxed);
+      mh::g_options[i].resolved.store(true, std::memory_order_release);
       return MH_OK;
     }
   mh::set_error("mh_set_option: unknown option '%s'", name ? name : "(null)");
