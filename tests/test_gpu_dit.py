@@ -505,3 +505,30 @@ def test_bf16_operand_mode_error_bounds(name):
         e57 = ((st["sample"].cpu()[0] - torch.from_numpy(g["p_sample_i57"])[0]).abs() * torch.tensor([256.0, 192.0])[:, None]).max().item()
         print(f"{name} one p_sample step vs reference: worst position {e57:.4f} px")
         assert e57 < 0.5
+
+
+def test_padded_window_at_the_pipeline_default_size_vs_oracle():
+    """`pad_sequence=True` at the pipeline's default max_seq_len = 1024 (diffusion_pipeline.py:186-193): 700 real points +
+    324 attendable pad positions, DiT-S, one CFG pair = 2048 rows -- the shape at which the bf16 x 3 path with pre-split
+    operands, the flash fp32 kernel's `open_from` mask and its pre-split output all meet.  eps against the oracle under the
+    padded mask tensor the reference builds (band padded with "allowed")."""
+    from mapperatorinator_amd.dit import BandMask, DiTHIP
+    from mapperatorinator_amd.testing import DIT_PRESETS, random_dit_state_dict, synthetic_dit_inputs
+    from oracle import dit as odit
+    depth, hidden, heads = DIT_PRESETS["DiT-S"]
+    sd = random_dit_state_dict(depth, hidden, seed=5)
+    T, real = 1024, 700
+    z, c, y = synthetic_dit_inputs(real, seed=8)
+    z = torch.nn.functional.pad(z, (0, T - real))
+    c = torch.nn.functional.pad(c, (0, T - real))
+    mask = BandMask(T, 128, open_from=real)
+    dit = DiTHIP(sd, depth, hidden, heads, device="cuda")
+    orc = odit.DiTOracle(sd, depth, hidden, heads)
+    t = torch.full((2,), 417, dtype=torch.long)
+    got = dit.forward_with_cfg(z.cuda(), t.cuda(), c.cuda(), y.cuda(), 1.5, attn_mask=mask).cpu()
+    want = orc.forward_with_cfg(z, t, c, y, 1.5, mask.to_tensor())
+    err = (got - want)[:, :, :real].abs().max().item()
+    print(f"padded 1024-point window: eps max abs err vs oracle {err:.2e} (scale {want.abs().max().item():.2f})")
+    assert err < 2e-4
+    plain = orc.forward_with_cfg(z[:, :, :real], t, c[:, :, :real], y, 1.5, BandMask(real, 128).to_tensor())
+    assert (plain - want[:, :, :real]).abs().max().item() > 1e-3, "the pad positions are attended: padding must change the result"
