@@ -57,7 +57,57 @@ def parse():
     ap.add_argument("--no-dit", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip config 1 / end-to-end / in-situ passes")
     ap.add_argument("--no-config5", action="store_true", help="skip the long-song (osuT5-large, 3 min songs) and DiT-B aux lines")
+    ap.add_argument("--selftest-launch", action="store_true",
+                    help="only form the process group (RCCL on a GPU box, gloo without one), all_gather the rank ids, print "
+                         "{selftest, n_gpus, rccl_ranks} and exit: the launch path of --gpus N without the workload")
     return ap.parse_args()
+
+
+def _free_port() -> int:
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks_if_needed(args) -> None:
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: become the launcher.  The process re-executes itself
+    under `torch.distributed.run --nproc-per-node N` (one rank per GPU, rendezvous on 127.0.0.1) and exits with the job's
+    status, so `--gpus N` ALWAYS means N ranks -- whether the driver wrapped the command in torchrun or not."""
+    if args.gpus <= 1 or "RANK" in os.environ or "WORLD_SIZE" in os.environ:
+        return
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def selftest_launch(args, world: int, rank: int, local_rank: int) -> None:
+    """The launch path alone: group formation on the backend the box offers, one all_gather, one line from rank 0."""
+    on_gpu = torch.cuda.is_available()
+    if on_gpu:
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank) if on_gpu else torch.device("cpu")
+    if world > 1 or "RANK" in os.environ:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        kw = dict(device_id=dev) if on_gpu else {}
+        dist.init_process_group("nccl" if on_gpu else "gloo", rank=rank, world_size=world, **kw)
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
+        mine = torch.tensor([rank], dtype=torch.int32, device=dev)
+        allr = torch.empty(world, dtype=torch.int32, device=dev)
+        dist.all_gather_into_tensor(allr, mine)
+        ranks = allr.cpu().tolist()
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        ranks = [0]
+    if rank == 0:
+        print(json.dumps({"selftest": "launch", "n_gpus": world, "rccl_ranks": ranks,
+                          "backend": "nccl (RCCL)" if on_gpu else "gloo"}), flush=True)
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -163,15 +213,22 @@ def dit_flops_per_step(depth: int, D: int, N: int, T: int, band: int = 0) -> flo
 
 def main():
     args = parse()
+    spawn_ranks_if_needed(args)                    # `--gpus N` without a launcher: re-execute under torch.distributed.run
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher formed WORLD_SIZE={world}; n_gpus must never "
+                         f"disagree with --gpus")
+    if args.selftest_launch:
+        return selftest_launch(args, world, rank, local_rank)
     use_dist = world > 1 or "RANK" in os.environ   # under torch.distributed.run the RCCL path is used even for N=1
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the product path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -569,6 +626,7 @@ def main():
                                f"per chunk, mel+encoder+cross-KV+AR decode (BASELINE configs[1])",
                    "chunks_per_gpu": B, "new_tokens": new, "src_frames": SRC_FRAMES, "vocab": tok.vocab_size_out,
                    "parallelism": f"chunk-sharded x{world}, all_gather of token streams (+ diffusion coordinates in aux)"},
+        "rccl_ranks": dist.get_world_size() if use_dist else 0,   # size of the RCCL group the token all_gather ran over (0: no group)
         "roofline": roofline, "cpu_baseline": cpu, "aux": aux,
     }
     print(json.dumps(line), flush=True)

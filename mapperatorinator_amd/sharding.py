@@ -59,8 +59,9 @@ def sharded_generate(generate_fn: Callable, model_kwargs: dict, pad_id: int, max
 
     Returns (tokens int64 CPU (B, max_length) padded with pad_id, lengths int64 (B,), local_stats) and, with
     refine_fn, a 4th element: coords fp32 CPU (B, 2, Tq) in global chunk order."""
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    grouped = dist.is_initialized()      # a formed group is USED even at world 1 (the RCCL path of a 1-GPU box = the N-GPU path)
+    world = dist.get_world_size(group) if grouped else 1
+    rank = dist.get_rank(group) if grouped else 0
     B = model_kwargs["inputs"].shape[0]
     lo, hi = shard_bounds(B, rank, world)
     shard = {k: (v[lo:hi] if isinstance(v, torch.Tensor) and v.shape[:1] == (B,) else v)
@@ -74,7 +75,7 @@ def sharded_generate(generate_fn: Callable, model_kwargs: dict, pad_id: int, max
         raise ValueError(f"generate_fn returned {toks.shape[1]} columns, max_length is {max_length}")
     # everything that travels is assembled ON the collective's device (RCCL: the GPU; gloo: the CPU): a generate_fn /
     # refine_fn that returns device tensors is never bounced through the host before the gather
-    dev = _comm_device(group, comm_device) if world > 1 else toks.device
+    dev = _comm_device(group, comm_device) if grouped else toks.device
     local = torch.full((hi - lo, max_length + 1), pad_id, dtype=torch.int32, device=dev)
     local[:, : toks.shape[1]] = toks.to(device=dev, dtype=torch.int32)
     local[:, max_length] = toks.shape[1]          # column max_length carries the produced length
@@ -84,7 +85,7 @@ def sharded_generate(generate_fn: Callable, model_kwargs: dict, pad_id: int, max
         coords = refine_fn(shard, toks) if hi > lo else None
         # every rank must agree on Tq even when its shard is empty: settle it with the first non-empty shard's shape
         shape_t = torch.tensor(list(coords.shape[1:]) if coords is not None else [0, 0], dtype=torch.int64, device=dev)
-        if world > 1:
+        if grouped:
             shapes = [torch.zeros_like(shape_t) for _ in range(world)]      # outputs live where the input lives
             dist.all_gather(shapes, shape_t, group=group)
             shape_t = max((s_.cpu() for s_ in shapes), key=lambda s_: int(s_.prod()))
@@ -96,7 +97,7 @@ def sharded_generate(generate_fn: Callable, model_kwargs: dict, pad_id: int, max
                 raise ValueError(f"refine_fn returned {tuple(coords.shape)}; every rank must use the same (2, Tq) = {coord_shape}")
             packed = coords.to(device=dev, dtype=torch.float32).contiguous().reshape(hi - lo, n_coord).view(torch.int32)
         local = torch.cat([local, packed], 1)
-    if world == 1:
+    if not grouped:
         full = local.cpu()
     else:
         full = all_gather_ragged(local, B, group).cpu()

@@ -807,3 +807,21 @@ def test_request_batcher_answers_every_request_like_a_call_of_its_own():
         n = min(got.shape[1], alone.shape[1] - pad)          # a batch runs until its longest row ends: pad columns may differ
         assert torch.equal(got[:, :n], alone[:, pad:pad + n]) and (got[:, n:] == 0).all() and (alone[:, pad + n:] == 0).all()
         assert rec["result"]["stats"]["generated_tokens"] == stats["generated_tokens"]
+
+
+def test_sharded_generate_on_rccl_world_1():
+    """SURVEY 8e on the backend the N-GPU job uses: an RCCL process group (one rank: what this box offers) carries the token
+    streams of `model_generate` and the device-resident coordinates of a DiT refine through ONE all_gather; both must come
+    back bit-equal to the plain calls.  Own process: a process group is process-global state (tools/nccl_world1_check.py)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "nccl_world1_check.py")], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert p.returncode == 0, (p.stdout[-1000:], p.stderr[-3000:])
+    line = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")][-1]
+    assert line["tokens_equal"] and line["coords_bit_equal"] and line["backend"] == "nccl"

@@ -108,3 +108,33 @@ def test_two_rank_gather_equals_single_process(B):
         lo, hi = shard_bounds(B, r, 2)
         if hi > lo:
             assert int(ret[0][1][lo:hi].max()) == int((want[lo:hi] != 0).nonzero()[:, 1].max()) + 1
+
+
+# ---- bench.py --gpus N is its own launcher: N ranks, never a silent single-rank run ---------------
+def _run_bench(argv, env_extra=None, timeout=300):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + argv, env=env, capture_output=True, text=True,
+                       timeout=timeout)
+    lines = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
+    return p, lines
+
+
+def test_bench_gpus_2_forms_two_ranks_by_itself():
+    """`python bench.py --gpus 2` with NO launcher around it must come back from a 2-rank group (gloo here, RCCL on a GPU
+    box): the launch path of the real bench, minus the workload."""
+    p, lines = _run_bench(["--gpus", "2", "--selftest-launch"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert len(lines) == 1, p.stdout
+    assert lines[0]["n_gpus"] == 2 and lines[0]["rccl_ranks"] == [0, 1]
+
+
+def test_bench_refuses_a_world_that_disagrees_with_gpus():
+    """a launcher that formed 1 rank while the command says --gpus 2 is an error, not a 1-GPU measurement"""
+    p, lines = _run_bench(["--gpus", "2", "--selftest-launch"], env_extra={"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
+    assert p.returncode != 0 and not lines
+    assert "must never" in p.stderr
