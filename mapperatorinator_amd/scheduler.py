@@ -61,6 +61,7 @@ class SequentialWindowScheduler:
         self.engine = model.engine
         self.encode_batch, self.decode_batch = int(encode_batch), int(decode_batch)
         self.stats = dict(windows=0, decode_calls=0, encode_calls=0, generated_tokens=0, elapsed_seconds=0.0)
+        self._seed_calls: dict = {}       # explicit seed -> decode calls made with it BY THIS scheduler
 
     # ---- stage 1: everything that depends on the audio only ------------------------------------------------
     @torch.no_grad()
@@ -144,6 +145,8 @@ class SequentialWindowScheduler:
             for group in asks.values():
                 # guidance doubles the decode batch (negative rows + prompt rows): half as many windows per call
                 step = max(1, self.decode_batch // 2) if float(group[0][2].get("cfg_scale", 1.0)) > 1.0 else self.decode_batch
+                # beam search decodes (window, beam) rows: num_beams rows per window (processor.py:159; the timing pass uses 2)
+                step = max(1, step // max(1, int(group[0][2].get("num_beams", 1) or 1)))
                 for a in range(0, len(group), step):
                     self._decode_group(jobs, kvs, w, group[a:a + step], pad_id)
         self.stats["elapsed_seconds"] += time.perf_counter() - start
@@ -154,10 +157,20 @@ class SequentialWindowScheduler:
         # rows of different songs share this batch where the reference runs one batch-1 call per window: the conditional
         # temperature must look at each row's OWN history (the reference's processor reads row 0 of its batch)
         gk = dict(group[0][2], conditional_temperature_per_row=True)
+        if gk.get("seed") is not None and gk.get("seed_call_index") is None:
+            # explicit seed: the n-th decode call of THIS scheduler with that seed draws from stream (seed, n) -- the count is
+            # the scheduler's own, so a run reproduces whatever else samples in the process (server.fresh_seed)
+            n = self._seed_calls.get(gk["seed"], 0)
+            self._seed_calls[gk["seed"]] = n + 1
+            gk["seed_call_index"] = n
         sp, eos = build_sampling(tok, gk, self.model.config.max_target_positions)
         cfg = sp.cfg_scale > 1.0
-        if len(group) * (2 if cfg else 1) > 64:
-            raise ValueError(f"{len(group)} windows{' x 2 (guidance)' if cfg else ''} exceed the engine's 64-row decode batch")
+        nb = int(getattr(sp, "num_beams", 1) or 1)
+        if nb > 1 and cfg:
+            raise NotImplementedError("beam search under classifier-free guidance is not on the HIP path")
+        if len(group) * (2 if cfg else 1) * nb > 64:
+            raise ValueError(f"{len(group)} windows{' x 2 (guidance)' if cfg else ''}{f' x {nb} beams' if nb > 1 else ''} exceed "
+                             f"the engine's 64-row decode batch")
         prompts = _left_pad([g[1]["decoder_input_ids"] for g in group], pad_id, torch.int64)
         masks = None
         if any(g[1].get("decoder_attention_mask") is not None for g in group):
@@ -190,15 +203,23 @@ class SequentialWindowScheduler:
             m_all = None if masks is None else (torch.cat([masks, masks], 0) if cfg else masks)
             # generate_kwargs["cross_kv_fp8"]: the token steps stream an e4m3 copy of this wave's cross K / V
             kv8 = eng.cross_kv_fp8(kv) if gk.get("cross_kv_fp8") else None
-            tokens, n_out, _ = eng.decode(kv, p_all.to(dev, torch.int32).contiguous(),
-                                          None if m_all is None else m_all.to(dev).contiguous(),
-                                          eos_table.to(dev), sp, kv_fp8=kv8)
+            if nb == 1:
+                tokens, n_out, _ = eng.decode(kv, p_all.to(dev, torch.int32).contiguous(),
+                                              None if m_all is None else m_all.to(dev).contiguous(),
+                                              eos_table.to(dev), sp, kv_fp8=kv8)
         eng._leave()
-        eng.synchronize()
-        n_cols = int(n_out.item())
-        if cfg:
-            tokens = tokens[len(group):]
-        result = tokens[:, :n_cols].to(torch.int64).cpu()
+        if nb > 1:
+            # HF beam search over the step-wise decode entry (beam.py), the windows of this wave as its batch: every window's
+            # hypotheses are ranked among themselves only, so a window decodes as in the reference's batch-1 call; rows that
+            # end early carry HF's fill (the first EOS id) and are cut at their first EOS-set id below like any other row
+            from .beam import beam_search
+            result = beam_search(eng, kv, p_all, m_all, eos, sp, nb).to(torch.int64).cpu()
+        else:
+            eng.synchronize()
+            n_cols = int(n_out.item())
+            if cfg:
+                tokens = tokens[len(group):]
+            result = tokens[:, :n_cols].to(torch.int64).cpu()
         elapsed = time.perf_counter() - t0
         self.stats["decode_calls"] += 1
         P = prompts.shape[1]

@@ -114,21 +114,33 @@ def _build_generation_stats(result, model_kwargs, pad_token_id, elapsed_seconds)
 
 
 _SEED_CALLS: dict = {}
+_SEED_CALLS_MAX = 4096                    # distinct explicit seeds remembered (least recently used ones are forgotten)
+_SEED_LOCK = __import__("threading").Lock()
 
 
-def fresh_seed(seed=None) -> int:
+def fresh_seed(seed=None, call_index=None) -> int:
     """Seed of one generate call.  The reference samples with `torch.multinomial`, which ADVANCES the global generator
     on every draw, so two calls never replay the same uniforms; the in-kernel RNG is keyed by (seed, row, column), so
     the call's seed must move instead.  Without an explicit seed: one 63-bit draw from torch's default generator per call
     (still a deterministic function of `torch.manual_seed`).  With an explicit `seed` (a caller that wants reproducible
     runs): the n-th call made with that seed gets splitmix64(seed, n) -- the windows and waves of a song, or consecutive
     `model_generate` calls, draw from different streams, and the same sequence of calls reproduces the same tokens
-    (`reset_seed_calls()` restarts the count)."""
+    (`reset_seed_calls()` restarts the count).  That count is process-wide (guarded by a lock, bounded); a caller whose
+    draws must not depend on what else ran in the process -- other threads, a batcher splitting requests differently, the
+    ranks of a sharded job -- passes its OWN count as `call_index` (generate kwarg `seed_call_index`)."""
     if seed is None:
         return int(torch.randint(0, 2 ** 63 - 1, (1,), dtype=torch.int64).item())
     seed = int(seed) & 0xFFFFFFFFFFFFFFFF
-    n = _SEED_CALLS.get(seed, 0)
-    _SEED_CALLS[seed] = n + 1
+    if call_index is not None:
+        # the caller owns the count (a scheduler / batcher / sharded rank that wants its draws independent of what else
+        # ran in the process): stream (seed, call_index), nothing global is read or advanced
+        n = int(call_index)
+    else:
+        with _SEED_LOCK:
+            n = _SEED_CALLS.pop(seed, 0)
+            _SEED_CALLS[seed] = n + 1                 # (re-inserted last: the dict stays in least-recently-used order)
+            while len(_SEED_CALLS) > _SEED_CALLS_MAX:
+                _SEED_CALLS.pop(next(iter(_SEED_CALLS)))
     z = (seed + 0x9E3779B97F4A7C15 * (n + 1)) & 0xFFFFFFFFFFFFFFFF
     z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
     z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
@@ -137,7 +149,8 @@ def fresh_seed(seed=None) -> int:
 
 def reset_seed_calls() -> None:
     """Forget how many calls were made with each explicit seed (see `fresh_seed`)."""
-    _SEED_CALLS.clear()
+    with _SEED_LOCK:
+        _SEED_CALLS.clear()
 
 
 def build_sampling(tokenizer, generate_kwargs: dict, max_target_positions: int):
@@ -212,7 +225,7 @@ def build_sampling(tokenizer, generate_kwargs: dict, max_target_positions: int):
     sp.num_beams = num_beams               # (host attribute: beam search runs through mapperatorinator_amd.beam)
     sp.pad_id = int(gk.get("pad_token_id", getattr(tokenizer, "pad_id", 0)) or 0)
     sp.max_length = int(gk.get("max_length", max_target_positions))
-    sp.seed = fresh_seed(gk.get("seed")) if sp.do_sample else 0     # greedy decoding leaves the global generator alone
+    sp.seed = fresh_seed(gk.get("seed"), gk.get("seed_call_index")) if sp.do_sample else 0   # greedy decoding leaves the global generator alone
     # ConditionalTemperatureLogitsWarper looks at row 0's history for the whole batch in the reference
     # (logit_processors.py:75-80); callers that batch rows of DIFFERENT songs / shards, where the reference would have
     # run batch-1 calls, ask for the per-row form (scheduler.py, sharding.py)
@@ -357,12 +370,13 @@ class RequestBatcher:
         self.grouped_requests: dict = {}
         self.prefetch = True          # start the next batch's H2D before this batch decodes (HIP engine only)
         self._staged, self._stager = None, None
+        self._seed_calls: dict = {}   # explicit seed -> batches decoded with it BY THIS batcher (fresh_seed's call_index)
 
     def submit(self, model_kwargs: dict, generate_kwargs: dict) -> dict:
         """Queue one request (what `_client_handler` does on `conn.recv()`, :297-322); returns its record, whose
         'result' is filled by `step` once 'work_done' == 'total_work'."""
         record = dict(model_kwargs=model_kwargs, total_work=int(model_kwargs["inputs"].shape[0]), work_done=0, work_taken=0, result=None,
-                      generated_tokens=0, elapsed_seconds=0.0, done=False)
+                      generated_tokens=0, elapsed_seconds=0.0, done=False, error=None)
         self.grouped_requests.setdefault(frozenset(generate_kwargs.items()), []).append(record)
         return record
 
@@ -442,10 +456,24 @@ class RequestBatcher:
         self._staged = self._stage(self._take_batch())
         if ev is not None:
             torch.cuda.current_stream(collated["inputs"].device).wait_event(ev)
-        outputs, stats = self.generate_fn(self.model, self.tokenizer, collated, generate_kwargs)
+        if generate_kwargs.get("seed") is not None and generate_kwargs.get("seed_call_index") is None:
+            n = self._seed_calls.get(generate_kwargs["seed"], 0)
+            self._seed_calls[generate_kwargs["seed"]] = n + 1
+            generate_kwargs = dict(generate_kwargs, seed_call_index=n)
+        try:
+            outputs, stats = self.generate_fn(self.model, self.tokenizer, collated, generate_kwargs)
+        except BaseException as e:
+            # the reference answers every request of a failed batch with RETRY_SIGNAL (server.py:418-424) instead of leaving
+            # its client waiting: here each of them is closed with the error (rows of it still queued or staged are dropped
+            # with it -- the caller resubmits the whole request), then the error goes on to whoever drives the batcher
+            self._fail([req for _, req, _ in batch], e)
+            raise
         per_row = stats.get("generated_tokens_per_sample", [])
         row = 0
         for (_, req, work), pad in zip(batch, paddings):
+            if req["error"] is not None:           # closed by a failure of an earlier part: its rows are not delivered
+                row += work
+                continue
             out = outputs[row:row + work, pad:]
             req["generated_tokens"] += sum(per_row[row:row + work])
             row += work
@@ -466,6 +494,19 @@ class RequestBatcher:
                                            "tokens_per_second": toks / secs if secs > 0 else 0.0}}
                 req["done"] = True
         return row
+
+    def _fail(self, reqs, exc) -> None:
+        dead = {id(r) for r in reqs}
+        for r in reqs:
+            r["error"], r["done"], r["result"] = exc, True, None
+        for key in list(self.grouped_requests):
+            left = [r for r in self.grouped_requests[key] if id(r) not in dead]
+            if left:
+                self.grouped_requests[key] = left
+            else:
+                del self.grouped_requests[key]
+        # rows of a failed request that the prefetched batch already holds stay in it (the batch is collated and on its way to
+        # the device); `step` skips them when it hands the results out
 
     def drain(self) -> int:
         """Run batches until nothing is queued; returns how many batches ran."""

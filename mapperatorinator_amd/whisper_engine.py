@@ -106,6 +106,12 @@ class PackedVarWhisper:
                               1, 0.125, in_frames, int(global_attn_every_n_layers), int(local_attention) // 2)
         w = _lib.MhT5Weights()
         pe, pd = "transformer.model.encoder.", "transformer.model.decoder."
+        c1, c2 = sd[pe + "conv1.weight"], sd[pe + "conv2.weight"]
+        if c1.shape[1] != n_mels or tuple(c2.shape[:2]) != (d, d) or c1.shape[0] != d or c1.shape[2] != 3 or c2.shape[2] != 3:
+            # a checkpoint whose conv1 takes n_mels + conditioning channels (input_features with conditioning embedders,
+            # modeling_mapperatorinator.py:104-128) would have its extra channels CROPPED by the padding below
+            raise NotImplementedError(f"conv front-end of shape conv1 {tuple(c1.shape)} / conv2 {tuple(c2.shape)} is not on the HIP path: "
+                                      f"expected conv1 ({d}, n_mels = {n_mels}, 3) and conv2 ({d}, {d}, 3)")
         w.conv1_w = conv(sd[pe + "conv1.weight"], self.n_mels_pad).data_ptr()
         w.conv1_b = vec(sd[pe + "conv1.bias"]).data_ptr()
         w.conv2_w = conv(sd[pe + "conv2.weight"], d).data_ptr()

@@ -657,8 +657,11 @@ def test_model_object_generate_and_forward_seam_b2():
     assert worst < 5e-4
 
 
-def test_window_scheduler_matches_sequential_loop():
-    """8f rank 1: three songs with 3 / 2 / 4 dependent windows through SequentialWindowScheduler (all windows encoded up
+@pytest.mark.parametrize("beams", [1, 2])
+def test_window_scheduler_matches_sequential_loop(beams):
+    """`beams` = 2: the reference's timing pass decodes with two beams (processor.py:159 forwards `num_beams`); the scheduler
+    must beam-search its waves too (it used to decode them greedily without a word).
+    8f rank 1: three songs with 3 / 2 / 4 dependent windows through SequentialWindowScheduler (all windows encoded up
     front, wave w decodes window w of every song as one batch) == the reference-shaped loop (one batch-1
     `model_generate` per window, in order).  Each prompt is built from the previous window's output, so a scheduling
     mistake (wrong K/V row, wrong order, stale prompt) changes the tokens."""
@@ -672,7 +675,8 @@ def test_window_scheduler_matches_sequential_loop():
     ts0, ts1 = ts_range(tok)
 
     def kwargs_for(w, n):   # first window: no lookback trimming; last: no lookahead (processor.py:327-328)
-        return gen_kwargs(tgt, lookback_time=400 if w != 0 else 0, lookahead_time=3000 if w != n - 1 else 0, temperature=0.9)
+        return gen_kwargs(tgt, lookback_time=400 if w != 0 else 0, lookahead_time=3000 if w != n - 1 else 0, temperature=0.9,
+                          num_beams=beams)
 
     def prompt_from(prev):  # sos + up to 3 non-special ids of the previous window's output
         if prev is None:
@@ -715,6 +719,10 @@ def test_window_scheduler_matches_sequential_loop():
             assert a.shape == b.shape and torch.equal(a, b), (k, w, a.tolist(), b.tolist())
     # fewer decode calls than windows: songs were interleaved
     assert stats["decode_calls"] < sum(n_windows)
+    if beams > 1:   # the fixture must tell beam search from greedy decoding, or this case proves nothing
+        greedy, _ = model_generate(model, tok, dict(inputs=songs[0][:1], decoder_input_ids=prompt_from(None)),
+                                   dict(kwargs_for(0, n_windows[0]), num_beams=1))
+        assert greedy[0].tolist() != want[0][0].tolist()
 
 
 def test_conditioning_embedders_fp32_match_reference_golden():

@@ -477,3 +477,88 @@ def test_slider_set_packing_filters_windows_and_refuses_what_the_kernel_cannot_d
         pack_slider_set([[S(np.arange(40, 40 + MAX_BEZIER_SPAN + 1), 90, "Bezier", 5.0)]], 0, 100)
     long_but_split = S(np.concatenate([np.arange(40, 60), [59], np.arange(60, 80)]), 90, "Bezier", 5.0)   # 41 points, spans of 20 + 21
     assert pack_slider_set([[long_but_split]], 0, 100)[2] == [3]
+
+
+def test_request_batcher_closes_the_requests_of_a_failed_batch():
+    """a generate call that raises (a refused kwarg combination, OOM) must not strand its requests -- the reference
+    answers every request of the batch with RETRY_SIGNAL (osuT5/osuT5/inference/server.py:418-424).  Here: the failed batch's
+    requests are closed with the error (rows still queued are dropped with them), requests that were not in the batch are
+    answered normally afterwards, and the error reaches the driver."""
+    import types
+
+    import pytest
+    import torch
+
+    from mapperatorinator_amd import server as our_server
+    calls = []
+
+    def flaky_generate(model, tokenizer, model_kwargs, generate_kwargs):
+        n = model_kwargs["decoder_input_ids"].shape[0]
+        calls.append(n)
+        if len(calls) == 1:
+            raise NotImplementedError("refused combination")
+        return torch.full((n, 6), 7, dtype=torch.int64), dict(generated_tokens_per_sample=[4] * n, elapsed_seconds=0.25)
+
+    b = our_server.RequestBatcher(None, types.SimpleNamespace(pad_id=0), max_batch_size=4, generate_fn=flaky_generate)
+    ids = torch.ones(6, 2, dtype=torch.long)
+    big = b.submit(dict(inputs=torch.zeros(6, 10), decoder_input_ids=ids), dict(num_beams=1))      # 4 rows in batch 1, 2 staged
+    small = b.submit(dict(inputs=torch.zeros(1, 10), decoder_input_ids=ids[:1]), dict(num_beams=1))
+    with pytest.raises(NotImplementedError):
+        b.step()
+    assert big["done"] and isinstance(big["error"], NotImplementedError) and big["result"] is None
+    assert not small["done"] and small["error"] is None
+    b.drain()
+    assert small["done"] and small["error"] is None and small["result"]["output"].shape == (1, 6)
+    assert big["result"] is None and not b.pending
+
+
+def test_fresh_seed_call_index_is_independent_of_process_history():
+    """an explicit (seed, call_index) names a stream by itself; the process-wide count only serves callers that do
+    not keep their own, is bounded and locked."""
+    from mapperatorinator_amd import server as s
+    s.reset_seed_calls()
+    a0, a1 = s.fresh_seed(11), s.fresh_seed(11)
+    assert a0 != a1
+    assert s.fresh_seed(11, call_index=0) == a0 and s.fresh_seed(11, call_index=1) == a1      # no global state touched
+    assert s.fresh_seed(11) not in (a0, a1)
+    for k in range(s._SEED_CALLS_MAX + 50):
+        s.fresh_seed(1000 + k)
+    assert len(s._SEED_CALLS) <= s._SEED_CALLS_MAX
+    s.reset_seed_calls()
+    assert s.fresh_seed(11) == a0
+
+
+def test_varwhisper_packer_refuses_conditioning_channels_in_conv1():
+    """a conv1 with n_mels + conditioning input channels must be refused, not cropped to n_mels."""
+    import pytest
+    import torch
+
+    from mapperatorinator_amd.testing import random_varwhisper_state_dict
+    from mapperatorinator_amd.whisper_engine import VARWHISPER_PRESETS, PackedVarWhisper
+    d = VARWHISPER_PRESETS["test"]
+    sd = random_varwhisper_state_dict(d.d_model, d.n_heads, d.n_enc_layers, d.n_dec_layers, d.d_ff, 200, 180, seed=0)
+    k = "transformer.model.encoder.conv1.weight"
+    n_mels = sd[k].shape[1]
+    sd[k] = torch.cat([sd[k], torch.zeros(sd[k].shape[0], 16, 3)], 1)          # + 16 conditioning channels
+    with pytest.raises(NotImplementedError, match="conv1"):
+        PackedVarWhisper(sd, d, 200, 180, n_mels, 64, 32, torch.float32, "cpu")
+
+
+def test_kernels_with_asm_issued_loads_have_no_scratch_and_no_spills():
+    """gemm_glds3 / gemm_s3g (and every later kernel on the same discipline) read LDS through inline-asm
+    `ds_read`s behind hand-counted `s_waitcnt`s; hipcc treats an asm output as valid at once, so a spill of such a register
+    stores stale bytes.  The built code objects must report zero scratch and zero spilled registers for them."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("ckr", os.path.join(root, "tools", "check_kernel_resources.py"))
+    ckr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ckr)
+    lib = os.path.join(root, "mapperatorinator_amd", "lib", "libmapperhip.so")
+    rows = [k for elf in ckr.code_objects(lib) for k in ckr.kernels_of(elf)]
+    watched = [k for k in rows if any(w in k[".symbol"] for w in ckr.ASM_LOAD_KERNELS)]
+    assert len(rows) > 100 and len(watched) >= 20
+    for k in watched:
+        assert int(k.get(".private_segment_fixed_size", 0)) == 0, k[".symbol"]
+        assert int(k.get(".vgpr_spill_count", 0)) == 0 and int(k.get(".sgpr_spill_count", 0)) == 0, k[".symbol"]
+    assert ckr.main([lib]) == 0
