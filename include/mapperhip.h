@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MH_ABI_VERSION 6
+#define MH_ABI_VERSION 7
 #define MH_MAX_LAYERS 32
 
 typedef enum MhStatus {
@@ -33,7 +33,10 @@ typedef enum MhStatus {
   MH_ERR_STATE = -3,   /* object used in the wrong state */
 } MhStatus;
 
-typedef enum MhDtype { MH_F32 = 0, MH_BF16 = 1 } MhDtype;
+/* MH_MX8 (ABI 7): OCP MX-fp8 -- e4m3 elements (one byte each) + one E8M0 scale byte per (row, 32 consecutive k); an OPERAND
+ * type of mh_gemm and of the reduced-precision modes built on it (MhT5Config.enc_operand_dtype, MhDiTConfig.operand_dtype),
+ * never a storage type of activations that leave a stage.  Layouts: see mh_quantize_mx8. */
+typedef enum MhDtype { MH_F32 = 0, MH_BF16 = 1, MH_MX8 = 2 } MhDtype;
 
 /* epilogues of mh_gemm */
 typedef enum MhEpilogue {
@@ -81,8 +84,10 @@ int mh_abi_version(void);
  *   "dit_s3_presplit"    MH_DIT_S3_PRESPLIT    1    batched fp32-semantics DiT: activations written pre-split by their
  *                                                   producers + three-stage bf16 x 3 GEMM; 0 = the 64x64 kernel that splits A
  *                                                   while staging it (bit-identical GEMM results; the fc1 GELU differs)
+ *   "mx8_opsel"          MH_MX8_OPSEL          1    MX-fp8 GEMM: the K step's scale byte is picked by the MFMA's OP_SEL (1) or
+ *                                                   shifted into byte 0 by a VALU op (0); same arithmetic
  * (further switches -- decode_cu_split, gemm_tile128_min, gemm_tile256_min, attn_small_max_wgs, dit_split3_min_rows,
- * dit_s3_fused_ln -- are documented next to their definitions in csrc/api.hip.)
+ * dit_s3_fused_ln, mx8_tile256_min -- are documented next to their definitions in csrc/api.hip.)
  * Unknown names return MH_ERR_ARG (set) / -1 (get). */
 int mh_set_option(const char* name, long value);
 long mh_get_option(const char* name);
@@ -149,8 +154,28 @@ typedef struct MhGemm {
    * GATE_RESID, BIAS_GELU; N, ldc multiples of 4); | 4 = with 2 and MH_EPI_BIAS_GELU: C is written pre-split as well
    * (it is the next GEMM's A operand; ldc multiple of 32). */
   int w_split3;
+  /* ABI 7 -- dtype = MH_MX8 (BASELINE configs[4] "fp8 MFMA"): A [M][lda] and W [N][ldw] hold e4m3 BYTES (lda, ldw counted in
+   * elements = bytes, multiples of 16; K a multiple of 128), a_scale / w_scale their E8M0 scales in the row layout of
+   * mh_quantize_mx8 (mh_mx8_scale_row_bytes(K) bytes per row).  The product runs on v_mfma_scale_f32_16x16x128_f8f6f4 with
+   * fp32 accumulation; outputs are what the epilogue says with T = bf16 (STORE, STORE_F32, RESID, GEGLU, BIAS_GELU,
+   * GATE_RESID, KV_SCATTER, QKV_VT; N, ldc multiples of 4). */
+  const uint8_t* a_scale; const uint8_t* w_scale;
 } MhGemm;
 int mh_gemm(const MhGemm* g, void* stream);
+
+/* MX-fp8 quantisation of a row-major matrix (the A / W operands of mh_gemm with dtype = MH_MX8).
+ * x [rows][ldx] of in_dtype (MH_F32 / MH_BF16), K % 128 == 0 columns used.  Per (row, block of 32 consecutive k):
+ *   amax = max |x|; e = floor(log2(amax)) - 8, raised by one when amax * 2^-e > 448 (the largest finite e4m3 value: nothing is
+ *   ever clipped); scale byte = clamp(e + 127, 0, 254) (all-zero block: 0 with zero elements); element = RNE_e4m3(x * 2^-e).
+ * q [rows][ldq] bytes (ldq >= K, multiple of 16).  scales [rows][mh_mx8_scale_row_bytes(K)] bytes, LANE-MAJOR in groups of
+ * four 128-k steps: byte (kt / 4) * 16 + lg * 4 + (kt % 4) holds the scale of k block kt * 4 + lg (kt = k / 128, lg =
+ * (k % 128) / 32) -- the dword a lane of the MFMA fetches for four K steps; unused bytes of the last group are 0. */
+int64_t mh_mx8_scale_row_bytes(int K);
+int mh_quantize_mx8(const void* x, int ldx, int rows, int K, int in_dtype, uint8_t* q, int ldq, uint8_t* scales, void* stream);
+/* RMSNorm (mh_rmsnorm) with the MX-fp8 operand written directly: y = w * x * rsqrt(mean(x^2) + eps) in fp32, rounded to
+ * `round_dtype` (MH_BF16: the value a bf16 activation buffer would have held; MH_F32: not rounded), then quantised as above. */
+int mh_rmsnorm_mx8(const float* x, int ldx, const float* w, int rows, int d, float eps, int round_dtype, uint8_t* q, int ldq,
+                   uint8_t* scales, void* stream);
 
 /* T5 RMSNorm (HF T5LayerNorm; restated at custom_transformers/t5.py:50-62):
  * y[T] = w * x * rsqrt(mean(x^2) + eps), x fp32 [rows, d] (ldx), y [rows, ldy]. */

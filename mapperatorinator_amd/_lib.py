@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 MH_MAX_LAYERS = 32
-MH_F32, MH_BF16 = 0, 1
+MH_F32, MH_BF16, MH_MX8 = 0, 1, 2
 (EPI_STORE, EPI_STORE_F32, EPI_RESID, EPI_GEGLU, EPI_BIAS_GELU, EPI_GATE_RESID, EPI_KV_SCATTER,
  EPI_QKV_VT, EPI_QKV_CACHE, EPI_BIAS_GELU_ERF) = range(10)
 
@@ -30,7 +30,8 @@ class MhGemm(C.Structure):
                 ("C3", VP), ("C4", VP), ("cache_len", C.c_int),
                 ("dtype", C.c_int), ("epilogue", C.c_int),
                 ("stats_out", VP), ("ln_stats", VP), ("ln_strips", C.c_int), ("ln_shift", VP), ("ln_scale", VP),
-                ("ln_ld", C.c_int), ("ln_eps", C.c_float), ("w_split3", C.c_int)]
+                ("ln_ld", C.c_int), ("ln_eps", C.c_float), ("w_split3", C.c_int),
+                ("a_scale", VP), ("w_scale", VP)]      # ABI 7: MH_MX8 operands
 
 
 class MhT5Config(C.Structure):
@@ -94,7 +95,7 @@ class MhSliderSet(C.Structure):
                 ("end_idx", VP), ("length", VP)]
 
 
-ABI_VERSION = 6   # MH_ABI_VERSION of include/mapperhip.h
+ABI_VERSION = 7   # MH_ABI_VERSION of include/mapperhip.h
 
 # every symbol include/mapperhip.h declares: (name, restype, argtypes)
 I, I64, F = C.c_int, C.c_int64, C.c_float
@@ -107,6 +108,9 @@ SYMBOLS = {
     "mh_mel": (I, [VP, I, I, I, I, I, VP, VP, VP, VP, VP, VP, I, VP, I, I, VP]),
     "mh_gemm": (I, [C.POINTER(MhGemm), VP]),
     "mh_rmsnorm": (I, [VP, I, VP, VP, I, I, I, F, I, VP]),
+    "mh_mx8_scale_row_bytes": (I64, [I]),
+    "mh_quantize_mx8": (I, [VP, I, I, I, I, VP, I, VP, VP]),
+    "mh_rmsnorm_mx8": (I, [VP, I, VP, I, I, F, I, VP, I, VP, VP]),
     "mh_attention": (I, [VP, I, I, VP, I, VP, VP, I, I, I, I, F, I, I, VP]),
     "mh_whisper_frontend_workspace_bytes": (I64, [I, I, I, I, I]),
     "mh_whisper_frontend": (I, [VP, I, I, I, VP, VP, VP, VP, VP, I, VP, VP, I64, I, VP]),

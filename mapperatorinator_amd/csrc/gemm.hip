@@ -35,6 +35,7 @@ struct GemmP {
   bool ascending_k;
   int split3;   // fp32 only: W holds [hi bf16 x32 | lo bf16 x32] per 32-float K block, A is split on the way into LDS
   int debug;    // option gemm_lds_pad >> 20 (debugging aid)
+  const uint8_t* a_scale; const uint8_t* w_scale; int ks_b;   // MH_MX8: E8M0 scales (lane-major groups, mx8.hip), bytes per row
 };
 
 // `v` already contains the bias; `old` = previous C value (RESID / GATE_RESID), `g` = gate value, `v2` = paired
@@ -537,6 +538,137 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmP p) {
   }
 }
 
+// ---- epilogue of the three-stage kernels (transposed accumulators: a lane owns 4 CONSECUTIVE columns of one row) ---------
+// acc[j][i][r] = C[row m0 + wr*16*MI + i*16 + (lane & 15)][col n0 + wc*64 + j*16 + (lane >> 4)*4 + r].  Shared by the bf16 form
+// (gemm_glds3_kernel) and the MX-fp8 form (gemm_mx8_kernel): the C / D layout of the 16x16 MFMAs does not depend on the operand type.
+template <int EPI, int MI>
+__device__ __forceinline__ void g3_epilogue(const GemmP& p, f32x4_t (&acc)[4][MI], int m0, int n0, int wr, int wc, int lane) {
+  using T = bf16_t;
+  constexpr int WM = 16 * MI, WN = 64, NI = 4;
+  const int lgc = lane >> 4;
+  // ---- epilogue: 4 consecutive columns per lane; every load it needs is in flight before the first store of its row
+  // block (a load consumed behind a store makes hipcc wait for that store: one write round trip per element) ----------
+  constexpr bool kReadsC = (EPI == MH_EPI_RESID || EPI == MH_EPI_GATE_RESID);
+  constexpr bool kPos = (EPI == MH_EPI_BIAS_GELU_ERF);
+  const int l15 = lane & 15;
+  const int ecol_base = n0 + wc * WN + lgc * 4;     // + j * 16
+  const int erow_base = m0 + wr * WM + l15;         // + i * 16
+  auto f4 = [](const float* q) { return *reinterpret_cast<const float4*>(q); };
+  auto st_bf16x4 = [](void* base, long idx, const float (&v)[4]) {
+    *reinterpret_cast<uint2*>(reinterpret_cast<T*>(base) + idx) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+  };
+  auto st_f32x4 = [](void* base, long idx, const float (&v)[4]) {
+    *reinterpret_cast<float4*>(reinterpret_cast<float*>(base) + idx) = make_float4(v[0], v[1], v[2], v[3]);
+  };
+  float4 bias4[NI];
+#pragma unroll
+  for (int jj = 0; jj < NI; ++jj) {
+    int c = ecol_base + jj * 16;
+    c = c < p.N ? c : p.N - 4;
+    bias4[jj] = (EPI != MH_EPI_GEGLU && p.bias) ? f4(p.bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+#pragma unroll
+  for (int jj = 0; jj < NI; ++jj)
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      acc[jj][i][0] += bias4[jj].x; acc[jj][i][1] += bias4[jj].y; acc[jj][i][2] += bias4[jj].z; acc[jj][i][3] += bias4[jj].w;
+      asm volatile("" : "+v"(acc[jj][i]));   // materialised HERE: hipcc otherwise sinks the add (and the wait for the bias
+    }                                        // load) behind the stores, and every store then waits for the one before it
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int row = erow_base + i * 16;
+    const bool rok = row < p.M;
+    const int rowc = rok ? row : p.M - 1;
+    float4 old4[NI], g4[NI];
+    if constexpr (kReadsC || kPos) {
+#pragma unroll
+      for (int jj = 0; jj < NI; ++jj) {
+        int c = ecol_base + jj * 16;
+        c = c < p.N ? c : p.N - 4;
+        old4[jj] = kReadsC ? f4(reinterpret_cast<const float*>(p.C) + (long)rowc * p.ldc + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (EPI == MH_EPI_GATE_RESID) g4[jj] = f4(p.gate + (long)(rowc / p.rows_per_batch) * p.gate_ld + c);
+        else if (kPos && p.gate) g4[jj] = f4(p.gate + (long)(rowc % p.rows_per_batch) * p.gate_ld + c);
+        else g4[jj] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    // all values of this row block first (pinned: nothing that depends on a load may sink behind a store), then the stores
+    f32x4_t vv[NI];
+#pragma unroll
+    for (int jj = 0; jj < NI; ++jj) {
+      f32x4_t v = acc[jj][i];
+      if constexpr (EPI == MH_EPI_GEGLU) {
+        if (!(jj & 1)) {                             // 16-row weight blocks alternate wi_0 / wi_1: jj the gate, jj + 1 the linear half
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = gelu_tanh(v[r]) * acc[jj + 1][i][r];
+        }
+      } else if constexpr (EPI == MH_EPI_RESID) {
+        v[0] += old4[jj].x; v[1] += old4[jj].y; v[2] += old4[jj].z; v[3] += old4[jj].w;
+      } else if constexpr (EPI == MH_EPI_GATE_RESID) {
+        v[0] = old4[jj].x + g4[jj].x * v[0]; v[1] = old4[jj].y + g4[jj].y * v[1];
+        v[2] = old4[jj].z + g4[jj].z * v[2]; v[3] = old4[jj].w + g4[jj].w * v[3];
+      } else if constexpr (EPI == MH_EPI_BIAS_GELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_tanh_fast(v[r]);
+      } else if constexpr (EPI == MH_EPI_BIAS_GELU_ERF) {
+        const float gq[4] = {g4[jj].x, g4[jj].y, g4[jj].z, g4[jj].w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = 0.5f * v[r] * (1.0f + erff(v[r] * 0.70710678118654752f)) + gq[r];
+      }
+      asm volatile("" : "+v"(v));
+      vv[jj] = v;
+    }
+#pragma unroll
+    for (int jj = 0; jj < NI; ++jj) {
+      const int c = ecol_base + jj * 16;
+      const float v[4] = {vv[jj][0], vv[jj][1], vv[jj][2], vv[jj][3]};
+      if constexpr (EPI == MH_EPI_GEGLU) {
+        if (jj & 1) continue;
+        const int oc = (n0 + wc * WN) / 2 + (jj / 2) * 16 + lgc * 4;
+        if (rok && oc < p.N / 2) st_bf16x4(p.C, (long)row * p.ldc + oc, v);
+        continue;
+      }
+      if (!rok || c >= p.N) continue;
+      if constexpr (EPI == MH_EPI_STORE || EPI == MH_EPI_BIAS_GELU || EPI == MH_EPI_BIAS_GELU_ERF) {
+        st_bf16x4(p.C, (long)row * p.ldc + c, v);
+      } else if constexpr (EPI == MH_EPI_STORE_F32 || EPI == MH_EPI_RESID || EPI == MH_EPI_GATE_RESID) {
+        st_f32x4(p.C, (long)row * p.ldc + c, v);
+      } else if constexpr (EPI == MH_EPI_KV_SCATTER) {
+        const int dd = c & 63, h = (c >> 6) % p.kv_H, lk = (c >> 6) / p.kv_H;
+        const int b = row / p.kv_L, key = row - b * p.kv_L;
+        st_bf16x4(p.C, ((((long)lk * p.kv_B + b) * p.kv_H + h) * p.kv_L + key) * 64 + dd, v);
+      } else if constexpr (EPI == MH_EPI_QKV_VT) {
+        if (c < p.n_split) {
+          st_bf16x4(p.C, (long)row * p.ldc + c, v);
+        } else {
+          const int c2 = c - p.n_split;
+          const int b = row / p.kv_L, key = row - b * p.kv_L;
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            reinterpret_cast<T*>(p.C2)[((long)b * p.kv_H * 64 + c2 + r) * p.kv_Lpad + key] = Elem<T>::from_f32(v[r]);
+        }
+      } else if constexpr (EPI == MH_EPI_QKV_CACHE) {
+        if (c < p.n_split) {
+          st_bf16x4(p.C, (long)row * p.ldc + c, v);
+        } else {
+          const int inner = p.kv_H * 64;
+          const int c2 = c - p.n_split;
+          const int kv = c2 / inner, cc = c2 - kv * inner;
+          const int b = row / p.kv_L, ip = row - b * p.kv_L;
+          const long dst = (((long)b * p.kv_H + (cc >> 6)) * p.cache_len + ip) * 64 + (cc & 63);
+          if (kv == 0) {
+            st_bf16x4(p.C2, dst, v);
+          } else {
+            st_bf16x4(p.C3, dst, v);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              reinterpret_cast<T*>(p.C4)[((long)b * p.kv_H * 64 + cc + r) * p.kv_Lpad + ip] = Elem<T>::from_f32(v[r]);
+          }
+        }
+      }
+    }
+  }
+}
+
 // ---- G3: bf16, 256 x 128 tile, 8 waves as 4(M) x 2(N), THREE LDS stages filled by LDS-DMA two K steps ahead --------------
 // The two-stage kernel above waits for the whole next stage at the end of every K step (vmcnt(0) + barrier): with the
 // 0.2 us of MFMA work a step holds, a step costs one loaded memory round trip (~2.2 us measured on the encoder GEMMs, two
@@ -717,127 +849,7 @@ __global__ __launch_bounds__(512) void gemm_glds3_kernel(GemmP p) {
   mma(a1, b1);
 #undef G3_WAIT
 
-  // ---- epilogue: 4 consecutive columns per lane; every load it needs is in flight before the first store of its row
-  // block (a load consumed behind a store makes hipcc wait for that store: one write round trip per element) ----------
-  constexpr bool kReadsC = (EPI == MH_EPI_RESID || EPI == MH_EPI_GATE_RESID);
-  constexpr bool kPos = (EPI == MH_EPI_BIAS_GELU_ERF);
-  const int l15 = lane & 15;
-  const int ecol_base = n0 + wc * WN + lgc * 4;     // + j * 16
-  const int erow_base = m0 + wr * WM + l15;         // + i * 16
-  auto f4 = [](const float* q) { return *reinterpret_cast<const float4*>(q); };
-  auto st_bf16x4 = [](void* base, long idx, const float (&v)[4]) {
-    *reinterpret_cast<uint2*>(reinterpret_cast<T*>(base) + idx) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-  };
-  auto st_f32x4 = [](void* base, long idx, const float (&v)[4]) {
-    *reinterpret_cast<float4*>(reinterpret_cast<float*>(base) + idx) = make_float4(v[0], v[1], v[2], v[3]);
-  };
-  float4 bias4[NI];
-#pragma unroll
-  for (int jj = 0; jj < NI; ++jj) {
-    int c = ecol_base + jj * 16;
-    c = c < p.N ? c : p.N - 4;
-    bias4[jj] = (EPI != MH_EPI_GEGLU && p.bias) ? f4(p.bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-#pragma unroll
-  for (int jj = 0; jj < NI; ++jj)
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      acc[jj][i][0] += bias4[jj].x; acc[jj][i][1] += bias4[jj].y; acc[jj][i][2] += bias4[jj].z; acc[jj][i][3] += bias4[jj].w;
-      asm volatile("" : "+v"(acc[jj][i]));   // materialised HERE: hipcc otherwise sinks the add (and the wait for the bias
-    }                                        // load) behind the stores, and every store then waits for the one before it
-#pragma unroll
-  for (int i = 0; i < MI; ++i) {
-    const int row = erow_base + i * 16;
-    const bool rok = row < p.M;
-    const int rowc = rok ? row : p.M - 1;
-    float4 old4[NI], g4[NI];
-    if constexpr (kReadsC || kPos) {
-#pragma unroll
-      for (int jj = 0; jj < NI; ++jj) {
-        int c = ecol_base + jj * 16;
-        c = c < p.N ? c : p.N - 4;
-        old4[jj] = kReadsC ? f4(reinterpret_cast<const float*>(p.C) + (long)rowc * p.ldc + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-        if (EPI == MH_EPI_GATE_RESID) g4[jj] = f4(p.gate + (long)(rowc / p.rows_per_batch) * p.gate_ld + c);
-        else if (kPos && p.gate) g4[jj] = f4(p.gate + (long)(rowc % p.rows_per_batch) * p.gate_ld + c);
-        else g4[jj] = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-    }
-    // all values of this row block first (pinned: nothing that depends on a load may sink behind a store), then the stores
-    f32x4_t vv[NI];
-#pragma unroll
-    for (int jj = 0; jj < NI; ++jj) {
-      f32x4_t v = acc[jj][i];
-      if constexpr (EPI == MH_EPI_GEGLU) {
-        if (!(jj & 1)) {                             // 16-row weight blocks alternate wi_0 / wi_1: jj the gate, jj + 1 the linear half
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = gelu_tanh(v[r]) * acc[jj + 1][i][r];
-        }
-      } else if constexpr (EPI == MH_EPI_RESID) {
-        v[0] += old4[jj].x; v[1] += old4[jj].y; v[2] += old4[jj].z; v[3] += old4[jj].w;
-      } else if constexpr (EPI == MH_EPI_GATE_RESID) {
-        v[0] = old4[jj].x + g4[jj].x * v[0]; v[1] = old4[jj].y + g4[jj].y * v[1];
-        v[2] = old4[jj].z + g4[jj].z * v[2]; v[3] = old4[jj].w + g4[jj].w * v[3];
-      } else if constexpr (EPI == MH_EPI_BIAS_GELU) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = gelu_tanh_fast(v[r]);
-      } else if constexpr (EPI == MH_EPI_BIAS_GELU_ERF) {
-        const float gq[4] = {g4[jj].x, g4[jj].y, g4[jj].z, g4[jj].w};
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = 0.5f * v[r] * (1.0f + erff(v[r] * 0.70710678118654752f)) + gq[r];
-      }
-      asm volatile("" : "+v"(v));
-      vv[jj] = v;
-    }
-#pragma unroll
-    for (int jj = 0; jj < NI; ++jj) {
-      const int c = ecol_base + jj * 16;
-      const float v[4] = {vv[jj][0], vv[jj][1], vv[jj][2], vv[jj][3]};
-      if constexpr (EPI == MH_EPI_GEGLU) {
-        if (jj & 1) continue;
-        const int oc = (n0 + wc * WN) / 2 + (jj / 2) * 16 + lgc * 4;
-        if (rok && oc < p.N / 2) st_bf16x4(p.C, (long)row * p.ldc + oc, v);
-        continue;
-      }
-      if (!rok || c >= p.N) continue;
-      if constexpr (EPI == MH_EPI_STORE || EPI == MH_EPI_BIAS_GELU || EPI == MH_EPI_BIAS_GELU_ERF) {
-        st_bf16x4(p.C, (long)row * p.ldc + c, v);
-      } else if constexpr (EPI == MH_EPI_STORE_F32 || EPI == MH_EPI_RESID || EPI == MH_EPI_GATE_RESID) {
-        st_f32x4(p.C, (long)row * p.ldc + c, v);
-      } else if constexpr (EPI == MH_EPI_KV_SCATTER) {
-        const int dd = c & 63, h = (c >> 6) % p.kv_H, lk = (c >> 6) / p.kv_H;
-        const int b = row / p.kv_L, key = row - b * p.kv_L;
-        st_bf16x4(p.C, ((((long)lk * p.kv_B + b) * p.kv_H + h) * p.kv_L + key) * 64 + dd, v);
-      } else if constexpr (EPI == MH_EPI_QKV_VT) {
-        if (c < p.n_split) {
-          st_bf16x4(p.C, (long)row * p.ldc + c, v);
-        } else {
-          const int c2 = c - p.n_split;
-          const int b = row / p.kv_L, key = row - b * p.kv_L;
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            reinterpret_cast<T*>(p.C2)[((long)b * p.kv_H * 64 + c2 + r) * p.kv_Lpad + key] = Elem<T>::from_f32(v[r]);
-        }
-      } else if constexpr (EPI == MH_EPI_QKV_CACHE) {
-        if (c < p.n_split) {
-          st_bf16x4(p.C, (long)row * p.ldc + c, v);
-        } else {
-          const int inner = p.kv_H * 64;
-          const int c2 = c - p.n_split;
-          const int kv = c2 / inner, cc = c2 - kv * inner;
-          const int b = row / p.kv_L, ip = row - b * p.kv_L;
-          const long dst = (((long)b * p.kv_H + (cc >> 6)) * p.cache_len + ip) * 64 + (cc & 63);
-          if (kv == 0) {
-            st_bf16x4(p.C2, dst, v);
-          } else {
-            st_bf16x4(p.C3, dst, v);
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              reinterpret_cast<T*>(p.C4)[((long)b * p.kv_H * 64 + cc + r) * p.kv_Lpad + ip] = Elem<T>::from_f32(v[r]);
-          }
-        }
-      }
-    }
-  }
+  g3_epilogue<EPI, MI>(p, acc, m0, n0, wr, wc, lane);
 }
 
 // ---- S3G: the bf16 x 3 fp32 GEMM on the three-stage LDS-DMA structure, BOTH operands pre-split -----------------------
@@ -1098,6 +1110,298 @@ __global__ __launch_bounds__(512) void gemm_s3g_kernel(GemmP p) {
   }   // tile loop
 }
 
+// ---- MX8: OCP e4m3 operands + one E8M0 scale per (row, 32 consecutive k) on v_mfma_scale_f32_16x16x128_f8f6f4 -------------
+// BASELINE configs[4] ("fp8 MFMA").  The three-stage LDS-DMA structure of gemm_glds3_kernel with the K step re-read: a
+// 128-byte row of a stage is 128 e4m3 values = ONE MFMA k (the bf16 form needs two 16x16x32 MFMAs per 64 values), so a K
+// step moves the same bytes through HBM / L2 / LDS as the bf16 kernel and multiplies twice the k range in the same matrix-core
+// time (16 MFMAs x 32 cycles per wave and step) -- the MX rate is 2x the bf16 rate at equal operand bytes per step.
+//   operand layout (measured, tools/micro/mfma_mx_probe*.hip): lane (row = l & 15, lg = l >> 4) holds bytes [lg*16, +16) and
+//   [64 + lg*16, +16) of its row's 128-byte k step; the scale register's byte OP_SEL of that lane scales k block lg (32
+//   consecutive k) of the row -- for both operands.  Swizzled stage rows as in the bf16 kernels: 16-byte chunk c of tile
+//   row r sits at chunk c ^ (r & 7), so a fragment is two conflict-free ds_read_b128.
+//   scales: [rows][16 * ceil(K / 512)] bytes, byte (kt / 4) * 16 + lg * 4 + (kt % 4) = E8M0 of k block kt * 4 + lg (kt = K step):
+//   a lane fetches ONE dword per row block and four K steps and selects the step's byte with OP_SEL (0..3) -- 8 dword loads
+//   per wave and four steps, issued a group ahead by inline asm and covered by the counted vmcnt waits of the DMA pipeline.
+//   two phases per K step: A = DMA of step kt + 2, reads of (stage kt: W blocks 2, 3), MFMAs of W blocks 0, 1 | wait, barrier;
+//   B = reads of (stage kt + 1: A blocks 0..MI-1 into the other register set, W blocks 0, 1), MFMAs of W blocks 2, 3.
+// Transposed product and epilogue as gemm_glds3_kernel (bf16 outputs / fp32 residual stream).  OPSEL = false: the scale byte
+// is shifted into place (v_lshrrev) and OP_SEL stays 0 -- the A/B form of the same arithmetic.
+typedef __attribute__((ext_vector_type(8))) int i32x8_t;
+typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+
+template <int EPI, int MI, bool OPSEL>
+__global__ __launch_bounds__(512) void gemm_mx8_kernel(GemmP p) {
+  constexpr int BM = 64 * MI, BN = 128, NST = 3;
+  constexpr int kRowStride = 128, kStage = (BM + BN) * kRowStride;
+  constexpr int WM = 16 * MI, WN = 64, NI = 4;
+  constexpr int NA = MI;                     // A-tile DMA instructions per wave and stage
+  constexpr int NDMA = NA + 2, NSC = MI + NI;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wr = wid >> 1, wc = wid & 1;
+
+  const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
+  const int nwg = nbm * nbn;
+  int bid = blockIdx.x;
+  {   // block b runs on XCD b % 8: give every XCD a contiguous range of the work list (bijective)
+    const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  int bm, bn;
+  {   // groups of GM row panels (<= ~2.5 MB of A), inside a group the row panel runs fastest
+    const long panel_bytes = (long)BM * p.K;
+    int GM = (int)((5L << 19) / (panel_bytes > 0 ? panel_bytes : 1));
+    GM = GM < 2 ? 2 : (GM > 16 ? 16 : GM);
+    const int per_group = GM * nbn;
+    const int grp = bid / per_group, rem = bid - grp * per_group;
+    const int gm = (nbm - grp * GM) < GM ? (nbm - grp * GM) : GM;
+    bn = rem / gm;
+    bm = grp * GM + (rem - bn * gm);
+  }
+  const int m0 = bm * BM, n0 = bn * BN;
+  const int nk = p.K / 128;                  // K % 128 == 0 (dispatch condition)
+
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  const char* srcp[NDMA];
+  {
+    const int r8 = lane >> 3;
+    const long k_off = (long)(((lane & 7) ^ r8) * 16);                // pre-swizzled source chunk (tile row & 7 == r8)
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      int ra_ = m0 + (i * 8 + wid) * 8 + r8; ra_ = ra_ < p.M ? ra_ : p.M - 1;
+      srcp[i] = p.A + (long)ra_ * p.lda_b + k_off;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int rb_ = n0 + (i * 8 + wid) * 8 + r8; rb_ = rb_ < p.N ? rb_ : p.N - 1;
+      srcp[NA + i] = p.W + (long)rb_ * p.ldw_b + k_off;
+    }
+  }
+  auto issue = [&](int st) {          // the NEXT K tile (the pointers advance)
+    char* base = smem + st * kStage;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      __builtin_amdgcn_global_load_lds((gptr_t)srcp[i], (lptr_t)(base + (i * 8 + wid) * 1024), 16, 0, 0);
+      srcp[i] += 128;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      __builtin_amdgcn_global_load_lds((gptr_t)srcp[NA + i], (lptr_t)(base + BM * kRowStride + (i * 8 + wid) * 1024), 16, 0, 0);
+      srcp[NA + i] += 128;
+    }
+  };
+
+  const int frow = lane & 15, sw = frow & 7, lgc = lane >> 4;
+  // scale dwords of this lane: W row blocks j (scale of the MFMA's first operand), A row blocks i (second operand); 32-bit
+  // offsets from the two (scalar) base pointers, advancing one 16-byte group per four K steps
+  uint32_t sco[NSC];
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    int r = n0 + wc * WN + j * 16 + frow; r = r < p.N ? r : p.N - 1;
+    sco[j] = (uint32_t)(r * p.ks_b + lgc * 4);
+  }
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    int r = m0 + wr * WM + i * 16 + frow; r = r < p.M ? r : p.M - 1;
+    sco[NI + i] = (uint32_t)(r * p.ks_b + lgc * 4);
+  }
+  const uint8_t* const wsb = p.w_scale;
+  const uint8_t* const asb = p.a_scale;
+  int scur[NSC], snxt[NSC];
+  auto load_scales = [&](int (&dst)[NSC]) {   // the NEXT group of four K steps (the offsets advance); asm: counted by hand
+#pragma unroll
+    for (int q = 0; q < NSC; ++q) {
+      if (q < NI) asm volatile("global_load_dword %0, %1, %2" : "=v"(dst[q]) : "v"(sco[q]), "s"(wsb) : "memory");
+      else asm volatile("global_load_dword %0, %1, %2" : "=v"(dst[q]) : "v"(sco[q]), "s"(asb) : "memory");
+      sco[q] += 16;
+    }
+  };
+
+  f32x4_t acc[NI][MI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j)
+#pragma unroll
+    for (int i = 0; i < MI; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  // Waits are inline asm that NAME the registers they make valid as in/out operands: the asm-issued loads look complete to
+  // hipcc the moment they are issued, so without that dependence an MFMA (a pure register operation) may be placed above the
+  // wait that its operands need -- sched_barrier pins the scheduler only, not the IR passes that run before it.
+  i32x4_t alo[2][MI], ahi[2][MI], blo[NI], bhi[NI];
+#define MX_DEP4(x) "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3])
+#define MX_DEP2(x) "+v"(x[0]), "+v"(x[1])
+  auto wait_scales = [&](int (&v)[NSC]) {      // (no instruction: the vmcnt wait that covers them stands next to it)
+    if constexpr (MI == 4) asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+    else asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]));
+  };
+#define MX_WAIT(str) do { asm volatile(str ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+  load_scales(scur);
+  issue(0);
+  if (nk > 1) {
+    issue(1);
+    if constexpr (MI == 4) MX_WAIT("s_waitcnt vmcnt(6)");    // scales and stage 0 of this wave have landed, stage 1 may still fly
+    else MX_WAIT("s_waitcnt vmcnt(4)");
+  } else {
+    MX_WAIT("s_waitcnt vmcnt(0)");
+  }
+  wait_scales(scur);
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
+  const uint32_t a_off = (uint32_t)((wr * WM + frow) * kRowStride), b_off = (uint32_t)((BM + wc * WN + frow) * kRowStride);
+  const uint32_t c_lo = (uint32_t)((lgc ^ sw) * 16), c_hi = (uint32_t)(((4 + lgc) ^ sw) * 16);
+  // row block q of a 16-row-block column sits q * 2048 bytes further (16 rows x 128 bytes)
+#define MX_RD(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=v"(dst) : "v"(addr))
+  auto ld_a = [&](int st, i32x4_t (&lo)[MI], i32x4_t (&hi)[MI]) {
+    const uint32_t pl = lds0 + st * kStage + a_off + c_lo, ph = lds0 + st * kStage + a_off + c_hi;
+    MX_RD(lo[0], pl, 0); MX_RD(hi[0], ph, 0);
+    MX_RD(lo[1], pl, 2048); MX_RD(hi[1], ph, 2048);
+    if constexpr (MI == 4) {
+      MX_RD(lo[2], pl, 4096); MX_RD(hi[2], ph, 4096);
+      MX_RD(lo[3], pl, 6144); MX_RD(hi[3], ph, 6144);
+    }
+  };
+  auto ld_b01 = [&](int st) {
+    const uint32_t pl = lds0 + st * kStage + b_off + c_lo, ph = lds0 + st * kStage + b_off + c_hi;
+    MX_RD(blo[0], pl, 0); MX_RD(bhi[0], ph, 0);
+    MX_RD(blo[1], pl, 2048); MX_RD(bhi[1], ph, 2048);
+  };
+  auto ld_b23 = [&](int st) {
+    const uint32_t pl = lds0 + st * kStage + b_off + c_lo, ph = lds0 + st * kStage + b_off + c_hi;
+    MX_RD(blo[2], pl, 4096); MX_RD(bhi[2], ph, 4096);
+    MX_RD(blo[3], pl, 6144); MX_RD(bhi[3], ph, 6144);
+  };
+#undef MX_RD
+  ld_a(0, alo[0], ahi[0]);
+  ld_b01(0);
+  int cur = 0, nxt2 = 2;
+
+  // One K step.  OPS = kt & 3 (compile time): the step's byte of the scale dwords and the register set of its A fragments;
+  // DMA: step kt + 2 exists and is requested here; SCALES: the next group's scale dwords are requested here (OPS == 0 only);
+  // LAST: no step follows.  Every wait is a compile-time constant: the K loop has no data-dependent branch inside a step.
+  auto step = [&](auto ops_c, auto dma_c, auto scales_c, auto last_c) {
+    constexpr int OPS = decltype(ops_c)::value;
+    constexpr bool DMA = decltype(dma_c)::value, SCALES = decltype(scales_c)::value, LAST = decltype(last_c)::value;
+    constexpr int SET = OPS & 1;
+    static_assert(!SCALES || (OPS == 0 && DMA), "scale groups start at OPS 0, with steps behind them");
+    if constexpr (SCALES) load_scales(snxt);
+    if constexpr (DMA) issue(nxt2);
+    ld_b23(cur);
+    // this step's A blocks and W blocks 0, 1 (read one phase ago) are in; the 4 reads just issued may still fly
+    if constexpr (MI == 4)
+      asm volatile("s_waitcnt lgkmcnt(4)" : MX_DEP4(alo[SET]), MX_DEP4(ahi[SET]), MX_DEP2(blo), MX_DEP2(bhi) :: "memory");
+    else
+      asm volatile("s_waitcnt lgkmcnt(4)" : MX_DEP2(alo[SET]), MX_DEP2(ahi[SET]), MX_DEP2(blo), MX_DEP2(bhi) :: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (OPS == 1) wait_scales(snxt);   // (requested one step ago; the vmcnt wait at the end of that step's phase A covered them)
+    auto mma = [&](int j0) {
+#pragma unroll
+      for (int j = j0; j < j0 + 2; ++j) {
+        const i32x8_t wf = __builtin_shufflevector(blo[j], bhi[j], 0, 1, 2, 3, 4, 5, 6, 7);
+        const int sws = OPSEL ? scur[j] : (int)((unsigned)scur[j] >> (8 * OPS));
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          const i32x8_t af = __builtin_shufflevector(alo[SET][i], ahi[SET][i], 0, 1, 2, 3, 4, 5, 6, 7);
+          const int sas = OPSEL ? scur[NI + i] : (int)((unsigned)scur[NI + i] >> (8 * OPS));
+          acc[j][i] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf, af, acc[j][i], 0, 0, OPSEL ? OPS : 0, sws, OPSEL ? OPS : 0, sas);
+        }
+      }
+    };
+    mma(0);
+    __builtin_amdgcn_sched_barrier(0);
+    // W blocks 2, 3 are in (every read of stage kt by this wave has retired); stage kt + 1 of this wave has landed -- what may
+    // stay in flight is this step's DMA and (group starts) the scale dwords
+#define MX_B23 "+v"(blo[2]), "+v"(blo[3]), "+v"(bhi[2]), "+v"(bhi[3])
+    if constexpr (LAST) {
+      asm volatile("s_waitcnt lgkmcnt(0)" : MX_B23 :: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
+      if constexpr (SCALES) { if constexpr (MI == 4) asm volatile("s_waitcnt vmcnt(14) lgkmcnt(0)" : MX_B23 :: "memory"); else asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" : MX_B23 :: "memory"); }
+      else if constexpr (DMA) { if constexpr (MI == 4) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" : MX_B23 :: "memory"); else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" : MX_B23 :: "memory"); }
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : MX_B23 :: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      cur = cur == NST - 1 ? 0 : cur + 1;
+      nxt2 = nxt2 == NST - 1 ? 0 : nxt2 + 1;
+      ld_a(cur, alo[SET ^ 1], ahi[SET ^ 1]);
+      ld_b01(cur);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#undef MX_B23
+    mma(2);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (OPS == 3) {
+#pragma unroll
+      for (int q = 0; q < NSC; ++q) scur[q] = snxt[q];
+    }
+  };
+  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+  using Y = std::true_type; using N_ = std::false_type;
+  int kt = 0;
+  for (; kt + 6 <= nk; kt += 4) {      // four steps that all have a step kt + 2 behind them, and a group behind this one
+    step(I0{}, Y{}, Y{}, N_{});
+    step(I1{}, Y{}, N_{}, N_{});
+    step(I2{}, Y{}, N_{}, N_{});
+    step(I3{}, Y{}, N_{}, N_{});
+  }
+  switch (nk - kt) {                   // 1 .. 5 steps left; the last two request nothing
+    case 1: step(I0{}, N_{}, N_{}, Y{}); break;
+    case 2: step(I0{}, N_{}, N_{}, N_{}); step(I1{}, N_{}, N_{}, Y{}); break;
+    case 3: step(I0{}, Y{}, N_{}, N_{}); step(I1{}, N_{}, N_{}, N_{}); step(I2{}, N_{}, N_{}, Y{}); break;
+    case 4: step(I0{}, Y{}, N_{}, N_{}); step(I1{}, Y{}, N_{}, N_{}); step(I2{}, N_{}, N_{}, N_{}); step(I3{}, N_{}, N_{}, Y{}); break;
+    default:
+      step(I0{}, Y{}, Y{}, N_{}); step(I1{}, Y{}, N_{}, N_{}); step(I2{}, Y{}, N_{}, N_{}); step(I3{}, N_{}, N_{}, N_{});
+      step(I0{}, N_{}, N_{}, Y{});
+      break;
+  }
+#undef MX_WAIT
+#undef MX_DEP4
+#undef MX_DEP2
+  g3_epilogue<EPI, MI>(p, acc, m0, n0, wr, wc, lane);
+}
+
+template <int EPI, int MI>
+int launch_mx8(const GemmP& p, hipStream_t s) {
+  constexpr int BM = 64 * MI;
+  const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + 127) / 128;
+  if (option(OPT_MX8_OPSEL) != 0)
+    hipLaunchKernelGGL((gemm_mx8_kernel<EPI, MI, true>), dim3(nbm * nbn), dim3(512), 3 * (BM + 128) * 128, s, p);
+  else
+    hipLaunchKernelGGL((gemm_mx8_kernel<EPI, MI, false>), dim3(nbm * nbn), dim3(512), 3 * (BM + 128) * 128, s, p);
+  return check_launch("gemm_mx8_kernel");
+}
+template <int EPI>
+bool prepare_mx8() {
+  bool ok = true;
+  ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mx8_kernel<EPI, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (128 + 128) * 128) == hipSuccess;
+  ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mx8_kernel<EPI, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (128 + 128) * 128) == hipSuccess;
+  return ok;
+}
+template <int EPI>
+int dispatch_mx8(const GemmP& p, hipStream_t s) {
+  // 128 x 128 tiles (wave tile 32 x 64).  The 256-row form (MI = 4: 64 accumulators + two A fragment sets of 32 + W fragments 32 +
+  // scales) does not fit the 256 registers a wave of a 512-thread workgroup may hold under hipcc's allocation: it spilled
+  // asm-loaded fragments (tools/check_kernel_resources.py fails the build on that) and is not instantiated.
+  return launch_mx8<EPI, 2>(p, s);
+}
+int dispatch_mx8_epi(const GemmP& p, int epi, hipStream_t s) {
+  switch (epi) {
+    case MH_EPI_STORE: return dispatch_mx8<MH_EPI_STORE>(p, s);
+    case MH_EPI_STORE_F32: return dispatch_mx8<MH_EPI_STORE_F32>(p, s);
+    case MH_EPI_RESID: return dispatch_mx8<MH_EPI_RESID>(p, s);
+    case MH_EPI_GEGLU: return dispatch_mx8<MH_EPI_GEGLU>(p, s);
+    case MH_EPI_BIAS_GELU: return dispatch_mx8<MH_EPI_BIAS_GELU>(p, s);
+    case MH_EPI_GATE_RESID: return dispatch_mx8<MH_EPI_GATE_RESID>(p, s);
+    case MH_EPI_KV_SCATTER: return dispatch_mx8<MH_EPI_KV_SCATTER>(p, s);
+    case MH_EPI_QKV_VT: return dispatch_mx8<MH_EPI_QKV_VT>(p, s);
+  }
+  set_error("mh_gemm: epilogue %d is not built for MH_MX8 operands", epi);
+  return MH_ERR_ARG;
+}
+
 template <int EPI, int MI>
 int launch_s3g(const GemmP& p, hipStream_t s) {
   constexpr int BM = 64 * MI;
@@ -1230,7 +1534,9 @@ int gemm_prepare() {
   static bool done = false;
   if (done) return MH_OK;
   if (!(prepare_type<bf16_t>() && prepare_type<float>() && prepare_s3g<MH_EPI_QKV_VT>() && prepare_s3g<MH_EPI_GATE_RESID>() &&
-        prepare_s3g<MH_EPI_BIAS_GELU>() && prepare_s3g<MH_EPI_STORE_F32>())) {
+        prepare_s3g<MH_EPI_BIAS_GELU>() && prepare_s3g<MH_EPI_STORE_F32>() && prepare_mx8<MH_EPI_STORE>() &&
+        prepare_mx8<MH_EPI_STORE_F32>() && prepare_mx8<MH_EPI_RESID>() && prepare_mx8<MH_EPI_GEGLU>() && prepare_mx8<MH_EPI_BIAS_GELU>() &&
+        prepare_mx8<MH_EPI_GATE_RESID>() && prepare_mx8<MH_EPI_KV_SCATTER>() && prepare_mx8<MH_EPI_QKV_VT>())) {
     set_error("gemm_prepare: hipFuncSetAttribute failed: %s", hipGetErrorString(hipGetLastError()));
     return MH_ERR_LAUNCH;
   }
@@ -1241,7 +1547,31 @@ int gemm_prepare() {
 int gemm(const MhGemm& g, hipStream_t s, bool ascending_k) {
   MH_REQUIRE(g.A && g.W && g.C, "mh_gemm: null operand");
   MH_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0, "mh_gemm: bad shape M=%d N=%d K=%d", g.M, g.N, g.K);
-  MH_REQUIRE(g.dtype == MH_F32 || g.dtype == MH_BF16, "mh_gemm: bad dtype %d", g.dtype);
+  MH_REQUIRE(g.dtype == MH_F32 || g.dtype == MH_BF16 || g.dtype == MH_MX8, "mh_gemm: bad dtype %d", g.dtype);
+  if (g.dtype == MH_MX8) {
+    // e4m3 elements (1 byte) + E8M0 scales: K steps of 128, vector epilogue; outputs are bf16 / fp32 as the epilogue says
+    MH_REQUIRE(g.a_scale && g.w_scale, "mh_gemm: MH_MX8 needs a_scale and w_scale");
+    MH_REQUIRE(g.K % 128 == 0 && g.lda % 16 == 0 && g.ldw % 16 == 0 && g.lda >= g.K && g.ldw >= g.K,
+               "mh_gemm: MH_MX8 needs K %% 128 == 0 and lda, ldw multiples of 16 (K=%d lda=%d ldw=%d)", g.K, g.lda, g.ldw);
+    MH_REQUIRE(((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.W % 16) == 0 && ((uintptr_t)g.a_scale % 4) == 0 && ((uintptr_t)g.w_scale % 4) == 0,
+               "mh_gemm: MH_MX8 operands must be 16-byte aligned, scales 4-byte aligned");
+    MH_REQUIRE(g.N % 4 == 0 && g.ldc % 4 == 0 && (g.gate == nullptr || g.gate_ld % 4 == 0) && (g.epilogue != MH_EPI_GEGLU || g.N % 32 == 0) &&
+                   !g.stats_out && !g.ln_stats && !g.w_split3,
+               "mh_gemm: MH_MX8 needs N, ldc (gate_ld) multiples of 4 and takes no LayerNorm fusion / split3");
+    if (g.epilogue == MH_EPI_GATE_RESID) MH_REQUIRE(g.gate && g.rows_per_batch > 0, "mh_gemm: GATE_RESID needs gate and rows_per_batch");
+    if (g.epilogue == MH_EPI_KV_SCATTER)
+      MH_REQUIRE(g.kv_B > 0 && g.kv_H > 0 && g.kv_L > 0 && g.M == g.kv_B * g.kv_L && g.N % (g.kv_H * 64) == 0, "mh_gemm: bad KV scatter geometry");
+    if (g.epilogue == MH_EPI_QKV_VT)
+      MH_REQUIRE(g.C2 && g.kv_H > 0 && g.kv_L > 0 && g.kv_Lpad >= g.kv_L && g.n_split > 0 && g.N - g.n_split == g.kv_H * 64 && g.M % g.kv_L == 0,
+                 "mh_gemm: bad QKV_VT geometry");
+    { int rc = gemm_prepare(); if (rc != MH_OK) return rc; }
+    GemmP q{};
+    q.A = (const char*)g.A; q.lda_b = g.lda; q.W = (const char*)g.W; q.ldw_b = g.ldw; q.C = g.C; q.ldc = g.ldc;
+    q.M = g.M; q.N = g.N; q.K = g.K; q.bias = g.bias; q.gate = g.gate; q.gate_ld = g.gate_ld; q.rows_per_batch = g.rows_per_batch;
+    q.kv_B = g.kv_B; q.kv_H = g.kv_H; q.kv_L = g.kv_L; q.C2 = g.C2; q.n_split = g.n_split; q.kv_Lpad = g.kv_Lpad;
+    q.a_scale = g.a_scale; q.w_scale = g.w_scale; q.ks_b = mx8_scale_row_bytes(g.K);
+    return dispatch_mx8_epi(q, g.epilogue, s);
+  }
   const int es = g.dtype == MH_BF16 ? 2 : 4;
   const int vec = 16 / es;
   MH_REQUIRE(g.K % vec == 0 && g.lda % vec == 0 && g.ldw % vec == 0,
