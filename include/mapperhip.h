@@ -234,6 +234,13 @@ typedef struct MhT5Config {
   int local_every;          /* arch 1: global_attn_every_n_layers -- layer l is LOCAL iff l % local_every != 0; <= 1: none */
   int local_window;         /* arch 1: local_attention // 2 keys either side for local layers (the reference applies the
                                window on its flash-attention path only, modeling_varwhisper.py:330)                      */
+  /* --- ABI 7: BASELINE configs[4] "fp8 MFMA" ----------------------------------------------------------------------- */
+  int enc_operand_dtype;    /* 0 (= the storage type) or MH_MX8: the encoder blocks' four projections and the cross-K/V
+                               projection take MX-fp8 operands (weights pre-quantised by the host: MhT5Weights.*_mx;
+                               activations quantised where they are produced: RMSNorm output directly, attention output and
+                               gated-GELU hidden by a pass over the bf16 buffer).  Needs dtype = MH_BF16, arch 0, d_model /
+                               d_ff multiples of 128.  A reduced-precision mode of its own (the reference has none): gates
+                               are error bounds against the fp32 reference goldens, never bit-exactness.                 */
 } MhT5Config;
 
 typedef struct MhT5Weights {
@@ -280,6 +287,13 @@ typedef struct MhT5Weights {
    * (:212-226) and rounded to the storage type there: encoder positions 0 .. src_len-1, decoder 0 .. tgt_len-1;
    * *_local = the same with local_rope_theta for local layers (may alias the global ones)                           */
   const float* enc_rope; const float* enc_rope_local; const float* dec_rope; const float* dec_rope_local;
+  /* --- ABI 7, enc_operand_dtype = MH_MX8 only: the MX-fp8 copies (mh_quantize_mx8 layout: e4m3 [N][K] + scales
+   * [N][mh_mx8_scale_row_bytes(K)]) of enc_qkv / enc_o / enc_wi (interleaved like enc_wi) / enc_wo / dec_ckv_all --------- */
+  const uint8_t* enc_qkv_mx[MH_MAX_LAYERS]; const uint8_t* enc_qkv_mxs[MH_MAX_LAYERS];
+  const uint8_t* enc_o_mx[MH_MAX_LAYERS]; const uint8_t* enc_o_mxs[MH_MAX_LAYERS];
+  const uint8_t* enc_wi_mx[MH_MAX_LAYERS]; const uint8_t* enc_wi_mxs[MH_MAX_LAYERS];
+  const uint8_t* enc_wo_mx[MH_MAX_LAYERS]; const uint8_t* enc_wo_mxs[MH_MAX_LAYERS];
+  const uint8_t* dec_ckv_all_mx; const uint8_t* dec_ckv_all_mxs;
 } MhT5Weights;
 
 /* bytes of scratch needed by mh_t5_encode for a batch of B chunks */
@@ -309,6 +323,11 @@ int mh_t5_encode_cond(const MhT5Config* cfg, const MhT5Weights* w, const void* m
  * key_value_states, computed once per chunk and kept in the encoder-side StaticCache:
  * osuT5/osuT5/inference/cache_utils.py:32-35).
  * cross_kv out: [n_dec][2][B][H][L][64] element type cfg.dtype. */
+/* (ABI 7) the same with scratch for the MX-fp8 copy of enc_out when cfg->enc_operand_dtype = MH_MX8 (mh_t5_cross_kv refuses
+ * that mode: it has nowhere to put the copy); workspace >= mh_t5_cross_kv_workspace_bytes(cfg, B) (0 for the plain modes). */
+int64_t mh_t5_cross_kv_workspace_bytes(const MhT5Config* cfg, int B);
+int mh_t5_cross_kv_ws(const MhT5Config* cfg, const MhT5Weights* w, const void* enc_out, int B, void* cross_kv, void* workspace,
+                      int64_t workspace_bytes, void* stream);
 int mh_t5_cross_kv(const MhT5Config* cfg, const MhT5Weights* w, const void* enc_out, int B,
                    void* cross_kv, void* stream);
 

@@ -41,7 +41,8 @@ class MhT5Config(C.Structure):
                 ("tgt_len", C.c_int), ("dtype", C.c_int), ("eps", C.c_float),
                 # ABI 5: the Whisper-family backbone (arch 1)
                 ("arch", C.c_int), ("attn_scale", C.c_float), ("in_frames", C.c_int), ("local_every", C.c_int),
-                ("local_window", C.c_int)]
+                ("local_window", C.c_int),
+                ("enc_operand_dtype", C.c_int)]      # ABI 7: 0 or MH_MX8
 
 
 class MhT5Weights(C.Structure):
@@ -57,7 +58,11 @@ class MhT5Weights(C.Structure):
                 ("enc_qkv_b", _PTR_ARR), ("enc_o_b", _PTR_ARR), ("enc_fc1_b", _PTR_ARR), ("enc_fc2_b", _PTR_ARR),
                 ("dec_qkv_b", _PTR_ARR), ("dec_o_b", _PTR_ARR), ("dec_cq_b", _PTR_ARR), ("dec_ckv_b_all", VP),
                 ("dec_co_b", _PTR_ARR), ("dec_fc1_b", _PTR_ARR), ("dec_fc2_b", _PTR_ARR),
-                ("enc_rope", VP), ("enc_rope_local", VP), ("dec_rope", VP), ("dec_rope_local", VP)]
+                ("enc_rope", VP), ("enc_rope_local", VP), ("dec_rope", VP), ("dec_rope_local", VP),
+                # ABI 7: MX-fp8 copies of the encoder projections and of the cross-K/V projection
+                ("enc_qkv_mx", _PTR_ARR), ("enc_qkv_mxs", _PTR_ARR), ("enc_o_mx", _PTR_ARR), ("enc_o_mxs", _PTR_ARR),
+                ("enc_wi_mx", _PTR_ARR), ("enc_wi_mxs", _PTR_ARR), ("enc_wo_mx", _PTR_ARR), ("enc_wo_mxs", _PTR_ARR),
+                ("dec_ckv_all_mx", VP), ("dec_ckv_all_mxs", VP)]
 
 
 class MhSampling(C.Structure):
@@ -117,6 +122,8 @@ SYMBOLS = {
     "mh_t5_encode_workspace_bytes": (I64, [C.POINTER(MhT5Config), I]),
     "mh_t5_encode": (I, [C.POINTER(MhT5Config), C.POINTER(MhT5Weights), VP, I, VP, VP, VP, I64, VP]),
     "mh_t5_cross_kv": (I, [C.POINTER(MhT5Config), C.POINTER(MhT5Weights), VP, I, VP, VP]),
+    "mh_t5_cross_kv_workspace_bytes": (I64, [C.POINTER(MhT5Config), I]),
+    "mh_t5_cross_kv_ws": (I, [C.POINTER(MhT5Config), C.POINTER(MhT5Weights), VP, I, VP, VP, I64, VP]),
     "mh_t5_encode_cond": (I, [C.POINTER(MhT5Config), C.POINTER(MhT5Weights), VP, I, VP, VP, VP, VP, I64, VP]),
     "mh_t5_decode_workspace_bytes": (I64, [C.POINTER(MhT5Config), I]),
     "mh_t5_cross_kv_fp8_bytes": (I64, [C.POINTER(MhT5Config), I]),

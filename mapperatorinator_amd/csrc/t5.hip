@@ -33,8 +33,14 @@ int check_cfg(const MhT5Config* c, const char* who) {
     MH_REQUIRE(c->in_frames >= 1 && c->src_len == (c->in_frames - 1) / 2 + 1, "%s: src_len must be the conv-strided in_frames", who);
     MH_REQUIRE(c->attn_scale > 0.f, "%s: attn_scale must be positive", who);
   }
+  MH_REQUIRE(c->enc_operand_dtype == 0 || c->enc_operand_dtype == MH_MX8, "%s: enc_operand_dtype must be 0 or MH_MX8", who);
+  if (c->enc_operand_dtype == MH_MX8)
+    MH_REQUIRE(c->dtype == MH_BF16 && c->arch == 0 && c->d_model % 128 == 0 && c->d_ff % 128 == 0,
+               "%s: MX-fp8 encoder operands need bf16 storage, the T5 backbone and d_model / d_ff multiples of 128", who);
   return MH_OK;
 }
+inline bool enc_mx(const MhT5Config* c) { return c->enc_operand_dtype == MH_MX8; }
+inline int64_t mx_operand_bytes(int64_t rows, int K) { return align256(rows * K) + align256(rows * mx8_scale_row_bytes(K)); }
 inline bool is_local_layer(const MhT5Config* c, int l) { return c->arch == 1 && c->local_every > 1 && c->local_window > 0 && l % c->local_every != 0; }
 
 #define MH_TRY(expr)              \
@@ -64,6 +70,8 @@ extern "C" int64_t mh_t5_encode_workspace_bytes(const MhT5Config* c, int B) {
   t += align256((int64_t)B * inner * Lpad * es);           // vt
   t += align256(rows * inner * es);                        // attn
   t += align256(rows * c->d_ff * es);                      // ff
+  if (c->enc_operand_dtype == MH_MX8)                      // MX-fp8 copy of the current GEMM's A operand (widest: d_ff columns)
+    t += mx_operand_bytes(rows, c->d_ff > c->d_model ? c->d_ff : c->d_model);
   return t;
 }
 
@@ -215,7 +223,17 @@ extern "C" int mh_t5_encode_cond(const MhT5Config* c, const MhT5Weights* w, cons
   void* vt = ar.take((int64_t)B * inner * Lpad * es);
   void* attn = ar.take((int64_t)rows * inner * es);
   void* ff = ar.take((int64_t)rows * dff * es);
-  MH_REQUIRE(ar.ok() && ff, "mh_t5_encode: arena overflow");
+  const bool mx = enc_mx(c);
+  const int kmax = dff > d ? dff : d;
+  uint8_t* xq = mx ? (uint8_t*)ar.take((int64_t)rows * kmax) : nullptr;                       // e4m3 bytes of the current A operand
+  uint8_t* xs = mx ? (uint8_t*)ar.take((int64_t)rows * mx8_scale_row_bytes(kmax)) : nullptr;  // its E8M0 scales
+  MH_REQUIRE(ar.ok() && ff && (!mx || xs), "mh_t5_encode: arena overflow");
+  if (mx) {
+    MH_REQUIRE(w->dec_ckv_all_mx && w->dec_ckv_all_mxs, "mh_t5_encode: enc_operand_dtype = MH_MX8 needs the MX-fp8 weight copies");
+    for (int l = 0; l < c->n_enc_layers; ++l)
+      MH_REQUIRE(w->enc_qkv_mx[l] && w->enc_qkv_mxs[l] && w->enc_o_mx[l] && w->enc_o_mxs[l] && w->enc_wi_mx[l] && w->enc_wi_mxs[l] &&
+                     w->enc_wo_mx[l] && w->enc_wo_mxs[l], "mh_t5_encode: enc_operand_dtype = MH_MX8 needs the MX-fp8 weight copies (layer %d)", l);
+  }
   if (hipMemsetAsync(vt, 0, (size_t)B * inner * Lpad * es, s) != hipSuccess) return check_launch("memset vt");
 
   MhGemm g;
@@ -233,26 +251,38 @@ extern "C" int mh_t5_encode_cond(const MhT5Config* c, const MhT5Weights* w, cons
   }
   MH_TRY(gemm(g, s));
 
+  // MX-fp8 operands (enc_operand_dtype = MH_MX8): the A operand of each projection is the e4m3 + E8M0 copy in xq / xs -- written
+  // by the RMSNorm itself (the bf16 rounding of the storage mode applied first, so the quantiser sees what the bf16 path multiplies),
+  // or by a pass over the bf16 buffer the attention / the gated GELU wrote
+  auto operand = [&](MhGemm& gg, const void* a_plain, int K, const void* w_plain, const uint8_t* w_mx, const uint8_t* w_mxs) {
+    if (mx) { gg.A = xq; gg.lda = K; gg.a_scale = xs; gg.W = w_mx; gg.ldw = K; gg.w_scale = w_mxs; gg.dtype = MH_MX8; }
+    else { gg.A = a_plain; gg.lda = K; gg.W = w_plain; gg.ldw = K; gg.dtype = c->dtype; }
+  };
   for (int l = 0; l < c->n_enc_layers; ++l) {
-    MH_TRY(rmsnorm(h, d, w->enc_ln1[l], n, d, rows, d, c->eps, c->dtype, s));
+    if (mx) MH_TRY(rmsnorm_mx8(h, d, w->enc_ln1[l], rows, d, c->eps, MH_BF16, xq, d, xs, s));
+    else MH_TRY(rmsnorm(h, d, w->enc_ln1[l], n, d, rows, d, c->eps, c->dtype, s));
     g = MhGemm{};
-    g.A = n; g.lda = d; g.W = w->enc_qkv[l]; g.ldw = d; g.C = qk; g.ldc = 2 * inner; g.M = rows; g.N = 3 * inner;
-    g.K = d; g.dtype = c->dtype; g.epilogue = MH_EPI_QKV_VT; g.C2 = vt; g.n_split = 2 * inner; g.kv_B = B; g.kv_H = H;
+    operand(g, n, d, w->enc_qkv[l], w->enc_qkv_mx[l], w->enc_qkv_mxs[l]);
+    g.C = qk; g.ldc = 2 * inner; g.M = rows; g.N = 3 * inner;
+    g.K = d; g.epilogue = MH_EPI_QKV_VT; g.C2 = vt; g.n_split = 2 * inner; g.kv_B = B; g.kv_H = H;
     g.kv_L = L; g.kv_Lpad = Lpad;
     MH_TRY(gemm(g, s));
     MH_TRY(attention(qk, 2 * inner, inner, vt, Lpad, w->enc_rel_bias, attn, inner, B, L, H, 1.0f, 0, c->dtype, s));
+    if (mx) MH_TRY(quantize_mx8(attn, inner, rows, inner, MH_BF16, xq, inner, xs, s));
     g = MhGemm{};
-    g.A = attn; g.lda = inner; g.W = w->enc_o[l]; g.ldw = inner; g.C = h; g.ldc = d; g.M = rows; g.N = d; g.K = inner;
-    g.dtype = c->dtype; g.epilogue = MH_EPI_RESID;
+    operand(g, attn, inner, w->enc_o[l], w->enc_o_mx[l], w->enc_o_mxs[l]);
+    g.C = h; g.ldc = d; g.M = rows; g.N = d; g.K = inner; g.epilogue = MH_EPI_RESID;
     MH_TRY(gemm(g, s));
-    MH_TRY(rmsnorm(h, d, w->enc_ln2[l], n, d, rows, d, c->eps, c->dtype, s));
+    if (mx) MH_TRY(rmsnorm_mx8(h, d, w->enc_ln2[l], rows, d, c->eps, MH_BF16, xq, d, xs, s));
+    else MH_TRY(rmsnorm(h, d, w->enc_ln2[l], n, d, rows, d, c->eps, c->dtype, s));
     g = MhGemm{};
-    g.A = n; g.lda = d; g.W = w->enc_wi[l]; g.ldw = d; g.C = ff; g.ldc = dff; g.M = rows; g.N = 2 * dff; g.K = d;
-    g.dtype = c->dtype; g.epilogue = MH_EPI_GEGLU;
+    operand(g, n, d, w->enc_wi[l], w->enc_wi_mx[l], w->enc_wi_mxs[l]);
+    g.C = ff; g.ldc = dff; g.M = rows; g.N = 2 * dff; g.K = d; g.epilogue = MH_EPI_GEGLU;
     MH_TRY(gemm(g, s));
+    if (mx) MH_TRY(quantize_mx8(ff, dff, rows, dff, MH_BF16, xq, dff, xs, s));
     g = MhGemm{};
-    g.A = ff; g.lda = dff; g.W = w->enc_wo[l]; g.ldw = dff; g.C = h; g.ldc = d; g.M = rows; g.N = d; g.K = dff;
-    g.dtype = c->dtype; g.epilogue = MH_EPI_RESID;
+    operand(g, ff, dff, w->enc_wo[l], w->enc_wo_mx[l], w->enc_wo_mxs[l]);
+    g.C = h; g.ldc = d; g.M = rows; g.N = d; g.K = dff; g.epilogue = MH_EPI_RESID;
     MH_TRY(gemm(g, s));
   }
   MH_TRY(rmsnorm(h, d, w->enc_final_ln, enc_out, d, rows, d, c->eps, c->dtype, s));
@@ -260,10 +290,37 @@ extern "C" int mh_t5_encode_cond(const MhT5Config* c, const MhT5Weights* w, cons
   return MH_OK;
 }
 
+extern "C" int64_t mh_t5_cross_kv_workspace_bytes(const MhT5Config* c, int B) {
+  if (!c || B <= 0) return -1;
+  return c->enc_operand_dtype == MH_MX8 ? mx_operand_bytes((int64_t)B * c->src_len, c->d_model) : 0;
+}
+
+extern "C" int mh_t5_cross_kv_ws(const MhT5Config* c, const MhT5Weights* w, const void* enc_out, int B, void* cross_kv, void* workspace,
+                                 int64_t workspace_bytes, void* stream) {
+  MH_TRY(check_cfg(c, "mh_t5_cross_kv"));
+  MH_REQUIRE(w && enc_out && cross_kv && B > 0, "mh_t5_cross_kv: null argument");
+  if (!enc_mx(c)) return mh_t5_cross_kv(c, w, enc_out, B, cross_kv, stream);
+  MH_REQUIRE(workspace && workspace_bytes >= mh_t5_cross_kv_workspace_bytes(c, B), "mh_t5_cross_kv_ws: workspace too small");
+  MH_REQUIRE(w->dec_ckv_all_mx && w->dec_ckv_all_mxs, "mh_t5_cross_kv_ws: enc_operand_dtype = MH_MX8 needs dec_ckv_all_mx / _mxs");
+  hipStream_t s = (hipStream_t)stream;
+  const int inner = c->n_heads * 64, d = c->d_model, rows = B * c->src_len;
+  Arena ar(workspace, workspace_bytes);
+  uint8_t* xq = (uint8_t*)ar.take((int64_t)rows * d);
+  uint8_t* xs = (uint8_t*)ar.take((int64_t)rows * mx8_scale_row_bytes(d));
+  MH_REQUIRE(ar.ok() && xs, "mh_t5_cross_kv_ws: arena overflow");
+  MH_TRY(quantize_mx8(enc_out, d, rows, d, MH_BF16, xq, d, xs, s));
+  MhGemm g = MhGemm{};
+  g.A = xq; g.lda = d; g.a_scale = xs; g.W = w->dec_ckv_all_mx; g.ldw = d; g.w_scale = w->dec_ckv_all_mxs; g.C = cross_kv; g.ldc = 0;
+  g.M = rows; g.N = c->n_dec_layers * 2 * inner; g.K = d; g.dtype = MH_MX8;
+  g.epilogue = MH_EPI_KV_SCATTER; g.kv_B = B; g.kv_H = c->n_heads; g.kv_L = c->src_len;
+  return gemm(g, s);
+}
+
 extern "C" int mh_t5_cross_kv(const MhT5Config* c, const MhT5Weights* w, const void* enc_out, int B, void* cross_kv,
                               void* stream) {
   MH_TRY(check_cfg(c, "mh_t5_cross_kv"));
   MH_REQUIRE(w && enc_out && cross_kv && B > 0, "mh_t5_cross_kv: null argument");
+  MH_REQUIRE(!enc_mx(c), "mh_t5_cross_kv: enc_operand_dtype = MH_MX8 needs scratch for the quantised encoder output: call mh_t5_cross_kv_ws");
   const int inner = c->n_heads * 64;
   MhGemm g = MhGemm{};
   g.A = enc_out; g.lda = c->d_model; g.W = w->dec_ckv_all; g.ldw = c->d_model; g.C = cross_kv; g.ldc = 0;

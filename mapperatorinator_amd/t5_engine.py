@@ -90,8 +90,17 @@ class PackedT5:
     """Device-resident packed weights + the MhT5Config / MhT5Weights structs that describe them."""
 
     def __init__(self, sd: dict, dims: T5Dims, vocab_in: int, vocab_out: int, n_mels: int, src_len: int,
-                 tgt_len: int, dtype: torch.dtype, device):
+                 tgt_len: int, dtype: torch.dtype, device, enc_operand_dtype: Optional[str] = None):
+        """`enc_operand_dtype="mx8"` (BASELINE configs[4] "fp8 MFMA"; bf16 storage only): the encoder blocks' projections and
+        the cross-K/V projection also get MX-fp8 copies (OCP e4m3 + E8M0 per 32 k, mx8.quantize_mx8 -- the rule the device
+        applies to the activations) and MhT5Config.enc_operand_dtype selects the MX GEMMs.  A reduced-precision mode of its
+        own, never the default; the decoder is untouched (its GEMVs are latency-bound)."""
         assert dtype in (torch.float32, torch.bfloat16)
+        if enc_operand_dtype not in (None, "mx8"):
+            raise ValueError(f"enc_operand_dtype must be None or 'mx8', got {enc_operand_dtype!r}")
+        if enc_operand_dtype == "mx8" and (dtype != torch.bfloat16 or dims.d_model % 128 or dims.d_ff % 128):
+            raise ValueError("MX-fp8 encoder operands need bf16 storage and d_model / d_ff multiples of 128")
+        self.enc_operand_dtype = enc_operand_dtype
         self.dims, self.dtype, self.device = dims, dtype, torch.device(device)
         self.vocab_in, self.vocab_out, self.n_mels = vocab_in, vocab_out, n_mels
         self.n_mels_pad = _round_up(n_mels, 32)
@@ -107,6 +116,12 @@ class PackedT5:
             self._keep.append(t)
             return t
 
+        def mxmat(t):  # MX-fp8 copy of a GEMM operand: the weights as the bf16 path holds them, then quantised
+            from .mx8 import quantize_mx8
+            q, sc = quantize_mx8(t.detach().to(torch.float32).to(dtype).to(torch.float32).to(dev))
+            self._keep += [q, sc]
+            return q.data_ptr(), sc.data_ptr()
+
         def vec(t):  # fp32 vector holding the storage-dtype-rounded values
             t = t.detach().to(dtype).to(torch.float32).contiguous().to(dev)
             self._keep.append(t)
@@ -121,7 +136,8 @@ class PackedT5:
         cfg = _lib.MhT5Config(dims.d_model, dims.d_kv, dims.d_ff, dims.n_heads, dims.n_enc_layers, dims.n_dec_layers,
                               vocab_in, vocab_out, n_mels, self.n_mels_pad, src_len, tgt_len,
                               _lib.MH_BF16 if dtype == torch.bfloat16 else _lib.MH_F32, dims.eps,
-                              0, 1.0, src_len, 0, 0)      # arch 0 = T5
+                              0, 1.0, src_len, 0, 0,      # arch 0 = T5
+                              _lib.MH_MX8 if enc_operand_dtype == "mx8" else 0)
         w = _lib.MhT5Weights()
         # columns beyond n_mels belong to the conditioning vectors: they reach the device as a per-chunk row bias
         # (conditioning.ConditioningEmbedders.row_bias, mh_t5_encode_cond)
@@ -145,6 +161,11 @@ class PackedT5:
             f = b + "layer.1.DenseReluDense."
             w.enc_wi[l] = mat(interleave16(sd[f + "wi_0.weight"], sd[f + "wi_1.weight"])).data_ptr()
             w.enc_wo[l] = mat(sd[f + "wo.weight"]).data_ptr()
+            if enc_operand_dtype == "mx8":
+                w.enc_qkv_mx[l], w.enc_qkv_mxs[l] = mxmat(torch.cat([sd[a + "q.weight"], sd[a + "k.weight"], sd[a + "v.weight"]], 0))
+                w.enc_o_mx[l], w.enc_o_mxs[l] = mxmat(sd[a + "o.weight"])
+                w.enc_wi_mx[l], w.enc_wi_mxs[l] = mxmat(interleave16(sd[f + "wi_0.weight"], sd[f + "wi_1.weight"]))
+                w.enc_wo_mx[l], w.enc_wo_mxs[l] = mxmat(sd[f + "wo.weight"])
         w.enc_final_ln = vec(sd[pe + "final_layer_norm.weight"]).data_ptr()
         ckv = []
         for l in range(dims.n_dec_layers):
@@ -163,6 +184,8 @@ class PackedT5:
             w.dec_wi[l] = mat(interleave16(sd[f + "wi_0.weight"], sd[f + "wi_1.weight"])).data_ptr()
             w.dec_wo[l] = mat(sd[f + "wo.weight"]).data_ptr()
         w.dec_ckv_all = mat(torch.cat(ckv, 0)).data_ptr()
+        if enc_operand_dtype == "mx8":
+            w.dec_ckv_all_mx, w.dec_ckv_all_mxs = mxmat(torch.cat(ckv, 0))
         w.dec_final_ln = vec(sd[pd + "final_layer_norm.weight"]).data_ptr()
         w.lm_head = mat(sd["transformer.lm_head.weight"]).data_ptr()
         self.cfg, self.w = cfg, w
@@ -202,13 +225,14 @@ class T5Engine:
     def __init__(self, state_dict: dict, dims: T5Dims, vocab_in: int, vocab_out: int, n_mels: int = 388,
                  src_len: int = 1251, tgt_len: int = 512, dtype: torch.dtype = torch.bfloat16, device="cuda",
                  sample_rate: int = 16000, n_fft: int = 1024, hop_length: int = 128, f_min: int = 0,
-                 f_max: int = 8000, log_scale: bool = False):
+                 f_max: int = 8000, log_scale: bool = False, enc_operand_dtype: Optional[str] = None):
         if not torch.cuda.is_available():
             raise RuntimeError("T5Engine needs a ROCm GPU; there is no CPU fallback")
         self.lib = _lib.load()
         self.device = torch.device(device)
         self.dims, self.dtype = dims, dtype
-        self.packed = PackedT5(state_dict, dims, vocab_in, vocab_out, n_mels, src_len, tgt_len, dtype, self.device)
+        self.packed = PackedT5(state_dict, dims, vocab_in, vocab_out, n_mels, src_len, tgt_len, dtype, self.device,
+                               enc_operand_dtype=enc_operand_dtype)
         self.spectrogram = MelSpectrogram("nnAudio", log_scale, sample_rate, n_fft, n_mels, hop_length, f_min,
                                           f_max, "constant").to(self.device)
         self.hop_length, self.src_len, self.tgt_len = hop_length, src_len, tgt_len
@@ -276,8 +300,10 @@ class T5Engine:
         B = enc.shape[0]
         kv = torch.empty((self.dims.n_dec_layers, 2, B, self.dims.n_heads, p.src_len, 64), dtype=self.dtype,
                          device=self.device)
-        rc = self.lib.mh_t5_cross_kv(C.byref(p.cfg), C.byref(p.w), enc.data_ptr(), B, kv.data_ptr(), self._s())
-        _lib.check(rc, "mh_t5_cross_kv")
+        need = self.lib.mh_t5_cross_kv_workspace_bytes(C.byref(p.cfg), B)     # (> 0 only with MX-fp8 operands: the quantised enc)
+        ws = self._workspace("ckv", max(int(need), 256))
+        rc = self.lib.mh_t5_cross_kv_ws(C.byref(p.cfg), C.byref(p.w), enc.data_ptr(), B, kv.data_ptr(), ws.data_ptr(), ws.numel(), self._s())
+        _lib.check(rc, "mh_t5_cross_kv_ws")
         return kv
 
     def cross_kv_fp8(self, kv: torch.Tensor) -> torch.Tensor:

@@ -83,3 +83,20 @@ def dequantize_mx8(q: np.ndarray, scales: np.ndarray) -> np.ndarray:
 def mx8_matmul(qa, sa, qw, sw) -> np.ndarray:
     """C[m, n] = sum_k A[m, k] W[n, k] of the values the two MX operands stand for, float64"""
     return dequantize_mx8(qa, sa) @ dequantize_mx8(qw, sw).T
+
+
+def fake_quant_torch(x):
+    """torch restatement of quantise -> dequantise along the last axis (blocks of 32): the fp32 values an MX-fp8 operand made
+    from `x` stands for.  Used by the model-level oracles (oracle/t5.py, oracle/dit.py) where numpy would be slow; pinned to
+    the numpy form above in tests/test_host_cpu.py."""
+    import torch
+    shp = x.shape
+    xb = x.detach().to(torch.float32).reshape(-1, shp[-1] // 32, 32)
+    amax = xb.abs().amax(dim=2)
+    _, ex = torch.frexp(amax)
+    e = ex.to(torch.int32) - 9
+    e = torch.where(torch.ldexp(amax, -e) > 448.0, e + 1, e)
+    e = torch.where(amax > 0, e, torch.full_like(e, -127)).clamp(-127, 127)
+    ee = e.unsqueeze(-1).expand_as(xb)
+    q = torch.ldexp(xb, -ee).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(torch.float32)
+    return torch.ldexp(q, ee).reshape(shp)

@@ -80,7 +80,13 @@ class T5Oracle:
     """Stateless math over a reference-named state_dict (see PackedT5 for the same key names)."""
 
     def __init__(self, sd: dict, d_model, d_ff, n_heads, n_enc, n_dec, eps=1e-6, n_buckets=32, max_distance=128,
-                 rounding=None):
+                 rounding=None, enc_mx8=False):
+        """`enc_mx8` (with rounding="bf16"): the contract of MhT5Config.enc_operand_dtype = MH_MX8 -- the encoder blocks' four
+        projections and the cross-K/V projection multiply the MX-fp8 images (oracle/mx8.py) of their bf16 operands; everything
+        else as the bf16 contract.  (float32 matmul of the dequantised operands: the matrix core's own 13-bit alignment window,
+        profiles/r04_micro_mx8_precision.txt, is far below the quantisation step and is not modelled.)"""
+        assert not enc_mx8 or rounding == "bf16"
+        self.enc_mx8 = enc_mx8
         self.r = Rounding(rounding)
         self.sd = {k: self.r.w(v.detach().to(torch.float32)) for k, v in sd.items()
                    if v.dtype.is_floating_point}
@@ -105,11 +111,22 @@ class T5Oracle:
         B, H, T, _ = out.shape
         return out.transpose(1, 2).reshape(B, T, H * 64)
 
-    def _ffn(self, x, pre):
+    def _ffn(self, x, pre, lin=None):
         r, sd = self.r, self.sd
-        g = x @ sd[pre + "wi_0.weight"].t()
-        u = x @ sd[pre + "wi_1.weight"].t()
-        return r(gelu_new(g) * u) @ sd[pre + "wo.weight"].t()
+        lin = lin or (lambda a, name: a @ sd[name].t())
+        g = lin(x, pre + "wi_0.weight")
+        u = lin(x, pre + "wi_1.weight")
+        return lin(r(gelu_new(g) * u), pre + "wo.weight")
+
+    def _enc_lin(self, a, name):
+        """a projection of the encoder side: plain, or on the MX-fp8 images of both operands"""
+        if not self.enc_mx8:
+            return a @ self.sd[name].t()
+        from .mx8 import fake_quant_torch
+        cache = self.__dict__.setdefault("_mxw", {})
+        if name not in cache:
+            cache[name] = fake_quant_torch(self.sd[name])
+        return fake_quant_torch(a) @ cache[name].t()
 
     def enc_bias(self, L):
         pos = torch.arange(L)
@@ -138,13 +155,14 @@ class T5Oracle:
         for l in range(self.ne):
             b = f"transformer.encoder.block.{l}."
             a = b + "layer.0.SelfAttention."
+            lin = self._enc_lin
             n = r(rms_norm(h, sd[b + "layer.0.layer_norm.weight"], self.eps))
-            q = self._heads(r(n @ sd[a + "q.weight"].t()))
-            k = self._heads(r(n @ sd[a + "k.weight"].t()))
-            v = self._heads(r(n @ sd[a + "v.weight"].t()))
-            h = h + r(self._attn(q, k, v, bias)) @ sd[a + "o.weight"].t()
+            q = self._heads(r(lin(n, a + "q.weight")))
+            k = self._heads(r(lin(n, a + "k.weight")))
+            v = self._heads(r(lin(n, a + "v.weight")))
+            h = h + lin(r(self._attn(q, k, v, bias)), a + "o.weight")
             n = r(rms_norm(h, sd[b + "layer.1.layer_norm.weight"], self.eps))
-            h = h + self._ffn(n, b + "layer.1.DenseReluDense.")
+            h = h + self._ffn(n, b + "layer.1.DenseReluDense.", lin)
         return rms_norm(h, sd["transformer.encoder.final_layer_norm.weight"], self.eps)
 
     def encode_audio(self, audio, n_mels=388, cond=None):
@@ -158,7 +176,7 @@ class T5Oracle:
         out = []
         for l in range(self.nd):
             x = f"transformer.decoder.block.{l}.layer.1.EncDecAttention."
-            out.append((self._heads(r(e @ sd[x + "k.weight"].t())), self._heads(r(e @ sd[x + "v.weight"].t()))))
+            out.append((self._heads(r(self._enc_lin(e, x + "k.weight"))), self._heads(r(self._enc_lin(e, x + "v.weight")))))
         return out
 
     def decoder_step(self, tok, pos, cache, ckv, key_mask):

@@ -46,10 +46,10 @@ def test_argument_validation_without_gpu():
 
 def test_struct_layouts_match_header_sizes():
     # pointer arrays of MH_MAX_LAYERS entries, ints packed as in C
-    assert C.sizeof(_lib.MhT5Config) == 14 * 4 + 5 * 4                    # ABI 5: arch, attn_scale, in_frames, local_every, local_window
+    assert C.sizeof(_lib.MhT5Config) == 14 * 4 + 5 * 4 + 4                # ABI 5: arch, attn_scale, in_frames, local_every, local_window; ABI 7: enc_operand_dtype
     base = 4 * 8 + 16 * 4 + 3 * 4 + 4 + 8                                # 4B pad before the uint64 seed
     assert C.sizeof(_lib.MhSampling) == base + 9 * 4 + 4 + 8 + 2 * 4 + 8   # ABI 2 tail: 9 words, pad, tok_flags; ABI 3: 2 words; ABI 4: cross_kv_fp8
-    assert C.sizeof(_lib.MhT5Weights) == 8 * (5 + 6 * 32 + 1 + 5 * 32 + 1 + 4 * 32 + 2) + 8 * (4 + 4 * 32 + 3 * 32 + 1 + 3 * 32 + 4)   # + ABI 5 (arch 1)
+    assert C.sizeof(_lib.MhT5Weights) == 8 * (5 + 6 * 32 + 1 + 5 * 32 + 1 + 4 * 32 + 2) + 8 * (4 + 4 * 32 + 3 * 32 + 1 + 3 * 32 + 4) + 8 * (8 * 32 + 2)   # + ABI 5 (arch 1) + ABI 7 (MX-fp8 copies)
     assert C.sizeof(_lib.MhDiTWeights) == 8 * (12 + 10 * 32 + 4 + 1 + 4 * 32 + 4 * 32)   # + the pre-split (bf16 x 3) and the bf16 copies
 
 
@@ -562,3 +562,29 @@ def test_kernels_with_asm_issued_loads_have_no_scratch_and_no_spills():
         assert int(k.get(".private_segment_fixed_size", 0)) == 0, k[".symbol"]
         assert int(k.get(".vgpr_spill_count", 0)) == 0 and int(k.get(".sgpr_spill_count", 0)) == 0, k[".symbol"]
     assert ckr.main([lib]) == 0
+
+
+def test_mx8_host_packer_oracle_and_torch_restatement_agree():
+    """three statements of the MX-fp8 quantisation rule (numpy oracle, its torch form used inside the model oracles, the
+    product's weight packer) produce the same bytes / values, including zero blocks, outliers and the 448 boundary"""
+    import numpy as np
+    import torch
+
+    from mapperatorinator_amd import mx8 as host
+    from oracle import mx8 as omx
+    rng = np.random.default_rng(5)
+    x = (rng.standard_normal((41, 640)) * np.exp(rng.standard_normal((41, 640)) * 2)).astype(np.float32)
+    x[3, :96] = 0.0
+    x[7, 33] = 1.0e6
+    x[9, :32] = np.linspace(449.0, 511.0, 32, dtype=np.float32) * 2.0 ** -3          # amax * 2^-e in (448, 512): the exponent is raised
+    q, s = omx.quantize_mx8(x)
+    qh, sh = host.quantize_mx8(torch.from_numpy(x))
+    assert np.array_equal(q, qh.numpy()) and np.array_equal(s, sh.numpy())
+    assert s.shape[1] == host.scale_row_bytes(640) == 32
+    d = omx.dequantize_mx8(q, s)
+    assert np.array_equal(d, host.dequantize_mx8(qh, sh).numpy().astype(np.float64))
+    assert np.array_equal(d, omx.fake_quant_torch(torch.from_numpy(x)).numpy().astype(np.float64))
+    assert np.all(np.abs(d[9, :32]) <= np.abs(x[9, :32]).max() * 1.0001), "nothing may be clipped or overshoot"
+    # e4m3 grid facts the rule relies on
+    t = omx.e4m3_decode_table()
+    assert t[0x7e] == 448.0 and np.isnan(t[0x7f]) and t[0x01] == 2.0 ** -9 and t[0x08] == 2.0 ** -6
