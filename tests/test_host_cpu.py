@@ -584,7 +584,7 @@ def test_mx8_host_packer_oracle_and_torch_restatement_agree():
     d = omx.dequantize_mx8(q, s)
     assert np.array_equal(d, host.dequantize_mx8(qh, sh).numpy().astype(np.float64))
     assert np.array_equal(d, omx.fake_quant_torch(torch.from_numpy(x)).numpy().astype(np.float64))
-    assert np.all(np.abs(d[9, :32]) <= np.abs(x[9, :32]).max() * 1.0001), "nothing may be clipped or overshoot"
+    assert np.all(np.abs(d[9, :32] - x[9, :32]) <= np.abs(x[9, :32]).max() * 2.0 ** -4), "nothing may be clipped: round-to-nearest error only"
     # e4m3 grid facts the rule relies on
     t = omx.e4m3_decode_table()
     assert t[0x7e] == 448.0 and np.isnan(t[0x7f]) and t[0x01] == 2.0 ** -9 and t[0x08] == 2.0 ** -6
