@@ -41,6 +41,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6.3 TB/s achievable
 F32_MFMA_PEAK_TF = 157.3  # exact-f32 MFMA (= fp32 vector) peak, same guide
 BF16_MFMA_PEAK_TF = 2500.0  # dense bf16 MFMA peak, same guide
+MX8_MFMA_PEAK_TF = 5000.0   # dense MX-fp8 MFMA peak (v_mfma_scale_f32_*_f8f6f4), same guide
 SRC_FRAMES, N_SAMPLES = 1251, 160000
 
 
@@ -406,6 +407,28 @@ def main():
             aux["config5_dit_bf16_operands"] = dict(lowp, chunks=B, note="32 chunks x 100 DDPM steps, block GEMMs + attention on bf16 operands "
                                                     "(fp32 residual stream / LayerNorm / softmax / DDPM update); NOT the parity mode: eps within "
                                                     "5e-3 of scale and one p_sample step within 0.03 px of the fp32 reference golden")
+            # ---- BASELINE configs[4] "fp8 MFMA": the same denoiser batch with the block GEMMs on MX-fp8 operands
+            # (v_mfma_scale_f32_16x16x128_f8f6f4), and the T5 encoder + cross-K/V projection of the headline batch in the MX mode
+            fp8 = {}
+            for pname in ("DiT-S", "DiT-B"):
+                dd, hh, nn = DIT_PRESETS[pname]
+                d8 = DiTHIP(random_dit_state_dict(dd, hh, seed=0), dd, hh, nn, device=dev, operand_dtype="mx8")
+
+                def mx_stage():
+                    kw = dict(c=c, y=y, cfg_scale=1.0, attn_mask=BandMask(Tq, 128))
+                    return diff.p_sample_loop(d8.forward_with_cfg, z.shape, z, model_kwargs=kw, step_noise=torch.randn(100, *z.shape, device=dev))
+                dt8 = timed(mx_stage, 2)
+                fl = dit_flops_per_step(dd, hh, 2 * B, Tq) * 100
+                gemm_fl = 2 * B * (dd * 2.0 * Tq * 12 * hh * hh) * 100                    # the four block projections (the MX part)
+                fp8[pname] = {"ms_per_100_steps": round(dt8 * 1e3, 2), "steps_per_s_per_chunk": round(100 * B / dt8, 1),
+                              "tflops": round(fl / dt8 / 1e12, 1), "frac_of_mx8_mfma_peak": round(gemm_fl / dt8 / 1e12 / MX8_MFMA_PEAK_TF, 4),
+                              "vs_bf16_operands": round(lowp[pname]["ms_per_100_steps"] / (dt8 * 1e3), 3)}
+                del d8
+            aux["config5_fp8"] = {"dit": dict(fp8, chunks=B, note="32 chunks x 100 DDPM steps, the four block projections of every DiT block on MX-fp8 "
+                                              "operands (OCP e4m3 + E8M0 per 32 k; LayerNorm-modulate writes the operand, attention output and GELU "
+                                              "hidden quantised by a pass of their own), attention on bf16 operands; frac_of_mx8_mfma_peak = flops "
+                                              "of those projections / whole-loop time / 5 PFLOP/s; NOT a parity mode: error bounds in "
+                                              "tests/test_gpu_dit.py::test_mx8_operand_mode_error_bounds")}
         # configs[2] end to end: T5 path + diffusion refine of the same chunks, whole job
         aux["config3_end_to_end"] = {"chunks": world * B, "seconds": round(ms_per_step / 1e3 + dt_all, 4),
                                      "chunks_per_s": round(world * B / (ms_per_step / 1e3 + dt_all), 2),
@@ -591,6 +614,46 @@ def main():
             del mw, ew
         except Exception as e:   # an auxiliary figure must never cost the bench line
             print(f"whisper-family pass failed: {e!r}", file=sys.stderr)
+
+    # ---- BASELINE configs[4] "fp8 MFMA", T5 side: mel + encoder + cross-K/V of the headline batch with MX-fp8 operands ----
+    if not args.no_extras and not args.no_config5 and world == 1 and args.dtype == "bf16":
+        try:
+            enc_lines = {}
+            for sz in ("base", "large"):
+                dz = T5_PRESETS[sz]
+                per = {}
+                for mode in (None, "mx8"):
+                    mm = MapperatorinatorHIP(random_t5_state_dict(dz, tok.vocab_size_in, tok.vocab_size_out, seed=0, lm_head_gain=6.0), dz,
+                                             vocab_size_in=tok.vocab_size_in, vocab_size_out=tok.vocab_size_out, src_seq_len=SRC_FRAMES,
+                                             tgt_seq_len=tgt_len, dtype=torch.bfloat16, device=dev, enc_operand_dtype=mode)
+                    em = mm.engine
+
+                    def enc_step():
+                        em._enter()
+                        with torch.cuda.stream(em.stream):
+                            kv_ = em.cross_kv(em.encode_mel(em.mel(audio)))
+                        em._leave()
+                        return kv_
+                    enc_step()
+                    torch.cuda.synchronize(dev)
+                    t0 = time.perf_counter()
+                    for _ in range(5):
+                        enc_step()
+                    torch.cuda.synchronize(dev)
+                    per[mode or "bf16"] = (time.perf_counter() - t0) / 5
+                    del mm, em
+                Lr = B * SRC_FRAMES
+                gemm_fl = 2.0 * Lr * (dz.n_enc_layers * (4 * dz.d_model * dz.inner + 3 * dz.d_model * dz.d_ff) + dz.n_dec_layers * 2 * dz.inner * dz.d_model)
+                enc_lines[sz] = {"bf16_ms": round(per["bf16"] * 1e3, 2), "mx8_ms": round(per["mx8"] * 1e3, 2), "speedup": round(per["bf16"] / per["mx8"], 3),
+                                 "projection_tflops_mx8": round(gemm_fl / per["mx8"] / 1e12, 1),
+                                 "frac_of_mx8_mfma_peak": round(gemm_fl / per["mx8"] / 1e12 / MX8_MFMA_PEAK_TF, 4)}
+            aux.setdefault("config5_fp8", {})["t5_encoder"] = dict(
+                enc_lines, chunks=B, note="mel + encoder + cross-K/V projection of 32 chunks; mx8 = MhT5Config.enc_operand_dtype MH_MX8 (block "
+                "projections + cross-K/V projection on MX-fp8 operands, attention bf16); frac = flops of those projections / whole-stage time "
+                "(mel, attention, norms and quantiser passes included) / 5 PFLOP/s; NOT a parity mode: teacher-forced agreement against the fp32 "
+                "reference goldens in tests/test_gpu_t5.py::test_mx8_encoder_teacher_forced_on_the_reference_fp32_run")
+        except Exception as e:   # an auxiliary figure must never cost the bench line
+            print(f"config 5 fp8 encoder pass failed: {e!r}", file=sys.stderr)
 
     # ---- BASELINE configs[4]: whole 3-minute songs, KV-cached, through the window scheduler (tools/long_song_bench.py) ----
     if not args.no_extras and not args.no_config5 and world == 1:

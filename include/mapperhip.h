@@ -470,7 +470,10 @@ typedef struct MhDiTConfig {
   int t_freq_dim;    /* TimestepEmbedder frequency_embedding_size = 256                  */
   int first_k_pad;   /* padded K of the first layer GEMM (in_channels*freq_dim+context)  */
   int class_pad;     /* padded K of y_embedder[0]                                        */
-  int operand_dtype; /* MH_F32 (reference semantics) or MH_BF16 (block GEMM operands, see above) */
+  int operand_dtype; /* MH_F32 (reference semantics), MH_BF16 (block GEMM operands, see above) or -- ABI 7, BASELINE configs[4]
+                        "fp8 MFMA" -- MH_MX8: the four block projections on MX-fp8 operands (LayerNorm-modulate writes the operand
+                        directly; attention output and GELU hidden are bf16 as in the MH_BF16 mode and quantised by a pass of their
+                        own; attention itself on bf16 operands); hidden %% 128 == 0.  Error-bound gates, as MH_BF16. */
 } MhDiTConfig;
 
 typedef struct MhDiTWeights {       /* all fp32, matrices [N][Kpad]                                  */
@@ -494,6 +497,12 @@ typedef struct MhDiTWeights {       /* all fp32, matrices [N][Kpad]             
   /* bf16 copies [N][K] of the four block projections; required when operand_dtype = MH_BF16 */
   const void* qkv_wb[MH_MAX_LAYERS]; const void* out_wb[MH_MAX_LAYERS];
   const void* fc1_wb[MH_MAX_LAYERS]; const void* fc2_wb[MH_MAX_LAYERS];
+  /* (ABI 7) MX-fp8 copies of the four block projections (mh_quantize_mx8 layout: e4m3 [N][K] | scales [N][mh_mx8_scale_row_bytes(K)]);
+   * required when operand_dtype = MH_MX8 */
+  const uint8_t* qkv_wm[MH_MAX_LAYERS]; const uint8_t* qkv_wms[MH_MAX_LAYERS];
+  const uint8_t* out_wm[MH_MAX_LAYERS]; const uint8_t* out_wms[MH_MAX_LAYERS];
+  const uint8_t* fc1_wm[MH_MAX_LAYERS]; const uint8_t* fc1_wms[MH_MAX_LAYERS];
+  const uint8_t* fc2_wm[MH_MAX_LAYERS]; const uint8_t* fc2_wms[MH_MAX_LAYERS];
 } MhDiTWeights;
 
 int64_t mh_dit_workspace_bytes(const MhDiTConfig* cfg, int N, int T);

@@ -91,7 +91,10 @@ class MhDiTWeights(C.Structure):
                 ("fc2_w", _PTR_ARR), ("fc2_b", _PTR_ARR), ("fin_ada_w", VP), ("fin_ada_b", VP),
                 ("fin_w", VP), ("fin_b", VP),
                 ("first_w3", VP), ("qkv_w3", _PTR_ARR), ("out_w3", _PTR_ARR), ("fc1_w3", _PTR_ARR), ("fc2_w3", _PTR_ARR),
-                ("qkv_wb", _PTR_ARR), ("out_wb", _PTR_ARR), ("fc1_wb", _PTR_ARR), ("fc2_wb", _PTR_ARR)]
+                ("qkv_wb", _PTR_ARR), ("out_wb", _PTR_ARR), ("fc1_wb", _PTR_ARR), ("fc2_wb", _PTR_ARR),
+                # ABI 7: MX-fp8 copies (elements, scales) of the block projections
+                ("qkv_wm", _PTR_ARR), ("qkv_wms", _PTR_ARR), ("out_wm", _PTR_ARR), ("out_wms", _PTR_ARR),
+                ("fc1_wm", _PTR_ARR), ("fc1_wms", _PTR_ARR), ("fc2_wm", _PTR_ARR), ("fc2_wms", _PTR_ARR)]
 
 
 class MhSliderSet(C.Structure):

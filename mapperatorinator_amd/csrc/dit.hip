@@ -237,8 +237,9 @@ int check_dit(const MhDiTConfig* c, int N, int T) {
   MH_REQUIRE(c->first_k_pad % 32 == 0 && c->first_k_pad >= 2 * c->freq_dim + c->context_size, "dit: bad first_k_pad");
   MH_REQUIRE(c->class_pad >= c->class_size, "dit: bad class_pad");
   MH_REQUIRE(N >= 2 && N % 2 == 0 && T > 0, "dit: N must be even (CFG batch) and T > 0");
-  MH_REQUIRE(c->operand_dtype == MH_F32 || c->operand_dtype == MH_BF16, "dit: operand_dtype must be MH_F32 or MH_BF16");
+  MH_REQUIRE(c->operand_dtype == MH_F32 || c->operand_dtype == MH_BF16 || c->operand_dtype == MH_MX8, "dit: operand_dtype must be MH_F32, MH_BF16 or MH_MX8");
   MH_REQUIRE(c->operand_dtype == MH_F32 || c->hidden % 8 == 0, "dit: bf16 operands need hidden %% 8 == 0");
+  MH_REQUIRE(c->operand_dtype != MH_MX8 || c->hidden % 128 == 0, "dit: MX-fp8 operands need hidden %% 128 == 0");
   return MH_OK;
 }
 
@@ -347,11 +348,47 @@ int dit_body(const MhDiTConfig* c, const MhDiTWeights* w, const float* x, const 
     g.epilogue = MH_EPI_GATE_RESID;
     MH_TRY(gemm(g, s));
   }
+  // MX-fp8 operands (BASELINE configs[4] "fp8 MFMA"): the block GEMMs on v_mfma_scale_f32_16x16x128_f8f6f4; LayerNorm-modulate
+  // writes its output as the MX operand directly, the attention output and the GELU hidden (bf16, as in the bf16-operand mode)
+  // are quantised by a pass of their own.  The MX copies live in the unused upper halves of the fp32-sized activation buffers.
+  const bool lowp8 = c->operand_dtype == MH_MX8;
+  for (int l = 0; l < c->depth && lowp8; ++l) {
+    MH_REQUIRE(w->qkv_wm[l] && w->qkv_wms[l] && w->out_wm[l] && w->out_wms[l] && w->fc1_wm[l] && w->fc1_wms[l] && w->fc2_wm[l] && w->fc2_wms[l],
+               "dit: operand_dtype = MH_MX8 needs the MX-fp8 weight copies (layer %d)", l);
+    const float* mod = b.cond_cur + (long)l * 6 * D;
+    uint8_t* xq = reinterpret_cast<uint8_t*>(b.xm);                    uint8_t* xqs = xq + (long)NT * D;            // [NT][D] | scales
+    uint8_t* aq = reinterpret_cast<uint8_t*>(b.attn) + (long)NT * D * 2;  uint8_t* aqs = aq + (long)NT * D;         // behind the bf16 attention output
+    uint8_t* hq = reinterpret_cast<uint8_t*>(b.hid) + (long)NT * 4 * D * 2; uint8_t* hqs = hq + (long)NT * 4 * D;  // behind the bf16 hidden
+    MH_TRY(ln_modulate_mx8(b.xs, D, mod + 0 * D, mod + 1 * D, ld_row, T, NT, D, 1e-6f, xq, D, xqs, s));
+    g = MhGemm{};
+    g.A = xq; g.lda = D; g.a_scale = xqs; g.W = w->qkv_wm[l]; g.ldw = D; g.w_scale = w->qkv_wms[l]; g.C = b.qk; g.ldc = 2 * D; g.M = NT; g.N = 3 * D; g.K = D;
+    g.bias = w->qkv_b[l]; g.dtype = MH_MX8; g.epilogue = MH_EPI_QKV_VT; g.C2 = b.vt; g.n_split = 2 * D; g.kv_B = N;
+    g.kv_H = H; g.kv_L = T; g.kv_Lpad = b.Tpad;
+    MH_TRY(gemm(g, s));
+    MH_TRY(attention(b.qk, 2 * D, D, b.vt, b.Tpad, nullptr, b.attn, D, N, T, H, 0.125f, band, MH_BF16, s, open_from));
+    MH_TRY(quantize_mx8(b.attn, D, NT, D, MH_BF16, aq, D, aqs, s));
+    g = MhGemm{};
+    g.A = aq; g.lda = D; g.a_scale = aqs; g.W = w->out_wm[l]; g.ldw = D; g.w_scale = w->out_wms[l]; g.C = b.xs; g.ldc = D; g.M = NT; g.N = D; g.K = D;
+    g.bias = w->out_b[l]; g.gate = mod + 2 * D; g.gate_ld = ld_row; g.rows_per_batch = T; g.dtype = MH_MX8;
+    g.epilogue = MH_EPI_GATE_RESID;
+    MH_TRY(gemm(g, s));
+    MH_TRY(ln_modulate_mx8(b.xs, D, mod + 3 * D, mod + 4 * D, ld_row, T, NT, D, 1e-6f, xq, D, xqs, s));
+    g = MhGemm{};
+    g.A = xq; g.lda = D; g.a_scale = xqs; g.W = w->fc1_wm[l]; g.ldw = D; g.w_scale = w->fc1_wms[l]; g.C = b.hid; g.ldc = 4 * D; g.M = NT; g.N = 4 * D; g.K = D;
+    g.bias = w->fc1_b[l]; g.dtype = MH_MX8; g.epilogue = MH_EPI_BIAS_GELU;
+    MH_TRY(gemm(g, s));
+    MH_TRY(quantize_mx8(b.hid, 4 * D, NT, 4 * D, MH_BF16, hq, 4 * D, hqs, s));
+    g = MhGemm{};
+    g.A = hq; g.lda = 4 * D; g.a_scale = hqs; g.W = w->fc2_wm[l]; g.ldw = 4 * D; g.w_scale = w->fc2_wms[l]; g.C = b.xs; g.ldc = D; g.M = NT; g.N = D; g.K = 4 * D;
+    g.bias = w->fc2_b[l]; g.gate = mod + 5 * D; g.gate_ld = ld_row; g.rows_per_batch = T; g.dtype = MH_MX8;
+    g.epilogue = MH_EPI_GATE_RESID;
+    MH_TRY(gemm(g, s));
+  }
   // fp32 semantics, big batches: the bf16 x 3 GEMMs with BOTH operands pre-split (gemm_s3g_kernel: three-stage LDS-DMA,
   // no conversion work inside the GEMM) -- LayerNorm-modulate, the attention and the GELU epilogue write their outputs as
   // [32 x bf16 hi | 32 x bf16 lo] per 32 values straight away (the same bytes as fp32, the same buffers).  Option
   // dit_s3_presplit = 0: the 64 x 64 kernel that splits A while staging it.
-  const bool s3g = !lowp && s3 && option(OPT_DIT_S3_PRESPLIT) != 0 && D % 32 == 0;
+  const bool s3g = !lowp && !lowp8 && s3 && option(OPT_DIT_S3_PRESPLIT) != 0 && D % 32 == 0;
   for (int l = 0; l < c->depth && s3g; ++l) {
     const float* mod = b.cond_cur + (long)l * 6 * D;
     MH_TRY(ln_modulate(b.xs, D, mod + 0 * D, mod + 1 * D, ld_row, T, b.xm, D, NT, D, 1e-6f, MH_LN_SPLIT3, s));
@@ -377,7 +414,7 @@ int dit_body(const MhDiTConfig* c, const MhDiTWeights* w, const float* x, const 
     g.epilogue = MH_EPI_GATE_RESID; g.w_split3 = 3;
     MH_TRY(gemm(g, s));
   }
-  for (int l = 0; l < c->depth && !lowp && !s3g; ++l) {
+  for (int l = 0; l < c->depth && !lowp && !lowp8 && !s3g; ++l) {
     const float* mod = b.cond_cur + (long)l * 6 * D;
     // attention branch
     g = MhGemm{};

@@ -37,9 +37,12 @@ class DiTHIP:
             raise RuntimeError("DiTHIP needs a ROCm GPU; there is no CPU fallback")
         if hidden != num_heads * 64:
             raise NotImplementedError("HIP attention kernels are built for head_dim = 64")
-        if operand_dtype not in (torch.float32, torch.bfloat16):
-            raise ValueError("operand_dtype: torch.float32 (the reference's semantics) or torch.bfloat16 (block GEMM operands "
-                             "rounded to bf16, fp32 accumulation / residual stream / LayerNorm / softmax / DDPM update)")
+        if operand_dtype not in (torch.float32, torch.bfloat16, "mx8"):
+            raise ValueError("operand_dtype: torch.float32 (the reference's semantics), torch.bfloat16 (block GEMM operands "
+                             "rounded to bf16, fp32 accumulation / residual stream / LayerNorm / softmax / DDPM update) or 'mx8' "
+                             "(BASELINE configs[4]: the four block projections on MX-fp8 operands, the rest as the bf16 mode)")
+        if operand_dtype == "mx8" and hidden % 128:
+            raise ValueError("MX-fp8 operands need hidden % 128 == 0")
         self.lib = _lib.load()
         self.device = torch.device(device)
         self.operand_dtype = operand_dtype
@@ -79,9 +82,16 @@ class DiTHIP:
             self._keep.append(x)
             return x.data_ptr()
 
+        def tm(x):
+            from .mx8 import quantize_mx8
+            q, sc = quantize_mx8(x.detach().to(torch.float32).to(torch.bfloat16).to(torch.float32).to(dev))   # the bf16 mode's weights, quantised
+            self._keep += [q, sc]
+            return q.data_ptr(), sc.data_ptr()
+
         lowp = operand_dtype == torch.bfloat16
+        mx = isinstance(operand_dtype, str) and operand_dtype == "mx8"
         cfg = _lib.MhDiTConfig(hidden, depth, num_heads, context_size, class_size, 2, 128, 256, _round_up(k1, 32),
-                               class_size, _lib.MH_BF16 if lowp else _lib.MH_F32)
+                               class_size, _lib.MH_MX8 if mx else (_lib.MH_BF16 if lowp else _lib.MH_F32))
         w = _lib.MhDiTWeights()
         # frequency tables with the same fp32 tensor ops as timestep_embedding (positional_embedding.py:38-43)
         w.pos_freqs = t(torch.exp(-math.log(10000) * torch.arange(0, 64, dtype=torch.float32) / 64))
@@ -105,6 +115,11 @@ class DiTHIP:
             if lowp:
                 w.qkv_wb[l], w.out_wb[l] = tb(sd[b + "attn.in_proj_weight"]), tb(sd[b + "attn.out_proj.weight"])
                 w.fc1_wb[l], w.fc2_wb[l] = tb(sd[b + "mlp.fc1.weight"]), tb(sd[b + "mlp.fc2.weight"])
+            if mx:
+                w.qkv_wm[l], w.qkv_wms[l] = tm(sd[b + "attn.in_proj_weight"])
+                w.out_wm[l], w.out_wms[l] = tm(sd[b + "attn.out_proj.weight"])
+                w.fc1_wm[l], w.fc1_wms[l] = tm(sd[b + "mlp.fc1.weight"])
+                w.fc2_wm[l], w.fc2_wms[l] = tm(sd[b + "mlp.fc2.weight"])
         w.fin_ada_w, w.fin_ada_b = t(sd["final_layer.adaLN_modulation.1.weight"]), t(sd["final_layer.adaLN_modulation.1.bias"])
         w.fin_w, w.fin_b = t(sd["final_layer.linear.weight"]), t(sd["final_layer.linear.bias"])
         self.cfg, self.w = cfg, w

@@ -35,17 +35,29 @@ class DiTOracle:
     """`rounding="bf16"` restates the device's reduced-precision mode (MhDiTConfig.operand_dtype = MH_BF16, BASELINE
     configs[4]) -- NOT a reference mode: the weights of the four block projections and every activation that becomes their
     (or the attention's) MFMA operand are rounded to bf16 (LayerNorm-modulate output; q, k, v; the softmax probabilities;
-    the attention output; the GELU hidden); accumulation and everything else stays fp32."""
+    the attention output; the GELU hidden); accumulation and everything else stays fp32.
+    `rounding="mx8"` (MhDiTConfig.operand_dtype = MH_MX8, "fp8 MFMA"): as "bf16", and the four block projections multiply the
+    MX-fp8 images (oracle/mx8.py) of their operands -- the LayerNorm-modulate output is quantised from fp32 (the device's
+    producer writes the MX operand directly), attention output and GELU hidden from their bf16 values, the weights from their
+    bf16 copies."""
 
     def __init__(self, sd: dict, depth: int, hidden: int, num_heads: int, rounding=None):
         self.sd = {k: v.detach().float() for k, v in sd.items()}
         self.depth, self.D, self.H = depth, hidden, num_heads
-        assert rounding in (None, "bf16")
-        self.r = (lambda a: a.to(torch.bfloat16).to(torch.float32)) if rounding == "bf16" else (lambda a: a)
-        if rounding == "bf16":
+        assert rounding in (None, "bf16", "mx8")
+        self.r = (lambda a: a.to(torch.bfloat16).to(torch.float32)) if rounding in ("bf16", "mx8") else (lambda a: a)
+        self.mx = rounding == "mx8"
+        if self.mx:
+            from .mx8 import fake_quant_torch
+            self.fq = fake_quant_torch
+        else:
+            self.fq = lambda a: a
+        # (activation entering a block projection, already bf16-rounded or not) -> the operand the GEMM multiplies
+        self.ra = (lambda a: self.fq(a)) if self.mx else self.r
+        if rounding in ("bf16", "mx8"):
             for l in range(depth):
                 for n in ("attn.in_proj_weight", "attn.out_proj.weight", "mlp.fc1.weight", "mlp.fc2.weight"):
-                    self.sd[f"blocks.{l}.{n}"] = self.r(self.sd[f"blocks.{l}.{n}"])
+                    self.sd[f"blocks.{l}.{n}"] = self.fq(self.r(self.sd[f"blocks.{l}.{n}"]))
 
     def _lin(self, x, name):
         return x @ self.sd[name + ".weight"].t() + self.sd[name + ".bias"]
@@ -54,7 +66,7 @@ class DiTOracle:
         sd, D, H = self.sd, self.D, self.H
         N, T, _ = x.shape
         r = self.r
-        qkv = r(r(x) @ sd[f"blocks.{l}.attn.in_proj_weight"].t() + sd[f"blocks.{l}.attn.in_proj_bias"])
+        qkv = r(self.ra(x) @ sd[f"blocks.{l}.attn.in_proj_weight"].t() + sd[f"blocks.{l}.attn.in_proj_bias"])
         q, k, v = qkv.split(D, dim=-1)
         sh = lambda a: a.view(N, T, H, D // H).transpose(1, 2)
         s = torch.matmul(sh(q), sh(k).transpose(-1, -2)) * (1.0 / math.sqrt(D // H))
@@ -63,7 +75,7 @@ class DiTOracle:
         # (the flash kernel rounds the un-normalised exp(s - running max) and divides by the fp32 sum of the unrounded
         # values; rounding the normalised probabilities instead differs by bf16 rounding noise only)
         o = torch.matmul(r(torch.softmax(s, -1)), sh(v)).transpose(1, 2).reshape(N, T, D)
-        return self._lin(r(o), f"blocks.{l}.attn.out_proj")
+        return self._lin(self.fq(r(o)), f"blocks.{l}.attn.out_proj")
 
     def forward(self, x, t, c, y, attn_mask=None):
         sd = self.sd
@@ -81,8 +93,8 @@ class DiTOracle:
             m = layer_norm(h) * (1 + sc1[:, None]) + sh1[:, None]
             h = h + g1[:, None] * self._mha(m, l, attn_mask)
             m = layer_norm(h) * (1 + sc2[:, None]) + sh2[:, None]
-            u = F.gelu(self._lin(self.r(m), f"blocks.{l}.mlp.fc1"), approximate="tanh")
-            h = h + g2[:, None] * self._lin(self.r(u), f"blocks.{l}.mlp.fc2")
+            u = F.gelu(self._lin(self.ra(m), f"blocks.{l}.mlp.fc1"), approximate="tanh")
+            h = h + g2[:, None] * self._lin(self.fq(self.r(u)), f"blocks.{l}.mlp.fc2")
         shf, scf = self._lin(F.silu(b), "final_layer.adaLN_modulation.1").chunk(2, dim=1)
         out = self._lin(layer_norm(h) * (1 + scf[:, None]) + shf[:, None], "final_layer.linear")
         return out.transpose(1, 2)

@@ -50,7 +50,7 @@ def test_struct_layouts_match_header_sizes():
     base = 4 * 8 + 16 * 4 + 3 * 4 + 4 + 8                                # 4B pad before the uint64 seed
     assert C.sizeof(_lib.MhSampling) == base + 9 * 4 + 4 + 8 + 2 * 4 + 8   # ABI 2 tail: 9 words, pad, tok_flags; ABI 3: 2 words; ABI 4: cross_kv_fp8
     assert C.sizeof(_lib.MhT5Weights) == 8 * (5 + 6 * 32 + 1 + 5 * 32 + 1 + 4 * 32 + 2) + 8 * (4 + 4 * 32 + 3 * 32 + 1 + 3 * 32 + 4) + 8 * (8 * 32 + 2)   # + ABI 5 (arch 1) + ABI 7 (MX-fp8 copies)
-    assert C.sizeof(_lib.MhDiTWeights) == 8 * (12 + 10 * 32 + 4 + 1 + 4 * 32 + 4 * 32)   # + the pre-split (bf16 x 3) and the bf16 copies
+    assert C.sizeof(_lib.MhDiTWeights) == 8 * (12 + 10 * 32 + 4 + 1 + 4 * 32 + 4 * 32 + 8 * 32)   # + the pre-split (bf16 x 3), the bf16 and (ABI 7) the MX-fp8 copies
 
 
 def test_no_cpu_fallback():
