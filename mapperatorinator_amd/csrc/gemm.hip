@@ -1114,28 +1114,36 @@ __global__ __launch_bounds__(512) void gemm_s3g_kernel(GemmP p) {
 // BASELINE configs[4] ("fp8 MFMA").  The three-stage LDS-DMA structure of gemm_glds3_kernel with the K step re-read: a
 // 128-byte row of a stage is 128 e4m3 values = ONE MFMA k (the bf16 form needs two 16x16x32 MFMAs per 64 values), so a K
 // step moves the same bytes through HBM / L2 / LDS as the bf16 kernel and multiplies twice the k range in the same matrix-core
-// time (16 MFMAs x 32 cycles per wave and step) -- the MX rate is 2x the bf16 rate at equal operand bytes per step.
+// time (32 cycles per MFMA) -- the MX rate is 2x the bf16 rate at equal operand bytes per step.
 //   operand layout (measured, tools/micro/mfma_mx_probe*.hip): lane (row = l & 15, lg = l >> 4) holds bytes [lg*16, +16) and
 //   [64 + lg*16, +16) of its row's 128-byte k step; the scale register's byte OP_SEL of that lane scales k block lg (32
 //   consecutive k) of the row -- for both operands.  Swizzled stage rows as in the bf16 kernels: 16-byte chunk c of tile
 //   row r sits at chunk c ^ (r & 7), so a fragment is two conflict-free ds_read_b128.
 //   scales: [rows][16 * ceil(K / 512)] bytes, byte (kt / 4) * 16 + lg * 4 + (kt % 4) = E8M0 of k block kt * 4 + lg (kt = K step):
-//   a lane fetches ONE dword per row block and four K steps and selects the step's byte with OP_SEL (0..3) -- 8 dword loads
-//   per wave and four steps, issued a group ahead by inline asm and covered by the counted vmcnt waits of the DMA pipeline.
-//   two phases per K step: A = DMA of step kt + 2, reads of (stage kt: W blocks 2, 3), MFMAs of W blocks 0, 1 | wait, barrier;
-//   B = reads of (stage kt + 1: A blocks 0..MI-1 into the other register set, W blocks 0, 1), MFMAs of W blocks 2, 3.
-// Transposed product and epilogue as gemm_glds3_kernel (bf16 outputs / fp32 residual stream).  OPSEL = false: the scale byte
-// is shifted into place (v_lshrrev) and OP_SEL stays 0 -- the A/B form of the same arithmetic.
+//   a lane fetches ONE dword per row block and four K steps and selects the step's byte with OP_SEL (0..3) -- MI + 4 dword
+//   loads per wave and four steps, issued a group ahead by inline asm and covered by the counted vmcnt waits of the DMA pipeline.
+// Two geometries of one kernel (NW waves as NW/2 (M) x 2 (N), wave tile 16 MI x 64):
+//   NW = 4, MI = 8: 256 x 128 tile, FOUR waves of 128 x 64 -- one wave per SIMD, so a wave may hold 512 registers: 128
+//     accumulators (AGPRs) beside 128 fragment registers.  24 fragment reads feed 32 MFMAs per K step (0.75 per MFMA; the
+//     64 x 64 wave tile of the bf16 kernel needs 1.0, a 32 x 64 tile 1.5).  Eight waves of 64 x 64 do not fit: with 256
+//     registers per wave hipcc spilled asm-loaded fragments (tools/check_kernel_resources.py fails the build on that).
+//   NW = 8, MI = 2: 128 x 128 tile for grids that would leave CUs idle at 256 rows per tile.
+// Two phases per K step, split by A row blocks so that the A fragments need ONE register set:
+//   phase 1: DMA of step kt + 2 (+ the next scale group every fourth step) | reads of (stage kt: A blocks MI/2 ..) | MFMAs of A
+//            blocks 0 .. MI/2 - 1 with all four W blocks | wait (stage kt + 1 landed, every read of stage kt retired), barrier
+//   phase 2: reads of (stage kt + 1: A blocks 0 .. MI/2 - 1, the four W blocks into the OTHER W set) | MFMAs of A blocks MI/2 ..
+// Transposed product and epilogue as gemm_glds3_kernel (bf16 outputs / fp32 residual stream).
 typedef __attribute__((ext_vector_type(8))) int i32x8_t;
 typedef __attribute__((ext_vector_type(4))) int i32x4_t;
 
-template <int EPI, int MI, bool OPSEL>
-__global__ __launch_bounds__(512) void gemm_mx8_kernel(GemmP p) {
-  constexpr int BM = 64 * MI, BN = 128, NST = 3;
+template <int EPI, int MI, int NW>
+__global__ __launch_bounds__(NW * 64) void gemm_mx8_kernel(GemmP p) {
+  constexpr int BM = 16 * MI * (NW / 2), BN = 128, NST = 3;
   constexpr int kRowStride = 128, kStage = (BM + BN) * kRowStride;
-  constexpr int WM = 16 * MI, WN = 64, NI = 4;
-  constexpr int NA = MI;                     // A-tile DMA instructions per wave and stage
-  constexpr int NDMA = NA + 2, NSC = MI + NI;
+  constexpr int WM = 16 * MI, WN = 64, NI = 4, MH_ = MI / 2;
+  constexpr int NA = BM / 8 / NW, NB = BN / 8 / NW;      // DMA instructions per wave and stage (8 rows x 128 bytes each)
+  constexpr int NDMA = NA + NB, NSC = MI + NI;
+  static_assert(MI % 2 == 0 && NSC <= 12 && 2 * MH_ + 2 * NI <= 28, "operand lists of the wait statements");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wr = wid >> 1, wc = wid & 1;
@@ -1169,12 +1177,12 @@ __global__ __launch_bounds__(512) void gemm_mx8_kernel(GemmP p) {
     const long k_off = (long)(((lane & 7) ^ r8) * 16);                // pre-swizzled source chunk (tile row & 7 == r8)
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      int ra_ = m0 + (i * 8 + wid) * 8 + r8; ra_ = ra_ < p.M ? ra_ : p.M - 1;
+      int ra_ = m0 + (i * NW + wid) * 8 + r8; ra_ = ra_ < p.M ? ra_ : p.M - 1;
       srcp[i] = p.A + (long)ra_ * p.lda_b + k_off;
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      int rb_ = n0 + (i * 8 + wid) * 8 + r8; rb_ = rb_ < p.N ? rb_ : p.N - 1;
+    for (int i = 0; i < NB; ++i) {
+      int rb_ = n0 + (i * NW + wid) * 8 + r8; rb_ = rb_ < p.N ? rb_ : p.N - 1;
       srcp[NA + i] = p.W + (long)rb_ * p.ldw_b + k_off;
     }
   }
@@ -1182,12 +1190,12 @@ __global__ __launch_bounds__(512) void gemm_mx8_kernel(GemmP p) {
     char* base = smem + st * kStage;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      __builtin_amdgcn_global_load_lds((gptr_t)srcp[i], (lptr_t)(base + (i * 8 + wid) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)srcp[i], (lptr_t)(base + (i * NW + wid) * 1024), 16, 0, 0);
       srcp[i] += 128;
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      __builtin_amdgcn_global_load_lds((gptr_t)srcp[NA + i], (lptr_t)(base + BM * kRowStride + (i * 8 + wid) * 1024), 16, 0, 0);
+    for (int i = 0; i < NB; ++i) {
+      __builtin_amdgcn_global_load_lds((gptr_t)srcp[NA + i], (lptr_t)(base + BM * kRowStride + (i * NW + wid) * 1024), 16, 0, 0);
       srcp[NA + i] += 128;
     }
   };
@@ -1224,26 +1232,42 @@ __global__ __launch_bounds__(512) void gemm_mx8_kernel(GemmP p) {
 #pragma unroll
     for (int i = 0; i < MI; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  // Waits are inline asm that NAME the registers they make valid as in/out operands: the asm-issued loads look complete to
-  // hipcc the moment they are issued, so without that dependence an MFMA (a pure register operation) may be placed above the
-  // wait that its operands need -- sched_barrier pins the scheduler only, not the IR passes that run before it.
-  i32x4_t alo[2][MI], ahi[2][MI], blo[NI], bhi[NI];
+  // Every fragment read, every wait and every MFMA of the K loop is a VOLATILE asm statement: hipcc keeps volatile asm
+  // statements in program order, so an MFMA can never be placed above the wait its operands need (the builtin form could:
+  // a pure register operation, and the asm-issued loads look complete to hipcc the moment they are issued).  What remains
+  // for the compiler is register assignment: the two 16-byte halves of a fragment are joined into the MFMA's 8-register
+  // operand by a shufflevector, which must coalesce to NOTHING (the ds_reads write straight into the halves of the tuple) --
+  // a copy could be scheduled above the wait.  Checked in the ISA of this build (the K loop holds no move of a fragment
+  // register, only the scale dwords move); the guards that run on every build are tools/check_kernel_resources.py (no scratch,
+  // no spills) and the EXACT product tests of tests/test_gpu_mx8.py over every K-tail case -- a stale fragment is a wrong integer.
+  i32x4_t alo_[MI], ahi_[MI], blo_[2][NI], bhi_[2][NI];
 #define MX_DEP4(x) "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3])
-#define MX_DEP2(x) "+v"(x[0]), "+v"(x[1])
   auto wait_scales = [&](int (&v)[NSC]) {      // (no instruction: the vmcnt wait that covers them stands next to it)
-    if constexpr (MI == 4) asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+    if constexpr (NSC == 12) asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]));
     else asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]));
+    static_assert(NSC == 12 || NSC == 6, "scale register lists");
   };
-#define MX_WAIT(str) do { asm volatile(str ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+  // vmcnt immediates: what may stay in flight behind the stage that must have landed
+#define MX_STR2(x) #x
+#define MX_STR(x) MX_STR2(x)
+  auto wait_vm = [&](auto n_c) {               // s_waitcnt vmcnt(N), N in {0, NDMA, NDMA + NSC}
+    constexpr int N_ = decltype(n_c)::value;
+    if constexpr (N_ == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N_ == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N_ == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else if constexpr (N_ == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if constexpr (N_ == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    else static_assert(N_ < 0, "vmcnt immediate not listed");
+  };
   load_scales(scur);
   issue(0);
   if (nk > 1) {
     issue(1);
-    if constexpr (MI == 4) MX_WAIT("s_waitcnt vmcnt(6)");    // scales and stage 0 of this wave have landed, stage 1 may still fly
-    else MX_WAIT("s_waitcnt vmcnt(4)");
+    wait_vm(std::integral_constant<int, NDMA>{});      // scales and stage 0 of this wave have landed, stage 1 may still fly
   } else {
-    MX_WAIT("s_waitcnt vmcnt(0)");
+    wait_vm(std::integral_constant<int, 0>{});
   }
+  __builtin_amdgcn_sched_barrier(0);
   wait_scales(scur);
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
@@ -1252,140 +1276,143 @@ __global__ __launch_bounds__(512) void gemm_mx8_kernel(GemmP p) {
   const uint32_t a_off = (uint32_t)((wr * WM + frow) * kRowStride), b_off = (uint32_t)((BM + wc * WN + frow) * kRowStride);
   const uint32_t c_lo = (uint32_t)((lgc ^ sw) * 16), c_hi = (uint32_t)(((4 + lgc) ^ sw) * 16);
   // row block q of a 16-row-block column sits q * 2048 bytes further (16 rows x 128 bytes)
-#define MX_RD(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=v"(dst) : "v"(addr))
-  auto ld_a = [&](int st, i32x4_t (&lo)[MI], i32x4_t (&hi)[MI]) {
+#define MX_RD(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF))
+  auto ld_a_half = [&](int st, auto half_c) {            // A row blocks half * MI/2 .. of stage st
+    constexpr int H0 = decltype(half_c)::value * MH_;
+    auto& alo = alo_; auto& ahi = ahi_;        // (named in a plain expression: a generic lambda does not capture a variable that only an asm operand uses)
     const uint32_t pl = lds0 + st * kStage + a_off + c_lo, ph = lds0 + st * kStage + a_off + c_hi;
-    MX_RD(lo[0], pl, 0); MX_RD(hi[0], ph, 0);
-    MX_RD(lo[1], pl, 2048); MX_RD(hi[1], ph, 2048);
-    if constexpr (MI == 4) {
-      MX_RD(lo[2], pl, 4096); MX_RD(hi[2], ph, 4096);
-      MX_RD(lo[3], pl, 6144); MX_RD(hi[3], ph, 6144);
+#pragma unroll
+    for (int q = 0; q < MH_; ++q) {
+      if constexpr (MH_ >= 1) { if (q == 0) { MX_RD(alo[H0 + 0], pl, (H0 + 0) * 2048); MX_RD(ahi[H0 + 0], ph, (H0 + 0) * 2048); } }
+      if constexpr (MH_ >= 2) { if (q == 1) { MX_RD(alo[H0 + 1], pl, (H0 + 1) * 2048); MX_RD(ahi[H0 + 1], ph, (H0 + 1) * 2048); } }
+      if constexpr (MH_ >= 4) { if (q == 2) { MX_RD(alo[H0 + 2], pl, (H0 + 2) * 2048); MX_RD(ahi[H0 + 2], ph, (H0 + 2) * 2048); } }
+      if constexpr (MH_ >= 4) { if (q == 3) { MX_RD(alo[H0 + 3], pl, (H0 + 3) * 2048); MX_RD(ahi[H0 + 3], ph, (H0 + 3) * 2048); } }
     }
   };
-  auto ld_b01 = [&](int st) {
+  auto ld_b = [&](int st, auto set_c) {
+    constexpr int S = decltype(set_c)::value;
+    auto& blo = blo_; auto& bhi = bhi_;
     const uint32_t pl = lds0 + st * kStage + b_off + c_lo, ph = lds0 + st * kStage + b_off + c_hi;
-    MX_RD(blo[0], pl, 0); MX_RD(bhi[0], ph, 0);
-    MX_RD(blo[1], pl, 2048); MX_RD(bhi[1], ph, 2048);
-  };
-  auto ld_b23 = [&](int st) {
-    const uint32_t pl = lds0 + st * kStage + b_off + c_lo, ph = lds0 + st * kStage + b_off + c_hi;
-    MX_RD(blo[2], pl, 4096); MX_RD(bhi[2], ph, 4096);
-    MX_RD(blo[3], pl, 6144); MX_RD(bhi[3], ph, 6144);
+    MX_RD(blo[S][0], pl, 0); MX_RD(bhi[S][0], ph, 0);
+    MX_RD(blo[S][1], pl, 2048); MX_RD(bhi[S][1], ph, 2048);
+    MX_RD(blo[S][2], pl, 4096); MX_RD(bhi[S][2], ph, 4096);
+    MX_RD(blo[S][3], pl, 6144); MX_RD(bhi[S][3], ph, 6144);
   };
 #undef MX_RD
-  ld_a(0, alo[0], ahi[0]);
-  ld_b01(0);
+  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+  ld_a_half(0, I0{});
+  ld_b(0, I0{});
   int cur = 0, nxt2 = 2;
 
-  // One K step.  OPS = kt & 3 (compile time): the step's byte of the scale dwords and the register set of its A fragments;
-  // DMA: step kt + 2 exists and is requested here; SCALES: the next group's scale dwords are requested here (OPS == 0 only);
-  // LAST: no step follows.  Every wait is a compile-time constant: the K loop has no data-dependent branch inside a step.
-  auto step = [&](auto ops_c, auto dma_c, auto scales_c, auto last_c) {
-    constexpr int OPS = decltype(ops_c)::value;
-    constexpr bool DMA = decltype(dma_c)::value, SCALES = decltype(scales_c)::value, LAST = decltype(last_c)::value;
-    constexpr int SET = OPS & 1;
-    static_assert(!SCALES || (OPS == 0 && DMA), "scale groups start at OPS 0, with steps behind them");
-    if constexpr (SCALES) load_scales(snxt);
-    if constexpr (DMA) issue(nxt2);
-    ld_b23(cur);
-    // this step's A blocks and W blocks 0, 1 (read one phase ago) are in; the 4 reads just issued may still fly
-    if constexpr (MI == 4)
-      asm volatile("s_waitcnt lgkmcnt(4)" : MX_DEP4(alo[SET]), MX_DEP4(ahi[SET]), MX_DEP2(blo), MX_DEP2(bhi) :: "memory");
-    else
-      asm volatile("s_waitcnt lgkmcnt(4)" : MX_DEP2(alo[SET]), MX_DEP2(ahi[SET]), MX_DEP2(blo), MX_DEP2(bhi) :: "memory");
+  // One K step; SET = kt & 1 (compile time): the W register set the step multiplies (it reads the next step's W blocks into the
+  // other one).  Everything else that varies along K is a block-uniform scalar branch around asm statements: whether a step
+  // kt + 2 exists (DMA), whether a scale group is requested (every fourth step), whether a step follows at all.  The step's
+  // scale byte is byte 0 of the scale dwords: they are shifted down one byte per step (MI + 4 VALU ops beside 4 MI MFMAs), so
+  // OP_SEL stays 0 and ONE step body serves every step -- the loop is rolled (two steps per iteration for the two W sets).
+  // An earlier form unrolled four steps with OP_SEL 0..3 and a five-way tail: 19 inlined step bodies whose register
+  // assignments hipcc joined with copies of not-yet-landed fragments.
+#pragma unroll
+  for (int q = 0; q < NSC; ++q) snxt[q] = 0;
+  auto step = [&](auto set_c, int kt) {
+    constexpr int SET = decltype(set_c)::value;
+    auto& alo = alo_; auto& ahi = ahi_; auto& blo = blo_; auto& bhi = bhi_;
+    const bool more = (kt & 3) == 0 && kt + 4 < nk;
+    const bool dma = kt + 2 < nk;
+    const bool last = kt + 1 >= nk;
+    if (more) load_scales(snxt);
+    if (dma) issue(nxt2);
+    ld_a_half(cur, I1{});
+    // A blocks 0 .. MI/2 - 1 and this step's W blocks (read one phase ago) are in; the MI reads just issued may still fly
+    if constexpr (MI == 8) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (OPS == 1) wait_scales(snxt);   // (requested one step ago; the vmcnt wait at the end of that step's phase A covered them)
-    auto mma = [&](int j0) {
+    auto& acc_r = acc; auto& scur_r = scur;      // (plain uses: see ld_a_half)
+    auto mma = [&](auto half_c) {
+      constexpr int H0 = decltype(half_c)::value * MH_;
+      auto& acc = acc_r; auto& scur = scur_r;
 #pragma unroll
-      for (int j = j0; j < j0 + 2; ++j) {
-        const i32x8_t wf = __builtin_shufflevector(blo[j], bhi[j], 0, 1, 2, 3, 4, 5, 6, 7);
-        const int sws = OPSEL ? scur[j] : (int)((unsigned)scur[j] >> (8 * OPS));
+      for (int i = H0; i < H0 + MH_; ++i) {
+        const i32x8_t af = __builtin_shufflevector(alo[i], ahi[i], 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
-          const i32x8_t af = __builtin_shufflevector(alo[SET][i], ahi[SET][i], 0, 1, 2, 3, 4, 5, 6, 7);
-          const int sas = OPSEL ? scur[NI + i] : (int)((unsigned)scur[NI + i] >> (8 * OPS));
-          acc[j][i] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf, af, acc[j][i], 0, 0, OPSEL ? OPS : 0, sws, OPSEL ? OPS : 0, sas);
+        for (int j = 0; j < NI; ++j) {
+          const i32x8_t wf = __builtin_shufflevector(blo[SET][j], bhi[SET][j], 0, 1, 2, 3, 4, 5, 6, 7);
+          // inline asm with the accumulator tied in place: the builtin let hipcc rotate accumulators through fresh registers
+          // (D != C), which doubled their footprint and spilled asm-loaded fragments.  Accumulators: AGPRs (`+a`) for the
+          // one-wave-per-SIMD geometry (512 registers per wave: 256 + 256); VGPRs for the eight-wave form (a kernel that
+          // touches AGPRs gets its 256 registers split 128 + 128 by hipcc).
+          if constexpr (NW == 4) asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]" : "+a"(acc[j][i]) : "v"(wf), "v"(af), "v"(scur[j]), "v"(scur[NI + i]));
+          else asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]" : "+v"(acc[j][i]) : "v"(wf), "v"(af), "v"(scur[j]), "v"(scur[NI + i]));
         }
       }
     };
-    mma(0);
+    mma(I0{});
     __builtin_amdgcn_sched_barrier(0);
-    // W blocks 2, 3 are in (every read of stage kt by this wave has retired); stage kt + 1 of this wave has landed -- what may
-    // stay in flight is this step's DMA and (group starts) the scale dwords
-#define MX_B23 "+v"(blo[2]), "+v"(blo[3]), "+v"(bhi[2]), "+v"(bhi[3])
-    if constexpr (LAST) {
-      asm volatile("s_waitcnt lgkmcnt(0)" : MX_B23 :: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-    } else {
-      if constexpr (SCALES) { if constexpr (MI == 4) asm volatile("s_waitcnt vmcnt(14) lgkmcnt(0)" : MX_B23 :: "memory"); else asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" : MX_B23 :: "memory"); }
-      else if constexpr (DMA) { if constexpr (MI == 4) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" : MX_B23 :: "memory"); else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" : MX_B23 :: "memory"); }
-      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : MX_B23 :: "memory");
-      __builtin_amdgcn_sched_barrier(0);
+    // stage kt + 1 of this wave has landed -- what may stay in flight is this step's DMA and (group starts) the scale dwords;
+    // A blocks MI/2 .. are in and every read of stage kt by this wave has retired
+    if (!last) {
+      if (more) wait_vm(std::integral_constant<int, NDMA + NSC>{});
+      else if (dma) wait_vm(std::integral_constant<int, NDMA>{});
+      else wait_vm(std::integral_constant<int, 0>{});
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (!last) {
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       cur = cur == NST - 1 ? 0 : cur + 1;
       nxt2 = nxt2 == NST - 1 ? 0 : nxt2 + 1;
-      ld_a(cur, alo[SET ^ 1], ahi[SET ^ 1]);
-      ld_b01(cur);
+      ld_a_half(cur, I0{});
+      ld_b(cur, std::integral_constant<int, SET ^ 1>{});
       __builtin_amdgcn_sched_barrier(0);
     }
-#undef MX_B23
-    mma(2);
+    mma(I1{});
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (OPS == 3) {
+    // the next step's scale byte into byte 0 (a new group every fourth step: requested three steps ago, landed behind the
+    // vmcnt wait of the step after that)
+    if ((kt & 3) == 3) {
 #pragma unroll
       for (int q = 0; q < NSC; ++q) scur[q] = snxt[q];
+    } else {
+#pragma unroll
+      for (int q = 0; q < NSC; ++q) scur[q] = (int)((unsigned)scur[q] >> 8);
     }
   };
-  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
-  using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
-  using Y = std::true_type; using N_ = std::false_type;
   int kt = 0;
-  for (; kt + 6 <= nk; kt += 4) {      // four steps that all have a step kt + 2 behind them, and a group behind this one
-    step(I0{}, Y{}, Y{}, N_{});
-    step(I1{}, Y{}, N_{}, N_{});
-    step(I2{}, Y{}, N_{}, N_{});
-    step(I3{}, Y{}, N_{}, N_{});
+  for (; kt + 2 <= nk; kt += 2) {
+    step(I0{}, kt);
+    step(I1{}, kt + 1);
   }
-  switch (nk - kt) {                   // 1 .. 5 steps left; the last two request nothing
-    case 1: step(I0{}, N_{}, N_{}, Y{}); break;
-    case 2: step(I0{}, N_{}, N_{}, N_{}); step(I1{}, N_{}, N_{}, Y{}); break;
-    case 3: step(I0{}, Y{}, N_{}, N_{}); step(I1{}, N_{}, N_{}, N_{}); step(I2{}, N_{}, N_{}, Y{}); break;
-    case 4: step(I0{}, Y{}, N_{}, N_{}); step(I1{}, Y{}, N_{}, N_{}); step(I2{}, N_{}, N_{}, N_{}); step(I3{}, N_{}, N_{}, Y{}); break;
-    default:
-      step(I0{}, Y{}, Y{}, N_{}); step(I1{}, Y{}, N_{}, N_{}); step(I2{}, Y{}, N_{}, N_{}); step(I3{}, N_{}, N_{}, N_{});
-      step(I0{}, N_{}, N_{}, Y{});
-      break;
-  }
-#undef MX_WAIT
+  if (kt < nk) step(I0{}, kt);
 #undef MX_DEP4
-#undef MX_DEP2
+#undef MX_STR
+#undef MX_STR2
+  // the MFMAs are asm: hipcc does not know that the accumulators come out of the matrix pipe (8 passes behind the last
+  // issue) and pads nothing in front of their first VALU / accvgpr read
+  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 7" ::: "memory");
   g3_epilogue<EPI, MI>(p, acc, m0, n0, wr, wc, lane);
 }
 
-template <int EPI, int MI>
+template <int EPI, int MI, int NW>
 int launch_mx8(const GemmP& p, hipStream_t s) {
-  constexpr int BM = 64 * MI;
+  constexpr int BM = 16 * MI * (NW / 2);
   const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + 127) / 128;
-  if (option(OPT_MX8_OPSEL) != 0)
-    hipLaunchKernelGGL((gemm_mx8_kernel<EPI, MI, true>), dim3(nbm * nbn), dim3(512), 3 * (BM + 128) * 128, s, p);
-  else
-    hipLaunchKernelGGL((gemm_mx8_kernel<EPI, MI, false>), dim3(nbm * nbn), dim3(512), 3 * (BM + 128) * 128, s, p);
+  hipLaunchKernelGGL((gemm_mx8_kernel<EPI, MI, NW>), dim3(nbm * nbn), dim3(NW * 64), 3 * (BM + 128) * 128, s, p);
   return check_launch("gemm_mx8_kernel");
 }
 template <int EPI>
 bool prepare_mx8() {
   bool ok = true;
-  ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mx8_kernel<EPI, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (128 + 128) * 128) == hipSuccess;
-  ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mx8_kernel<EPI, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (128 + 128) * 128) == hipSuccess;
+  ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mx8_kernel<EPI, 8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (256 + 128) * 128) == hipSuccess;
+  ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mx8_kernel<EPI, 2, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (128 + 128) * 128) == hipSuccess;
   return ok;
 }
 template <int EPI>
 int dispatch_mx8(const GemmP& p, hipStream_t s) {
-  // 128 x 128 tiles (wave tile 32 x 64).  The 256-row form (MI = 4: 64 accumulators + two A fragment sets of 32 + W fragments 32 +
-  // scales) does not fit the 256 registers a wave of a 512-thread workgroup may hold under hipcc's allocation: it spilled
-  // asm-loaded fragments (tools/check_kernel_resources.py fails the build on that) and is not instantiated.
-  return launch_mx8<EPI, 2>(p, s);
+  // fewer 256-row tiles than option mx8_tile256_min: the 128-row form doubles the workgroups
+  const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + 127) / 128);
+  if (tiles256 < option(OPT_MX8_TILE256_MIN)) return launch_mx8<EPI, 2, 8>(p, s);
+  return launch_mx8<EPI, 8, 4>(p, s);
 }
 int dispatch_mx8_epi(const GemmP& p, int epi, hipStream_t s) {
   switch (epi) {
