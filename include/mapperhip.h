@@ -84,8 +84,10 @@ int mh_abi_version(void);
  *   "dit_s3_presplit"    MH_DIT_S3_PRESPLIT    1    batched fp32-semantics DiT: activations written pre-split by their
  *                                                   producers + three-stage bf16 x 3 GEMM; 0 = the 64x64 kernel that splits A
  *                                                   while staging it (bit-identical GEMM results; the fc1 GELU differs)
- *   "mx8_opsel"          MH_MX8_OPSEL          1    MX-fp8 GEMM: the K step's scale byte is picked by the MFMA's OP_SEL (1) or
- *                                                   shifted into byte 0 by a VALU op (0); same arithmetic
+ *   "decode_overlap"     MH_DECODE_OVERLAP     0    1: dependent-launch overlap of a chain's token step (two streams per chain,
+ *                                                   device-side progress words instead of stream order; T5 backbone, chains of
+ *                                                   <= 16 rows, d_model 128 / 512 / 768 / 1024).  Bit-identical tokens and logits;
+ *                                                   measured slower than the plain step (profiles/r04_decode_overlap.txt)
  * (further switches -- decode_cu_split, gemm_tile128_min, gemm_tile256_min, attn_small_max_wgs, dit_split3_min_rows,
  * dit_s3_fused_ln, mx8_tile256_min -- are documented next to their definitions in csrc/api.hip.)
  * Unknown names return MH_ERR_ARG (set) / -1 (get). */

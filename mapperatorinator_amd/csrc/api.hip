@@ -50,8 +50,8 @@ static OptionSlot g_options[OPT_COUNT] = {
     {"gemm_tile256_min", "MH_GEMM_TILE256_MIN", 96, false},      // the three-stage 256x128 bf16 tile (one workgroup per CU) is used from this many tiles on (batched DiT-S bf16: 171.6 ms at 192, 167.4 at 96, 168.6 at 48)
     {"attn_flash2", "MH_ATTN_FLASH2", 1, false},                 // bf16 attention: 1 = transposed-S kernel (128 queries per workgroup, probabilities stay in registers), 0 = the 64-query kernel with the LDS P patch
     {"dit_s3_presplit", "MH_DIT_S3_PRESPLIT", 1, false},         // fp32-semantics DiT, big batches: 1 = activations written pre-split by their producers + three-stage bf16 x 3 GEMM, 0 = the 64x64 kernel that splits A while staging it
-    {"mx8_opsel", "MH_MX8_OPSEL", 1, false},                     // MX-fp8 GEMM: 1 = the K step's scale byte is selected by the MFMA's OP_SEL, 0 = shifted into byte 0 (v_lshrrev) with OP_SEL 0
     {"mx8_tile256_min", "MH_MX8_TILE256_MIN", 192, false},       // MX-fp8 GEMM: the 256x128 tile from this many tiles on, the 128x128 form of the same kernel below
+    {"decode_overlap", "MH_DECODE_OVERLAP", 0, false},           // 1: dependent-launch overlap of a chain's token step (two streams per chain + progress words, decode_kernels.hpp): same tokens bit for bit; measured SLOWER than the plain step on the real kernels (profiles/r04_decode_overlap.txt) -- kept as a tested experiment, default off
 };
 
 long option(int id) {

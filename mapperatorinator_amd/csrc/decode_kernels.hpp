@@ -188,6 +188,106 @@ __device__ inline void store_head_row_from_lds_wt(T* dst, const float* src, int 
   }
 }
 
+// ---- dependent-launch overlap (option decode_overlap, default OFF; tools/micro/chain_pdl.hip, profiles/r04_decode_overlap.txt) --
+// a structural change of the 74-launch token step.  Built, exact, and measured SLOWER than the plain step --
+// kept as a tested experiment.  The kernels of a chain's token step alternate between TWO streams (launched eagerly, kernel by
+// kernel), so kernel k + 1 is launched -- and sits on its CUs -- while kernel k is still running.  Stream order no longer
+// carries the dependence between them; a device-side progress word does:
+//   * a DEP kernel first requests everything that does NOT depend on its predecessor (its weight slice, the RMSNorm weight,
+//     the position), then thread 0 polls the chain's progress word until it reaches epoch * 256 + slot (relaxed agent-scope
+//     loads + s_sleep; BOUNDED: a lost dependence raises the chain's error word instead of hanging the GPU);
+//   * everything the predecessor wrote is then loaded with `sc1` loads: this CU's L1 may hold a line of the residual stream /
+//     activation buffers that another CU has rewritten since (the kernel-start invalidate happened while the producer ran);
+//     the producers store write-through (store_wt and friends) as they always did;
+//   * at its end every wave waits vmcnt(0) (its write-through stores have left), the workgroup arrives on a ticket sharded by
+//     XCD (blockIdx & 7) and the last arriver of the last shard publishes epoch * 256 + slot + 1.
+// What this takes off the chain's critical path is the dispatch of the next kernel (~1.65 us) and its first round trip for
+// weights; what it adds is the arrival fan-in and the poll (~1 us).  SYNTHETIC chains with the step's launch geometry gain:
+// 43.0 -> 35 us per layer with two chains side by side.  The REAL step loses: 262 -> 334 ms of decode (32 chunks x 384 tokens).
+// The waiting kernel is not free: a resident attention workgroup holds 16 waves x 120 (self) / 2 x 16 x 64 (cross) registers
+// on 192 of the 256 CUs while it spins, so the kernel it waits for -- and the other chain's kernels -- run on what is left;
+// the synthetic GEMVs of the probe are register-light, the real ones (96-188 registers, 26 KB of LDS) are not.  Tokens and
+// logits are bit-identical to the plain step (tests/test_gpu_t5.py) -- the mechanism is sound, the occupancy price is not paid back.
+constexpr int kDepMaxSlots = 6 * MH_MAX_LAYERS + 2;
+struct DepSync {             // one per chain, in the decode workspace (zeroed at the start of a generate call)
+  unsigned progress; unsigned pad0[63];    // the chain's progress word
+  unsigned epoch; unsigned pad1[63];       // the chain's step counter (bumped by the step's last node)
+  unsigned err; unsigned pad2[63];         // lost dependences
+  unsigned tickets[kDepMaxSlots][9][32];   // per kernel slot: arrival counters of 8 XCD shards + top, 32 words apart
+};
+struct DepP {                // 16 bytes of kernel arguments (the plain forms carry them unused)
+  DepSync* sync;
+  unsigned slot, nwg;        // index of this kernel in the step; its workgroup count
+};
+__device__ inline unsigned dep_ld(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <bool DEP> __device__ inline unsigned dep_epoch(const DepP& d) {   // (thread 0 keeps it; requested with the first loads)
+  if constexpr (DEP) return threadIdx.x == 0 ? dep_ld(&d.sync->epoch) : 0u;
+  return 0u;
+}
+template <bool DEP> __device__ inline void dep_wait(const DepP& d, unsigned epoch) {
+  if constexpr (DEP) {
+    if (threadIdx.x == 0 && d.slot > 0) {      // slot 0 follows the previous step through the graph launches' stream order
+      const unsigned want = epoch * 256u + d.slot;
+      int n = 0;
+      while ((int)(dep_ld(&d.sync->progress) - want) < 0) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++n > (1 << 16)) { atomicAdd(&d.sync->err, 1u); break; }
+      }
+    }
+    __syncthreads();
+  }
+}
+template <bool DEP> __device__ inline void dep_signal(const DepP& d, unsigned epoch) {
+  if constexpr (DEP) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's write-through stores have left
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned shard = blockIdx.x & 7u;
+      const unsigned per = (d.nwg + 7u - shard) / 8u;      // workgroups with this shard index
+      unsigned* t = &d.sync->tickets[d.slot][shard][0];
+      if (__hip_atomic_fetch_add(t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == per - 1) {
+        __hip_atomic_store(t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned shards = d.nwg < 8u ? d.nwg : 8u;
+        unsigned* top = &d.sync->tickets[d.slot][8][0];
+        if (__hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == shards - 1) {
+          __hip_atomic_store(top, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(&d.sync->progress, epoch * 256u + d.slot + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    }
+  }
+}
+// loads of what the predecessor wrote.  DEP: `sc1` (L1-bypassing) loads issued by inline asm STRAIGHT INTO the destination
+// variable -- hipcc does not know they are in flight (it would copy a returned temporary at once, i.e. before the data has
+// arrived), so every use must sit behind dep_landed() AND a dep_pin() of the destination (an empty asm that re-defines the
+// register: nothing that reads it can be scheduled above the wait).
+template <bool DEP> __device__ inline void dep_ld16(uint4& dst, const void* p) {
+  if constexpr (DEP) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(reinterpret_cast<u32x4_t&>(dst)) : "v"(p) : "memory");
+  else dst = *reinterpret_cast<const uint4*>(p);
+}
+template <bool DEP> __device__ inline void dep_ld16(float4& dst, const void* p) {
+  typedef __attribute__((ext_vector_type(4))) float f32x4v_t;
+  if constexpr (DEP) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(reinterpret_cast<f32x4v_t&>(dst)) : "v"(p) : "memory");
+  else dst = *reinterpret_cast<const float4*>(p);
+}
+template <bool DEP> __device__ inline void dep_ld4(float& dst, const float* p) {
+  if constexpr (DEP) asm volatile("global_load_dword %0, %1, off sc1" : "=v"(dst) : "v"(p) : "memory");
+  else dst = *p;
+}
+template <bool DEP> __device__ inline void dep_landed() {
+  if constexpr (DEP) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+template <bool DEP> __device__ inline void dep_pin(uint4& v) {
+  if constexpr (DEP) asm volatile("" : "+v"(reinterpret_cast<u32x4_t&>(v)));
+}
+template <bool DEP> __device__ inline void dep_pin(float& v) {
+  if constexpr (DEP) asm volatile("" : "+v"(v));
+}
+template <bool DEP> __device__ inline void dep_pin(float4& v) {
+  typedef __attribute__((ext_vector_type(4))) float f32x4v_t;
+  if constexpr (DEP) asm volatile("" : "+v"(reinterpret_cast<f32x4v_t&>(v)));
+}
+
 // ---- decode GEMV ("skinny GEMM": M = batch rows <= 64) ------------------------------------------------------------
 // out[b][n] = sum_k A[b][k] * W[n][k] on the 16x16 MFMA atoms.  One workgroup owns ONE 16-column tile of which `nv`
 // columns are real (nv = 16, 8 or 4: a 768-column projection becomes 48, 96 or 192 workgroups; the other tile columns
@@ -302,9 +402,10 @@ constexpr int kGemvCH = 8;   // k-blocks per wave whose loads are in flight at o
 #else
 #define MH_GEMV_WPE_ATTR
 #endif
-template <typename T, int MF, int NWV, int PRO, int EPI, bool BIAS = false>
+template <typename T, int MF, int NWV, int PRO, int EPI, bool BIAS = false, bool DEP = false>
 __global__ __launch_bounds__(NWV * 64) MH_GEMV_WPE_ATTR
-void gemv_kernel(MH_GEMV_LEAD_PARAMS, SkinnyP p) {
+void gemv_kernel(MH_GEMV_LEAD_PARAMS, SkinnyP p, DepP dep) {
+  static_assert(!DEP || MF == 1, "the overlap form is built for chains of <= 16 rows");
   p.A = A_; p.W = W_; p.h = h_; p.ln_w = lnw_; p.K = K_; p.lda = K_; p.ldw = K_; p.B = B_; p.N = N_; p.nv = nv_;
   if (EPI == SK_RESID) p.ldh = N_;   // the residual stream is dense [B, N] (checked on the host)
   constexpr int VEC = Elem<T>::kVec;   // elements per 16-byte vector (per lane per k-block)
@@ -377,14 +478,19 @@ void gemv_kernel(MH_GEMV_LEAD_PARAMS, SkinnyP p) {
   constexpr int PROBE = MH_GEMV_PROBE;
   float bias_v = 0.f;
   if (BIAS) bias_v = p.bias[ocol < p.N ? ocol : p.N - 1];
-  if (EPI == SK_RESID && l15 < nv && !(PROBE & 4)) {   // requested before anything is waited for
-#pragma unroll
-    for (int u = 0; u < UPW; ++u) {
-      const int unit = wid + u * NWV;
-      const int row = (unit >> 2) * 16 + lg * 4 + (unit & 3);
-      if (unit < MF * 4) oldh[u] = p.h[(long)(row < p.B ? row : p.B - 1) * p.ldh + (ocol < p.N ? ocol : p.N - 1)];
-    }
-  }
+  // (a macro, not a lambda: a by-reference capture of `oldh` made hipcc keep the array in memory and promote it to LDS --
+  // 4 KB per wave, an LDS round trip per value: the residual GEMVs went from 5.4 to 17 us)
+#define MH_LOAD_OLDH()                                                                                                        \
+  do {                                                                                                                        \
+    _Pragma("unroll") for (int u = 0; u < UPW; ++u) {                                                                         \
+      const int unit = wid + u * NWV;                                                                                         \
+      const int row = (unit >> 2) * 16 + lg * 4 + (unit & 3);                                                                 \
+      if (unit < MF * 4) dep_ld4<DEP>(oldh[u], p.h + (long)(row < p.B ? row : p.B - 1) * p.ldh + (ocol < p.N ? ocol : p.N - 1)); \
+    }                                                                                                                         \
+  } while (0)
+  if (!DEP && EPI == SK_RESID && l15 < nv && !(PROBE & 4)) MH_LOAD_OLDH();   // requested before anything is waited for
+  const unsigned dep_ep = dep_epoch<DEP>(dep);
+  bool dep_waited = false;
 
   f32x4_t acc[MF];
 #pragma unroll
@@ -412,12 +518,24 @@ void gemv_kernel(MH_GEMV_LEAD_PARAMS, SkinnyP p) {
           wv[c] = *reinterpret_cast<const uint4*>(Wp + (2 * (pw < npair ? pw : npair - 1) + (c & 1)) * KB);   // clamped address
         }
       }
+      if (DEP && !dep_waited) {   // the weights of this pass are on their way: now the predecessor's data
+        dep_wait<DEP>(dep, dep_ep);
+        dep_waited = true;
+        if (EPI == SK_RESID && l15 < nv) MH_LOAD_OLDH();
+      }
 #pragma unroll
       for (int cp = 0; cp < CP; ++cp) {
         const int pw = pw0 + NWV * cp;
         const long off = (long)(pw < npair ? pw : npair - 1) * 128;
-        xa[cp] = *reinterpret_cast<const uint4*>(Ab + rx + off);
-        ya[cp] = *reinterpret_cast<const uint4*>(Ab + ry + off);
+        dep_ld16<DEP>(xa[cp], Ab + rx + off);
+        dep_ld16<DEP>(ya[cp], Ab + ry + off);
+      }
+      if constexpr (DEP) {
+        dep_landed<DEP>();
+#pragma unroll
+        for (int cp = 0; cp < CP; ++cp) { dep_pin<DEP>(xa[cp]); dep_pin<DEP>(ya[cp]); }
+#pragma unroll
+        for (int u = 0; u < UPW; ++u) dep_pin<DEP>(oldh[u]);
       }
       MH_LOADS_ISSUED();
       MH_LOADS_ISSUED();
@@ -449,6 +567,11 @@ void gemv_kernel(MH_GEMV_LEAD_PARAMS, SkinnyP p) {
         wv[c] = *reinterpret_cast<const uint4*>(Wp + (kb < nkb ? kb : nkb - 1) * KB);   // clamped address
       }
     }
+    if (DEP && !dep_waited) {   // the weights of this pass are on their way: now the predecessor's data
+      dep_wait<DEP>(dep, dep_ep);
+      dep_waited = true;
+      if (EPI == SK_RESID && l15 < nv) MH_LOAD_OLDH();
+    }
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
       const int kb = kblock(kb0, c);
@@ -466,13 +589,19 @@ void gemv_kernel(MH_GEMV_LEAD_PARAMS, SkinnyP p) {
       } else if (PRO == PRO_PLAIN) {
 #pragma unroll
         for (int f = 0; f < MF; ++f)
-          av[c][f] = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.A) + (long)arow[f] * p.lda + kel + lg * VEC);
+          dep_ld16<DEP>(av[c][f], reinterpret_cast<const T*>(p.A) + (long)arow[f] * p.lda + kel + lg * VEC);
       } else if (!RLINES) {
 #pragma unroll
-        for (int f = 0; f < MF; ++f)
-          hraw[c][f] = VecOps<T>::load_raw(reinterpret_cast<const float*>(p.A) + (long)arow[f] * p.lda + kel + lg * VEC);
+        for (int f = 0; f < MF; ++f) {
+          if constexpr (DEP && sizeof(T) == 4) {   // (fp32 storage: one 16-byte vector per k-block)
+            dep_ld16<DEP>(hraw[c][f].a, reinterpret_cast<const float*>(p.A) + (long)arow[f] * p.lda + kel + lg * VEC);
+          } else {
+            hraw[c][f] = VecOps<T>::load_raw(reinterpret_cast<const float*>(p.A) + (long)arow[f] * p.lda + kel + lg * VEC);
+          }
+        }
       }
     }
+    static_assert(!DEP || PRO == PRO_PLAIN || RLINES || sizeof(T) == 4, "overlap form: every dependent load has an sc1 path");
     uint4 xr[RLINES ? CH : 1], yr[RLINES ? CH : 1];
     if (RLINES) {   // one 128-byte line of fp32 per row and k-block: rows 0..7 / 8..15 of the block as two whole-line loads
       const int r8 = lane >> 3;
@@ -482,9 +611,30 @@ void gemv_kernel(MH_GEMV_LEAD_PARAMS, SkinnyP p) {
       for (int c = 0; c < CH; ++c) {
         const int kb = kb0 + NWV * c;
         const long off = (long)(kb < nkb ? kb : nkb - 1) * 128;
-        xr[c] = *reinterpret_cast<const uint4*>(Ab + rx + off);
-        yr[c] = *reinterpret_cast<const uint4*>(Ab + ry + off);
+        dep_ld16<DEP>(xr[c], Ab + rx + off);
+        dep_ld16<DEP>(yr[c], Ab + ry + off);
       }
+    }
+    if constexpr (DEP) {
+      dep_landed<DEP>();
+      if (RLINES) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) { dep_pin<DEP>(xr[c]); dep_pin<DEP>(yr[c]); }
+      }
+      if constexpr (PRO == PRO_RMSNORM && !RLINES && sizeof(T) == 4) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+#pragma unroll
+          for (int f = 0; f < MF; ++f) dep_pin<DEP>(hraw[c][f].a);
+      }
+      if constexpr (PRO == PRO_PLAIN) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+#pragma unroll
+          for (int f = 0; f < MF; ++f) dep_pin<DEP>(av[c][f]);
+      }
+#pragma unroll
+      for (int u = 0; u < UPW; ++u) dep_pin<DEP>(oldh[u]);
     }
     MH_LOADS_ISSUED();
     MH_STAMP(KID, 0);   // loads issued
@@ -587,6 +737,8 @@ void gemv_kernel(MH_GEMV_LEAD_PARAMS, SkinnyP p) {
     }
   }
   MH_STAMP(KID, 3);     // epilogue stores issued
+  dep_signal<DEP>(dep, dep_ep);
+#undef MH_LOAD_OLDH
 }
 
 // ---- single-query attention (online softmax in registers) -----------------------------------------
@@ -847,17 +999,22 @@ template <> struct Raw8<float> {
 // The statistics come from the row itself (wave sums -> 16 LDS floats that every thread adds in the same order).
 // Two halves: `issue` only REQUESTS the row and the weight (it needs nothing but preloaded kernel arguments), `finish`
 // waits for them -- whatever else the kernel can request goes in between.
-template <typename T>
+template <typename T, bool DEP = false>
 struct NormRow {
   float x, g;
-  __device__ inline void issue(const HeadProjP& hp, int b) {
+  __device__ inline void issue_weight(const HeadProjP& hp) {      // (independent of the predecessor)
     const int tid = threadIdx.x;
-    const int kc = tid < hp.d ? tid : hp.d - 1;
-    x = hp.h[(long)b * hp.ldh + kc];
-    g = hp.ln_w[kc];
+    g = hp.ln_w[tid < hp.d ? tid : hp.d - 1];
   }
-  __device__ inline void finish(const HeadProjP& hp, float* xn, float* red16) const {
+  __device__ inline void issue_row(const HeadProjP& hp, int b) {   // the residual row the predecessor wrote
     const int tid = threadIdx.x;
+    dep_ld4<DEP>(x, hp.h + (long)b * hp.ldh + (tid < hp.d ? tid : hp.d - 1));
+  }
+  __device__ inline void issue(const HeadProjP& hp, int b) { issue_row(hp, b); issue_weight(hp); }
+  __device__ inline void finish(const HeadProjP& hp, float* xn, float* red16) {
+    const int tid = threadIdx.x;
+    dep_landed<DEP>();
+    dep_pin<DEP>(x);
     const float sq = wave_sum(tid < hp.d ? x * x : 0.f);
     if ((tid & 63) == 0) red16[tid >> 6] = sq;
     __syncthreads();
@@ -929,10 +1086,10 @@ struct HeadProj {
 // cross-attention of one (b, h) with its own query projection; 16 waves, one key split (the default configuration
 // of dec_cross_attn_kernel, same key interleave and merge order)
 // F8: K / V are the e4m3 copy (64-byte rows, 8 bytes per lane; the scales multiply the scores and the output)
-template <typename T, int KC, int U, bool F8 = false, bool WH = false>
+template <typename T, int KC, int U, bool F8 = false, bool WH = false, bool DEP = false>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8)))   // <= 64 VGPRs: 2 workgroups per CU
 void dec_cross_attn_q_kernel(const float* h_, const float* lnw_, const void* W_, const void* k_, const void* v_, int H_, int L_, int d_,
-                             int kvB_, CrossAttnP p, HeadProjP hp) {   // leading scalars: preloaded kernel arguments (see gemv_kernel)
+                             int kvB_, CrossAttnP p, HeadProjP hp, DepP dep) {   // leading scalars: preloaded kernel arguments (see gemv_kernel)
   hp.h = h_; hp.ln_w = lnw_; hp.W = W_; hp.ldh = d_; hp.ldw = d_; hp.d = d_;
   p.k = k_; p.v = v_; p.H = H_; p.L = L_; p.kv_B = kvB_;
   constexpr int NW = 16;
@@ -951,12 +1108,20 @@ void dec_cross_attn_q_kernel(const float* h_, const float* lnw_, const void* W_,
   const E* kb = reinterpret_cast<const E*>(p.k) + ((long)kvb * p.H + h) * p.L * 64;
   const E* vb = reinterpret_cast<const E*>(p.v) + ((long)kvb * p.H + h) * p.L * 64;
   HeadProj<T, KC, 1> proj;
-  NormRow<T> nrow;
+  NormRow<T, DEP> nrow;
   // everything the prologue needs is requested at once, from preloaded arguments only: the residual row, the RMSNorm
   // weight and (bf16: fp32 -- the parity path -- would not fit the 64-register budget of two workgroups per CU) this
   // head's 64 x d slice of Wq, which does not depend on the activations; then the remaining kernel arguments
-  nrow.issue(hp, b);
-  if (sizeof(T) == 2) proj.load(hp, row0);
+  const unsigned dep_ep = dep_epoch<DEP>(dep);
+  if constexpr (DEP) {   // overlap form: weights first, then wait for the o-projection GEMV, then its residual row
+    nrow.issue_weight(hp);
+    if (sizeof(T) == 2) proj.load(hp, row0);
+    dep_wait<DEP>(dep, dep_ep);
+    nrow.issue_row(hp, b);
+  } else {
+    nrow.issue(hp, b);
+    if (sizeof(T) == 2) proj.load(hp, row0);
+  }
   // (LDS-DMA prefetch of every wave's first 1-3 key iterations during this prologue -- 32 KB of LDS per iteration, issued as
   // inline asm behind shadow loads so that no wait of the prologue covers it -- was built and measured: 703 / 703 / 729 us
   // per token step for 1 / 2 / 3 iterations against 679 without.  Not kept.)
@@ -987,6 +1152,7 @@ void dec_cross_attn_q_kernel(const float* h_, const float* lnw_, const void* W_,
     atomicMin(slot, t_start);
     atomicMax(slot + 1, (unsigned long long)wall_clock64());
   }
+  dep_signal<DEP>(dep, dep_ep);
 }
 
 // normalised rows b0 .. b0+R-1 (clamped to B-1) into LDS as T elements: xs[r][k] = T(ln_w[k] * (h[b][k] * rsqrt(mean(h[b]^2)
@@ -1021,11 +1187,11 @@ __device__ inline void norm_rows_to_lds(const HeadProjP& hp, int b0, int B, T (*
 
 // self-attention of one (b, h) with its own q / k / v projections: appends the new key / value row to the caches and
 // attends over keys 0 .. pos-1 from the cache plus the new key straight from LDS (merged last)
-template <typename T, int KC, bool WH = false>
+template <typename T, int KC, bool WH = false, bool DEP = false>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4)))   // 16 waves = 4 per SIMD: the whole 128-register budget
 void dec_self_attn_qkv_kernel(const float* h_, const float* lnw_, const void* W_, const int* pos_,
                                                                  const void* kc_, const void* vc_, int H_, int d_, SelfAttnP p,
-                                                                 HeadProjP hp) {   // leading scalars: preloaded kernel arguments
+                                                                 HeadProjP hp, DepP dep) {   // leading scalars: preloaded kernel arguments
   hp.h = h_; hp.ln_w = lnw_; hp.W = W_; hp.ldh = d_; hp.ldw = d_; hp.d = d_;
   p.pos = pos_; p.kc = kc_; p.vc = vc_; p.H = H_;
   const int inner = H_ * 64;
@@ -1041,8 +1207,9 @@ void dec_self_attn_qkv_kernel(const float* h_, const float* lnw_, const void* W_
   // the first round trip carries everything that does not depend on another load: the residual row + RMSNorm weight, the
   // position, and the two loop-invariant values of the tail (the bias at distance 0 and the prompt mask of the new key:
   // they used to be two serial round trips at the END of the kernel)
-  NormRow<T> nrow;
-  nrow.issue(hp, b);
+  NormRow<T, DEP> nrow;
+  const unsigned dep_ep = dep_epoch<DEP>(dep);
+  if constexpr (DEP) nrow.issue_weight(hp); else nrow.issue(hp, b);
   const int pos = *p.pos;
   constexpr bool kAllAtOnce = sizeof(T) == 2 && KC <= 7;
   HeadProj<T, KC, kAllAtOnce ? 3 : 1> proj;
@@ -1056,10 +1223,15 @@ void dec_self_attn_qkv_kernel(const float* h_, const float* lnw_, const void* W_
     rope_s = p.rope[(long)pos * 64 + 32 + (threadIdx.x & 31)];
   }
   const int new_key_mask = (mask_row && pos < p.P) ? (int)mask_row[pos < p.P ? pos : 0] : 1;
+  if constexpr (DEP) {   // overlap form: this head's q / k / v weight slice travels while the workgroup waits for the wo GEMV of the layer before
+    if (kAllAtOnce) proj.load3(hp, row03);
+    dep_wait<DEP>(dep, dep_ep);
+    nrow.issue_row(hp, b);
+  }
   nrow.finish(hp, xn, red16);
   const float* qb = WH ? p.qkv_bias : nullptr;
   if (kAllAtOnce) {
-    proj.load3(hp, row03);   // (requested AFTER the normalisation: holding the 18 vectors across it measured 688 vs 677 us per token step)
+    if constexpr (!DEP) proj.load3(hp, row03);   // (requested AFTER the normalisation: holding the 18 vectors across it measured 688 vs 677 us per token step)
     proj.apply(xn, qkv, qb, row03);
   } else {   // fp32 storage, or d_model = 1024 in bf16: one projection at a time (register budget of a 1024-thread workgroup)
 #pragma unroll
@@ -1116,6 +1288,7 @@ void dec_self_attn_qkv_kernel(const float* h_, const float* lnw_, const void* W_
     a = a * fa + qkv[2][d] * fb;
     store_head_row_wt<T>(reinterpret_cast<T*>(p.out) + (long)b * p.ldo + h * 64, l > 0.f ? a / l : 0.f, &sm[0][0]);
   }
+  dep_signal<DEP>(dep, dep_ep);
 }
 
 // The same for R = 2 or 4 rows of one head per workgroup (option decode_self_rows): rows b0 .. b0+R-1 share the head's

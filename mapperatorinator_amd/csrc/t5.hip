@@ -8,6 +8,7 @@
 //   model_generate (osuT5/osuT5/inference/server.py:83-156) with the reference logits processors.
 #include <stdlib.h>
 
+#include <functional>
 #include <map>
 #include <mutex>
 #include <thread>
@@ -797,7 +798,7 @@ int gemv_cols(int N) {
 }
 
 template <typename T, int MF, int PRO, int EPI, bool BIAS = false>
-int launch_skinny(dec::SkinnyP p, hipStream_t s) {
+int launch_skinny(dec::SkinnyP p, hipStream_t s, const dec::DepP* dep = nullptr) {
   const int kb = 4 * (16 / (int)sizeof(T));
   MH_REQUIRE(p.K % kb == 0 && p.K >= kb, "decode: K=%d must be a positive multiple of %d", p.K, kb);
   const int nkb = p.K / kb;
@@ -815,18 +816,26 @@ int launch_skinny(dec::SkinnyP p, hipStream_t s) {
       set_error("decode: RMSNorm GEMV needs d_model <= 1024 in bf16 storage");
       return MH_ERR_ARG;
     } else {
-      hipLaunchKernelGGL((dec::gemv_kernel<T, MF, 8, PRO, EPI, BIAS>), dim3(tiles), dim3(512), 0, s, MH_GEMV_LEAD_ARGS(p), p);
+      if constexpr (MF == 1 && !BIAS) {
+        if (dep) { dec::DepP dd = *dep; dd.nwg = (unsigned)tiles; hipLaunchKernelGGL((dec::gemv_kernel<T, MF, 8, PRO, EPI, BIAS, true>), dim3(tiles), dim3(512), 0, s, MH_GEMV_LEAD_ARGS(p), p, dd); return check_launch("gemv_kernel"); }
+      }
+      hipLaunchKernelGGL((dec::gemv_kernel<T, MF, 8, PRO, EPI, BIAS>), dim3(tiles), dim3(512), 0, s, MH_GEMV_LEAD_ARGS(p), p, dec::DepP{});
     }
   } else {
-    hipLaunchKernelGGL((dec::gemv_kernel<T, MF, 4, PRO, EPI, BIAS>), dim3(tiles), dim3(256), 0, s, MH_GEMV_LEAD_ARGS(p), p);
+    if constexpr (MF == 1 && !BIAS) {
+      if (dep) { dec::DepP dd = *dep; dd.nwg = (unsigned)tiles; hipLaunchKernelGGL((dec::gemv_kernel<T, MF, 4, PRO, EPI, BIAS, true>), dim3(tiles), dim3(256), 0, s, MH_GEMV_LEAD_ARGS(p), p, dd); return check_launch("gemv_kernel"); }
+    }
+    hipLaunchKernelGGL((dec::gemv_kernel<T, MF, 4, PRO, EPI, BIAS>), dim3(tiles), dim3(256), 0, s, MH_GEMV_LEAD_ARGS(p), p, dec::DepP{});
   }
+  MH_REQUIRE(!dep, "decode: the overlap form of this GEMV is not built");
   return check_launch("gemv_kernel");
 }
 
 template <typename T, int PRO, int EPI, bool BIAS = false>
-int skinny(const dec::SkinnyP& p, hipStream_t s) {
+int skinny(const dec::SkinnyP& p, hipStream_t s, const dec::DepP* dep = nullptr) {
   MH_REQUIRE(!BIAS || p.bias, "decode: biased GEMV without a bias");
-  if (p.B <= 16) return launch_skinny<T, 1, PRO, EPI, BIAS>(p, s);
+  if (p.B <= 16) return launch_skinny<T, 1, PRO, EPI, BIAS>(p, s, dep);
+  MH_REQUIRE(!dep, "decode: the overlap form needs chains of <= 16 rows");
   if (p.B <= 32) return launch_skinny<T, 2, PRO, EPI, BIAS>(p, s);
   return launch_skinny<T, 4, PRO, EPI, BIAS>(p, s);
 }
@@ -858,11 +867,23 @@ bool fused_proj_enabled(int d) { return option(OPT_DECODE_FUSED_PROJ) != 0 && d 
 
 #define MH_SELF_LEAD_ARGS hp.h, hp.ln_w, hp.W, sa.pos, sa.kc, sa.vc, sa.H, hp.d
 #define MH_CROSS_LEAD_ARGS hp.h, hp.ln_w, hp.W, ca.k, ca.v, ca.H, ca.L, hp.d, ca.kv_B
+// KC values the overlap (DEP) forms of the attention kernels are instantiated for: d_model 128 (tests), 512, 768, 1024
+constexpr bool dep_kc(int KC) { return KC == 1 || KC == 4 || KC == 6 || KC == 8; }
 template <typename T, int KC>
-int launch_self_qkv(const dec::SelfAttnP& sa, const dec::HeadProjP& hp, int inner, hipStream_t s) {
+int launch_self_qkv(const dec::SelfAttnP& sa, const dec::HeadProjP& hp, int inner, hipStream_t s, const dec::DepP* dep = nullptr) {
   MH_REQUIRE(hp.ldh == hp.d && hp.ldw == hp.d && inner == sa.H * 64, "decode: dense residual rows / projection weights expected");
+  if (dep) {
+    if constexpr (dep_kc(KC)) {
+      dec::DepP dd = *dep; dd.nwg = (unsigned)(sa.B * sa.H);
+      hipLaunchKernelGGL((dec::dec_self_attn_qkv_kernel<T, KC, false, true>), dim3(sa.B * sa.H), dim3(1024), 0, s, MH_SELF_LEAD_ARGS, sa, hp, dd);
+      return check_launch("dec_self_attn_qkv_kernel");
+    } else {
+      set_error("decode: the overlap form is built for d_model 128 / 512 / 768 / 1024");
+      return MH_ERR_ARG;
+    }
+  }
   if (sa.rope) {   // the Whisper family: biased fused Wqkv, RoPE, scaled scores, optional window
-    hipLaunchKernelGGL((dec::dec_self_attn_qkv_kernel<T, KC, true>), dim3(sa.B * sa.H), dim3(1024), 0, s, MH_SELF_LEAD_ARGS, sa, hp);
+    hipLaunchKernelGGL((dec::dec_self_attn_qkv_kernel<T, KC, true>), dim3(sa.B * sa.H), dim3(1024), 0, s, MH_SELF_LEAD_ARGS, sa, hp, dec::DepP{});
     return check_launch("dec_self_attn_qkv_kernel");
   }
   // option decode_self_rows: rows of one head per workgroup (1, 2 or 4) -- they share the head's weight slice
@@ -872,50 +893,61 @@ int launch_self_qkv(const dec::SelfAttnP& sa, const dec::HeadProjP& hp, int inne
   else if (R >= 2)
     hipLaunchKernelGGL((dec::dec_self_attn_qkv_rows_kernel<T, KC, 2>), dim3((sa.B + 1) / 2 * sa.H), dim3(1024), 0, s, MH_SELF_LEAD_ARGS, sa, hp);
   else
-    hipLaunchKernelGGL((dec::dec_self_attn_qkv_kernel<T, KC>), dim3(sa.B * sa.H), dim3(1024), 0, s, MH_SELF_LEAD_ARGS, sa, hp);
+    hipLaunchKernelGGL((dec::dec_self_attn_qkv_kernel<T, KC>), dim3(sa.B * sa.H), dim3(1024), 0, s, MH_SELF_LEAD_ARGS, sa, hp, dec::DepP{});
   return check_launch("dec_self_attn_qkv_kernel");
 }
 template <typename T>
-int launch_self_qkv_d(const dec::SelfAttnP& sa, const dec::HeadProjP& hp, int inner, hipStream_t s) {
+int launch_self_qkv_d(const dec::SelfAttnP& sa, const dec::HeadProjP& hp, int inner, hipStream_t s, const dec::DepP* dep = nullptr) {
   switch (hp.d) {
-    case 128: return launch_self_qkv<T, 1>(sa, hp, inner, s);
-    case 256: return launch_self_qkv<T, 2>(sa, hp, inner, s);
-    case 384: return launch_self_qkv<T, 3>(sa, hp, inner, s);
-    case 512: return launch_self_qkv<T, 4>(sa, hp, inner, s);
-    case 640: return launch_self_qkv<T, 5>(sa, hp, inner, s);
-    case 768: return launch_self_qkv<T, 6>(sa, hp, inner, s);
-    case 896: return launch_self_qkv<T, 7>(sa, hp, inner, s);
-    default: return launch_self_qkv<T, 8>(sa, hp, inner, s);
+    case 128: return launch_self_qkv<T, 1>(sa, hp, inner, s, dep);
+    case 256: return launch_self_qkv<T, 2>(sa, hp, inner, s, dep);
+    case 384: return launch_self_qkv<T, 3>(sa, hp, inner, s, dep);
+    case 512: return launch_self_qkv<T, 4>(sa, hp, inner, s, dep);
+    case 640: return launch_self_qkv<T, 5>(sa, hp, inner, s, dep);
+    case 768: return launch_self_qkv<T, 6>(sa, hp, inner, s, dep);
+    case 896: return launch_self_qkv<T, 7>(sa, hp, inner, s, dep);
+    default: return launch_self_qkv<T, 8>(sa, hp, inner, s, dep);
   }
 }
 template <typename T, int KC>
-int launch_cross_q(const dec::CrossAttnP& ca, const dec::HeadProjP& hp, hipStream_t s) {
+int launch_cross_q(const dec::CrossAttnP& ca, const dec::HeadProjP& hp, hipStream_t s, const dec::DepP* dep = nullptr) {
   MH_REQUIRE(hp.ldh == hp.d && hp.ldw == hp.d, "decode: dense residual rows / projection weights expected");
+  if (dep) {
+    if constexpr (dep_kc(KC)) {
+      MH_REQUIRE(ca.scale == 0.f && ca.kscale == nullptr, "decode: the overlap form is built for the T5 backbone with bf16 / fp32 cross K/V");
+      dec::DepP dd = *dep; dd.nwg = (unsigned)(ca.B * ca.H);
+      hipLaunchKernelGGL((dec::dec_cross_attn_q_kernel<T, KC, 1, false, false, true>), dim3(ca.B * ca.H), dim3(1024), 0, s, MH_CROSS_LEAD_ARGS, ca, hp, dd);
+      return check_launch("dec_cross_attn_q_kernel");
+    } else {
+      set_error("decode: the overlap form is built for d_model 128 / 512 / 768 / 1024");
+      return MH_ERR_ARG;
+    }
+  }
   // one key in flight per 8-lane group: 64 VGPRs without spills (two 16-wave workgroups per CU); U = 2 measured the
   // same bandwidth in the stand-alone kernel
   if (ca.scale != 0.f) {   // the Whisper family: biased Wq, scaled scores
     MH_REQUIRE(ca.kscale == nullptr, "decode: the fp8 cross K/V copy is not wired for the Whisper family");
-    hipLaunchKernelGGL((dec::dec_cross_attn_q_kernel<T, KC, 1, false, true>), dim3(ca.B * ca.H), dim3(1024), 0, s, MH_CROSS_LEAD_ARGS, ca, hp);
+    hipLaunchKernelGGL((dec::dec_cross_attn_q_kernel<T, KC, 1, false, true>), dim3(ca.B * ca.H), dim3(1024), 0, s, MH_CROSS_LEAD_ARGS, ca, hp, dec::DepP{});
   } else if (ca.kscale != nullptr) {
     if constexpr (sizeof(T) == 2)
-      hipLaunchKernelGGL((dec::dec_cross_attn_q_kernel<T, KC, 1, true>), dim3(ca.B * ca.H), dim3(1024), 0, s, MH_CROSS_LEAD_ARGS, ca, hp);
+      hipLaunchKernelGGL((dec::dec_cross_attn_q_kernel<T, KC, 1, true>), dim3(ca.B * ca.H), dim3(1024), 0, s, MH_CROSS_LEAD_ARGS, ca, hp, dec::DepP{});
     else { set_error("decode: the fp8 cross K/V copy needs bf16 storage"); return MH_ERR_ARG; }
   } else {
-    hipLaunchKernelGGL((dec::dec_cross_attn_q_kernel<T, KC, 1>), dim3(ca.B * ca.H), dim3(1024), 0, s, MH_CROSS_LEAD_ARGS, ca, hp);
+    hipLaunchKernelGGL((dec::dec_cross_attn_q_kernel<T, KC, 1>), dim3(ca.B * ca.H), dim3(1024), 0, s, MH_CROSS_LEAD_ARGS, ca, hp, dec::DepP{});
   }
   return check_launch("dec_cross_attn_q_kernel");
 }
 template <typename T>
-int launch_cross_q_d(const dec::CrossAttnP& ca, const dec::HeadProjP& hp, hipStream_t s) {
+int launch_cross_q_d(const dec::CrossAttnP& ca, const dec::HeadProjP& hp, hipStream_t s, const dec::DepP* dep = nullptr) {
   switch (hp.d) {
-    case 128: return launch_cross_q<T, 1>(ca, hp, s);
-    case 256: return launch_cross_q<T, 2>(ca, hp, s);
-    case 384: return launch_cross_q<T, 3>(ca, hp, s);
-    case 512: return launch_cross_q<T, 4>(ca, hp, s);
-    case 640: return launch_cross_q<T, 5>(ca, hp, s);
-    case 768: return launch_cross_q<T, 6>(ca, hp, s);
-    case 896: return launch_cross_q<T, 7>(ca, hp, s);
-    default: return launch_cross_q<T, 8>(ca, hp, s);
+    case 128: return launch_cross_q<T, 1>(ca, hp, s, dep);
+    case 256: return launch_cross_q<T, 2>(ca, hp, s, dep);
+    case 384: return launch_cross_q<T, 3>(ca, hp, s, dep);
+    case 512: return launch_cross_q<T, 4>(ca, hp, s, dep);
+    case 640: return launch_cross_q<T, 5>(ca, hp, s, dep);
+    case 768: return launch_cross_q<T, 6>(ca, hp, s, dep);
+    case 896: return launch_cross_q<T, 7>(ca, hp, s, dep);
+    default: return launch_cross_q<T, 8>(ca, hp, s, dep);
   }
 }
 
@@ -923,10 +955,47 @@ int launch_cross_q_d(const dec::CrossAttnP& ca, const dec::HeadProjP& hp, hipStr
 struct DecodeTiming { unsigned long long* buf = nullptr; int ring = 0; };
 DecodeTiming g_timing;
 
+// dependent-launch overlap of one chain's step (option decode_overlap; decode_kernels.hpp): the chain's second stream, the
+// event that orders a step's second-stream kernels behind the previous step's epoch bump, the chain's DepSync block.
+// The step is launched EAGERLY, kernel by kernel, alternating between the two streams -- not replayed as a graph: a graph's
+// parallel branch runs on a stream of the runtime's choosing, and whenever that stream shared a hardware queue with the
+// launch stream and kernel k + 1 was queued in front of kernel k, k + 1 spun for a predecessor that could not start (lost
+// dependences; measured with 2 chains = 4 branches on the 4 default queues).  With eager launches the host enqueues k before
+// k + 1, so a shared queue only costs the overlap, never the dependence.
+struct OverlapCtx { hipStream_t s2; hipEvent_t step_done; dec::DepSync* sync; int which; };   // which: -1 = every kernel (0 / 1: even / odd slots only)
+__global__ void dec_epoch_bump_kernel(dec::DepSync* sy) {   // last node of a step: the next step's targets move up
+  const unsigned e = sy->epoch + 1;
+  __hip_atomic_store(&sy->epoch, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(&sy->progress, e * 256u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+bool overlap_possible(const MhT5Config* c, int rows_per_chain, bool kv8, bool cfg) {
+  const int d = c->d_model;
+  return option(OPT_DECODE_OVERLAP) != 0 && c->arch == 0 && rows_per_chain <= 16 && !kv8 && !cfg && fused_proj_enabled(d) &&
+         option(OPT_DECODE_FUSED_PROJ) == 1 && option(OPT_DECODE_SELF_ROWS) <= 1 && (d == 128 || d == 512 || d == 768 || d == 1024) &&
+         option(OPT_DECODE_CU_SPLIT) == 0 && 6 * c->n_dec_layers + 2 <= dec::kDepMaxSlots;
+}
+
 template <typename T>
 int enqueue_step(const MhT5Config* c, const MhT5Weights* w, const void* cross_kv, int B, int Bfull, int kvB,
                  const uint8_t* prompt_mask, int P, const DecBuffers& bf, const SampleP& smp, hipStream_t s,
-                 const void* kv8 = nullptr, const float* kv8_scales = nullptr, bool with_sampler = true, int kv_group = 0) {
+                 const void* kv8 = nullptr, const float* kv8_scales = nullptr, bool with_sampler = true, int kv_group = 0,
+                 const OverlapCtx* ov = nullptr) {
+  // ov: the step's kernels alternate between `s` and ov->s2 (two branches of the captured graph) and order themselves through
+  // the chain's progress word; the sampler and the epoch bump follow the join on `s`
+  unsigned slot = 0;
+  dec::DepP dep_cur{};
+  auto st = [&]() -> hipStream_t { return (ov && (slot & 1)) ? ov->s2 : s; };
+  auto dp = [&]() -> const dec::DepP* {
+    if (!ov) return nullptr;
+    dep_cur.sync = ov->sync; dep_cur.slot = slot; dep_cur.nwg = 0;
+    return &dep_cur;
+  };
+  if (ov) {
+    MH_REQUIRE(c->arch == 0 && B <= 16 && !kv8 && kv_group == 0 && with_sampler, "decode: overlap form requested for a step it is not built for");
+    // the second stream's kernels read the step counter at their start: they must not start before the previous step's bump
+    if (ov->which < 0 && hipStreamWaitEvent(ov->s2, ov->step_done, 0) != hipSuccess) return check_launch("overlap step wait");
+  }
+  auto take = [&]() -> bool { return !ov || ov->which < 0 || (int)(slot & 1) == ov->which; };
   // with_sampler = false: the step ends with the logits (mh_t5_step: the host selects); kv_group > 1: rows are (chunk, beam)
   // pairs and row b reads cross K/V row b / kv_group
   // kv8 / kv8_scales: the chain's first row of the e4m3 copy of cross_kv and of its scales (mh_t5_quantize_cross_kv)
@@ -994,8 +1063,10 @@ int enqueue_step(const MhT5Config* c, const MhT5Weights* w, const void* cross_kv
     if (fused_self) {
       dec::HeadProjP hp{};
       hp.h = bf.h; hp.ldh = d; hp.ln_w = w->dec_ln1[l]; hp.eps = c->eps; hp.W = w->dec_qkv[l]; hp.ldw = d; hp.d = d;
-      MH_TRY(launch_self_qkv_d<T>(sa, hp, inner, s));
+      if (take()) MH_TRY(launch_self_qkv_d<T>(sa, hp, inner, st(), dp()));
+      ++slot;
     } else {
+      MH_REQUIRE(!ov, "decode: the overlap form needs decode_fused_proj = 1");
       sk = dec::SkinnyP{};
       sk.A = bf.h; sk.lda = d; sk.ln_w = w->dec_ln1[l]; sk.eps = c->eps; sk.W = w->dec_qkv[l]; sk.ldw = d; sk.B = B;
       sk.N = 3 * inner; sk.K = d; sk.out = bf.q; sk.ldo = inner; sk.kc = (char*)bf.self_k + cache_off;
@@ -1007,7 +1078,8 @@ int enqueue_step(const MhT5Config* c, const MhT5Weights* w, const void* cross_kv
     sk = dec::SkinnyP{};
     sk.A = bf.attn; sk.lda = inner; sk.W = w->dec_o[l]; sk.ldw = inner; sk.B = B; sk.N = d; sk.K = inner; sk.h = bf.h;
     sk.ldh = d;
-    MH_TRY((skinny<T, dec::PRO_PLAIN, dec::SK_RESID>(sk, s)));
+    if (take()) MH_TRY((skinny<T, dec::PRO_PLAIN, dec::SK_RESID>(sk, st(), dp())));
+    ++slot;
     // cross attention
     dec::CrossAttnP ca{};
     const long kv_layer = (long)kvB * H * L * 64 * es;
@@ -1027,8 +1099,10 @@ int enqueue_step(const MhT5Config* c, const MhT5Weights* w, const void* cross_kv
     if (fused) {
       dec::HeadProjP hp{};
       hp.h = bf.h; hp.ldh = d; hp.ln_w = w->dec_ln2[l]; hp.eps = c->eps; hp.W = w->dec_cq[l]; hp.ldw = d; hp.d = d;
-      MH_TRY(launch_cross_q_d<T>(ca, hp, s));
+      if (take()) MH_TRY(launch_cross_q_d<T>(ca, hp, st(), dp()));
+      ++slot;
     } else {
+      MH_REQUIRE(!ov, "decode: the overlap form needs decode_fused_proj = 1");
       sk = dec::SkinnyP{};
       sk.A = bf.h; sk.lda = d; sk.ln_w = w->dec_ln2[l]; sk.eps = c->eps; sk.W = w->dec_cq[l]; sk.ldw = d; sk.B = B;
       sk.N = inner; sk.K = d; sk.out = bf.q; sk.ldo = inner;
@@ -1038,24 +1112,37 @@ int enqueue_step(const MhT5Config* c, const MhT5Weights* w, const void* cross_kv
     sk = dec::SkinnyP{};
     sk.A = bf.attn; sk.lda = inner; sk.W = w->dec_co[l]; sk.ldw = inner; sk.B = B; sk.N = d; sk.K = inner; sk.h = bf.h;
     sk.ldh = d;
-    MH_TRY((skinny<T, dec::PRO_PLAIN, dec::SK_RESID>(sk, s)));
+    if (take()) MH_TRY((skinny<T, dec::PRO_PLAIN, dec::SK_RESID>(sk, st(), dp())));
+    ++slot;
     // feed forward
     sk = dec::SkinnyP{};
     sk.A = bf.h; sk.lda = d; sk.ln_w = w->dec_ln3[l]; sk.eps = c->eps; sk.W = w->dec_wi[l]; sk.ldw = d; sk.B = B;
     sk.N = 2 * dff; sk.K = d; sk.out = bf.ff; sk.ldo = dff;
-    MH_TRY((skinny<T, dec::PRO_RMSNORM, dec::SK_GEGLU>(sk, s)));
+    if (take()) MH_TRY((skinny<T, dec::PRO_RMSNORM, dec::SK_GEGLU>(sk, st(), dp())));
+    ++slot;
     sk = dec::SkinnyP{};
     sk.A = bf.ff; sk.lda = dff; sk.W = w->dec_wo[l]; sk.ldw = dff; sk.B = B; sk.N = d; sk.K = dff; sk.h = bf.h;
     sk.ldh = d;
-    MH_TRY((skinny<T, dec::PRO_PLAIN, dec::SK_RESID>(sk, s)));
+    if (take()) MH_TRY((skinny<T, dec::PRO_PLAIN, dec::SK_RESID>(sk, st(), dp())));
+    ++slot;
   }
   dec::SkinnyP sk{};
   sk.A = bf.h; sk.lda = d; sk.ln_w = w->dec_final_ln; sk.eps = c->eps; sk.W = w->lm_head; sk.ldw = d; sk.B = B;
   sk.N = c->vocab_out; sk.K = d; sk.out = bf.logits; sk.ldo = c->vocab_out;
-  MH_TRY((skinny<T, dec::PRO_RMSNORM, dec::SK_LOGITS>(sk, s)));
+  if (take()) MH_TRY((skinny<T, dec::PRO_RMSNORM, dec::SK_LOGITS>(sk, st(), dp())));
+  ++slot;
+  // (overlap form: the lm_head GEMV is an even slot, i.e. on `s`, and has waited for the last second-stream kernel through the
+  // progress word -- the sampler behind it in stream order sees the whole step finished)
+  static_assert((6 * 1 + 0) % 2 == 0, "six kernels per layer: the lm_head slot is even");
   if (!with_sampler) return MH_OK;
+  if (ov && ov->which == 1) return MH_OK;          // (the odd-slot graph ends with the last wo GEMV)
   hipLaunchKernelGGL(dec_sample_kernel<T>, dim3(smp.pair > 0 ? smp.pair : B), dim3(256), 0, s, smp);
   MH_TRY(check_launch("dec_sample_kernel"));
+  if (ov) {
+    hipLaunchKernelGGL(dec_epoch_bump_kernel, dim3(1), dim3(1), 0, s, ov->sync);
+    MH_TRY(check_launch("dec_epoch_bump_kernel"));
+    if (ov->which < 0 && hipEventRecord(ov->step_done, s) != hipSuccess) return check_launch("overlap step record");
+  }
   return MH_OK;
 }
 
@@ -1115,6 +1202,7 @@ extern "C" int64_t mh_t5_decode_workspace_bytes(const MhT5Config* c, int B) {
   t += align256((int64_t)c->n_dec_layers * B * inner * c->tgt_len * es) * 2;      // self K, V caches
   t += align256(B) + align256((int64_t)B * 4) * 2 + align256(sizeof(DecState)) * kMaxChains;   // flags / state
   t += align256((int64_t)B * c->vocab_out * 4) * 3;                               // processed scores + LookbackBias history
+  t += align256(sizeof(mh::dec::DepSync)) * kMaxChains;                           // progress words / arrival tickets (decode_overlap)
   t += prefill_layout(c, B, c->tgt_len - 1, nullptr, 0, nullptr);                  // batched prompt prefill
   return t;
 }
@@ -1277,6 +1365,8 @@ struct ChainPool {   // extra streams + fork/join events of ONE device, created 
   hipStream_t part[2] = {};      // two streams bound to disjoint halves of the CUs (option decode_cu_split)
   int part_mode = 0;
   hipEvent_t fork = nullptr, join[kMaxChains] = {};
+  hipStream_t streams2[kMaxChains] = {};                         // option decode_overlap: a chain's second stream
+  hipEvent_t fork2[kMaxChains] = {};                             //   and its "previous step finished" event
   bool ready = false;
   int init() {
     if (ready) return MH_OK;
@@ -1287,6 +1377,18 @@ struct ChainPool {   // extra streams + fork/join events of ONE device, created 
         return check_launch("chain stream create");
     }
     ready = true;
+    return MH_OK;
+  }
+  // option decode_overlap: the chains' second streams, created on first use
+  bool ready2 = false;
+  int init_overlap(int n) {
+    if (ready2) return MH_OK;
+    for (int i = 0; i < n; ++i) {
+      if (hipStreamCreateWithFlags(&streams2[i], hipStreamNonBlocking) != hipSuccess ||
+          hipEventCreateWithFlags(&fork2[i], hipEventDisableTiming) != hipSuccess)
+        return check_launch("overlap stream create");
+    }
+    ready2 = true;
     return MH_OK;
   }
   // Two decode chains on disjoint CU sets: their kernels never queue behind each other for CU slots and (mode 1) never
@@ -1421,7 +1523,8 @@ extern "C" int mh_t5_generate(const MhT5Config* c, const MhT5Weights* w, const v
   DecState* st_all = (DecState*)ar.take((int64_t)align256(sizeof(DecState)) * kMaxChains);
   float* proc = (float*)ar.take((int64_t)B * V * 4);
   float* hist_scores = (float*)ar.take((int64_t)B * V * 4 * 2);
-  MH_REQUIRE(ar.ok() && hist_scores, "mh_t5_generate: arena overflow");
+  char* dep_sync_all = (char*)ar.take((int64_t)align256(sizeof(dec::DepSync)) * kMaxChains);
+  MH_REQUIRE(ar.ok() && hist_scores && dep_sync_all, "mh_t5_generate: arena overflow");
   // a CFG pair spans both halves of the batch and the (batch-wide) conditional temperature reads row 0's history: one chain
   const int n_chains = (cfg || (sp->n_cond > 0 && !sp->cond_per_row)) ? 1 : pick_chains(B);
   const int rows_per = ceil_div(B, n_chains);
@@ -1466,6 +1569,11 @@ extern "C" int mh_t5_generate(const MhT5Config* c, const MhT5Weights* w, const v
   hipGraph_t graphs[kMaxChains] = {};
   hipGraphExec_t execs[kMaxChains] = {};
   DecState* states[kMaxChains] = {};
+  dec::DepSync* syncs[kMaxChains] = {};
+  std::function<int()> eager_step[kMaxChains];
+  // (at most two chains: 2 x 2 branches = the four hardware queues a process gets by default)
+  const bool overlap = n_chains <= 2 && overlap_possible(c, rows_per, sp->cross_kv_fp8 != nullptr, cfg);
+  if (overlap) MH_TRY(g_pool.init_overlap(2));
   int used = 0, rc = MH_OK;
   for (int ci = 0; ci < n_chains && rc == MH_OK; ++ci) {
     const int b0 = ci * rows_per;
@@ -1499,8 +1607,8 @@ extern "C" int mh_t5_generate(const MhT5Config* c, const MhT5Weights* w, const v
     else hipLaunchKernelGGL(dec_init_kernel<float>, dim3(Bc), dim3(256), 0, cs, smp, Bc, start_pos);
     rc = check_launch("dec_init_kernel");
     if (rc != MH_OK) break;
-    // capture one step of this chain (every kernel reads the position from device memory) for replay
-    if (hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) != hipSuccess) { rc = check_launch("begin capture"); break; }
+    syncs[ci] = (dec::DepSync*)(dep_sync_all + (long)ci * align256(sizeof(dec::DepSync)));
+    if (overlap && hipMemsetAsync(syncs[ci], 0, sizeof(dec::DepSync), cs) != hipSuccess) { rc = check_launch("overlap state reset"); break; }
     const void* kv8 = nullptr;
     const float* kv8_scales = nullptr;
     if (sp->cross_kv_fp8) {   // packed e4m3 copy: data, then (256-byte aligned) the scales
@@ -1508,6 +1616,22 @@ extern "C" int mh_t5_generate(const MhT5Config* c, const MhT5Weights* w, const v
       kv8 = (const char*)sp->cross_kv_fp8 + (long)b0 * H * c->src_len * 64;
       kv8_scales = reinterpret_cast<const float*>((const char*)sp->cross_kv_fp8 + align256(data_bytes)) + (long)b0 * H;
     }
+    if (overlap) {
+      OverlapCtx ov{g_pool.streams2[ci], g_pool.fork2[ci], syncs[ci], -1};
+      if (hipEventRecord(ov.step_done, cs) != hipSuccess) { rc = check_launch("overlap first record"); break; }   // (behind dec_init + the state reset)
+      // eager two-stream form: nothing is captured; the chain's launcher thread enqueues every step kernel by kernel.
+      // (Two LINEAR graphs -- even slots on the chain stream, odd slots on a CU-masked stream of its own -- were built and
+      // measured as well: 363 ms of decode against 334 ms eager and 262 ms for the plain step, and they still lost dependences
+      // in one test case; removed.)
+      eager_step[ci] = [=]() -> int {
+        return bf16 ? enqueue_step<bf16_t>(c, w, ckv, Bc, B, kvB, pm, P, bf, smp, cs, kv8, kv8_scales, true, 0, &ov)
+                    : enqueue_step<float>(c, w, ckv, Bc, B, kvB, pm, P, bf, smp, cs, kv8, kv8_scales, true, 0, &ov);
+      };
+      ++used;
+      continue;
+    }
+    // capture one step of this chain (every kernel reads the position from device memory) for replay
+    if (hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) != hipSuccess) { rc = check_launch("begin capture"); break; }
     int rce = bf16 ? enqueue_step<bf16_t>(c, w, ckv, Bc, B, kvB, pm, P, bf, smp, cs, kv8, kv8_scales)
                    : enqueue_step<float>(c, w, ckv, Bc, B, kvB, pm, P, bf, smp, cs, kv8, kv8_scales);
     hipError_t ce = hipStreamEndCapture(cs, &graphs[ci]);
@@ -1526,8 +1650,10 @@ extern "C" int mh_t5_generate(const MhT5Config* c, const MhT5Weights* w, const v
     int step = 0;
     while (step < total_steps) {
       const int burst = total_steps - step < poll_every ? total_steps - step : poll_every;
-      for (int i = 0; i < burst; ++i)
-        if (hipGraphLaunch(execs[ci], chain_stream[ci]) != hipSuccess) return MH_ERR_LAUNCH;
+      for (int i = 0; i < burst; ++i) {
+        if (eager_step[ci]) { if (eager_step[ci]() != MH_OK) return MH_ERR_LAUNCH; }
+        else if (hipGraphLaunch(execs[ci], chain_stream[ci]) != hipSuccess) return MH_ERR_LAUNCH;
+      }
       step += burst;
       if (step < total_steps && !forced) {
         int running = 1;
@@ -1554,6 +1680,10 @@ extern "C" int mh_t5_generate(const MhT5Config* c, const MhT5Weights* w, const v
   }
   // join the chains back into the caller's stream
   for (int ci = 0; ci < used; ++ci) {
+    if (overlap) {   // the second stream's last kernel finished before the last lm_head did; order it in front of the join all the same
+      (void)hipEventRecord(g_pool.join[ci], g_pool.streams2[ci]);
+      (void)hipStreamWaitEvent(chain_stream[ci], g_pool.join[ci], 0);
+    }
     (void)hipEventRecord(g_pool.join[ci], chain_stream[ci]);
     (void)hipStreamWaitEvent(s, g_pool.join[ci], 0);
   }
@@ -1562,6 +1692,13 @@ extern "C" int mh_t5_generate(const MhT5Config* c, const MhT5Weights* w, const v
     rc = check_launch("dec_finalize_kernel");
   }
   (void)hipStreamSynchronize(s);   // the graph objects must outlive their launches
+  if (overlap && rc == MH_OK) {    // a kernel that gave up waiting for its predecessor produced garbage: say so
+    for (int ci = 0; ci < used; ++ci) {
+      unsigned lost = 0;
+      if (hipMemcpy(&lost, &syncs[ci]->err, 4, hipMemcpyDeviceToHost) != hipSuccess) { rc = check_launch("overlap error word"); break; }
+      if (lost) { set_error("mh_t5_generate: %u dependences were lost on chain %d under decode_overlap (set the option to 0)", lost, ci); rc = MH_ERR_STATE; break; }
+    }
+  }
   for (int ci = 0; ci < kMaxChains; ++ci) {
     if (execs[ci]) (void)hipGraphExecDestroy(execs[ci]);
     if (graphs[ci]) (void)hipGraphDestroy(graphs[ci]);

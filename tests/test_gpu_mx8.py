@@ -131,19 +131,14 @@ SHAPES = [(256, 128, 128), (300, 200, 256), (512, 384, 384), (200, 136, 512), (1
           (640, 1024, 1024), (384, 2304, 1152), (4096, 512, 2816), (512, 768, 3072), (8192, 2304, 768)]
 
 
-@pytest.mark.parametrize("opsel", [1, 0])
 @pytest.mark.parametrize("shape", SHAPES)
-def test_mx8_gemm_against_the_float64_product_of_the_dequantised_operands(shape, opsel):
+def test_mx8_gemm_against_the_float64_product_of_the_dequantised_operands(shape):
     L, lib = _lib()
     M, N, K = shape
     rng = np.random.default_rng(M + N + K)
     A = heavy_tailed(M, K, seed=1)
     W = (rng.standard_normal((N, K)) * rng.uniform(0.2, 3.0, (N, 1))).astype(np.float32)      # asymmetric: row scales differ
-    old = L.set_option("mx8_opsel", opsel)
-    try:
-        got, ref = run_mx8_gemm(A, W, L.EPI_STORE_F32)
-    finally:
-        L.set_option("mx8_opsel", old)
+    got, ref = run_mx8_gemm(A, W, L.EPI_STORE_F32)
     # fp32 accumulation of K products whose partial sums reach |a|.|w|: bound the error by the row / column magnitudes
     from oracle import mx8 as omx
     qa, sa = omx.quantize_mx8(A)

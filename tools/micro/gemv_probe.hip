@@ -30,13 +30,13 @@ static void enqueue(hipStream_t s, const Bufs& b, int i, int nv) {
   p.B = B; p.ln_w = b.lnw; p.eps = 1e-6f;
   if (WHICH == 0) {          // o / co projection + residual: N = 768, K = 768
     p.A = b.attn; p.lda = D; p.W = W; p.ldw = D; p.N = D; p.K = D; p.h = b.h; p.ldh = D; p.nv = nv;
-    hipLaunchKernelGGL((gemv_kernel<bf16_t, 1, 4, PRO_PLAIN, SK_RESID>), dim3((D + nv - 1) / nv), dim3(256), 0, s, MH_GEMV_LEAD_ARGS(p), p);
+    hipLaunchKernelGGL((gemv_kernel<bf16_t, 1, 4, PRO_PLAIN, SK_RESID>), dim3((D + nv - 1) / nv), dim3(256), 0, s, MH_GEMV_LEAD_ARGS(p), p, DepP{});
   } else if (WHICH == 1) {   // RMSNorm + wi + gated GELU: N = 2 * 2048, K = 768
     p.A = b.h; p.lda = D; p.W = W; p.ldw = D; p.N = 2 * DFF; p.K = D; p.out = b.ff; p.ldo = DFF; p.nv = 16;
-    hipLaunchKernelGGL((gemv_kernel<bf16_t, 1, 4, PRO_RMSNORM, SK_GEGLU>), dim3(DFF / 8), dim3(256), 0, s, MH_GEMV_LEAD_ARGS(p), p);
+    hipLaunchKernelGGL((gemv_kernel<bf16_t, 1, 4, PRO_RMSNORM, SK_GEGLU>), dim3(DFF / 8), dim3(256), 0, s, MH_GEMV_LEAD_ARGS(p), p, DepP{});
   } else {                   // wo + residual: N = 768, K = 2048 (8 waves)
     p.A = b.ff; p.lda = DFF; p.W = W; p.ldw = DFF; p.N = D; p.K = DFF; p.h = b.h; p.ldh = D; p.nv = nv;
-    hipLaunchKernelGGL((gemv_kernel<bf16_t, 1, 8, PRO_PLAIN, SK_RESID>), dim3((D + nv - 1) / nv), dim3(512), 0, s, MH_GEMV_LEAD_ARGS(p), p);
+    hipLaunchKernelGGL((gemv_kernel<bf16_t, 1, 8, PRO_PLAIN, SK_RESID>), dim3((D + nv - 1) / nv), dim3(512), 0, s, MH_GEMV_LEAD_ARGS(p), p, DepP{});
   }
 }
 
