@@ -13,6 +13,7 @@ casts them (gaussian_diffusion.py:951-963).
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import math
 from typing import Callable, Optional
@@ -33,8 +34,7 @@ class DiTHIP:
 
     def __init__(self, state_dict: dict, depth: int, hidden: int, num_heads: int, context_size: int = 272,
                  class_size: int = 300, device="cuda", operand_dtype: torch.dtype = torch.float32):
-        if not torch.cuda.is_available():
-            raise RuntimeError("DiTHIP needs a ROCm GPU; there is no CPU fallback")
+        self.require_gpu()
         if hidden != num_heads * 64:
             raise NotImplementedError("HIP attention kernels are built for head_dim = 64")
         if operand_dtype not in (torch.float32, torch.bfloat16, "mx8"):
@@ -123,7 +123,7 @@ class DiTHIP:
         w.fin_ada_w, w.fin_ada_b = t(sd["final_layer.adaLN_modulation.1.weight"]), t(sd["final_layer.adaLN_modulation.1.bias"])
         w.fin_w, w.fin_b = t(sd["final_layer.linear.weight"]), t(sd["final_layer.linear.bias"])
         self.cfg, self.w = cfg, w
-        self.stream = torch.cuda.Stream(self.device)
+        self.stream = self.new_stream()
         self._ws = None
 
     @classmethod
@@ -152,6 +152,28 @@ class DiTHIP:
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(int(need), dtype=torch.uint8, device=self.device)
         return self._ws
+
+    # ---- device and streams: the only places this class touches torch.cuda, so that a CPU test can put a stand-in for the
+    # library underneath the unchanged host logic (tests/test_oracle_pinned.py); the product has no CPU path ------------------
+    def require_gpu(self):
+        if not torch.cuda.is_available():
+            raise RuntimeError("DiTHIP needs a ROCm GPU; there is no CPU fallback")
+
+    def new_stream(self):
+        return torch.cuda.Stream(self.device)
+
+    def caller_stream(self) -> int:
+        """the raw handle of the stream the caller is on"""
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    @contextlib.contextmanager
+    def on_own_stream(self):
+        """the denoiser's own stream, ordered behind the caller's stream on entry and in front of it on exit; yields its handle"""
+        cur = torch.cuda.current_stream(self.device)
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            yield self.stream.cuda_stream
+        cur.wait_stream(self.stream)
 
     def band_from_mask(self, attn_mask: Optional[torch.Tensor], T: int):
         """The reference passes a (T, T) bool mask, True = masked, built as a band
@@ -194,7 +216,7 @@ class DiTHIP:
         t32 = t.to(dev, torch.int32).contiguous()
         out = torch.empty((N, 4, T), dtype=torch.float32, device=dev)
         ws = self.workspace(N, T)
-        s = torch.cuda.current_stream(dev).cuda_stream
+        s = self.caller_stream()
         rc = self.lib.mh_dit_forward_cfg(C.byref(self.cfg), C.byref(self.w), x.data_ptr(), t32.data_ptr(),
                                          c.data_ptr(), y.data_ptr(), float(cfg_scale), band, open_from, N, T, out.data_ptr(),
                                          ws.data_ptr(), ws.numel(), s)
@@ -425,18 +447,16 @@ class SpacedDiffusionHIP:
                 iref = denoised_fn.ref.to(dev, torch.float32).contiguous()
             if isinstance(denoised_fn, SliderInpaintSpec):
                 sset = C.byref(denoised_fn.cset)
-            dit.stream.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(dit.stream):
+            with dit.on_own_stream() as own:
                 rc = lib.mh_ddpm_sample_loop(C.byref(dit.cfg), C.byref(dit.w), x.data_ptr(), c.data_ptr(),
                                              y.data_ptr(), cfg_scale, band, open_from, N, T, n, t_map.data_ptr(),
                                              coefs.data_ptr(), noise_by_i.data_ptr(), _lib.ptr(imask), _lib.ptr(iref),
-                                             sset, ws.data_ptr(), ws.numel(), dit.stream.cuda_stream)
+                                             sset, ws.data_ptr(), ws.numel(), own)
             _lib.check(rc, "mh_ddpm_sample_loop")
-            torch.cuda.current_stream(dev).wait_stream(dit.stream)
             return x
 
         # arbitrary host denoised_fn (slider re-projection): per-step launches, x0 round trip through python
-        s = torch.cuda.current_stream(dev).cuda_stream
+        s = dit.caller_stream()
         mout = torch.empty((N, 4, T), dtype=torch.float32, device=dev)
         x0 = torch.empty_like(x)
         for i in reversed(range(n)):
@@ -481,7 +501,7 @@ class SpacedDiffusionHIP:
         mout = torch.empty((N, 4, T), dtype=torch.float32, device=dev)
         out, x0 = torch.empty_like(x), torch.empty_like(x)
         ws = dit.workspace(N, T)
-        s = torch.cuda.current_stream(dev).cuda_stream
+        s = dit.caller_stream()
         lib = dit.lib
         _lib.check(lib.mh_dit_forward_cfg(C.byref(dit.cfg), C.byref(dit.w), x.data_ptr(), t32.data_ptr(), c.data_ptr(),
                                           y.data_ptr(), float(mk.get("cfg_scale", 1.0)), band, open_from, N, T, mout.data_ptr(),
