@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MH_ABI_VERSION 7
+#define MH_ABI_VERSION 8
 #define MH_MAX_LAYERS 32
 
 typedef enum MhStatus {
@@ -62,7 +62,7 @@ typedef enum MhEpilogue {
 const char* mh_last_error(void);
 int mh_abi_version(void);
 
-/* Tuning options (process-wide): each has a default, an environment override read at first use and this run-time
+/* Tuning options (process-wide; per engine through an option set, below): each has a default, an environment override read at first use and this run-time
  * setter.  They choose between kernels that compute the same results (bit-identical unless noted):
  *   "gemm_splitk_tiles"  MH_GEMM_SPLITK_TILES  192  fp32/bf16 GEMMs with fewer 32x32 tiles than this use the 16x16
  *                                                   split-K tile (different fp32 summation order); 0 = never
@@ -84,6 +84,10 @@ int mh_abi_version(void);
  *   "dit_s3_presplit"    MH_DIT_S3_PRESPLIT    1    batched fp32-semantics DiT: activations written pre-split by their
  *                                                   producers + three-stage bf16 x 3 GEMM; 0 = the 64x64 kernel that splits A
  *                                                   while staging it (bit-identical GEMM results; the fc1 GELU differs)
+ *   "decode_launch_threads" MH_DECODE_LAUNCH_THREADS 1  one host launcher thread per decode chain; 0 = one thread feeds all chains
+ *                                                   round robin (for profilers whose counter passes do not survive concurrent
+ *                                                   launcher threads)
+ *   "decode_graph_cache" MH_DECODE_GRAPH_CACHE 1    step graphs kept across mh_t5_generate calls (0: captured per call)
  *   "decode_overlap"     MH_DECODE_OVERLAP     0    1: dependent-launch overlap of a chain's token step (two streams per chain,
  *                                                   device-side progress words instead of stream order; T5 backbone, chains of
  *                                                   <= 16 rows, d_model 128 / 512 / 768 / 1024).  Bit-identical tokens and logits;
@@ -93,6 +97,18 @@ int mh_abi_version(void);
  * Unknown names return MH_ERR_ARG (set) / -1 (get). */
 int mh_set_option(const char* name, long value);
 long mh_get_option(const char* name);
+/* ABI 8 -- option sets: overrides owned by ONE engine instead of the process.  A set starts empty (every option falls through to
+ * the process-wide value above); MhT5Config.options / MhDiTConfig.options point at it (NULL = process-wide values only) and every
+ * entry point that takes such a config resolves its options through the set for the duration of the call, the decode chains'
+ * launcher threads included.  Two engines in one process can so run different kernel variants side by side.  The set must
+ * outlive the calls that name it; setting an option while a call that uses the set is in flight is a data race the caller
+ * excludes.  mh_options_get returns the override, else the process-wide value; unknown names: MH_ERR_ARG / -1. */
+typedef struct MhOptionSet MhOptionSet;
+MhOptionSet* mh_options_create(void);
+void mh_options_destroy(MhOptionSet* set);
+int mh_options_set(MhOptionSet* set, const char* name, long value);
+int mh_options_clear(MhOptionSet* set, const char* name);      /* drop one override (name = NULL: all of them) */
+long mh_options_get(const MhOptionSet* set, const char* name);
 /* sizeof() of the ABI structs as this library was compiled, so that a binding can verify its own layout:
  * which = 0 MhGemm, 1 MhT5Config, 2 MhT5Weights, 3 MhSampling, 4 MhDiTConfig, 5 MhDiTWeights,
  * 6 MhSliderSet; -1 otherwise. */
@@ -243,6 +259,7 @@ typedef struct MhT5Config {
                                gated-GELU hidden by a pass over the bf16 buffer).  Needs dtype = MH_BF16, arch 0, d_model /
                                d_ff multiples of 128.  A reduced-precision mode of its own (the reference has none): gates
                                are error bounds against the fp32 reference goldens, never bit-exactness.                 */
+  const MhOptionSet* options;   /* ABI 8: this engine's option overrides (mh_options_create), NULL = the process-wide values */
 } MhT5Config;
 
 typedef struct MhT5Weights {
@@ -454,6 +471,11 @@ int mh_t5_cross_attn_probe(const MhT5Config* cfg, const MhT5Weights* w, const vo
  * timed one.  buf == NULL (ring 0) switches it off.  mh_t5_decode_chains(B) = row chains mh_t5_generate uses for B. */
 int mh_t5_decode_timing(void* buf, int ring);
 int mh_t5_decode_chains(int B);
+int mh_t5_decode_chains_cfg(const MhT5Config* cfg, int B);   /* ABI 8: ... under cfg->options */
+/* ABI 8: instantiated step graphs are kept across mh_t5_generate calls (option "decode_graph_cache", default 1: LRU of 16, a
+ * call replays an earlier call's graph iff every address, size, sampling field other than seed / rng_row0, option value and the
+ * weights struct agree byte for byte).  Counters of graphs replayed from / captured into the cache since the last reset. */
+int mh_t5_step_graph_cache_stats(long* hits, long* misses, int reset);
 int mh_wall_clock_khz(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -476,6 +498,7 @@ typedef struct MhDiTConfig {
                         "fp8 MFMA" -- MH_MX8: the four block projections on MX-fp8 operands (LayerNorm-modulate writes the operand
                         directly; attention output and GELU hidden are bf16 as in the MH_BF16 mode and quantised by a pass of their
                         own; attention itself on bf16 operands); hidden %% 128 == 0.  Error-bound gates, as MH_BF16. */
+  const MhOptionSet* options;   /* ABI 8: this engine's option overrides, NULL = the process-wide values */
 } MhDiTConfig;
 
 typedef struct MhDiTWeights {       /* all fp32, matrices [N][Kpad]                                  */

@@ -42,7 +42,8 @@ class MhT5Config(C.Structure):
                 # ABI 5: the Whisper-family backbone (arch 1)
                 ("arch", C.c_int), ("attn_scale", C.c_float), ("in_frames", C.c_int), ("local_every", C.c_int),
                 ("local_window", C.c_int),
-                ("enc_operand_dtype", C.c_int)]      # ABI 7: 0 or MH_MX8
+                ("enc_operand_dtype", C.c_int),      # ABI 7: 0 or MH_MX8
+                ("options", VP)]                     # ABI 8: MhOptionSet* of this engine (NULL = process-wide values)
 
 
 class MhT5Weights(C.Structure):
@@ -79,7 +80,8 @@ class MhSampling(C.Structure):
 class MhDiTConfig(C.Structure):
     _fields_ = [("hidden", C.c_int), ("depth", C.c_int), ("n_heads", C.c_int), ("context_size", C.c_int),
                 ("class_size", C.c_int), ("in_channels", C.c_int), ("freq_dim", C.c_int),
-                ("t_freq_dim", C.c_int), ("first_k_pad", C.c_int), ("class_pad", C.c_int), ("operand_dtype", C.c_int)]
+                ("t_freq_dim", C.c_int), ("first_k_pad", C.c_int), ("class_pad", C.c_int), ("operand_dtype", C.c_int),
+                ("options", VP)]      # ABI 8
 
 
 class MhDiTWeights(C.Structure):
@@ -103,7 +105,7 @@ class MhSliderSet(C.Structure):
                 ("end_idx", VP), ("length", VP)]
 
 
-ABI_VERSION = 7   # MH_ABI_VERSION of include/mapperhip.h
+ABI_VERSION = 8   # MH_ABI_VERSION of include/mapperhip.h
 
 # every symbol include/mapperhip.h declares: (name, restype, argtypes)
 I, I64, F = C.c_int, C.c_int64, C.c_float
@@ -113,6 +115,11 @@ SYMBOLS = {
     "mh_struct_size": (I, [I]),
     "mh_set_option": (I, [C.c_char_p, C.c_long]),
     "mh_get_option": (C.c_long, [C.c_char_p]),
+    "mh_options_create": (VP, []),
+    "mh_options_destroy": (None, [VP]),
+    "mh_options_set": (I, [VP, C.c_char_p, C.c_long]),
+    "mh_options_clear": (I, [VP, C.c_char_p]),
+    "mh_options_get": (C.c_long, [VP, C.c_char_p]),
     "mh_mel": (I, [VP, I, I, I, I, I, VP, VP, VP, VP, VP, VP, I, VP, I, I, VP]),
     "mh_gemm": (I, [C.POINTER(MhGemm), VP]),
     "mh_rmsnorm": (I, [VP, I, VP, VP, I, I, I, F, I, VP]),
@@ -141,6 +148,8 @@ SYMBOLS = {
     "mh_t5_cross_attn_probe": (I, [C.POINTER(MhT5Config), C.POINTER(MhT5Weights), VP, I, I, C.POINTER(C.c_float), VP, I64, VP]),
     "mh_t5_decode_timing": (I, [VP, I]),
     "mh_t5_decode_chains": (I, [I]),
+    "mh_t5_decode_chains_cfg": (I, [C.POINTER(MhT5Config), I]),
+    "mh_t5_step_graph_cache_stats": (I, [C.POINTER(C.c_long), C.POINTER(C.c_long), I]),
     "mh_wall_clock_khz": (I, []),
     "mh_dit_workspace_bytes": (I64, [C.POINTER(MhDiTConfig), I, I]),
     "mh_dit_forward_cfg": (I, [C.POINTER(MhDiTConfig), C.POINTER(MhDiTWeights), VP, VP, VP, VP, F, I, I, I, I,
@@ -192,6 +201,34 @@ def set_option(name: str, value: int) -> int:
     old = lib.mh_get_option(name.encode())
     check(lib.mh_set_option(name.encode(), int(value)), f"mh_set_option({name})")
     return old
+
+
+class OptionSet:
+    """An engine's own option overrides (MhOptionSet, ABI 8): `T5Engine(..., options={"decode_chains": 1})` runs with them
+    while another engine in the same process keeps the process-wide values.  `handle` goes into MhT5Config / MhDiTConfig
+    `.options`; the object must outlive the engine's calls (the engines keep a reference)."""
+
+    def __init__(self, values: dict = None):
+        self._lib = load()
+        self.handle = self._lib.mh_options_create()
+        if not self.handle:
+            raise MemoryError("mh_options_create")
+        for k, v in (values or {}).items():
+            self[k] = v
+
+    def __setitem__(self, name: str, value: int):
+        check(self._lib.mh_options_set(self.handle, name.encode(), int(value)), f"mh_options_set({name})")
+
+    def __getitem__(self, name: str) -> int:
+        return int(self._lib.mh_options_get(self.handle, name.encode()))
+
+    def clear(self, name: str = None):
+        check(self._lib.mh_options_clear(self.handle, None if name is None else name.encode()), "mh_options_clear")
+
+    def __del__(self):
+        h, self.handle = getattr(self, "handle", None), None
+        if h:
+            self._lib.mh_options_destroy(h)
 
 
 def check(rc: int, what: str = ""):

@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include <atomic>
+#include <new>
 
 #include "common.hpp"
 
@@ -52,9 +53,27 @@ static OptionSlot g_options[OPT_COUNT] = {
     {"dit_s3_presplit", "MH_DIT_S3_PRESPLIT", 1, false},         // fp32-semantics DiT, big batches: 1 = activations written pre-split by their producers + three-stage bf16 x 3 GEMM, 0 = the 64x64 kernel that splits A while staging it
     {"mx8_tile256_min", "MH_MX8_TILE256_MIN", 192, false},       // MX-fp8 GEMM: the 256x128 tile from this many tiles on, the 128x128 form of the same kernel below
     {"decode_overlap", "MH_DECODE_OVERLAP", 0, false},           // 1: dependent-launch overlap of a chain's token step (two streams per chain + progress words, decode_kernels.hpp): same tokens bit for bit; measured SLOWER than the plain step on the real kernels (profiles/r04_decode_overlap.txt) -- kept as a tested experiment, default off
+    {"decode_launch_threads", "MH_DECODE_LAUNCH_THREADS", 1, false},   // 1: one host launcher thread per decode chain (graph replay costs ~0.4 ms of host time per step); 0: one thread feeds all chains round robin -- for profilers whose counter passes do not survive concurrent launcher threads (rocprofv3 --pmc)
+    {"decode_graph_cache", "MH_DECODE_GRAPH_CACHE", 1, false},   // 1: instantiated step graphs are kept across mh_t5_generate calls (LRU of 16, exact-description match); 0: captured per call
 };
 
+static thread_local const MhOptionSet* tl_option_set = nullptr;
+
+}  // namespace mh
+
+struct MhOptionSet {
+  long value[mh::OPT_COUNT];
+  bool has[mh::OPT_COUNT];
+};
+
+namespace mh {
+
+OptionScope::OptionScope(const MhOptionSet* set) : prev(tl_option_set) { tl_option_set = set; }
+OptionScope::~OptionScope() { tl_option_set = prev; }
+const MhOptionSet* current_option_set() { return tl_option_set; }
+
 long option(int id) {
+  if (tl_option_set && tl_option_set->has[id]) return tl_option_set->value[id];
   OptionSlot& o = g_options[id];
   if (!o.resolved.load(std::memory_order_acquire)) {
     const char* e = getenv(o.env);
@@ -82,6 +101,39 @@ extern "C" long mh_get_option(const char* name) {
     if (strcmp(mh::g_options[i].name, name) == 0) return mh::option(i);
   mh::set_error("mh_get_option: unknown option '%s'", name ? name : "(null)");
   return -1;
+}
+
+static int option_index(const char* name) {
+  for (int i = 0; name && i < mh::OPT_COUNT; ++i)
+    if (strcmp(mh::g_options[i].name, name) == 0) return i;
+  return -1;
+}
+
+extern "C" MhOptionSet* mh_options_create(void) { return new (std::nothrow) MhOptionSet(); }   // value-initialised: no overrides
+extern "C" void mh_options_destroy(MhOptionSet* set) { delete set; }
+
+extern "C" int mh_options_set(MhOptionSet* set, const char* name, long value) {
+  const int i = option_index(name);
+  if (!set || i < 0) { mh::set_error("mh_options_set: %s '%s'", set ? "unknown option" : "null set,", name ? name : "(null)"); return MH_ERR_ARG; }
+  set->value[i] = value;
+  set->has[i] = true;
+  return MH_OK;
+}
+
+extern "C" int mh_options_clear(MhOptionSet* set, const char* name) {
+  if (!set) { mh::set_error("mh_options_clear: null set"); return MH_ERR_ARG; }
+  if (!name) { for (int i = 0; i < mh::OPT_COUNT; ++i) set->has[i] = false; return MH_OK; }
+  const int i = option_index(name);
+  if (i < 0) { mh::set_error("mh_options_clear: unknown option '%s'", name); return MH_ERR_ARG; }
+  set->has[i] = false;
+  return MH_OK;
+}
+
+extern "C" long mh_options_get(const MhOptionSet* set, const char* name) {
+  const int i = option_index(name);
+  if (i < 0) { mh::set_error("mh_options_get: unknown option '%s'", name ? name : "(null)"); return -1; }
+  mh::OptionScope sc(set);
+  return mh::option(i);
 }
 
 extern "C" const char* mh_last_error(void) { return mh::g_err; }

@@ -478,11 +478,13 @@ int ddpm_step(const float* model_out, const float* x, const float* noise, const 
 using namespace mh;
 
 extern "C" int64_t mh_dit_workspace_bytes(const MhDiTConfig* c, int N, int T) {
+  mh::OptionScope option_scope(c ? c->options : nullptr);
   if (!c || N <= 0 || T <= 0) return -1;
   return dit_ws_layout(c, N, T, nullptr, 0, nullptr) + align256((int64_t)N * 4 * T * 4) + cond_scratch_bytes(c, N);
 }
 
 extern "C" int64_t mh_ddpm_loop_workspace_bytes(const MhDiTConfig* c, int N, int T, int n_steps) {
+  mh::OptionScope option_scope(c ? c->options : nullptr);
   if (!c || N <= 0 || T <= 0 || n_steps <= 0) return -1;
   return dit_ws_layout(c, N, T, nullptr, 0, nullptr) + align256((int64_t)N * 4 * T * 4) +
          cond_scratch_bytes(c, n_steps * N) + align256(cond_floats(c, N) * 4 * (int64_t)n_steps) +
@@ -492,6 +494,7 @@ extern "C" int64_t mh_ddpm_loop_workspace_bytes(const MhDiTConfig* c, int N, int
 extern "C" int mh_dit_forward_cfg(const MhDiTConfig* c, const MhDiTWeights* w, const float* x, const int32_t* t,
                                   const float* cc, const float* y, float cfg_scale, int band, int open_from, int N, int T,
                                   float* out, void* workspace, int64_t workspace_bytes, void* stream) {
+  mh::OptionScope option_scope(c ? c->options : nullptr);
   MH_TRY(check_dit(c, N, T));
   MH_REQUIRE(w && x && t && cc && y && out && workspace, "mh_dit_forward_cfg: null argument");
   MH_REQUIRE(workspace_bytes >= mh_dit_workspace_bytes(c, N, T), "mh_dit_forward_cfg: workspace too small");
@@ -520,6 +523,7 @@ extern "C" int mh_ddpm_sample_loop(const MhDiTConfig* c, const MhDiTWeights* w, 
                                    const int32_t* t_map, const float* coefs, const float* noise,
                                    const uint8_t* inpaint_mask, const float* inpaint_ref, const MhSliderSet* sliders,
                                    void* workspace, int64_t workspace_bytes, void* stream) {
+  mh::OptionScope option_scope(c ? c->options : nullptr);
   MH_TRY(check_dit(c, N, T));
   MH_REQUIRE(w && x_io && cc && y && t_map && coefs && noise && workspace && n_steps > 0,
              "mh_ddpm_sample_loop: null argument");

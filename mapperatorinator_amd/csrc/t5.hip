@@ -8,6 +8,7 @@
 //   model_generate (osuT5/osuT5/inference/server.py:83-156) with the reference logits processors.
 #include <stdlib.h>
 
+#include <atomic>
 #include <functional>
 #include <map>
 #include <mutex>
@@ -59,6 +60,7 @@ using namespace mh;
 // encoder
 // ------------------------------------------------------------------------------------------------
 extern "C" int64_t mh_t5_encode_workspace_bytes(const MhT5Config* c, int B) {
+  mh::OptionScope option_scope(c ? c->options : nullptr);
   if (!c || B <= 0) return -1;
   const int64_t rows = (int64_t)B * c->src_len, es = es_of(c->dtype);
   const int inner = c->n_heads * 64, Lpad = round_up(c->src_len, 64);
@@ -151,11 +153,13 @@ __global__ __launch_bounds__(256) void fill_rows_kernel(float* __restrict__ h, c
 
 extern "C" int mh_t5_encode(const MhT5Config* c, const MhT5Weights* w, const void* mel, int B, void* enc_out,
                             float* enc_out_f32, void* workspace, int64_t workspace_bytes, void* stream) {
+  mh::OptionScope option_scope(c ? c->options : nullptr);
   return mh_t5_encode_cond(c, w, mel, B, nullptr, enc_out, enc_out_f32, workspace, workspace_bytes, stream);
 }
 
 extern "C" int mh_t5_encode_cond(const MhT5Config* c, const MhT5Weights* w, const void* mel, int B, const float* row_bias,
                                  void* enc_out, float* enc_out_f32, void* workspace, int64_t workspace_bytes, void* stream) {
+  mh::OptionScope option_scope(c ? c->options : nullptr);
   MH_TRY(check_cfg(c, "mh_t5_encode"));
   MH_REQUIRE(w && mel && enc_out && workspace && B > 0, "mh_t5_encode: null argument");
   MH_REQUIRE(workspace_bytes >= mh_t5_encode_workspace_bytes(c, B), "mh_t5_encode: workspace too small");
@@ -292,12 +296,14 @@ extern "C" int mh_t5_encode_cond(const MhT5Config* c, const MhT5Weights* w, cons
 }
 
 extern "C" int64_t mh_t5_cross_kv_workspace_bytes(const MhT5Config* c, int B) {
+  mh::OptionScope option_scope(c ? c->options : nullptr);
   if (!c || B <= 0) return -1;
   return c->enc_operand_dtype == MH_MX8 ? mx_operand_bytes((int64_t)B * c->src_len, c->d_model) : 0;
 }
 
 extern "C" int mh_t5_cross_kv_ws(const MhT5Config* c, const MhT5Weights* w, const void* enc_out, int B, void* cross_kv, void* workspace,
                                  int64_t workspace_bytes, void* stream) {
+  mh::OptionScope option_scope(c ? c->options : nullptr);
   MH_TRY(check_cfg(c, "mh_t5_cross_kv"));
   MH_REQUIRE(w && enc_out && cross_kv && B > 0, "mh_t5_cross_kv: null argument");
   if (!enc_mx(c)) return mh_t5_cross_kv(c, w, enc_out, B, cross_kv, stream);
@@ -319,6 +325,7 @@ extern "C" int mh_t5_cross_kv_ws(const MhT5Config* c, const MhT5Weights* w, cons
 
 extern "C" int mh_t5_cross_kv(const MhT5Config* c, const MhT5Weights* w, const void* enc_out, int B, void* cross_kv,
                               void* stream) {
+  mh::OptionScope option_scope(c ? c->options : nullptr);
   MH_TRY(check_cfg(c, "mh_t5_cross_kv"));
   MH_REQUIRE(w && enc_out && cross_kv && B > 0, "mh_t5_cross_kv: null argument");
   MH_REQUIRE(!enc_mx(c), "mh_t5_cross_kv: enc_operand_dtype = MH_MX8 needs scratch for the quantised encoder output: call mh_t5_cross_kv_ws");
@@ -341,7 +348,8 @@ struct DecState {       // device-resident control block
   int pos;              // index of the token being fed this step
   int n_running;        // rows not yet finished (written by the sampler)
   int ticket;           // arrival counter of the sampler's workgroups (the last one advances `pos`)
-  int pad1;
+  unsigned rng_row0;    // MhSampling.rng_row0 and .seed of the running call: written by dec_init_kernel and read from here by
+  unsigned long long seed;   // the sampler, so that the replayed step graph does not carry them (they change call by call)
 };
 
 struct SampleP {
@@ -400,7 +408,7 @@ __global__ __launch_bounds__(256) void dec_init_kernel(SampleP p, int chain_rows
     p.last_ts_val[b] = v;
     p.finished[b] = 0;
     p.finish_col[b] = p.max_length - 1;
-    if (lb == 0) { p.st->pos = start_pos; p.st->n_running = chain_rows; p.st->ticket = 0; }
+    if (lb == 0) { p.st->pos = start_pos; p.st->n_running = chain_rows; p.st->ticket = 0; p.st->rng_row0 = p.sp.rng_row0; p.st->seed = p.sp.seed; }
   }
   const int tok = p.tokens[(long)b * p.max_length + start_pos];
   const T* e = reinterpret_cast<const T*>(p.dec_embed) + (long)tok * p.d;
@@ -644,7 +652,7 @@ __global__ __launch_bounds__(256) void dec_sample_kernel(SampleP p) {
       float base = incl - run;
       for (int w2 = 0; w2 < wid; ++w2) base += sf[w2];
       const float mass = sf[0] + sf[1] + sf[2] + sf[3];
-      const float u = uniform01(sp.seed, (uint32_t)gr + sp.rng_row0, (uint32_t)col) * mass;
+      const float u = uniform01(p.st->seed, (uint32_t)gr + p.st->rng_row0, (uint32_t)col) * mass;
       int first = 0x7fffffff, last = -1;
       float prev = 0.f;
 #pragma unroll
@@ -712,7 +720,7 @@ __global__ __launch_bounds__(256) void dec_sample_kernel(SampleP p) {
         __syncthreads();
       }
       if (tid == 0) {
-        const float u = uniform01(sp.seed, (uint32_t)gr + sp.rng_row0, (uint32_t)col) * s_sum;
+        const float u = uniform01(p.st->seed, (uint32_t)gr + p.st->rng_row0, (uint32_t)col) * s_sum;
         float cum = 0.f;
         int pick = tok;
         for (int v = 0; v < p.V; ++v) {
@@ -1191,6 +1199,7 @@ int64_t prefill_layout(const MhT5Config* c, int B, int np_max, void* base, int64
 }  // namespace mh
 
 extern "C" int64_t mh_t5_decode_workspace_bytes(const MhT5Config* c, int B) {
+  mh::OptionScope option_scope(c ? c->options : nullptr);
   if (!c || B <= 0) return -1;
   const int64_t es = es_of(c->dtype);
   const int inner = c->n_heads * 64;
@@ -1465,12 +1474,14 @@ __global__ __launch_bounds__(256) void kv_quant_fp8_kernel(const bf16_t* src, ui
 }
 
 extern "C" int64_t mh_t5_cross_kv_fp8_bytes(const MhT5Config* c, int B) {
+  mh::OptionScope option_scope(c ? c->options : nullptr);
   if (!c || B <= 0) return -1;
   const int64_t data = (int64_t)c->n_dec_layers * 2 * B * c->n_heads * c->src_len * 64;
   return align256(data) + align256((int64_t)c->n_dec_layers * 2 * B * c->n_heads * 4);
 }
 
 extern "C" int mh_t5_quantize_cross_kv(const MhT5Config* c, const void* cross_kv, int B, void* out, void* stream) {
+  mh::OptionScope option_scope(c ? c->options : nullptr);
   MH_TRY(check_cfg(c, "mh_t5_quantize_cross_kv"));
   MH_REQUIRE(cross_kv && out && B > 0, "mh_t5_quantize_cross_kv: null argument");
   MH_REQUIRE(c->dtype == MH_BF16, "mh_t5_quantize_cross_kv: needs bf16 storage");
@@ -1481,11 +1492,83 @@ extern "C" int mh_t5_quantize_cross_kv(const MhT5Config* c, const void* cross_kv
   return check_launch("kv_quant_fp8_kernel");
 }
 
+namespace mh {
+// ------------------------------------------------------------------------------------------------
+// Instantiated step graphs kept ACROSS mh_t5_generate calls.  A chain's step graph bakes in nothing but addresses, sizes, the
+// sampling struct and the kernel choice (the position and every per-call state live in device memory), so a later call
+// whose inputs are byte-for-byte the same description -- the normal case of an engine that decodes window after window out
+// of the same workspace with the same prompt length -- replays the graph of the earlier one instead of capturing and
+// instantiating ~75 nodes again.  The key is the exact byte string of everything enqueue_step() receives plus every option
+// value and the timing hook (exact compare: a spurious difference costs a capture, never a wrong graph).  Small LRU; an entry in
+// use by a concurrent call is never shared (hipGraphExec objects are single-flight) nor evicted.  Option decode_graph_cache = 0
+// switches it off.
+struct StepGraphEntry {
+  std::vector<unsigned char> key;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  uint64_t stamp = 0;
+  bool in_use = false;
+};
+constexpr size_t kStepGraphCacheMax = 16;
+static std::mutex g_step_graph_mu;
+static std::vector<StepGraphEntry*> g_step_graphs;
+static uint64_t g_step_graph_clock = 0;
+static std::atomic<long> g_step_graph_hits{0}, g_step_graph_misses{0};
+
+static StepGraphEntry* step_graph_acquire(const std::vector<unsigned char>& key) {
+  std::lock_guard<std::mutex> lk(g_step_graph_mu);
+  for (StepGraphEntry* e : g_step_graphs)
+    if (!e->in_use && e->key == key) {
+      e->in_use = true;
+      e->stamp = ++g_step_graph_clock;
+      return e;
+    }
+  return nullptr;
+}
+
+// takes ownership of graph / exec; returns the entry (in use) -- or nullptr when the cache is full of entries in use
+static StepGraphEntry* step_graph_insert(std::vector<unsigned char>&& key, hipGraph_t graph, hipGraphExec_t exec) {
+  std::lock_guard<std::mutex> lk(g_step_graph_mu);
+  while (g_step_graphs.size() >= kStepGraphCacheMax) {
+    int victim = -1;
+    for (size_t i = 0; i < g_step_graphs.size(); ++i)
+      if (!g_step_graphs[i]->in_use && (victim < 0 || g_step_graphs[i]->stamp < g_step_graphs[victim]->stamp)) victim = (int)i;
+    if (victim < 0) return nullptr;
+    StepGraphEntry* v = g_step_graphs[victim];
+    (void)hipGraphExecDestroy(v->exec);
+    (void)hipGraphDestroy(v->graph);
+    delete v;
+    g_step_graphs.erase(g_step_graphs.begin() + victim);
+  }
+  StepGraphEntry* e = new StepGraphEntry();
+  e->key = std::move(key);
+  e->graph = graph;
+  e->exec = exec;
+  e->in_use = true;
+  e->stamp = ++g_step_graph_clock;
+  g_step_graphs.push_back(e);
+  return e;
+}
+
+static void step_graph_release(StepGraphEntry* e) {
+  std::lock_guard<std::mutex> lk(g_step_graph_mu);
+  e->in_use = false;
+}
+}  // namespace mh
+
+extern "C" int mh_t5_step_graph_cache_stats(long* hits, long* misses, int reset) {
+  if (hits) *hits = mh::g_step_graph_hits.load();
+  if (misses) *misses = mh::g_step_graph_misses.load();
+  if (reset) { mh::g_step_graph_hits.store(0); mh::g_step_graph_misses.store(0); }
+  return MH_OK;
+}
+
 extern "C" int mh_t5_generate(const MhT5Config* c, const MhT5Weights* w, const void* cross_kv, int B,
                               const int32_t* prompt, const uint8_t* prompt_mask, int P, const uint8_t* eos_table,
                               const MhSampling* sp, int32_t* tokens, int32_t* n_steps_out, float* logits_dump,
                               const int32_t* forced, void* workspace, int64_t workspace_bytes, int poll_every,
                               void* stream) {
+  mh::OptionScope option_scope(c ? c->options : nullptr);
   MH_TRY(check_cfg(c, "mh_t5_generate"));
   MH_REQUIRE(w && cross_kv && prompt && eos_table && sp && tokens && n_steps_out && workspace,
              "mh_t5_generate: null argument");
@@ -1568,6 +1651,7 @@ extern "C" int mh_t5_generate(const MhT5Config* c, const MhT5Weights* w, const v
   const bool bf16 = c->dtype == MH_BF16;
   hipGraph_t graphs[kMaxChains] = {};
   hipGraphExec_t execs[kMaxChains] = {};
+  StepGraphEntry* cached[kMaxChains] = {};     // chains whose graph lives in the cross-call cache (not destroyed below)
   DecState* states[kMaxChains] = {};
   dec::DepSync* syncs[kMaxChains] = {};
   std::function<int()> eager_step[kMaxChains];
@@ -1630,7 +1714,33 @@ extern "C" int mh_t5_generate(const MhT5Config* c, const MhT5Weights* w, const v
       ++used;
       continue;
     }
-    // capture one step of this chain (every kernel reads the position from device memory) for replay
+    // one step of this chain (every kernel reads the position from device memory) as a graph for replay: an earlier call's, if
+    // its description is byte for byte this one's, else captured now
+    std::vector<unsigned char> key;
+    if (option(OPT_DECODE_GRAPH_CACHE) != 0) {
+      auto put = [&key](const void* p, size_t n) { key.insert(key.end(), (const unsigned char*)p, (const unsigned char*)p + n); };
+      MhT5Config cc = *c;
+      cc.options = nullptr;
+      long opts[OPT_COUNT];
+      for (int o = 0; o < OPT_COUNT; ++o) opts[o] = option(o);
+      int dev_id = 0;
+      (void)hipGetDevice(&dev_id);
+      const void* ptrs[] = {ckv, pm, kv8, kv8_scales, (const void*)g_timing.buf};
+      const int ints[] = {Bc, B, kvB, P, g_timing.ring, dev_id, bf16 ? 1 : 0};
+      put(&cc, sizeof(cc)); put(opts, sizeof(opts)); put(w, sizeof(*w)); put(ptrs, sizeof(ptrs)); put(ints, sizeof(ints));
+      SampleP smp_key = smp;          // (seed and rng_row0 reach the sampler through DecState, not through the graph)
+      smp_key.sp.seed = 0;
+      smp_key.sp.rng_row0 = 0;
+      put(&bf, sizeof(bf)); put(&smp_key, sizeof(smp_key));
+      if (StepGraphEntry* e = step_graph_acquire(key)) {
+        cached[ci] = e;
+        execs[ci] = e->exec;
+        g_step_graph_hits.fetch_add(1);
+        ++used;
+        continue;
+      }
+      g_step_graph_misses.fetch_add(1);
+    }
     if (hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) != hipSuccess) { rc = check_launch("begin capture"); break; }
     int rce = bf16 ? enqueue_step<bf16_t>(c, w, ckv, Bc, B, kvB, pm, P, bf, smp, cs, kv8, kv8_scales)
                    : enqueue_step<float>(c, w, ckv, Bc, B, kvB, pm, P, bf, smp, cs, kv8, kv8_scales);
@@ -1639,6 +1749,12 @@ extern "C" int mh_t5_generate(const MhT5Config* c, const MhT5Weights* w, const v
     if (rce != MH_OK) { rc = rce; break; }
     if (ce != hipSuccess || !graphs[ci]) { set_error("mh_t5_generate: stream capture failed: %s", hipGetErrorString(ce)); rc = MH_ERR_LAUNCH; break; }
     if (hipGraphInstantiate(&execs[ci], graphs[ci], nullptr, nullptr, 0) != hipSuccess) { rc = check_launch("graph instantiate"); break; }
+    if (!key.empty()) {
+      if (StepGraphEntry* e = step_graph_insert(std::move(key), graphs[ci], execs[ci])) {
+        cached[ci] = e;          // the cache owns graph and exec now
+        graphs[ci] = nullptr;
+      }
+    }
   }
 
   const int total_steps = sp->max_length - 1 - start_pos;   // positions start_pos .. max_length-2 are fed
@@ -1669,9 +1785,36 @@ extern "C" int mh_t5_generate(const MhT5Config* c, const MhT5Weights* w, const v
     int rcs[kMaxChains] = {};
     if (used <= 1) {
       if (used == 1) rcs[0] = run_chain(0);
+    } else if (option(OPT_DECODE_LAUNCH_THREADS) == 0) {
+      // one thread, the chains' steps interleaved (slower on the host side; the same kernels with the same arguments)
+      bool alive[kMaxChains];
+      for (int ci = 0; ci < used; ++ci) alive[ci] = true;
+      for (int step = 0; step < total_steps;) {
+        const int burst = total_steps - step < poll_every ? total_steps - step : poll_every;
+        for (int i = 0; i < burst; ++i)
+          for (int ci = 0; ci < used; ++ci) {
+            if (!alive[ci] || rcs[ci] != MH_OK) continue;
+            if (eager_step[ci]) { if (eager_step[ci]() != MH_OK) rcs[ci] = MH_ERR_LAUNCH; }
+            else if (hipGraphLaunch(execs[ci], chain_stream[ci]) != hipSuccess) rcs[ci] = MH_ERR_LAUNCH;
+          }
+        step += burst;
+        bool any = false;
+        for (int ci = 0; ci < used; ++ci) {
+          if (!alive[ci] || rcs[ci] != MH_OK) continue;
+          if (step < total_steps && !forced) {
+            int running = 1;
+            if (hipMemcpyAsync(&running, &states[ci]->n_running, 4, hipMemcpyDeviceToHost, chain_stream[ci]) != hipSuccess ||
+                hipStreamSynchronize(chain_stream[ci]) != hipSuccess) { rcs[ci] = MH_ERR_LAUNCH; continue; }
+            if (running == 0) alive[ci] = false;
+          }
+          any = any || alive[ci];
+        }
+        if (!any) break;
+      }
     } else {
       std::vector<std::thread> th;
-      for (int ci = 1; ci < used; ++ci) th.emplace_back([&, ci] { rcs[ci] = run_chain(ci); });
+      const MhOptionSet* set = current_option_set();   // thread-local in the caller: re-installed in every launcher
+      for (int ci = 1; ci < used; ++ci) th.emplace_back([&, ci, set] { OptionScope sc(set); rcs[ci] = run_chain(ci); });
       rcs[0] = run_chain(0);
       for (auto& t : th) t.join();
     }
@@ -1700,6 +1843,7 @@ extern "C" int mh_t5_generate(const MhT5Config* c, const MhT5Weights* w, const v
     }
   }
   for (int ci = 0; ci < kMaxChains; ++ci) {
+    if (cached[ci]) { step_graph_release(cached[ci]); continue; }
     if (execs[ci]) (void)hipGraphExecDestroy(execs[ci]);
     if (graphs[ci]) (void)hipGraphDestroy(graphs[ci]);
   }
@@ -1712,6 +1856,7 @@ extern "C" int mh_t5_generate(const MhT5Config* c, const MhT5Weights* w, const v
 // decoder stack at once (the batched prefill path: MFMA GEMMs + flash attention, causal + key mask), then the
 // final RMSNorm and lm_head.  logits fp32 [B, T, V].
 extern "C" int64_t mh_t5_forward_workspace_bytes(const MhT5Config* c, int B, int T) {
+  mh::OptionScope option_scope(c ? c->options : nullptr);
   if (!c || B <= 0 || T <= 0) return -1;
   const int64_t es = es_of(c->dtype);
   return mh::prefill_layout(c, B, T, nullptr, 0, nullptr) +
@@ -1721,6 +1866,7 @@ extern "C" int64_t mh_t5_forward_workspace_bytes(const MhT5Config* c, int B, int
 extern "C" int mh_t5_decoder_forward(const MhT5Config* c, const MhT5Weights* w, const void* cross_kv, int B,
                                      const int32_t* ids, const uint8_t* mask, int T, float* logits, void* workspace,
                                      int64_t workspace_bytes, void* stream) {
+  mh::OptionScope option_scope(c ? c->options : nullptr);
   MH_TRY(check_cfg(c, "mh_t5_decoder_forward"));
   for (int l = 0; l < c->n_dec_layers; ++l)
     MH_REQUIRE(!is_local_layer(c, l), "mh_t5_decoder_forward: local (windowed) layers have no batched prompt path -- use mh_t5_generate with `forced` and `logits_dump`");
@@ -1779,6 +1925,10 @@ extern "C" int mh_wall_clock_khz(void) {   // rate of the device wall clock the 
 }
 
 extern "C" int mh_t5_decode_chains(int B) { return B > 0 ? mh::pick_chains(B) : 0; }
+extern "C" int mh_t5_decode_chains_cfg(const MhT5Config* c, int B) {   // ... under the engine's option set
+  mh::OptionScope option_scope(c ? c->options : nullptr);
+  return B > 0 ? mh::pick_chains(B) : 0;
+}
 
 // ------------------------------------------------------------------------------------------------
 // Measurement hook for bench.py's roofline line: the dominant decode kernel (cross-attention over the
@@ -1787,6 +1937,7 @@ extern "C" int mh_t5_decode_chains(int B) { return B > 0 ? mh::pick_chains(B) : 
 // K/V: B*H*L*64*2 elements).  ms_out[0] = average milliseconds per launch (split kernel + merge kernel).
 extern "C" int mh_t5_cross_attn_probe(const MhT5Config* c, const MhT5Weights* w, const void* cross_kv, int B, int reps,
                                       float* ms_out, void* workspace, int64_t workspace_bytes, void* stream) {
+  mh::OptionScope option_scope(c ? c->options : nullptr);
   MH_TRY(check_cfg(c, "mh_t5_cross_attn_probe"));
   MH_REQUIRE(cross_kv && ms_out && workspace && B > 0 && B <= 64 && reps > 0, "mh_t5_cross_attn_probe: bad argument");
   MH_REQUIRE(workspace_bytes >= mh_t5_decode_workspace_bytes(c, B), "mh_t5_cross_attn_probe: workspace too small");
@@ -1843,6 +1994,7 @@ extern "C" int mh_t5_cross_attn_probe(const MhT5Config* c, const MhT5Weights* w,
 extern "C" int mh_t5_step(const MhT5Config* c, const MhT5Weights* w, const void* cross_kv, int B, int kv_group, const int32_t* ids,
                           int pos, const uint8_t* prompt_mask, int P, float* logits, void* workspace, int64_t workspace_bytes,
                           void* stream) {
+  mh::OptionScope option_scope(c ? c->options : nullptr);
   MH_TRY(check_cfg(c, "mh_t5_step"));
   MH_REQUIRE(w && cross_kv && ids && logits && workspace, "mh_t5_step: null argument");
   MH_REQUIRE(B > 0 && B <= 64, "mh_t5_step: batch %d not in [1, 64]", B);
@@ -1880,11 +2032,13 @@ extern "C" int mh_t5_step(const MhT5Config* c, const MhT5Weights* w, const void*
 // self-attention cache rows of every layer: row b <- row src[b] for positions 0 .. n_pos-1 (`cache.reorder_cache(beam_idx)`).
 // scratch: 2 * n_dec * B * inner * n_pos elements of the storage type (mh_t5_reorder_cache_scratch_bytes).
 extern "C" int64_t mh_t5_reorder_cache_scratch_bytes(const MhT5Config* c, int B, int n_pos) {
+  mh::OptionScope option_scope(c ? c->options : nullptr);
   if (!c || B <= 0 || n_pos <= 0) return -1;
   return align256(2LL * c->n_dec_layers * B * c->n_heads * 64 * n_pos * es_of(c->dtype));
 }
 extern "C" int mh_t5_reorder_cache(const MhT5Config* c, int B, const int32_t* src, int n_pos, void* workspace, int64_t workspace_bytes,
                                    void* scratch, int64_t scratch_bytes, void* stream) {
+  mh::OptionScope option_scope(c ? c->options : nullptr);
   MH_TRY(check_cfg(c, "mh_t5_reorder_cache"));
   MH_REQUIRE(src && workspace && scratch && B > 0 && B <= 64 && n_pos > 0 && n_pos <= c->tgt_len, "mh_t5_reorder_cache: bad argument");
   MH_REQUIRE(workspace_bytes >= mh_t5_decode_workspace_bytes(c, B) && scratch_bytes >= mh_t5_reorder_cache_scratch_bytes(c, B, n_pos),

@@ -33,7 +33,8 @@ class DiTHIP:
     """fp32 DiT denoiser on libmapperhip.  `state_dict` uses the reference's parameter names."""
 
     def __init__(self, state_dict: dict, depth: int, hidden: int, num_heads: int, context_size: int = 272,
-                 class_size: int = 300, device="cuda", operand_dtype: torch.dtype = torch.float32):
+                 class_size: int = 300, device="cuda", operand_dtype: torch.dtype = torch.float32,
+                 options: Optional[dict] = None):
         self.require_gpu()
         if hidden != num_heads * 64:
             raise NotImplementedError("HIP attention kernels are built for head_dim = 64")
@@ -122,6 +123,8 @@ class DiTHIP:
                 w.fc2_wm[l], w.fc2_wms[l] = tm(sd[b + "mlp.fc2.weight"])
         w.fin_ada_w, w.fin_ada_b = t(sd["final_layer.adaLN_modulation.1.weight"]), t(sd["final_layer.adaLN_modulation.1.bias"])
         w.fin_w, w.fin_b = t(sd["final_layer.linear.weight"]), t(sd["final_layer.linear.bias"])
+        self.options = _lib.OptionSet(options)          # this denoiser's own overrides of the library's tuning options
+        cfg.options = self.options.handle
         self.cfg, self.w = cfg, w
         self.stream = self.new_stream()
         self._ws = None

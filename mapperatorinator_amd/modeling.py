@@ -43,8 +43,9 @@ class MapperatorinatorHIP:
                  dtype: torch.dtype = torch.bfloat16, device="cuda", sample_rate: int = 16000, n_fft: int = 1024,
                  hop_length: int = 128, f_min: int = 0, f_max: int = 8000, spectrogram_log_scale: bool = False,
                  pad_token_id: int = 0, bos_token_id: int = 1, eos_token_id: int = 2, backbone_options: Optional[dict] = None,
-                 enc_operand_dtype: Optional[str] = None):
-        """`dims`: T5Dims (google/t5-v1_1-*) or VarWhisperDims (OliBomby/varwhisper-*; `src_seq_len` then counts log-mel
+                 enc_operand_dtype: Optional[str] = None, options: Optional[dict] = None):
+        """`options`: engine-owned overrides of the library's tuning options (T5Engine).
+        `dims`: T5Dims (google/t5-v1_1-*) or VarWhisperDims (OliBomby/varwhisper-*; `src_seq_len` then counts log-mel
         frames as the reference's data.src_seq_len does, `backbone_options` = global_rope_theta / local_rope_theta /
         global_attn_every_n_layers / local_attention)."""
         self.is_whisper = isinstance(dims, VarWhisperDims)
@@ -52,11 +53,11 @@ class MapperatorinatorHIP:
             raise NotImplementedError("MX-fp8 encoder operands are built for the T5 backbone only")
         if self.is_whisper:
             self.engine = VarWhisperEngine(state_dict, dims, vocab_size_in, vocab_size_out, n_mels, src_seq_len, tgt_seq_len,
-                                           dtype, device, sample_rate, n_fft, hop_length, f_min, f_max, **(backbone_options or {}))
+                                           dtype, device, sample_rate, n_fft, hop_length, f_min, f_max, options=options, **(backbone_options or {}))
         else:
             self.engine = T5Engine(state_dict, dims, vocab_size_in, vocab_size_out, n_mels, src_seq_len, tgt_seq_len,
                                    dtype, device, sample_rate, n_fft, hop_length, f_min, f_max, spectrogram_log_scale,
-                                   enc_operand_dtype=enc_operand_dtype)
+                                   enc_operand_dtype=enc_operand_dtype, options=options)
         self._source_state_dict = state_dict      # caller-owned tensors under the reference's parameter names (not copied)
         # difficulty / mapper / song-position / style embedders, if the state dict carries them (host side; their output
         # reaches the device as a per-chunk row bias of the encoder input projection)

@@ -225,7 +225,10 @@ class T5Engine:
     def __init__(self, state_dict: dict, dims: T5Dims, vocab_in: int, vocab_out: int, n_mels: int = 388,
                  src_len: int = 1251, tgt_len: int = 512, dtype: torch.dtype = torch.bfloat16, device="cuda",
                  sample_rate: int = 16000, n_fft: int = 1024, hop_length: int = 128, f_min: int = 0,
-                 f_max: int = 8000, log_scale: bool = False, enc_operand_dtype: Optional[str] = None):
+                 f_max: int = 8000, log_scale: bool = False, enc_operand_dtype: Optional[str] = None,
+                 options: Optional[dict] = None):
+        """`options`: this engine's own overrides of the library's tuning options ({"decode_chains": 1, ...}; names in
+        include/mapperhip.h) -- other engines in the process keep theirs.  `self.options[name] = v` changes one later."""
         if not torch.cuda.is_available():
             raise RuntimeError("T5Engine needs a ROCm GPU; there is no CPU fallback")
         self.lib = _lib.load()
@@ -238,6 +241,11 @@ class T5Engine:
         self.hop_length, self.src_len, self.tgt_len = hop_length, src_len, tgt_len
         self.stream = torch.cuda.Stream(self.device)
         self._ws = {}
+        self._own_options(options)
+
+    def _own_options(self, options: Optional[dict]):
+        self.options = _lib.OptionSet(options)
+        self.packed.cfg.options = self.options.handle
 
     # ---- buffers ---------------------------------------------------------------------------------
     def _workspace(self, kind: str, nbytes: int) -> torch.Tensor:

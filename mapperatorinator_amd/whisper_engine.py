@@ -177,7 +177,7 @@ class VarWhisperEngine(T5Engine):
                  src_len: int = 2048, tgt_len: int = 2560, dtype: torch.dtype = torch.bfloat16, device="cuda",
                  sample_rate: int = 16000, n_fft: int = 1024, hop_length: int = 128, f_min: int = 20, f_max: int = 8000,
                  global_rope_theta: float = 10000.0, local_rope_theta: float = 10000.0, global_attn_every_n_layers: int = 1,
-                 local_attention: int = 128):
+                 local_attention: int = 128, options: Optional[dict] = None):
         """`src_len` = log-mel frames per chunk as in the reference's config (data.src_seq_len); the encoder (and the
         cross-attention) sees (src_len - 1) // 2 + 1 positions."""
         if not torch.cuda.is_available():
@@ -192,6 +192,7 @@ class VarWhisperEngine(T5Engine):
         self.hop_length, self.in_frames, self.src_len, self.tgt_len = hop_length, src_len, self.packed.src_len, tgt_len
         self.stream = torch.cuda.Stream(self.device)
         self._ws = {}
+        self._own_options(options)
 
     def mel(self, audio: torch.Tensor) -> torch.Tensor:
         """(B, Ns) fp32 -> (B, in_frames, n_mels_pad) log-mel frames in the storage dtype: the time-major transpose of the

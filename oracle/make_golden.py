@@ -416,6 +416,17 @@ def pipeline_case():
         out["positions" + tag] = rh.reference_pipeline_positions(ref, seq_x, seq_o, seq_c, cv, ucv, noise,
                                                                  start_time=start_time, end_time=end_time,
                                                                  sliders=sliders if "sliders" in tag else (), **kk).numpy()
+        if "short" not in tag:
+            # the fp32 noise floor of the long runs: the SAME reference pipeline and draws around a second, independent fp32
+            # CPU implementation of the denoiser (oracle/dit.py).  Where these two disagree a third fp32 implementation (the
+            # device) cannot be asked to agree better -- the GPU gate is a multiple of this spread, not a constant.
+            from oracle import dit as odit
+            alt = odit.DiTOracle(sd, depth, hidden, heads)
+            out["positions" + tag + "_alt"] = rh.reference_pipeline_positions(alt, seq_x, seq_o, seq_c, cv, ucv, list(noise),
+                                                                              start_time=start_time, end_time=end_time,
+                                                                              sliders=sliders if "sliders" in tag else (), **kk).numpy()
+            d = np.abs(out["positions" + tag + "_alt"] - out["positions" + tag]).max(0)
+            print("  floor", tag or "_full", "max", d.max(), "median", np.median(d), "p90", np.quantile(d, 0.9))
     pos = torch.from_numpy(out["positions"])
     np.savez_compressed(os.path.join(OUT, "dit_pipeline.npz"), case=json.dumps(c), start_time=start_time,
                         end_time=end_time, seq_c_slice=seq_c[:, ::37].numpy(), **out)

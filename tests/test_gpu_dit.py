@@ -251,9 +251,19 @@ def test_window_pipeline_matches_reference_golden(variant):
     if "short" in variant:
         assert err.max().item() < 0.05
     else:
-        # (the padded last window -- 44 real points attending 116 zero-embedded pad tokens -- is the most sensitive one:
-        # measured max 12.9 px at one point, median 0.025 px; its tight gate is the pad_short variant, 0.003 px)
-        assert err.median().item() < 0.1 and err.quantile(0.9).item() < 1.0 and err.max().item() < (25.6 if "pad" in variant else 12.8)
+        # The long runs amplify fp32 rounding at a few points, so their gate is relative to the fp32 NOISE FLOOR the fixture
+        # carries: the same reference pipeline and draws around a second, independent fp32 CPU denoiser (oracle/dit.py,
+        # `<key>_alt`, oracle/make_golden.py).  Two CPU fp32 implementations already differ by `floor` -- and those two share
+        # their BLAS (every matmul of both goes through the same sgemm, so only their LayerNorm / softmax / embedding
+        # arithmetic differs); the device changes the summation order of the GEMMs as well (MFMA tiles, split-K).  It must
+        # stay within FLOOR_K x that spread in max / p90 / median -- not within a constant.  Measured on the `full` variant:
+        # max 9.3 vs floor 1.74 px (5.3 x), p90 0.44 vs 0.042 (10.4 x), median 0.014 vs 0.0023 (6 x).
+        floor = (torch.from_numpy(g[key + "_alt"]) - want).abs().max(0).values
+        print(f"   fp32 noise floor px: max {floor.max().item():.4f} median {floor.median().item():.4f} p90 {floor.quantile(0.9).item():.4f}")
+        FLOOR_K = 16.0
+        assert err.max().item() < FLOOR_K * floor.max().item()
+        assert err.quantile(0.9).item() < FLOOR_K * floor.quantile(0.9).item()
+        assert err.median().item() < FLOOR_K * floor.median().item() + 0.01       # (+0.01 px: the median floor is 0.002 px)
     # points outside [start_time, end_time] are never generated: they keep the given positions
     given = torch.stack([torch.from_numpy(x), torch.from_numpy(y)])
     frozen = (torch.from_numpy(times) < float(g["start_time"])) | (torch.from_numpy(times) > float(g["end_time"]))
@@ -263,6 +273,50 @@ def test_window_pipeline_matches_reference_golden(variant):
     assert (pos[0][:, frozen] - given[:, frozen]).abs().max().item() < 1e-3
     assert (want[:, frozen] - given[:, frozen]).abs().max().item() < 1e-3
     assert (pos[0][:, ~frozen] - given[:, ~frozen]).abs().mean().item() > 10
+
+
+def test_reference_closure_protocol_on_the_device_vs_pipeline_golden():
+    """The device half of tests/test_oracle_pinned.py::test_the_three_integration_edits_applied_together: the reference's
+    pipeline hands `p_sample_loop` / `p_sample` a plain python closure as `denoised_fn` (diffusion_pipeline.py:201-222), which
+    `SpacedDiffusionHIP` serves with the two-call mh_ddpm_step protocol (raw eps -> x0 out, the closure's x0 back in).  The same
+    window loop with exactly such closures on the real engine must land on the reference's positions (fixture `short`), and on
+    the positions of the fused in-paint path (same arithmetic, FMA contraction aside: 1e-3 px)."""
+    import json
+
+    from mapperatorinator_amd.diffusion_pipeline import DiffusionPipelineHIP, points_to_sequence
+    from mapperatorinator_amd.dit import DiTHIP
+    from mapperatorinator_amd.testing import DIT_PRESETS, random_dit_state_dict, synthetic_hit_objects
+    g = np.load(f"{GOLDEN}/dit_pipeline.npz")
+    c = json.loads(str(g["case"]))
+    depth, hidden, heads = DIT_PRESETS[c["preset"]]
+    dit = DiTHIP(random_dit_state_dict(depth, hidden, seed=c["weight_seed"]), depth, hidden, heads, device="cuda")
+    x, y, times, dist, typ = synthetic_hit_objects(c["T"], c["point_seed"])
+    seq_x, seq_o, seq_c = points_to_sequence(x, y, times, dist, typ)
+    cv, ucv = torch.zeros(300), torch.zeros(300)
+    cv[c["classes"]] = 1
+    ucv[c["null_classes"]] = 1
+    k = dict(c["knobs"], timesteps=[2] + [0] * 9, refine_iters=1)
+    pipe = DiffusionPipelineHIP(dit, timesteps=k["timesteps"], seq_len=k["seq_len"], max_seq_len=k["max_seq_len"],
+                                overlap_buffer=k["overlap_buffer"], cfg_scale=k["cfg_scale"], refine_model=dit,
+                                refine_iters=k["refine_iters"], start_time=float(g["start_time"]), end_time=float(g["end_time"]))
+    closures = []
+
+    def factory(mask, z_part, start, end):          # what `sample_part` builds (:201-206, no sliders)
+        def denoised_fn(x0):
+            closures.append((start, end))
+            return torch.where(mask, x0, z_part)
+        return denoised_fn
+
+    def run(**kw):
+        rng = np.random.default_rng(c["noise_seed"] + 1)
+        src = lambda n, shape: torch.from_numpy(np.stack([rng.standard_normal(shape).astype(np.float32) for _ in range(n)]))
+        return pipe.generate_positions(seq_x, seq_o, seq_c, cv, ucv, noise_source=src, **kw)
+    pos = run(denoised_fn_factory=factory)
+    n_windows = len(range(0, c["T"] - 2 * k["overlap_buffer"], k["max_seq_len"] - 2 * k["overlap_buffer"]))
+    assert len(closures) == n_windows * (1 + 2 + 1)          # the initial in-paint, 2 DDPM steps, 1 refine step per window
+    want = torch.from_numpy(g["positions_short"])
+    assert (pos[0] - want).abs().max().item() < 0.05
+    assert (pos - run()).abs().max().item() < 1e-3
 
 
 @pytest.mark.parametrize("variant", ["short", "full"])

@@ -968,3 +968,95 @@ def test_decode_overlap_is_bit_identical_to_the_plain_step_at_the_headline_batch
             assert torch.equal(ov["logits"][:n], plain["logits"][:n]), f"run {rep}: logits differ under decode_overlap"
     finally:
         _lib.set_option("decode_overlap", old)
+
+
+def test_engines_own_their_option_sets():
+    """ABI 8: two engines in ONE process with different kernel variants (MhT5Config.options), interleaved with a third that
+    follows the process-wide values -- every one reproduces the reference's greedy ids, an engine's override wins over
+    mh_set_option, and the process-wide value is untouched by the sets."""
+    import ctypes as C
+
+    from mapperatorinator_amd import _lib
+    from mapperatorinator_amd.modeling import MapperatorinatorHIP
+    from mapperatorinator_amd.server import model_generate
+    from mapperatorinator_amd.t5_engine import T5_PRESETS
+    g, size, tok, sd, audio, src, tgt = golden_case("t5_tiny")
+    lib = _lib.load()
+
+    def make(options):
+        return MapperatorinatorHIP(sd, T5_PRESETS[size], vocab_size_in=tok.vocab_size_in, vocab_size_out=tok.vocab_size_out,
+                                   src_seq_len=src, tgt_seq_len=tgt, dtype=torch.float32, device="cuda", options=options)
+    a = make(dict(decode_chains=1, decode_fused_proj=0, decode_graph_cache=0))
+    b = make(dict(decode_chains=3, decode_gemv_cols=4))
+    plain = make(None)
+    assert a.engine.options["decode_chains"] == 1 and b.engine.options["decode_chains"] == 3
+    assert lib.mh_get_option(b"decode_chains") == 0 and plain.engine.options["decode_chains"] == 0
+    assert lib.mh_t5_decode_chains_cfg(C.byref(a.engine.packed.cfg), 3) == 1
+    assert lib.mh_t5_decode_chains_cfg(C.byref(b.engine.packed.cfg), 3) == 3
+    with pytest.raises(RuntimeError, match="unknown option"):
+        a.engine.options["no_such_option"] = 1
+    prompt = torch.from_numpy(g["prompt"])
+    mk = dict(inputs=audio, decoder_input_ids=prompt, decoder_attention_mask=prompt.ne(0))
+    for m in (a, b, plain, b, a):
+        ids, _ = model_generate(m, tok, mk, gen_kwargs(tgt))
+        assert np.array_equal(ids.numpy(), g["ids"])
+    old = _lib.set_option("decode_chains", 2)
+    try:
+        assert plain.engine.options["decode_chains"] == 2 and a.engine.options["decode_chains"] == 1
+        assert lib.mh_t5_decode_chains_cfg(C.byref(plain.engine.packed.cfg), 3) == 2
+        b.engine.options.clear("decode_chains")
+        assert b.engine.options["decode_chains"] == 2 and b.engine.options["decode_gemv_cols"] == 4
+        for m in (plain, a, b):
+            ids, _ = model_generate(m, tok, mk, gen_kwargs(tgt))
+            assert np.array_equal(ids.numpy(), g["ids"])
+    finally:
+        _lib.set_option("decode_chains", old)
+
+
+def test_step_graphs_are_replayed_across_generate_calls():
+    """Item "cache instantiated step graphs": a second mh_t5_generate whose description (addresses, sizes, sampling fields other
+    than the seed, options, weights) is byte for byte the first one's replays the first one's graphs.  Greedy ids stay the
+    golden ones; sampled runs with different seeds share the graphs (seed and rng_row0 travel through the device state block)
+    and give exactly what an engine that captures per call gives for the same seeds."""
+    import ctypes as C
+
+    from mapperatorinator_amd import _lib
+    from mapperatorinator_amd.modeling import MapperatorinatorHIP
+    from mapperatorinator_amd.server import model_generate
+    from mapperatorinator_amd.t5_engine import T5_PRESETS
+    g, size, tok, sd, audio, src, tgt = golden_case("t5_small")
+    lib = _lib.load()
+
+    def make(options):
+        return MapperatorinatorHIP(sd, T5_PRESETS[size], vocab_size_in=tok.vocab_size_in, vocab_size_out=tok.vocab_size_out,
+                                   src_seq_len=src, tgt_seq_len=tgt, dtype=torch.float32, device="cuda", options=options)
+
+    def stats(reset=0):
+        h, m = C.c_long(0), C.c_long(0)
+        lib.mh_t5_step_graph_cache_stats(C.byref(h), C.byref(m), reset)
+        return h.value, m.value
+    cached, percall = make(None), make(dict(decode_graph_cache=0))
+    prompt = torch.from_numpy(g["prompt"])
+    mk = dict(inputs=audio, decoder_input_ids=prompt, decoder_attention_mask=prompt.ne(0))
+    stats(reset=1)
+    for _ in range(3):
+        ids, _ = model_generate(cached, tok, mk, gen_kwargs(tgt))
+        assert np.array_equal(ids.numpy(), g["ids"])
+    h, m = stats()
+    n_chains = lib.mh_t5_decode_chains_cfg(C.byref(cached.engine.packed.cfg), prompt.shape[0])
+    print("step graphs: hits", h, "captures", m, "chains", n_chains)
+    assert m >= n_chains and h >= n_chains, "the repeated call did not find its graphs"
+    ids, _ = model_generate(percall, tok, mk, gen_kwargs(tgt))
+    assert np.array_equal(ids.numpy(), g["ids"]) and stats() == (h, m)        # the per-call engine never touches the cache
+    # sampling: three seeds on the cached engine (graphs shared between them) == the per-call engine on the same seeds
+    outs = []
+    for eng in (cached, percall):
+        stats(reset=1)
+        outs.append([model_generate(eng, tok, mk, gen_kwargs(tgt, do_sample=True, top_p=0.9, temperature=1.3, seed=100 + k,
+                                                             seed_call_index=0))[0] for k in range(3)])
+        if eng is cached:
+            h2, m2 = stats()
+            assert h2 >= 2 * n_chains, (h2, m2)
+    for x, y in zip(*outs):
+        assert torch.equal(x, y)
+    assert not torch.equal(outs[0][0], outs[0][1]), "different seeds must draw different tokens"

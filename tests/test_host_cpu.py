@@ -46,11 +46,43 @@ def test_argument_validation_without_gpu():
 
 def test_struct_layouts_match_header_sizes():
     # pointer arrays of MH_MAX_LAYERS entries, ints packed as in C
-    assert C.sizeof(_lib.MhT5Config) == 14 * 4 + 5 * 4 + 4                # ABI 5: arch, attn_scale, in_frames, local_every, local_window; ABI 7: enc_operand_dtype
+    assert C.sizeof(_lib.MhT5Config) == 14 * 4 + 5 * 4 + 4 + 8            # ABI 5: arch, attn_scale, in_frames, local_every, local_window; ABI 7: enc_operand_dtype; ABI 8: options
+    assert C.sizeof(_lib.MhDiTConfig) == 11 * 4 + 4 + 8                    # 4B pad before the ABI 8 options pointer
     base = 4 * 8 + 16 * 4 + 3 * 4 + 4 + 8                                # 4B pad before the uint64 seed
     assert C.sizeof(_lib.MhSampling) == base + 9 * 4 + 4 + 8 + 2 * 4 + 8   # ABI 2 tail: 9 words, pad, tok_flags; ABI 3: 2 words; ABI 4: cross_kv_fp8
     assert C.sizeof(_lib.MhT5Weights) == 8 * (5 + 6 * 32 + 1 + 5 * 32 + 1 + 4 * 32 + 2) + 8 * (4 + 4 * 32 + 3 * 32 + 1 + 3 * 32 + 4) + 8 * (8 * 32 + 2)   # + ABI 5 (arch 1) + ABI 7 (MX-fp8 copies)
     assert C.sizeof(_lib.MhDiTWeights) == 8 * (12 + 10 * 32 + 4 + 1 + 4 * 32 + 4 * 32 + 8 * 32)   # + the pre-split (bf16 x 3), the bf16 and (ABI 7) the MX-fp8 copies
+
+
+def test_option_sets_override_and_fall_through_without_gpu():
+    """ABI 8: an MhOptionSet starts empty (falls through to the process-wide value), holds its own overrides, refuses unknown
+    names, and workspace sizing follows the set named by the config (decode_chains changes nothing there, but the call must
+    resolve options through the set: mh_t5_decode_chains_cfg)."""
+    lib = _lib.load()
+    a, b = _lib.OptionSet(dict(decode_chains=1)), _lib.OptionSet()
+    assert a["decode_chains"] == 1 and b["decode_chains"] == lib.mh_get_option(b"decode_chains")
+    b["decode_chains"] = 3
+    assert (a["decode_chains"], b["decode_chains"]) == (1, 3)
+    old = _lib.set_option("gemm_splitk_tiles", 77)
+    try:
+        assert a["gemm_splitk_tiles"] == 77                 # no override: the process-wide value
+        a["gemm_splitk_tiles"] = 5
+        assert a["gemm_splitk_tiles"] == 5 and b["gemm_splitk_tiles"] == 77 and lib.mh_get_option(b"gemm_splitk_tiles") == 77
+        a.clear("gemm_splitk_tiles")
+        assert a["gemm_splitk_tiles"] == 77
+    finally:
+        _lib.set_option("gemm_splitk_tiles", old)
+    with pytest.raises(RuntimeError, match="unknown option"):
+        a["nope"] = 1
+    assert lib.mh_options_get(a.handle, b"nope") == -1
+    cfg = _lib.MhT5Config(128, 64, 256, 2, 2, 2, 10, 10, 388, 416, 251, 48, 0, 1e-6)
+    assert lib.mh_t5_decode_chains_cfg(C.byref(cfg), 32) == lib.mh_t5_decode_chains(32)
+    cfg.options = a.handle
+    assert lib.mh_t5_decode_chains_cfg(C.byref(cfg), 32) == 1
+    cfg.options = b.handle
+    assert lib.mh_t5_decode_chains_cfg(C.byref(cfg), 32) == 3
+    b.clear()
+    assert lib.mh_t5_decode_chains_cfg(C.byref(cfg), 32) == lib.mh_t5_decode_chains(32)
 
 
 def test_no_cpu_fallback():

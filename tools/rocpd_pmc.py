@@ -4,7 +4,10 @@
 streams: FETCH_SIZE tallies 64 B per 128-B request -> corrected fetch bytes = 2 * FETCH_SIZE * 1024.  WRITE_SIZE is
 uncalibrated and reported raw.
 
-  rocpd_pmc.py FETCH.db WRITE.db OUT.txt [KERNEL_SUBSTRING OUT.json WORKLOAD_NOTE]
+  rocpd_pmc.py FETCH.db WRITE.db OUT.txt [KERNEL_SUBSTRING OUT.json WORKLOAD_NOTE [N_CHAINS ALG_STEP_BYTES]]
+
+With N_CHAINS the JSON also carries the step-level figure: corrected fetch + write bytes of ALL decode-step kernels (dec::*,
+dec_sample_kernel) per token step (token steps = dec_sample_kernel launches / N_CHAINS), and its ratio to ALG_STEP_BYTES.
 """
 import json
 import sqlite3
@@ -42,6 +45,18 @@ def main(argv):
               "hbm_bytes_per_launch": int(round(2 * f * 1024 + w * 1024)), "launches": c,
               "correction": "2 x FETCH_SIZE x 1024 (gfx950 wide-stream half-count) + WRITE_SIZE x 1024",
               "workload": argv[6] if len(argv) > 6 else ""}
+        if len(argv) > 7:
+            n_chains = int(argv[7])
+            dec = [n for n in fetch if "dec::" in n or "dec_sample_kernel" in n]
+            samp = [n for n in dec if "dec_sample_kernel" in n]
+            steps = sum(fetch[n][0] for n in samp) / n_chains
+            tot = sum(fetch[n][0] * (2 * fetch[n][1] * 1024 + write.get(n, (0, 0.0))[1] * 1024) for n in dec)
+            js["step"] = {"decode_chains": n_chains, "token_steps": steps, "decode_kernels": len(dec),
+                          "launches_per_token_step": sum(fetch[n][0] for n in dec) / steps,
+                          "hbm_bytes_per_token_step": int(round(tot / steps))}
+            if len(argv) > 8:
+                js["step"]["alg_bytes_per_token_step"] = int(argv[8])
+                js["step"]["traffic_ratio"] = round(tot / steps / int(argv[8]), 4)
         json.dump(js, open(argv[5], "w"), indent=1)
         print(js)
 
