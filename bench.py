@@ -484,13 +484,26 @@ def main():
     use_us = in_situ_us if in_situ_us else ms.value * 1e3
     use_rows = rows_per_launch if in_situ_us else B
     achieved = use_rows * bytes_per_row / (use_us * 1e-6) / 1e9
+    pmc_record = {}
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r04_pmc_cross_attn.json")) as fh:
+            pmc_record = json.load(fh)
+        pmc_record["rows_per_launch"] = 32 // int(pmc_record.get("step", {}).get("decode_chains", 1))
+    except (OSError, ValueError):
+        pmc_record = {}
     roofline = {
         "bound": "hbm", "kernel": "dec_cross_attn_q_kernel (decode cross-attention over the encoder K/V incl. its query projection)",
         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-        "traffic": None,   # PMC FETCH_SIZE/WRITE_SIZE need rocprofv3 around the process: not measurable from inside this run
-        "traffic_source": "profiles/r03_pmc_hbm_traffic.txt / r03_pmc_cross_attn.json (rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE passes of this "
-                          "command, builder-run, one 32-row chain: 126.24 MB fetched + 0.05 MB written per 122.98 MB launch = 1.027 x "
-                          "algorithmic; the counter passes cannot run inside this process)",
+        # PMC FETCH_SIZE / WRITE_SIZE need rocprofv3 around the process: not measurable from inside this run.  The committed
+        # record of the counter passes of THIS command in the timed configuration (two 16-row chains) is quoted instead.
+        "traffic": pmc_record.get("hbm_bytes_per_launch") if pmc_record.get("rows_per_launch") == use_rows else None,
+        "traffic_source": ("profiles/r04_pmc_cross_attn.json / r04_pmc_hbm_traffic.txt: rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE "
+                           "(separate passes) around this command, builder-run, two 16-row decode chains fed by one launcher thread "
+                           "(MH_DECODE_LAUNCH_THREADS=0); bytes = 2 x FETCH_SIZE x 1024 + WRITE_SIZE x 1024 per launch (gfx950 correction of "
+                           "MI355X_MICROARCH.md); the counter passes cannot run inside this process"),
+        "traffic_over_algorithmic": (round(pmc_record["hbm_bytes_per_launch"] / (use_rows * bytes_per_row), 4)
+                                     if pmc_record.get("rows_per_launch") == use_rows else None),
+        "step_traffic": pmc_record.get("step"),     # all decode kernels of a token step: PMC bytes vs SURVEY 8d bytes
         "how": ("in situ: mean (last workgroup end - first workgroup start) over the launches of one extra decode pass, "
                 "device wall clock; the other chain's kernels run beside it" if in_situ_us else "stand-alone probe"),
         "rows_per_launch": use_rows, "alg_bytes_per_launch": use_rows * bytes_per_row, "us_per_launch": round(use_us, 2),

@@ -88,6 +88,12 @@ int mh_abi_version(void);
  *                                                   round robin (for profilers whose counter passes do not survive concurrent
  *                                                   launcher threads)
  *   "decode_graph_cache" MH_DECODE_GRAPH_CACHE 1    step graphs kept across mh_t5_generate calls (0: captured per call)
+ *   "decode_fold_oproj"  MH_DECODE_FOLD_OPROJ  0    T5 backbone: 1 = the self-attention kernel multiplies its head's output with its
+ *                                                   64 columns of Wo itself (partial rows added in head order downstream): 5
+ *                                                   dependent launches per decoder layer; 2 = the cross-attention kernel as well
+ *                                                   (a row's last workgroup updates the residual stream): 4 launches; 0 = 6.
+ *                                                   fp32 summation order of the output projections differs; measured no faster
+ *                                                   (profiles/r04_decode_fold_oproj.txt)
  *   "decode_overlap"     MH_DECODE_OVERLAP     0    1: dependent-launch overlap of a chain's token step (two streams per chain,
  *                                                   device-side progress words instead of stream order; T5 backbone, chains of
  *                                                   <= 16 rows, d_model 128 / 512 / 768 / 1024).  Bit-identical tokens and logits;

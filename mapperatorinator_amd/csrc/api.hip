@@ -55,6 +55,7 @@ static OptionSlot g_options[OPT_COUNT] = {
     {"decode_overlap", "MH_DECODE_OVERLAP", 0, false},           // 1: dependent-launch overlap of a chain's token step (two streams per chain + progress words, decode_kernels.hpp): same tokens bit for bit; measured SLOWER than the plain step on the real kernels (profiles/r04_decode_overlap.txt) -- kept as a tested experiment, default off
     {"decode_launch_threads", "MH_DECODE_LAUNCH_THREADS", 1, false},   // 1: one host launcher thread per decode chain (graph replay costs ~0.4 ms of host time per step); 0: one thread feeds all chains round robin -- for profilers whose counter passes do not survive concurrent launcher threads (rocprofv3 --pmc)
     {"decode_graph_cache", "MH_DECODE_GRAPH_CACHE", 1, false},   // 1: instantiated step graphs are kept across mh_t5_generate calls (LRU of 16, exact-description match); 0: captured per call
+    {"decode_fold_oproj", "MH_DECODE_FOLD_OPROJ", 0, false},   // T5 backbone: 1 = the self-attention kernel multiplies its head's output with its 64 columns of Wo itself (partial rows, absorbed in head order by the cross-attention prologue and by the cross output projection's residual epilogue): 5 dependent launches per decoder layer; 2 = the cross-attention kernel as well (its row's last workgroup updates the residual stream): 4 launches; 0 = stand-alone output-projection GEMVs: 6 launches.  Same greedy ids in fp32 (GPU tests); measured 688 / 707 / 684 us per token step for 1 / 2 / 0 at the headline batch (profiles/r04_decode_fold_oproj.txt): the removed launches cost what the folded work costs -- default 0
 };
 
 static thread_local const MhOptionSet* tl_option_set = nullptr;

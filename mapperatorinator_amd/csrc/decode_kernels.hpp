@@ -306,7 +306,7 @@ template <bool DEP> __device__ inline void dep_pin(float4& v) {
 //     whole-line loads was built and measured: the extra LDS write / barrier / read costs what the loads save (o-projection
 //     3.61 us alone, 4.12 beside a second chain; whole step 37.4 k vs 38.1 k tok/s without it) -- not kept.
 enum { PRO_PLAIN = 0, PRO_RMSNORM = 1 };
-enum { SK_STORE = 0, SK_QKV = 1, SK_GEGLU = 2, SK_RESID = 3, SK_LOGITS = 4, SK_GELU_ERF = 5 };   // (GELU_ERF: the Whisper family's fc1)
+enum { SK_STORE = 0, SK_QKV = 1, SK_GEGLU = 2, SK_RESID = 3, SK_LOGITS = 4, SK_GELU_ERF = 5, SK_RESID_PARTS = 6 };   // (GELU_ERF: the Whisper family's fc1; RESID_PARTS: RESID + the partial rows of a folded output projection, FoldP)
 
 struct SkinnyP {
   const void* A; int lda;      // PRO_PLAIN: T [B, lda];  PRO_RMSNORM: fp32 residual stream [B, lda]
@@ -320,6 +320,7 @@ struct SkinnyP {
   int H, tgt_len, inner;
   const int* pos;
   const float* bias;           // kernel template BIAS (the Whisper family's biased projections): fp32 [N], else unused
+  const float* parts; int parts_H;   // RESID_PARTS: h[b][n] += sum_hh parts[b][hh][n] (head order) + acc
 };
 
 template <typename T> struct VecOps;
@@ -407,7 +408,7 @@ __global__ __launch_bounds__(NWV * 64) MH_GEMV_WPE_ATTR
 void gemv_kernel(MH_GEMV_LEAD_PARAMS, SkinnyP p, DepP dep) {
   static_assert(!DEP || MF == 1, "the overlap form is built for chains of <= 16 rows");
   p.A = A_; p.W = W_; p.h = h_; p.ln_w = lnw_; p.K = K_; p.lda = K_; p.ldw = K_; p.B = B_; p.N = N_; p.nv = nv_;
-  if (EPI == SK_RESID) p.ldh = N_;   // the residual stream is dense [B, N] (checked on the host)
+  if (EPI == SK_RESID || EPI == SK_RESID_PARTS) p.ldh = N_;   // the residual stream is dense [B, N] (checked on the host)
   constexpr int VEC = Elem<T>::kVec;   // elements per 16-byte vector (per lane per k-block)
   constexpr int KB = 4 * VEC;          // k elements per k-block (4 lane groups x 16 B)
   constexpr int CH = kGemvCH;
@@ -488,7 +489,20 @@ void gemv_kernel(MH_GEMV_LEAD_PARAMS, SkinnyP p, DepP dep) {
       if (unit < MF * 4) dep_ld4<DEP>(oldh[u], p.h + (long)(row < p.B ? row : p.B - 1) * p.ldh + (ocol < p.N ? ocol : p.N - 1)); \
     }                                                                                                                         \
   } while (0)
-  if (!DEP && EPI == SK_RESID && l15 < nv && !(PROBE & 4)) MH_LOAD_OLDH();   // requested before anything is waited for
+  if (!DEP && (EPI == SK_RESID || EPI == SK_RESID_PARTS) && l15 < nv && !(PROBE & 4)) MH_LOAD_OLDH();   // requested before anything is waited for
+  // RESID_PARTS: the partial rows of the folded self-attention output projection (FoldP) that the residual row has not absorbed
+  // yet -- 16 more values per output element, requested with the old value, added in head order in the epilogue
+  float pv[EPI == SK_RESID_PARTS ? UPW : 1][EPI == SK_RESID_PARTS ? 16 : 1];
+  if constexpr (EPI == SK_RESID_PARTS) {
+#pragma unroll
+    for (int u = 0; u < UPW; ++u) {
+      const int unit = wid + u * NWV;
+      const int row = (unit >> 2) * 16 + lg * 4 + (unit & 3);
+      const float* pp = p.parts + ((long)(row < p.B ? row : p.B - 1) * p.parts_H) * p.N + (ocol < p.N ? ocol : p.N - 1);
+#pragma unroll
+      for (int hh = 0; hh < 16; ++hh) pv[u][hh] = (unit < MF * 4 && l15 < nv) ? pp[(long)(hh < p.parts_H ? hh : p.parts_H - 1) * p.N] : 0.f;
+    }
+  }
   const unsigned dep_ep = dep_epoch<DEP>(dep);
   bool dep_waited = false;
 
@@ -723,6 +737,11 @@ void gemv_kernel(MH_GEMV_LEAD_PARAMS, SkinnyP p, DepP dep) {
       if (ok) store_wt(reinterpret_cast<float*>(p.out) + (long)row * p.ldo + ocol, v);
     } else if (EPI == SK_RESID) {
       if (ok) store_wt(p.h + (long)row * p.ldh + ocol, oldh[u] + v);
+    } else if (EPI == SK_RESID_PARTS) {
+      float base = oldh[u];
+#pragma unroll
+      for (int hh = 0; hh < 16; ++hh) base += (hh < p.parts_H) ? pv[u][hh] : 0.f;
+      if (ok) store_wt(p.h + (long)row * p.ldh + ocol, base + v);
     } else if (EPI == SK_QKV) {
       if (ok) {
         const int part = ocol / p.inner, c = ocol - part * p.inner;
@@ -1011,6 +1030,18 @@ struct NormRow {
     dep_ld4<DEP>(x, hp.h + (long)b * hp.ldh + (tid < hp.d ? tid : hp.d - 1));
   }
   __device__ inline void issue(const HeadProjP& hp, int b) { issue_row(hp, b); issue_weight(hp); }
+  // the residual row plus the H partial rows of the folded output projection in front of this kernel, added in head order; all
+  // 1 + 16 loads are in flight together (heads >= H re-read the last one and add nothing): one round trip, like the plain form
+  __device__ inline void issue_row_parts(const HeadProjP& hp, int b, const float* parts, int H) {
+    const int tid = threadIdx.x, k = tid < hp.d ? tid : hp.d - 1;
+    x = hp.h[(long)b * hp.ldh + k];
+    const float* pp = parts + (long)b * H * hp.d + k;
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = pp[(long)(u < H ? u : H - 1) * hp.d];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) x += (u < H) ? v[u] : 0.f;
+  }
   __device__ inline void finish(const HeadProjP& hp, float* xn, float* red16) {
     const int tid = threadIdx.x;
     dep_landed<DEP>();
@@ -1083,13 +1114,78 @@ struct HeadProj {
   }
 };
 
+// ---- the output projection folded into the attention kernels (option decode_fold_oproj) -------------------------------------
+// An attention workgroup owns one (row, head): 64 of the `inner` inputs of the output projection.  Instead of storing them for
+// a stand-alone GEMV (one more dependent launch, twice per layer) it multiplies them with its head's 64 columns of Wo itself
+// and writes a PARTIAL product row part[row][head][0..d).  The partials are added in head order 0 .. H-1, so the result does not
+// depend on which workgroup finishes first:
+//   self-attention -> the cross-attention kernel of the same layer adds them to the residual row while it loads it
+//                     (12 more coalesced loads per thread in a prologue that waits for one round trip anyway);
+//   cross-attention -> the LAST workgroup of a row to arrive (one ticket per row) adds the self- and the cross-partials to
+//                     the residual row and stores it: the release / ticket / acquire hand-off of a split-K reduction.
+// Six dependent launches per decoder layer become four.
+struct FoldP {
+  const void* Wo; int ldwo;        // [d][ldwo] element type T: the layer's output projection (ldwo = inner)
+  float* part_out;                 // [B][H][d] fp32: what this kernel writes
+  const float* part_in;            // [B][H][d] fp32 partials of the preceding self-attention kernel (cross kernel), else null
+  int* tickets;                    // cross kernel: one arrival counter per row, zero between launches
+  float* h_out; int ldh;           // cross kernel: the residual stream, updated in place by a row's last workgroup
+};
+
+// ao: the head's 64 attention outputs, T-rounded, in LDS.  stage: d floats of LDS.  Every thread of a 1024-thread workgroup:
+// output o = c * 128 + (tid >> 3) of pass c, input chunk ks = tid & 7 (8 lanes read the 128 (bf16) / 256 (fp32) contiguous bytes of
+// one Wo row slice).  Leaves the d partial sums in `stage` (synchronised).
+template <typename T, int KC, bool AHEAD>
+struct HeadOProj {
+  // AHEAD (self-attention kernel, 128-register budget), bf16: the whole slice (KC 16-byte pieces per lane, <= 32 registers) is
+  // requested by `load` -- BEFORE the attention partials are merged, so the round trip overlaps the merge -- and multiplied by
+  // `apply`.  Otherwise (fp32: 2 KC float4 would not fit beside the merge; the cross-attention kernel: 64 registers) `apply`
+  // loads the pieces itself, all of them at once in bf16, two at a time in fp32.
+  static constexpr bool kAhead = AHEAD && sizeof(T) == 2;
+  static constexpr int NB = sizeof(T) == 2 ? KC : (KC < 2 ? KC : 2);
+  Raw8<T> raw[NB];
+  __device__ inline void load(const FoldP& f, int h) {
+    if constexpr (kAhead) {
+      const int tid = threadIdx.x, og = tid >> 3, ks = tid & 7;
+      const T* wp = reinterpret_cast<const T*>(f.Wo) + (long)og * f.ldwo + h * 64 + ks * 8;
+#pragma unroll
+      for (int c = 0; c < KC; ++c) raw[c].load(wp + (long)c * 128 * f.ldwo);
+    }
+  }
+  __device__ inline void apply(const FoldP& f, int h, const float* ao, float* stage) {
+    const int tid = threadIdx.x, og = tid >> 3, ks = tid & 7;
+    const T* wp = reinterpret_cast<const T*>(f.Wo) + (long)og * f.ldwo + h * 64 + ks * 8;
+    const float4 x0 = *reinterpret_cast<const float4*>(ao + ks * 8);
+    const float4 x1 = *reinterpret_cast<const float4*>(ao + ks * 8 + 4);
+#pragma unroll
+    for (int c0 = 0; c0 < KC; c0 += NB) {
+      if constexpr (!kAhead) {
+#pragma unroll
+        for (int u = 0; u < NB; ++u)
+          if (c0 + u < KC) raw[u].load(wp + (long)(c0 + u) * 128 * f.ldwo);
+      }
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        if (c0 + u >= KC) continue;
+        float w[8];
+        raw[u].unpack(w);
+        float acc = x0.x * w[0] + x0.y * w[1] + x0.z * w[2] + x0.w * w[3] + x1.x * w[4] + x1.y * w[5] + x1.z * w[6] + x1.w * w[7];
+        acc = group_sum<8>(acc);
+        if (ks == 0) stage[(c0 + u) * 128 + og] = acc;
+      }
+    }
+    __syncthreads();
+  }
+};
+
 // cross-attention of one (b, h) with its own query projection; 16 waves, one key split (the default configuration
 // of dec_cross_attn_kernel, same key interleave and merge order)
 // F8: K / V are the e4m3 copy (64-byte rows, 8 bytes per lane; the scales multiply the scores and the output)
-template <typename T, int KC, int U, bool F8 = false, bool WH = false, bool DEP = false>
+template <typename T, int KC, int U, bool F8 = false, bool WH = false, bool DEP = false, int FOLD = 0>   // FOLD: 1 = partial rows in AND out, 2 = in only
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8)))   // <= 64 VGPRs: 2 workgroups per CU
 void dec_cross_attn_q_kernel(const float* h_, const float* lnw_, const void* W_, const void* k_, const void* v_, int H_, int L_, int d_,
-                             int kvB_, CrossAttnP p, HeadProjP hp, DepP dep) {   // leading scalars: preloaded kernel arguments (see gemv_kernel)
+                             int kvB_, CrossAttnP p, HeadProjP hp, DepP dep, FoldP fold) {   // leading scalars: preloaded kernel arguments (see gemv_kernel)
+  static_assert(!FOLD || (!WH && !DEP), "the folded output projection is built for the T5 backbone's plain step");
   hp.h = h_; hp.ln_w = lnw_; hp.W = W_; hp.ldh = d_; hp.ldw = d_; hp.d = d_;
   p.k = k_; p.v = v_; p.H = H_; p.L = L_; p.kv_B = kvB_;
   constexpr int NW = 16;
@@ -1118,6 +1214,10 @@ void dec_cross_attn_q_kernel(const float* h_, const float* lnw_, const void* W_,
     if (sizeof(T) == 2) proj.load(hp, row0);
     dep_wait<DEP>(dep, dep_ep);
     nrow.issue_row(hp, b);
+  } else if constexpr (FOLD) {
+    nrow.issue_row_parts(hp, b, fold.part_in, p.H);
+    nrow.issue_weight(hp);
+    if (sizeof(T) == 2) proj.load(hp, row0);
   } else {
     nrow.issue(hp, b);
     if (sizeof(T) == 2) proj.load(hp, row0);
@@ -1128,6 +1228,8 @@ void dec_cross_attn_q_kernel(const float* h_, const float* lnw_, const void* W_,
   unsigned long long t_start = 0;
   if (p.tstamp && threadIdx.x == 0) t_start = (unsigned long long)wall_clock64();
   nrow.finish(hp, xn, red16);
+  __shared__ float xres[FOLD == 1 ? 1024 : 1];
+  if constexpr (FOLD == 1) xres[threadIdx.x] = nrow.x;   // the un-normalised row, for the residual update at the end (not held in a register across the key stream)
   MH_STAMP(KID_CROSS, 0);   // row normalised
   if (sizeof(T) != 2) proj.load(hp, row0);
   proj.apply(xn, qs, WH ? p.q_bias : nullptr, row0);
@@ -1141,12 +1243,47 @@ void dec_cross_attn_q_kernel(const float* h_, const float* lnw_, const void* W_,
   partial_init(st);
   attend_keys<T, U, E>(st, q, kb, vb, wid * 8 + g, p.L, 8 * NW, nullptr, 0, nullptr, 0, ks);
   MH_STAMP(KID_CROSS, 2);   // keys streamed (this wave)
+  HeadOProj<T, KC, false> oproj;
   partial_merge_groups<T>(st);
   float m, l, a;
   block_merge<T, NW>(st, sm, m, l, a);
   MH_STAMP(KID_CROSS, 3);   // partials merged
-  if (threadIdx.x < 64)
-    store_head_row_wt<T>(reinterpret_cast<T*>(p.out) + (long)b * p.ldo + h * 64, l > 0.f ? a / l * vs : 0.f, &sm[0][0]);
+  if constexpr (FOLD == 1) {
+    // this head's share of the output projection, then -- last workgroup of the row only -- the residual update
+    if (threadIdx.x < 64) qs[0][threadIdx.x] = Elem<T>::to_f32(Elem<T>::from_f32(l > 0.f ? a / l * vs : 0.f));
+    __syncthreads();
+    oproj.apply(fold, h, qs[0], xn);
+    float* mine = fold.part_out + ((long)b * p.H + h) * hp.d;
+    if (threadIdx.x * 4 < hp.d) {
+      const float4 v4 = *reinterpret_cast<const float4*>(xn + threadIdx.x * 4);
+      store16_wt(mine + threadIdx.x * 4, u32x4_t{__float_as_uint(v4.x), __float_as_uint(v4.y), __float_as_uint(v4.z), __float_as_uint(v4.w)});
+    }
+    // hand-off without fences: the partial rows leave by write-through (sc1) stores, every wave waits for its own, the ticket
+    // is drawn behind the workgroup barrier, and the row's last workgroup reads all partial rows with sc1 loads (they are
+    // rewritten every layer and step: a cached copy would be a stale one)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int t = __hip_atomic_fetch_add(&fold.tickets[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = (t == p.H - 1);
+      if (last) __hip_atomic_store(&fold.tickets[b], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (nobody else touches it before the next launch)
+      red16[0] = __int_as_float(last);
+    }
+    __syncthreads();
+    if (__float_as_int(red16[0]) && (int)threadIdx.x < hp.d) {
+      const float* pp = fold.part_out + (long)b * p.H * hp.d + threadIdx.x;
+      float xr = xres[threadIdx.x];            // residual row + self-attention partials (what was normalised)
+      float v[16];     // (agent-scope relaxed atomic loads = sc1 loads the compiler keeps count of)
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = __hip_atomic_load(pp + (long)(u < p.H ? u : p.H - 1) * hp.d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int u = 0; u < 16; ++u) xr += (u < p.H) ? v[u] : 0.f;
+      fold.h_out[(long)b * fold.ldh + threadIdx.x] = xr;
+    }
+  } else {
+    if (threadIdx.x < 64)
+      store_head_row_wt<T>(reinterpret_cast<T*>(p.out) + (long)b * p.ldo + h * 64, l > 0.f ? a / l * vs : 0.f, &sm[0][0]);
+  }
   if (p.tstamp && threadIdx.x == 0 && *p.pos < p.ts_ring) {      // the first ts_ring positions of the call, one slot each
     unsigned long long* slot = p.tstamp + 2 * ((long)(*p.pos) * p.ts_layers + p.ts_layer);
     atomicMin(slot, t_start);
@@ -1187,11 +1324,12 @@ __device__ inline void norm_rows_to_lds(const HeadProjP& hp, int b0, int B, T (*
 
 // self-attention of one (b, h) with its own q / k / v projections: appends the new key / value row to the caches and
 // attends over keys 0 .. pos-1 from the cache plus the new key straight from LDS (merged last)
-template <typename T, int KC, bool WH = false, bool DEP = false>
+template <typename T, int KC, bool WH = false, bool DEP = false, bool FOLD = false>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4)))   // 16 waves = 4 per SIMD: the whole 128-register budget
 void dec_self_attn_qkv_kernel(const float* h_, const float* lnw_, const void* W_, const int* pos_,
                                                                  const void* kc_, const void* vc_, int H_, int d_, SelfAttnP p,
-                                                                 HeadProjP hp, DepP dep) {   // leading scalars: preloaded kernel arguments
+                                                                 HeadProjP hp, DepP dep, FoldP fold) {   // leading scalars: preloaded kernel arguments
+  static_assert(!FOLD || (!WH && !DEP), "the folded output projection is built for the T5 backbone's plain step");
   hp.h = h_; hp.ln_w = lnw_; hp.W = W_; hp.ldh = d_; hp.ldw = d_; hp.d = d_;
   p.pos = pos_; p.kc = kc_; p.vc = vc_; p.H = H_;
   const int inner = H_ * 64;
@@ -1274,6 +1412,8 @@ void dec_self_attn_qkv_kernel(const float* h_, const float* lnw_, const void* W_
   attend_keys<T, 2>(st, q, kcache, vcache, j_first + wid * 8 + g, pos, 8 * NW, bias_row, pos, mask_row, p.P, sc,
                     (WH && p.window > 0) ? pos - p.window : 0);
   MH_STAMP(KID_SELF, 1);    // cached keys attended (this wave)
+  HeadOProj<T, KC, true> oproj;
+  if constexpr (FOLD) oproj.load(fold, h);      // (the cached keys are attended: the slice travels under the merge)
   partial_merge_groups<T>(st);
   float m, l, a;
   block_merge<T, NW>(st, sm, m, l, a);
@@ -1286,7 +1426,14 @@ void dec_self_attn_qkv_kernel(const float* h_, const float* lnw_, const void* W_
     const float fa = fexp<T>(m - mn), fb = fexp<T>(sn - mn);
     l = l * fa + fb;
     a = a * fa + qkv[2][d] * fb;
-    store_head_row_wt<T>(reinterpret_cast<T*>(p.out) + (long)b * p.ldo + h * 64, l > 0.f ? a / l : 0.f, &sm[0][0]);
+    if constexpr (FOLD) qkv[0][d] = Elem<T>::to_f32(Elem<T>::from_f32(l > 0.f ? a / l : 0.f));   // (q is dead: the head's output, T-rounded)
+    else store_head_row_wt<T>(reinterpret_cast<T*>(p.out) + (long)b * p.ldo + h * 64, l > 0.f ? a / l : 0.f, &sm[0][0]);
+  }
+  if constexpr (FOLD) {   // this head's share of the output projection: one partial row, added by the cross-attention kernel
+    __syncthreads();
+    oproj.apply(fold, h, qkv[0], xn);
+    float* mine = fold.part_out + ((long)b * p.H + h) * hp.d;
+    if (threadIdx.x * 4 < hp.d) *reinterpret_cast<float4*>(mine + threadIdx.x * 4) = *reinterpret_cast<const float4*>(xn + threadIdx.x * 4);
   }
   dep_signal<DEP>(dep, dep_ep);
 }

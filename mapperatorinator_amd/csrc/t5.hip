@@ -815,7 +815,8 @@ int launch_skinny(dec::SkinnyP p, hipStream_t s, const dec::DepP* dep = nullptr)
   const bool wide = nkb > 4 * dec::kGemvCH;
   MH_REQUIRE(PRO != dec::PRO_RMSNORM || nkb <= 8 * dec::kGemvCH, "decode: RMSNorm prologue needs K <= %d", 8 * dec::kGemvCH * kb);
   MH_REQUIRE(p.lda == p.K && p.ldw == p.K, "decode: the GEMV operands must be dense (lda = ldw = K)");
-  MH_REQUIRE(EPI != dec::SK_RESID || (p.N % 4 == 0 && p.ldh == p.N), "decode: residual GEMV needs a dense [B, N] residual stream, N a multiple of 4");
+  MH_REQUIRE((EPI != dec::SK_RESID && EPI != dec::SK_RESID_PARTS) || (p.N % 4 == 0 && p.ldh == p.N), "decode: residual GEMV needs a dense [B, N] residual stream, N a multiple of 4");
+  MH_REQUIRE(EPI != dec::SK_RESID_PARTS || (p.parts && p.parts_H >= 1 && p.parts_H <= 16 && !dep), "decode: residual GEMV with partial rows needs 1 .. 16 of them");
   int tiles;
   if (EPI == dec::SK_GEGLU) { p.nv = 8; tiles = ceil_div(p.N / 2, 8); }
   else { p.nv = gemv_cols(p.N); tiles = ceil_div(p.N, p.nv); }
@@ -859,6 +860,7 @@ struct DecBuffers {
   float* h; void* q; void* attn; void* ff; float* logits; int chain;
   void* self_k; void* self_v;  // [n_dec][B][H][tgt][64]
   uint8_t* finished; int32_t* finish_col; int32_t* last_ts; DecState* st;
+  float* part_self; float* part_cross; int* tickets;   // folded output projections (decode_kernels.hpp FoldP): [B][H][d] x 2, [B]
 };
 
 template <typename T>
@@ -878,12 +880,18 @@ bool fused_proj_enabled(int d) { return option(OPT_DECODE_FUSED_PROJ) != 0 && d 
 // KC values the overlap (DEP) forms of the attention kernels are instantiated for: d_model 128 (tests), 512, 768, 1024
 constexpr bool dep_kc(int KC) { return KC == 1 || KC == 4 || KC == 6 || KC == 8; }
 template <typename T, int KC>
-int launch_self_qkv(const dec::SelfAttnP& sa, const dec::HeadProjP& hp, int inner, hipStream_t s, const dec::DepP* dep = nullptr) {
+int launch_self_qkv(const dec::SelfAttnP& sa, const dec::HeadProjP& hp, int inner, hipStream_t s, const dec::DepP* dep = nullptr,
+                    const dec::FoldP* fold = nullptr) {
   MH_REQUIRE(hp.ldh == hp.d && hp.ldw == hp.d && inner == sa.H * 64, "decode: dense residual rows / projection weights expected");
+  if (fold) {   // output projection folded in (T5 backbone, one row per workgroup, plain step)
+    MH_REQUIRE(!dep && !sa.rope, "decode: the folded output projection is built for the T5 backbone's plain step");
+    hipLaunchKernelGGL((dec::dec_self_attn_qkv_kernel<T, KC, false, false, true>), dim3(sa.B * sa.H), dim3(1024), 0, s, MH_SELF_LEAD_ARGS, sa, hp, dec::DepP{}, *fold);
+    return check_launch("dec_self_attn_qkv_kernel");
+  }
   if (dep) {
     if constexpr (dep_kc(KC)) {
       dec::DepP dd = *dep; dd.nwg = (unsigned)(sa.B * sa.H);
-      hipLaunchKernelGGL((dec::dec_self_attn_qkv_kernel<T, KC, false, true>), dim3(sa.B * sa.H), dim3(1024), 0, s, MH_SELF_LEAD_ARGS, sa, hp, dd);
+      hipLaunchKernelGGL((dec::dec_self_attn_qkv_kernel<T, KC, false, true>), dim3(sa.B * sa.H), dim3(1024), 0, s, MH_SELF_LEAD_ARGS, sa, hp, dd, dec::FoldP{});
       return check_launch("dec_self_attn_qkv_kernel");
     } else {
       set_error("decode: the overlap form is built for d_model 128 / 512 / 768 / 1024");
@@ -891,7 +899,7 @@ int launch_self_qkv(const dec::SelfAttnP& sa, const dec::HeadProjP& hp, int inne
     }
   }
   if (sa.rope) {   // the Whisper family: biased fused Wqkv, RoPE, scaled scores, optional window
-    hipLaunchKernelGGL((dec::dec_self_attn_qkv_kernel<T, KC, true>), dim3(sa.B * sa.H), dim3(1024), 0, s, MH_SELF_LEAD_ARGS, sa, hp, dec::DepP{});
+    hipLaunchKernelGGL((dec::dec_self_attn_qkv_kernel<T, KC, true>), dim3(sa.B * sa.H), dim3(1024), 0, s, MH_SELF_LEAD_ARGS, sa, hp, dec::DepP{}, dec::FoldP{});
     return check_launch("dec_self_attn_qkv_kernel");
   }
   // option decode_self_rows: rows of one head per workgroup (1, 2 or 4) -- they share the head's weight slice
@@ -901,30 +909,46 @@ int launch_self_qkv(const dec::SelfAttnP& sa, const dec::HeadProjP& hp, int inne
   else if (R >= 2)
     hipLaunchKernelGGL((dec::dec_self_attn_qkv_rows_kernel<T, KC, 2>), dim3((sa.B + 1) / 2 * sa.H), dim3(1024), 0, s, MH_SELF_LEAD_ARGS, sa, hp);
   else
-    hipLaunchKernelGGL((dec::dec_self_attn_qkv_kernel<T, KC>), dim3(sa.B * sa.H), dim3(1024), 0, s, MH_SELF_LEAD_ARGS, sa, hp, dec::DepP{});
+    hipLaunchKernelGGL((dec::dec_self_attn_qkv_kernel<T, KC>), dim3(sa.B * sa.H), dim3(1024), 0, s, MH_SELF_LEAD_ARGS, sa, hp, dec::DepP{}, dec::FoldP{});
   return check_launch("dec_self_attn_qkv_kernel");
 }
 template <typename T>
-int launch_self_qkv_d(const dec::SelfAttnP& sa, const dec::HeadProjP& hp, int inner, hipStream_t s, const dec::DepP* dep = nullptr) {
+int launch_self_qkv_d(const dec::SelfAttnP& sa, const dec::HeadProjP& hp, int inner, hipStream_t s, const dec::DepP* dep = nullptr,
+                      const dec::FoldP* fold = nullptr) {
   switch (hp.d) {
-    case 128: return launch_self_qkv<T, 1>(sa, hp, inner, s, dep);
-    case 256: return launch_self_qkv<T, 2>(sa, hp, inner, s, dep);
-    case 384: return launch_self_qkv<T, 3>(sa, hp, inner, s, dep);
-    case 512: return launch_self_qkv<T, 4>(sa, hp, inner, s, dep);
-    case 640: return launch_self_qkv<T, 5>(sa, hp, inner, s, dep);
-    case 768: return launch_self_qkv<T, 6>(sa, hp, inner, s, dep);
-    case 896: return launch_self_qkv<T, 7>(sa, hp, inner, s, dep);
-    default: return launch_self_qkv<T, 8>(sa, hp, inner, s, dep);
+    case 128: return launch_self_qkv<T, 1>(sa, hp, inner, s, dep, fold);
+    case 256: return launch_self_qkv<T, 2>(sa, hp, inner, s, dep, fold);
+    case 384: return launch_self_qkv<T, 3>(sa, hp, inner, s, dep, fold);
+    case 512: return launch_self_qkv<T, 4>(sa, hp, inner, s, dep, fold);
+    case 640: return launch_self_qkv<T, 5>(sa, hp, inner, s, dep, fold);
+    case 768: return launch_self_qkv<T, 6>(sa, hp, inner, s, dep, fold);
+    case 896: return launch_self_qkv<T, 7>(sa, hp, inner, s, dep, fold);
+    default: return launch_self_qkv<T, 8>(sa, hp, inner, s, dep, fold);
   }
 }
 template <typename T, int KC>
-int launch_cross_q(const dec::CrossAttnP& ca, const dec::HeadProjP& hp, hipStream_t s, const dec::DepP* dep = nullptr) {
+int launch_cross_q(const dec::CrossAttnP& ca, const dec::HeadProjP& hp, hipStream_t s, const dec::DepP* dep = nullptr,
+                   const dec::FoldP* fold = nullptr) {
   MH_REQUIRE(hp.ldh == hp.d && hp.ldw == hp.d, "decode: dense residual rows / projection weights expected");
+  if (fold) {   // fold->part_out: its own output projection folded in as well (FOLD 1), else only the self-attention partials absorbed (FOLD 2)
+    MH_REQUIRE(!dep && ca.scale == 0.f, "decode: the folded output projection is built for the T5 backbone's plain step");
+    const bool both = fold->part_out != nullptr;
+    if (ca.kscale != nullptr) {
+      if constexpr (sizeof(T) == 2) {
+        if (both) hipLaunchKernelGGL((dec::dec_cross_attn_q_kernel<T, KC, 1, true, false, false, 1>), dim3(ca.B * ca.H), dim3(1024), 0, s, MH_CROSS_LEAD_ARGS, ca, hp, dec::DepP{}, *fold);
+        else hipLaunchKernelGGL((dec::dec_cross_attn_q_kernel<T, KC, 1, true, false, false, 2>), dim3(ca.B * ca.H), dim3(1024), 0, s, MH_CROSS_LEAD_ARGS, ca, hp, dec::DepP{}, *fold);
+      } else { set_error("decode: the fp8 cross K/V copy needs bf16 storage"); return MH_ERR_ARG; }
+    } else {
+      if (both) hipLaunchKernelGGL((dec::dec_cross_attn_q_kernel<T, KC, 1, false, false, false, 1>), dim3(ca.B * ca.H), dim3(1024), 0, s, MH_CROSS_LEAD_ARGS, ca, hp, dec::DepP{}, *fold);
+      else hipLaunchKernelGGL((dec::dec_cross_attn_q_kernel<T, KC, 1, false, false, false, 2>), dim3(ca.B * ca.H), dim3(1024), 0, s, MH_CROSS_LEAD_ARGS, ca, hp, dec::DepP{}, *fold);
+    }
+    return check_launch("dec_cross_attn_q_kernel");
+  }
   if (dep) {
     if constexpr (dep_kc(KC)) {
       MH_REQUIRE(ca.scale == 0.f && ca.kscale == nullptr, "decode: the overlap form is built for the T5 backbone with bf16 / fp32 cross K/V");
       dec::DepP dd = *dep; dd.nwg = (unsigned)(ca.B * ca.H);
-      hipLaunchKernelGGL((dec::dec_cross_attn_q_kernel<T, KC, 1, false, false, true>), dim3(ca.B * ca.H), dim3(1024), 0, s, MH_CROSS_LEAD_ARGS, ca, hp, dd);
+      hipLaunchKernelGGL((dec::dec_cross_attn_q_kernel<T, KC, 1, false, false, true>), dim3(ca.B * ca.H), dim3(1024), 0, s, MH_CROSS_LEAD_ARGS, ca, hp, dd, dec::FoldP{});
       return check_launch("dec_cross_attn_q_kernel");
     } else {
       set_error("decode: the overlap form is built for d_model 128 / 512 / 768 / 1024");
@@ -935,27 +959,28 @@ int launch_cross_q(const dec::CrossAttnP& ca, const dec::HeadProjP& hp, hipStrea
   // same bandwidth in the stand-alone kernel
   if (ca.scale != 0.f) {   // the Whisper family: biased Wq, scaled scores
     MH_REQUIRE(ca.kscale == nullptr, "decode: the fp8 cross K/V copy is not wired for the Whisper family");
-    hipLaunchKernelGGL((dec::dec_cross_attn_q_kernel<T, KC, 1, false, true>), dim3(ca.B * ca.H), dim3(1024), 0, s, MH_CROSS_LEAD_ARGS, ca, hp, dec::DepP{});
+    hipLaunchKernelGGL((dec::dec_cross_attn_q_kernel<T, KC, 1, false, true>), dim3(ca.B * ca.H), dim3(1024), 0, s, MH_CROSS_LEAD_ARGS, ca, hp, dec::DepP{}, dec::FoldP{});
   } else if (ca.kscale != nullptr) {
     if constexpr (sizeof(T) == 2)
-      hipLaunchKernelGGL((dec::dec_cross_attn_q_kernel<T, KC, 1, true>), dim3(ca.B * ca.H), dim3(1024), 0, s, MH_CROSS_LEAD_ARGS, ca, hp, dec::DepP{});
+      hipLaunchKernelGGL((dec::dec_cross_attn_q_kernel<T, KC, 1, true>), dim3(ca.B * ca.H), dim3(1024), 0, s, MH_CROSS_LEAD_ARGS, ca, hp, dec::DepP{}, dec::FoldP{});
     else { set_error("decode: the fp8 cross K/V copy needs bf16 storage"); return MH_ERR_ARG; }
   } else {
-    hipLaunchKernelGGL((dec::dec_cross_attn_q_kernel<T, KC, 1>), dim3(ca.B * ca.H), dim3(1024), 0, s, MH_CROSS_LEAD_ARGS, ca, hp, dec::DepP{});
+    hipLaunchKernelGGL((dec::dec_cross_attn_q_kernel<T, KC, 1>), dim3(ca.B * ca.H), dim3(1024), 0, s, MH_CROSS_LEAD_ARGS, ca, hp, dec::DepP{}, dec::FoldP{});
   }
   return check_launch("dec_cross_attn_q_kernel");
 }
 template <typename T>
-int launch_cross_q_d(const dec::CrossAttnP& ca, const dec::HeadProjP& hp, hipStream_t s, const dec::DepP* dep = nullptr) {
+int launch_cross_q_d(const dec::CrossAttnP& ca, const dec::HeadProjP& hp, hipStream_t s, const dec::DepP* dep = nullptr,
+                     const dec::FoldP* fold = nullptr) {
   switch (hp.d) {
-    case 128: return launch_cross_q<T, 1>(ca, hp, s, dep);
-    case 256: return launch_cross_q<T, 2>(ca, hp, s, dep);
-    case 384: return launch_cross_q<T, 3>(ca, hp, s, dep);
-    case 512: return launch_cross_q<T, 4>(ca, hp, s, dep);
-    case 640: return launch_cross_q<T, 5>(ca, hp, s, dep);
-    case 768: return launch_cross_q<T, 6>(ca, hp, s, dep);
-    case 896: return launch_cross_q<T, 7>(ca, hp, s, dep);
-    default: return launch_cross_q<T, 8>(ca, hp, s, dep);
+    case 128: return launch_cross_q<T, 1>(ca, hp, s, dep, fold);
+    case 256: return launch_cross_q<T, 2>(ca, hp, s, dep, fold);
+    case 384: return launch_cross_q<T, 3>(ca, hp, s, dep, fold);
+    case 512: return launch_cross_q<T, 4>(ca, hp, s, dep, fold);
+    case 640: return launch_cross_q<T, 5>(ca, hp, s, dep, fold);
+    case 768: return launch_cross_q<T, 6>(ca, hp, s, dep, fold);
+    case 896: return launch_cross_q<T, 7>(ca, hp, s, dep, fold);
+    default: return launch_cross_q<T, 8>(ca, hp, s, dep, fold);
   }
 }
 
@@ -1064,6 +1089,20 @@ int enqueue_step(const MhT5Config* c, const MhT5Weights* w, const void* cross_kv
     // self attention
     const bool fused = fused_proj_enabled(d);                                  // cross-attention projects its own query
     const bool fused_self = fused && option(OPT_DECODE_FUSED_PROJ) == 1;       // (2: stand-alone QKV GEMV, fused cross-attention)
+    // both output projections inside the attention kernels (FoldP, decode_kernels.hpp): four dependent launches per layer, not six
+    // option decode_fold_oproj: 1 = the self-attention output projection (its partial rows are absorbed by the cross-attention
+    // kernel's prologue and by the cross output projection's residual epilogue: 5 launches per layer), 2 = both (4 launches)
+    const long fold_mode = (fused_self && !ov && with_sampler && bf.tickets && option(OPT_DECODE_SELF_ROWS) <= 1 && H <= 16) ? option(OPT_DECODE_FOLD_OPROJ) : 0;
+    const bool fold = fold_mode != 0, fold_cross = fold_mode == 2;
+    dec::FoldP fo_self{}, fo_cross{};
+    if (fold) {
+      fo_self.Wo = w->dec_o[l]; fo_self.ldwo = inner; fo_self.part_out = bf.part_self;
+      fo_cross.part_in = bf.part_self;
+      if (fold_cross) {
+        fo_cross.Wo = w->dec_co[l]; fo_cross.ldwo = inner; fo_cross.part_out = bf.part_cross;
+        fo_cross.tickets = bf.tickets; fo_cross.h_out = bf.h; fo_cross.ldh = d;
+      }
+    }
     dec::SelfAttnP sa{};
     sa.q = bf.q; sa.ldq = inner; sa.kc = (char*)bf.self_k + cache_off; sa.vc = (char*)bf.self_v + cache_off;
     sa.bias = w->dec_rel_bias; sa.prompt_mask = prompt_mask;
@@ -1071,7 +1110,7 @@ int enqueue_step(const MhT5Config* c, const MhT5Weights* w, const void* cross_kv
     if (fused_self) {
       dec::HeadProjP hp{};
       hp.h = bf.h; hp.ldh = d; hp.ln_w = w->dec_ln1[l]; hp.eps = c->eps; hp.W = w->dec_qkv[l]; hp.ldw = d; hp.d = d;
-      if (take()) MH_TRY(launch_self_qkv_d<T>(sa, hp, inner, st(), dp()));
+      if (take()) MH_TRY(launch_self_qkv_d<T>(sa, hp, inner, st(), dp(), fold ? &fo_self : nullptr));
       ++slot;
     } else {
       MH_REQUIRE(!ov, "decode: the overlap form needs decode_fused_proj = 1");
@@ -1083,11 +1122,13 @@ int enqueue_step(const MhT5Config* c, const MhT5Weights* w, const void* cross_kv
       hipLaunchKernelGGL(dec::dec_self_attn_kernel<T>, dim3(B * H), dim3(256), 0, s, sa);
       MH_TRY(check_launch("dec_self_attn_kernel"));
     }
-    sk = dec::SkinnyP{};
-    sk.A = bf.attn; sk.lda = inner; sk.W = w->dec_o[l]; sk.ldw = inner; sk.B = B; sk.N = d; sk.K = inner; sk.h = bf.h;
-    sk.ldh = d;
-    if (take()) MH_TRY((skinny<T, dec::PRO_PLAIN, dec::SK_RESID>(sk, st(), dp())));
-    ++slot;
+    if (!fold) {
+      sk = dec::SkinnyP{};
+      sk.A = bf.attn; sk.lda = inner; sk.W = w->dec_o[l]; sk.ldw = inner; sk.B = B; sk.N = d; sk.K = inner; sk.h = bf.h;
+      sk.ldh = d;
+      if (take()) MH_TRY((skinny<T, dec::PRO_PLAIN, dec::SK_RESID>(sk, st(), dp())));
+      ++slot;
+    }
     // cross attention
     dec::CrossAttnP ca{};
     const long kv_layer = (long)kvB * H * L * 64 * es;
@@ -1107,7 +1148,7 @@ int enqueue_step(const MhT5Config* c, const MhT5Weights* w, const void* cross_kv
     if (fused) {
       dec::HeadProjP hp{};
       hp.h = bf.h; hp.ldh = d; hp.ln_w = w->dec_ln2[l]; hp.eps = c->eps; hp.W = w->dec_cq[l]; hp.ldw = d; hp.d = d;
-      if (take()) MH_TRY(launch_cross_q_d<T>(ca, hp, st(), dp()));
+      if (take()) MH_TRY(launch_cross_q_d<T>(ca, hp, st(), dp(), fold ? &fo_cross : nullptr));
       ++slot;
     } else {
       MH_REQUIRE(!ov, "decode: the overlap form needs decode_fused_proj = 1");
@@ -1117,11 +1158,16 @@ int enqueue_step(const MhT5Config* c, const MhT5Weights* w, const void* cross_kv
       MH_TRY((skinny<T, dec::PRO_RMSNORM, dec::SK_STORE>(sk, s)));
       MH_TRY(launch_cross<T>(ca, s));
     }
-    sk = dec::SkinnyP{};
-    sk.A = bf.attn; sk.lda = inner; sk.W = w->dec_co[l]; sk.ldw = inner; sk.B = B; sk.N = d; sk.K = inner; sk.h = bf.h;
-    sk.ldh = d;
-    if (take()) MH_TRY((skinny<T, dec::PRO_PLAIN, dec::SK_RESID>(sk, st(), dp())));
-    ++slot;
+    if (!fold_cross) {
+      sk = dec::SkinnyP{};
+      sk.A = bf.attn; sk.lda = inner; sk.W = w->dec_co[l]; sk.ldw = inner; sk.B = B; sk.N = d; sk.K = inner; sk.h = bf.h;
+      sk.ldh = d;
+      if (fold) {   // ... and the residual row absorbs the self-attention partials here
+        sk.parts = bf.part_self; sk.parts_H = H;
+        MH_TRY((skinny<T, dec::PRO_PLAIN, dec::SK_RESID_PARTS>(sk, s)));
+      } else if (take()) MH_TRY((skinny<T, dec::PRO_PLAIN, dec::SK_RESID>(sk, st(), dp())));
+      ++slot;
+    }
     // feed forward
     sk = dec::SkinnyP{};
     sk.A = bf.h; sk.lda = d; sk.ln_w = w->dec_ln3[l]; sk.eps = c->eps; sk.W = w->dec_wi[l]; sk.ldw = d; sk.B = B;
@@ -1212,6 +1258,7 @@ extern "C" int64_t mh_t5_decode_workspace_bytes(const MhT5Config* c, int B) {
   t += align256(B) + align256((int64_t)B * 4) * 2 + align256(sizeof(DecState)) * kMaxChains;   // flags / state
   t += align256((int64_t)B * c->vocab_out * 4) * 3;                               // processed scores + LookbackBias history
   t += align256(sizeof(mh::dec::DepSync)) * kMaxChains;                           // progress words / arrival tickets (decode_overlap)
+  t += align256((int64_t)B * c->n_heads * c->d_model * 4) * 2 + align256((int64_t)B * 4);   // folded output projections: partial rows, row tickets
   t += prefill_layout(c, B, c->tgt_len - 1, nullptr, 0, nullptr);                  // batched prompt prefill
   return t;
 }
@@ -1607,7 +1654,11 @@ extern "C" int mh_t5_generate(const MhT5Config* c, const MhT5Weights* w, const v
   float* proc = (float*)ar.take((int64_t)B * V * 4);
   float* hist_scores = (float*)ar.take((int64_t)B * V * 4 * 2);
   char* dep_sync_all = (char*)ar.take((int64_t)align256(sizeof(dec::DepSync)) * kMaxChains);
-  MH_REQUIRE(ar.ok() && hist_scores && dep_sync_all, "mh_t5_generate: arena overflow");
+  all.part_self = (float*)ar.take((int64_t)B * H * d * 4);
+  all.part_cross = (float*)ar.take((int64_t)B * H * d * 4);
+  all.tickets = (int*)ar.take((int64_t)B * 4);
+  MH_REQUIRE(ar.ok() && hist_scores && dep_sync_all && all.tickets, "mh_t5_generate: arena overflow");
+  if (hipMemsetAsync(all.tickets, 0, (size_t)B * 4, s) != hipSuccess) return check_launch("ticket reset");   // (every launch leaves them at zero again)
   // a CFG pair spans both halves of the batch and the (batch-wide) conditional temperature reads row 0's history: one chain
   const int n_chains = (cfg || (sp->n_cond > 0 && !sp->cond_per_row)) ? 1 : pick_chains(B);
   const int rows_per = ceil_div(B, n_chains);
@@ -1675,6 +1726,9 @@ extern "C" int mh_t5_generate(const MhT5Config* c, const MhT5Weights* w, const v
     bf.self_k = (char*)all.self_k + (long)b0 * inner * c->tgt_len * es;
     bf.self_v = (char*)all.self_v + (long)b0 * inner * c->tgt_len * es;
     bf.finished = all.finished + b0;
+    bf.part_self = all.part_self + (long)b0 * H * d;
+    bf.part_cross = all.part_cross + (long)b0 * H * d;
+    bf.tickets = all.tickets + b0;
     bf.st = (DecState*)((char*)st_all + (long)ci * align256(sizeof(DecState)));
     states[ci] = bf.st;
     const void* ckv = (const char*)cross_kv + (long)b0 * H * c->src_len * 64 * es;

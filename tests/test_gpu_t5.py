@@ -82,7 +82,10 @@ def test_fp32_matches_reference_golden(name):
                                   dict(decode_gemv_cols=4), dict(decode_chains=1), dict(decode_chains=3),
                                   dict(decode_prefill=0, decode_fused_proj=0), dict(decode_fused_proj=2), dict(decode_self_rows=2),
                                   dict(decode_self_rows=4), dict(decode_overlap=1), dict(decode_overlap=1, decode_chains=1),
-                                  dict(decode_overlap=1, decode_chains=2, decode_gemv_cols=4)])
+                                  dict(decode_overlap=1, decode_chains=2, decode_gemv_cols=4),
+                                  dict(decode_fold_oproj=1), dict(decode_fold_oproj=1, decode_chains=1),
+                                  dict(decode_fold_oproj=1, decode_chains=1, decode_prefill=0), dict(decode_fold_oproj=2),
+                                  dict(decode_fold_oproj=2, decode_chains=3, decode_gemv_cols=4)])
 def test_decode_kernel_variants_reproduce_the_reference_tokens(opts):
     """Every run-time selectable form of the decode step (mh_set_option: stand-alone QKV / cross-Q GEMVs instead of
     the attention kernels' own projections, 16 / 8 / 4 real columns per GEMV tile, 1 or 3 row chains, token-by-token
@@ -487,28 +490,37 @@ def test_rows_do_not_depend_on_the_rows_beside_them(dtype, B, chains):
     """Chains of more than 16 rows use the 2- / 4-fragment GEMV (MF >= 2), chains of <= 16 rows the whole-line one
     (MF == 1): both must add a row's products in the same order (k-block pairs per wave), so a chunk decodes to the same
     ids alone (MF 1) and inside a batch of 24 (one chain, MF 2), 40 (two chains of 20, MF 2) or 64 rows (two chains of
-    32, MF 2)."""
+    32, MF 2).  Every run decodes from the SAME cross K/V rows (the encoder of the whole batch): the encoder's GEMMs choose
+    their tile family -- and with it the fp32 summation order -- by the number of rows, which in bf16 moves near-tie
+    decisions of a solo run (documented at option gemm_splitk_tiles); the claim here is about the decode step."""
     from mapperatorinator_amd import Tokenizer, _lib
-    from mapperatorinator_amd.server import model_generate
+    from mapperatorinator_amd.server import build_sampling
     from mapperatorinator_amd.t5_engine import T5_PRESETS
     from mapperatorinator_amd.testing import random_t5_state_dict, synthetic_audio
     src, tgt = 251, 48
     tok = Tokenizer.benchmark_vocab(src_seq_len=src)
     sd = random_t5_state_dict(T5_PRESETS["small"], tok.vocab_size_in, tok.vocab_size_out, seed=9, lm_head_gain=6.0)
     model = build("small", tok, sd, src, tgt, dtype)
-    audio = synthetic_audio(B, 32000, seed=12)
-    prompt = torch.tensor([[1]] * B)
-    gk = gen_kwargs(tgt)
+    eng = model.engine
+    audio = synthetic_audio(B, 32000, seed=12).cuda()
+    prompt = torch.tensor([[1]] * B, dtype=torch.int32, device="cuda")
+    sp, eos = build_sampling(tok, gen_kwargs(tgt), tgt)
+    table = torch.zeros(tok.vocab_size_out, dtype=torch.uint8, device="cuda")
+    table[list(eos)] = 1
+    kv = eng.cross_kv(eng.encode(audio))
+    torch.cuda.synchronize()
     old = _lib.set_option("decode_chains", chains)
     try:
-        ids, _ = model_generate(model, tok, dict(inputs=audio, decoder_input_ids=prompt, decoder_attention_mask=prompt.ne(0)), gk)
+        ids, n_all, _ = eng.decode(kv, prompt, None, table, sp)
     finally:
         _lib.set_option("decode_chains", old)
-    for b in (0, 7, 17, B - 1):
-        one, _ = model_generate(model, tok, dict(inputs=audio[b:b + 1], decoder_input_ids=prompt[:1],
-                                                 decoder_attention_mask=prompt[:1].ne(0)), gk)
-        n = one.shape[1]
-        assert torch.equal(one[0], ids[b, :n]) and (ids[b, n:] == 0).all(), f"row {b} of {B} depends on its batch"
+    ids = ids.cpu()
+    rows = sorted(set([0, 7, 17, B - 1] + list(range(3, B, 5))))
+    for b in rows:
+        one, n_one, _ = eng.decode(kv[:, :, b:b + 1].contiguous(), prompt[:1], None, table, sp)
+        n = int(n_one)
+        one = one.cpu()
+        assert torch.equal(one[0, :n], ids[b, :n]) and (ids[b, n:] == 0).all(), f"row {b} of {B} depends on its batch"
 
 
 
