@@ -1122,11 +1122,16 @@ __global__ __launch_bounds__(512) void gemm_s3g_kernel(GemmP p) {
 //   scales: [rows][16 * ceil(K / 512)] bytes, byte (kt / 4) * 16 + lg * 4 + (kt % 4) = E8M0 of k block kt * 4 + lg (kt = K step):
 //   a lane fetches ONE dword per row block and four K steps and selects the step's byte with OP_SEL (0..3) -- MI + 4 dword
 //   loads per wave and four steps, issued a group ahead by inline asm and covered by the counted vmcnt waits of the DMA pipeline.
-// Two geometries of one kernel (NW waves as NW/2 (M) x 2 (N), wave tile 16 MI x 64):
+// Three geometries of one kernel (NW waves as NW/2 (M) x 2 (N), wave tile 16 MI x 64):
+//   NW = 8, MI = 4: 256 x 128 tile, EIGHT waves of 64 x 64, two per SIMD (214 VGPRs, accumulators in VGPRs: a kernel that touches
+//     AGPRs gets its 256 registers split 128 + 128) -- one wave's fragment reads run under the other's MFMAs.  The default
+//     (option mx8_waves = 8): 1.07-1.46 x the bf16 kernel on the encoder / DiT-B shapes, 1534 TFLOP/s at 8192^3
+//     (profiles/r04_mx8_gemm_bench.txt).  An earlier form of the K loop spilled asm-loaded fragments at this geometry
+//     (tools/check_kernel_resources.py fails the build on that); the rolled loop with one A register set fits.
 //   NW = 4, MI = 8: 256 x 128 tile, FOUR waves of 128 x 64 -- one wave per SIMD, so a wave may hold 512 registers: 128
 //     accumulators (AGPRs) beside 128 fragment registers.  24 fragment reads feed 32 MFMAs per K step (0.75 per MFMA; the
-//     64 x 64 wave tile of the bf16 kernel needs 1.0, a 32 x 64 tile 1.5).  Eight waves of 64 x 64 do not fit: with 256
-//     registers per wave hipcc spilled asm-loaded fragments (tools/check_kernel_resources.py fails the build on that).
+//     64 x 64 wave tile needs 1.0) but nothing overlaps a wave's own waits: 0.99-1.37 x bf16, 1418 TFLOP/s at 8192^3
+//     (option mx8_waves = 4).
 //   NW = 8, MI = 2: 128 x 128 tile for grids that would leave CUs idle at 256 rows per tile.
 // Two phases per K step, split by A row blocks so that the A fragments need ONE register set:
 //   phase 1: DMA of step kt + 2 (+ the next scale group every fourth step) | reads of (stage kt: A blocks MI/2 ..) | MFMAs of A
@@ -1244,8 +1249,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_mx8_kernel(GemmP p) {
 #define MX_DEP4(x) "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3])
   auto wait_scales = [&](int (&v)[NSC]) {      // (no instruction: the vmcnt wait that covers them stands next to it)
     if constexpr (NSC == 12) asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]));
+    else if constexpr (NSC == 8) asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
     else asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]));
-    static_assert(NSC == 12 || NSC == 6, "scale register lists");
+    static_assert(NSC == 12 || NSC == 8 || NSC == 6, "scale register lists");
   };
   // vmcnt immediates: what may stay in flight behind the stage that must have landed
 #define MX_STR2(x) #x
@@ -1254,6 +1260,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_mx8_kernel(GemmP p) {
     constexpr int N_ = decltype(n_c)::value;
     if constexpr (N_ == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else if constexpr (N_ == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N_ == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N_ == 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
     else if constexpr (N_ == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
     else if constexpr (N_ == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     else if constexpr (N_ == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
@@ -1325,7 +1333,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_mx8_kernel(GemmP p) {
     ld_a_half(cur, I1{});
     // A blocks 0 .. MI/2 - 1 and this step's W blocks (read one phase ago) are in; the MI reads just issued may still fly
     if constexpr (MI == 8) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+    else if constexpr (MI == 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+    static_assert(MI == 8 || MI == 4 || MI == 2, "2 * (MI / 2) reads were just issued");
     __builtin_amdgcn_sched_barrier(0);
     auto& acc_r = acc; auto& scur_r = scur;      // (plain uses: see ld_a_half)
     auto mma = [&](auto half_c) {
@@ -1405,6 +1415,7 @@ bool prepare_mx8() {
   bool ok = true;
   ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mx8_kernel<EPI, 8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (256 + 128) * 128) == hipSuccess;
   ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mx8_kernel<EPI, 2, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (128 + 128) * 128) == hipSuccess;
+  ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mx8_kernel<EPI, 4, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (256 + 128) * 128) == hipSuccess;
   return ok;
 }
 template <int EPI>
@@ -1412,6 +1423,7 @@ int dispatch_mx8(const GemmP& p, hipStream_t s) {
   // fewer 256-row tiles than option mx8_tile256_min: the 128-row form doubles the workgroups
   const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + 127) / 128);
   if (tiles256 < option(OPT_MX8_TILE256_MIN)) return launch_mx8<EPI, 2, 8>(p, s);
+  if (option(OPT_MX8_WAVES) == 8) return launch_mx8<EPI, 4, 8>(p, s);     // 256 x 128 tile as eight waves of 64 x 64 (two per SIMD)
   return launch_mx8<EPI, 8, 4>(p, s);
 }
 int dispatch_mx8_epi(const GemmP& p, int epi, hipStream_t s) {
