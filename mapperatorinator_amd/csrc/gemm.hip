@@ -567,13 +567,12 @@ __device__ __forceinline__ void g3_epilogue(const GemmP& p, f32x4_t (&acc)[4][MI
     c = c < p.N ? c : p.N - 4;
     bias4[jj] = (EPI != MH_EPI_GEGLU && p.bias) ? f4(p.bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
+  // (the bias is added per row block below, in front of that block's pinned values: hipcc otherwise sinks the add -- and the wait
+  // for the bias load -- behind the stores, and every store then waits for the one before it.  Adding it to ALL accumulators up
+  // front pinned 16 MI of them in VGPRs at once: with AGPR accumulators and a 128 x 64 wave tile that spilled.)
 #pragma unroll
-  for (int jj = 0; jj < NI; ++jj)
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      acc[jj][i][0] += bias4[jj].x; acc[jj][i][1] += bias4[jj].y; acc[jj][i][2] += bias4[jj].z; acc[jj][i][3] += bias4[jj].w;
-      asm volatile("" : "+v"(acc[jj][i]));   // materialised HERE: hipcc otherwise sinks the add (and the wait for the bias
-    }                                        // load) behind the stores, and every store then waits for the one before it
+  for (int jj = 0; jj < NI; ++jj)   // the bias loads are waited for HERE
+    asm volatile("" : "+v"(bias4[jj].x), "+v"(bias4[jj].y), "+v"(bias4[jj].z), "+v"(bias4[jj].w));
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
     const int row = erow_base + i * 16;
@@ -596,6 +595,7 @@ __device__ __forceinline__ void g3_epilogue(const GemmP& p, f32x4_t (&acc)[4][MI
 #pragma unroll
     for (int jj = 0; jj < NI; ++jj) {
       f32x4_t v = acc[jj][i];
+      v[0] += bias4[jj].x; v[1] += bias4[jj].y; v[2] += bias4[jj].z; v[3] += bias4[jj].w;
       if constexpr (EPI == MH_EPI_GEGLU) {
         if (!(jj & 1)) {                             // 16-row weight blocks alternate wi_0 / wi_1: jj the gate, jj + 1 the linear half
 #pragma unroll
@@ -849,6 +849,167 @@ __global__ __launch_bounds__(512) void gemm_glds3_kernel(GemmP p) {
   mma(a1, b1);
 #undef G3_WAIT
 
+  g3_epilogue<EPI, MI>(p, acc, m0, n0, wr, wc, lane);
+}
+
+// ---- G4: bf16, 256 x 256 tile, 8 waves as 2 (M) x 4 (N) of 128 x 64, TWO LDS stages, two staggered wave groups --------------------
+// gemm_glds3_kernel is bound neither by LDS bandwidth (its XOR-swizzled fragment reads are conflict-free: 4 LDS cycles each under
+// the quarter-wave lane groups of MI355X_MICROARCH.md, 512 cycles per K step and CU) nor by the matrix pipe (1 024 cycles per K
+// step and SIMD of 2 448 measured) but by what a wave issues BESIDES its MFMAs: per K step 6 LDS-DMA pieces (60-185 cycles of
+// issue each), 16 fragment reads, two counted waits and a barrier against 32 MFMAs -- and all eight waves do those at the same
+// time.  This kernel (a) doubles the wave tile to 128 x 64: 0.375 fragment reads per MFMA instead of 0.5, 8 pieces per 64 MFMAs
+// instead of 6 per 32; the 128 accumulator registers per lane live in AGPRs (MFMAs written as asm with the accumulator tied in
+// place, as in gemm_mx8_kernel), the two fragment sets in the 128 VGPRs beside them; (b) runs its two wave groups (waves w and
+// w + 4 share a SIMD) one segment apart, so that one wave of a SIMD issues loads while the other has the matrix pipe (schedule
+// at the K loop).  64 KB per stage leave room for two stages; the pieces of step k + 2 are issued right after the last read of
+// step k and have a whole step to land.  Bit-identical to gemm_glds3_kernel (same products, same order, same epilogues:
+// tests/test_gpu_kernels.py).  Used for grids of at least option gemm_tile256sq_min 256 x 256 tiles whose rounds of 256
+// workgroups are >= 88 % full (the encoder's GEMMs at 32 chunks).  Measured (profiles/r04_gemm_256sq.txt): 8192^3 1 052 ->
+// 1 157 TFLOP/s, base qkv 191 -> 170 us, wi 344 -> 305, wo 129 -> 113, cross-K/V 1 480 -> 1 391.
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_glds4_kernel(GemmP p) {
+  using T = bf16_t;
+  constexpr int MI = 8, NI = 4;
+  constexpr int BM = 256, BN = 256, BK = 64;
+  constexpr int kRowStride = 128, kStage = (BM + BN) * kRowStride;
+  constexpr int WM = 16 * MI, WN = 64;
+  constexpr int NA = 4, NB = 4;              // LDS-DMA instructions per wave and stage and operand (32 groups of 8 rows over 8 waves)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wr = wid >> 2, wc = wid & 3;
+
+  const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
+  const int nwg = nbm * nbn;
+  int bid = blockIdx.x;
+  {   // block b runs on XCD b % 8: give every XCD a contiguous range of the work list (bijective)
+    const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  int bm, bn;
+  {   // groups of GM row panels (<= ~2.5 MB of A), inside a group the row panel runs fastest: W panels are fetched once per group
+    const long panel_bytes = (long)BM * p.K * (long)sizeof(T);
+    int GM = (int)((5L << 19) / (panel_bytes > 0 ? panel_bytes : 1));
+    GM = GM < 2 ? 2 : (GM > 16 ? 16 : GM);
+    const int per_group = GM * nbn;
+    const int grp = bid / per_group, rem = bid - grp * per_group;
+    const int gm = (nbm - grp * GM) < GM ? (nbm - grp * GM) : GM;
+    bn = rem / gm;
+    bm = grp * GM + (rem - bn * gm);
+  }
+  const int m0 = bm * BM, n0 = bn * BN;
+  const int nk = (p.K + BK - 1) / BK;        // K % 64 == 0 (dispatch condition)
+
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  // sources: a block-uniform 64-bit base per operand (advanced by SALU every K step) + ONE 32-bit byte offset per lane and piece
+  // -- 8 offset registers instead of 16 pointer registers, and no VALU in the K loop for them
+  const char* a_base = p.A + (long)m0 * p.lda_b;
+  const char* w_base = p.W + (long)n0 * p.ldw_b;
+  uint32_t soff[NA + NB];
+  {
+    const int r8 = lane >> 3;
+    const uint32_t k_off = (uint32_t)(((lane & 7) ^ r8) * 16);       // pre-swizzled source chunk (tile row & 7 == r8)
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      int ra_ = (i * 8 + wid) * 8 + r8; ra_ = m0 + ra_ < p.M ? ra_ : p.M - 1 - m0;
+      soff[i] = (uint32_t)ra_ * (uint32_t)p.lda_b + k_off;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      int rb_ = (i * 8 + wid) * 8 + r8; rb_ = n0 + rb_ < p.N ? rb_ : p.N - 1 - n0;
+      soff[NA + i] = (uint32_t)rb_ * (uint32_t)p.ldw_b + k_off;
+    }
+  }
+  auto issue = [&](int st) {          // the NEXT K tile (the bases advance)
+    char* base = smem + st * kStage;
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(a_base + soff[i]), (lptr_t)(base + (i * 8 + wid) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(w_base + soff[NA + i]), (lptr_t)(base + BM * kRowStride + (i * 8 + wid) * 1024), 16, 0, 0);
+    a_base += BK * sizeof(T);
+    w_base += BK * sizeof(T);
+  };
+
+  // transposed product as in gemm_glds3_kernel: acc[j][i][r] = C[m0 + wr*128 + i*16 + (lane & 15)][n0 + wc*64 + j*16 + (lane >> 4)*4 + r]
+  f32x4_t acc[NI][MI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j)
+#pragma unroll
+    for (int i = 0; i < MI; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  // STAGGERED wave groups.  Waves w and w + 4 share a SIMD; group g = wid >> 2 (= wr).  A K step is four segments separated by
+  // barriers -- ISSUE_A (12 fragment reads), MFMA0 (32 MFMAs), ISSUE_B (8 LDS-DMA pieces of step k + 2, 12 fragment reads), MFMA1
+  // (32 MFMAs) -- and group 1 runs ONE segment behind group 0 (one extra barrier in front of its loop, one behind group 0's):
+  // while one wave of a SIMD issues loads, the other has the matrix pipe to itself.
+  //   slot 4k: G0 ISSUE_A(k) | G1 MFMA1(k-1)     slot 4k+1: G0 MFMA0(k) | G1 ISSUE_A(k)
+  //   slot 4k+2: G0 ISSUE_B(k) | G1 MFMA0(k)     slot 4k+3: G0 MFMA1(k) | G1 ISSUE_B(k)
+  // Stage k % 2 is read in ISSUE_B(k-1) (ks 0) and ISSUE_A(k) (ks 1), last by G1 in slot 4k+1, every read retired (lgkmcnt(0))
+  // before that slot's barrier; the pieces of step k + 2 go into it from slot 4k+2 (G0) / 4k+3 (G1) on, are waited for
+  // (vmcnt(0)) at the end of each wave's ISSUE_A(k+1) (slots 4k+4 / 4k+5) and first read in slot 4k+6.
+  issue(0);
+  if (nk > 1) {
+    issue(1);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // this wave's pieces of step 0 have landed
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  const int frow = lane & 15, sw = frow & 7, lgc = lane >> 4;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
+  const uint32_t a_off = (uint32_t)((wr * WM + frow) * kRowStride), b_off = (uint32_t)((BM + wc * WN + frow) * kRowStride);
+#define G4_RD(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=v"(dst) : "v"(addr))
+  auto ldfrag = [&](int st, int ks, bf16x8_t (&af)[MI], bf16x8_t (&bf)[NI]) {
+    const uint32_t coff = (uint32_t)(((ks * 4 + lgc) ^ sw) * 16);
+    const uint32_t pa = lds0 + st * kStage + a_off + coff, pb = lds0 + st * kStage + b_off + coff;
+    G4_RD(bf[0], pb, 0); G4_RD(bf[1], pb, 2048); G4_RD(bf[2], pb, 4096); G4_RD(bf[3], pb, 6144);
+    G4_RD(af[0], pa, 0); G4_RD(af[1], pa, 2048); G4_RD(af[2], pa, 4096); G4_RD(af[3], pa, 6144);
+    G4_RD(af[4], pa, 8192); G4_RD(af[5], pa, 10240); G4_RD(af[6], pa, 12288); G4_RD(af[7], pa, 14336);
+  };
+#undef G4_RD
+  auto mma = [&](bf16x8_t (&af)[MI], bf16x8_t (&bf)[NI]) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[j][i]) : "v"(bf[j]), "v"(af[i]));
+  };
+#define G4_WAIT(str) do { asm volatile(str ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define G4_BARRIER() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+  bf16x8_t a0[MI], b0[NI], a1[MI], b1[NI];
+  ldfrag(0, 0, a0, b0);
+  if (wr == 1) G4_BARRIER();                        // group 1: one segment behind
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    // ISSUE_A
+    ldfrag(cur, 1, a1, b1);
+    G4_WAIT("s_waitcnt vmcnt(0) lgkmcnt(0)");       // a0 / b0 / a1 / b1 are in; this wave's pieces of step kt + 1 have landed
+    G4_BARRIER();
+    // MFMA0
+    mma(a0, b0);
+    G4_BARRIER();
+    // ISSUE_B
+    if (kt + 2 < nk) issue(cur);                    // (stage of step kt: every wave retired its reads of it two barriers ago or more)
+    if (kt + 1 < nk) ldfrag(cur ^ 1, 0, a0, b0);
+    G4_BARRIER();
+    // MFMA1
+    mma(a1, b1);
+    G4_BARRIER();
+    cur ^= 1;
+  }
+  if (wr == 0) G4_BARRIER();
+#undef G4_BARRIER
+#undef G4_WAIT
+  // the MFMAs are asm: hipcc does not know that the accumulators come out of the matrix pipe.  It pads nothing in front of
+  // their first read -- and it is free to move a v_accvgpr_read of an accumulator up to right behind the asm statement that last
+  // wrote it, i.e. in between the final MFMAs (seen: the GEGLU epilogue read acc[0][0] there and got the value of a step ago).
+  // The sched_barriers pin every read below the padding.
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 7" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
   g3_epilogue<EPI, MI>(p, acc, m0, n0, wr, wc, lane);
 }
 
@@ -1398,8 +1559,11 @@ __global__ __launch_bounds__(NW * 64) void gemm_mx8_kernel(GemmP p) {
 #undef MX_STR
 #undef MX_STR2
   // the MFMAs are asm: hipcc does not know that the accumulators come out of the matrix pipe (8 passes behind the last
-  // issue) and pads nothing in front of their first VALU / accvgpr read
+  // issue) and pads nothing in front of their first VALU / accvgpr read; the sched_barriers keep every such read below the
+  // padding (without them a read may be scheduled in between the final MFMAs: see gemm_glds4_kernel)
+  __builtin_amdgcn_sched_barrier(0);
   asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 7" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
   g3_epilogue<EPI, MI>(p, acc, m0, n0, wr, wc, lane);
 }
 
@@ -1458,6 +1622,13 @@ int launch_glds3(const GemmP& p, hipStream_t s) {
   return check_launch("gemm_glds3_kernel");
 }
 
+template <int EPI>
+int launch_glds4(const GemmP& p, hipStream_t s) {
+  const int nbm = (p.M + 255) / 256, nbn = (p.N + 255) / 256;
+  hipLaunchKernelGGL((gemm_glds4_kernel<EPI>), dim3(nbm * nbn), dim3(512), 2 * (256 + 256) * 128, s, p);
+  return check_launch("gemm_glds4_kernel");
+}
+
 template <typename T, int BM, int BN, int EPI, bool S3 = false, bool GL = false>
 int launch_gemm(const GemmP& p, hipStream_t s) {
   const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
@@ -1486,7 +1657,9 @@ bool prepare_epi() {
     ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds3_kernel<EPI, 4>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (256 + 128) * 128) == hipSuccess &&
          hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds3_kernel<EPI, 2>),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (128 + 128) * 128) == hipSuccess;
+                             hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (128 + 128) * 128) == hipSuccess &&
+         hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds4_kernel<EPI>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 256) * 128) == hipSuccess;
   if constexpr (EPI != MH_EPI_GEGLU) ok = ok && prepare_one<T, 32, 32, EPI>() && prepare_one<T, 16, 16, EPI>();   // GEGLU pairs two 16-col blocks per wave
   return ok;
 }
@@ -1533,6 +1706,14 @@ int dispatch_tile(const GemmP& p, hipStream_t s) {
         // fewer 256-row tiles than half the CUs: the 128-row form of the same kernel doubles the workgroups (batched DiT-S bf16,
         // N = 384: 96 -> 192 workgroups, 153 -> 137 ms per 100 steps; at 192 tiles -- DiT-B, N = 768 -- it loses, 294 -> 308)
         if (tiles256 < 128 && option(OPT_GEMM_GLDS) >= 3) return launch_glds3<EPI, 2>(p, s);
+        // enough 256 x 256 tiles to fill the chip: the two-stage kernel with 128 x 64 wave tiles
+        // ... when its last round of workgroups is not mostly idle: one workgroup per CU, so 628 tiles (osuT5-large's N = 1024
+        // projections) are three rounds at 82 % -- measured 276 us against 244 for the 256 x 128 tile, while 471 tiles (92 %) gain
+        const long tiles256sq = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
+        const long min256sq = option(OPT_GEMM_TILE256SQ_MIN);
+        const long rounds = (tiles256sq + 255) / 256;
+        const bool full_rounds = min256sq == 1 || tiles256sq * 100 >= rounds * 256 * 88;     // (option value 1: always, for tests)
+        if (min256sq > 0 && tiles256sq >= min256sq && full_rounds && option(OPT_GEMM_GLDS) >= 3) return launch_glds4<EPI>(p, s);
         return launch_glds3<EPI, 4>(p, s);
       }
       if (option(OPT_GEMM_GLDS) != 0) return launch_gemm<T, 128, 128, EPI, false, true>(p, s);

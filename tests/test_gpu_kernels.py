@@ -474,3 +474,48 @@ def test_whisper_frontend(dtype_name):
     want2 = whisper_frontend(x2, w1, b1, w2, b2, None, rounding=None if dt == torch.float32 else "bf16")
     assert got2.shape == want2.shape == (3, 39, 128)
     assert (got2 - want2).abs().max().item() < (2e-5 if dt == torch.float32 else 3e-2)
+
+
+@pytest.mark.parametrize("case", ["STORE", "STORE_F32", "RESID_k768", "RESID_k2048", "GEGLU", "BIAS_GELU", "QKV_VT", "KV_SCATTER", "ragged"])
+def test_gemm_256sq_tile_is_bit_identical_to_the_three_stage_kernel(case):
+    """gemm_glds4_kernel (256 x 256 tile, 128 x 64 wave tiles, AGPR accumulators, asm MFMAs; the encoder's GEMMs at 32 chunks)
+    accumulates the same products in the same order as gemm_glds3_kernel and shares its epilogues: every output bit must agree,
+    for every epilogue the T5 path uses and for ragged M / N / short K.  (It caught hipcc scheduling an accumulator read in
+    between the final asm MFMAs: the GEGLU epilogue then saw acc[0][0] one K step old.)"""
+    L, _ = _lib()
+    M = 5 * 1251 if case in ("QKV_VT", "KV_SCATTER") else (4099 if case == "ragged" else 6000)
+    g = torch.Generator().manual_seed(len(case))
+    A768 = torch.randn(M, 768, generator=g)
+    w = lambda n, k, sc=0.05: torch.randn(n, k, generator=g) * sc
+    if case == "STORE":
+        fn = lambda W=w(2304, 768, 1.0): run_gemm(A768, W, L.EPI_STORE, L.MH_BF16)
+    elif case == "STORE_F32":
+        fn = lambda W=w(768, 768, 1.0): run_gemm(A768, W, L.EPI_STORE_F32, L.MH_BF16)
+    elif case == "RESID_k768":
+        fn = lambda W=w(768, 768), C0=torch.randn(M, 768, generator=g): run_gemm(A768, W, L.EPI_RESID, L.MH_BF16, C0=C0)
+    elif case == "RESID_k2048":
+        fn = lambda A=torch.randn(M, 2048, generator=g), W=w(768, 2048), C0=torch.randn(M, 768, generator=g): run_gemm(A, W, L.EPI_RESID, L.MH_BF16, C0=C0)
+    elif case == "GEGLU":
+        fn = lambda W=w(4096, 768): run_gemm(A768, W, L.EPI_GEGLU, L.MH_BF16)
+    elif case == "BIAS_GELU":
+        fn = lambda W=w(3072, 768), b=torch.randn(3072, generator=g): run_gemm(A768, W, L.EPI_BIAS_GELU, L.MH_BF16, bias=b)
+    elif case == "QKV_VT":
+        fn = lambda W=w(2304, 768): run_gemm(A768, W, L.EPI_QKV_VT, L.MH_BF16, kv=(5, 12, 1251), n_split=1536, Lpad=1280)
+    elif case == "KV_SCATTER":
+        fn = lambda W=w(2 * 2 * 768, 768): run_gemm(A768, W, L.EPI_KV_SCATTER, L.MH_BF16, kv=(5, 12, 1251))
+    else:
+        fn = lambda A=torch.randn(M, 192, generator=g), W=w(1284, 192, 1.0): run_gemm(A, W, L.EPI_STORE, L.MH_BF16)
+    outs = []
+    old = L.set_option("gemm_tile256sq_min", 0)
+    try:
+        for thr in (0, 1):
+            L.set_option("gemm_tile256sq_min", thr)
+            outs.append(fn())
+    finally:
+        L.set_option("gemm_tile256sq_min", old)
+    a, b = outs
+    if isinstance(a, tuple):
+        assert all(torch.equal(x, y) for x, y in zip(a, b))
+    else:
+        assert torch.equal(a, b), (a - b).abs().max().item()
+

@@ -8,6 +8,11 @@ has issued; if it spills or copies such a register before the hand-placed wait, 
 That produced wrong results once (the 256-row bf16x3 form).  The kernels named in ASM_LOAD_KERNELS must therefore compile to
 ZERO scratch and ZERO spilled registers -- checked at build time (`__graft_entry__.build()`) and in the CPU test suite.
 
+One refinement: scratch traffic that sits entirely BEHIND the kernel's last MFMA (checked in the disassembly) is an epilogue
+spill -- every asm-loaded fragment has been consumed by then, nothing asm-issued is in flight -- and is reported but allowed
+(the 256 x 256 bf16 tile keeps 128 accumulators in AGPRs and has 128 VGPRs for everything else: some of its epilogues park an
+address pair in scratch).
+
 usage: check_kernel_resources.py [lib.so] [--all]        (exit status 1 on a violation)"""
 from __future__ import annotations
 
@@ -62,6 +67,19 @@ def kernels_of(elf: bytes):
     return out
 
 
+def scratch_only_behind_last_mfma(elf: bytes, symbol: str) -> bool:
+    """True iff every scratch_* instruction of kernel `symbol` comes after its last v_mfma instruction (program order)"""
+    with tempfile.NamedTemporaryFile(suffix=".co") as f:
+        f.write(elf)
+        f.flush()
+        txt = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--mcpu=gfx950", f"--disassemble-symbols={symbol}", f.name],
+                             check=True, capture_output=True, text=True).stdout
+    ins = [ln.split("//")[0].strip() for ln in txt.splitlines() if "\t" in ln]
+    mf = [i for i, ln in enumerate(ins) if ln.startswith("v_mfma")]
+    sc = [i for i, ln in enumerate(ins) if ln.startswith("scratch_")]
+    return bool(mf) and bool(sc) and min(sc) > max(mf)
+
+
 def demangle(names):
     """c++filt when the box has one; mangled names contain the kernel's plain name anyway, which is all the policy matches on"""
     import shutil
@@ -76,25 +94,34 @@ def main(argv):
     show_all = "--all" in argv
     paths = [a for a in argv if not a.startswith("--")]
     lib = paths[0] if paths else os.path.join(ROOT, "mapperatorinator_amd", "lib", "libmapperhip.so")
-    rows = []
+    rows, owner = [], []
     for elf in code_objects(lib):
-        rows += kernels_of(elf)
+        ks = kernels_of(elf)
+        rows += ks
+        owner += [elf] * len(ks)
     if not rows:
         print(f"{lib}: no gfx950 kernels found", file=sys.stderr)
         return 2
     names = demangle([r[".symbol"].removesuffix(".kd") for r in rows])
     bad, n_checked = [], 0
-    for r, nm in zip(rows, names):
+    n_epi = 0
+    for r, nm, elf in zip(rows, names, owner):
         scratch = int(r.get(".private_segment_fixed_size", 0))
         spills = int(r.get(".vgpr_spill_count", 0)) + int(r.get(".sgpr_spill_count", 0))
         watched = any(w in nm for w in ASM_LOAD_KERNELS)
         n_checked += watched
+        if watched and (scratch or spills) and scratch_only_behind_last_mfma(elf, r[".symbol"].removesuffix(".kd")):
+            n_epi += 1
+            if show_all:
+                print(f"ep vgpr {r.get('.vgpr_count', '?'):>3} agpr {r.get('.agpr_count', '?'):>3} scratch {scratch:>5} spills {spills:>3}  (behind the last MFMA) {nm[:120]}")
+            continue
         if show_all or (watched and (scratch or spills)):
             print(f"{'!!' if watched and (scratch or spills) else '  '} vgpr {r.get('.vgpr_count', '?'):>3} agpr {r.get('.agpr_count', '?'):>3} "
                   f"sgpr {r.get('.sgpr_count', '?'):>3} lds {r.get('.group_segment_fixed_size', '?'):>6} scratch {scratch:>5} spills {spills:>3}  {nm[:150]}")
         if watched and (scratch or spills):
             bad.append(nm)
-    print(f"{len(rows)} kernels, {n_checked} with asm-issued loads checked for scratch / spills: {'FAIL ' + str(len(bad)) if bad else 'ok'}")
+    print(f"{len(rows)} kernels, {n_checked} with asm-issued loads checked for scratch / spills: {'FAIL ' + str(len(bad)) if bad else 'ok'}"
+          + (f" ({n_epi} with epilogue-only spills behind their last MFMA)" if n_epi else ""))
     return 1 if bad else 0
 
 
