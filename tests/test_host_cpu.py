@@ -587,12 +587,15 @@ def test_kernels_with_asm_issued_loads_have_no_scratch_and_no_spills():
     ckr = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(ckr)
     lib = os.path.join(root, "mapperatorinator_amd", "lib", "libmapperhip.so")
-    rows = [k for elf in ckr.code_objects(lib) for k in ckr.kernels_of(elf)]
-    watched = [k for k in rows if any(w in k[".symbol"] for w in ckr.ASM_LOAD_KERNELS)]
+    rows = [(k, elf) for elf in ckr.code_objects(lib) for k in ckr.kernels_of(elf)]
+    watched = [(k, elf) for k, elf in rows if any(w in k[".symbol"] for w in ckr.ASM_LOAD_KERNELS)]
     assert len(rows) > 100 and len(watched) >= 20
-    for k in watched:
-        assert int(k.get(".private_segment_fixed_size", 0)) == 0, k[".symbol"]
-        assert int(k.get(".vgpr_spill_count", 0)) == 0 and int(k.get(".sgpr_spill_count", 0)) == 0, k[".symbol"]
+    for k, elf in watched:
+        dirty = (int(k.get(".private_segment_fixed_size", 0)) or int(k.get(".vgpr_spill_count", 0)) or int(k.get(".sgpr_spill_count", 0)))
+        if dirty:   # allowed only where the disassembly shows every scratch access behind the kernel's last MFMA (an epilogue
+            # spill: nothing asm-issued is in flight there) -- the 256 x 256 bf16 tile with its 128 AGPR accumulators
+            assert "gemm_glds4_kernel" in k[".symbol"], k[".symbol"]
+            assert ckr.scratch_only_behind_last_mfma(elf, k[".symbol"].removesuffix(".kd")), k[".symbol"]
     assert ckr.main([lib]) == 0
 
 
