@@ -852,6 +852,137 @@ __global__ __launch_bounds__(512) void gemm_glds3_kernel(GemmP p) {
   g3_epilogue<EPI, MI>(p, acc, m0, n0, wr, wc, lane);
 }
 
+// ---- G2S: bf16, 128 x 128 tile, TWO LDS stages (64 KB): two workgroups per CU ----------------------------------------------------
+// For SHORT K (the batched DiT's K = 384 / 768 projections: 6-12 K steps) a tile's prologue (the first stage's round trip) and
+// epilogue (stores, residual / gate reads) are as long as its K loop, and the three-stage kernels hold a whole CU (96-144 KB of
+// LDS): nothing runs under them.  Two stages of (128 + 128) rows x 128 bytes are 64 KB, the wave tile 32 x 64 needs ~90 VGPRs:
+// two workgroups share a CU and one's prologue / epilogue runs under the other's K loop.  The DMA of step kt + 1 is issued at the
+// start of step kt (its buffer held step kt - 1, retired by every wave before that step's barrier) and waited for at the
+// barrier in the middle of step kt.  Same swizzle, fragment reads, MFMA order and epilogues as gemm_glds3_kernel<EPI, 2>:
+// bit-identical results.  Dispatch: K <= option gemm_2stage_max_k.
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_glds2s_kernel(GemmP p) {
+  using T = bf16_t;
+  constexpr int MI = 2, NI = 4;
+  constexpr int BM = 128, BN = 128, BK = 64;
+  constexpr int kRowStride = 128, kStage = (BM + BN) * kRowStride;
+  constexpr int WM = 16 * MI, WN = 64;
+  constexpr int NA = 2, NB = 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wr = wid >> 1, wc = wid & 1;
+
+  const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
+  const int nwg = nbm * nbn;
+  int bid = blockIdx.x;
+  {   // block b runs on XCD b % 8: give every XCD a contiguous range of the work list (bijective)
+    const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  int bm, bn;
+  {
+    const long panel_bytes = (long)BM * p.K * (long)sizeof(T);
+    int GM = (int)((5L << 19) / (panel_bytes > 0 ? panel_bytes : 1));
+    GM = GM < 2 ? 2 : (GM > 16 ? 16 : GM);
+    const int per_group = GM * nbn;
+    const int grp = bid / per_group, rem = bid - grp * per_group;
+    const int gm = (nbm - grp * GM) < GM ? (nbm - grp * GM) : GM;
+    bn = rem / gm;
+    bm = grp * GM + (rem - bn * gm);
+  }
+  const int m0 = bm * BM, n0 = bn * BN;
+  const int nk = (p.K + BK - 1) / BK;
+
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  const char* a_base = p.A + (long)m0 * p.lda_b;
+  const char* w_base = p.W + (long)n0 * p.ldw_b;
+  uint32_t soff[NA + NB];
+  {
+    const int r8 = lane >> 3;
+    const uint32_t k_off = (uint32_t)(((lane & 7) ^ r8) * 16);
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      int ra_ = (i * 8 + wid) * 8 + r8; ra_ = m0 + ra_ < p.M ? ra_ : p.M - 1 - m0;
+      soff[i] = (uint32_t)ra_ * (uint32_t)p.lda_b + k_off;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      int rb_ = (i * 8 + wid) * 8 + r8; rb_ = n0 + rb_ < p.N ? rb_ : p.N - 1 - n0;
+      soff[NA + i] = (uint32_t)rb_ * (uint32_t)p.ldw_b + k_off;
+    }
+  }
+  auto issue = [&](int st) {
+    char* base = smem + st * kStage;
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(a_base + soff[i]), (lptr_t)(base + (i * 8 + wid) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(w_base + soff[NA + i]), (lptr_t)(base + BM * kRowStride + (i * 8 + wid) * 1024), 16, 0, 0);
+    a_base += BK * sizeof(T);
+    w_base += BK * sizeof(T);
+  };
+
+  f32x4_t acc[NI][MI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j)
+#pragma unroll
+    for (int i = 0; i < MI; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  issue(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  const int frow = lane & 15, sw = frow & 7, lgc = lane >> 4;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
+  const uint32_t a_off = (uint32_t)((wr * WM + frow) * kRowStride), b_off = (uint32_t)((BM + wc * WN + frow) * kRowStride);
+  auto ldfrag = [&](int st, int ks, bf16x8_t (&af)[MI], bf16x8_t (&bf)[NI]) {
+    const uint32_t coff = (uint32_t)(((ks * 4 + lgc) ^ sw) * 16);
+    const uint32_t pa = lds0 + st * kStage + a_off + coff, pb = lds0 + st * kStage + b_off + coff;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(af[0]) : "v"(pa));
+    asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(af[1]) : "v"(pa));
+    asm volatile("ds_read_b128 %0, %1" : "=v"(bf[0]) : "v"(pb));
+    asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(bf[1]) : "v"(pb));
+    asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(bf[2]) : "v"(pb));
+    asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(bf[3]) : "v"(pb));
+  };
+  auto mma = [&](const bf16x8_t (&af)[MI], const bf16x8_t (&bf)[NI]) {
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int i = 0; i < MI; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], acc[j][i], 0, 0, 0);
+  };
+#define G2_WAIT(str) do { asm volatile(str ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+  bf16x8_t a0[MI], b0[NI], a1[MI], b1[NI];
+  ldfrag(0, 0, a0, b0);
+  int cur = 0;
+  for (int kt = 0; kt + 1 < nk; ++kt) {
+    issue(cur ^ 1);
+    ldfrag(cur, 1, a1, b1);
+    G2_WAIT("s_waitcnt lgkmcnt(6)");               // a0 / b0 (read one phase ago) are in
+    mma(a0, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    G2_WAIT("s_waitcnt vmcnt(0) lgkmcnt(0)");      // a1 / b1 are in; this wave's pieces of step kt + 1 have landed
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    cur ^= 1;
+    ldfrag(cur, 0, a0, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(a1, b1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  ldfrag(cur, 1, a1, b1);                          // last step
+  G2_WAIT("s_waitcnt lgkmcnt(6)");
+  mma(a0, b0);
+  __builtin_amdgcn_sched_barrier(0);
+  G2_WAIT("s_waitcnt lgkmcnt(0)");
+  mma(a1, b1);
+#undef G2_WAIT
+  g3_epilogue<EPI, MI>(p, acc, m0, n0, wr, wc, lane);
+}
+
 // ---- G4: bf16, 256 x 256 tile, 8 waves as 2 (M) x 4 (N) of 128 x 64, TWO LDS stages, two staggered wave groups --------------------
 // gemm_glds3_kernel is bound neither by LDS bandwidth (its XOR-swizzled fragment reads are conflict-free: 4 LDS cycles each under
 // the quarter-wave lane groups of MI355X_MICROARCH.md, 512 cycles per K step and CU) nor by the matrix pipe (1 024 cycles per K
@@ -1623,6 +1754,13 @@ int launch_glds3(const GemmP& p, hipStream_t s) {
 }
 
 template <int EPI>
+int launch_glds2s(const GemmP& p, hipStream_t s) {
+  const int nbm = (p.M + 127) / 128, nbn = (p.N + 127) / 128;
+  hipLaunchKernelGGL((gemm_glds2s_kernel<EPI>), dim3(nbm * nbn), dim3(512), 2 * (128 + 128) * 128, s, p);
+  return check_launch("gemm_glds2s_kernel");
+}
+
+template <int EPI>
 int launch_glds4(const GemmP& p, hipStream_t s) {
   const int nbm = (p.M + 255) / 256, nbn = (p.N + 255) / 256;
   hipLaunchKernelGGL((gemm_glds4_kernel<EPI>), dim3(nbm * nbn), dim3(512), 2 * (256 + 256) * 128, s, p);
@@ -1659,7 +1797,9 @@ bool prepare_epi() {
          hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds3_kernel<EPI, 2>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (128 + 128) * 128) == hipSuccess &&
          hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds4_kernel<EPI>),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 256) * 128) == hipSuccess;
+                             hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 256) * 128) == hipSuccess &&
+         hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds2s_kernel<EPI>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + 128) * 128) == hipSuccess;
   if constexpr (EPI != MH_EPI_GEGLU) ok = ok && prepare_one<T, 32, 32, EPI>() && prepare_one<T, 16, 16, EPI>();   // GEGLU pairs two 16-col blocks per wave
   return ok;
 }
@@ -1702,6 +1842,8 @@ int dispatch_tile(const GemmP& p, hipStream_t s) {
       const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + 127) / 128);
       const bool vec_ok = p.N % 4 == 0 && p.ldc % 4 == 0 && (p.gate == nullptr || p.gate_ld % 4 == 0) &&
                           (EPI != MH_EPI_GEGLU || p.N % 8 == 0) && p.K % 64 == 0;
+      if (option(OPT_GEMM_GLDS) >= 3 && p.K <= option(OPT_GEMM_2STAGE_MAX_K) && !p.stats_out && vec_ok)
+        return launch_glds2s<EPI>(p, s);      // short K: two workgroups per CU, one's prologue / epilogue under the other's K loop
       if (option(OPT_GEMM_GLDS) >= 2 && tiles256 >= option(OPT_GEMM_TILE256_MIN) && !p.stats_out && vec_ok) {
         // fewer 256-row tiles than half the CUs: the 128-row form of the same kernel doubles the workgroups (batched DiT-S bf16,
         // N = 384: 96 -> 192 workgroups, 153 -> 137 ms per 100 steps; at 192 tiles -- DiT-B, N = 768 -- it loses, 294 -> 308)

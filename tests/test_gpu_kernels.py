@@ -519,3 +519,36 @@ def test_gemm_256sq_tile_is_bit_identical_to_the_three_stage_kernel(case):
     else:
         assert torch.equal(a, b), (a - b).abs().max().item()
 
+
+@pytest.mark.parametrize("case", ["STORE", "GATE_RESID", "BIAS_GELU", "RESID_ragged", "QKV_VT"])
+def test_gemm_two_stage_tile_is_bit_identical_to_the_three_stage_kernel(case):
+    """gemm_glds2s_kernel (128 x 128 tile, two LDS stages = 64 KB: two workgroups per CU; the batched DiT's short-K projections)
+    against the three-stage kernels: same products, same order, same epilogues -- every output bit."""
+    L, _ = _lib()
+    g = torch.Generator().manual_seed(3 + len(case))
+    M = 8192
+    if case == "STORE":
+        fn = lambda A=torch.randn(M, 384, generator=g), W=torch.randn(1152, 384, generator=g): run_gemm(A, W, L.EPI_STORE, L.MH_BF16)
+    elif case == "GATE_RESID":
+        fn = lambda A=torch.randn(M, 1536, generator=g), W=torch.randn(384, 1536, generator=g) * 0.05, C0=torch.randn(M, 384, generator=g), G=torch.randn(64, 384, generator=g): run_gemm(
+            A, W, L.EPI_GATE_RESID, L.MH_BF16, C0=C0, gate=G, rows_per_batch=128)
+    elif case == "BIAS_GELU":
+        fn = lambda A=torch.randn(M, 384, generator=g), W=torch.randn(1536, 384, generator=g) * 0.05, b=torch.randn(1536, generator=g): run_gemm(
+            A, W, L.EPI_BIAS_GELU, L.MH_BF16, bias=b)
+    elif case == "RESID_ragged":
+        fn = lambda A=torch.randn(4099, 192, generator=g), W=torch.randn(1284, 192, generator=g), C0=torch.randn(4099, 1284, generator=g): run_gemm(
+            A, W, L.EPI_RESID, L.MH_BF16, C0=C0)
+    else:
+        fn = lambda A=torch.randn(64 * 128, 384, generator=g), W=torch.randn(1152, 384, generator=g) * 0.05: run_gemm(
+            A, W, L.EPI_QKV_VT, L.MH_BF16, kv=(64, 6, 128), n_split=768, Lpad=128)
+    outs = []
+    old = L.set_option("gemm_2stage_max_k", 0)
+    try:
+        for mk in (0, 4096):
+            L.set_option("gemm_2stage_max_k", mk)
+            outs.append(fn())
+    finally:
+        L.set_option("gemm_2stage_max_k", old)
+    a, b = outs
+    assert all(torch.equal(x, y) for x, y in zip(a, b)) if isinstance(a, tuple) else torch.equal(a, b)
+

@@ -27,7 +27,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LLVM = os.environ.get("ROCM_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
 MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
 # demangled-name fragments of the kernels whose loads are issued by inline asm and covered by counted waits
-ASM_LOAD_KERNELS = ("gemm_glds3_kernel", "gemm_s3g_kernel", "gemm_mx8_kernel", "gemm_glds4_kernel")
+ASM_LOAD_KERNELS = ("gemm_glds3_kernel", "gemm_s3g_kernel", "gemm_mx8_kernel", "gemm_glds4_kernel", "gemm_glds2s_kernel")
 
 
 def code_objects(lib_path: str):
