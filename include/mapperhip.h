@@ -98,6 +98,13 @@ int mh_abi_version(void);
  *                                                   device-side progress words instead of stream order; T5 backbone, chains of
  *                                                   <= 16 rows, d_model 128 / 512 / 768 / 1024).  Bit-identical tokens and logits;
  *                                                   measured slower than the plain step (profiles/r04_decode_overlap.txt)
+ *   "gemm_tile256sq_min" MH_GEMM_TILE256SQ_MIN 440  bf16 GEMM: the 256x256 tile (two LDS stages, 128x64 wave tiles, staggered wave
+ *                                                   groups) from this many tiles on when its rounds of 256 workgroups are >= 88 %
+ *                                                   full (0 = never; bit-identical to the 256x128 three-stage kernel)
+ *   "gemm_2stage_max_k"  MH_GEMM_2STAGE_MAX_K  512  bf16 GEMM with K <= this: 128x128 tile on two LDS stages, two workgroups per CU
+ *                                                   (0 = never; bit-identical)
+ *   "mx8_waves"          MH_MX8_WAVES          8    MX-fp8 GEMM, 256x128 tile: eight waves of 64x64 (two per SIMD) or 4 = four
+ *                                                   waves of 128x64 with AGPR accumulators (bit-identical)
  * (further switches -- decode_cu_split, gemm_tile128_min, gemm_tile256_min, attn_small_max_wgs, dit_split3_min_rows,
  * dit_s3_fused_ln, mx8_tile256_min -- are documented next to their definitions in csrc/api.hip.)
  * Unknown names return MH_ERR_ARG (set) / -1 (get). */
