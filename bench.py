@@ -634,7 +634,8 @@ def main():
                                                  f"positions per 16.4 s chunk), batch={B}, {new} greedy tokens per chunk",
                                      "tokens_per_s": round(int((tw[:, 1:] != 0).sum().item()) / dtw, 1), "ms_per_step": round(dtw * 1e3, 2)}
             del mw, ew
-        except Exception as e:   # an auxiliary figure must never cost the bench line
+        except Exception as e:   # an auxiliary figure must never cost the bench line -- but it must not vanish silently either
+            aux.setdefault("errors", []).append(f"whisper_family: {e!r}")
             print(f"whisper-family pass failed: {e!r}", file=sys.stderr)
 
     # ---- BASELINE configs[4] "fp8 MFMA", T5 side: mel + encoder + cross-K/V of the headline batch with MX-fp8 operands ----
@@ -674,7 +675,8 @@ def main():
                 "projections + cross-K/V projection on MX-fp8 operands, attention bf16); frac = flops of those projections / whole-stage time "
                 "(mel, attention, norms and quantiser passes included) / 5 PFLOP/s; NOT a parity mode: teacher-forced agreement against the fp32 "
                 "reference goldens in tests/test_gpu_t5.py::test_mx8_encoder_teacher_forced_on_the_reference_fp32_run")
-        except Exception as e:   # an auxiliary figure must never cost the bench line
+        except Exception as e:
+            aux.setdefault("errors", []).append(f"config5_fp8.t5_encoder: {e!r}")
             print(f"config 5 fp8 encoder pass failed: {e!r}", file=sys.stderr)
 
     # ---- BASELINE configs[4]: whole 3-minute songs, KV-cached, through the window scheduler (tools/long_song_bench.py) ----
@@ -689,7 +691,8 @@ def main():
                 "base": lsb.run("base", songs=32, windows=18, fp8_kv=(False,), device=str(dev)),
                 "note": "32 songs x 18 windows (3 min each): every window encoded up front, its cross K/V resident in HBM, wave w "
                         "decodes window w of all songs; window w's prompt carries the last 32 tokens of window w-1"}
-        except Exception as e:   # an auxiliary figure must never cost the bench line
+        except Exception as e:
+            aux.setdefault("errors", []).append(f"config5_long_songs: {e!r}")
             print(f"config 5 long-song pass failed: {e!r}", file=sys.stderr)
 
     cpu = None
@@ -699,7 +702,8 @@ def main():
             if key in aux:
                 try:
                     aux[key]["cpu_baseline"] = fn()
-                except Exception as e:   # an auxiliary figure must never cost the bench line
+                except Exception as e:
+                    aux.setdefault("errors", []).append(f"cpu_baseline[{key}]: {e!r}")
                     print(f"cpu baseline for {key} failed: {e!r}", file=sys.stderr)
 
     line = {
