@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MH_ABI_VERSION 8
+#define MH_ABI_VERSION 9
 #define MH_MAX_LAYERS 32
 
 typedef enum MhStatus {
@@ -191,6 +191,11 @@ typedef struct MhGemm {
    * fp32 accumulation; outputs are what the epilogue says with T = bf16 (STORE, STORE_F32, RESID, GEGLU, BIAS_GELU,
    * GATE_RESID, KV_SCATTER, QKV_VT; N, ldc multiples of 4). */
   const uint8_t* a_scale; const uint8_t* w_scale;
+  /* ABI 9 -- dtype = MH_MX8 with MH_EPI_GEGLU / MH_EPI_BIAS_GELU: when mx_out != NULL the epilogue writes the MX-fp8 image of its
+   * bf16 result (the next GEMM's A operand) instead of the bf16 matrix: e4m3 bytes [M][ldc] (ldc = bytes per row) at mx_out and
+   * E8M0 scales at mx_out_scales (mh_mx8_scale_row_bytes(width) bytes per row; width = N, or N / 2 for GEGLU, a multiple of 128).
+   * Bit for bit what mh_quantize_mx8 makes of the bf16 result; C is not written and may be NULL. */
+  uint8_t* mx_out; uint8_t* mx_out_scales;
 } MhGemm;
 int mh_gemm(const MhGemm* g, void* stream);
 

@@ -31,7 +31,8 @@ class MhGemm(C.Structure):
                 ("dtype", C.c_int), ("epilogue", C.c_int),
                 ("stats_out", VP), ("ln_stats", VP), ("ln_strips", C.c_int), ("ln_shift", VP), ("ln_scale", VP),
                 ("ln_ld", C.c_int), ("ln_eps", C.c_float), ("w_split3", C.c_int),
-                ("a_scale", VP), ("w_scale", VP)]      # ABI 7: MH_MX8 operands
+                ("a_scale", VP), ("w_scale", VP),      # ABI 7: MH_MX8 operands
+                ("mx_out", VP), ("mx_out_scales", VP)]   # ABI 9: MX-fp8 image of a GEGLU / BIAS_GELU result
 
 
 class MhT5Config(C.Structure):
@@ -105,7 +106,7 @@ class MhSliderSet(C.Structure):
                 ("end_idx", VP), ("length", VP)]
 
 
-ABI_VERSION = 8   # MH_ABI_VERSION of include/mapperhip.h
+ABI_VERSION = 9   # MH_ABI_VERSION of include/mapperhip.h
 
 # every symbol include/mapperhip.h declares: (name, restype, argtypes)
 I, I64, F = C.c_int, C.c_int64, C.c_float

@@ -59,6 +59,7 @@ static OptionSlot g_options[OPT_COUNT] = {
     {"mx8_waves", "MH_MX8_WAVES", 8, false},   // MX-fp8 GEMM, 256 x 128 tile: 4 = four waves of 128 x 64 (one per SIMD, accumulators in AGPRs), 8 = eight waves of 64 x 64 (two per SIMD: one wave's fragment reads run under the other's MFMAs)
     {"gemm_tile256sq_min", "MH_GEMM_TILE256SQ_MIN", 440, false},   // bf16 GEMM: the 256 x 256 tile (two LDS stages, 128 x 64 wave tiles, AGPR accumulators) from this many tiles on, if its rounds of 256 workgroups are >= 88 % full (0 = never, 1 = whenever the three-stage kernel would run: tests)
     {"gemm_2stage_max_k", "MH_GEMM_2STAGE_MAX_K", 512, false},   // bf16 GEMM with K <= this: the two-stage 128 x 128 kernel (64 KB of LDS: two workgroups per CU) instead of the three-stage forms (0 = never).  Batched DiT-S bf16 (K = 384 on three of four projections): 130.3 -> 121.6 ms per 100 steps; at 1024 DiT-B (K = 768) 284.6 -> 287.7, at 4096 299.7
+    {"mx8_fused_quant", "MH_MX8_FUSED_QUANT", 1, false},   // MX-fp8 modes: 1 = the gated-GELU / GELU GEMM writes its result as the next GEMM's MX operand itself (MhGemm.mx_out; the same bytes), 0 = a quantiser pass over the bf16 result
 };
 
 static thread_local const MhOptionSet* tl_option_set = nullptr;

@@ -18,7 +18,7 @@ void set_error(const char* fmt, ...);
 int check_launch(const char* what);
 
 // ---- tuning options (api.hip: default <- environment at first use <- mh_set_option at run time) ----
-enum { OPT_GEMM_SPLITK_TILES = 0, OPT_DECODE_CHAINS, OPT_DECODE_PREFILL, OPT_DECODE_GEMV_COLS, OPT_DECODE_FUSED_PROJ, OPT_DECODE_CU_SPLIT, OPT_GEMM_TILE128_MIN, OPT_ATTN_SMALL_MAX_WGS, OPT_DIT_SPLIT3_MIN_ROWS, OPT_DECODE_SELF_ROWS, OPT_GEMM_GLDS, OPT_GEMM_LDS_PAD, OPT_DIT_S3_FUSED_LN, OPT_GEMM_TILE256_MIN, OPT_ATTN_FLASH2, OPT_DIT_S3_PRESPLIT, OPT_MX8_TILE256_MIN, OPT_DECODE_OVERLAP, OPT_DECODE_LAUNCH_THREADS, OPT_DECODE_GRAPH_CACHE, OPT_DECODE_FOLD_OPROJ, OPT_MX8_WAVES, OPT_GEMM_TILE256SQ_MIN, OPT_GEMM_2STAGE_MAX_K, OPT_COUNT };
+enum { OPT_GEMM_SPLITK_TILES = 0, OPT_DECODE_CHAINS, OPT_DECODE_PREFILL, OPT_DECODE_GEMV_COLS, OPT_DECODE_FUSED_PROJ, OPT_DECODE_CU_SPLIT, OPT_GEMM_TILE128_MIN, OPT_ATTN_SMALL_MAX_WGS, OPT_DIT_SPLIT3_MIN_ROWS, OPT_DECODE_SELF_ROWS, OPT_GEMM_GLDS, OPT_GEMM_LDS_PAD, OPT_DIT_S3_FUSED_LN, OPT_GEMM_TILE256_MIN, OPT_ATTN_FLASH2, OPT_DIT_S3_PRESPLIT, OPT_MX8_TILE256_MIN, OPT_DECODE_OVERLAP, OPT_DECODE_LAUNCH_THREADS, OPT_DECODE_GRAPH_CACHE, OPT_DECODE_FOLD_OPROJ, OPT_MX8_WAVES, OPT_GEMM_TILE256SQ_MIN, OPT_GEMM_2STAGE_MAX_K, OPT_MX8_FUSED_QUANT, OPT_COUNT };
 long option(int id);   // the calling thread's option set (OptionScope) first, then the process-wide value
 // RAII: the entry points that take a config install its option set for the calling thread; launcher threads re-install it
 struct OptionScope {
@@ -191,5 +191,22 @@ __host__ __device__ inline int t5_bucket(int rel, bool bidirectional, int num_bu
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 // MX-fp8 operands: E8M0 scale bytes per row (lane-major groups of four 128-k steps, 16 bytes each; mx8.hip)
 inline int mx8_scale_row_bytes(int K) { return 16 * ((K + 511) / 512); }
+
+// ---- MX-fp8 quantisation rule, shared by the producers (mx8.hip) and the GEMM epilogues that write an MX operand (gemm.hip) ----
+// scale exponent of a block from its amax (> 0): returns e (unbiased), never clipping
+__device__ inline int mx8_exponent(float amax) {
+  const int e = (int)((__float_as_uint(amax) >> 23) & 0xff) - 127 - 8;       // floor(log2(amax)) - 8 (amax normal; denormal blocks -> -135, clamped below)
+  const float scaled = amax * __uint_as_float((uint32_t)(127 - e) << 23);     // amax * 2^-e in [256, 512)
+  return scaled > 448.0f ? e + 1 : e;
+}
+__device__ inline long mx8_scale_index(int k) {          // byte index of the scale of the block holding column k
+  const int kt = k >> 7, lg = (k >> 5) & 3;
+  return (long)(kt >> 2) * 16 + lg * 4 + (kt & 3);
+}
+
+// 2^-e as a float (e clamped to the E8M0 range)
+__device__ inline float mx8_inv_scale(int e) {
+  return __uint_as_float((uint32_t)(127 - e < 1 ? 1 : (127 - e > 254 ? 254 : 127 - e)) << 23);
+}
 
 }  // namespace mh

@@ -376,8 +376,13 @@ int dit_body(const MhDiTConfig* c, const MhDiTWeights* w, const float* x, const 
     g = MhGemm{};
     g.A = xq; g.lda = D; g.a_scale = xqs; g.W = w->fc1_wm[l]; g.ldw = D; g.w_scale = w->fc1_wms[l]; g.C = b.hid; g.ldc = 4 * D; g.M = NT; g.N = 4 * D; g.K = D;
     g.bias = w->fc1_b[l]; g.dtype = MH_MX8; g.epilogue = MH_EPI_BIAS_GELU;
+    const bool mx_fused = (4 * D) % 128 == 0 && option(OPT_MX8_FUSED_QUANT) != 0;   // the GELU hidden leaves fc1 as fc2's MX-fp8 operand
+    if (mx_fused) {
+      if ((4 * D) % 512) MH_REQUIRE(hipMemsetAsync(hqs, 0, (size_t)NT * mx8_scale_row_bytes(4 * D), s) == hipSuccess, "dit: scale reset failed");
+      g.mx_out = hq; g.mx_out_scales = hqs; g.ldc = 4 * D;
+    }
     MH_TRY(gemm(g, s));
-    MH_TRY(quantize_mx8(b.hid, 4 * D, NT, 4 * D, MH_BF16, hq, 4 * D, hqs, s));
+    if (!mx_fused) MH_TRY(quantize_mx8(b.hid, 4 * D, NT, 4 * D, MH_BF16, hq, 4 * D, hqs, s));
     g = MhGemm{};
     g.A = hq; g.lda = 4 * D; g.a_scale = hqs; g.W = w->fc2_wm[l]; g.ldw = 4 * D; g.w_scale = w->fc2_wms[l]; g.C = b.xs; g.ldc = D; g.M = NT; g.N = D; g.K = 4 * D;
     g.bias = w->fc2_b[l]; g.gate = mod + 5 * D; g.gate_ld = ld_row; g.rows_per_batch = T; g.dtype = MH_MX8;

@@ -36,6 +36,7 @@ struct GemmP {
   int split3;   // fp32 only: W holds [hi bf16 x32 | lo bf16 x32] per 32-float K block, A is split on the way into LDS
   int debug;    // option gemm_lds_pad >> 20 (debugging aid)
   const uint8_t* a_scale; const uint8_t* w_scale; int ks_b;   // MH_MX8: E8M0 scales (lane-major groups, mx8.hip), bytes per row
+  uint8_t* mxq; uint8_t* mxs; int mxs_b;                        // MX-fp8 image of the epilogue's result (template MXO): bytes [M][ldc], scales [M][mxs_b]
 };
 
 // `v` already contains the bias; `old` = previous C value (RESID / GATE_RESID), `g` = gate value, `v2` = paired
@@ -541,8 +542,9 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmP p) {
 // ---- epilogue of the three-stage kernels (transposed accumulators: a lane owns 4 CONSECUTIVE columns of one row) ---------
 // acc[j][i][r] = C[row m0 + wr*16*MI + i*16 + (lane & 15)][col n0 + wc*64 + j*16 + (lane >> 4)*4 + r].  Shared by the bf16 form
 // (gemm_glds3_kernel) and the MX-fp8 form (gemm_mx8_kernel): the C / D layout of the 16x16 MFMAs does not depend on the operand type.
-template <int EPI, int MI>
+template <int EPI, int MI, bool MXO = false>
 __device__ __forceinline__ void g3_epilogue(const GemmP& p, f32x4_t (&acc)[4][MI], int m0, int n0, int wr, int wc, int lane) {
+  static_assert(!MXO || EPI == MH_EPI_GEGLU || EPI == MH_EPI_BIAS_GELU, "MX-fp8 output: the epilogues whose result is the next GEMM's A operand");
   using T = bf16_t;
   constexpr int WM = 16 * MI, WN = 64, NI = 4;
   const int lgc = lane >> 4;
@@ -616,6 +618,45 @@ __device__ __forceinline__ void g3_epilogue(const GemmP& p, f32x4_t (&acc)[4][MI
       }
       asm volatile("" : "+v"(v));
       vv[jj] = v;
+    }
+    if constexpr (MXO) {
+      // The result as the next GEMM's MX-fp8 A operand (mx8.hip's rule on the bf16-ROUNDED values, so the bytes are those of
+      // mh_quantize_mx8 over the bf16 matrix this epilogue would have written).  A 32-column block of the output row is held by
+      // the 4 lanes lgc = 0..3 of this row (4 consecutive columns each) in two accumulator tiles: jj = {2b, 2b + 1} (BIAS_GELU:
+      // columns wc*64 + b*32 ..) or jj = {0, 2} (GEGLU: the wave's 32 output columns are one block).
+      constexpr int NBLK = EPI == MH_EPI_GEGLU ? 1 : 2;
+#pragma unroll
+      for (int b = 0; b < NBLK; ++b) {
+        const int j0 = EPI == MH_EPI_GEGLU ? 0 : 2 * b, j1 = EPI == MH_EPI_GEGLU ? 2 : 2 * b + 1;
+        float x[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          x[r] = Elem<T>::to_f32(Elem<T>::from_f32(vv[j0][r]));
+          x[4 + r] = Elem<T>::to_f32(Elem<T>::from_f32(vv[j1][r]));
+        }
+        float am = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) am = fmaxf(am, fabsf(x[r]));
+        am = fmaxf(am, __shfl_xor(am, 16, 64));
+        am = fmaxf(am, __shfl_xor(am, 32, 64));
+        int e = am > 0.f ? mx8_exponent(am) : -127;
+        e = e < -127 ? -127 : (e > 127 ? 127 : e);
+        const float inv = mx8_inv_scale(e);
+        int o0 = __builtin_amdgcn_cvt_pk_fp8_f32(x[0] * inv, x[1] * inv, 0, false);
+        o0 = __builtin_amdgcn_cvt_pk_fp8_f32(x[2] * inv, x[3] * inv, o0, true);
+        int o1 = __builtin_amdgcn_cvt_pk_fp8_f32(x[4] * inv, x[5] * inv, 0, false);
+        o1 = __builtin_amdgcn_cvt_pk_fp8_f32(x[6] * inv, x[7] * inv, o1, true);
+        // output column of this lane's first value in tile j0 / j1
+        const int cbase = EPI == MH_EPI_GEGLU ? (n0 + wc * WN) / 2 + lgc * 4 : n0 + wc * WN + b * 32 + lgc * 4;
+        const int width = EPI == MH_EPI_GEGLU ? p.N / 2 : p.N;
+        if (rok && cbase < width) {
+          uint8_t* qrow = p.mxq + (long)row * p.ldc;
+          *reinterpret_cast<uint32_t*>(qrow + cbase) = (uint32_t)o0;
+          *reinterpret_cast<uint32_t*>(qrow + cbase + 16) = (uint32_t)o1;
+          if (lgc == 0) p.mxs[(long)row * p.mxs_b + mx8_scale_index(cbase)] = (uint8_t)(e + 127);
+        }
+      }
+      continue;
     }
 #pragma unroll
     for (int jj = 0; jj < NI; ++jj) {
@@ -1433,7 +1474,7 @@ __global__ __launch_bounds__(512) void gemm_s3g_kernel(GemmP p) {
 typedef __attribute__((ext_vector_type(8))) int i32x8_t;
 typedef __attribute__((ext_vector_type(4))) int i32x4_t;
 
-template <int EPI, int MI, int NW>
+template <int EPI, int MI, int NW, bool MXO = false>
 __global__ __launch_bounds__(NW * 64) void gemm_mx8_kernel(GemmP p) {
   constexpr int BM = 16 * MI * (NW / 2), BN = 128, NST = 3;
   constexpr int kRowStride = 128, kStage = (BM + BN) * kRowStride;
@@ -1695,14 +1736,14 @@ __global__ __launch_bounds__(NW * 64) void gemm_mx8_kernel(GemmP p) {
   __builtin_amdgcn_sched_barrier(0);
   asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 7" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
-  g3_epilogue<EPI, MI>(p, acc, m0, n0, wr, wc, lane);
+  g3_epilogue<EPI, MI, MXO>(p, acc, m0, n0, wr, wc, lane);
 }
 
-template <int EPI, int MI, int NW>
+template <int EPI, int MI, int NW, bool MXO = false>
 int launch_mx8(const GemmP& p, hipStream_t s) {
   constexpr int BM = 16 * MI * (NW / 2);
   const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + 127) / 128;
-  hipLaunchKernelGGL((gemm_mx8_kernel<EPI, MI, NW>), dim3(nbm * nbn), dim3(NW * 64), 3 * (BM + 128) * 128, s, p);
+  hipLaunchKernelGGL((gemm_mx8_kernel<EPI, MI, NW, MXO>), dim3(nbm * nbn), dim3(NW * 64), 3 * (BM + 128) * 128, s, p);
   return check_launch("gemm_mx8_kernel");
 }
 template <int EPI>
@@ -1711,12 +1752,24 @@ bool prepare_mx8() {
   ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mx8_kernel<EPI, 8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (256 + 128) * 128) == hipSuccess;
   ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mx8_kernel<EPI, 2, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (128 + 128) * 128) == hipSuccess;
   ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mx8_kernel<EPI, 4, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (256 + 128) * 128) == hipSuccess;
+  if constexpr (EPI == MH_EPI_GEGLU || EPI == MH_EPI_BIAS_GELU) {   // ... and their forms that write the result as an MX-fp8 operand
+    ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mx8_kernel<EPI, 8, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (256 + 128) * 128) == hipSuccess;
+    ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mx8_kernel<EPI, 2, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (128 + 128) * 128) == hipSuccess;
+    ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mx8_kernel<EPI, 4, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (256 + 128) * 128) == hipSuccess;
+  }
   return ok;
 }
 template <int EPI>
 int dispatch_mx8(const GemmP& p, hipStream_t s) {
   // fewer 256-row tiles than option mx8_tile256_min: the 128-row form doubles the workgroups
   const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + 127) / 128);
+  if constexpr (EPI == MH_EPI_GEGLU || EPI == MH_EPI_BIAS_GELU) {
+    if (p.mxq) {   // the result leaves as the next GEMM's MX-fp8 operand
+      if (tiles256 < option(OPT_MX8_TILE256_MIN)) return launch_mx8<EPI, 2, 8, true>(p, s);
+      if (option(OPT_MX8_WAVES) == 8) return launch_mx8<EPI, 4, 8, true>(p, s);
+      return launch_mx8<EPI, 8, 4, true>(p, s);
+    }
+  }
   if (tiles256 < option(OPT_MX8_TILE256_MIN)) return launch_mx8<EPI, 2, 8>(p, s);
   if (option(OPT_MX8_WAVES) == 8) return launch_mx8<EPI, 4, 8>(p, s);     // 256 x 128 tile as eight waves of 64 x 64 (two per SIMD)
   return launch_mx8<EPI, 8, 4>(p, s);
@@ -1907,7 +1960,7 @@ int gemm_prepare() {
 }
 
 int gemm(const MhGemm& g, hipStream_t s, bool ascending_k) {
-  MH_REQUIRE(g.A && g.W && g.C, "mh_gemm: null operand");
+  MH_REQUIRE(g.A && g.W && (g.C || (g.dtype == MH_MX8 && g.mx_out)), "mh_gemm: null operand");
   MH_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0, "mh_gemm: bad shape M=%d N=%d K=%d", g.M, g.N, g.K);
   MH_REQUIRE(g.dtype == MH_F32 || g.dtype == MH_BF16 || g.dtype == MH_MX8, "mh_gemm: bad dtype %d", g.dtype);
   if (g.dtype == MH_MX8) {
@@ -1932,6 +1985,13 @@ int gemm(const MhGemm& g, hipStream_t s, bool ascending_k) {
     q.M = g.M; q.N = g.N; q.K = g.K; q.bias = g.bias; q.gate = g.gate; q.gate_ld = g.gate_ld; q.rows_per_batch = g.rows_per_batch;
     q.kv_B = g.kv_B; q.kv_H = g.kv_H; q.kv_L = g.kv_L; q.C2 = g.C2; q.n_split = g.n_split; q.kv_Lpad = g.kv_Lpad;
     q.a_scale = g.a_scale; q.w_scale = g.w_scale; q.ks_b = mx8_scale_row_bytes(g.K);
+    if (g.mx_out) {
+      const int width = g.epilogue == MH_EPI_GEGLU ? g.N / 2 : g.N;
+      MH_REQUIRE(g.epilogue == MH_EPI_GEGLU || g.epilogue == MH_EPI_BIAS_GELU, "mh_gemm: mx_out goes with MH_EPI_GEGLU / MH_EPI_BIAS_GELU");
+      MH_REQUIRE(g.mx_out_scales && width % 128 == 0 && g.ldc >= width && ((uintptr_t)g.mx_out % 4) == 0,
+                 "mh_gemm: mx_out needs mx_out_scales, an output width that is a multiple of 128 and ldc >= width (width=%d ldc=%d)", width, g.ldc);
+      q.mxq = g.mx_out; q.mxs = g.mx_out_scales; q.mxs_b = mx8_scale_row_bytes(width);
+    }
     return dispatch_mx8_epi(q, g.epilogue, s);
   }
   const int es = g.dtype == MH_BF16 ? 2 : 4;

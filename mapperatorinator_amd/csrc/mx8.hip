@@ -17,12 +17,6 @@
 namespace mh {
 namespace {
 
-// scale exponent of a block from its amax (> 0): returns e (unbiased), never clipping
-__device__ inline int mx8_exponent(float amax) {
-  const int e = (int)((__float_as_uint(amax) >> 23) & 0xff) - 127 - 8;       // floor(log2(amax)) - 8 (amax normal; denormal blocks -> -135, clamped below)
-  const float scaled = amax * __uint_as_float((uint32_t)(127 - e) << 23);     // amax * 2^-e in [256, 512)
-  return scaled > 448.0f ? e + 1 : e;
-}
 // 4 fp32 values of a lane, block amax over the 8 lanes of its 32-value block -> 4 e4m3 bytes + the block's scale byte
 __device__ inline uint32_t mx8_quant4(float a, float b, float c, float d, int& scale_byte) {
   float m = fmaxf(fmaxf(fabsf(a), fabsf(b)), fmaxf(fabsf(c), fabsf(d)));
@@ -37,11 +31,6 @@ __device__ inline uint32_t mx8_quant4(float a, float b, float c, float d, int& s
   o = __builtin_amdgcn_cvt_pk_fp8_f32(c * inv, d * inv, o, true);
   return (uint32_t)o;
 }
-__device__ inline long mx8_scale_index(int k) {          // byte index of the scale of the block holding column k
-  const int kt = k >> 7, lg = (k >> 5) & 3;
-  return (long)(kt >> 2) * 16 + lg * 4 + (kt & 3);
-}
-
 template <typename T> __device__ inline float4 ld4(const T* p);
 template <> __device__ inline float4 ld4<float>(const float* p) { return *reinterpret_cast<const float4*>(p); }
 template <> __device__ inline float4 ld4<bf16_t>(const bf16_t* p) {

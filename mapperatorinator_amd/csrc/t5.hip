@@ -283,10 +283,20 @@ extern "C" int mh_t5_encode_cond(const MhT5Config* c, const MhT5Weights* w, cons
     g = MhGemm{};
     operand(g, n, d, w->enc_wi[l], w->enc_wi_mx[l], w->enc_wi_mxs[l]);
     g.C = ff; g.ldc = dff; g.M = rows; g.N = 2 * dff; g.K = d; g.epilogue = MH_EPI_GEGLU;
+    // MX mode: the gated GELU leaves the GEMM as the MX-fp8 operand of wo (the bytes mh_quantize_mx8 would make of the bf16
+    // hidden) -- into the second operand buffer: xq / xs still hold this GEMM's own A operand
+    const bool mx_fused = mx && dff % 128 == 0 && option(OPT_MX8_FUSED_QUANT) != 0;
+    uint8_t* xq2 = reinterpret_cast<uint8_t*>(ff);                 // (the bf16 hidden is not written then: its buffer holds the MX image)
+    uint8_t* xs2 = xq2 + (int64_t)rows * dff;
+    if (mx_fused) {
+      if (dff % 512) MH_REQUIRE(hipMemsetAsync(xs2, 0, (size_t)rows * mx8_scale_row_bytes(dff), s) == hipSuccess, "mh_t5_encode: scale reset failed");
+      g.mx_out = xq2; g.mx_out_scales = xs2; g.ldc = dff;
+    }
     MH_TRY(gemm(g, s));
-    if (mx) MH_TRY(quantize_mx8(ff, dff, rows, dff, MH_BF16, xq, dff, xs, s));
+    if (mx && !mx_fused) MH_TRY(quantize_mx8(ff, dff, rows, dff, MH_BF16, xq, dff, xs, s));
     g = MhGemm{};
     operand(g, ff, dff, w->enc_wo[l], w->enc_wo_mx[l], w->enc_wo_mxs[l]);
+    if (mx_fused) { g.A = xq2; g.a_scale = xs2; }
     g.C = h; g.ldc = d; g.M = rows; g.N = d; g.K = dff; g.epilogue = MH_EPI_RESID;
     MH_TRY(gemm(g, s));
   }

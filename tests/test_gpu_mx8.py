@@ -215,3 +215,52 @@ def test_mx8_gemm_refuses_what_it_cannot_do():
     assert lib.mh_gemm(C.byref(g), _stream()) != 0 and b"K %% 128" not in lib.mh_last_error() and b"128" in lib.mh_last_error()
     g.K, g.lda, g.ldw, g.a_scale = 128, 192, 192, None
     assert lib.mh_gemm(C.byref(g), _stream()) != 0 and b"a_scale" in lib.mh_last_error()
+
+
+@pytest.mark.parametrize("epi_name", ["BIAS_GELU", "GEGLU"])
+@pytest.mark.parametrize("shape", [(520, 256, 768), (4099, 1024, 384), (8192, 3072, 768), (2048, 5632, 256)])
+def test_fused_mx_output_is_the_quantiser_over_the_bf16_result(epi_name, shape):
+    """ABI 9 (MhGemm.mx_out): the GELU / gated-GELU GEMM of the MX modes writes its result as the next GEMM's MX-fp8 operand
+    itself.  Byte for byte (elements AND scales) what mh_quantize_mx8 makes of the bf16 matrix the plain epilogue writes -- both
+    tile forms, ragged M, zero blocks and outliers included; rows beyond M and the bf16 output are not touched."""
+    L, lib = _lib()
+    from oracle import mx8 as omx
+    M, N, K = shape
+    epi = L.EPI_BIAS_GELU if epi_name == "BIAS_GELU" else L.EPI_GEGLU
+    width = N if epi == L.EPI_BIAS_GELU else N // 2
+    rng = np.random.default_rng(M + N)
+    A = heavy_tailed(M, K, seed=K) * 0.05
+    A[7] = 0.0                                                       # a whole zero row: zero blocks in the output
+    W = (rng.standard_normal((N, K)) * 0.05).astype(np.float32)
+    W[: N // 4] *= 40.0                                              # a wide range of block magnitudes across the output row
+    bias = (rng.standard_normal(N).astype(np.float32) if epi == L.EPI_BIAS_GELU else None)
+    qa, sa = omx.quantize_mx8(A)
+    qw, sw = omx.quantize_mx8(W)
+    t = [torch.from_numpy(v).cuda().contiguous() for v in (qa, sa, qw, sw)]
+    b = torch.from_numpy(bias).cuda() if bias is not None else None
+
+    def run(fused):
+        g = L.MhGemm()
+        g.A, g.lda, g.W, g.ldw, g.a_scale, g.w_scale = t[0].data_ptr(), K, t[2].data_ptr(), K, t[1].data_ptr(), t[3].data_ptr()
+        g.M, g.N, g.K, g.dtype, g.epilogue = M, N, K, L.MH_MX8, epi
+        if b is not None:
+            g.bias = b.data_ptr()
+        out = torch.full((M, width), 7.0, dtype=torch.bfloat16, device="cuda")
+        g.C, g.ldc = out.data_ptr(), width
+        ks = int(lib.mh_mx8_scale_row_bytes(width))
+        q = torch.full((M + 3, width), 0xAA, dtype=torch.uint8, device="cuda")
+        s = torch.zeros((M + 3, ks), dtype=torch.uint8, device="cuda")
+        if fused:
+            g.mx_out, g.mx_out_scales = q.data_ptr(), s.data_ptr()
+        L.check(lib.mh_gemm(C.byref(g), _stream()), "mh_gemm(MX8)")
+        torch.cuda.synchronize()
+        return out, q, s
+    plain, _, _ = run(False)
+    untouched, q, s = run(True)
+    assert bool((untouched == 7.0).all()), "the bf16 output must not be written in the fused form"
+    assert bool((q[M:] == 0xAA).all()) and bool((s[M:] == 0).all()), "rows beyond M were written"
+    want_q, want_s = device_quantize(plain, L.MH_BF16)
+    if width % 512:      # the quantiser zeroes the unused tail bytes of the last scale group; so did the zero-filled buffer here
+        assert int(lib.mh_mx8_scale_row_bytes(width)) == want_s.shape[1]
+    assert torch.equal(q[:M], want_q), f"{int((q[:M] != want_q).sum())} element bytes differ"
+    assert torch.equal(s[:M], want_s), f"{int((s[:M] != want_s).sum())} scale bytes differ"

@@ -1,5 +1,5 @@
 """Batched DiT denoiser: B chunks x 100 DDPM steps as one replayed hipGraph.
-    python tools/dit_batch_bench.py B [preset=DiT-S] [fp32|bf16]"""
+    python tools/dit_batch_bench.py B [preset=DiT-S] [fp32|bf16|mx8]"""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mapperatorinator_amd.dit import BandMask, DiTHIP, create_diffusion
@@ -10,7 +10,7 @@ preset = sys.argv[2] if len(sys.argv) > 2 else "DiT-S"
 mode = sys.argv[3] if len(sys.argv) > 3 else "fp32"
 depth, hidden, heads = DIT_PRESETS[preset]
 dit = DiTHIP(random_dit_state_dict(depth, hidden, seed=0), depth, hidden, heads, device=dev,
-             operand_dtype=torch.bfloat16 if mode == "bf16" else torch.float32)
+             operand_dtype="mx8" if mode == "mx8" else (torch.bfloat16 if mode == "bf16" else torch.float32))
 parts = [synthetic_dit_inputs(Tq, seed=b) for b in range(B)]
 z = torch.cat([p[0][:1] for p in parts] + [p[0][1:] for p in parts]).to(dev)
 c = torch.cat([p[1][:1] for p in parts] + [p[1][1:] for p in parts]).to(dev)
