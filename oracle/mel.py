@@ -10,10 +10,14 @@ nnAudio 0.3.4's published algorithm:
     then `** power` (power=2.0);
   * librosa-style Slaney mel filterbank, area normalised (norm=1), float32, applied as a matmul.
 
-PARITY UNPINNED for this one piece: the reference ships no mel test vectors and the nnAudio
-wheel is absent, so the restatement is validated analytically (tests/test_oracle_mel.py: frame
-count, pure-tone bin energy (N/4)^2, silence == 0, filter areas) and against an independent
-float64 FFT formulation -- not against nnAudio outputs.
+PINNED TO AN INDEPENDENT THIRD-PARTY IMPLEMENTATION (round 5): nnAudio itself is absent from the image (and the
+reference ships no mel test vectors), but `transformers.audio_utils` (installed; numpy rfft + its own Slaney / HTK
+filterbanks, written independently of nnAudio, librosa and torchaudio) implements the same published definitions.
+tests/test_oracle_pinned.py::test_mel_oracle_pinned_to_transformers_audio_utils holds this file to it: filterbank
+within 5e-8 (measured 1.0e-8) with every triangle on the same bins and the same single all-zero filter, the full mel
+of noise and tones within 3e-6 of the peak (measured 5.8e-7 .. 9.1e-7) for the nnAudio parameterisation and within
+2e-6 / 1e-5 (log1p) for the torchaudio one.  The analytic checks (frame count, pure-tone bin energy (N/4)^2,
+silence == 0, filter areas, float64 FFT cross-check) stay in test_mel_oracle_analytic.
 """
 from __future__ import annotations
 
@@ -150,7 +154,8 @@ def mel_spectrogram_torchaudio(audio, n_fft=1024, hop=128, n_mels=128, sr=16000,
     """The `torchaudio` branch of the reference wrapper (osuT5/osuT5/model/spectrogram.py:38-49, 79-83) restated with
     plain torch: torchaudio.transforms.MelSpectrogram = torch.stft (periodic hann, center=True, `pad_mode`, onesided,
     power 2) followed by `melscale_fbanks(n_freqs, f_min, f_max, n_mels, sample_rate, norm=None, mel_scale="htk")`.
-    parity unpinned: torchaudio is not installed here; `torch.stft` is the routine it calls.
+    torchaudio is not installed here; `torch.stft` is the routine it calls, and the result is pinned to
+    `transformers.audio_utils.spectrogram(pad_mode="reflect", mel_scale="htk", norm=None)` (see the module header).
     audio (B, Ns) -> (B, Ns // hop + 1, n_mels) float32."""
     import math
     x = audio.to(torch.float32)

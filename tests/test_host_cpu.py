@@ -239,6 +239,16 @@ def test_mel_host_tables():
         s_, ln, of = int(t.fb_start[i]), int(t.fb_len[i]), int(t.fb_off[i])
         dense[i, s_:s_ + ln] = t.fb_w[of:of + ln].numpy()
     assert np.array_equal(dense, hfb)
+    # both PRODUCT tables against an independent third-party implementation (transformers.audio_utils; nnAudio / torchaudio
+    # themselves are absent from the image): every triangle edge on the same bin
+    au = pytest.importorskip("transformers.audio_utils")
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref_sl = au.mel_filter_bank(513, 388, 0.0, 8000.0, 16000, norm="slaney", mel_scale="slaney").T
+        ref_htk = au.mel_filter_bank(513, 128, 20.0, 8000.0, 16000, norm=None, mel_scale="htk").T
+    assert np.abs(fb - ref_sl).max() < 5e-8 and np.array_equal(fb > 0, ref_sl.astype(np.float32) > 0)
+    assert np.abs(hfb - ref_htk).max() < 5e-7 and np.array_equal(hfb > 0, ref_htk.astype(np.float32) > 0)
 
 
 def test_diffusion_pipeline_host_glue():
