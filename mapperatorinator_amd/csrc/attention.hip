@@ -13,6 +13,8 @@
 // become the A operand of the PV product.  Q, K, V^T, the output and the masks are addressed through
 // explicit (row, batch, head) strides so that the same kernel reads the packed QKV GEMM output, the
 // [B][H][L][64] K/V caches of the decoder and their transposed copies.
+#include <type_traits>
+
 #include "internal.hpp"
 
 namespace mh {
@@ -269,16 +271,56 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(AttnArgs p) {
 //                 softmax statistics: the rescale needs no shuffle.
 // Two query blocks per wave share every K and V^T fragment: per 64-key tile 32 MFMAs on 16 KB of fragment reads (was 16 on
 // 20 KB).  Scores are kept in the log2 domain (one FMA applies scale and bias), a tile that needs no masking skips it.
-template <int QB>
-__global__ __launch_bounds__(256) void flash2_bf16_kernel(AttnArgs p) {
+// Round 5: (i) ONE-dimensional grid with an XCD-aware id -> (query tile, head, batch) map: the dispatcher places workgroup
+// id i on XCD i % 8, so XCD x takes the CONSECUTIVE virtual ids [x * per_xcd, (x + 1) * per_xcd) -- all query tiles of a
+// (batch, head) pair run on one XCD, next to each other in time, and its L2 fetches that pair's K / V^T once (the 3-D grid
+// spread them over all eight: FETCH_SIZE 2.8-5.8 x the 184 MB of Q / K / V per launch, profiles/r04_pmc_hbm_traffic.txt);
+// (ii) the staging is split (guide T14): the NEXT tile's global loads are issued while this tile is computed, into 16
+// registers, and written to the OTHER LDS buffer -- one barrier per tile instead of two and no exposed global round trip
+// (the single-buffered loop waited ~3 us per tile for its own loads with only two workgroups per CU to hide them).  All
+// loads of the loop are unconditional with clamped indices (a branch around a load makes hipcc drain vmcnt at the join),
+// and a tile's bias loads are issued BEFORE the prefetch of the tile after next: vmcnt counts in order, the bias must not
+// wait behind the prefetch.  Same products, same order per tile: bit-identical to the previous form.
+// Reductions over the 4 lane groups (lanes l15, l15 + 16, + 32, + 48) on the VALU: gfx950's v_permlane16_swap / v_permlane32_swap
+// exchange 16-lane rows / 32-lane halves between two registers, so {x, x} -> {[r0 r0 r2 r2], [r1 r1 r3 r3]} and one max / add
+// is the xor-16 butterfly step -- no ds_bpermute round trip through the LDS crossbar and, with it, no `s_waitcnt lgkmcnt(0)` that
+// also waits for every fragment read in flight (__shfl_xor compiles to ds_bpermute_b32 here).
+__device__ inline float max_over_lane_groups(float v) {
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ inline float sum_over_lane_groups(float v) {   // (r0 + r1) + (r2 + r3) in every lane: the order of `v += xor 16; v += xor 32`
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
+// tools/flash2_bench.py builds this kernel with parts switched OFF to price them (bit mask: 1 bias loads, 2 exponentials,
+// 4 the global -> LDS staging, 8 the cross-lane reductions, 16 QK^T MFMAs, 32 PV MFMAs); always 0 in the library
+#ifndef MH_F2_PROBE
+#define MH_F2_PROBE 0
+#endif
+// SIMPLE: no band, no causal mask, no key mask (the encoders) -- known at compile time, so the general tile form is only the
+// `key < Lk` test of the last tile and the clamped bias gather, and the LEAN form can afford the S^T / softmax overlap (a second
+// S^T register set; with the band / causal / key-mask arithmetic compiled in, the allocator spills inside the tile loop).
+template <int QB, bool BIAS, bool SIMPLE>
+__global__ __launch_bounds__(256, 2) void flash2_bf16_kernel(AttnArgs p_, int nqt, int H, int total) {
+  AttnArgs p = p_;
+  if constexpr (SIMPLE) { p.band = 0; p.causal = 0; p.key_mask = nullptr; p.open_from = 0; }
   using T = bf16_t;
   constexpr int RS = 64 * 2 + 16;           // padded LDS row stride (bytes)
+  constexpr int TILE = 64 * RS;             // one K or V^T tile
   constexpr int WQ = QB * 16;               // queries per wave
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* Ks = smem;                           // [64 keys][64 d]
-  char* Vts = smem + 64 * RS;                // [64 d][64 keys]
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][K tile | V^T tile]
+  const int per_xcd = gridDim.x >> 3;
+  const int vid = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (vid >= total) return;
+  const int qt = vid % nqt, bh_ = vid / nqt;
+  const int h = bh_ % H, b = bh_ / H;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
   const int Lq = p.Lq, Lk = p.Lk;
   const int qb0 = qt * 4 * WQ;
   const int q0w = qb0 + wid * WQ;
@@ -328,164 +370,291 @@ __global__ __launch_bounds__(256) void flash2_bf16_kernel(AttnArgs p) {
     if (qb0 + 4 * WQ - 1 >= open_from) { t_lo = 0; t_hi = t_last; }
     else t_open = open_from / 64;
   }
+  // the visited tiles in order: t_lo .. t_hi, then (pad columns of an open band) t_open .. t_last   (block-uniform)
+  auto next_tile = [&](int kt) -> int {
+    int n = kt + 1;
+    if (n > t_hi && n < t_open) n = t_open;
+    return n <= t_last ? n : -1;
+  };
+  int kt = t_lo;
+  if (kt > t_hi && kt < t_open) kt = t_open;
 
   const char* kbase = (const char*)p.k + (long)b * p.k_bs + (long)h * p.k_hs;
   const char* vbase = (const char*)p.vt + (long)b * p.vt_bs + (long)h * p.vt_hs;
-  const float* bh = p.bias ? p.bias + (long)h * p.bias_hs + p.bias_center : nullptr;
+  const float* bh = BIAS ? p.bias + (long)h * p.bias_hs + p.bias_center : nullptr;
   const uint8_t* mrow = p.key_mask ? p.key_mask + (long)b * p.mask_ld : nullptr;
   const float c2 = p.scale * kLog2e;
 
-  for (int kt = t_lo; kt <= t_last; ++kt) {
-    if (kt > t_hi && kt < t_open) continue;      // (block-uniform) between the band and the pad columns
-    const int kv0 = kt * 64;
-    // ---- stage K tile [key][d] and V^T tile [d][key]: 2 + 2 16-byte chunks per thread ----
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int idx = tid + 256 * i;
-      const int row = idx >> 3, ch = idx & 7;
-      int kr = kv0 + row;
-      kr = kr < Lk ? kr : Lk - 1;
-      const uint4 kv = *reinterpret_cast<const uint4*>(kbase + (long)kr * p.k_rs + ch * 16);
-      const uint4 vv = *reinterpret_cast<const uint4*>(vbase + ((long)row * p.Lkpad + kv0) * 2 + ch * 16);
-      *reinterpret_cast<uint4*>(Ks + row * RS + ch * 16) = kv;
-      *reinterpret_cast<uint4*>(Vts + row * RS + ch * 16) = vv;
+  // staging: thread -> (row = idx >> 3, 16-byte chunk = idx & 7) of the K tile [key][d] and the V^T tile [d][key], idx = tid, tid + 256
+  const int srow = tid >> 3, sch = (tid & 7) * 16;
+  const long vrow0 = (long)srow * p.Lkpad * 2 + sch, vrow1 = (long)(srow + 32) * p.Lkpad * 2 + sch;
+  const int soff0 = srow * RS + sch, soff1 = (srow + 32) * RS + sch;
+  uint4 kr0, kr1, vr0, vr1;
+  // K tiles are staged TWO tiles ahead of the tile whose softmax runs, V^T tiles ONE ahead (a step computes S of tile i + 1 and
+  // P V of tile i): K ring slot = tile ordinal & 1, V^T ring slot likewise -- smem = [K slot 0 | K slot 1 | V^T slot 0 | V^T slot 1]
+#define MH_F2_ISSUE_K(tile)                                                                        \
+  do {                                                                                             \
+    const int kv0_ = (tile) * 64;                                                                  \
+    int ka_ = kv0_ + srow, kb_ = kv0_ + srow + 32;                                                 \
+    ka_ = ka_ < Lk ? ka_ : Lk - 1;                                                                 \
+    kb_ = kb_ < Lk ? kb_ : Lk - 1;                                                                 \
+    kr0 = *reinterpret_cast<const uint4*>(kbase + (long)ka_ * p.k_rs + sch);                       \
+    kr1 = *reinterpret_cast<const uint4*>(kbase + (long)kb_ * p.k_rs + sch);                       \
+  } while (0)
+#define MH_F2_ISSUE_V(tile)                                                                        \
+  do {                                                                                             \
+    const int kv0_ = (tile) * 64;                                                                  \
+    vr0 = *reinterpret_cast<const uint4*>(vbase + vrow0 + (long)kv0_ * 2);                         \
+    vr1 = *reinterpret_cast<const uint4*>(vbase + vrow1 + (long)kv0_ * 2);                         \
+  } while (0)
+#define MH_F2_WRITE_K(slot)                                                                        \
+  do {                                                                                             \
+    char* kd_ = smem + (slot) * TILE;                                                              \
+    *reinterpret_cast<uint4*>(kd_ + soff0) = kr0;                                                  \
+    *reinterpret_cast<uint4*>(kd_ + soff1) = kr1;                                                  \
+  } while (0)
+#define MH_F2_WRITE_V(slot)                                                                        \
+  do {                                                                                             \
+    char* vd_ = smem + (2 + (slot)) * TILE;                                                        \
+    *reinterpret_cast<uint4*>(vd_ + soff0) = vr0;                                                  \
+    *reinterpret_cast<uint4*>(vd_ + soff1) = vr1;                                                  \
+  } while (0)
+  // S^T = K Q^T of one tile: dst[kb][qb][r] = score(key kb*16 + lg*4 + r of the tile, query q0w + qb*16 + l15)
+#define MH_F2_QK(dst, Ks_)                                                                         \
+  do {                                                                                             \
+    _Pragma("unroll") for (int kb = 0; kb < 4; ++kb)                                               \
+      _Pragma("unroll") for (int qb = 0; qb < QB; ++qb) dst[kb][qb] = f32x4_t{0.f, 0.f, 0.f, 0.f}; \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                               \
+      _Pragma("unroll") for (int kb = 0; kb < 4; ++kb) {                                           \
+        const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>((Ks_) + (kb * 16 + l15) * RS + (ks * 32 + lg * 8) * 2); \
+        _Pragma("unroll") for (int qb = 0; qb < QB; ++qb) {                                        \
+          if (MH_F2_PROBE & 16) dst[kb][qb][0] += __builtin_bit_cast(f32x4_t, kf)[qb] * 1e-30f;    \
+          else dst[kb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qb][ks], dst[kb][qb], 0, 0, 0); \
+        }                                                                                          \
+      }                                                                                            \
+  } while (0)
+
+  if (kt <= t_last) {                       // (block-uniform; an empty range leaves zeros)
+    // tiles t0 (= kt), t1, t2, t3 of the visited sequence; a missing one is replaced by a valid tile whose data is never used
+    int t1 = next_tile(kt);
+    int t2 = t1 >= 0 ? next_tile(t1) : -1;
+    {   // K / V^T of the first tile and K of the second in ONE round trip (short sequences -- the DiT's 128 points -- are all prologue)
+      MH_F2_ISSUE_K(t1 >= 0 ? t1 : kt);
+      const uint4 k1a = kr0, k1b = kr1;
+      MH_F2_ISSUE_K(kt); MH_F2_ISSUE_V(kt);
+      MH_F2_WRITE_K(0); MH_F2_WRITE_V(0);
+      kr0 = k1a; kr1 = k1b;
+      MH_F2_WRITE_K(1);
     }
+    MH_F2_ISSUE_K(t2 >= 0 ? t2 : kt); MH_F2_ISSUE_V(t1 >= 0 ? t1 : kt);      // in flight across the barrier: written by step 0
     __syncthreads();
-
-    // ---- S^T = K Q^T: st[kb][qb][r] = score(key kv0 + kb*16 + lg*4 + r, query q0w + qb*16 + l15) ----
-    f32x4_t st[4][QB];
-#pragma unroll
-    for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-      for (int qb = 0; qb < QB; ++qb) st[kb][qb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int kb = 0; kb < 4; ++kb) {
-        const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(Ks + (kb * 16 + l15) * RS + (ks * 32 + lg * 8) * 2);
-#pragma unroll
-        for (int qb = 0; qb < QB; ++qb) st[kb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qb][ks], st[kb][qb], 0, 0, 0);
+    f32x4_t stA[4][QB], stB[4][QB];
+    MH_F2_QK(stA, smem);
+    __syncthreads();                        // step 0 overwrites K slot 0: every wave has read it
+    int ord = 0;                            // ordinal of tile kt in the visited sequence
+    const int qlo = p.q_pos0 + q0w, qhi = qlo + WQ - 1;                         // positions of this wave's queries
+    // One step = softmax of tile kt (its S^T arrives in `st`, computed by the previous step) + S^T of tile t1 into `sn` + P V of
+    // tile kt.  The MFMAs of the next tile's S^T do not depend on this tile's softmax: both sit in one basic block so that the
+    // matrix pipe works in the shadow of the VALU stream (the kernel is VALU-issue-bound: tools/flash2_bench.py probe builds --
+    // with MFMAs compiled out it took 250 of 372 us, i.e. the un-pipelined form ran its MFMAs beside nothing).
+    // Two compiled forms chosen per wave and tile (wave-uniform: a scalar branch).  LEAN: no mask of any kind and (with a bias)
+    // the whole wave on the vector-load path -- straight-line code; the general form evaluates masks and bias clamps per element.
+    auto step = [&](auto lean_c, f32x4_t (&st)[4][QB], f32x4_t (&sn)[4][QB], int t3) {
+      constexpr bool LEAN = decltype(lean_c)::value;
+      const char* Kn = smem + ((ord + 1) & 1) * TILE;             // K of tile t1
+      const char* Vts = smem + (2 + (ord & 1)) * TILE;            // V^T of tile kt
+      const int kv0 = kt * 64;
+      bool need_mask = false;
+      if constexpr (!LEAN) {
+        need_mask = (kv0 + 63 >= Lk) || mrow != nullptr;
+        if (p.band != 0) need_mask = need_mask || (kv0 - qhi < rel_lo) || (kv0 + 63 - qlo > rel_hi);
+        if (p.causal) need_mask = need_mask || (kv0 + 63 > qlo);
       }
-
-    // ---- log2-domain scores: s2 = s * scale * log2(e) + bias * log2(e); masks only where this tile needs them ----
-    const int qlo = p.q_pos0 + q0w, qhi = qlo + WQ - 1;                       // positions of this wave's queries
-    bool need_mask = (kv0 + 63 >= Lk) || mrow != nullptr;
-    if (p.band != 0) need_mask = need_mask || (kv0 - qhi < rel_lo) || (kv0 + 63 - qlo > rel_hi);
-    if (p.causal) need_mask = need_mask || (kv0 + 63 > qlo);
-    // Relative bias, fast path (bias_sign = +1, tile away from the table's ends): rel = key - query of element (kb, qb, r) is
-    // rel0 + 16 (kb - qb) + r with rel0 = kv0 + lg*4 - (q_pos0 + q0w + l15): the 4 r values are CONSECUTIVE table entries and
-    // query block qb's key block kb + 1 reads what block qb + 1's kb + ... -- 4 + QB - 1 unaligned 16-byte loads per lane
-    // instead of 16 QB scalar gathers with their index arithmetic (the kernel is VALU-bound: VALUBusy 88 %).
-    const int rel0 = kv0 + lg * 4 - (p.q_pos0 + q0w + l15);
-    const bool bias_fast = bh && p.bias_sign == 1 && !need_mask && (rel0 - 16 * (QB - 1) >= p.bias_min) && (rel0 + 51 <= p.bias_max);
-    float4 bq[4 + QB - 1];
-    if (bias_fast) {
+      // Relative bias, vector path (bias_sign = +1, tile away from the table's ends): rel = key - query of element (kb, qb, r) is
+      // rel0 + 16 (kb - qb) + r with rel0 = kv0 + lg*4 - (q_pos0 + q0w + l15): the 4 r values are CONSECUTIVE table entries --
+      // 4 + QB - 1 unaligned 16-byte loads per lane instead of 16 QB scalar gathers with their index arithmetic.  Issued BEFORE
+      // the staging loads below: vmcnt counts in order, the bias must not wait behind the prefetch.
+      const int rel0 = kv0 + lg * 4 - (qlo + l15);
+      float4 bq[BIAS && LEAN ? 4 + QB - 1 : 1];
+      if constexpr (BIAS && LEAN) {
 #pragma unroll
-      for (int g = 0; g < 4 + QB - 1; ++g) {
-        const float4 t = *reinterpret_cast<const float4*>(bh + rel0 + 16 * (g - (QB - 1)));      // group g <-> kb - qb = g - (QB - 1)
-        bq[g] = make_float4(t.x * kLog2e, t.y * kLog2e, t.z * kLog2e, t.w * kLog2e);
-      }
-    }
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb) {
-      const int qg = q0w + qb * 16 + l15;
-      const int qpos = p.q_pos0 + (qg < Lq ? qg : Lq - 1);
-      if (bias_fast) {
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb) {
-          const float4 t = bq[kb - qb + QB - 1];
-          st[kb][qb][0] = st[kb][qb][0] * c2 + t.x; st[kb][qb][1] = st[kb][qb][1] * c2 + t.y;
-          st[kb][qb][2] = st[kb][qb][2] * c2 + t.z; st[kb][qb][3] = st[kb][qb][3] * c2 + t.w;
+        for (int g = 0; g < 4 + QB - 1; ++g) {
+          if (MH_F2_PROBE & 1) bq[g] = make_float4(c2, c2, c2, c2);
+          else bq[g] = *reinterpret_cast<const float4*>(bh + rel0 + 16 * (g - (QB - 1)));   // group g <-> kb - qb = g - (QB - 1)
         }
-      } else if (bh) {
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int kg = kv0 + kb * 16 + lg * 4 + r;
-            int idx = p.bias_sign * ((kg < Lk ? kg : Lk - 1) - qpos);
-            idx = idx < p.bias_min ? p.bias_min : (idx > p.bias_max ? p.bias_max : idx);
-            st[kb][qb][r] = st[kb][qb][r] * c2 + bh[idx] * kLog2e;
-          }
-      } else {
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) st[kb][qb][r] *= c2;
       }
-      if (need_mask) {                                                          // wave-uniform
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int kg = kv0 + kb * 16 + lg * 4 + r;
-            const int rel = kg - qpos;
-            bool ok = kg < Lk;
-            if (mrow) ok = ok && (kg >= p.mask_len || mrow[kg < p.mask_len ? kg : p.mask_len - 1] != 0);
-            if (p.band != 0) ok = ok && (((rel >= rel_lo) && (rel <= rel_hi)) || kg >= open_from || qpos >= open_from);
-            if (p.causal) ok = ok && (rel <= 0);
-            st[kb][qb][r] = ok ? st[kb][qb][r] : -INFINITY;
-          }
+      // ---- staged registers (K of t2, V^T of t1: requested one step ago) into their ring slots; K of t3 / V^T of t2 requested ----
+      if (!(MH_F2_PROBE & 4)) {
+        MH_F2_WRITE_K(ord & 1);
+        MH_F2_WRITE_V((ord + 1) & 1);
+        MH_F2_ISSUE_K(t3 >= 0 ? t3 : kt);
+        MH_F2_ISSUE_V(t2 >= 0 ? t2 : kt);
       }
-      // ---- online softmax of query (qb, l15): 16 keys in this lane, the other 48 in lanes l15 + 16 / 32 / 48 ----
-      float mx = -INFINITY;
-#pragma unroll
-      for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[kb][qb][r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float mn = fmaxf(m[qb], mx);
-      const float mu = mn == -INFINITY ? 0.f : mn;          // a fully masked row so far: keep exp2(-inf - 0) = 0, not NaN
-      const float alpha = __builtin_amdgcn_exp2f(m[qb] - mu);     // raw v_exp_f32 (exp2f() adds a denormal path: 11 more instructions each)
-      m[qb] = mn;
-      float sum = 0.f;
-#pragma unroll
-      for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float pv = __builtin_amdgcn_exp2f(st[kb][qb][r] - mu);
-          st[kb][qb][r] = pv;
-          sum += pv;
-        }
-      lsum[qb] = lsum[qb] * alpha + sum;                    // this lane's keys only: reduced over lg once, at the end
-#pragma unroll
-      for (int db = 0; db < 4; ++db) {
-        o[qb][db][0] *= alpha; o[qb][db][1] *= alpha; o[qb][db][2] *= alpha; o[qb][db][3] *= alpha;
-      }
-    }
+      // ---- S^T of the next tile (UNCONDITIONAL: in the last step it multiplies a stale K slot into a register set nobody reads -- a
+      // skip would keep the old contents of `sn` alive through the whole step: 32 registers, and the loop spills).  LEAN form of a SIMPLE problem: here, in
+      // front of the softmax it overlaps with; otherwise behind P V (the per-element mask arithmetic needs the registers) ----
+      if constexpr (LEAN && SIMPLE) MH_F2_QK(sn, Kn);
 
-    // ---- O^T += V^T P^T: k-slot lg*8 + j of step s <-> key (2s + j/4)*16 + lg*4 + j%4 (both operands) ----
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-      bf16x8_t pf[QB];
+      // ---- log2-domain scores: s2 = s * scale * log2(e) + bias * log2(e); masks only where this tile needs them ----
 #pragma unroll
       for (int qb = 0; qb < QB; ++qb) {
-        const uint32_t w0 = pack_bf16x2(st[2 * s2][qb][0], st[2 * s2][qb][1]), w1 = pack_bf16x2(st[2 * s2][qb][2], st[2 * s2][qb][3]);
-        const uint32_t w2 = pack_bf16x2(st[2 * s2 + 1][qb][0], st[2 * s2 + 1][qb][1]), w3 = pack_bf16x2(st[2 * s2 + 1][qb][2], st[2 * s2 + 1][qb][3]);
-        const uint4 pk = make_uint4(w0, w1, w2, w3);
-        pf[qb] = __builtin_bit_cast(bf16x8_t, pk);
-      }
+        if constexpr (LEAN) {
 #pragma unroll
-      for (int db = 0; db < 4; ++db) {
-        const char* vr = Vts + (db * 16 + l15) * RS + (2 * s2 * 16 + lg * 4) * 2;
-        const uint2 v0 = *reinterpret_cast<const uint2*>(vr);
-        const uint2 v1 = *reinterpret_cast<const uint2*>(vr + 32);
-        const uint4 vk = make_uint4(v0.x, v0.y, v1.x, v1.y);
-        const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, vk);
+          for (int kb = 0; kb < 4; ++kb) {
+            if constexpr (BIAS) {
+              const float4 t = bq[kb - qb + QB - 1];
+              st[kb][qb][0] = st[kb][qb][0] * c2 + t.x * kLog2e; st[kb][qb][1] = st[kb][qb][1] * c2 + t.y * kLog2e;
+              st[kb][qb][2] = st[kb][qb][2] * c2 + t.z * kLog2e; st[kb][qb][3] = st[kb][qb][3] * c2 + t.w * kLog2e;
+            } else {
+              st[kb][qb][0] *= c2; st[kb][qb][1] *= c2; st[kb][qb][2] *= c2; st[kb][qb][3] *= c2;
+            }
+          }
+        } else {
+          // (lane coordinates through an opaque copy: hipcc would otherwise hoist every per-element index of this rarely taken
+          // form out of the tile loop and keep them alive across the lean form, which then spills)
+          int l15x = l15, lgx = lg;
+          asm volatile("" : "+v"(l15x), "+v"(lgx));
+          const int qg = q0w + qb * 16 + l15x;
+          const int qpos = p.q_pos0 + (qg < Lq ? qg : Lq - 1);
+          if constexpr (BIAS) {
 #pragma unroll
-        for (int qb = 0; qb < QB; ++qb) o[qb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qb], o[qb][db], 0, 0, 0);
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int kg = kv0 + kb * 16 + lgx * 4 + r;
+                int idx = p.bias_sign * ((kg < Lk ? kg : Lk - 1) - qpos);
+                idx = idx < p.bias_min ? p.bias_min : (idx > p.bias_max ? p.bias_max : idx);
+                st[kb][qb][r] = st[kb][qb][r] * c2 + bh[idx] * kLog2e;
+                if (r == 3) __builtin_amdgcn_sched_barrier(0);   // 4 gathers in flight, not 32: this rarely taken form must not set the kernel's register count
+              }
+          } else {
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) st[kb][qb][r] *= c2;
+          }
+          if (need_mask) {                                                          // wave-uniform
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int kg = kv0 + kb * 16 + lgx * 4 + r;
+                const int rel = kg - qpos;
+                bool ok = kg < Lk;
+                if (mrow) ok = ok && (kg >= p.mask_len || mrow[kg < p.mask_len ? kg : p.mask_len - 1] != 0);
+                if (p.band != 0) ok = ok && (((rel >= rel_lo) && (rel <= rel_hi)) || kg >= open_from || qpos >= open_from);
+                if (p.causal) ok = ok && (rel <= 0);
+                st[kb][qb][r] = ok ? st[kb][qb][r] : -INFINITY;
+                if (r == 3) __builtin_amdgcn_sched_barrier(0);
+              }
+          }
+        }
+        // ---- online softmax of query (qb, l15): 16 keys in this lane, the other 48 in lanes l15 + 16 / 32 / 48 ----
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[kb][qb][r]);
+        if (!(MH_F2_PROBE & 8)) mx = max_over_lane_groups(mx);
+        const float mn = fmaxf(m[qb], mx);
+        const float mu = mn == -INFINITY ? 0.f : mn;          // a fully masked row so far: keep exp2(-inf - 0) = 0, not NaN
+        const float alpha = __builtin_amdgcn_exp2f(m[qb] - mu);     // raw v_exp_f32 (exp2f() adds a denormal path: 11 more instructions each)
+        m[qb] = mn;
+        float sum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float pv = (MH_F2_PROBE & 2) ? (st[kb][qb][r] - mu) : __builtin_amdgcn_exp2f(st[kb][qb][r] - mu);
+            st[kb][qb][r] = pv;
+            sum += pv;
+          }
+        lsum[qb] = lsum[qb] * alpha + sum;                    // this lane's keys only: reduced over lg once, at the end
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+          o[qb][db][0] *= alpha; o[qb][db][1] *= alpha; o[qb][db][2] *= alpha; o[qb][db][3] *= alpha;
+        }
       }
+
+      // the compiler would emit the 16 S^T MFMAs of the next tile as one block in front of the softmax: spread them through it,
+      // one MFMA per ~14 VALU instructions (16 cycles of matrix pipe under ~56+ cycles of VALU issue)
+      if constexpr (LEAN && SIMPLE) {
+#pragma unroll
+        for (int i = 0; i < 8 * QB; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // MFMA
+          __builtin_amdgcn_sched_group_barrier(0x002, 14, 0);   // VALU
+        }
+      }
+      // ---- O^T += V^T P^T: k-slot lg*8 + j of step s <-> key (2s + j/4)*16 + lg*4 + j%4 (both operands) ----
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        bf16x8_t pf[QB];
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+          const uint32_t w0 = pack_bf16x2(st[2 * s2][qb][0], st[2 * s2][qb][1]), w1 = pack_bf16x2(st[2 * s2][qb][2], st[2 * s2][qb][3]);
+          const uint32_t w2 = pack_bf16x2(st[2 * s2 + 1][qb][0], st[2 * s2 + 1][qb][1]), w3 = pack_bf16x2(st[2 * s2 + 1][qb][2], st[2 * s2 + 1][qb][3]);
+          const uint4 pk = make_uint4(w0, w1, w2, w3);
+          pf[qb] = __builtin_bit_cast(bf16x8_t, pk);
+        }
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+          const char* vr = Vts + (db * 16 + l15) * RS + (2 * s2 * 16 + lg * 4) * 2;
+          const uint2 v0 = *reinterpret_cast<const uint2*>(vr);
+          const uint2 v1 = *reinterpret_cast<const uint2*>(vr + 32);
+          const uint4 vk = make_uint4(v0.x, v0.y, v1.x, v1.y);
+          const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, vk);
+#pragma unroll
+          for (int qb = 0; qb < QB; ++qb) {
+            if (MH_F2_PROBE & 32) o[qb][db][0] += __builtin_bit_cast(f32x4_t, vf)[qb] * __builtin_bit_cast(f32x4_t, pf[qb])[db];
+            else o[qb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qb], o[qb][db], 0, 0, 0);
+          }
+        }
+      }
+      if constexpr (!(LEAN && SIMPLE)) MH_F2_QK(sn, Kn);   // (a skip in the last step would keep `sn` alive: 178 instead of 164 registers = two workgroups per CU instead of three, and the DiT's 768-workgroup launches need three: 14.1 vs 16.5 us)
+    };
+    // LEAN iff no element of the tile is masked for any query of the wave and every lane's bias reads stay inside the table
+    auto is_lean = [&]() -> bool {
+      const int kv0 = kt * 64;
+      bool lean = (kv0 + 63 < Lk) && mrow == nullptr;
+      if (p.band != 0) lean = lean && !((kv0 - qhi < rel_lo) || (kv0 + 63 - qlo > rel_hi));
+      if (p.causal) lean = lean && !(kv0 + 63 > qlo);
+      if (BIAS) lean = lean && p.bias_sign == 1 && (kv0 - (qlo + 15) - 16 * (QB - 1) >= p.bias_min) && (kv0 + 12 - qlo + 51 <= p.bias_max);
+      return __builtin_amdgcn_readfirstlane((int)lean) != 0;
+    };
+    // two steps per trip with the roles of the two S^T register sets swapped (a runtime-indexed set would live in scratch)
+    while (true) {
+      int t3 = t2 >= 0 ? next_tile(t2) : -1;
+      if constexpr (SIMPLE) {
+        if (is_lean()) step(std::true_type{}, stA, stB, t3);
+        else step(std::false_type{}, stA, stB, t3);
+      } else {
+        step(std::false_type{}, stA, stB, t3);     // band / causal / key-mask problems are short (the DiT's windows, a prompt): ONE compiled
+      }                                            // form -- their time is instruction fetch and prologue, not the tile arithmetic
+      if (t1 < 0) break;
+      __syncthreads();
+      kt = t1; t1 = t2; t2 = t3; ++ord;
+      t3 = t2 >= 0 ? next_tile(t2) : -1;
+      if constexpr (SIMPLE) {
+        if (is_lean()) step(std::true_type{}, stB, stA, t3);
+        else step(std::false_type{}, stB, stA, t3);
+      } else {
+        step(std::false_type{}, stB, stA, t3);
+      }
+      if (t1 < 0) break;
+      __syncthreads();
+      kt = t1; t1 = t2; t2 = t3; ++ord;
     }
-    __syncthreads();
   }
+#undef MH_F2_ISSUE_K
+#undef MH_F2_ISSUE_V
+#undef MH_F2_WRITE_K
+#undef MH_F2_WRITE_V
+#undef MH_F2_QK
 
   // ---- normalise and store: 4 consecutive d per lane (a fully masked query row -- a left-pad position -- yields zeros) ----
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
-    float l = lsum[qb];
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
+    const float l = sum_over_lane_groups(lsum[qb]);
     const int qg = q0w + qb * 16 + l15;
     if (qg >= Lq) continue;
     const float inv = l > 0.f ? 1.0f / l : 0.f;
@@ -528,7 +697,20 @@ int attention_general(const AttnArgs& a, int B, int H, int dtype, hipStream_t s)
   const int es = dtype == MH_BF16 ? 2 : 4;
   if (dtype == MH_BF16 && option(OPT_ATTN_FLASH2) != 0 && a.out_rs % 8 == 0 && a.out_bs % 8 == 0) {
     // bf16: transposed-S kernel, 128 queries per workgroup (option attn_flash2 = 0: the 64-query kernel below)
-    hipLaunchKernelGGL(flash2_bf16_kernel<2>, dim3(ceil_div(a.Lq, 128), H, B), dim3(256), (size_t)128 * (64 * 2 + 16), s, a);
+    const int nqt = ceil_div(a.Lq, 128);
+    const long total = (long)nqt * H * B;
+    MH_REQUIRE(total < (1L << 30), "attention: too many workgroups");
+    const int per_xcd = (int)((total + 7) / 8);
+    const size_t smem = (size_t)4 * 64 * (64 * 2 + 16);        // two buffers of (K tile | V^T tile)
+    const bool simple = a.band == 0 && !a.causal && a.key_mask == nullptr;
+    if (a.bias && simple)
+      hipLaunchKernelGGL((flash2_bf16_kernel<2, true, true>), dim3(8 * per_xcd), dim3(256), smem, s, a, nqt, H, (int)total);
+    else if (a.bias)
+      hipLaunchKernelGGL((flash2_bf16_kernel<2, true, false>), dim3(8 * per_xcd), dim3(256), smem, s, a, nqt, H, (int)total);
+    else if (simple)
+      hipLaunchKernelGGL((flash2_bf16_kernel<2, false, true>), dim3(8 * per_xcd), dim3(256), smem, s, a, nqt, H, (int)total);
+    else
+      hipLaunchKernelGGL((flash2_bf16_kernel<2, false, false>), dim3(8 * per_xcd), dim3(256), smem, s, a, nqt, H, (int)total);
     return check_launch("flash2_bf16_kernel");
   }
   dim3 grid(ceil_div(a.Lq, 64), H, B), block(256);
