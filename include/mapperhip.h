@@ -72,10 +72,6 @@ int mh_abi_version(void);
  *   "decode_fused_proj"  MH_DECODE_FUSED_PROJ  1    decode attention kernels project their own q / k / v (0: stand-alone
  *                                                   GEMV launches; fp32 summation order of the projections differs;
  *                                                   2: stand-alone QKV GEMV, cross-attention keeps its own projection)
- *   "decode_self_rows"   MH_DECODE_SELF_ROWS   1    rows of one head per decode self-attention workgroup (1, 2, 4): they share
- *                                                   the head's q / k / v weight slice; a row's key interleave is 16 / rows
- *                                                   waves wide (fp32 order of its softmax sums differs between settings,
- *                                                   never with the batch)
  *   "gemm_glds"          MH_GEMM_GLDS          3    bf16 GEMM operands by LDS-DMA: 3 = three-stage kernel (256x128 tiles, 128x128
  *                                                   below half a wave of them), 2 = 256x128 only, 1 = two-stage 128x128,
  *                                                   0 = register staging
@@ -88,25 +84,15 @@ int mh_abi_version(void);
  *                                                   round robin (for profilers whose counter passes do not survive concurrent
  *                                                   launcher threads)
  *   "decode_graph_cache" MH_DECODE_GRAPH_CACHE 1    step graphs kept across mh_t5_generate calls (0: captured per call)
- *   "decode_fold_oproj"  MH_DECODE_FOLD_OPROJ  0    T5 backbone: 1 = the self-attention kernel multiplies its head's output with its
- *                                                   64 columns of Wo itself (partial rows added in head order downstream): 5
- *                                                   dependent launches per decoder layer; 2 = the cross-attention kernel as well
- *                                                   (a row's last workgroup updates the residual stream): 4 launches; 0 = 6.
- *                                                   fp32 summation order of the output projections differs; measured no faster
- *                                                   (profiles/r04_decode_fold_oproj.txt)
- *   "decode_overlap"     MH_DECODE_OVERLAP     0    1: dependent-launch overlap of a chain's token step (two streams per chain,
- *                                                   device-side progress words instead of stream order; T5 backbone, chains of
- *                                                   <= 16 rows, d_model 128 / 512 / 768 / 1024).  Bit-identical tokens and logits;
- *                                                   measured slower than the plain step (profiles/r04_decode_overlap.txt)
  *   "gemm_tile256sq_min" MH_GEMM_TILE256SQ_MIN 440  bf16 GEMM: the 256x256 tile (two LDS stages, 128x64 wave tiles, staggered wave
  *                                                   groups) from this many tiles on when its rounds of 256 workgroups are >= 88 %
  *                                                   full (0 = never; bit-identical to the 256x128 three-stage kernel)
  *   "gemm_2stage_max_k"  MH_GEMM_2STAGE_MAX_K  512  bf16 GEMM with K <= this: 128x128 tile on two LDS stages, two workgroups per CU
  *                                                   (0 = never; bit-identical)
- *   "mx8_waves"          MH_MX8_WAVES          8    MX-fp8 GEMM, 256x128 tile: eight waves of 64x64 (two per SIMD) or 4 = four
- *                                                   waves of 128x64 with AGPR accumulators (bit-identical)
- * (further switches -- decode_cu_split, gemm_tile128_min, gemm_tile256_min, attn_small_max_wgs, dit_split3_min_rows,
- * dit_s3_fused_ln, mx8_tile256_min -- are documented next to their definitions in csrc/api.hip.)
+ * (further switches -- gemm_tile128_min, gemm_tile256_min, attn_small_max_wgs, dit_split3_min_rows, mx8_tile256_min,
+ * mx8_fused_quant -- are documented next to their definitions in csrc/api.hip.  Round 5 removed the measured-slower variants
+ * decode_overlap, decode_fold_oproj, decode_cu_split, decode_self_rows, mx8_waves = 4, dit_s3_fused_ln and the debugging aid
+ * gemm_lds_pad; their measurements stay in profiles/r02_* .. r04_*.)
  * Unknown names return MH_ERR_ARG (set) / -1 (get). */
 int mh_set_option(const char* name, long value);
 long mh_get_option(const char* name);

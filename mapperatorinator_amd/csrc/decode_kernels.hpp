@@ -188,106 +188,6 @@ __device__ inline void store_head_row_from_lds_wt(T* dst, const float* src, int 
   }
 }
 
-// ---- dependent-launch overlap (option decode_overlap, default OFF; tools/micro/chain_pdl.hip, profiles/r04_decode_overlap.txt) --
-// a structural change of the 74-launch token step.  Built, exact, and measured SLOWER than the plain step --
-// kept as a tested experiment.  The kernels of a chain's token step alternate between TWO streams (launched eagerly, kernel by
-// kernel), so kernel k + 1 is launched -- and sits on its CUs -- while kernel k is still running.  Stream order no longer
-// carries the dependence between them; a device-side progress word does:
-//   * a DEP kernel first requests everything that does NOT depend on its predecessor (its weight slice, the RMSNorm weight,
-//     the position), then thread 0 polls the chain's progress word until it reaches epoch * 256 + slot (relaxed agent-scope
-//     loads + s_sleep; BOUNDED: a lost dependence raises the chain's error word instead of hanging the GPU);
-//   * everything the predecessor wrote is then loaded with `sc1` loads: this CU's L1 may hold a line of the residual stream /
-//     activation buffers that another CU has rewritten since (the kernel-start invalidate happened while the producer ran);
-//     the producers store write-through (store_wt and friends) as they always did;
-//   * at its end every wave waits vmcnt(0) (its write-through stores have left), the workgroup arrives on a ticket sharded by
-//     XCD (blockIdx & 7) and the last arriver of the last shard publishes epoch * 256 + slot + 1.
-// What this takes off the chain's critical path is the dispatch of the next kernel (~1.65 us) and its first round trip for
-// weights; what it adds is the arrival fan-in and the poll (~1 us).  SYNTHETIC chains with the step's launch geometry gain:
-// 43.0 -> 35 us per layer with two chains side by side.  The REAL step loses: 262 -> 334 ms of decode (32 chunks x 384 tokens).
-// The waiting kernel is not free: a resident attention workgroup holds 16 waves x 120 (self) / 2 x 16 x 64 (cross) registers
-// on 192 of the 256 CUs while it spins, so the kernel it waits for -- and the other chain's kernels -- run on what is left;
-// the synthetic GEMVs of the probe are register-light, the real ones (96-188 registers, 26 KB of LDS) are not.  Tokens and
-// logits are bit-identical to the plain step (tests/test_gpu_t5.py) -- the mechanism is sound, the occupancy price is not paid back.
-constexpr int kDepMaxSlots = 6 * MH_MAX_LAYERS + 2;
-struct DepSync {             // one per chain, in the decode workspace (zeroed at the start of a generate call)
-  unsigned progress; unsigned pad0[63];    // the chain's progress word
-  unsigned epoch; unsigned pad1[63];       // the chain's step counter (bumped by the step's last node)
-  unsigned err; unsigned pad2[63];         // lost dependences
-  unsigned tickets[kDepMaxSlots][9][32];   // per kernel slot: arrival counters of 8 XCD shards + top, 32 words apart
-};
-struct DepP {                // 16 bytes of kernel arguments (the plain forms carry them unused)
-  DepSync* sync;
-  unsigned slot, nwg;        // index of this kernel in the step; its workgroup count
-};
-__device__ inline unsigned dep_ld(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-template <bool DEP> __device__ inline unsigned dep_epoch(const DepP& d) {   // (thread 0 keeps it; requested with the first loads)
-  if constexpr (DEP) return threadIdx.x == 0 ? dep_ld(&d.sync->epoch) : 0u;
-  return 0u;
-}
-template <bool DEP> __device__ inline void dep_wait(const DepP& d, unsigned epoch) {
-  if constexpr (DEP) {
-    if (threadIdx.x == 0 && d.slot > 0) {      // slot 0 follows the previous step through the graph launches' stream order
-      const unsigned want = epoch * 256u + d.slot;
-      int n = 0;
-      while ((int)(dep_ld(&d.sync->progress) - want) < 0) {
-        __builtin_amdgcn_s_sleep(2);
-        if (++n > (1 << 16)) { atomicAdd(&d.sync->err, 1u); break; }
-      }
-    }
-    __syncthreads();
-  }
-}
-template <bool DEP> __device__ inline void dep_signal(const DepP& d, unsigned epoch) {
-  if constexpr (DEP) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's write-through stores have left
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      const unsigned shard = blockIdx.x & 7u;
-      const unsigned per = (d.nwg + 7u - shard) / 8u;      // workgroups with this shard index
-      unsigned* t = &d.sync->tickets[d.slot][shard][0];
-      if (__hip_atomic_fetch_add(t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == per - 1) {
-        __hip_atomic_store(t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned shards = d.nwg < 8u ? d.nwg : 8u;
-        unsigned* top = &d.sync->tickets[d.slot][8][0];
-        if (__hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == shards - 1) {
-          __hip_atomic_store(top, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_store(&d.sync->progress, epoch * 256u + d.slot + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-      }
-    }
-  }
-}
-// loads of what the predecessor wrote.  DEP: `sc1` (L1-bypassing) loads issued by inline asm STRAIGHT INTO the destination
-// variable -- hipcc does not know they are in flight (it would copy a returned temporary at once, i.e. before the data has
-// arrived), so every use must sit behind dep_landed() AND a dep_pin() of the destination (an empty asm that re-defines the
-// register: nothing that reads it can be scheduled above the wait).
-template <bool DEP> __device__ inline void dep_ld16(uint4& dst, const void* p) {
-  if constexpr (DEP) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(reinterpret_cast<u32x4_t&>(dst)) : "v"(p) : "memory");
-  else dst = *reinterpret_cast<const uint4*>(p);
-}
-template <bool DEP> __device__ inline void dep_ld16(float4& dst, const void* p) {
-  typedef __attribute__((ext_vector_type(4))) float f32x4v_t;
-  if constexpr (DEP) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(reinterpret_cast<f32x4v_t&>(dst)) : "v"(p) : "memory");
-  else dst = *reinterpret_cast<const float4*>(p);
-}
-template <bool DEP> __device__ inline void dep_ld4(float& dst, const float* p) {
-  if constexpr (DEP) asm volatile("global_load_dword %0, %1, off sc1" : "=v"(dst) : "v"(p) : "memory");
-  else dst = *p;
-}
-template <bool DEP> __device__ inline void dep_landed() {
-  if constexpr (DEP) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-template <bool DEP> __device__ inline void dep_pin(uint4& v) {
-  if constexpr (DEP) asm volatile("" : "+v"(reinterpret_cast<u32x4_t&>(v)));
-}
-template <bool DEP> __device__ inline void dep_pin(float& v) {
-  if constexpr (DEP) asm volatile("" : "+v"(v));
-}
-template <bool DEP> __device__ inline void dep_pin(float4& v) {
-  typedef __attribute__((ext_vector_type(4))) float f32x4v_t;
-  if constexpr (DEP) asm volatile("" : "+v"(reinterpret_cast<f32x4v_t&>(v)));
-}
-
 // ---- decode GEMV ("skinny GEMM": M = batch rows <= 64) ------------------------------------------------------------
 // out[b][n] = sum_k A[b][k] * W[n][k] on the 16x16 MFMA atoms.  One workgroup owns ONE 16-column tile of which `nv`
 // columns are real (nv = 16, 8 or 4: a 768-column projection becomes 48, 96 or 192 workgroups; the other tile columns
@@ -306,7 +206,7 @@ template <bool DEP> __device__ inline void dep_pin(float4& v) {
 //     whole-line loads was built and measured: the extra LDS write / barrier / read costs what the loads save (o-projection
 //     3.61 us alone, 4.12 beside a second chain; whole step 37.4 k vs 38.1 k tok/s without it) -- not kept.
 enum { PRO_PLAIN = 0, PRO_RMSNORM = 1 };
-enum { SK_STORE = 0, SK_QKV = 1, SK_GEGLU = 2, SK_RESID = 3, SK_LOGITS = 4, SK_GELU_ERF = 5, SK_RESID_PARTS = 6 };   // (GELU_ERF: the Whisper family's fc1; RESID_PARTS: RESID + the partial rows of a folded output projection, FoldP)
+enum { SK_STORE = 0, SK_QKV = 1, SK_GEGLU = 2, SK_RESID = 3, SK_LOGITS = 4, SK_GELU_ERF = 5 };   // (GELU_ERF: the Whisper family's fc1)
 
 struct SkinnyP {
   const void* A; int lda;      // PRO_PLAIN: T [B, lda];  PRO_RMSNORM: fp32 residual stream [B, lda]
@@ -320,7 +220,6 @@ struct SkinnyP {
   int H, tgt_len, inner;
   const int* pos;
   const float* bias;           // kernel template BIAS (the Whisper family's biased projections): fp32 [N], else unused
-  const float* parts; int parts_H;   // RESID_PARTS: h[b][n] += sum_hh parts[b][hh][n] (head order) + acc
 };
 
 template <typename T> struct VecOps;
@@ -403,12 +302,11 @@ constexpr int kGemvCH = 8;   // k-blocks per wave whose loads are in flight at o
 #else
 #define MH_GEMV_WPE_ATTR
 #endif
-template <typename T, int MF, int NWV, int PRO, int EPI, bool BIAS = false, bool DEP = false>
+template <typename T, int MF, int NWV, int PRO, int EPI, bool BIAS = false>
 __global__ __launch_bounds__(NWV * 64) MH_GEMV_WPE_ATTR
-void gemv_kernel(MH_GEMV_LEAD_PARAMS, SkinnyP p, DepP dep) {
-  static_assert(!DEP || MF == 1, "the overlap form is built for chains of <= 16 rows");
+void gemv_kernel(MH_GEMV_LEAD_PARAMS, SkinnyP p) {
   p.A = A_; p.W = W_; p.h = h_; p.ln_w = lnw_; p.K = K_; p.lda = K_; p.ldw = K_; p.B = B_; p.N = N_; p.nv = nv_;
-  if (EPI == SK_RESID || EPI == SK_RESID_PARTS) p.ldh = N_;   // the residual stream is dense [B, N] (checked on the host)
+  if (EPI == SK_RESID) p.ldh = N_;   // the residual stream is dense [B, N] (checked on the host)
   constexpr int VEC = Elem<T>::kVec;   // elements per 16-byte vector (per lane per k-block)
   constexpr int KB = 4 * VEC;          // k elements per k-block (4 lane groups x 16 B)
   constexpr int CH = kGemvCH;
@@ -486,26 +384,10 @@ void gemv_kernel(MH_GEMV_LEAD_PARAMS, SkinnyP p, DepP dep) {
     _Pragma("unroll") for (int u = 0; u < UPW; ++u) {                                                                         \
       const int unit = wid + u * NWV;                                                                                         \
       const int row = (unit >> 2) * 16 + lg * 4 + (unit & 3);                                                                 \
-      if (unit < MF * 4) dep_ld4<DEP>(oldh[u], p.h + (long)(row < p.B ? row : p.B - 1) * p.ldh + (ocol < p.N ? ocol : p.N - 1)); \
+      if (unit < MF * 4) oldh[u] = p.h[(long)(row < p.B ? row : p.B - 1) * p.ldh + (ocol < p.N ? ocol : p.N - 1)];          \
     }                                                                                                                         \
   } while (0)
-  if (!DEP && (EPI == SK_RESID || EPI == SK_RESID_PARTS) && l15 < nv && !(PROBE & 4)) MH_LOAD_OLDH();   // requested before anything is waited for
-  // RESID_PARTS: the partial rows of the folded self-attention output projection (FoldP) that the residual row has not absorbed
-  // yet -- 16 more values per output element, requested with the old value, added in head order in the epilogue
-  float pv[EPI == SK_RESID_PARTS ? UPW : 1][EPI == SK_RESID_PARTS ? 16 : 1];
-  if constexpr (EPI == SK_RESID_PARTS) {
-#pragma unroll
-    for (int u = 0; u < UPW; ++u) {
-      const int unit = wid + u * NWV;
-      const int row = (unit >> 2) * 16 + lg * 4 + (unit & 3);
-      const float* pp = p.parts + ((long)(row < p.B ? row : p.B - 1) * p.parts_H) * p.N + (ocol < p.N ? ocol : p.N - 1);
-#pragma unroll
-      for (int hh = 0; hh < 16; ++hh) pv[u][hh] = (unit < MF * 4 && l15 < nv) ? pp[(long)(hh < p.parts_H ? hh : p.parts_H - 1) * p.N] : 0.f;
-    }
-  }
-  const unsigned dep_ep = dep_epoch<DEP>(dep);
-  bool dep_waited = false;
-
+  if (EPI == SK_RESID && l15 < nv && !(PROBE & 4)) MH_LOAD_OLDH();   // requested before anything is waited for
   f32x4_t acc[MF];
 #pragma unroll
   for (int f = 0; f < MF; ++f) acc[f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -532,24 +414,12 @@ void gemv_kernel(MH_GEMV_LEAD_PARAMS, SkinnyP p, DepP dep) {
           wv[c] = *reinterpret_cast<const uint4*>(Wp + (2 * (pw < npair ? pw : npair - 1) + (c & 1)) * KB);   // clamped address
         }
       }
-      if (DEP && !dep_waited) {   // the weights of this pass are on their way: now the predecessor's data
-        dep_wait<DEP>(dep, dep_ep);
-        dep_waited = true;
-        if (EPI == SK_RESID && l15 < nv) MH_LOAD_OLDH();
-      }
 #pragma unroll
       for (int cp = 0; cp < CP; ++cp) {
         const int pw = pw0 + NWV * cp;
         const long off = (long)(pw < npair ? pw : npair - 1) * 128;
-        dep_ld16<DEP>(xa[cp], Ab + rx + off);
-        dep_ld16<DEP>(ya[cp], Ab + ry + off);
-      }
-      if constexpr (DEP) {
-        dep_landed<DEP>();
-#pragma unroll
-        for (int cp = 0; cp < CP; ++cp) { dep_pin<DEP>(xa[cp]); dep_pin<DEP>(ya[cp]); }
-#pragma unroll
-        for (int u = 0; u < UPW; ++u) dep_pin<DEP>(oldh[u]);
+        xa[cp] = *reinterpret_cast<const uint4*>(Ab + rx + off);
+        ya[cp] = *reinterpret_cast<const uint4*>(Ab + ry + off);
       }
       MH_LOADS_ISSUED();
       MH_LOADS_ISSUED();
@@ -581,11 +451,6 @@ void gemv_kernel(MH_GEMV_LEAD_PARAMS, SkinnyP p, DepP dep) {
         wv[c] = *reinterpret_cast<const uint4*>(Wp + (kb < nkb ? kb : nkb - 1) * KB);   // clamped address
       }
     }
-    if (DEP && !dep_waited) {   // the weights of this pass are on their way: now the predecessor's data
-      dep_wait<DEP>(dep, dep_ep);
-      dep_waited = true;
-      if (EPI == SK_RESID && l15 < nv) MH_LOAD_OLDH();
-    }
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
       const int kb = kblock(kb0, c);
@@ -603,19 +468,13 @@ void gemv_kernel(MH_GEMV_LEAD_PARAMS, SkinnyP p, DepP dep) {
       } else if (PRO == PRO_PLAIN) {
 #pragma unroll
         for (int f = 0; f < MF; ++f)
-          dep_ld16<DEP>(av[c][f], reinterpret_cast<const T*>(p.A) + (long)arow[f] * p.lda + kel + lg * VEC);
+          av[c][f] = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.A) + (long)arow[f] * p.lda + kel + lg * VEC);
       } else if (!RLINES) {
 #pragma unroll
-        for (int f = 0; f < MF; ++f) {
-          if constexpr (DEP && sizeof(T) == 4) {   // (fp32 storage: one 16-byte vector per k-block)
-            dep_ld16<DEP>(hraw[c][f].a, reinterpret_cast<const float*>(p.A) + (long)arow[f] * p.lda + kel + lg * VEC);
-          } else {
-            hraw[c][f] = VecOps<T>::load_raw(reinterpret_cast<const float*>(p.A) + (long)arow[f] * p.lda + kel + lg * VEC);
-          }
-        }
+        for (int f = 0; f < MF; ++f)
+          hraw[c][f] = VecOps<T>::load_raw(reinterpret_cast<const float*>(p.A) + (long)arow[f] * p.lda + kel + lg * VEC);
       }
     }
-    static_assert(!DEP || PRO == PRO_PLAIN || RLINES || sizeof(T) == 4, "overlap form: every dependent load has an sc1 path");
     uint4 xr[RLINES ? CH : 1], yr[RLINES ? CH : 1];
     if (RLINES) {   // one 128-byte line of fp32 per row and k-block: rows 0..7 / 8..15 of the block as two whole-line loads
       const int r8 = lane >> 3;
@@ -625,30 +484,9 @@ void gemv_kernel(MH_GEMV_LEAD_PARAMS, SkinnyP p, DepP dep) {
       for (int c = 0; c < CH; ++c) {
         const int kb = kb0 + NWV * c;
         const long off = (long)(kb < nkb ? kb : nkb - 1) * 128;
-        dep_ld16<DEP>(xr[c], Ab + rx + off);
-        dep_ld16<DEP>(yr[c], Ab + ry + off);
+        xr[c] = *reinterpret_cast<const uint4*>(Ab + rx + off);
+        yr[c] = *reinterpret_cast<const uint4*>(Ab + ry + off);
       }
-    }
-    if constexpr (DEP) {
-      dep_landed<DEP>();
-      if (RLINES) {
-#pragma unroll
-        for (int c = 0; c < CH; ++c) { dep_pin<DEP>(xr[c]); dep_pin<DEP>(yr[c]); }
-      }
-      if constexpr (PRO == PRO_RMSNORM && !RLINES && sizeof(T) == 4) {
-#pragma unroll
-        for (int c = 0; c < CH; ++c)
-#pragma unroll
-          for (int f = 0; f < MF; ++f) dep_pin<DEP>(hraw[c][f].a);
-      }
-      if constexpr (PRO == PRO_PLAIN) {
-#pragma unroll
-        for (int c = 0; c < CH; ++c)
-#pragma unroll
-          for (int f = 0; f < MF; ++f) dep_pin<DEP>(av[c][f]);
-      }
-#pragma unroll
-      for (int u = 0; u < UPW; ++u) dep_pin<DEP>(oldh[u]);
     }
     MH_LOADS_ISSUED();
     MH_STAMP(KID, 0);   // loads issued
@@ -737,11 +575,6 @@ void gemv_kernel(MH_GEMV_LEAD_PARAMS, SkinnyP p, DepP dep) {
       if (ok) store_wt(reinterpret_cast<float*>(p.out) + (long)row * p.ldo + ocol, v);
     } else if (EPI == SK_RESID) {
       if (ok) store_wt(p.h + (long)row * p.ldh + ocol, oldh[u] + v);
-    } else if (EPI == SK_RESID_PARTS) {
-      float base = oldh[u];
-#pragma unroll
-      for (int hh = 0; hh < 16; ++hh) base += (hh < p.parts_H) ? pv[u][hh] : 0.f;
-      if (ok) store_wt(p.h + (long)row * p.ldh + ocol, base + v);
     } else if (EPI == SK_QKV) {
       if (ok) {
         const int part = ocol / p.inner, c = ocol - part * p.inner;
@@ -756,7 +589,6 @@ void gemv_kernel(MH_GEMV_LEAD_PARAMS, SkinnyP p, DepP dep) {
     }
   }
   MH_STAMP(KID, 3);     // epilogue stores issued
-  dep_signal<DEP>(dep, dep_ep);
 #undef MH_LOAD_OLDH
 }
 
@@ -1018,7 +850,7 @@ template <> struct Raw8<float> {
 // The statistics come from the row itself (wave sums -> 16 LDS floats that every thread adds in the same order).
 // Two halves: `issue` only REQUESTS the row and the weight (it needs nothing but preloaded kernel arguments), `finish`
 // waits for them -- whatever else the kernel can request goes in between.
-template <typename T, bool DEP = false>
+template <typename T>
 struct NormRow {
   float x, g;
   __device__ inline void issue_weight(const HeadProjP& hp) {      // (independent of the predecessor)
@@ -1027,25 +859,11 @@ struct NormRow {
   }
   __device__ inline void issue_row(const HeadProjP& hp, int b) {   // the residual row the predecessor wrote
     const int tid = threadIdx.x;
-    dep_ld4<DEP>(x, hp.h + (long)b * hp.ldh + (tid < hp.d ? tid : hp.d - 1));
+    x = hp.h[(long)b * hp.ldh + (tid < hp.d ? tid : hp.d - 1)];
   }
   __device__ inline void issue(const HeadProjP& hp, int b) { issue_row(hp, b); issue_weight(hp); }
-  // the residual row plus the H partial rows of the folded output projection in front of this kernel, added in head order; all
-  // 1 + 16 loads are in flight together (heads >= H re-read the last one and add nothing): one round trip, like the plain form
-  __device__ inline void issue_row_parts(const HeadProjP& hp, int b, const float* parts, int H) {
-    const int tid = threadIdx.x, k = tid < hp.d ? tid : hp.d - 1;
-    x = hp.h[(long)b * hp.ldh + k];
-    const float* pp = parts + (long)b * H * hp.d + k;
-    float v[16];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) v[u] = pp[(long)(u < H ? u : H - 1) * hp.d];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) x += (u < H) ? v[u] : 0.f;
-  }
   __device__ inline void finish(const HeadProjP& hp, float* xn, float* red16) {
     const int tid = threadIdx.x;
-    dep_landed<DEP>();
-    dep_pin<DEP>(x);
     const float sq = wave_sum(tid < hp.d ? x * x : 0.f);
     if ((tid & 63) == 0) red16[tid >> 6] = sq;
     __syncthreads();
@@ -1114,78 +932,13 @@ struct HeadProj {
   }
 };
 
-// ---- the output projection folded into the attention kernels (option decode_fold_oproj) -------------------------------------
-// An attention workgroup owns one (row, head): 64 of the `inner` inputs of the output projection.  Instead of storing them for
-// a stand-alone GEMV (one more dependent launch, twice per layer) it multiplies them with its head's 64 columns of Wo itself
-// and writes a PARTIAL product row part[row][head][0..d).  The partials are added in head order 0 .. H-1, so the result does not
-// depend on which workgroup finishes first:
-//   self-attention -> the cross-attention kernel of the same layer adds them to the residual row while it loads it
-//                     (12 more coalesced loads per thread in a prologue that waits for one round trip anyway);
-//   cross-attention -> the LAST workgroup of a row to arrive (one ticket per row) adds the self- and the cross-partials to
-//                     the residual row and stores it: the release / ticket / acquire hand-off of a split-K reduction.
-// Six dependent launches per decoder layer become four.
-struct FoldP {
-  const void* Wo; int ldwo;        // [d][ldwo] element type T: the layer's output projection (ldwo = inner)
-  float* part_out;                 // [B][H][d] fp32: what this kernel writes
-  const float* part_in;            // [B][H][d] fp32 partials of the preceding self-attention kernel (cross kernel), else null
-  int* tickets;                    // cross kernel: one arrival counter per row, zero between launches
-  float* h_out; int ldh;           // cross kernel: the residual stream, updated in place by a row's last workgroup
-};
-
-// ao: the head's 64 attention outputs, T-rounded, in LDS.  stage: d floats of LDS.  Every thread of a 1024-thread workgroup:
-// output o = c * 128 + (tid >> 3) of pass c, input chunk ks = tid & 7 (8 lanes read the 128 (bf16) / 256 (fp32) contiguous bytes of
-// one Wo row slice).  Leaves the d partial sums in `stage` (synchronised).
-template <typename T, int KC, bool AHEAD>
-struct HeadOProj {
-  // AHEAD (self-attention kernel, 128-register budget), bf16: the whole slice (KC 16-byte pieces per lane, <= 32 registers) is
-  // requested by `load` -- BEFORE the attention partials are merged, so the round trip overlaps the merge -- and multiplied by
-  // `apply`.  Otherwise (fp32: 2 KC float4 would not fit beside the merge; the cross-attention kernel: 64 registers) `apply`
-  // loads the pieces itself, all of them at once in bf16, two at a time in fp32.
-  static constexpr bool kAhead = AHEAD && sizeof(T) == 2;
-  static constexpr int NB = sizeof(T) == 2 ? KC : (KC < 2 ? KC : 2);
-  Raw8<T> raw[NB];
-  __device__ inline void load(const FoldP& f, int h) {
-    if constexpr (kAhead) {
-      const int tid = threadIdx.x, og = tid >> 3, ks = tid & 7;
-      const T* wp = reinterpret_cast<const T*>(f.Wo) + (long)og * f.ldwo + h * 64 + ks * 8;
-#pragma unroll
-      for (int c = 0; c < KC; ++c) raw[c].load(wp + (long)c * 128 * f.ldwo);
-    }
-  }
-  __device__ inline void apply(const FoldP& f, int h, const float* ao, float* stage) {
-    const int tid = threadIdx.x, og = tid >> 3, ks = tid & 7;
-    const T* wp = reinterpret_cast<const T*>(f.Wo) + (long)og * f.ldwo + h * 64 + ks * 8;
-    const float4 x0 = *reinterpret_cast<const float4*>(ao + ks * 8);
-    const float4 x1 = *reinterpret_cast<const float4*>(ao + ks * 8 + 4);
-#pragma unroll
-    for (int c0 = 0; c0 < KC; c0 += NB) {
-      if constexpr (!kAhead) {
-#pragma unroll
-        for (int u = 0; u < NB; ++u)
-          if (c0 + u < KC) raw[u].load(wp + (long)(c0 + u) * 128 * f.ldwo);
-      }
-#pragma unroll
-      for (int u = 0; u < NB; ++u) {
-        if (c0 + u >= KC) continue;
-        float w[8];
-        raw[u].unpack(w);
-        float acc = x0.x * w[0] + x0.y * w[1] + x0.z * w[2] + x0.w * w[3] + x1.x * w[4] + x1.y * w[5] + x1.z * w[6] + x1.w * w[7];
-        acc = group_sum<8>(acc);
-        if (ks == 0) stage[(c0 + u) * 128 + og] = acc;
-      }
-    }
-    __syncthreads();
-  }
-};
-
 // cross-attention of one (b, h) with its own query projection; 16 waves, one key split (the default configuration
 // of dec_cross_attn_kernel, same key interleave and merge order)
 // F8: K / V are the e4m3 copy (64-byte rows, 8 bytes per lane; the scales multiply the scores and the output)
-template <typename T, int KC, int U, bool F8 = false, bool WH = false, bool DEP = false, int FOLD = 0>   // FOLD: 1 = partial rows in AND out, 2 = in only
+template <typename T, int KC, int U, bool F8 = false, bool WH = false>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8)))   // <= 64 VGPRs: 2 workgroups per CU
 void dec_cross_attn_q_kernel(const float* h_, const float* lnw_, const void* W_, const void* k_, const void* v_, int H_, int L_, int d_,
-                             int kvB_, CrossAttnP p, HeadProjP hp, DepP dep, FoldP fold) {   // leading scalars: preloaded kernel arguments (see gemv_kernel)
-  static_assert(!FOLD || (!WH && !DEP), "the folded output projection is built for the T5 backbone's plain step");
+                             int kvB_, CrossAttnP p, HeadProjP hp) {   // leading scalars: preloaded kernel arguments (see gemv_kernel)
   hp.h = h_; hp.ln_w = lnw_; hp.W = W_; hp.ldh = d_; hp.ldw = d_; hp.d = d_;
   p.k = k_; p.v = v_; p.H = H_; p.L = L_; p.kv_B = kvB_;
   constexpr int NW = 16;
@@ -1204,32 +957,18 @@ void dec_cross_attn_q_kernel(const float* h_, const float* lnw_, const void* W_,
   const E* kb = reinterpret_cast<const E*>(p.k) + ((long)kvb * p.H + h) * p.L * 64;
   const E* vb = reinterpret_cast<const E*>(p.v) + ((long)kvb * p.H + h) * p.L * 64;
   HeadProj<T, KC, 1> proj;
-  NormRow<T, DEP> nrow;
+  NormRow<T> nrow;
   // everything the prologue needs is requested at once, from preloaded arguments only: the residual row, the RMSNorm
   // weight and (bf16: fp32 -- the parity path -- would not fit the 64-register budget of two workgroups per CU) this
   // head's 64 x d slice of Wq, which does not depend on the activations; then the remaining kernel arguments
-  const unsigned dep_ep = dep_epoch<DEP>(dep);
-  if constexpr (DEP) {   // overlap form: weights first, then wait for the o-projection GEMV, then its residual row
-    nrow.issue_weight(hp);
-    if (sizeof(T) == 2) proj.load(hp, row0);
-    dep_wait<DEP>(dep, dep_ep);
-    nrow.issue_row(hp, b);
-  } else if constexpr (FOLD) {
-    nrow.issue_row_parts(hp, b, fold.part_in, p.H);
-    nrow.issue_weight(hp);
-    if (sizeof(T) == 2) proj.load(hp, row0);
-  } else {
-    nrow.issue(hp, b);
-    if (sizeof(T) == 2) proj.load(hp, row0);
-  }
+  nrow.issue(hp, b);
+  if (sizeof(T) == 2) proj.load(hp, row0);
   // (LDS-DMA prefetch of every wave's first 1-3 key iterations during this prologue -- 32 KB of LDS per iteration, issued as
   // inline asm behind shadow loads so that no wait of the prologue covers it -- was built and measured: 703 / 703 / 729 us
   // per token step for 1 / 2 / 3 iterations against 679 without.  Not kept.)
   unsigned long long t_start = 0;
   if (p.tstamp && threadIdx.x == 0) t_start = (unsigned long long)wall_clock64();
   nrow.finish(hp, xn, red16);
-  __shared__ float xres[FOLD == 1 ? 1024 : 1];
-  if constexpr (FOLD == 1) xres[threadIdx.x] = nrow.x;   // the un-normalised row, for the residual update at the end (not held in a register across the key stream)
   MH_STAMP(KID_CROSS, 0);   // row normalised
   if (sizeof(T) != 2) proj.load(hp, row0);
   proj.apply(xn, qs, WH ? p.q_bias : nullptr, row0);
@@ -1243,93 +982,26 @@ void dec_cross_attn_q_kernel(const float* h_, const float* lnw_, const void* W_,
   partial_init(st);
   attend_keys<T, U, E>(st, q, kb, vb, wid * 8 + g, p.L, 8 * NW, nullptr, 0, nullptr, 0, ks);
   MH_STAMP(KID_CROSS, 2);   // keys streamed (this wave)
-  HeadOProj<T, KC, false> oproj;
   partial_merge_groups<T>(st);
   float m, l, a;
   block_merge<T, NW>(st, sm, m, l, a);
   MH_STAMP(KID_CROSS, 3);   // partials merged
-  if constexpr (FOLD == 1) {
-    // this head's share of the output projection, then -- last workgroup of the row only -- the residual update
-    if (threadIdx.x < 64) qs[0][threadIdx.x] = Elem<T>::to_f32(Elem<T>::from_f32(l > 0.f ? a / l * vs : 0.f));
-    __syncthreads();
-    oproj.apply(fold, h, qs[0], xn);
-    float* mine = fold.part_out + ((long)b * p.H + h) * hp.d;
-    if (threadIdx.x * 4 < hp.d) {
-      const float4 v4 = *reinterpret_cast<const float4*>(xn + threadIdx.x * 4);
-      store16_wt(mine + threadIdx.x * 4, u32x4_t{__float_as_uint(v4.x), __float_as_uint(v4.y), __float_as_uint(v4.z), __float_as_uint(v4.w)});
-    }
-    // hand-off without fences: the partial rows leave by write-through (sc1) stores, every wave waits for its own, the ticket
-    // is drawn behind the workgroup barrier, and the row's last workgroup reads all partial rows with sc1 loads (they are
-    // rewritten every layer and step: a cached copy would be a stale one)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      const int t = __hip_atomic_fetch_add(&fold.tickets[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const int last = (t == p.H - 1);
-      if (last) __hip_atomic_store(&fold.tickets[b], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (nobody else touches it before the next launch)
-      red16[0] = __int_as_float(last);
-    }
-    __syncthreads();
-    if (__float_as_int(red16[0]) && (int)threadIdx.x < hp.d) {
-      const float* pp = fold.part_out + (long)b * p.H * hp.d + threadIdx.x;
-      float xr = xres[threadIdx.x];            // residual row + self-attention partials (what was normalised)
-      float v[16];     // (agent-scope relaxed atomic loads = sc1 loads the compiler keeps count of)
-#pragma unroll
-      for (int u = 0; u < 16; ++u) v[u] = __hip_atomic_load(pp + (long)(u < p.H ? u : p.H - 1) * hp.d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-      for (int u = 0; u < 16; ++u) xr += (u < p.H) ? v[u] : 0.f;
-      fold.h_out[(long)b * fold.ldh + threadIdx.x] = xr;
-    }
-  } else {
-    if (threadIdx.x < 64)
-      store_head_row_wt<T>(reinterpret_cast<T*>(p.out) + (long)b * p.ldo + h * 64, l > 0.f ? a / l * vs : 0.f, &sm[0][0]);
-  }
+  if (threadIdx.x < 64)
+    store_head_row_wt<T>(reinterpret_cast<T*>(p.out) + (long)b * p.ldo + h * 64, l > 0.f ? a / l * vs : 0.f, &sm[0][0]);
   if (p.tstamp && threadIdx.x == 0 && *p.pos < p.ts_ring) {      // the first ts_ring positions of the call, one slot each
     unsigned long long* slot = p.tstamp + 2 * ((long)(*p.pos) * p.ts_layers + p.ts_layer);
     atomicMin(slot, t_start);
     atomicMax(slot + 1, (unsigned long long)wall_clock64());
   }
-  dep_signal<DEP>(dep, dep_ep);
-}
-
-// normalised rows b0 .. b0+R-1 (clamped to B-1) into LDS as T elements: xs[r][k] = T(ln_w[k] * (h[b][k] * rsqrt(mean(h[b]^2)
-// + eps))), one pass of loads, by a 1024-thread workgroup (d <= 1024); the statistics as in norm_row_to_lds
-template <typename T, int R>
-__device__ inline void norm_rows_to_lds(const HeadProjP& hp, int b0, int B, T (*xs)[1024], float (*red)[16]) {
-  const int tid = threadIdx.x;
-  const int kc = tid < hp.d ? tid : hp.d - 1;
-  float x[R];
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const int br = b0 + r < B ? b0 + r : B - 1;
-    x[r] = hp.h[(long)br * hp.ldh + kc];
-  }
-  const float g = hp.ln_w[kc];
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const float sq = wave_sum(tid < hp.d ? x[r] * x[r] : 0.f);
-    if ((tid & 63) == 0) red[r][tid >> 6] = sq;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    float tot = 0.f;
-#pragma unroll
-    for (int w = 0; w < 16; ++w) tot += red[r][w];
-    const float rs = rsqrtf(tot / (float)hp.d + hp.eps);
-    if (tid < hp.d) xs[r][tid] = Elem<T>::from_f32(g * (x[r] * rs));
-  }
-  __syncthreads();
 }
 
 // self-attention of one (b, h) with its own q / k / v projections: appends the new key / value row to the caches and
 // attends over keys 0 .. pos-1 from the cache plus the new key straight from LDS (merged last)
-template <typename T, int KC, bool WH = false, bool DEP = false, bool FOLD = false>
+template <typename T, int KC, bool WH = false>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4)))   // 16 waves = 4 per SIMD: the whole 128-register budget
 void dec_self_attn_qkv_kernel(const float* h_, const float* lnw_, const void* W_, const int* pos_,
                                                                  const void* kc_, const void* vc_, int H_, int d_, SelfAttnP p,
-                                                                 HeadProjP hp, DepP dep, FoldP fold) {   // leading scalars: preloaded kernel arguments
-  static_assert(!FOLD || (!WH && !DEP), "the folded output projection is built for the T5 backbone's plain step");
+                                                                 HeadProjP hp) {   // leading scalars: preloaded kernel arguments
   hp.h = h_; hp.ln_w = lnw_; hp.W = W_; hp.ldh = d_; hp.ldw = d_; hp.d = d_;
   p.pos = pos_; p.kc = kc_; p.vc = vc_; p.H = H_;
   const int inner = H_ * 64;
@@ -1345,9 +1017,8 @@ void dec_self_attn_qkv_kernel(const float* h_, const float* lnw_, const void* W_
   // the first round trip carries everything that does not depend on another load: the residual row + RMSNorm weight, the
   // position, and the two loop-invariant values of the tail (the bias at distance 0 and the prompt mask of the new key:
   // they used to be two serial round trips at the END of the kernel)
-  NormRow<T, DEP> nrow;
-  const unsigned dep_ep = dep_epoch<DEP>(dep);
-  if constexpr (DEP) nrow.issue_weight(hp); else nrow.issue(hp, b);
+  NormRow<T> nrow;
+  nrow.issue(hp, b);
   const int pos = *p.pos;
   constexpr bool kAllAtOnce = sizeof(T) == 2 && KC <= 7;
   HeadProj<T, KC, kAllAtOnce ? 3 : 1> proj;
@@ -1361,15 +1032,10 @@ void dec_self_attn_qkv_kernel(const float* h_, const float* lnw_, const void* W_
     rope_s = p.rope[(long)pos * 64 + 32 + (threadIdx.x & 31)];
   }
   const int new_key_mask = (mask_row && pos < p.P) ? (int)mask_row[pos < p.P ? pos : 0] : 1;
-  if constexpr (DEP) {   // overlap form: this head's q / k / v weight slice travels while the workgroup waits for the wo GEMV of the layer before
-    if (kAllAtOnce) proj.load3(hp, row03);
-    dep_wait<DEP>(dep, dep_ep);
-    nrow.issue_row(hp, b);
-  }
   nrow.finish(hp, xn, red16);
   const float* qb = WH ? p.qkv_bias : nullptr;
   if (kAllAtOnce) {
-    if constexpr (!DEP) proj.load3(hp, row03);   // (requested AFTER the normalisation: holding the 18 vectors across it measured 688 vs 677 us per token step)
+    proj.load3(hp, row03);   // (requested AFTER the normalisation: holding the 18 vectors across it measured 688 vs 677 us per token step)
     proj.apply(xn, qkv, qb, row03);
   } else {   // fp32 storage, or d_model = 1024 in bf16: one projection at a time (register budget of a 1024-thread workgroup)
 #pragma unroll
@@ -1412,8 +1078,6 @@ void dec_self_attn_qkv_kernel(const float* h_, const float* lnw_, const void* W_
   attend_keys<T, 2>(st, q, kcache, vcache, j_first + wid * 8 + g, pos, 8 * NW, bias_row, pos, mask_row, p.P, sc,
                     (WH && p.window > 0) ? pos - p.window : 0);
   MH_STAMP(KID_SELF, 1);    // cached keys attended (this wave)
-  HeadOProj<T, KC, true> oproj;
-  if constexpr (FOLD) oproj.load(fold, h);      // (the cached keys are attended: the slice travels under the merge)
   partial_merge_groups<T>(st);
   float m, l, a;
   block_merge<T, NW>(st, sm, m, l, a);
@@ -1426,128 +1090,7 @@ void dec_self_attn_qkv_kernel(const float* h_, const float* lnw_, const void* W_
     const float fa = fexp<T>(m - mn), fb = fexp<T>(sn - mn);
     l = l * fa + fb;
     a = a * fa + qkv[2][d] * fb;
-    if constexpr (FOLD) qkv[0][d] = Elem<T>::to_f32(Elem<T>::from_f32(l > 0.f ? a / l : 0.f));   // (q is dead: the head's output, T-rounded)
-    else store_head_row_wt<T>(reinterpret_cast<T*>(p.out) + (long)b * p.ldo + h * 64, l > 0.f ? a / l : 0.f, &sm[0][0]);
-  }
-  if constexpr (FOLD) {   // this head's share of the output projection: one partial row, added by the cross-attention kernel
-    __syncthreads();
-    oproj.apply(fold, h, qkv[0], xn);
-    float* mine = fold.part_out + ((long)b * p.H + h) * hp.d;
-    if (threadIdx.x * 4 < hp.d) *reinterpret_cast<float4*>(mine + threadIdx.x * 4) = *reinterpret_cast<const float4*>(xn + threadIdx.x * 4);
-  }
-  dep_signal<DEP>(dep, dep_ep);
-}
-
-// The same for R = 2 or 4 rows of one head per workgroup (option decode_self_rows): rows b0 .. b0+R-1 share the head's
-// 3 x 64 x d weight slice, which is requested ONCE, at kernel entry (before the row statistics are waited for), straight
-// into MFMA fragments: wave w owns the 16-feature tile tg = w & 3 of each of q / k / v and the quarter ks = w >> 2 of K
-// (A operand = the R normalised rows from LDS, tile rows >= R repeat row 0 and are never read back); the 4 K-quarters are
-// added through LDS in fixed order.  R = 1 re-reads 295 KB of weights per (row, head) -- 57 MB of L2 reads per 16-row
-// launch at base dims -- and occupies 192 CUs with a 110-register 16-wave workgroup each (nothing of the other decode
-// chain fits beside it); R rows per workgroup divide both by R.  Then 16 / R waves per row attend over the cache.  A
-// row's arithmetic depends on R (projection on the MFMA atom, key interleave 16 / R waves wide), never on the batch.
-template <typename T, int KC, int R>
-__global__ __launch_bounds__(1024) void dec_self_attn_qkv_rows_kernel(const float* h_, const float* lnw_, const void* W_, const int* pos_,
-                                                                      const void* kc_, const void* vc_, int H_, int d_, SelfAttnP p,
-                                                                      HeadProjP hp) {   // leading scalars: preloaded kernel arguments
-  hp.h = h_; hp.ln_w = lnw_; hp.W = W_; hp.ldh = d_; hp.ldw = d_; hp.d = d_;
-  p.pos = pos_; p.kc = kc_; p.vc = vc_; p.H = H_;
-  const int inner = H_ * 64;
-  constexpr int NW = 16, NWR = NW / R;   // waves per row
-  constexpr int U = 4;                   // keys in flight per 8-lane group (the weight fragments are dead by then)
-  constexpr int VEC = Elem<T>::kVec, KB = 4 * VEC;
-  constexpr int NF = KC * 128 / KB / 4;  // k-blocks per K-quarter: KC (bf16) or 2 KC (fp32)
-  constexpr int PPP = (sizeof(T) == 2 && KC <= 6) ? 3 : 1;   // projections per pass (register budget: <= 18 fragments)
-  __shared__ float sm[NW][66];
-  __shared__ __attribute__((aligned(16))) T xs[R][1024];
-  __shared__ float qkv[R][3][64];
-  __shared__ float red[R][16];
-  __shared__ f32x4_t part[3][NW][16];    // [projection][wave][feature of the tile]: accumulator rows 0..3 = batch rows
-  MH_STAMP0();
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int l15 = lane & 15, lg = lane >> 4;
-  const int b0 = (blockIdx.x / p.H) * R, h = blockIdx.x % p.H;
-  const int tg = wid & 3, ks = wid >> 2;
-  const T* wbase = reinterpret_cast<const T*>(hp.W) + (long)(h * 64 + tg * 16 + l15) * hp.ldw + ks * NF * KB + lg * VEC;
-  const long wpart = (long)inner * hp.ldw;
-  uint4 wv[PPP][NF];
-#pragma unroll
-  for (int pp = 0; pp < PPP; ++pp)
-#pragma unroll
-    for (int c = 0; c < NF; ++c) wv[pp][c] = *reinterpret_cast<const uint4*>(wbase + pp * wpart + c * KB);
-  const int pos = *p.pos;
-  norm_rows_to_lds<T, R>(hp, b0, p.B, xs, red);
-  const T* xrow = xs[l15 < R ? l15 : 0] + ks * NF * KB + lg * VEC;
-#pragma unroll
-  for (int p0 = 0; p0 < 3; p0 += PPP) {
-    if (p0 > 0) {
-#pragma unroll
-      for (int c = 0; c < NF; ++c) wv[0][c] = *reinterpret_cast<const uint4*>(wbase + p0 * wpart + c * KB);
-    }
-#pragma unroll
-    for (int pp = 0; pp < PPP; ++pp) {
-      f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int c = 0; c < NF; ++c) acc = VecOps<T>::mma(*reinterpret_cast<const uint4*>(xrow + c * KB), wv[pp][c], acc);
-      if (lg == 0) part[p0 + pp][wid][l15] = acc;
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x < 3 * R * 64) {   // (projection, row, feature): the 4 K-quarters in fixed order
-    const int f = threadIdx.x & 63, rr = (threadIdx.x >> 6) % R, pj = threadIdx.x / (64 * R);
-    const float* pf = reinterpret_cast<const float*>(part);
-    float v = 0.f;
-#pragma unroll
-    for (int q4 = 0; q4 < 4; ++q4) v += pf[(((pj * NW) + q4 * 4 + (f >> 4)) * 16 + (f & 15)) * 4 + rr];
-    qkv[rr][pj][f] = Elem<T>::to_f32(Elem<T>::from_f32(v));
-  }
-  __syncthreads();
-  MH_STAMP(KID_SELF, 0);    // q / k / v projected
-  const int c8 = (lane & 7) * 8, g = lane >> 3;
-  const int r = wid / NWR, wr = wid % NWR;            // this wave's row and its index among the row's waves
-  const bool live = b0 + r < p.B;
-  const int b = live ? b0 + r : p.B - 1;              // a dead row recomputes the last one and stores nothing
-  T* kcache = reinterpret_cast<T*>(const_cast<void*>(p.kc)) + ((long)b * p.H + h) * p.tgt_len * 64;
-  T* vcache = reinterpret_cast<T*>(const_cast<void*>(p.vc)) + ((long)b * p.H + h) * p.tgt_len * 64;
-  if (live && wr == 1) store_head_row_from_lds_wt<T>(kcache + (long)pos * 64, qkv[r][1], lane);
-  if (live && wr == 2) store_head_row_from_lds_wt<T>(vcache + (long)pos * 64, qkv[r][2], lane);
-  float q[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) q[i] = qkv[r][0][c8 + i];
-  const float* bias_row = p.bias + (long)h * p.tgt_len;
-  const uint8_t* mask_row = p.prompt_mask ? p.prompt_mask + (long)b * p.P : nullptr;
-  Partial st;
-  partial_init(st);
-  attend_keys<T, U>(st, q, kcache, vcache, wr * 8 + g, pos, 8 * NWR, bias_row, pos, mask_row, p.P, 1.0f);
-  MH_STAMP(KID_SELF, 1);    // cached keys attended (this wave)
-  partial_merge_groups<T>(st);
-  if (g == 0) {
-    if (lane == 0) { sm[wid][0] = st.m; sm[wid][1] = st.l; }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) sm[wid][2 + c8 + i] = st.acc[i];
-  }
-  __syncthreads();
-  if (wr == 0) {   // the first wave of a row merges the row's NWR partials in wave order, then the new key
-    const int d = lane, w0 = r * NWR;
-    float m = sm[w0][0];
-#pragma unroll
-    for (int w = 1; w < NWR; ++w) m = fmaxf(m, sm[w0 + w][0]);
-    float l = 0.f, a = 0.f;
-#pragma unroll
-    for (int w = 0; w < NWR; ++w) {
-      const float f = fexp<T>(sm[w0 + w][0] - m);
-      l += sm[w0 + w][1] * f;
-      a += sm[w0 + w][2 + d] * f;
-    }
-    MH_STAMP(KID_SELF, 2);    // partials merged
-    float sn = wave_sum(qkv[r][0][d] * qkv[r][1][d]) + bias_row[0];
-    if (mask_row && pos < p.P && mask_row[pos < p.P ? pos : 0] == 0) sn = -INFINITY;
-    const float mn = fmaxf(m, sn);
-    const float fa = fexp<T>(m - mn), fb = fexp<T>(sn - mn);
-    l = l * fa + fb;
-    a = a * fa + qkv[r][2][d] * fb;
-    const float res = l > 0.f ? a / l : 0.f;
-    if (live) store_head_row_wt<T>(reinterpret_cast<T*>(p.out) + (long)b * p.ldo + h * 64, res, &sm[w0][0]);   // (this wave's own merge rows)
+    store_head_row_wt<T>(reinterpret_cast<T*>(p.out) + (long)b * p.ldo + h * 64, l > 0.f ? a / l : 0.f, &sm[0][0]);
   }
 }
 

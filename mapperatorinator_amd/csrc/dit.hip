@@ -298,12 +298,11 @@ int dit_body(const MhDiTConfig* c, const MhDiTWeights* w, const float* x, const 
   const int strips = D / 16;
   // big denoiser batches (many chunks stacked): the five large projections run as bf16 x 3 on the bf16 matrix cores
   // (MhGemm.w_split3); a single chunk keeps the exact-fp32 kernels.  The split path takes its LayerNorm + modulate from
-  // the stand-alone pass by default: fusing it into the split kernel's A load (option dit_s3_fused_ln = 1) is slower
+  // the stand-alone pass: fusing it into the split kernel's A load (an option until round 5) is slower
   // (32 chunks x 100 steps: 303.7 vs 292.3 ms -- the modulate arithmetic sits in front of every split store).  History:
   // an earlier build of that fused form returned non-repeatable rows (6, 7 mod 8) on grids of > 1000 workgroups
   // (tools/s3_ln_probe.py); the present code shape is repeatable and exact against the un-fused form
   // (tests/test_gpu_kernels.py::test_gemm_bf16x3_with_fused_layernorm_is_repeatable); the cause was not isolated in the ISA.
-  const bool s3_fused_ln = option(OPT_DIT_S3_FUSED_LN) != 0;
   const long s3min = option(OPT_DIT_SPLIT3_MIN_ROWS);
   const bool s3 = s3min > 0 && NT >= s3min && w->first_w3 && D % 32 == 0 && c->first_k_pad % 32 == 0;
   auto weights = [&](const float* exact, const void* split, MhGemm& gg) {
@@ -427,7 +426,7 @@ int dit_body(const MhDiTConfig* c, const MhDiTWeights* w, const float* x, const 
     g.bias = w->qkv_b[l]; g.dtype = MH_F32; g.epilogue = MH_EPI_QKV_VT; g.C2 = b.vt; g.n_split = 2 * D; g.kv_B = N;
     g.kv_H = H; g.kv_L = T; g.kv_Lpad = b.Tpad;
     weights(w->qkv_w[l], w->qkv_w3[l], g);
-    if (fuse_ln && (!g.w_split3 || s3_fused_ln)) {
+    if (fuse_ln && !g.w_split3) {
       g.ln_stats = b.stats; g.ln_strips = strips; g.ln_shift = mod + 0 * D; g.ln_scale = mod + 1 * D; g.ln_ld = ld_row;
       g.ln_eps = 1e-6f; g.rows_per_batch = T;
     } else {
@@ -447,7 +446,7 @@ int dit_body(const MhDiTConfig* c, const MhDiTWeights* w, const float* x, const 
     g.A = b.xs; g.lda = D; g.ldw = D; g.C = b.hid; g.ldc = 4 * D; g.M = NT; g.N = 4 * D; g.K = D;
     g.bias = w->fc1_b[l]; g.dtype = MH_F32; g.epilogue = MH_EPI_BIAS_GELU;
     weights(w->fc1_w[l], w->fc1_w3[l], g);
-    if (fuse_ln && (!g.w_split3 || s3_fused_ln)) {
+    if (fuse_ln && !g.w_split3) {
       g.ln_stats = b.stats; g.ln_strips = strips; g.ln_shift = mod + 3 * D; g.ln_scale = mod + 4 * D; g.ln_ld = ld_row;
       g.ln_eps = 1e-6f; g.rows_per_batch = T;
     } else {

@@ -34,7 +34,6 @@ struct GemmP {
   const float* ln_shift; const float* ln_scale; int ln_ld; float ln_eps;
   bool ascending_k;
   int split3;   // fp32 only: W holds [hi bf16 x32 | lo bf16 x32] per 32-float K block, A is split on the way into LDS
-  int debug;    // option gemm_lds_pad >> 20 (debugging aid)
   const uint8_t* a_scale; const uint8_t* w_scale; int ks_b;   // MH_MX8: E8M0 scales (lane-major groups, mx8.hip), bytes per row
   uint8_t* mxq; uint8_t* mxs; int mxs_b;                        // MX-fp8 image of the epilogue's result (template MXO): bytes [M][ldc], scales [M][mxs_b]
 };
@@ -216,10 +215,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmP p) {
       if (kLnCapable && ln) {
         const bool kin = kt * BK + cchunk * VEC < p.K;   // K-tail columns stay zero
         float mu = lnst[2 * (crow + RPP * i)], rs = lnst[2 * (crow + RPP * i) + 1];
-        if (p.debug & 1) { mu = 0.f; rs = 1.f; }
         const float m = kin ? 1.f : 0.f;
         uint4 qsc = xsc[i], qsh = xsh[i];
-        if (p.debug & 2) { qsc = make_uint4(0, 0, 0, 0); qsh = make_uint4(0, 0, 0, 0); }
         v.x = __float_as_uint(m * ((__uint_as_float(v.x) - mu) * rs * (1.f + __uint_as_float(qsc.x)) + __uint_as_float(qsh.x)));
         v.y = __float_as_uint(m * ((__uint_as_float(v.y) - mu) * rs * (1.f + __uint_as_float(qsc.y)) + __uint_as_float(qsh.y)));
         v.z = __float_as_uint(m * ((__uint_as_float(v.z) - mu) * rs * (1.f + __uint_as_float(qsc.z)) + __uint_as_float(qsh.z)));
@@ -1455,16 +1452,13 @@ __global__ __launch_bounds__(512) void gemm_s3g_kernel(GemmP p) {
 //   scales: [rows][16 * ceil(K / 512)] bytes, byte (kt / 4) * 16 + lg * 4 + (kt % 4) = E8M0 of k block kt * 4 + lg (kt = K step):
 //   a lane fetches ONE dword per row block and four K steps and selects the step's byte with OP_SEL (0..3) -- MI + 4 dword
 //   loads per wave and four steps, issued a group ahead by inline asm and covered by the counted vmcnt waits of the DMA pipeline.
-// Three geometries of one kernel (NW waves as NW/2 (M) x 2 (N), wave tile 16 MI x 64):
+// Two geometries of one kernel (NW waves as NW/2 (M) x 2 (N), wave tile 16 MI x 64; a third -- FOUR waves of 128 x 64 with AGPR
+// accumulators, 0.99-1.37 x bf16 / 1418 TFLOP/s at 8192^3 against 1.07-1.46 x / 1534 -- was removed in round 5):
 //   NW = 8, MI = 4: 256 x 128 tile, EIGHT waves of 64 x 64, two per SIMD (214 VGPRs, accumulators in VGPRs: a kernel that touches
-//     AGPRs gets its 256 registers split 128 + 128) -- one wave's fragment reads run under the other's MFMAs.  The default
-//     (option mx8_waves = 8): 1.07-1.46 x the bf16 kernel on the encoder / DiT-B shapes, 1534 TFLOP/s at 8192^3
+//     AGPRs gets its 256 registers split 128 + 128) -- one wave's fragment reads run under the other's MFMAs.  The default:
+//     1.07-1.46 x the bf16 kernel on the encoder / DiT-B shapes, 1534 TFLOP/s at 8192^3
 //     (profiles/r04_mx8_gemm_bench.txt).  An earlier form of the K loop spilled asm-loaded fragments at this geometry
 //     (tools/check_kernel_resources.py fails the build on that); the rolled loop with one A register set fits.
-//   NW = 4, MI = 8: 256 x 128 tile, FOUR waves of 128 x 64 -- one wave per SIMD, so a wave may hold 512 registers: 128
-//     accumulators (AGPRs) beside 128 fragment registers.  24 fragment reads feed 32 MFMAs per K step (0.75 per MFMA; the
-//     64 x 64 wave tile needs 1.0) but nothing overlaps a wave's own waits: 0.99-1.37 x bf16, 1418 TFLOP/s at 8192^3
-//     (option mx8_waves = 4).
 //   NW = 8, MI = 2: 128 x 128 tile for grids that would leave CUs idle at 256 rows per tile.
 // Two phases per K step, split by A row blocks so that the A fragments need ONE register set:
 //   phase 1: DMA of step kt + 2 (+ the next scale group every fourth step) | reads of (stage kt: A blocks MI/2 ..) | MFMAs of A
@@ -1749,11 +1743,9 @@ int launch_mx8(const GemmP& p, hipStream_t s) {
 template <int EPI>
 bool prepare_mx8() {
   bool ok = true;
-  ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mx8_kernel<EPI, 8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (256 + 128) * 128) == hipSuccess;
   ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mx8_kernel<EPI, 2, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (128 + 128) * 128) == hipSuccess;
   ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mx8_kernel<EPI, 4, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (256 + 128) * 128) == hipSuccess;
   if constexpr (EPI == MH_EPI_GEGLU || EPI == MH_EPI_BIAS_GELU) {   // ... and their forms that write the result as an MX-fp8 operand
-    ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mx8_kernel<EPI, 8, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (256 + 128) * 128) == hipSuccess;
     ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mx8_kernel<EPI, 2, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (128 + 128) * 128) == hipSuccess;
     ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mx8_kernel<EPI, 4, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (256 + 128) * 128) == hipSuccess;
   }
@@ -1766,13 +1758,11 @@ int dispatch_mx8(const GemmP& p, hipStream_t s) {
   if constexpr (EPI == MH_EPI_GEGLU || EPI == MH_EPI_BIAS_GELU) {
     if (p.mxq) {   // the result leaves as the next GEMM's MX-fp8 operand
       if (tiles256 < option(OPT_MX8_TILE256_MIN)) return launch_mx8<EPI, 2, 8, true>(p, s);
-      if (option(OPT_MX8_WAVES) == 8) return launch_mx8<EPI, 4, 8, true>(p, s);
-      return launch_mx8<EPI, 8, 4, true>(p, s);
+      return launch_mx8<EPI, 4, 8, true>(p, s);
     }
   }
   if (tiles256 < option(OPT_MX8_TILE256_MIN)) return launch_mx8<EPI, 2, 8>(p, s);
-  if (option(OPT_MX8_WAVES) == 8) return launch_mx8<EPI, 4, 8>(p, s);     // 256 x 128 tile as eight waves of 64 x 64 (two per SIMD)
-  return launch_mx8<EPI, 8, 4>(p, s);
+  return launch_mx8<EPI, 4, 8>(p, s);     // 256 x 128 tile as eight waves of 64 x 64 (two per SIMD); the four-wave 128 x 64 geometry measured 0.99-1.37 x the bf16 kernel against 1.07-1.46 x (profiles/r04_mx8_gemm_bench.txt) and was removed in round 5
 }
 int dispatch_mx8_epi(const GemmP& p, int epi, hipStream_t s) {
   switch (epi) {
@@ -1824,7 +1814,6 @@ template <typename T, int BM, int BN, int EPI, bool S3 = false, bool GL = false>
 int launch_gemm(const GemmP& p, hipStream_t s) {
   const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
   size_t smem = 2 * (size_t)(BM + BN) * (RowBytes<BM>::v + 16) + BM * 8 + 2048;   // + LayerNorm statistics
-  if (BM <= 64) smem += (size_t)(option(OPT_GEMM_LDS_PAD) & 0xfffff);   // (debugging aid; <= 64 KB total without the opt-in attribute)
   hipLaunchKernelGGL((gemm_tn_kernel<T, BM, BN, EPI, S3, GL>), dim3(nbm * nbn), dim3(256), smem, s, p);
   return check_launch("gemm_tn_kernel");
 }
@@ -2018,7 +2007,6 @@ int gemm(const MhGemm& g, hipStream_t s, bool ascending_k) {
   GemmP p;
   p.ascending_k = ascending_k;
   p.split3 = g.w_split3;
-  p.debug = (int)(option(OPT_GEMM_LDS_PAD) >> 20);
   p.C3 = g.C3; p.C4 = g.C4; p.cache_len = g.cache_len;
   p.C2 = g.C2; p.n_split = g.n_split; p.kv_Lpad = g.kv_Lpad;
   p.A = (const char*)g.A; p.lda_b = (long)g.lda * es;

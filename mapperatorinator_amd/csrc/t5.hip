@@ -816,7 +816,7 @@ int gemv_cols(int N) {
 }
 
 template <typename T, int MF, int PRO, int EPI, bool BIAS = false>
-int launch_skinny(dec::SkinnyP p, hipStream_t s, const dec::DepP* dep = nullptr) {
+int launch_skinny(dec::SkinnyP p, hipStream_t s) {
   const int kb = 4 * (16 / (int)sizeof(T));
   MH_REQUIRE(p.K % kb == 0 && p.K >= kb, "decode: K=%d must be a positive multiple of %d", p.K, kb);
   const int nkb = p.K / kb;
@@ -825,8 +825,7 @@ int launch_skinny(dec::SkinnyP p, hipStream_t s, const dec::DepP* dep = nullptr)
   const bool wide = nkb > 4 * dec::kGemvCH;
   MH_REQUIRE(PRO != dec::PRO_RMSNORM || nkb <= 8 * dec::kGemvCH, "decode: RMSNorm prologue needs K <= %d", 8 * dec::kGemvCH * kb);
   MH_REQUIRE(p.lda == p.K && p.ldw == p.K, "decode: the GEMV operands must be dense (lda = ldw = K)");
-  MH_REQUIRE((EPI != dec::SK_RESID && EPI != dec::SK_RESID_PARTS) || (p.N % 4 == 0 && p.ldh == p.N), "decode: residual GEMV needs a dense [B, N] residual stream, N a multiple of 4");
-  MH_REQUIRE(EPI != dec::SK_RESID_PARTS || (p.parts && p.parts_H >= 1 && p.parts_H <= 16 && !dep), "decode: residual GEMV with partial rows needs 1 .. 16 of them");
+  MH_REQUIRE(EPI != dec::SK_RESID || (p.N % 4 == 0 && p.ldh == p.N), "decode: residual GEMV needs a dense [B, N] residual stream, N a multiple of 4");
   int tiles;
   if (EPI == dec::SK_GEGLU) { p.nv = 8; tiles = ceil_div(p.N / 2, 8); }
   else { p.nv = gemv_cols(p.N); tiles = ceil_div(p.N, p.nv); }
@@ -835,26 +834,18 @@ int launch_skinny(dec::SkinnyP p, hipStream_t s, const dec::DepP* dep = nullptr)
       set_error("decode: RMSNorm GEMV needs d_model <= 1024 in bf16 storage");
       return MH_ERR_ARG;
     } else {
-      if constexpr (MF == 1 && !BIAS) {
-        if (dep) { dec::DepP dd = *dep; dd.nwg = (unsigned)tiles; hipLaunchKernelGGL((dec::gemv_kernel<T, MF, 8, PRO, EPI, BIAS, true>), dim3(tiles), dim3(512), 0, s, MH_GEMV_LEAD_ARGS(p), p, dd); return check_launch("gemv_kernel"); }
-      }
-      hipLaunchKernelGGL((dec::gemv_kernel<T, MF, 8, PRO, EPI, BIAS>), dim3(tiles), dim3(512), 0, s, MH_GEMV_LEAD_ARGS(p), p, dec::DepP{});
+      hipLaunchKernelGGL((dec::gemv_kernel<T, MF, 8, PRO, EPI, BIAS>), dim3(tiles), dim3(512), 0, s, MH_GEMV_LEAD_ARGS(p), p);
     }
   } else {
-    if constexpr (MF == 1 && !BIAS) {
-      if (dep) { dec::DepP dd = *dep; dd.nwg = (unsigned)tiles; hipLaunchKernelGGL((dec::gemv_kernel<T, MF, 4, PRO, EPI, BIAS, true>), dim3(tiles), dim3(256), 0, s, MH_GEMV_LEAD_ARGS(p), p, dd); return check_launch("gemv_kernel"); }
-    }
-    hipLaunchKernelGGL((dec::gemv_kernel<T, MF, 4, PRO, EPI, BIAS>), dim3(tiles), dim3(256), 0, s, MH_GEMV_LEAD_ARGS(p), p, dec::DepP{});
+    hipLaunchKernelGGL((dec::gemv_kernel<T, MF, 4, PRO, EPI, BIAS>), dim3(tiles), dim3(256), 0, s, MH_GEMV_LEAD_ARGS(p), p);
   }
-  MH_REQUIRE(!dep, "decode: the overlap form of this GEMV is not built");
   return check_launch("gemv_kernel");
 }
 
 template <typename T, int PRO, int EPI, bool BIAS = false>
-int skinny(const dec::SkinnyP& p, hipStream_t s, const dec::DepP* dep = nullptr) {
+int skinny(const dec::SkinnyP& p, hipStream_t s) {
   MH_REQUIRE(!BIAS || p.bias, "decode: biased GEMV without a bias");
-  if (p.B <= 16) return launch_skinny<T, 1, PRO, EPI, BIAS>(p, s, dep);
-  MH_REQUIRE(!dep, "decode: the overlap form needs chains of <= 16 rows");
+  if (p.B <= 16) return launch_skinny<T, 1, PRO, EPI, BIAS>(p, s);
   if (p.B <= 32) return launch_skinny<T, 2, PRO, EPI, BIAS>(p, s);
   return launch_skinny<T, 4, PRO, EPI, BIAS>(p, s);
 }
@@ -870,7 +861,6 @@ struct DecBuffers {
   float* h; void* q; void* attn; void* ff; float* logits; int chain;
   void* self_k; void* self_v;  // [n_dec][B][H][tgt][64]
   uint8_t* finished; int32_t* finish_col; int32_t* last_ts; DecState* st;
-  float* part_self; float* part_cross; int* tickets;   // folded output projections (decode_kernels.hpp FoldP): [B][H][d] x 2, [B]
 };
 
 template <typename T>
@@ -887,110 +877,56 @@ bool fused_proj_enabled(int d) { return option(OPT_DECODE_FUSED_PROJ) != 0 && d 
 
 #define MH_SELF_LEAD_ARGS hp.h, hp.ln_w, hp.W, sa.pos, sa.kc, sa.vc, sa.H, hp.d
 #define MH_CROSS_LEAD_ARGS hp.h, hp.ln_w, hp.W, ca.k, ca.v, ca.H, ca.L, hp.d, ca.kv_B
-// KC values the overlap (DEP) forms of the attention kernels are instantiated for: d_model 128 (tests), 512, 768, 1024
-constexpr bool dep_kc(int KC) { return KC == 1 || KC == 4 || KC == 6 || KC == 8; }
 template <typename T, int KC>
-int launch_self_qkv(const dec::SelfAttnP& sa, const dec::HeadProjP& hp, int inner, hipStream_t s, const dec::DepP* dep = nullptr,
-                    const dec::FoldP* fold = nullptr) {
+int launch_self_qkv(const dec::SelfAttnP& sa, const dec::HeadProjP& hp, int inner, hipStream_t s) {
   MH_REQUIRE(hp.ldh == hp.d && hp.ldw == hp.d && inner == sa.H * 64, "decode: dense residual rows / projection weights expected");
-  if (fold) {   // output projection folded in (T5 backbone, one row per workgroup, plain step)
-    MH_REQUIRE(!dep && !sa.rope, "decode: the folded output projection is built for the T5 backbone's plain step");
-    hipLaunchKernelGGL((dec::dec_self_attn_qkv_kernel<T, KC, false, false, true>), dim3(sa.B * sa.H), dim3(1024), 0, s, MH_SELF_LEAD_ARGS, sa, hp, dec::DepP{}, *fold);
-    return check_launch("dec_self_attn_qkv_kernel");
-  }
-  if (dep) {
-    if constexpr (dep_kc(KC)) {
-      dec::DepP dd = *dep; dd.nwg = (unsigned)(sa.B * sa.H);
-      hipLaunchKernelGGL((dec::dec_self_attn_qkv_kernel<T, KC, false, true>), dim3(sa.B * sa.H), dim3(1024), 0, s, MH_SELF_LEAD_ARGS, sa, hp, dd, dec::FoldP{});
-      return check_launch("dec_self_attn_qkv_kernel");
-    } else {
-      set_error("decode: the overlap form is built for d_model 128 / 512 / 768 / 1024");
-      return MH_ERR_ARG;
-    }
-  }
-  if (sa.rope) {   // the Whisper family: biased fused Wqkv, RoPE, scaled scores, optional window
-    hipLaunchKernelGGL((dec::dec_self_attn_qkv_kernel<T, KC, true>), dim3(sa.B * sa.H), dim3(1024), 0, s, MH_SELF_LEAD_ARGS, sa, hp, dec::DepP{}, dec::FoldP{});
-    return check_launch("dec_self_attn_qkv_kernel");
-  }
-  // option decode_self_rows: rows of one head per workgroup (1, 2 or 4) -- they share the head's weight slice
-  const long R = option(OPT_DECODE_SELF_ROWS);
-  if (R >= 4)
-    hipLaunchKernelGGL((dec::dec_self_attn_qkv_rows_kernel<T, KC, 4>), dim3((sa.B + 3) / 4 * sa.H), dim3(1024), 0, s, MH_SELF_LEAD_ARGS, sa, hp);
-  else if (R >= 2)
-    hipLaunchKernelGGL((dec::dec_self_attn_qkv_rows_kernel<T, KC, 2>), dim3((sa.B + 1) / 2 * sa.H), dim3(1024), 0, s, MH_SELF_LEAD_ARGS, sa, hp);
+  if (sa.rope)   // the Whisper family: biased fused Wqkv, RoPE, scaled scores, optional window
+    hipLaunchKernelGGL((dec::dec_self_attn_qkv_kernel<T, KC, true>), dim3(sa.B * sa.H), dim3(1024), 0, s, MH_SELF_LEAD_ARGS, sa, hp);
   else
-    hipLaunchKernelGGL((dec::dec_self_attn_qkv_kernel<T, KC>), dim3(sa.B * sa.H), dim3(1024), 0, s, MH_SELF_LEAD_ARGS, sa, hp, dec::DepP{}, dec::FoldP{});
+    hipLaunchKernelGGL((dec::dec_self_attn_qkv_kernel<T, KC>), dim3(sa.B * sa.H), dim3(1024), 0, s, MH_SELF_LEAD_ARGS, sa, hp);
   return check_launch("dec_self_attn_qkv_kernel");
 }
 template <typename T>
-int launch_self_qkv_d(const dec::SelfAttnP& sa, const dec::HeadProjP& hp, int inner, hipStream_t s, const dec::DepP* dep = nullptr,
-                      const dec::FoldP* fold = nullptr) {
+int launch_self_qkv_d(const dec::SelfAttnP& sa, const dec::HeadProjP& hp, int inner, hipStream_t s) {
   switch (hp.d) {
-    case 128: return launch_self_qkv<T, 1>(sa, hp, inner, s, dep, fold);
-    case 256: return launch_self_qkv<T, 2>(sa, hp, inner, s, dep, fold);
-    case 384: return launch_self_qkv<T, 3>(sa, hp, inner, s, dep, fold);
-    case 512: return launch_self_qkv<T, 4>(sa, hp, inner, s, dep, fold);
-    case 640: return launch_self_qkv<T, 5>(sa, hp, inner, s, dep, fold);
-    case 768: return launch_self_qkv<T, 6>(sa, hp, inner, s, dep, fold);
-    case 896: return launch_self_qkv<T, 7>(sa, hp, inner, s, dep, fold);
-    default: return launch_self_qkv<T, 8>(sa, hp, inner, s, dep, fold);
+    case 128: return launch_self_qkv<T, 1>(sa, hp, inner, s);
+    case 256: return launch_self_qkv<T, 2>(sa, hp, inner, s);
+    case 384: return launch_self_qkv<T, 3>(sa, hp, inner, s);
+    case 512: return launch_self_qkv<T, 4>(sa, hp, inner, s);
+    case 640: return launch_self_qkv<T, 5>(sa, hp, inner, s);
+    case 768: return launch_self_qkv<T, 6>(sa, hp, inner, s);
+    case 896: return launch_self_qkv<T, 7>(sa, hp, inner, s);
+    default: return launch_self_qkv<T, 8>(sa, hp, inner, s);
   }
 }
 template <typename T, int KC>
-int launch_cross_q(const dec::CrossAttnP& ca, const dec::HeadProjP& hp, hipStream_t s, const dec::DepP* dep = nullptr,
-                   const dec::FoldP* fold = nullptr) {
+int launch_cross_q(const dec::CrossAttnP& ca, const dec::HeadProjP& hp, hipStream_t s) {
   MH_REQUIRE(hp.ldh == hp.d && hp.ldw == hp.d, "decode: dense residual rows / projection weights expected");
-  if (fold) {   // fold->part_out: its own output projection folded in as well (FOLD 1), else only the self-attention partials absorbed (FOLD 2)
-    MH_REQUIRE(!dep && ca.scale == 0.f, "decode: the folded output projection is built for the T5 backbone's plain step");
-    const bool both = fold->part_out != nullptr;
-    if (ca.kscale != nullptr) {
-      if constexpr (sizeof(T) == 2) {
-        if (both) hipLaunchKernelGGL((dec::dec_cross_attn_q_kernel<T, KC, 1, true, false, false, 1>), dim3(ca.B * ca.H), dim3(1024), 0, s, MH_CROSS_LEAD_ARGS, ca, hp, dec::DepP{}, *fold);
-        else hipLaunchKernelGGL((dec::dec_cross_attn_q_kernel<T, KC, 1, true, false, false, 2>), dim3(ca.B * ca.H), dim3(1024), 0, s, MH_CROSS_LEAD_ARGS, ca, hp, dec::DepP{}, *fold);
-      } else { set_error("decode: the fp8 cross K/V copy needs bf16 storage"); return MH_ERR_ARG; }
-    } else {
-      if (both) hipLaunchKernelGGL((dec::dec_cross_attn_q_kernel<T, KC, 1, false, false, false, 1>), dim3(ca.B * ca.H), dim3(1024), 0, s, MH_CROSS_LEAD_ARGS, ca, hp, dec::DepP{}, *fold);
-      else hipLaunchKernelGGL((dec::dec_cross_attn_q_kernel<T, KC, 1, false, false, false, 2>), dim3(ca.B * ca.H), dim3(1024), 0, s, MH_CROSS_LEAD_ARGS, ca, hp, dec::DepP{}, *fold);
-    }
-    return check_launch("dec_cross_attn_q_kernel");
-  }
-  if (dep) {
-    if constexpr (dep_kc(KC)) {
-      MH_REQUIRE(ca.scale == 0.f && ca.kscale == nullptr, "decode: the overlap form is built for the T5 backbone with bf16 / fp32 cross K/V");
-      dec::DepP dd = *dep; dd.nwg = (unsigned)(ca.B * ca.H);
-      hipLaunchKernelGGL((dec::dec_cross_attn_q_kernel<T, KC, 1, false, false, true>), dim3(ca.B * ca.H), dim3(1024), 0, s, MH_CROSS_LEAD_ARGS, ca, hp, dd, dec::FoldP{});
-      return check_launch("dec_cross_attn_q_kernel");
-    } else {
-      set_error("decode: the overlap form is built for d_model 128 / 512 / 768 / 1024");
-      return MH_ERR_ARG;
-    }
-  }
   // one key in flight per 8-lane group: 64 VGPRs without spills (two 16-wave workgroups per CU); U = 2 measured the
   // same bandwidth in the stand-alone kernel
   if (ca.scale != 0.f) {   // the Whisper family: biased Wq, scaled scores
     MH_REQUIRE(ca.kscale == nullptr, "decode: the fp8 cross K/V copy is not wired for the Whisper family");
-    hipLaunchKernelGGL((dec::dec_cross_attn_q_kernel<T, KC, 1, false, true>), dim3(ca.B * ca.H), dim3(1024), 0, s, MH_CROSS_LEAD_ARGS, ca, hp, dec::DepP{}, dec::FoldP{});
+    hipLaunchKernelGGL((dec::dec_cross_attn_q_kernel<T, KC, 1, false, true>), dim3(ca.B * ca.H), dim3(1024), 0, s, MH_CROSS_LEAD_ARGS, ca, hp);
   } else if (ca.kscale != nullptr) {
     if constexpr (sizeof(T) == 2)
-      hipLaunchKernelGGL((dec::dec_cross_attn_q_kernel<T, KC, 1, true>), dim3(ca.B * ca.H), dim3(1024), 0, s, MH_CROSS_LEAD_ARGS, ca, hp, dec::DepP{}, dec::FoldP{});
+      hipLaunchKernelGGL((dec::dec_cross_attn_q_kernel<T, KC, 1, true>), dim3(ca.B * ca.H), dim3(1024), 0, s, MH_CROSS_LEAD_ARGS, ca, hp);
     else { set_error("decode: the fp8 cross K/V copy needs bf16 storage"); return MH_ERR_ARG; }
   } else {
-    hipLaunchKernelGGL((dec::dec_cross_attn_q_kernel<T, KC, 1>), dim3(ca.B * ca.H), dim3(1024), 0, s, MH_CROSS_LEAD_ARGS, ca, hp, dec::DepP{}, dec::FoldP{});
+    hipLaunchKernelGGL((dec::dec_cross_attn_q_kernel<T, KC, 1>), dim3(ca.B * ca.H), dim3(1024), 0, s, MH_CROSS_LEAD_ARGS, ca, hp);
   }
   return check_launch("dec_cross_attn_q_kernel");
 }
 template <typename T>
-int launch_cross_q_d(const dec::CrossAttnP& ca, const dec::HeadProjP& hp, hipStream_t s, const dec::DepP* dep = nullptr,
-                     const dec::FoldP* fold = nullptr) {
+int launch_cross_q_d(const dec::CrossAttnP& ca, const dec::HeadProjP& hp, hipStream_t s) {
   switch (hp.d) {
-    case 128: return launch_cross_q<T, 1>(ca, hp, s, dep, fold);
-    case 256: return launch_cross_q<T, 2>(ca, hp, s, dep, fold);
-    case 384: return launch_cross_q<T, 3>(ca, hp, s, dep, fold);
-    case 512: return launch_cross_q<T, 4>(ca, hp, s, dep, fold);
-    case 640: return launch_cross_q<T, 5>(ca, hp, s, dep, fold);
-    case 768: return launch_cross_q<T, 6>(ca, hp, s, dep, fold);
-    case 896: return launch_cross_q<T, 7>(ca, hp, s, dep, fold);
-    default: return launch_cross_q<T, 8>(ca, hp, s, dep, fold);
+    case 128: return launch_cross_q<T, 1>(ca, hp, s);
+    case 256: return launch_cross_q<T, 2>(ca, hp, s);
+    case 384: return launch_cross_q<T, 3>(ca, hp, s);
+    case 512: return launch_cross_q<T, 4>(ca, hp, s);
+    case 640: return launch_cross_q<T, 5>(ca, hp, s);
+    case 768: return launch_cross_q<T, 6>(ca, hp, s);
+    case 896: return launch_cross_q<T, 7>(ca, hp, s);
+    default: return launch_cross_q<T, 8>(ca, hp, s);
   }
 }
 
@@ -998,47 +934,10 @@ int launch_cross_q_d(const dec::CrossAttnP& ca, const dec::HeadProjP& hp, hipStr
 struct DecodeTiming { unsigned long long* buf = nullptr; int ring = 0; };
 DecodeTiming g_timing;
 
-// dependent-launch overlap of one chain's step (option decode_overlap; decode_kernels.hpp): the chain's second stream, the
-// event that orders a step's second-stream kernels behind the previous step's epoch bump, the chain's DepSync block.
-// The step is launched EAGERLY, kernel by kernel, alternating between the two streams -- not replayed as a graph: a graph's
-// parallel branch runs on a stream of the runtime's choosing, and whenever that stream shared a hardware queue with the
-// launch stream and kernel k + 1 was queued in front of kernel k, k + 1 spun for a predecessor that could not start (lost
-// dependences; measured with 2 chains = 4 branches on the 4 default queues).  With eager launches the host enqueues k before
-// k + 1, so a shared queue only costs the overlap, never the dependence.
-struct OverlapCtx { hipStream_t s2; hipEvent_t step_done; dec::DepSync* sync; int which; };   // which: -1 = every kernel (0 / 1: even / odd slots only)
-__global__ void dec_epoch_bump_kernel(dec::DepSync* sy) {   // last node of a step: the next step's targets move up
-  const unsigned e = sy->epoch + 1;
-  __hip_atomic_store(&sy->epoch, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __hip_atomic_store(&sy->progress, e * 256u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-bool overlap_possible(const MhT5Config* c, int rows_per_chain, bool kv8, bool cfg) {
-  const int d = c->d_model;
-  return option(OPT_DECODE_OVERLAP) != 0 && c->arch == 0 && rows_per_chain <= 16 && !kv8 && !cfg && fused_proj_enabled(d) &&
-         option(OPT_DECODE_FUSED_PROJ) == 1 && option(OPT_DECODE_SELF_ROWS) <= 1 && (d == 128 || d == 512 || d == 768 || d == 1024) &&
-         option(OPT_DECODE_CU_SPLIT) == 0 && 6 * c->n_dec_layers + 2 <= dec::kDepMaxSlots;
-}
-
 template <typename T>
 int enqueue_step(const MhT5Config* c, const MhT5Weights* w, const void* cross_kv, int B, int Bfull, int kvB,
                  const uint8_t* prompt_mask, int P, const DecBuffers& bf, const SampleP& smp, hipStream_t s,
-                 const void* kv8 = nullptr, const float* kv8_scales = nullptr, bool with_sampler = true, int kv_group = 0,
-                 const OverlapCtx* ov = nullptr) {
-  // ov: the step's kernels alternate between `s` and ov->s2 (two branches of the captured graph) and order themselves through
-  // the chain's progress word; the sampler and the epoch bump follow the join on `s`
-  unsigned slot = 0;
-  dec::DepP dep_cur{};
-  auto st = [&]() -> hipStream_t { return (ov && (slot & 1)) ? ov->s2 : s; };
-  auto dp = [&]() -> const dec::DepP* {
-    if (!ov) return nullptr;
-    dep_cur.sync = ov->sync; dep_cur.slot = slot; dep_cur.nwg = 0;
-    return &dep_cur;
-  };
-  if (ov) {
-    MH_REQUIRE(c->arch == 0 && B <= 16 && !kv8 && kv_group == 0 && with_sampler, "decode: overlap form requested for a step it is not built for");
-    // the second stream's kernels read the step counter at their start: they must not start before the previous step's bump
-    if (ov->which < 0 && hipStreamWaitEvent(ov->s2, ov->step_done, 0) != hipSuccess) return check_launch("overlap step wait");
-  }
-  auto take = [&]() -> bool { return !ov || ov->which < 0 || (int)(slot & 1) == ov->which; };
+                 const void* kv8 = nullptr, const float* kv8_scales = nullptr, bool with_sampler = true, int kv_group = 0) {
   // with_sampler = false: the step ends with the logits (mh_t5_step: the host selects); kv_group > 1: rows are (chunk, beam)
   // pairs and row b reads cross K/V row b / kv_group
   // kv8 / kv8_scales: the chain's first row of the e4m3 copy of cross_kv and of its scales (mh_t5_quantize_cross_kv)
@@ -1049,7 +948,7 @@ int enqueue_step(const MhT5Config* c, const MhT5Weights* w, const void* cross_kv
   const int es = (int)sizeof(T);
   const int* posp = &bf.st->pos;
   const bool wh = c->arch == 1;
-  if (wh) MH_REQUIRE(fused_proj_enabled(d) && option(OPT_DECODE_FUSED_PROJ) == 1 && option(OPT_DECODE_SELF_ROWS) <= 1 && w->dec_rope,
+  if (wh) MH_REQUIRE(fused_proj_enabled(d) && option(OPT_DECODE_FUSED_PROJ) == 1 && w->dec_rope,
                      "decode: the Whisper family runs on the fused attention kernels (d_model a multiple of 128 <= 1024) and needs its rotary table");
   for (int l = 0; l < c->n_dec_layers; ++l) {
     const long cache_off = (long)l * Bfull * H * tgt * 64 * es;
@@ -1099,20 +998,6 @@ int enqueue_step(const MhT5Config* c, const MhT5Weights* w, const void* cross_kv
     // self attention
     const bool fused = fused_proj_enabled(d);                                  // cross-attention projects its own query
     const bool fused_self = fused && option(OPT_DECODE_FUSED_PROJ) == 1;       // (2: stand-alone QKV GEMV, fused cross-attention)
-    // both output projections inside the attention kernels (FoldP, decode_kernels.hpp): four dependent launches per layer, not six
-    // option decode_fold_oproj: 1 = the self-attention output projection (its partial rows are absorbed by the cross-attention
-    // kernel's prologue and by the cross output projection's residual epilogue: 5 launches per layer), 2 = both (4 launches)
-    const long fold_mode = (fused_self && !ov && with_sampler && bf.tickets && option(OPT_DECODE_SELF_ROWS) <= 1 && H <= 16) ? option(OPT_DECODE_FOLD_OPROJ) : 0;
-    const bool fold = fold_mode != 0, fold_cross = fold_mode == 2;
-    dec::FoldP fo_self{}, fo_cross{};
-    if (fold) {
-      fo_self.Wo = w->dec_o[l]; fo_self.ldwo = inner; fo_self.part_out = bf.part_self;
-      fo_cross.part_in = bf.part_self;
-      if (fold_cross) {
-        fo_cross.Wo = w->dec_co[l]; fo_cross.ldwo = inner; fo_cross.part_out = bf.part_cross;
-        fo_cross.tickets = bf.tickets; fo_cross.h_out = bf.h; fo_cross.ldh = d;
-      }
-    }
     dec::SelfAttnP sa{};
     sa.q = bf.q; sa.ldq = inner; sa.kc = (char*)bf.self_k + cache_off; sa.vc = (char*)bf.self_v + cache_off;
     sa.bias = w->dec_rel_bias; sa.prompt_mask = prompt_mask;
@@ -1120,10 +1005,8 @@ int enqueue_step(const MhT5Config* c, const MhT5Weights* w, const void* cross_kv
     if (fused_self) {
       dec::HeadProjP hp{};
       hp.h = bf.h; hp.ldh = d; hp.ln_w = w->dec_ln1[l]; hp.eps = c->eps; hp.W = w->dec_qkv[l]; hp.ldw = d; hp.d = d;
-      if (take()) MH_TRY(launch_self_qkv_d<T>(sa, hp, inner, st(), dp(), fold ? &fo_self : nullptr));
-      ++slot;
+      MH_TRY(launch_self_qkv_d<T>(sa, hp, inner, s));
     } else {
-      MH_REQUIRE(!ov, "decode: the overlap form needs decode_fused_proj = 1");
       sk = dec::SkinnyP{};
       sk.A = bf.h; sk.lda = d; sk.ln_w = w->dec_ln1[l]; sk.eps = c->eps; sk.W = w->dec_qkv[l]; sk.ldw = d; sk.B = B;
       sk.N = 3 * inner; sk.K = d; sk.out = bf.q; sk.ldo = inner; sk.kc = (char*)bf.self_k + cache_off;
@@ -1132,13 +1015,10 @@ int enqueue_step(const MhT5Config* c, const MhT5Weights* w, const void* cross_kv
       hipLaunchKernelGGL(dec::dec_self_attn_kernel<T>, dim3(B * H), dim3(256), 0, s, sa);
       MH_TRY(check_launch("dec_self_attn_kernel"));
     }
-    if (!fold) {
-      sk = dec::SkinnyP{};
-      sk.A = bf.attn; sk.lda = inner; sk.W = w->dec_o[l]; sk.ldw = inner; sk.B = B; sk.N = d; sk.K = inner; sk.h = bf.h;
-      sk.ldh = d;
-      if (take()) MH_TRY((skinny<T, dec::PRO_PLAIN, dec::SK_RESID>(sk, st(), dp())));
-      ++slot;
-    }
+    sk = dec::SkinnyP{};
+    sk.A = bf.attn; sk.lda = inner; sk.W = w->dec_o[l]; sk.ldw = inner; sk.B = B; sk.N = d; sk.K = inner; sk.h = bf.h;
+    sk.ldh = d;
+    MH_TRY((skinny<T, dec::PRO_PLAIN, dec::SK_RESID>(sk, s)));
     // cross attention
     dec::CrossAttnP ca{};
     const long kv_layer = (long)kvB * H * L * 64 * es;
@@ -1158,56 +1038,35 @@ int enqueue_step(const MhT5Config* c, const MhT5Weights* w, const void* cross_kv
     if (fused) {
       dec::HeadProjP hp{};
       hp.h = bf.h; hp.ldh = d; hp.ln_w = w->dec_ln2[l]; hp.eps = c->eps; hp.W = w->dec_cq[l]; hp.ldw = d; hp.d = d;
-      if (take()) MH_TRY(launch_cross_q_d<T>(ca, hp, st(), dp(), fold ? &fo_cross : nullptr));
-      ++slot;
+      MH_TRY(launch_cross_q_d<T>(ca, hp, s));
     } else {
-      MH_REQUIRE(!ov, "decode: the overlap form needs decode_fused_proj = 1");
       sk = dec::SkinnyP{};
       sk.A = bf.h; sk.lda = d; sk.ln_w = w->dec_ln2[l]; sk.eps = c->eps; sk.W = w->dec_cq[l]; sk.ldw = d; sk.B = B;
       sk.N = inner; sk.K = d; sk.out = bf.q; sk.ldo = inner;
       MH_TRY((skinny<T, dec::PRO_RMSNORM, dec::SK_STORE>(sk, s)));
       MH_TRY(launch_cross<T>(ca, s));
     }
-    if (!fold_cross) {
-      sk = dec::SkinnyP{};
-      sk.A = bf.attn; sk.lda = inner; sk.W = w->dec_co[l]; sk.ldw = inner; sk.B = B; sk.N = d; sk.K = inner; sk.h = bf.h;
-      sk.ldh = d;
-      if (fold) {   // ... and the residual row absorbs the self-attention partials here
-        sk.parts = bf.part_self; sk.parts_H = H;
-        MH_TRY((skinny<T, dec::PRO_PLAIN, dec::SK_RESID_PARTS>(sk, s)));
-      } else if (take()) MH_TRY((skinny<T, dec::PRO_PLAIN, dec::SK_RESID>(sk, st(), dp())));
-      ++slot;
-    }
+    sk = dec::SkinnyP{};
+    sk.A = bf.attn; sk.lda = inner; sk.W = w->dec_co[l]; sk.ldw = inner; sk.B = B; sk.N = d; sk.K = inner; sk.h = bf.h;
+    sk.ldh = d;
+    MH_TRY((skinny<T, dec::PRO_PLAIN, dec::SK_RESID>(sk, s)));
     // feed forward
     sk = dec::SkinnyP{};
     sk.A = bf.h; sk.lda = d; sk.ln_w = w->dec_ln3[l]; sk.eps = c->eps; sk.W = w->dec_wi[l]; sk.ldw = d; sk.B = B;
     sk.N = 2 * dff; sk.K = d; sk.out = bf.ff; sk.ldo = dff;
-    if (take()) MH_TRY((skinny<T, dec::PRO_RMSNORM, dec::SK_GEGLU>(sk, st(), dp())));
-    ++slot;
+    MH_TRY((skinny<T, dec::PRO_RMSNORM, dec::SK_GEGLU>(sk, s)));
     sk = dec::SkinnyP{};
     sk.A = bf.ff; sk.lda = dff; sk.W = w->dec_wo[l]; sk.ldw = dff; sk.B = B; sk.N = d; sk.K = dff; sk.h = bf.h;
     sk.ldh = d;
-    if (take()) MH_TRY((skinny<T, dec::PRO_PLAIN, dec::SK_RESID>(sk, st(), dp())));
-    ++slot;
+    MH_TRY((skinny<T, dec::PRO_PLAIN, dec::SK_RESID>(sk, s)));
   }
   dec::SkinnyP sk{};
   sk.A = bf.h; sk.lda = d; sk.ln_w = w->dec_final_ln; sk.eps = c->eps; sk.W = w->lm_head; sk.ldw = d; sk.B = B;
   sk.N = c->vocab_out; sk.K = d; sk.out = bf.logits; sk.ldo = c->vocab_out;
-  if (take()) MH_TRY((skinny<T, dec::PRO_RMSNORM, dec::SK_LOGITS>(sk, st(), dp())));
-  ++slot;
-  // (overlap form: the lm_head GEMV is an even slot, i.e. on `s`, and has waited for the last second-stream kernel through the
-  // progress word -- the sampler behind it in stream order sees the whole step finished)
-  static_assert((6 * 1 + 0) % 2 == 0, "six kernels per layer: the lm_head slot is even");
+  MH_TRY((skinny<T, dec::PRO_RMSNORM, dec::SK_LOGITS>(sk, s)));
   if (!with_sampler) return MH_OK;
-  if (ov && ov->which == 1) return MH_OK;          // (the odd-slot graph ends with the last wo GEMV)
   hipLaunchKernelGGL(dec_sample_kernel<T>, dim3(smp.pair > 0 ? smp.pair : B), dim3(256), 0, s, smp);
-  MH_TRY(check_launch("dec_sample_kernel"));
-  if (ov) {
-    hipLaunchKernelGGL(dec_epoch_bump_kernel, dim3(1), dim3(1), 0, s, ov->sync);
-    MH_TRY(check_launch("dec_epoch_bump_kernel"));
-    if (ov->which < 0 && hipEventRecord(ov->step_done, s) != hipSuccess) return check_launch("overlap step record");
-  }
-  return MH_OK;
+  return check_launch("dec_sample_kernel");
 }
 
 // ---- step-wise decode (beam search) ----------------------------------------------------------------------------------
@@ -1267,8 +1126,6 @@ extern "C" int64_t mh_t5_decode_workspace_bytes(const MhT5Config* c, int B) {
   t += align256((int64_t)c->n_dec_layers * B * inner * c->tgt_len * es) * 2;      // self K, V caches
   t += align256(B) + align256((int64_t)B * 4) * 2 + align256(sizeof(DecState)) * kMaxChains;   // flags / state
   t += align256((int64_t)B * c->vocab_out * 4) * 3;                               // processed scores + LookbackBias history
-  t += align256(sizeof(mh::dec::DepSync)) * kMaxChains;                           // progress words / arrival tickets (decode_overlap)
-  t += align256((int64_t)B * c->n_heads * c->d_model * 4) * 2 + align256((int64_t)B * 4);   // folded output projections: partial rows, row tickets
   t += prefill_layout(c, B, c->tgt_len - 1, nullptr, 0, nullptr);                  // batched prompt prefill
   return t;
 }
@@ -1428,11 +1285,7 @@ int pick_chains(int B) {
 
 struct ChainPool {   // extra streams + fork/join events of ONE device, created on first use under that device
   hipStream_t streams[kMaxChains] = {};
-  hipStream_t part[2] = {};      // two streams bound to disjoint halves of the CUs (option decode_cu_split)
-  int part_mode = 0;
   hipEvent_t fork = nullptr, join[kMaxChains] = {};
-  hipStream_t streams2[kMaxChains] = {};                         // option decode_overlap: a chain's second stream
-  hipEvent_t fork2[kMaxChains] = {};                             //   and its "previous step finished" event
   bool ready = false;
   int init() {
     if (ready) return MH_OK;
@@ -1443,35 +1296,6 @@ struct ChainPool {   // extra streams + fork/join events of ONE device, created 
         return check_launch("chain stream create");
     }
     ready = true;
-    return MH_OK;
-  }
-  // option decode_overlap: the chains' second streams, created on first use
-  bool ready2 = false;
-  int init_overlap(int n) {
-    if (ready2) return MH_OK;
-    for (int i = 0; i < n; ++i) {
-      if (hipStreamCreateWithFlags(&streams2[i], hipStreamNonBlocking) != hipSuccess ||
-          hipEventCreateWithFlags(&fork2[i], hipEventDisableTiming) != hipSuccess)
-        return check_launch("overlap stream create");
-    }
-    ready2 = true;
-    return MH_OK;
-  }
-  // Two decode chains on disjoint CU sets: their kernels never queue behind each other for CU slots and (mode 1) never
-  // share an L2.  mode 1: XCD-interleaved numbering (CU bit i lives on XCD i % 8) -> chain 0 = XCDs 0-3, chain 1 = XCDs
-  // 4-7; mode 2: contiguous numbering (first / second 128 bits).
-  int init_partition(int mode) {
-    if (part_mode == mode) return MH_OK;
-    for (int i = 0; i < 2; ++i)
-      if (part[i]) { (void)hipStreamDestroy(part[i]); part[i] = nullptr; }
-    part_mode = 0;
-    for (int i = 0; i < 2; ++i) {
-      uint32_t mask[8];
-      for (int w = 0; w < 8; ++w)
-        mask[w] = mode == 1 ? (i == 0 ? 0x0F0F0F0Fu : 0xF0F0F0F0u) : ((w < 4) == (i == 0) ? 0xFFFFFFFFu : 0u);
-      if (hipExtStreamCreateWithCUMask(&part[i], 8, mask) != hipSuccess) return check_launch("hipExtStreamCreateWithCUMask");
-    }
-    part_mode = mode;
     return MH_OK;
   }
 };
@@ -1663,12 +1487,7 @@ extern "C" int mh_t5_generate(const MhT5Config* c, const MhT5Weights* w, const v
   DecState* st_all = (DecState*)ar.take((int64_t)align256(sizeof(DecState)) * kMaxChains);
   float* proc = (float*)ar.take((int64_t)B * V * 4);
   float* hist_scores = (float*)ar.take((int64_t)B * V * 4 * 2);
-  char* dep_sync_all = (char*)ar.take((int64_t)align256(sizeof(dec::DepSync)) * kMaxChains);
-  all.part_self = (float*)ar.take((int64_t)B * H * d * 4);
-  all.part_cross = (float*)ar.take((int64_t)B * H * d * 4);
-  all.tickets = (int*)ar.take((int64_t)B * 4);
-  MH_REQUIRE(ar.ok() && hist_scores && dep_sync_all && all.tickets, "mh_t5_generate: arena overflow");
-  if (hipMemsetAsync(all.tickets, 0, (size_t)B * 4, s) != hipSuccess) return check_launch("ticket reset");   // (every launch leaves them at zero again)
+  MH_REQUIRE(ar.ok() && hist_scores, "mh_t5_generate: arena overflow");
   // a CFG pair spans both halves of the batch and the (batch-wide) conditional temperature reads row 0's history: one chain
   const int n_chains = (cfg || (sp->n_cond > 0 && !sp->cond_per_row)) ? 1 : pick_chains(B);
   const int rows_per = ceil_div(B, n_chains);
@@ -1683,10 +1502,8 @@ extern "C" int mh_t5_generate(const MhT5Config* c, const MhT5Weights* w, const v
   std::lock_guard<std::mutex> pool_guard(dp->mu);
   ChainPool& g_pool = dp->pool;
   MH_TRY(g_pool.init());
-  const int cu_split = (n_chains == 2) ? (int)option(OPT_DECODE_CU_SPLIT) : 0;
-  if (cu_split == 1 || cu_split == 2) MH_TRY(g_pool.init_partition(cu_split));
   hipStream_t chain_stream[kMaxChains];
-  for (int i = 0; i < kMaxChains; ++i) chain_stream[i] = (g_pool.part_mode == cu_split && cu_split && i < 2) ? g_pool.part[i] : g_pool.streams[i];
+  for (int i = 0; i < kMaxChains; ++i) chain_stream[i] = g_pool.streams[i];
 
   // tokens[:, :P] = prompt; the remainder is produced by the sampler
   if (hipMemcpy2DAsync(tokens, (size_t)sp->max_length * 4, prompt, (size_t)P * 4, (size_t)P * 4, B,
@@ -1714,11 +1531,6 @@ extern "C" int mh_t5_generate(const MhT5Config* c, const MhT5Weights* w, const v
   hipGraphExec_t execs[kMaxChains] = {};
   StepGraphEntry* cached[kMaxChains] = {};     // chains whose graph lives in the cross-call cache (not destroyed below)
   DecState* states[kMaxChains] = {};
-  dec::DepSync* syncs[kMaxChains] = {};
-  std::function<int()> eager_step[kMaxChains];
-  // (at most two chains: 2 x 2 branches = the four hardware queues a process gets by default)
-  const bool overlap = n_chains <= 2 && overlap_possible(c, rows_per, sp->cross_kv_fp8 != nullptr, cfg);
-  if (overlap) MH_TRY(g_pool.init_overlap(2));
   int used = 0, rc = MH_OK;
   for (int ci = 0; ci < n_chains && rc == MH_OK; ++ci) {
     const int b0 = ci * rows_per;
@@ -1736,9 +1548,6 @@ extern "C" int mh_t5_generate(const MhT5Config* c, const MhT5Weights* w, const v
     bf.self_k = (char*)all.self_k + (long)b0 * inner * c->tgt_len * es;
     bf.self_v = (char*)all.self_v + (long)b0 * inner * c->tgt_len * es;
     bf.finished = all.finished + b0;
-    bf.part_self = all.part_self + (long)b0 * H * d;
-    bf.part_cross = all.part_cross + (long)b0 * H * d;
-    bf.tickets = all.tickets + b0;
     bf.st = (DecState*)((char*)st_all + (long)ci * align256(sizeof(DecState)));
     states[ci] = bf.st;
     const void* ckv = (const char*)cross_kv + (long)b0 * H * c->src_len * 64 * es;
@@ -1755,28 +1564,12 @@ extern "C" int mh_t5_generate(const MhT5Config* c, const MhT5Weights* w, const v
     else hipLaunchKernelGGL(dec_init_kernel<float>, dim3(Bc), dim3(256), 0, cs, smp, Bc, start_pos);
     rc = check_launch("dec_init_kernel");
     if (rc != MH_OK) break;
-    syncs[ci] = (dec::DepSync*)(dep_sync_all + (long)ci * align256(sizeof(dec::DepSync)));
-    if (overlap && hipMemsetAsync(syncs[ci], 0, sizeof(dec::DepSync), cs) != hipSuccess) { rc = check_launch("overlap state reset"); break; }
     const void* kv8 = nullptr;
     const float* kv8_scales = nullptr;
     if (sp->cross_kv_fp8) {   // packed e4m3 copy: data, then (256-byte aligned) the scales
       const int64_t data_bytes = (int64_t)c->n_dec_layers * 2 * kvB * H * c->src_len * 64;
       kv8 = (const char*)sp->cross_kv_fp8 + (long)b0 * H * c->src_len * 64;
       kv8_scales = reinterpret_cast<const float*>((const char*)sp->cross_kv_fp8 + align256(data_bytes)) + (long)b0 * H;
-    }
-    if (overlap) {
-      OverlapCtx ov{g_pool.streams2[ci], g_pool.fork2[ci], syncs[ci], -1};
-      if (hipEventRecord(ov.step_done, cs) != hipSuccess) { rc = check_launch("overlap first record"); break; }   // (behind dec_init + the state reset)
-      // eager two-stream form: nothing is captured; the chain's launcher thread enqueues every step kernel by kernel.
-      // (Two LINEAR graphs -- even slots on the chain stream, odd slots on a CU-masked stream of its own -- were built and
-      // measured as well: 363 ms of decode against 334 ms eager and 262 ms for the plain step, and they still lost dependences
-      // in one test case; removed.)
-      eager_step[ci] = [=]() -> int {
-        return bf16 ? enqueue_step<bf16_t>(c, w, ckv, Bc, B, kvB, pm, P, bf, smp, cs, kv8, kv8_scales, true, 0, &ov)
-                    : enqueue_step<float>(c, w, ckv, Bc, B, kvB, pm, P, bf, smp, cs, kv8, kv8_scales, true, 0, &ov);
-      };
-      ++used;
-      continue;
     }
     // one step of this chain (every kernel reads the position from device memory) as a graph for replay: an earlier call's, if
     // its description is byte for byte this one's, else captured now
@@ -1831,8 +1624,7 @@ extern "C" int mh_t5_generate(const MhT5Config* c, const MhT5Weights* w, const v
     while (step < total_steps) {
       const int burst = total_steps - step < poll_every ? total_steps - step : poll_every;
       for (int i = 0; i < burst; ++i) {
-        if (eager_step[ci]) { if (eager_step[ci]() != MH_OK) return MH_ERR_LAUNCH; }
-        else if (hipGraphLaunch(execs[ci], chain_stream[ci]) != hipSuccess) return MH_ERR_LAUNCH;
+        if (hipGraphLaunch(execs[ci], chain_stream[ci]) != hipSuccess) return MH_ERR_LAUNCH;
       }
       step += burst;
       if (step < total_steps && !forced) {
@@ -1858,8 +1650,7 @@ extern "C" int mh_t5_generate(const MhT5Config* c, const MhT5Weights* w, const v
         for (int i = 0; i < burst; ++i)
           for (int ci = 0; ci < used; ++ci) {
             if (!alive[ci] || rcs[ci] != MH_OK) continue;
-            if (eager_step[ci]) { if (eager_step[ci]() != MH_OK) rcs[ci] = MH_ERR_LAUNCH; }
-            else if (hipGraphLaunch(execs[ci], chain_stream[ci]) != hipSuccess) rcs[ci] = MH_ERR_LAUNCH;
+            if (hipGraphLaunch(execs[ci], chain_stream[ci]) != hipSuccess) rcs[ci] = MH_ERR_LAUNCH;
           }
         step += burst;
         bool any = false;
@@ -1887,10 +1678,6 @@ extern "C" int mh_t5_generate(const MhT5Config* c, const MhT5Weights* w, const v
   }
   // join the chains back into the caller's stream
   for (int ci = 0; ci < used; ++ci) {
-    if (overlap) {   // the second stream's last kernel finished before the last lm_head did; order it in front of the join all the same
-      (void)hipEventRecord(g_pool.join[ci], g_pool.streams2[ci]);
-      (void)hipStreamWaitEvent(chain_stream[ci], g_pool.join[ci], 0);
-    }
     (void)hipEventRecord(g_pool.join[ci], chain_stream[ci]);
     (void)hipStreamWaitEvent(s, g_pool.join[ci], 0);
   }
@@ -1899,13 +1686,6 @@ extern "C" int mh_t5_generate(const MhT5Config* c, const MhT5Weights* w, const v
     rc = check_launch("dec_finalize_kernel");
   }
   (void)hipStreamSynchronize(s);   // the graph objects must outlive their launches
-  if (overlap && rc == MH_OK) {    // a kernel that gave up waiting for its predecessor produced garbage: say so
-    for (int ci = 0; ci < used; ++ci) {
-      unsigned lost = 0;
-      if (hipMemcpy(&lost, &syncs[ci]->err, 4, hipMemcpyDeviceToHost) != hipSuccess) { rc = check_launch("overlap error word"); break; }
-      if (lost) { set_error("mh_t5_generate: %u dependences were lost on chain %d under decode_overlap (set the option to 0)", lost, ci); rc = MH_ERR_STATE; break; }
-    }
-  }
   for (int ci = 0; ci < kMaxChains; ++ci) {
     if (cached[ci]) { step_graph_release(cached[ci]); continue; }
     if (execs[ci]) (void)hipGraphExecDestroy(execs[ci]);
