@@ -47,7 +47,7 @@ SRC_FRAMES, N_SAMPLES = 1251, 160000
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks (one per GPU); default: WORLD_SIZE under a launcher, else 1")
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size", default="base", choices=["tiny", "small", "base", "large"])
@@ -139,7 +139,12 @@ def cpu_baseline(size: str, vocab, seconds_budget: float = 25.0):
     t0 = time.perf_counter()
     enc = o.encode_audio(audio)
     t_enc = time.perf_counter() - t0
-    new = 128                                   # (>= 128 tokens per chunk, so that the decode rate is not a 32-step estimate)
+    # 128 tokens per chunk (the decode rate must not be a 32-step estimate) unless the host is so slow that the
+    # sample would not fit `seconds_budget`: 8 probe tokens price a step, then as many as the budget allows (>= 32)
+    t1 = time.perf_counter()
+    o.generate(enc, prompt, None, [], 1 + 8, ts0, ts1, [1])
+    per_step = (time.perf_counter() - t1) / 8
+    new = int(max(32, min(128, (seconds_budget - t_enc) / max(per_step, 1e-6))))
     t1 = time.perf_counter()
     ids = o.generate(enc, prompt, None, [], 1 + new, ts0, ts1, [1])
     t_dec = time.perf_counter() - t1
@@ -223,6 +228,8 @@ def dit_flops_per_step(depth: int, D: int, N: int, T: int, band: int = 0) -> flo
 
 def main():
     args = parse()
+    if args.gpus is None:                          # not given: follow the launcher (`torchrun --nproc-per-node=N bench.py` runs N ranks)
+        args.gpus = int(os.environ.get("WORLD_SIZE", "1"))
     spawn_ranks_if_needed(args)                    # `--gpus N` without a launcher: re-execute under torch.distributed.run
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -686,11 +693,25 @@ def main():
             spec = importlib.util.spec_from_file_location("long_song_bench", os.path.join(ROOT, "tools", "long_song_bench.py"))
             lsb = importlib.util.module_from_spec(spec)
             spec.loader.exec_module(lsb)
+            large_runs = lsb.run("large", songs=32, windows=18, fp8_kv=(False, True), device=str(dev), collect_tokens=True)
+            large_bf16_tokens = large_runs[0].pop("_tokens")
+            large_runs[1].pop("_tokens", None)
             aux["config5_long_songs"] = {
-                "large": lsb.run("large", songs=32, windows=18, fp8_kv=(False, True), device=str(dev)),
+                "large": large_runs,
                 "base": lsb.run("base", songs=32, windows=18, fp8_kv=(False,), device=str(dev)),
                 "note": "32 songs x 18 windows (3 min each): every window encoded up front, its cross K/V resident in HBM, wave w "
                         "decodes window w of all songs; window w's prompt carries the last 32 tokens of window w-1"}
+            # configs[4] as ONE workload (tools/config5_full.py): the same songs with MX-fp8 encoder operands + e4m3 cross K/V, the
+            # agreement of its tokens with the bf16 run above, then DiT-B (MX-fp8 projections) over every window + its px error vs fp32
+            try:
+                spec5 = importlib.util.spec_from_file_location("config5_full", os.path.join(ROOT, "tools", "config5_full.py"))
+                c5 = importlib.util.module_from_spec(spec5)
+                spec5.loader.exec_module(c5)
+                torch.cuda.empty_cache()
+                aux["config5_full"] = c5.run(songs=32, windows=18, device=str(dev), bf16_tokens=large_bf16_tokens, bf16_line=dict(large_runs[0]))
+            except Exception as e:
+                aux.setdefault("errors", []).append(f"config5_full: {e!r}")
+                print(f"config 5 full pass failed: {e!r}", file=sys.stderr)
         except Exception as e:
             aux.setdefault("errors", []).append(f"config5_long_songs: {e!r}")
             print(f"config 5 long-song pass failed: {e!r}", file=sys.stderr)

@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmP p) {
 
   // fused LayerNorm + adaLN modulate on the A operand (fp32 activations of the DiT): mean / rstd of this tile's rows
   // from the producer's per-strip sums, kept in LDS behind the two tile stages
-  constexpr bool kLnCapable = std::is_same<T, float>::value;
+  constexpr bool kLnCapable = std::is_same<T, float>::value && !S3;   // (the bf16 x 3 form takes its LayerNorm from the stand-alone pass: refused in gemm())
   const bool ln = kLnCapable && p.ln_stats != nullptr;   // block-uniform
   float* lnst = reinterpret_cast<float*>(smem + 2 * kBufBytes);
   uint4 rsc[D][kLnCapable ? A_CHUNKS : 1], rsh[D][kLnCapable ? A_CHUNKS : 1];
@@ -2034,6 +2034,11 @@ int gemm(const MhGemm& g, hipStream_t s, bool ascending_k) {
   if (g.ln_stats)
     MH_REQUIRE(g.dtype == MH_F32 && g.ln_shift && g.ln_scale && g.ln_strips > 0 && g.rows_per_batch > 0 && g.ln_ld >= g.K,
                "mh_gemm: the fused LayerNorm-modulate prologue is fp32 only and needs shift / scale / strips / rows_per_batch");
+  // LayerNorm fused into the bf16 x 3 kernel's A load was an option of the batched DiT until round 5 (measured slower than the
+  // stand-alone pass: 303.7 vs 292.3 ms) with a history: an early build returned non-repeatable rows on grids of > 1000
+  // workgroups, the cause was never isolated in the ISA, and a later unrelated edit of this file brought the failure back.  A path
+  // nothing uses and nobody can vouch for is refused, not shipped.
+  MH_REQUIRE(!(g.ln_stats && g.w_split3), "mh_gemm: the fused LayerNorm-modulate prologue is not available with w_split3 (run mh_ln_modulate first)");
   if (g.dtype == MH_BF16) return dispatch_epi<bf16_t>(p, g.epilogue, s);
   return dispatch_epi<float>(p, g.epilogue, s);
 }

@@ -156,7 +156,9 @@ int quantize_mx8(const void* x, int ldx, int rows, int K, int in_dtype, uint8_t*
   MH_REQUIRE(x && rows > 0, "mh_quantize_mx8: bad arguments");
   MH_TRY_RC(check_mx8_out(K, q, ldq, scales, "mh_quantize_mx8"));
   MH_REQUIRE(in_dtype == MH_F32 || in_dtype == MH_BF16, "mh_quantize_mx8: in_dtype must be MH_F32 or MH_BF16");
-  MH_REQUIRE(ldx >= K && ldx % 4 == 0 && ((uintptr_t)x % 8) == 0, "mh_quantize_mx8: ldx %% 4 == 0, aligned rows");
+  // the kernel reads 16-byte vectors of fp32 (dwordx4) and 8-byte vectors of bf16: the rows must be aligned for THOSE loads
+  MH_REQUIRE(ldx >= K && ldx % 4 == 0 && ((uintptr_t)x % (in_dtype == MH_F32 ? 16 : 8)) == 0,
+             "mh_quantize_mx8: ldx %% 4 == 0 and x aligned to 16 bytes (fp32) / 8 bytes (bf16)");
   const int ks_b = mx8_scale_row_bytes(K);
   // bytes of the last scale group that no K step owns must be defined (the GEMM loads whole dwords): zero the array first
   // when K is not a multiple of 512
@@ -172,6 +174,7 @@ int rmsnorm_mx8(const float* x, int ldx, const float* w, int rows, int d, float 
   MH_REQUIRE(x && w && rows > 0, "mh_rmsnorm_mx8: bad arguments");
   MH_TRY_RC(check_mx8_out(d, q, ldq, scales, "mh_rmsnorm_mx8"));
   MH_REQUIRE(ldx % 4 == 0 && d <= 1024, "mh_rmsnorm_mx8: ldx %% 4 == 0 and d <= 1024 (the row lives in registers)");
+  MH_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0, "mh_rmsnorm_mx8: x and w must be 16-byte aligned (float4 loads)");
   MH_REQUIRE(round_dtype == MH_F32 || round_dtype == MH_BF16, "mh_rmsnorm_mx8: round_dtype must be MH_F32 or MH_BF16");
   const int ks_b = mx8_scale_row_bytes(d);
   if (d % 512 != 0 && hipMemsetAsync(scales, 0, (size_t)rows * ks_b, s) != hipSuccess) return check_launch("mh_rmsnorm_mx8 memset");
@@ -189,6 +192,8 @@ int ln_modulate_mx8(const float* x, int ldx, const float* shift, const float* sc
   MH_REQUIRE(x && shift && scale && rows > 0 && rows_per_batch > 0, "ln_modulate_mx8: bad arguments");
   MH_TRY_RC(check_mx8_out(d, q, ldq, scales, "ln_modulate_mx8"));
   MH_REQUIRE(ldx % 4 == 0 && mod_ld % 4 == 0 && d <= 1536, "ln_modulate_mx8: alignment / d <= 1536");
+  MH_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)shift % 16) == 0 && ((uintptr_t)scale % 16) == 0,
+             "ln_modulate_mx8: x, shift and scale must be 16-byte aligned (float4 loads)");
   const int ks_b = mx8_scale_row_bytes(d);
   if (d % 512 != 0 && hipMemsetAsync(scales, 0, (size_t)rows * ks_b, s) != hipSuccess) return check_launch("ln_modulate_mx8 memset");
   dim3 grid(ceil_div(rows, 4)), block(256);

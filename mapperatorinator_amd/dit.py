@@ -123,11 +123,21 @@ class DiTHIP:
                 w.fc2_wm[l], w.fc2_wms[l] = tm(sd[b + "mlp.fc2.weight"])
         w.fin_ada_w, w.fin_ada_b = t(sd["final_layer.adaLN_modulation.1.weight"]), t(sd["final_layer.adaLN_modulation.1.bias"])
         w.fin_w, w.fin_b = t(sd["final_layer.linear.weight"]), t(sd["final_layer.linear.bias"])
-        self.options = _lib.OptionSet(options)          # this denoiser's own overrides of the library's tuning options
-        cfg.options = self.options.handle
         self.cfg, self.w = cfg, w
+        self.options = options                          # this denoiser's own overrides of the library's tuning options (property below)
         self.stream = self.new_stream()
         self._ws = None
+
+    # replacing the set rewrites cfg.options: the config never points at a destroyed set
+    @property
+    def options(self) -> "_lib.OptionSet":
+        return self._options
+
+    @options.setter
+    def options(self, value):
+        new = value if isinstance(value, _lib.OptionSet) else _lib.OptionSet(value)
+        self.cfg.options = new.handle
+        self._options = new
 
     @classmethod
     def from_preset(cls, name: str, state_dict: dict, **kw):

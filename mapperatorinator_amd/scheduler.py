@@ -202,6 +202,8 @@ class SequentialWindowScheduler:
             p_all = torch.cat([neg, prompts], 0) if cfg else prompts
             m_all = None if masks is None else (torch.cat([masks, masks], 0) if cfg else masks)
             # generate_kwargs["cross_kv_fp8"]: the token steps stream an e4m3 copy of this wave's cross K / V
+            if gk.get("cross_kv_fp8") and nb > 1:
+                raise NotImplementedError("cross_kv_fp8 with beam search: the step-wise beam entry streams the bf16 cross K / V")
             kv8 = eng.cross_kv_fp8(kv) if gk.get("cross_kv_fp8") else None
             if nb == 1:
                 tokens, n_out, _ = eng.decode(kv, p_all.to(dev, torch.int32).contiguous(),

@@ -245,7 +245,18 @@ class T5Engine:
 
     def _own_options(self, options: Optional[dict]):
         self.options = _lib.OptionSet(options)
-        self.packed.cfg.options = self.options.handle
+
+    # `engine.options = OptionSet(...)` (or a dict) REPLACES the set: the packed config must follow, or it would keep the handle
+    # of a set that the old object's __del__ has destroyed
+    @property
+    def options(self) -> "_lib.OptionSet":
+        return self._options
+
+    @options.setter
+    def options(self, value):
+        new = value if isinstance(value, _lib.OptionSet) else _lib.OptionSet(value)
+        self.packed.cfg.options = new.handle      # first the config, then drop the old set
+        self._options = new
 
     # ---- buffers ---------------------------------------------------------------------------------
     def _workspace(self, kind: str, nbytes: int) -> torch.Tensor:

@@ -139,45 +139,21 @@ def test_gemm_lds_dma_tile_equals_register_staged_tile(shape):
     assert (outs[1][0].double() - ref).abs().max().item() < 2e-5 * math.sqrt(K) * 4 + 1e-4
 
 
-def test_gemm_bf16x3_with_fused_layernorm_is_repeatable():
-    """The bf16 x 3 GEMM with LayerNorm + modulate fused into its A load on a grid of > 1000 workgroups -- the combination
-    that once returned non-repeatable rows (6, 7 mod 8; tools/s3_ln_probe.py): six runs must be bit-identical, and with
-    an identity modulation (mean 0 / variance 1 statistics, zero shift / scale) bit-identical to the plain bf16 x 3 GEMM."""
+def test_gemm_bf16x3_refuses_the_fused_layernorm_prologue():
+    """LayerNorm + modulate fused into the bf16 x 3 GEMM's A load (an option of the batched DiT until round 5, measured slower
+    than the stand-alone pass) once returned non-repeatable rows and did so again after an unrelated edit; the cause was never
+    isolated.  The combination is refused by mh_gemm -- loudly -- instead of shipped."""
     L, lib = _lib()
-    g = torch.Generator().manual_seed(1)
-    M, N, K, rpb = 2048, 2304, 768, 128
-    A = torch.randn(M, K, generator=g); W = torch.randn(N, K, generator=g) * 0.1; bias = torch.randn(N, generator=g)
-    dev = "cuda"
-    Ad, Wd, bd = A.to(dev).contiguous(), split3_pack(W).to(dev).contiguous(), bias.to(dev)
-
-    def run(st, shift, scale, ln=True):
-        std, sh, sc = st.to(dev).contiguous(), shift.to(dev).contiguous(), scale.to(dev).contiguous()
-        out = torch.zeros((M, N), device=dev)
-        gm = L.MhGemm()
-        gm.A, gm.lda, gm.W, gm.ldw, gm.C, gm.ldc = Ad.data_ptr(), K, Wd.data_ptr(), K, out.data_ptr(), N
-        gm.M, gm.N, gm.K, gm.dtype, gm.epilogue, gm.bias, gm.w_split3 = M, N, K, L.MH_F32, L.EPI_STORE_F32, bd.data_ptr(), 1
-        if ln:
-            gm.ln_stats, gm.ln_strips, gm.ln_shift, gm.ln_scale, gm.ln_ld, gm.ln_eps, gm.rows_per_batch = (
-                std.data_ptr(), K // 16, sh.data_ptr(), sc.data_ptr(), K, 0.0, rpb)
-        L.check(lib.mh_gemm(C.byref(gm), _stream()), "mh_gemm")
-        torch.cuda.synchronize()
-        return out.cpu()
-
-    real_st = torch.stack([A.reshape(M, K // 16, 16).sum(-1), (A * A).reshape(M, K // 16, 16).sum(-1)], -1).permute(1, 0, 2).contiguous()
-    ident_st = torch.zeros_like(real_st)
-    ident_st[..., 1] = 16.0                              # sum 0, sum of squares K: mean 0, variance 1 (eps 0)
-    shift = torch.randn(M // rpb, K, generator=g) * 0.1
-    scale = torch.randn(M // rpb, K, generator=g) * 0.1
-    zero = torch.zeros_like(shift)
-    plain = run(real_st, zero, zero, ln=False)
-    ident = [run(ident_st, zero, zero) for _ in range(6)]
-    assert all(torch.equal(plain, o) for o in ident)
-    real = [run(real_st, shift, scale) for _ in range(6)]
-    assert all(torch.equal(real[0], o) for o in real[1:])
-    mu = A.mean(-1, keepdim=True); var = A.var(-1, unbiased=False, keepdim=True)
-    xn = (A - mu) * torch.rsqrt(var) * (1 + scale.repeat_interleave(rpb, 0)) + shift.repeat_interleave(rpb, 0)
-    ref = xn.double() @ W.double().t() + bias.double()
-    assert (real[0].double() - ref).abs().max().item() < 5e-3
+    M, N, K = 256, 128, 64
+    A = torch.zeros(M, K, device="cuda"); W = torch.zeros(N, 2 * K, device="cuda"); out = torch.zeros(M, N, device="cuda")
+    st = torch.zeros(K // 16, M, 2, device="cuda"); mod = torch.zeros(2, K, device="cuda")
+    gm = L.MhGemm()
+    gm.A, gm.lda, gm.W, gm.ldw, gm.C, gm.ldc = A.data_ptr(), K, W.data_ptr(), K, out.data_ptr(), N
+    gm.M, gm.N, gm.K, gm.dtype, gm.epilogue, gm.w_split3 = M, N, K, L.MH_F32, L.EPI_STORE_F32, 1
+    gm.ln_stats, gm.ln_strips, gm.ln_shift, gm.ln_scale, gm.ln_ld, gm.ln_eps, gm.rows_per_batch = (
+        st.data_ptr(), K // 16, mod.data_ptr(), mod.data_ptr(), K, 0.0, 128)
+    assert lib.mh_gemm(C.byref(gm), _stream()) != 0
+    assert b"w_split3" in lib.mh_last_error()
 
 
 def test_gemm_bf16x3_split_path():

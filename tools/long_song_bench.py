@@ -23,10 +23,13 @@ from mapperatorinator_amd.t5_engine import T5_PRESETS  # noqa: E402
 from mapperatorinator_amd.testing import random_t5_state_dict, synthetic_audio_varied  # noqa: E402
 
 
-def run(size="large", songs=32, windows=18, new_tokens=384, context_tokens=32, fp8_kv=(False,), device="cuda:0", model=None):
+def run(size="large", songs=32, windows=18, new_tokens=384, context_tokens=32, fp8_kv=(False,), device="cuda:0", model=None,
+        enc_operand_dtype=None, collect_tokens=False):
     """One dict per entry of `fp8_kv` (the model is built once).  Each carries `roofline_step`: SURVEY 8d bytes of one token
     step (decoder weights + lm_head once, + per song the cross K/V of every layer and the self K/V at the mean position)
-    over the measured seconds per token step of the WHOLE run (encode + prompt building + decode), vs the HBM peak."""
+    over the measured seconds per token step of the WHOLE run (encode + prompt building + decode), vs the HBM peak.
+    enc_operand_dtype="mx8": the encoder blocks and the cross-K/V projection on MX-fp8 operands (BASELINE configs[4]).
+    collect_tokens: each dict also carries "_tokens"[song][window] = the window's generated ids (a python list; drop before printing)."""
     dev = torch.device(device)
     src, n_samples = 1251, 160000
     tok = Tokenizer.benchmark_vocab(src_seq_len=src)
@@ -35,12 +38,13 @@ def run(size="large", songs=32, windows=18, new_tokens=384, context_tokens=32, f
     if model is None:
         model = MapperatorinatorHIP(random_t5_state_dict(dims, tok.vocab_size_in, tok.vocab_size_out, seed=0, lm_head_gain=6.0), dims,
                                     vocab_size_in=tok.vocab_size_in, vocab_size_out=tok.vocab_size_out, src_seq_len=src,
-                                    tgt_seq_len=tgt, dtype=torch.bfloat16, device=dev)
+                                    tgt_seq_len=tgt, dtype=torch.bfloat16, device=dev, enc_operand_dtype=enc_operand_dtype)
     audio = synthetic_audio_varied(songs * windows, n_samples, seed=3).view(songs, windows, n_samples)
     out = []
     for f8 in fp8_kv:
         gk = dict(max_length=tgt, do_sample=False, cross_kv_fp8=bool(f8))
         last = [None] * songs
+        toks = [[None] * windows for _ in range(songs)]
         n_tok = [0]
         cols = [0]
 
@@ -53,6 +57,8 @@ def run(size="large", songs=32, windows=18, new_tokens=384, context_tokens=32, f
 
             def on_result(w, row, st):
                 last[i] = row[1 + context_tokens:]
+                if collect_tokens:
+                    toks[i][w] = [int(t) for t in last[i]]
                 n_tok[0] += int(row.numel() - 1 - context_tokens)
                 if i == 0:
                     cols[0] += int(row.numel() - 1 - context_tokens)       # token steps the wave of window w ran
@@ -77,7 +83,8 @@ def run(size="large", songs=32, windows=18, new_tokens=384, context_tokens=32, f
         step_bytes = weights + min(64, songs) * (cross + self_kv)
         steps = max(1, cols[0]) * max(1, -(-songs // 64))
         us_per_step = dt / steps * 1e6
-        out.append({"workload": f"osuT5-{size} bf16, {songs} songs x {windows} windows of 10 s, {new_tokens} new "
+        out.append({"workload": f"osuT5-{size} bf16{' (encoder + cross-K/V projection on MX-fp8 operands)' if enc_operand_dtype else ''}, "
+                                f"{songs} songs x {windows} windows of 10 s, {new_tokens} new "
                                 f"tokens per window, {context_tokens} context tokens, cross K/V {'e4m3' if f8 else 'bf16'}",
                     "event_tokens_per_s": round(n_tok[0] / dt, 1), "seconds": round(dt, 3), "tokens": n_tok[0],
                     "song_seconds_per_s": round(songs * windows * 10.0 / dt, 1),
@@ -88,6 +95,8 @@ def run(size="large", songs=32, windows=18, new_tokens=384, context_tokens=32, f
                                       "frac": round(step_bytes / (us_per_step * 1e-6) / 1e9 / 8000.0, 4),
                                       "how": "SURVEY 8d bytes of one token step of one wave / (whole-run seconds / token steps of "
                                              "song 0): encode, prompt building and D2H are inside the time"}})
+        if collect_tokens:
+            out[-1]["_tokens"] = toks
     return out
 
 
