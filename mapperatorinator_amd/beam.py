@@ -16,8 +16,19 @@ vectorised `GenerationMixin._beam_search` -- transformers >= 4.50; line referenc
 The device side is the step-wise entry of the library (`mh_t5_step`: one decoder position for all (chunk, beam) rows, raw
 logits out; `mh_t5_reorder_cache`); the bookkeeping above runs as torch ops on the same GPU.  The logits processors of
 server.py:106-134 are applied here with torch ops (the in-kernel sampler of the greedy / sampling path selects per row and
-cannot rank across beams): MonotonicTimeShift, TimeshiftBias, (Conditional)Temperature and the lookback mask; guidance
-(cfg_scale > 1) and the types_first lookback renormalisation are refused in beam mode.
+cannot rank across beams): classifier-free guidance, MonotonicTimeShift, TimeshiftBias, (Conditional)Temperature and the lookback
+mask; the types_first lookback renormalisation is refused in beam mode.
+
+Guidance under beams (round 5; the timing pass sets beams, `super_timing_generator.py:28`, and `processor.py:709` halves its batch
+for exactly this case) follows what the reference + HF do, quirk included:
+  * `prepare_inputs_for_generation` (modeling_mapperatorinator.py:243-254) doubles the (chunk, beam) rows every step: the first
+    half carries the negative prompt over the first columns, the second half is the prompt's own rows;
+  * HF's `ClassifierFreeGuidanceLogitsProcessor` runs FIRST in the list, on log_softmax(logits) of all 2R rows, and treats the
+    first half as the conditional one: guided = second + (first - second) * scale, R rows; the other processors see the prompt rows'
+    sequences;
+  * `MapperatorinatorCache.reorder_cache` (inference/cache_utils.py:16-20) gathers the doubled cache with `beam_idx.repeat(2)` --
+    indices into the FIRST half for both halves: from the first reorder on, the prompt half's self-attention cache holds copies of the
+    negative half's rows.  Reproduced verbatim (golden `t5_tiny_beam.npz`, runs `b2g` / `b3g`).
 """
 from __future__ import annotations
 
@@ -39,8 +50,6 @@ class BeamProcessors:
     """The reference's processor list (server.py:106-134) on (rows, V) LOG-PROBABILITIES, from an MhSampling struct."""
 
     def __init__(self, sp, device):
-        if sp.cfg_scale > 1.0:
-            raise NotImplementedError("beam search under classifier-free guidance is not on the HIP path")
         if sp.lookback_types_first and sp.lookback_mask_end > sp.ts_start:
             raise NotImplementedError("beam search with the types_first lookback renormalisation is not on the HIP path")
         self.sp = sp
@@ -89,14 +98,27 @@ class BeamProcessors:
 def beam_search(engine, cross_kv: torch.Tensor, prompt: torch.Tensor, prompt_mask: Optional[torch.Tensor], eos_ids, sp,
                 num_beams: int, length_penalty: float = 1.0, early_stopping=False) -> torch.Tensor:
     """cross_kv: the G chunks' cross K/V (engine.cross_kv); prompt int (G, P) left-padded, prompt_mask (G, P) or None.
+    Under guidance (sp.cfg_scale > 1) `prompt` / `prompt_mask` carry 2G rows, [negative-prompt rows | prompt rows] (what
+    T5Engine.generate and the scheduler build), and cross_kv still has G rows.
     Returns int64 (G, P + new) on the engine's device: the best hypothesis per chunk, shorter ones filled the way HF does
     (`pad_token_id or eos_token_id[0]`: with pad id 0 that is the FIRST EOS id)."""
     dev, lib, p = engine.device, engine.lib, engine.packed
+    cfg = sp.cfg_scale > 1.0
+    neg_prompt = None
+    if cfg:
+        if prompt.shape[0] % 2:
+            raise ValueError("guidance: the prompt batch must be [negative rows | prompt rows]")
+        half = prompt.shape[0] // 2
+        neg_prompt, prompt = prompt[:half], prompt[half:]
+        neg_mask = None if prompt_mask is None else prompt_mask[:half]
+        prompt_mask = None if prompt_mask is None else prompt_mask[half:]
+        cross_kv = torch.cat([cross_kv, cross_kv], dim=2)          # [layer][k|v][chunk][H][L][64]: the negative rows read their chunk's K / V
     G, P = prompt.shape
     nb = int(num_beams)
-    R = G * nb
-    if R > 64:
-        raise ValueError(f"{G} chunks x {nb} beams exceed the engine's 64-row decode batch")
+    R = G * nb                                                     # rows the beam bookkeeping ranks
+    RE = 2 * R if cfg else R                                       # rows the engine decodes
+    if RE > 64:
+        raise ValueError(f"{G} chunks x {nb} beams{' x 2 (guidance)' if cfg else ''} exceed the engine's 64-row decode batch")
     V = p.vocab_out
     max_length = int(sp.max_length)
     if not (1 <= P < max_length <= p.tgt_len):
@@ -112,6 +134,11 @@ def beam_search(engine, cross_kv: torch.Tensor, prompt: torch.Tensor, prompt_mas
     fill = int(sp.pad_id) or (eos_list[0] if eos_list else -1)
     ids0 = prompt.to(dev, torch.int64).repeat_interleave(nb, 0)                       # (R, P): rows (chunk, beam)
     mask = None if prompt_mask is None else prompt_mask.to(dev).to(torch.uint8).repeat_interleave(nb, 0).contiguous()
+    ids0e = ids0                                                                      # what the engine is fed over the prompt columns
+    if cfg:
+        ids0e = torch.cat([neg_prompt.to(dev, torch.int64).repeat_interleave(nb, 0), ids0], 0)
+        if mask is not None:
+            mask = torch.cat([neg_mask.to(dev).to(torch.uint8).repeat_interleave(nb, 0), mask], 0).contiguous()
     running = torch.full((G, nb, max_length), fill, dtype=torch.int64, device=dev)
     running[:, :, :P] = ids0.view(G, nb, P)
     sequences = running.clone()
@@ -124,28 +151,35 @@ def beam_search(engine, cross_kv: torch.Tensor, prompt: torch.Tensor, prompt_mas
     running_bidx = torch.full((G, nb, n_new), -1, dtype=torch.int32, device=dev)
     beam_bidx = running_bidx.clone()
 
-    need = lib.mh_t5_decode_workspace_bytes(C.byref(p.cfg), R)
+    need = lib.mh_t5_decode_workspace_bytes(C.byref(p.cfg), RE)
     ws = torch.empty(int(need), dtype=torch.uint8, device=dev)                        # owned by this call: holds the caches
-    scratch = torch.empty(int(lib.mh_t5_reorder_cache_scratch_bytes(C.byref(p.cfg), R, max_length)), dtype=torch.uint8, device=dev)
-    logits = torch.empty((R, V), dtype=torch.float32, device=dev)
+    scratch = torch.empty(int(lib.mh_t5_reorder_cache_scratch_bytes(C.byref(p.cfg), RE, max_length)), dtype=torch.uint8, device=dev)
+    logits = torch.empty((RE, V), dtype=torch.float32, device=dev)
     stream = engine._s()
+    scale = float(sp.cfg_scale)
 
     def step(tokens: torch.Tensor, pos: int):
         t32 = tokens.to(torch.int32).contiguous()
-        rc = lib.mh_t5_step(C.byref(p.cfg), C.byref(p.w), cross_kv.data_ptr(), R, nb, t32.data_ptr(), pos, _lib.ptr(mask), P,
+        rc = lib.mh_t5_step(C.byref(p.cfg), C.byref(p.w), cross_kv.data_ptr(), RE, nb, t32.data_ptr(), pos, _lib.ptr(mask), P,
                             logits.data_ptr(), ws.data_ptr(), ws.numel(), stream)
         _lib.check(rc, "mh_t5_step")
 
     engine._enter()
     with torch.cuda.stream(engine.stream):
         for pos in range(P - 1):                                                      # the prompt, token by token
-            step(ids0[:, pos], pos)
+            step(ids0e[:, pos], pos)
         cur_len = P
         first = True
         while True:
             flat = running[:, :, :cur_len].reshape(R, cur_len)
-            step(flat[:, cur_len - 1], cur_len - 1)
-            log_probs = procs(flat, torch.log_softmax(logits, dim=-1))
+            last = flat[:, cur_len - 1]
+            if cfg:      # both halves are fed the beam's last token; over the prompt columns the first half has the negative prompt's
+                last = torch.cat([last if cur_len > P else ids0e[:R, P - 1], last], 0)
+            step(last, cur_len - 1)
+            lsm = torch.log_softmax(logits, dim=-1)
+            if cfg:      # HF's processor, first in the list: `cond, uncond = scores.split(R); uncond + (cond - uncond) * scale`
+                lsm = lsm[R:] + (lsm[:R] - lsm[R:]) * scale
+            log_probs = procs(flat, lsm)
             acc = (log_probs.view(G, nb, V) + running_scores[:, :, None]).reshape(G, nb * V)
             topk_lp, topk_idx = torch.topk(acc, k=K)
             src_beam = topk_idx // V
@@ -174,7 +208,9 @@ def beam_search(engine, cross_kv: torch.Tensor, prompt: torch.Tensor, prompt_mas
             sequences, beam_scores, beam_bidx, finished = _gather(m_seq, sel), _gather(m_sc, sel), _gather(m_bi, sel), _gather(m_fin, sel)
             # g. the caches follow the beams that keep running
             src = running_bidx[..., cur_len - P].reshape(R).to(torch.int32).contiguous()
-            rc = lib.mh_t5_reorder_cache(C.byref(p.cfg), R, src.data_ptr(), cur_len, ws.data_ptr(), ws.numel(), scratch.data_ptr(),
+            if cfg:      # `beam_idx.repeat(2)` (cache_utils.py:18): BOTH halves take their rows from the first half
+                src = torch.cat([src, src], 0).contiguous()
+            rc = lib.mh_t5_reorder_cache(C.byref(p.cfg), RE, src.data_ptr(), cur_len, ws.data_ptr(), ws.numel(), scratch.data_ptr(),
                                          scratch.numel(), stream)
             _lib.check(rc, "mh_t5_reorder_cache")
             cur_len += 1

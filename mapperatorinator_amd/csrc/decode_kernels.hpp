@@ -936,7 +936,10 @@ struct HeadProj {
 // of dec_cross_attn_kernel, same key interleave and merge order)
 // F8: K / V are the e4m3 copy (64-byte rows, 8 bytes per lane; the scales multiply the scores and the output)
 template <typename T, int KC, int U, bool F8 = false, bool WH = false>
-__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8)))   // <= 64 VGPRs: 2 workgroups per CU
+#ifndef MH_CROSS_WPE_MIN
+#define MH_CROSS_WPE_MIN 8     // (A/B builds: 4 = up to 128 VGPRs, one 16-wave workgroup per CU)
+#endif
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(MH_CROSS_WPE_MIN, 8)))   // <= 64 VGPRs: 2 workgroups per CU
 void dec_cross_attn_q_kernel(const float* h_, const float* lnw_, const void* W_, const void* k_, const void* v_, int H_, int L_, int d_,
                              int kvB_, CrossAttnP p, HeadProjP hp) {   // leading scalars: preloaded kernel arguments (see gemv_kernel)
   hp.h = h_; hp.ln_w = lnw_; hp.W = W_; hp.ldh = d_; hp.ldw = d_; hp.d = d_;

@@ -899,6 +899,9 @@ int launch_self_qkv_d(const dec::SelfAttnP& sa, const dec::HeadProjP& hp, int in
     default: return launch_self_qkv<T, 8>(sa, hp, inner, s);
   }
 }
+#ifndef MH_CROSS_U
+#define MH_CROSS_U 1     // keys in flight per 8-lane group of the fused cross-attention kernel (A/B builds: 2, 4)
+#endif
 template <typename T, int KC>
 int launch_cross_q(const dec::CrossAttnP& ca, const dec::HeadProjP& hp, hipStream_t s) {
   MH_REQUIRE(hp.ldh == hp.d && hp.ldw == hp.d, "decode: dense residual rows / projection weights expected");
@@ -906,13 +909,13 @@ int launch_cross_q(const dec::CrossAttnP& ca, const dec::HeadProjP& hp, hipStrea
   // same bandwidth in the stand-alone kernel
   if (ca.scale != 0.f) {   // the Whisper family: biased Wq, scaled scores
     MH_REQUIRE(ca.kscale == nullptr, "decode: the fp8 cross K/V copy is not wired for the Whisper family");
-    hipLaunchKernelGGL((dec::dec_cross_attn_q_kernel<T, KC, 1, false, true>), dim3(ca.B * ca.H), dim3(1024), 0, s, MH_CROSS_LEAD_ARGS, ca, hp);
+    hipLaunchKernelGGL((dec::dec_cross_attn_q_kernel<T, KC, MH_CROSS_U, false, true>), dim3(ca.B * ca.H), dim3(1024), 0, s, MH_CROSS_LEAD_ARGS, ca, hp);
   } else if (ca.kscale != nullptr) {
     if constexpr (sizeof(T) == 2)
-      hipLaunchKernelGGL((dec::dec_cross_attn_q_kernel<T, KC, 1, true>), dim3(ca.B * ca.H), dim3(1024), 0, s, MH_CROSS_LEAD_ARGS, ca, hp);
+      hipLaunchKernelGGL((dec::dec_cross_attn_q_kernel<T, KC, MH_CROSS_U, true>), dim3(ca.B * ca.H), dim3(1024), 0, s, MH_CROSS_LEAD_ARGS, ca, hp);
     else { set_error("decode: the fp8 cross K/V copy needs bf16 storage"); return MH_ERR_ARG; }
   } else {
-    hipLaunchKernelGGL((dec::dec_cross_attn_q_kernel<T, KC, 1>), dim3(ca.B * ca.H), dim3(1024), 0, s, MH_CROSS_LEAD_ARGS, ca, hp);
+    hipLaunchKernelGGL((dec::dec_cross_attn_q_kernel<T, KC, MH_CROSS_U>), dim3(ca.B * ca.H), dim3(1024), 0, s, MH_CROSS_LEAD_ARGS, ca, hp);
   }
   return check_launch("dec_cross_attn_q_kernel");
 }

@@ -166,8 +166,6 @@ class SequentialWindowScheduler:
         sp, eos = build_sampling(tok, gk, self.model.config.max_target_positions)
         cfg = sp.cfg_scale > 1.0
         nb = int(getattr(sp, "num_beams", 1) or 1)
-        if nb > 1 and cfg:
-            raise NotImplementedError("beam search under classifier-free guidance is not on the HIP path")
         if len(group) * (2 if cfg else 1) * nb > 64:
             raise ValueError(f"{len(group)} windows{' x 2 (guidance)' if cfg else ''}{f' x {nb} beams' if nb > 1 else ''} exceed "
                              f"the engine's 64-row decode batch")

@@ -338,7 +338,7 @@ def model_generate(model, tokenizer, model_kwargs, generate_kwargs):
     extra = {} if row_bias is None else dict(row_bias=row_bias)
     if getattr(sp, "num_beams", 1) > 1:
         # HF beam search (processor.py:159 `num_beams`; the timing generator uses two beams): mapperatorinator_amd/beam.py
-        out = model.engine.generate_beam(audio, prompt, mask, eos, sp, sp.num_beams, **extra)
+        out = model.engine.generate_beam(audio, prompt, mask, eos, sp, sp.num_beams, negative_prompt=neg, **extra)
     else:
         out = model.engine.generate(audio, prompt, mask, eos, sp, negative_prompt=neg, negative_mask=neg_mask,
                                     cross_kv_fp8=bool(generate_kwargs.get("cross_kv_fp8", False)), **extra)

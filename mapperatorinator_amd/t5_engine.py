@@ -394,11 +394,23 @@ class T5Engine:
 
     def generate_beam(self, audio: torch.Tensor, prompt: torch.Tensor, prompt_mask: Optional[torch.Tensor], eos_ids,
                       sampling: _lib.MhSampling, num_beams: int, row_bias: Optional[torch.Tensor] = None,
-                      length_penalty: float = 1.0, early_stopping=False):
+                      length_penalty: float = 1.0, early_stopping=False, negative_prompt: Optional[torch.Tensor] = None):
         """mel -> encoder -> cross K/V, then HF-style beam search over the step-wise decode entry (beam.py).  Returns
-        dict(tokens=int64 CPU (B, n_cols), n_cols, logits=None) like `generate`."""
+        dict(tokens=int64 CPU (B, n_cols), n_cols, logits=None) like `generate`.  `negative_prompt` with sampling.cfg_scale > 1:
+        classifier-free guidance under beams (the doubled batch of modeling_mapperatorinator.py:243-254; beam.py)."""
         from .beam import beam_search
         audio = audio.to(self.device, torch.float32)
+        if (negative_prompt is not None) != (sampling.cfg_scale > 1.0):
+            raise ValueError("negative_prompt and sampling.cfg_scale > 1 go together")
+        if negative_prompt is not None:
+            n = negative_prompt.shape[1]
+            if n > prompt.shape[1]:
+                raise ValueError("negative prompt longer than the prompt")
+            neg = prompt.clone()
+            neg[:, :n] = negative_prompt.to(prompt.dtype)
+            prompt = torch.cat([neg, prompt], 0)
+            if prompt_mask is not None:      # (the negative rows attend under the prompt's mask: see `generate`)
+                prompt_mask = torch.cat([prompt_mask, prompt_mask], 0)
         self._enter()
         with torch.cuda.stream(self.stream):
             kv = self.cross_kv(self.encode_mel(self.mel(audio), row_bias=row_bias))

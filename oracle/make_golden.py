@@ -275,9 +275,14 @@ def vw_case(name):
 
 
 BEAM_CASE = dict(src=251, tgt=40, ns=32000, wseed=13, gain=1.5, aseed=6, prompts=[[0, 0, 1], [1, 40, 700], [0, 1, 9]],
+                 negative=[[0, 0, 1], [0, 1, 701], [0, 0, 1]],
                  runs={"b2": dict(num_beams=2), "b3": dict(num_beams=3),
                        "b2p": dict(num_beams=2, lookahead_time=500, temperature=0.8, timeshift_bias=0.3),
-                       "b3p": dict(num_beams=3, lookahead_time=700, lookback_time=300, temperature=1.3)})
+                       "b3p": dict(num_beams=3, lookahead_time=700, lookback_time=300, temperature=1.3),
+                       # classifier-free guidance UNDER beams (the timing pass: processor.py:709 halves its batch for it): the doubled
+                       # rows of prepare_inputs_for_generation + `beam_idx.repeat(2)` of MapperatorinatorCache.reorder_cache
+                       "b2g": dict(num_beams=2, cfg_scale=2.0),
+                       "b3g": dict(num_beams=3, cfg_scale=1.5, temperature=0.8, timeshift_bias=0.3, lookahead_time=500)})
 
 
 def beam_case(name="t5_tiny_beam"):
@@ -290,12 +295,14 @@ def beam_case(name="t5_tiny_beam"):
                               gains=DIVERSE_GAINS)
     model.load_state_dict(sd, strict=False)
     audio = synthetic_audio_varied(len(c["prompts"]), c["ns"], seed=c["aseed"])
-    prompt = torch.tensor(c["prompts"])
-    out = dict(vocab_in=tok.vocab_size_in, vocab_out=tok.vocab_size_out, prompt=prompt.numpy(), runs=json.dumps(c["runs"]),
-               **{k: v for k, v in c.items() if k not in ("prompts", "runs")})
+    prompt, neg = torch.tensor(c["prompts"]), torch.tensor(c["negative"])
+    out = dict(vocab_in=tok.vocab_size_in, vocab_out=tok.vocab_size_out, prompt=prompt.numpy(), negative=neg.numpy(), runs=json.dumps(c["runs"]),
+               **{k: v for k, v in c.items() if k not in ("prompts", "runs", "negative")})
     for tag, kw in c["runs"].items():
-        ids, _ = rh.reference_generate(model, tok, audio, prompt, rh.default_generate_kwargs(c["tgt"], **kw), prompt.ne(0))
-        greedy, _ = rh.reference_generate(model, tok, audio, prompt, rh.default_generate_kwargs(c["tgt"], **dict(kw, num_beams=1)), prompt.ne(0))
+        ng = neg if kw.get("cfg_scale", 1.0) > 1.0 else None
+        ids, _ = rh.reference_generate(model, tok, audio, prompt, rh.default_generate_kwargs(c["tgt"], **kw), prompt.ne(0), negative_prompt=ng)
+        greedy, _ = rh.reference_generate(model, tok, audio, prompt, rh.default_generate_kwargs(c["tgt"], **dict(kw, num_beams=1)), prompt.ne(0),
+                                          negative_prompt=ng)
         out["ids_" + tag], out["greedy_" + tag] = ids.numpy(), greedy.numpy()
         w = min(ids.shape[1], greedy.shape[1])
         print(name, tag, tuple(ids.shape), "greedy", tuple(greedy.shape), "positions where beams and greedy differ",

@@ -256,14 +256,18 @@ def test_window_pipeline_matches_reference_golden(variant):
         # `<key>_alt`, oracle/make_golden.py).  Two CPU fp32 implementations already differ by `floor` -- and those two share
         # their BLAS (every matmul of both goes through the same sgemm, so only their LayerNorm / softmax / embedding
         # arithmetic differs); the device changes the summation order of the GEMMs as well (MFMA tiles, split-K).  It must
-        # stay within FLOOR_K x that spread in max / p90 / median -- not within a constant.  Measured on the `full` variant:
-        # max 9.3 vs floor 1.74 px (5.3 x), p90 0.44 vs 0.042 (10.4 x), median 0.014 vs 0.0023 (6 x).
+        # stay within a multiple of that spread per statistic -- not within a constant.  Measured in round 5 (gpurun_out/r5e), error vs
+        # floor and their ratio:           max                  p90                   median
+        #   full          9.25 / 1.74 px =  5.3 x   0.455 / 0.0424 = 10.7 x   0.0141 / 0.0023 = 6.1 x
+        #   sliders       5.58 / 5.74    =  1.0 x   0.320 / 0.1027 =  3.1 x   0.0168 / 0.0025 = 6.7 x
+        #   pad_sliders   7.75 / 3.42    =  2.3 x   0.604 / 0.0845 =  7.1 x   0.0235 / 0.0024 = 9.8 x
+        # The multiples below are those ratios' worst case + ~30 % (round 4 allowed 16 x everywhere: 27.8 px on the max).
         floor = (torch.from_numpy(g[key + "_alt"]) - want).abs().max(0).values
         print(f"   fp32 noise floor px: max {floor.max().item():.4f} median {floor.median().item():.4f} p90 {floor.quantile(0.9).item():.4f}")
-        FLOOR_K = 16.0
-        assert err.max().item() < FLOOR_K * floor.max().item()
-        assert err.quantile(0.9).item() < FLOOR_K * floor.quantile(0.9).item()
-        assert err.median().item() < FLOOR_K * floor.median().item() + 0.01       # (+0.01 px: the median floor is 0.002 px)
+        K_MAX, K_P90, K_MEDIAN = 8.0, 14.0, 13.0
+        assert err.max().item() < K_MAX * floor.max().item()
+        assert err.quantile(0.9).item() < K_P90 * floor.quantile(0.9).item()
+        assert err.median().item() < K_MEDIAN * floor.median().item()
     # points outside [start_time, end_time] are never generated: they keep the given positions
     given = torch.stack([torch.from_numpy(x), torch.from_numpy(y)])
     frozen = (torch.from_numpy(times) < float(g["start_time"])) | (torch.from_numpy(times) > float(g["end_time"]))

@@ -768,11 +768,13 @@ def test_conditioning_embedders_fp32_match_reference_golden():
         model_generate(model, tok, dict(inputs=audio, decoder_input_ids=prompt, decoder_attention_mask=prompt.ne(0)), gen_kwargs(tgt))
 
 
-@pytest.mark.parametrize("run", ["b2", "b3", "b2p", "b3p"])
+@pytest.mark.parametrize("run", ["b2", "b3", "b2p", "b3p", "b2g", "b3g"])
 def test_fp32_beam_search_matches_reference_golden(run):
     """`num_beams` 2 / 3 through `model_generate` on the HIP path (mapperatorinator_amd/beam.py over mh_t5_step /
     mh_t5_reorder_cache): the ids the REFERENCE returned for the same inputs through HF beam search and its cache reorder
-    (tests/golden/t5_tiny_beam.npz), bit for bit -- hypotheses of different lengths, processors and EOS windows included."""
+    (tests/golden/t5_tiny_beam.npz), bit for bit -- hypotheses of different lengths, processors and EOS windows included.  `b2g` /
+    `b3g`: classifier-free guidance under beams (doubled rows, HF's processor on log-probabilities, the reference's
+    `beam_idx.repeat(2)` cache gather)."""
     import json
     from mapperatorinator_amd import Tokenizer
     from mapperatorinator_amd.server import model_generate
@@ -787,8 +789,11 @@ def test_fp32_beam_search_matches_reference_golden(run):
     model = build("tiny", tok, sd, src, tgt, torch.float32)
     prompt = torch.from_numpy(g["prompt"])
     kw = json.loads(str(g["runs"]))[run]
-    ids, stats = model_generate(model, tok, dict(inputs=audio, decoder_input_ids=prompt, decoder_attention_mask=prompt.ne(0)),
-                                gen_kwargs(tgt, **kw))
+    mk = dict(inputs=audio, decoder_input_ids=prompt, decoder_attention_mask=prompt.ne(0))
+    if kw.get("cfg_scale", 1.0) > 1.0:
+        neg = torch.from_numpy(g["negative"])
+        mk.update(negative_prompt=neg, negative_prompt_attention_mask=neg.ne(0))
+    ids, stats = model_generate(model, tok, mk, gen_kwargs(tgt, **kw))
     want = g["ids_" + run]
     assert ids.shape == want.shape and np.array_equal(ids.numpy(), want), (ids.tolist(), want.tolist())
     assert ids.dtype == torch.int64 and ids.device.type == "cpu" and stats["generated_tokens"] > 0

@@ -52,6 +52,52 @@ def token_agreement(a, b):
             "mean_common_prefix_frac": round(sum(prefix) / max(1, len(prefix)), 4), "tokens_compared": tot}
 
 
+def teacher_forced_agreement(songs, new_tokens, dev):
+    """Two free-running greedy streams of a random-init model part at their first near-tie and never meet again, so position-wise
+    equality says little.  The comparable figure: the bf16 model decodes the first window of every song greedily; the MX-fp8-encoder
+    model with the e4m3 cross K/V is then FORCED along those tokens and asked, step by step, whether its own top-1 is the same token
+    (all steps / the steps the bf16 model decides by a logit gap >= 0.5 / >= 1.0)."""
+    from mapperatorinator_amd import Tokenizer
+    from mapperatorinator_amd.modeling import MapperatorinatorHIP
+    from mapperatorinator_amd.server import build_sampling
+    from mapperatorinator_amd.t5_engine import T5_PRESETS
+    from mapperatorinator_amd.testing import random_t5_state_dict, synthetic_audio_varied
+    src, tgt = 1251, 1 + new_tokens
+    tok = Tokenizer.benchmark_vocab(src_seq_len=src)
+    dims = T5_PRESETS["large"]
+    sd = random_t5_state_dict(dims, tok.vocab_size_in, tok.vocab_size_out, seed=0, lm_head_gain=6.0)
+    audio = synthetic_audio_varied(songs, 160000, seed=3)
+    prompt = torch.tensor([[tok.sos_id]] * songs)
+    gk = dict(precision="fp32", do_sample=False, num_beams=1, top_p=1.0, top_k=0, max_length=tgt, cfg_scale=1.0, timeshift_bias=0,
+              types_first=False, temperature=1.0, lookback_time=0, lookahead_time=0, context_type="map", pad_token_id=0)
+    sp, _ = build_sampling(tok, gk, tgt)
+
+    def model(mode):
+        return MapperatorinatorHIP(sd, dims, vocab_size_in=tok.vocab_size_in, vocab_size_out=tok.vocab_size_out, src_seq_len=src,
+                                   tgt_seq_len=tgt, dtype=torch.bfloat16, device=dev, enc_operand_dtype=mode)
+    mb = model(None)
+    free = mb.engine.generate(audio, prompt, None, [], sp)["tokens"]                     # (songs, tgt): no EOS set, every row runs
+    forced = torch.zeros((songs, tgt), dtype=torch.long)
+    forced[:, :free.shape[1]] = free
+    lb = mb.engine.generate(audio, prompt, None, [], sp, forced=forced, dump_logits=True)["logits"].float().cpu()
+    del mb
+    torch.cuda.empty_cache()
+    mm = model("mx8")
+    lm = mm.engine.generate(audio, prompt, None, [], sp, forced=forced, dump_logits=True, cross_kv_fp8=True)["logits"].float().cpu()
+    del mm
+    n = free.shape[1]
+    want = free[:, 1:n]                                                                # token chosen at step t (row-major)
+    top2 = lb[1:n].topk(2, dim=-1).values                                              # (steps, songs, 2)
+    gap = (top2[..., 0] - top2[..., 1]).T
+    ok = lm[1:n].argmax(-1).T == want
+    self_ok = lb[1:n].argmax(-1).T == want                                             # (the bf16 model against its own free run: 1.0 up to ties)
+    return {"steps": int(ok.numel()), "top1_same_as_bf16": round(ok.float().mean().item(), 4),
+            "top1_same_where_bf16_gap_ge_0.5": round(ok[gap >= 0.5].float().mean().item(), 4),
+            "top1_same_where_bf16_gap_ge_1.0": round(ok[gap >= 1.0].float().mean().item(), 4),
+            "frac_steps_gap_ge_0.5": round((gap >= 0.5).float().mean().item(), 4), "bf16_forced_vs_own_free_run": round(self_ok.float().mean().item(), 4),
+            "what": f"window 0 of {songs} songs, {n - 1} steps each, MX-fp8 encoder + e4m3 cross K/V forced along the bf16 model's greedy tokens"}
+
+
 def run(songs=32, windows=18, new_tokens=384, device="cuda:0", bf16_tokens=None, bf16_line=None):
     """bf16_tokens / bf16_line: the bf16-operand run of the same songs if the caller has it already (bench.py does)."""
     from mapperatorinator_amd.dit import BandMask, DiTHIP, create_diffusion
@@ -64,6 +110,8 @@ def run(songs=32, windows=18, new_tokens=384, device="cuda:0", bf16_tokens=None,
     mx = lsb.run("large", songs=songs, windows=windows, new_tokens=new_tokens, fp8_kv=(True,), device=device, enc_operand_dtype="mx8",
                  collect_tokens=True)[0]
     agree = token_agreement(mx.pop("_tokens"), bf16_tokens)
+    torch.cuda.empty_cache()
+    agree["teacher_forced"] = teacher_forced_agreement(songs, new_tokens, dev)
     torch.cuda.empty_cache()
     # ---- DiT-B, MX-fp8 block projections: every window of every song is one chunk of 128 points ----
     depth, hidden, heads = DIT_PRESETS["DiT-B"]
