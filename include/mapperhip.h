@@ -75,11 +75,6 @@ int mh_abi_version(void);
  *   "gemm_glds"          MH_GEMM_GLDS          3    bf16 GEMM operands by LDS-DMA: 3 = three-stage kernel (256x128 tiles, 128x128
  *                                                   below half a wave of them), 2 = 256x128 only, 1 = two-stage 128x128,
  *                                                   0 = register staging
- *   "attn_flash2"        MH_ATTN_FLASH2        1    bf16 attention: transposed-S kernel (probabilities stay in registers);
- *                                                   0 = the 64-query kernel with the LDS P patch (different fp32 order)
- *   "dit_s3_presplit"    MH_DIT_S3_PRESPLIT    1    batched fp32-semantics DiT: activations written pre-split by their
- *                                                   producers + three-stage bf16 x 3 GEMM; 0 = the 64x64 kernel that splits A
- *                                                   while staging it (bit-identical GEMM results; the fc1 GELU differs)
  *   "decode_launch_threads" MH_DECODE_LAUNCH_THREADS 1  one host launcher thread per decode chain; 0 = one thread feeds all chains
  *                                                   round robin (for profilers whose counter passes do not survive concurrent
  *                                                   launcher threads)
@@ -89,10 +84,11 @@ int mh_abi_version(void);
  *                                                   full (0 = never; bit-identical to the 256x128 three-stage kernel)
  *   "gemm_2stage_max_k"  MH_GEMM_2STAGE_MAX_K  512  bf16 GEMM with K <= this: 128x128 tile on two LDS stages, two workgroups per CU
  *                                                   (0 = never; bit-identical)
- * (further switches -- gemm_tile128_min, gemm_tile256_min, attn_small_max_wgs, dit_split3_min_rows, mx8_tile256_min,
- * mx8_fused_quant -- are documented next to their definitions in csrc/api.hip.  Round 5 removed the measured-slower variants
- * decode_overlap, decode_fold_oproj, decode_cu_split, decode_self_rows, mx8_waves = 4, dit_s3_fused_ln and the debugging aid
- * gemm_lds_pad; their measurements stay in profiles/r02_* .. r04_*.)
+ * (gemm_tile128_min and dit_split3_min_rows are documented next to their definitions in csrc/api.hip: 12 options in all.
+ * Round 5 removed the measured-slower variants decode_overlap, decode_fold_oproj, decode_cu_split, decode_self_rows,
+ * mx8_waves = 4, dit_s3_fused_ln, the debugging aid gemm_lds_pad, the variant switches attn_flash2, dit_s3_presplit and
+ * mx8_fused_quant (the faster form is the only one left) and turned the thresholds attn_small_max_wgs, gemm_tile256_min,
+ * mx8_tile256_min into constants; their measurements stay in profiles/r02_* .. r04_*.)
  * Unknown names return MH_ERR_ARG (set) / -1 (get). */
 int mh_set_option(const char* name, long value);
 long mh_get_option(const char* name);

@@ -41,18 +41,12 @@ static OptionSlot g_options[OPT_COUNT] = {
     {"decode_gemv_cols", "MH_DECODE_GEMV_COLS", 0, false},       // valid weight rows per 16-column MFMA tile of the decode GEMVs (0 = automatic)
     {"decode_fused_proj", "MH_DECODE_FUSED_PROJ", 1, false},     // 1: attention kernels project their own q / k / v, 0: stand-alone GEMVs
     {"gemm_tile128_min", "MH_GEMM_TILE128_MIN", 192, false},     // the 128x128 GEMM tile is used from this many tiles on (else 64x64 / smaller)
-    {"attn_small_max_wgs", "MH_ATTN_SMALL_MAX_WGS", 1024, false}, // fp32 attention at L <= 256: key-split latency kernel up to this many workgroups, flash kernel beyond
     {"dit_split3_min_rows", "MH_DIT_SPLIT3_MIN_ROWS", 2048, false},   // DiT denoiser batches of >= this many rows (N*T) run their big GEMMs as bf16 x 3 (0 = never)
     {"gemm_glds", "MH_GEMM_GLDS", 3, false},                     // bf16 GEMM operands by LDS-DMA (global_load_lds): 3 = three-stage kernel, 256x128 tiles or 128x128 where fewer than 128 of the big ones exist; 2 = 256x128 only; 1 = two-stage 128x128 only; 0 = register staging
-    {"gemm_tile256_min", "MH_GEMM_TILE256_MIN", 96, false},      // the three-stage 256x128 bf16 tile (one workgroup per CU) is used from this many tiles on (batched DiT-S bf16: 171.6 ms at 192, 167.4 at 96, 168.6 at 48)
-    {"attn_flash2", "MH_ATTN_FLASH2", 1, false},                 // bf16 attention: 1 = transposed-S kernel (128 queries per workgroup, probabilities stay in registers), 0 = the 64-query kernel with the LDS P patch
-    {"dit_s3_presplit", "MH_DIT_S3_PRESPLIT", 1, false},         // fp32-semantics DiT, big batches: 1 = activations written pre-split by their producers + three-stage bf16 x 3 GEMM, 0 = the 64x64 kernel that splits A while staging it
-    {"mx8_tile256_min", "MH_MX8_TILE256_MIN", 192, false},       // MX-fp8 GEMM: the 256x128 tile from this many tiles on, the 128x128 form of the same kernel below
     {"decode_launch_threads", "MH_DECODE_LAUNCH_THREADS", 1, false},   // 1: one host launcher thread per decode chain (graph replay costs ~0.4 ms of host time per step); 0: one thread feeds all chains round robin -- for profilers whose counter passes do not survive concurrent launcher threads (rocprofv3 --pmc)
     {"decode_graph_cache", "MH_DECODE_GRAPH_CACHE", 1, false},   // 1: instantiated step graphs are kept across mh_t5_generate calls (LRU of 16, exact-description match); 0: captured per call
     {"gemm_tile256sq_min", "MH_GEMM_TILE256SQ_MIN", 440, false},   // bf16 GEMM: the 256 x 256 tile (two LDS stages, 128 x 64 wave tiles, AGPR accumulators) from this many tiles on, if its rounds of 256 workgroups are >= 88 % full (0 = never, 1 = whenever the three-stage kernel would run: tests)
     {"gemm_2stage_max_k", "MH_GEMM_2STAGE_MAX_K", 512, false},   // bf16 GEMM with K <= this: the two-stage 128 x 128 kernel (64 KB of LDS: two workgroups per CU) instead of the three-stage forms (0 = never).  Batched DiT-S bf16 (K = 384 on three of four projections): 130.3 -> 121.6 ms per 100 steps; at 1024 DiT-B (K = 768) 284.6 -> 287.7, at 4096 299.7
-    {"mx8_fused_quant", "MH_MX8_FUSED_QUANT", 1, false},   // MX-fp8 modes: 1 = the gated-GELU / GELU GEMM writes its result as the next GEMM's MX operand itself (MhGemm.mx_out; the same bytes), 0 = a quantiser pass over the bf16 result
 };
 
 static thread_local const MhOptionSet* tl_option_set = nullptr;

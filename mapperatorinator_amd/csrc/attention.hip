@@ -695,8 +695,8 @@ int attention_general(const AttnArgs& a, int B, int H, int dtype, hipStream_t s)
                  a.vt_bs % 16 == 0 && a.vt_hs % 16 == 0,
              "attention: strides must be multiples of 16 bytes");
   const int es = dtype == MH_BF16 ? 2 : 4;
-  if (dtype == MH_BF16 && option(OPT_ATTN_FLASH2) != 0 && a.out_rs % 8 == 0 && a.out_bs % 8 == 0) {
-    // bf16: transposed-S kernel, 128 queries per workgroup (option attn_flash2 = 0: the 64-query kernel below)
+  if (dtype == MH_BF16 && a.out_rs % 8 == 0 && a.out_bs % 8 == 0) {
+    // bf16: transposed-S kernel, 128 queries per workgroup (the 64-query kernel below only for outputs it cannot store 8 bytes at a time)
     const int nqt = ceil_div(a.Lq, 128);
     const long total = (long)nqt * H * B;
     MH_REQUIRE(total < (1L << 30), "attention: too many workgroups");
@@ -859,7 +859,8 @@ __global__ __launch_bounds__(256) void attn_small_f32_kernel(SmallAttnP p) {
 // The key-split kernel is a LATENCY design (one CFG pair: 96 workgroups of 16 queries instead of 24 of 64); with many
 // chunks in one denoiser batch its per-lane operand loads (80 dword loads per lane, every workgroup re-reading its
 // head's K / V from L2) lose to the LDS-staged flash kernel: option attn_small_max_wgs (default 1024 workgroups).
-bool small_attn_ok(int B, int H, int L) { return (long)B * H * ceil_div(L, 16) <= option(OPT_ATTN_SMALL_MAX_WGS); }
+constexpr long kAttnSmallMaxWgs = 1024;   // (an option until round 5; measured crossover of the two kernels on the batched DiT)
+bool small_attn_ok(int B, int H, int L) { return (long)B * H * ceil_div(L, 16) <= kAttnSmallMaxWgs; }
 
 }  // namespace
 

@@ -375,7 +375,7 @@ int dit_body(const MhDiTConfig* c, const MhDiTWeights* w, const float* x, const 
     g = MhGemm{};
     g.A = xq; g.lda = D; g.a_scale = xqs; g.W = w->fc1_wm[l]; g.ldw = D; g.w_scale = w->fc1_wms[l]; g.C = b.hid; g.ldc = 4 * D; g.M = NT; g.N = 4 * D; g.K = D;
     g.bias = w->fc1_b[l]; g.dtype = MH_MX8; g.epilogue = MH_EPI_BIAS_GELU;
-    const bool mx_fused = (4 * D) % 128 == 0 && option(OPT_MX8_FUSED_QUANT) != 0;   // the GELU hidden leaves fc1 as fc2's MX-fp8 operand
+    const bool mx_fused = (4 * D) % 128 == 0;   // the GELU hidden leaves fc1 as fc2's MX-fp8 operand
     if (mx_fused) {
       if ((4 * D) % 512) MH_REQUIRE(hipMemsetAsync(hqs, 0, (size_t)NT * mx8_scale_row_bytes(4 * D), s) == hipSuccess, "dit: scale reset failed");
       g.mx_out = hq; g.mx_out_scales = hqs; g.ldc = 4 * D;
@@ -392,7 +392,7 @@ int dit_body(const MhDiTConfig* c, const MhDiTWeights* w, const float* x, const 
   // no conversion work inside the GEMM) -- LayerNorm-modulate, the attention and the GELU epilogue write their outputs as
   // [32 x bf16 hi | 32 x bf16 lo] per 32 values straight away (the same bytes as fp32, the same buffers).  Option
   // dit_s3_presplit = 0: the 64 x 64 kernel that splits A while staging it.
-  const bool s3g = !lowp && !lowp8 && s3 && option(OPT_DIT_S3_PRESPLIT) != 0 && D % 32 == 0;
+  const bool s3g = !lowp && !lowp8 && s3 && D % 32 == 0;
   for (int l = 0; l < c->depth && s3g; ++l) {
     const float* mod = b.cond_cur + (long)l * 6 * D;
     MH_TRY(ln_modulate(b.xs, D, mod + 0 * D, mod + 1 * D, ld_row, T, b.xm, D, NT, D, 1e-6f, MH_LN_SPLIT3, s));

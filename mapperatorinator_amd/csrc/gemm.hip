@@ -1751,17 +1751,19 @@ bool prepare_mx8() {
   }
   return ok;
 }
+// tile-count thresholds that were run-time options until round 5 (measured: batched DiT-S bf16 171.6 ms at 192, 167.4 at 96, 168.6 at 48)
+constexpr long kMx8Tile256Min = 192, kGemmTile256Min = 96;
 template <int EPI>
 int dispatch_mx8(const GemmP& p, hipStream_t s) {
   // fewer 256-row tiles than option mx8_tile256_min: the 128-row form doubles the workgroups
   const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + 127) / 128);
   if constexpr (EPI == MH_EPI_GEGLU || EPI == MH_EPI_BIAS_GELU) {
     if (p.mxq) {   // the result leaves as the next GEMM's MX-fp8 operand
-      if (tiles256 < option(OPT_MX8_TILE256_MIN)) return launch_mx8<EPI, 2, 8, true>(p, s);
+      if (tiles256 < kMx8Tile256Min) return launch_mx8<EPI, 2, 8, true>(p, s);
       return launch_mx8<EPI, 4, 8, true>(p, s);
     }
   }
-  if (tiles256 < option(OPT_MX8_TILE256_MIN)) return launch_mx8<EPI, 2, 8>(p, s);
+  if (tiles256 < kMx8Tile256Min) return launch_mx8<EPI, 2, 8>(p, s);
   return launch_mx8<EPI, 4, 8>(p, s);     // 256 x 128 tile as eight waves of 64 x 64 (two per SIMD); the four-wave 128 x 64 geometry measured 0.99-1.37 x the bf16 kernel against 1.07-1.46 x (profiles/r04_mx8_gemm_bench.txt) and was removed in round 5
 }
 int dispatch_mx8_epi(const GemmP& p, int epi, hipStream_t s) {
@@ -1886,7 +1888,7 @@ int dispatch_tile(const GemmP& p, hipStream_t s) {
                           (EPI != MH_EPI_GEGLU || p.N % 8 == 0) && p.K % 64 == 0;
       if (option(OPT_GEMM_GLDS) >= 3 && p.K <= option(OPT_GEMM_2STAGE_MAX_K) && !p.stats_out && vec_ok)
         return launch_glds2s<EPI>(p, s);      // short K: two workgroups per CU, one's prologue / epilogue under the other's K loop
-      if (option(OPT_GEMM_GLDS) >= 2 && tiles256 >= option(OPT_GEMM_TILE256_MIN) && !p.stats_out && vec_ok) {
+      if (option(OPT_GEMM_GLDS) >= 2 && tiles256 >= kGemmTile256Min && !p.stats_out && vec_ok) {
         // fewer 256-row tiles than half the CUs: the 128-row form of the same kernel doubles the workgroups (batched DiT-S bf16,
         // N = 384: 96 -> 192 workgroups, 153 -> 137 ms per 100 steps; at 192 tiles -- DiT-B, N = 768 -- it loses, 294 -> 308)
         if (tiles256 < 128 && option(OPT_GEMM_GLDS) >= 3) return launch_glds3<EPI, 2>(p, s);

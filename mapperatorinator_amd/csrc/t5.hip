@@ -285,7 +285,7 @@ extern "C" int mh_t5_encode_cond(const MhT5Config* c, const MhT5Weights* w, cons
     g.C = ff; g.ldc = dff; g.M = rows; g.N = 2 * dff; g.K = d; g.epilogue = MH_EPI_GEGLU;
     // MX mode: the gated GELU leaves the GEMM as the MX-fp8 operand of wo (the bytes mh_quantize_mx8 would make of the bf16
     // hidden) -- into the second operand buffer: xq / xs still hold this GEMM's own A operand
-    const bool mx_fused = mx && dff % 128 == 0 && option(OPT_MX8_FUSED_QUANT) != 0;
+    const bool mx_fused = mx && dff % 128 == 0;
     uint8_t* xq2 = reinterpret_cast<uint8_t*>(ff);                 // (the bf16 hidden is not written then: its buffer holds the MX image)
     uint8_t* xs2 = xq2 + (int64_t)rows * dff;
     if (mx_fused) {
