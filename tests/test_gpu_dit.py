@@ -77,11 +77,13 @@ def test_single_p_sample_and_loop(name):
     e = (out - ref).abs().max().item()
     print(name, "100-step loop vs reference: max abs", e)
     assert torch.isfinite(out).all() and e < 5e-2
-    # --- per-step gate along the ORACLE trajectory (no chaotic amplification): every 9th step
+    # --- per-step gate along the ORACLE trajectory (no chaotic amplification): every 9th step (DiT-S: over the first 37 steps --
+    # the CPU oracle costs 0.3 s per step there; DiT-XS walks all 100)
     od = odit.DiffusionOracle()
     x = z.clone()
     worst = 0.0
-    for k, i in enumerate(reversed(range(100))):
+    n_traj = 100 if name == "dit_xs" else 37
+    for k, i in enumerate(list(reversed(range(100)))[:n_traj]):
         tt = torch.full((2,), od.timestep_map[i], dtype=torch.long)
         eps_o = orc.forward_with_cfg(x, tt, c, y, cfg, mask)
         x_next = od.p_sample(eps_o, x, i, noise[k])
@@ -102,8 +104,11 @@ def test_single_p_sample_and_loop(name):
     spec = InpaintSpec(imask, z)
     out2 = diff.p_sample_loop(dit.forward_with_cfg, z.shape, zt, denoised_fn=spec, model_kwargs=dict(
         c=c.cuda(), y=y.cuda(), cfg_scale=cfg, attn_mask=mask), step_noise=noise).cpu()
-    want2 = od.sample_loop(orc, z, c, y, cfg, mask, noise, denoised_fn=spec)
-    assert (out2 - want2).abs().max().item() < 5e-2
+    if name == "dit_xs":      # (the oracle's own in-paint loop: 100 more CPU denoiser passes -- on the small preset only)
+        want2 = od.sample_loop(orc, z, c, y, cfg, mask, noise, denoised_fn=spec)
+        assert (out2 - want2).abs().max().item() < 5e-2
+    # the frozen points end on their reference positions (the last step's posterior mean is x0: coef1 = 1, coef2 = 0), the others move
+    assert (out2[:, :, :17] - z[:, :, :17]).abs().max().item() < 1e-4 and (out2[:, :, 17:] - z[:, :, 17:]).abs().mean().item() > 1e-3
     # generic python denoised_fn path (x0 round trip) must agree with the fused in-paint path
     out3 = diff.p_sample_loop(dit.forward_with_cfg, z.shape, zt, denoised_fn=lambda v: spec(v), model_kwargs=dict(
         c=c.cuda(), y=y.cuda(), cfg_scale=cfg, attn_mask=mask), step_noise=noise).cpu()
