@@ -47,6 +47,7 @@ static OptionSlot g_options[OPT_COUNT] = {
     {"decode_graph_cache", "MH_DECODE_GRAPH_CACHE", 1, false},   // 1: instantiated step graphs are kept across mh_t5_generate calls (LRU of 16, exact-description match); 0: captured per call
     {"gemm_tile256sq_min", "MH_GEMM_TILE256SQ_MIN", 440, false},   // bf16 GEMM: the 256 x 256 tile (two LDS stages, 128 x 64 wave tiles, AGPR accumulators) from this many tiles on, if its rounds of 256 workgroups are >= 88 % full (0 = never, 1 = whenever the three-stage kernel would run: tests)
     {"gemm_2stage_max_k", "MH_GEMM_2STAGE_MAX_K", 512, false},   // bf16 GEMM with K <= this: the two-stage 128 x 128 kernel (64 KB of LDS: two workgroups per CU) instead of the three-stage forms (0 = never).  Batched DiT-S bf16 (K = 384 on three of four projections): 130.3 -> 121.6 ms per 100 steps; at 1024 DiT-B (K = 768) 284.6 -> 287.7, at 4096 299.7
+    {"dit_skinny_max_rows", "MH_DIT_SKINNY_MAX_ROWS", 512, false},   // fp32-semantics DiT with at most this many rows (N T: one chunk = 256): the four block GEMMs as one-round-trip 16 x 16 latency kernels with the LayerNorm taken from registers (dit.hip dit_skinny_kernel); 0 = the LDS-tiled GEMMs (different fp32 summation order)
 };
 
 static thread_local const MhOptionSet* tl_option_set = nullptr;

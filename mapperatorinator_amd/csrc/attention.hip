@@ -307,7 +307,7 @@ __device__ inline float sum_over_lane_groups(float v) {   // (r0 + r1) + (r2 + r
 // `key < Lk` test of the last tile and the clamped bias gather, and the LEAN form can afford the S^T / softmax overlap (a second
 // S^T register set; with the band / causal / key-mask arithmetic compiled in, the allocator spills inside the tile loop).
 template <int QB, bool BIAS, bool SIMPLE>
-__global__ __launch_bounds__(256, 2) void flash2_bf16_kernel(AttnArgs p_, int nqt, int H, int total) {
+__global__ __launch_bounds__(256, QB == 1 ? 3 : 2) void flash2_bf16_kernel(AttnArgs p_, int nqt, int H, int total) {
   AttnArgs p = p_;
   if constexpr (SIMPLE) { p.band = 0; p.causal = 0; p.key_mask = nullptr; p.open_from = 0; }
   using T = bf16_t;
@@ -697,18 +697,22 @@ int attention_general(const AttnArgs& a, int B, int H, int dtype, hipStream_t s)
   const int es = dtype == MH_BF16 ? 2 : 4;
   if (dtype == MH_BF16 && a.out_rs % 8 == 0 && a.out_bs % 8 == 0) {
     // bf16: transposed-S kernel, 128 queries per workgroup (the 64-query kernel below only for outputs it cannot store 8 bytes at a time)
-    const int nqt = ceil_div(a.Lq, 128);
+    const bool simple = a.band == 0 && !a.causal && a.key_mask == nullptr;
+#ifndef MH_F2_QB_SIMPLE
+#define MH_F2_QB_SIMPLE 2      // query blocks (of 16) per wave of the encoder form (A/B builds: 1 = 64 queries per workgroup, three workgroups per CU)
+#endif
+    constexpr int QBS = MH_F2_QB_SIMPLE;
+    const int nqt = ceil_div(a.Lq, simple ? 64 * QBS : 128);
     const long total = (long)nqt * H * B;
     MH_REQUIRE(total < (1L << 30), "attention: too many workgroups");
     const int per_xcd = (int)((total + 7) / 8);
     const size_t smem = (size_t)4 * 64 * (64 * 2 + 16);        // two buffers of (K tile | V^T tile)
-    const bool simple = a.band == 0 && !a.causal && a.key_mask == nullptr;
     if (a.bias && simple)
-      hipLaunchKernelGGL((flash2_bf16_kernel<2, true, true>), dim3(8 * per_xcd), dim3(256), smem, s, a, nqt, H, (int)total);
+      hipLaunchKernelGGL((flash2_bf16_kernel<QBS, true, true>), dim3(8 * per_xcd), dim3(256), smem, s, a, nqt, H, (int)total);
     else if (a.bias)
       hipLaunchKernelGGL((flash2_bf16_kernel<2, true, false>), dim3(8 * per_xcd), dim3(256), smem, s, a, nqt, H, (int)total);
     else if (simple)
-      hipLaunchKernelGGL((flash2_bf16_kernel<2, false, true>), dim3(8 * per_xcd), dim3(256), smem, s, a, nqt, H, (int)total);
+      hipLaunchKernelGGL((flash2_bf16_kernel<QBS, false, true>), dim3(8 * per_xcd), dim3(256), smem, s, a, nqt, H, (int)total);
     else
       hipLaunchKernelGGL((flash2_bf16_kernel<2, false, false>), dim3(8 * per_xcd), dim3(256), smem, s, a, nqt, H, (int)total);
     return check_launch("flash2_bf16_kernel");

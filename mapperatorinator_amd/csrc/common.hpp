@@ -18,7 +18,7 @@ void set_error(const char* fmt, ...);
 int check_launch(const char* what);
 
 // ---- tuning options (api.hip: default <- environment at first use <- mh_set_option at run time) ----
-enum { OPT_GEMM_SPLITK_TILES = 0, OPT_DECODE_CHAINS, OPT_DECODE_PREFILL, OPT_DECODE_GEMV_COLS, OPT_DECODE_FUSED_PROJ, OPT_GEMM_TILE128_MIN, OPT_DIT_SPLIT3_MIN_ROWS, OPT_GEMM_GLDS, OPT_DECODE_LAUNCH_THREADS, OPT_DECODE_GRAPH_CACHE, OPT_GEMM_TILE256SQ_MIN, OPT_GEMM_2STAGE_MAX_K, OPT_COUNT };
+enum { OPT_GEMM_SPLITK_TILES = 0, OPT_DECODE_CHAINS, OPT_DECODE_PREFILL, OPT_DECODE_GEMV_COLS, OPT_DECODE_FUSED_PROJ, OPT_GEMM_TILE128_MIN, OPT_DIT_SPLIT3_MIN_ROWS, OPT_GEMM_GLDS, OPT_DECODE_LAUNCH_THREADS, OPT_DECODE_GRAPH_CACHE, OPT_GEMM_TILE256SQ_MIN, OPT_GEMM_2STAGE_MAX_K, OPT_DIT_SKINNY_MAX_ROWS, OPT_COUNT };
 long option(int id);   // the calling thread's option set (OptionScope) first, then the process-wide value
 // RAII: the entry points that take a config install its option set for the calling thread; launcher threads re-install it
 struct OptionScope {

@@ -392,15 +392,22 @@ def test_batched_chunks_equal_independent_runs(variant):
 
     old = _lib.set_option("gemm_splitk_tiles", 0)
     old3 = _lib.set_option("dit_split3_min_rows", 0)         # exact-fp32 GEMMs on both sides
+    oldk = _lib.set_option("dit_skinny_max_rows", 0)         # ... and the LDS-tiled kernels for the single chunk too
     try:
         same_tiles_single = [run_single(b) for b in range(B)]
         same_tiles_batched = run_batched()
+        # the one-round-trip 16 x 16 kernels (round 5) at ANY row count: their summation order depends on K only
+        _lib.set_option("dit_skinny_max_rows", 1 << 30)
+        skinny_single = [run_single(b) for b in range(B)]
+        skinny_batched = run_batched()
     finally:
         _lib.set_option("gemm_splitk_tiles", old)
         _lib.set_option("dit_split3_min_rows", old3)
+        _lib.set_option("dit_skinny_max_rows", oldk)
     assert same_tiles_batched.shape == (B, 2, T)
     for b in range(B):
         assert torch.equal(same_tiles_batched[b], same_tiles_single[b]), f"chunk {b}: batched row differs from its own run"
+        assert torch.equal(skinny_batched[b], skinny_single[b]), f"chunk {b}: batched row differs from its own run (skinny kernels)"
     batched = run_batched()                       # default kernels: 2 B T = 2400 rows >= 2048 -> bf16 x 3 GEMMs, other tiles
     single = [run_single(b) for b in range(B)]
     err = max((batched[b] - single[b]).abs().max().item() for b in range(B))
