@@ -742,7 +742,7 @@ struct SmallAttnP {
 template <int KBW>
 __global__ __launch_bounds__(256) void attn_small_f32_kernel(SmallAttnP p) {
   constexpr int PW = KBW * 16 + 4;                 // P patch row stride (floats)
-  __shared__ float Ps[4][16][PW];
+  __shared__ __attribute__((aligned(16))) float Ps[4][16][PW];
   __shared__ float m_s[4][16], l_s[4][16];
   __shared__ __attribute__((aligned(16))) float O_s[4][16][64];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -750,25 +750,31 @@ __global__ __launch_bounds__(256) void attn_small_f32_kernel(SmallAttnP p) {
   const int q0 = blockIdx.x * 16, h = blockIdx.y, b = blockIdx.z;
   const int L = p.L;
   const int kbase = wid * KBW * 16;                // this wave's first key
-  const float* qrow = p.q + ((long)b * L + (q0 + l15 < L ? q0 + l15 : L - 1)) * p.ld_qk + h * 64 + lg;
+  // Round 5: 16-byte loads.  An MFMA does not care in which order its k slots enumerate the contraction index as long as both
+  // operands agree, so lane group lg takes the 16 CONSECUTIVE head dims lg*16 .. +15 of its q / k row (4 float4 instead of 16 dwords
+  // at a stride of 4) and, for P V, the KBW*4 CONSECUTIVE keys kbase + lg*KBW*4 .. of its V^T row (KBW float4 instead of KBW*4
+  // dwords): 5 KBW + 4 load instructions per lane instead of 20 KBW + 16 -- the kernel is a latency kernel whose time is the
+  // CU's load path (every strided dword instruction touches 16 lines for 256 bytes).
+  const float* qrow = p.q + ((long)b * L + (q0 + l15 < L ? q0 + l15 : L - 1)) * p.ld_qk + h * 64 + lg * 16;
   // operands: every load is independent of every other -- all requested before the first MFMA
-  float qf[16], kf[KBW][16], vf[4][KBW * 4];
+  float4 qf[4], kf[KBW][4], vf[4][KBW];
 #pragma unroll
-  for (int ks = 0; ks < 16; ++ks) qf[ks] = qrow[ks * 4];
+  for (int j = 0; j < 4; ++j) qf[j] = *reinterpret_cast<const float4*>(qrow + j * 4);
 #pragma unroll
   for (int kb = 0; kb < KBW; ++kb) {
     const int key = kbase + kb * 16 + l15;
-    const float* krow = p.k + ((long)b * L + (key < L ? key : L - 1)) * p.ld_qk + h * 64 + lg;
+    const float* krow = p.k + ((long)b * L + (key < L ? key : L - 1)) * p.ld_qk + h * 64 + lg * 16;
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) kf[kb][ks] = krow[ks * 4];
+    for (int j = 0; j < 4; ++j) kf[kb][j] = *reinterpret_cast<const float4*>(krow + j * 4);
   }
   const float* vtb = p.vt + (long)b * p.vt_bs + (long)h * p.vt_hs;
 #pragma unroll
   for (int db = 0; db < 4; ++db)
 #pragma unroll
-    for (int kk = 0; kk < KBW * 4; ++kk) {
-      const int key = kbase + kk * 4 + lg;
-      vf[db][kk] = vtb[(long)(db * 16 + l15) * p.Lpad + (key < L ? key : L - 1)];   // never a pad column (P is 0 there)
+    for (int j = 0; j < KBW; ++j) {    // keys kbase + lg*KBW*4 + j*4 .. +3, clamped into the padded row (Lpad % 64 == 0): columns >= L meet P = 0
+      int k4 = kbase + lg * KBW * 4 + j * 4;
+      k4 = k4 <= p.Lpad - 4 ? k4 : p.Lpad - 4;
+      vf[db][j] = *reinterpret_cast<const float4*>(vtb + (long)(db * 16 + l15) * p.Lpad + k4);
     }
   // S = scale * Q K^T with the band mask; C layout: col = l15 (key in block), row = lg*4 + r (query)
   const int rel_lo = p.band > 0 ? -(p.band - 1) : (p.band < 0 ? p.band : -(1 << 30));          // band 0 = open, < 0 = |k - q| <= -band
@@ -780,7 +786,12 @@ __global__ __launch_bounds__(256) void attn_small_f32_kernel(SmallAttnP p) {
   for (int kb = 0; kb < KBW; ++kb) {
     f32x4_t a = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) a = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[ks], kf[kb][ks], a, 0, 0, 0);
+    for (int j = 0; j < 4; ++j) {
+      a = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[j].x, kf[kb][j].x, a, 0, 0, 0);
+      a = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[j].y, kf[kb][j].y, a, 0, 0, 0);
+      a = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[j].z, kf[kb][j].z, a, 0, 0, 0);
+      a = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[j].w, kf[kb][j].w, a, 0, 0, 0);
+    }
     const int key = kbase + kb * 16 + l15;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -816,10 +827,15 @@ __global__ __launch_bounds__(256) void attn_small_f32_kernel(SmallAttnP p) {
 #pragma unroll
   for (int db = 0; db < 4; ++db) o[db] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int kk = 0; kk < KBW * 4; ++kk) {
-    const float pf = Ps[wid][l15][kk * 4 + lg];
+  for (int j = 0; j < KBW; ++j) {      // k slot lg of step (j, i) <-> key lg*KBW*4 + j*4 + i of this wave's range, for P and V alike
+    const float4 pf = *reinterpret_cast<const float4*>(&Ps[wid][l15][lg * KBW * 4 + j * 4]);
 #pragma unroll
-    for (int db = 0; db < 4; ++db) o[db] = __builtin_amdgcn_mfma_f32_16x16x4f32(pf, vf[db][kk], o[db], 0, 0, 0);
+    for (int db = 0; db < 4; ++db) {
+      o[db] = __builtin_amdgcn_mfma_f32_16x16x4f32(pf.x, vf[db][j].x, o[db], 0, 0, 0);
+      o[db] = __builtin_amdgcn_mfma_f32_16x16x4f32(pf.y, vf[db][j].y, o[db], 0, 0, 0);
+      o[db] = __builtin_amdgcn_mfma_f32_16x16x4f32(pf.z, vf[db][j].z, o[db], 0, 0, 0);
+      o[db] = __builtin_amdgcn_mfma_f32_16x16x4f32(pf.w, vf[db][j].w, o[db], 0, 0, 0);
+    }
   }
   if (l15 == 0) {
 #pragma unroll

@@ -263,6 +263,11 @@ void dit_skinny_kernel(DitSkinnyP p) {
   // picks it only when rows_per_batch % 32 == 0, i.e. a row block never straddles two batch entries)
   __shared__ f32x4_t red[NWV * MF * 64];
   __shared__ float st1[PRO == DSK_PRO_LNMOD ? NWV : 1][MF * 16], st2[PRO == DSK_PRO_LNMOD ? NWV : 1][MF * 16];
+  // LNMOD, MF = 2 (the workgroup's rows share ONE batch entry: host condition): the modulation vectors go through LDS -- one
+  // 16-byte load per thread instead of 2 CH float4 per lane held across the statistics (48 registers: 184 -> ~120, i.e. four
+  // resident workgroups per CU instead of two, and the 576 / 768 workgroups of the qkv / fc1 projections run in ONE round)
+  constexpr bool kModLds = PRO == DSK_PRO_LNMOD && MF == 2;
+  __shared__ __attribute__((aligned(16))) float modv[kModLds ? 2 * 16 * NWV * CH : 4];     // [scale | shift] over K <= 16 NWV CH
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l15 = lane & 15, lg = lane >> 4;
   const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16 * MF;
@@ -297,9 +302,15 @@ void dit_skinny_kernel(DitSkinnyP p) {
   f32x4_t acc[MF];
 #pragma unroll
   for (int f = 0; f < MF; ++f) acc[f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float4 mod_raw = make_float4(0.f, 0.f, 0.f, 0.f);
+  if constexpr (kModLds) {   // thread t < K/4: scale[4t .. 4t+3]; K/4 <= t < K/2: shift (K/2 <= NWV * 64 * ... : checked below)
+    const int t4 = tid * 4;
+    const float* src = (t4 < p.K ? p.scale + t4 : p.shift + (t4 - p.K < p.K ? t4 - p.K : 0)) + (long)batch_a[0] * p.mod_ld;
+    mod_raw = *reinterpret_cast<const float4*>(src);
+  }
   int kb0 = wid;
   do {   // ONE pass unless K > 16 NWV CH (LNMOD: checked on the host); every wave runs at least one (the barrier of the statistics)
-    float4 av[MF][CH], wv[CH], sc[PRO == DSK_PRO_LNMOD ? CH : 1], sh[PRO == DSK_PRO_LNMOD ? CH : 1];
+    float4 av[MF][CH], wv[CH], sc[(PRO == DSK_PRO_LNMOD && !kModLds) ? CH : 1], sh[(PRO == DSK_PRO_LNMOD && !kModLds) ? CH : 1];
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
       const int kb = kb0 + NWV * c;
@@ -307,7 +318,7 @@ void dit_skinny_kernel(DitSkinnyP p) {
 #pragma unroll
       for (int f = 0; f < MF; ++f) av[f][c] = *reinterpret_cast<const float4*>(Ap[f] + kel);
       wv[c] = *reinterpret_cast<const float4*>(Wp + kel);
-      if (PRO == DSK_PRO_LNMOD) {      // (MF = 2: both fragments belong to batch_a[0], see above)
+      if constexpr (PRO == DSK_PRO_LNMOD && !kModLds) {
         sc[c] = *reinterpret_cast<const float4*>(p.scale + (long)batch_a[0] * p.mod_ld + kel + lg * 4);
         sh[c] = *reinterpret_cast<const float4*>(p.shift + (long)batch_a[0] * p.mod_ld + kel + lg * 4);
       }
@@ -329,6 +340,9 @@ void dit_skinny_kernel(DitSkinnyP p) {
         s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
         if (lg == 0) { st1[wid][f * 16 + l15] = s1; st2[wid][f * 16 + l15] = s2; }
       }
+      if constexpr (kModLds) {
+        if (tid * 4 < 2 * p.K) *reinterpret_cast<float4*>(modv + tid * 4) = mod_raw;      // [0, K): scale, [K, 2K): shift
+      }
       __syncthreads();
 #pragma unroll
       for (int f = 0; f < MF; ++f) {
@@ -339,11 +353,19 @@ void dit_skinny_kernel(DitSkinnyP p) {
         const float rs = rsqrtf(fmaxf(t2 / (float)p.K - mu * mu, 0.f) + p.eps);
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
-          float4 x = av[f][c];
-          x.x = (x.x - mu) * rs * (1.f + sc[c].x) + sh[c].x;
-          x.y = (x.y - mu) * rs * (1.f + sc[c].y) + sh[c].y;
-          x.z = (x.z - mu) * rs * (1.f + sc[c].z) + sh[c].z;
-          x.w = (x.w - mu) * rs * (1.f + sc[c].w) + sh[c].w;
+          float4 x = av[f][c], qs, qh;
+          if constexpr (kModLds) {
+            const int kb = kb0 + NWV * c;
+            const int kel = (kb < nkb ? kb : nkb - 1) * 16 + lg * 4;
+            qs = *reinterpret_cast<const float4*>(modv + kel);
+            qh = *reinterpret_cast<const float4*>(modv + p.K + kel);
+          } else {
+            qs = sc[c]; qh = sh[c];
+          }
+          x.x = (x.x - mu) * rs * (1.f + qs.x) + qh.x;
+          x.y = (x.y - mu) * rs * (1.f + qs.y) + qh.y;
+          x.z = (x.z - mu) * rs * (1.f + qs.z) + qh.z;
+          x.w = (x.w - mu) * rs * (1.f + qs.w) + qh.w;
           av[f][c] = x;
         }
       }
@@ -416,6 +438,10 @@ int dit_skinny(const DitSkinnyP& p, hipStream_t s) {
     } else if (nkb <= 8 * 6) {
       if (mf2) hipLaunchKernelGGL((dit_skinny_kernel<8, 6, 2, PRO, EPI>), grid, dim3(512), 0, s, p);
       else hipLaunchKernelGGL((dit_skinny_kernel<8, 6, 1, PRO, EPI>), grid, dim3(512), 0, s, p);
+    } else if (nkb <= 16 * 6 && p.rows_per_batch % 32 == 0) {
+      // long K (fc2: K = 4 D), 32 rows x 16 columns per workgroup, SIXTEEN waves split K: 6 k-blocks per wave in one round trip
+      dim3 g2(ceil_div(p.N, 16), ceil_div(p.M, 32));
+      if constexpr (PRO == DSK_PRO_PLAIN) hipLaunchKernelGGL((dit_skinny_kernel<16, 6, 2, PRO, EPI>), g2, dim3(1024), 0, s, p);
     } else {
       if (mf2) hipLaunchKernelGGL((dit_skinny_kernel<8, 12, 2, PRO, EPI>), grid, dim3(512), 0, s, p);
       else hipLaunchKernelGGL((dit_skinny_kernel<8, 12, 1, PRO, EPI>), grid, dim3(512), 0, s, p);
@@ -633,20 +659,12 @@ int dit_body(const MhDiTConfig* c, const MhDiTWeights* w, const float* x, const 
     q.A = b.xs; q.lda = D; q.W = w->fc1_w[l]; q.ldw = D; q.bias = w->fc1_b[l]; q.M = NT; q.N = 4 * D; q.K = D; q.rows_per_batch = T;
     q.shift = mod + 3 * D; q.scale = mod + 4 * D; q.mod_ld = ld_row; q.eps = 1e-6f; q.out = b.hid; q.ldo = 4 * D;
     MH_TRY((dit_skinny<DSK_PRO_LNMOD, DSK_EPI_GELU>(q, s)));
-    if (option(OPT_DIT_SKINNY_MAX_ROWS) >= (1 << 20)) {   // (tests: every GEMM on the skinny kernels -- rows then add up in an order that depends on K only)
-      q = DitSkinnyP{};
-      q.A = b.hid; q.lda = 4 * D; q.W = w->fc2_w[l]; q.ldw = 4 * D; q.bias = w->fc2_b[l]; q.M = NT; q.N = D; q.K = 4 * D; q.rows_per_batch = T;
-      q.xs = b.xs; q.ldx = D; q.gate = mod + 5 * D; q.gate_ld = ld_row;
-      MH_TRY((dit_skinny<DSK_PRO_PLAIN, DSK_EPI_GATE>(q, s)));
-    } else {
-      // fc2 (K = 4 D): a 16-column tile would pull 2 x 16 x 4 D floats per workgroup through the CU's load path for 16 x 16 outputs
-      // (measured 13.4 us against 10.5 us for the LDS-tiled split-K kernel) -- it stays on the tiled GEMM
-      g = MhGemm{};
-      g.A = b.hid; g.lda = 4 * D; g.ldw = 4 * D; g.C = b.xs; g.ldc = D; g.M = NT; g.N = D; g.K = 4 * D;
-      g.bias = w->fc2_b[l]; g.gate = mod + 5 * D; g.gate_ld = ld_row; g.rows_per_batch = T; g.dtype = MH_F32;
-      g.epilogue = MH_EPI_GATE_RESID; g.W = w->fc2_w[l];
-      MH_TRY(gemm(g, s));
-    }
+    // fc2 (K = 4 D): 32 rows x 16 columns per workgroup, sixteen waves split K (6 k-blocks each: still one round trip); a 16-row tile
+    // on eight waves measured 13.4 us and the LDS-tiled split-K kernel 12.3 us against ~10 us for this form (62.1 -> 60.3 ms per 100 steps)
+    q = DitSkinnyP{};
+    q.A = b.hid; q.lda = 4 * D; q.W = w->fc2_w[l]; q.ldw = 4 * D; q.bias = w->fc2_b[l]; q.M = NT; q.N = D; q.K = 4 * D; q.rows_per_batch = T;
+    q.xs = b.xs; q.ldx = D; q.gate = mod + 5 * D; q.gate_ld = ld_row;
+    MH_TRY((dit_skinny<DSK_PRO_PLAIN, DSK_EPI_GATE>(q, s)));
   }
   for (int l = 0; l < c->depth && !lowp && !lowp8 && !s3g && !skinny; ++l) {
     const float* mod = b.cond_cur + (long)l * 6 * D;
