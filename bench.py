@@ -666,11 +666,15 @@ def main():
                         return kv_
                     enc_step()
                     torch.cuda.synchronize(dev)
-                    t0 = time.perf_counter()
-                    for _ in range(5):
+                    # median of per-iteration times: ONE stalled launch in a 5-iteration average made this line read 20 ms for a
+                    # 14 ms stage once (round 5; the same build measures 12.5 ms three times in a row in tools/mx8_encoder_pmc.py)
+                    its = []
+                    for _ in range(7):
+                        t0 = time.perf_counter()
                         enc_step()
-                    torch.cuda.synchronize(dev)
-                    per[mode or "bf16"] = (time.perf_counter() - t0) / 5
+                        torch.cuda.synchronize(dev)
+                        its.append(time.perf_counter() - t0)
+                    per[mode or "bf16"] = sorted(its)[len(its) // 2]
                     del mm, em
                 Lr = B * SRC_FRAMES
                 gemm_fl = 2.0 * Lr * (dz.n_enc_layers * (4 * dz.d_model * dz.inner + 3 * dz.d_model * dz.d_ff) + dz.n_dec_layers * 2 * dz.inner * dz.d_model)
