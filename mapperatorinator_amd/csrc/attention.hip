@@ -47,8 +47,21 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(AttnArgs p) {
     int qr = q0w + l15;
     qr = qr < Lq ? qr : Lq - 1;
     const char* qp = (const char*)p.q + (long)b * p.q_bs + (long)qr * p.q_rs + (long)(h * 64 + lg * KCH) * ES;
+    if constexpr (sizeof(T) == 4) {
+      // fp32 (round 5): k slot lg of MFMA step (k16, i) <-> contraction index k16*16 + lg*4 + i -- for BOTH operands of a product, so
+      // the sum is the same set of terms in another order, and every fragment of four steps is ONE 16-byte access (global here,
+      // ds_read_b128 below) instead of four 4-byte ones: 36 LDS reads per 128 MFMAs of a key tile instead of 144
+      const char* qv = (const char*)p.q + (long)b * p.q_bs + (long)qr * p.q_rs + (long)(h * 64 + lg * 4) * ES;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) qf[ks] = Atom<T>::load(reinterpret_cast<const T*>(qp + ks * KM * ES));
+      for (int k16 = 0; k16 < 4; ++k16) {
+        const float4 t = *reinterpret_cast<const float4*>(qv + k16 * 64);
+        reinterpret_cast<float*>(qf)[k16 * 4 + 0] = t.x; reinterpret_cast<float*>(qf)[k16 * 4 + 1] = t.y;
+        reinterpret_cast<float*>(qf)[k16 * 4 + 2] = t.z; reinterpret_cast<float*>(qf)[k16 * 4 + 3] = t.w;
+      }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) qf[ks] = Atom<T>::load(reinterpret_cast<const T*>(qp + ks * KM * ES));
+    }
   }
 
   f32x4_t o[4];
@@ -118,6 +131,18 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(AttnArgs p) {
     f32x4_t s[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) s[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    if constexpr (sizeof(T) == 4) {
+#pragma unroll
+      for (int k16 = 0; k16 < 4; ++k16)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float4 kf = *reinterpret_cast<const float4*>(Ks + (j * 16 + l15) * RS + (k16 * 16 + lg * 4) * 4);
+          s[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(reinterpret_cast<const float*>(qf)[k16 * 4 + 0], kf.x, s[j], 0, 0, 0);
+          s[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(reinterpret_cast<const float*>(qf)[k16 * 4 + 1], kf.y, s[j], 0, 0, 0);
+          s[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(reinterpret_cast<const float*>(qf)[k16 * 4 + 2], kf.z, s[j], 0, 0, 0);
+          s[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(reinterpret_cast<const float*>(qf)[k16 * 4 + 3], kf.w, s[j], 0, 0, 0);
+        }
+    } else {
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
@@ -126,6 +151,7 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(AttnArgs p) {
             Atom<T>::load(reinterpret_cast<const T*>(Ks + (j * 16 + l15) * RS + (ks * KM + lg * KCH) * ES));
         s[j] = Atom<T>::mma(qf[ks], kf, s[j]);
       }
+    }
     }
 
     // ---- scale, bias, mask, online softmax ----
@@ -215,6 +241,20 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(AttnArgs p) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
     // ---- O += P V ----
+    if constexpr (sizeof(T) == 4) {
+#pragma unroll
+      for (int k16 = 0; k16 < 4; ++k16) {
+        const float4 pf = *reinterpret_cast<const float4*>(Pw + l15 * RS + (k16 * 16 + lg * 4) * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float4 vf = *reinterpret_cast<const float4*>(Vts + (j * 16 + l15) * RS + (k16 * 16 + lg * 4) * 4);
+          o[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(pf.x, vf.x, o[j], 0, 0, 0);
+          o[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(pf.y, vf.y, o[j], 0, 0, 0);
+          o[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(pf.z, vf.z, o[j], 0, 0, 0);
+          o[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(pf.w, vf.w, o[j], 0, 0, 0);
+        }
+      }
+    } else {
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       typename Atom<T>::frag_t pf =
@@ -225,6 +265,7 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(AttnArgs p) {
             Atom<T>::load(reinterpret_cast<const T*>(Vts + (j * 16 + l15) * RS + (ks * KM + lg * KCH) * ES));
         o[j] = Atom<T>::mma(pf, vf, o[j]);
       }
+    }
     }
     __syncthreads();
   }

@@ -400,6 +400,32 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmP p) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
           }
+      } else if constexpr (std::is_same<T, float>::value && !GL) {
+        // fp32 (round 5): k slot lg of MFMA step (g, e) <-> k index g*16 + lg*4 + e of the K step, for BOTH operands: the same products
+        // in another order, and the fragments of four MFMA steps are ONE ds_read_b128 each instead of four ds_read_b32 (2 reads per
+        // 16x16x4 MFMA were the inner loop's issue bound).  Every fp32 tile shape enumerates k this way, so `ascending_k` keeps
+        // its meaning: one summation order whatever the row count.
+        static_assert(kKsW % 4 == 0, "groups of four k steps");
+        const char* a4 = smem + cur * kBufBytes + (wr * WM + frow) * kRowStride + (lane >> 4) * 16;
+        const char* b4 = smem + cur * kBufBytes + (BM + wc * WN + frow) * kRowStride + (lane >> 4) * 16;
+#pragma unroll
+        for (int gq = 0; gq < kKsW / 4; ++gq) {
+          const int g = ks0 / 4 + gq;
+          float4 af[MI], bf[NI];
+#pragma unroll
+          for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const float4*>(a4 + i * 16 * kRowStride + g * 64);
+#pragma unroll
+          for (int j = 0; j < NI; ++j) bf[j] = *reinterpret_cast<const float4*>(b4 + j * 16 * kRowStride + g * 64);
+#pragma unroll
+          for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+            }
+        }
       } else
 #pragma unroll
       for (int kq = 0; kq < kKsW; ++kq) {
