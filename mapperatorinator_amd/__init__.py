@@ -25,7 +25,8 @@ def __getattr__(name):  # torch-dependent pieces are imported lazily
     if name in ("encode_events", "decode_tokens"):
         from . import tokenizer
         return getattr(tokenizer, name)
-    if name in ("DiffusionPipelineHIP", "points_to_sequence"):
+    if name in ("DiffusionPipelineHIP", "points_to_sequence", "events_to_sequence", "events_with_pos", "DiffusionTokenizer",
+                "DiffusionGenerationConfig", "get_class_vector"):
         from . import diffusion_pipeline
         return getattr(diffusion_pipeline, name)
     if name in ("SequentialWindowScheduler", "SongJob"):

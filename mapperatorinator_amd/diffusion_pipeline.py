@@ -10,10 +10,18 @@ loop (K7-K9).  Integer / indexing logic on the host, every float of the hot loop
                        window loop (:276-284), per-window in-paint mask incl. start_time / end_time (:223-234),
                        `p_sample_loop` (:243-252), the refine iterations (:254-267) and `to_positions` (:171-176)
 
-Grouping Events into hit-object points (`get_groups`, `update_event_times`) and writing positions back into Events
-(`events_with_pos`) is the reference's own integer host code either side of this seam and stays there; the
-`DiffusionSlider` list it builds (:389-437) is handed in as `sliders` and the slider end re-projection of `denoised_fn`
-(:208-220) runs on the device inside the DDPM graph (csrc/slider.hip).  `pad_sequence=True` (:186-193) is reproduced with
+Round 5: the integer host code either side of that seam is here too, so the stage is callable with the reference's own
+signature `generate(events, generation_config, timing) -> events`:
+
+  event_times          `update_event_times` (osuT5/osuT5/dataset/data_utils.py:724-804): the time of every event,
+                       anchor events interpolated between the timed events around them
+  group_events         `get_groups` (data_utils.py:907-979): events -> hit-object records + the event indices of each
+  events_to_sequence   (diffusion_pipeline.py:289-438) records -> points, `seq_indices`, the DiffusionSlider list
+  events_with_pos      (:447-469) positions written back as POS_X / POS_Y events
+  get_class_vector     (:65-109) the multi-hot class vector of a GenerationConfig
+All of it pinned against the reference's functions run here (`tests/golden/events_to_sequence.npz`, made by
+`oracle/make_golden.py events`).  The slider end re-projection of `denoised_fn` (:208-220) runs on the device inside the DDPM
+graph (csrc/slider.hip).  `pad_sequence=True` (:186-193) is reproduced with
 the reference's own quirk: the pad positions stay attendable (the attention kernels' `open_from`).
 """
 from __future__ import annotations
@@ -88,13 +96,340 @@ def band_mask(T: int, seq_len: int, device="cpu") -> torch.Tensor:
     return ~((q >= k - seq_len) & (q < k + seq_len))
 
 
+# ---- events <-> points: the integer host code either side of the diffusion stage -------------------------------------
+# Event classes by NAME, so the reference's own Event / EventType objects and ours (mapperatorinator_amd.event) both work.
+_ANCHORS = frozenset(("BEZIER_ANCHOR", "PERFECT_ANCHOR", "CATMULL_ANCHOR", "RED_ANCHOR"))            # data_utils.py:53-58
+_TIMED = frozenset(("CIRCLE", "SPINNER", "SPINNER_END", "SLIDER_HEAD", "LAST_ANCHOR", "SLIDER_END", "BEAT", "MEASURE",
+                    "TIMING_POINT", "KIAI", "HOLD_NOTE", "HOLD_NOTE_END", "DRUMROLL", "DRUMROLL_END", "DENDEN",
+                    "DENDEN_END", "SCROLL_SPEED_CHANGE"))                                             # data_utils.py:60-78
+_OBJECT_TYPES = _TIMED | _ANCHORS                                                                     # TYPE_EVENTS, :29-51
+_CURVE_OF_ANCHOR = {"BEZIER_ANCHOR": "Bezier", "PERFECT_ANCHOR": "PerfectCurve", "CATMULL_ANCHOR": "Catmull",
+                    "RED_ANCHOR": "Bezier", "LAST_ANCHOR": "Bezier"}
+
+
+def event_times(events: Sequence, types_first: bool = False, end_time: Optional[float] = None) -> list:
+    """Time of every event of a whole stream = `update_event_times(events, [], end_time, types_first)`
+    (data_utils.py:724-804).  Two sweeps.  (1) carry: an event takes the value of the TIME_SHIFT that governs its group --
+    the latest one at or before it, or with `types_first` the one right behind the type token.  (2) anchors have no
+    TIME_SHIFT of their own: walking AGAINST the group order (backwards; forwards with `types_first`) from the timed
+    event that follows the anchors in time, the k anchors still ahead of the walk split the remaining interval evenly,
+    truncated to int at every anchor (so the truncations compound exactly like the reference's); the attribute events
+    of an anchor group take the anchor's time."""
+    n = len(events)
+    name = [e.type.name for e in events]
+    times, now = [], 0
+    for i in range(n):
+        if types_first:
+            if i + 1 < n and name[i + 1] == "TIME_SHIFT":
+                now = events[i + 1].value
+        elif name[i] == "TIME_SHIFT":
+            now = events[i].value
+        times.append(now)
+    if n == 0:
+        return times
+    # for every position: where the nearest TIME_SHIFT lies on the far side of the walk, and how many anchors sit between
+    walk = range(n) if types_first else range(n - 1, -1, -1)
+    far_shift, anchors_to_shift = [None] * n, [0] * n
+    shift_at, run = None, 0
+    for i in reversed(walk):                       # from the far side towards the walk's start
+        if name[i] == "TIME_SHIFT":
+            shift_at, run = i, 0
+        elif name[i] in _ANCHORS:
+            run += 1
+        far_shift[i], anchors_to_shift[i] = shift_at, run
+    edge_time = (end_time if end_time is not None else times[-1]) if types_first else 0
+    now = times[0] if types_first else (end_time if end_time is not None else times[-1])
+    inside_anchor_run = False
+    for i in walk:
+        if name[i] in _TIMED:
+            inside_anchor_run = False
+        elif name[i] in _ANCHORS:
+            inside_anchor_run = True
+        if not inside_anchor_run:
+            now = times[i]
+        elif name[i] in _ANCHORS:
+            k = anchors_to_shift[i]
+            far = times[far_shift[i]] if far_shift[i] is not None else edge_time
+            now = int((now - far) / (k + 1) * k + far)
+            times[i] = now
+        else:
+            times[i] = now
+    return times
+
+
+@dataclass
+class HitObjectRecord:
+    """The fields of the reference's `Group` (data_utils.py:907-919) that the diffusion stage reads."""
+    type_name: Optional[str] = None
+    time: float = 0
+    distance: Optional[float] = None
+    x: Optional[float] = None
+    y: Optional[float] = None
+    new_combo: bool = False
+    scroll_speed: Optional[float] = None
+
+
+def group_events(events: Sequence, times: Optional[Sequence] = None, types_first: bool = False):
+    """`get_groups` (data_utils.py:922-979): one record per object-type event, with the attribute events that belong to it
+    (before the type token; behind it with `types_first`), and the event indices of every record.  Attribute events
+    that no type token claims join the last record (IndexError when there is none, like the reference)."""
+    records, members = [], []
+    cur, idx = HitObjectRecord(), []
+    for i, e in enumerate(events):
+        nm = e.type.name
+        idx.append(i)
+        if nm in _OBJECT_TYPES:
+            if types_first and cur.type_name is not None:
+                records.append(cur)
+                members.append(idx[:-1])
+                cur, idx = HitObjectRecord(), [i]
+            cur.type_name = nm
+            if times is not None:
+                cur.time = times[i]
+            if not types_first:
+                records.append(cur)
+                members.append(idx)
+                cur, idx = HitObjectRecord(), []
+        elif nm == "TIME_SHIFT":
+            cur.time = e.value
+        elif nm == "DISTANCE":
+            cur.distance = e.value
+        elif nm == "POS_X":
+            cur.x = e.value
+        elif nm == "POS_Y":
+            cur.y = e.value
+        elif nm == "NEW_COMBO":
+            cur.new_combo = True
+        elif nm == "SCROLL_SPEED":
+            cur.scroll_speed = e.value / 100
+    if cur.type_name is not None:
+        records.append(cur)
+        members.append(idx)
+    elif idx:
+        members[-1].extend(idx)
+    return records, members
+
+
+def timing_point_at(time, timing_points: Sequence):
+    """(diffusion_pipeline.py:440-445) the last timing point at or before `time` (a timedelta), else the first."""
+    hit = [tp for tp in timing_points if tp.offset <= time]
+    return hit[-1] if hit else timing_points[0]
+
+
+def events_to_sequence(events: Sequence, timing: Optional[Sequence], slider_multiplier: float, *,
+                       types_first: bool = False, has_sv: bool = True):
+    """(diffusion_pipeline.py:289-438) -> (seq_x (2,T), seq_o (T,), seq_c (272,T), T, seq_indices {event index -> point},
+    [DiffusionSlider]).  Every record whose type has a row in EVENT_INDEX becomes a point; events of other records
+    (beats, timing points ...) map to the NEXT point, trailing ones to the last.  Kept quirks: a coordinate of 0 counts
+    as "no position" and moves the point to the playfield centre (`not group.x`), a distance of 0 is re-derived from
+    the previous point; an empty stream returns `(zeros(2,0), zeros(1,0), zeros(1,0), 0, {}, [])`.
+    `timing`: objects with `.offset` (timedelta), `.ms_per_beat`, `.parent` (slider.TimingPoint); `types_first` /
+    `has_sv` are `args.train.data.types_first` / `.add_sv`."""
+    from datetime import timedelta
+    times = event_times(events, types_first=types_first)
+    records, members = group_events(events, times, types_first=types_first)
+    seq_indices, waiting = {}, []
+    px, py, pt, pd, prow = [], [], [], [], []
+    head_time = last_anchor_time = 0
+    prev = (256, 192)
+    for rec, idx in zip(records, members):
+        waiting.extend(idx)
+        row = EVENT_INDEX.get(rec.type_name)
+        if row is None:
+            continue
+        if rec.new_combo and rec.type_name in ("CIRCLE", "SLIDER_HEAD"):
+            row += 1
+        if rec.type_name == "SLIDER_END":
+            span, total = last_anchor_time - head_time, rec.time - head_time
+            row += repeat_type(max(int(round(total / span)), 1) if span > 0 else 1)
+        elif rec.type_name == "SLIDER_HEAD":
+            head_time = rec.time
+        elif rec.type_name == "LAST_ANCHOR":
+            last_anchor_time = rec.time
+        if not rec.x or not rec.y:
+            rec.x, rec.y = 256, 192
+        if not rec.distance:
+            rec.distance = ((rec.x - prev[0]) ** 2 + (rec.y - prev[1]) ** 2) ** 0.5
+        px.append(rec.x), py.append(rec.y), pt.append(rec.time), pd.append(rec.distance), prow.append(row)
+        for j in waiting:
+            seq_indices[j] = len(px) - 1
+        waiting = []
+        prev = (rec.x, rec.y)
+    for j in waiting:
+        seq_indices[j] = len(px) - 1
+    if not px:
+        return torch.zeros(2, 0), torch.zeros(1, 0), torch.zeros(1, 0), 0, {}, []
+    seq_x, seq_o, seq_c = points_to_sequence(px, py, pt, pd, prow)
+
+    sliders = []
+    if has_sv and timing is not None:
+        head = last = None
+        path = []                                   # (curve name, point) of head, anchors (a red anchor twice), last anchor
+        for rec, idx in zip(records, members):
+            point = None if rec.type_name not in _CURVE_OF_ANCHOR and rec.type_name != "SLIDER_HEAD" else seq_indices[idx[0]]
+            if rec.type_name == "SLIDER_HEAD":
+                head, last, path = rec, None, [("Bezier", point)]
+            elif rec.type_name in _CURVE_OF_ANCHOR:
+                path += [(_CURVE_OF_ANCHOR[rec.type_name], point)] * (2 if rec.type_name == "RED_ANCHOR" else 1)
+                if rec.type_name == "LAST_ANCHOR":
+                    last = rec
+            elif rec.type_name == "SLIDER_END" and head is not None and last is not None:
+                tp = timing_point_at(timedelta(milliseconds=int(round(head.time))), timing)
+                redline = tp if tp.parent is None else tp.parent
+                if head.scroll_speed is not None:
+                    length = head.scroll_speed * (last.time - head.time) * 100 / redline.ms_per_beat * slider_multiplier
+                    sliders.append(DiffusionSlider(np.array([pt_ for _, pt_ in path]), seq_indices[idx[0]], path[1][0], length))
+                head, last, path = None, None, []
+    return seq_x, seq_o, seq_c, len(px), seq_indices, sliders
+
+
+def events_with_pos(events: Sequence, positions: torch.Tensor, seq_indices: dict) -> list:
+    """(diffusion_pipeline.py:447-469) positions (2, T) in playfield pixels -> the event stream with every DISTANCE
+    event replaced by POS_X, POS_Y and every POS_X / POS_Y refreshed, rounded half-to-even like `int(round(.))`.  The new
+    events are of the class of the events handed in (the reference's or ours)."""
+    if not events:
+        return []
+    Ev, ET = type(events[0]), type(events[0].type)
+    xy = positions.detach().cpu().tolist()
+    out = []
+    for i, e in enumerate(events):
+        nm = e.type.name
+        if nm == "DISTANCE":
+            out += [Ev(ET["POS_X"], int(round(xy[0][seq_indices[i]]))), Ev(ET["POS_Y"], int(round(xy[1][seq_indices[i]])))]
+        elif nm in ("POS_X", "POS_Y"):
+            out.append(Ev(ET[nm], int(round(xy[0 if nm == "POS_X" else 1][seq_indices[i]]))))
+        else:
+            out.append(e)
+    return out
+
+
+class DiffusionTokenizer:
+    """The class vocabulary of the diffusion model: `osu_diffusion.utils.tokenizer.Tokenizer` (tokenizer.py:11-118, 216-250)
+    restated from its saved state (`tokenizer.pkl` beside the checkpoint is that state dict, inference.py:626-635), so
+    the stage runs without the reference package.  Token layout: [styles | difficulties | mappers | descriptors | circle
+    sizes], the last id of every family = "unknown".  Kept as they are: `encode_mapper` takes a BEATMAP id and looks its
+    mapper up (the pipeline hands it `mapper_id`, diffusion_pipeline.py:84); an unknown descriptor name encodes one PAST the
+    family's unknown id."""
+    _FAMILIES = ("num_classes", "num_diff_classes", "num_mapper_classes", "num_descriptor_classes", "num_cs_classes")
+    _TABLES = ("beatmap_idx", "beatmap_mapper", "mapper_idx", "beatmap_descriptors", "descriptor_idx")
+
+    def __init__(self, state_dict: Optional[dict] = None):
+        for k in self._FAMILIES:
+            setattr(self, k, 0)
+        for k in self._TABLES:
+            setattr(self, k, {})
+        self.max_difficulty = 0
+        if state_dict is not None:
+            self.load_state_dict(state_dict)
+
+    def load_state_dict(self, state_dict: dict) -> None:
+        for k in ("beatmap_idx", "num_classes", "num_diff_classes", "max_difficulty"):       # required (tokenizer.py:232-235)
+            setattr(self, k, state_dict[k])
+        for k in self._FAMILIES[2:] + self._TABLES[1:]:
+            if k in state_dict:
+                setattr(self, k, state_dict[k])
+
+    def state_dict(self) -> dict:
+        return {k: getattr(self, k) for k in self._FAMILIES + self._TABLES + ("max_difficulty",)}
+
+    def _base(self, family: int) -> int:
+        return sum(getattr(self, k) for k in self._FAMILIES[:family])
+
+    def _unk(self, family: int) -> int:
+        return self._base(family + 1) - 1
+
+    @staticmethod
+    def _bucket(value: float, n: int, full_scale: float) -> int:
+        return min(max(int(value * (n - 2) / full_scale), 0), n - 2)
+
+    num_tokens = property(lambda self: self._base(5))
+    style_unk = property(lambda self: self._unk(0))
+    diff_unk = property(lambda self: self._unk(1))
+    mapper_unk = property(lambda self: self._unk(2))
+    descriptor_unk = property(lambda self: self._unk(3))
+    cs_unk = property(lambda self: self._unk(4))
+
+    def encode_style(self, beatmap_id: int) -> int:
+        return self.beatmap_idx.get(beatmap_id, self.style_unk)
+
+    def encode_diff(self, diff: float) -> int:
+        return self._base(1) + self._bucket(diff, self.num_diff_classes, self.max_difficulty)
+
+    def encode_mapper_id(self, user_id: int) -> int:
+        return self._base(2) + self.mapper_idx.get(user_id, self.num_mapper_classes - 1)
+
+    def encode_mapper(self, beatmap_id: int) -> int:
+        return self.encode_mapper_id(self.beatmap_mapper.get(beatmap_id, -1))
+
+    def encode_descriptor_idx(self, descriptor_idx: int) -> int:
+        return self._base(3) + descriptor_idx
+
+    def encode_descriptor_name(self, descriptor: str) -> int:
+        return self.encode_descriptor_idx(self.descriptor_idx.get(descriptor, self.num_descriptor_classes))
+
+    def encode_descriptor(self, beatmap_id: int) -> list:
+        return [self.encode_descriptor_idx(i)
+                for i in self.beatmap_descriptors.get(beatmap_id, [self.num_descriptor_classes - 1])]
+
+    def encode_cs(self, cs: float) -> int:
+        return self._base(4) + self._bucket(cs, self.num_cs_classes, 10)
+
+
+def get_class_vector(tokenizer, config) -> torch.Tensor:
+    """(diffusion_pipeline.py:65-109) multi-hot class vector of a GenerationConfig over the osu_diffusion Tokenizer's
+    classes (the tokenizer object is the one pickled beside the checkpoint; only its attributes are read).  An
+    unknown / missing value selects the family's `*_unk` class; the messages of the reference are kept."""
+    v = torch.zeros(tokenizer.num_tokens)
+    families = (("num_classes", "beatmap_id", "encode_style", "style_unk", "beatmap_idx", "Beatmap"),
+                ("num_diff_classes", "difficulty", "encode_diff", "diff_unk", None, None),
+                ("num_mapper_classes", "mapper_id", "encode_mapper", "mapper_unk", "mapper_idx", "Mapper"),
+                ("num_cs_classes", "circle_size", "encode_cs", "cs_unk", None, None))
+    for count, field, encode, unk, known, label in families:
+        if getattr(tokenizer, count) <= 0:
+            continue
+        value = getattr(config, field, None)
+        if value is None:
+            v[getattr(tokenizer, unk)] = 1
+            continue
+        v[getattr(tokenizer, encode)(value)] = 1
+        if known is not None and value not in getattr(tokenizer, known):
+            print(f"{label} class {value} not found. Using default.")
+    if tokenizer.num_descriptor_classes > 0:
+        names = getattr(config, "descriptors", None)
+        found = [d for d in names or () if d in tokenizer.descriptor_idx]
+        if names and not found:
+            print("Descriptor classes not found. Using default.")
+        for d in names or ():
+            if found and d not in tokenizer.descriptor_idx:
+                print(f"Descriptor class {d} not found. Skipping.")
+        if found:
+            v[[tokenizer.encode_descriptor_name(d) for d in found]] = 1
+        else:
+            v[tokenizer.descriptor_unk] = 1
+    return v
+
+
+@dataclass
+class DiffusionGenerationConfig:
+    """The fields of the reference's GenerationConfig (osuT5/osuT5/inference/processor.py:26-43) this stage reads; any
+    object with these attributes (the reference's own included) is accepted by `generate`."""
+    beatmap_id: Optional[int] = None
+    difficulty: Optional[float] = None
+    mapper_id: Optional[int] = None
+    circle_size: Optional[float] = None
+    slider_multiplier: float = 1.4
+    descriptors: Optional[Sequence] = None
+    negative_descriptors: Optional[Sequence] = None
+
+
 class DiffusionPipelineHIP:
     """Same knobs as the reference object (diffusion_pipeline.py:40-63 / config.py:98-106)."""
 
     def __init__(self, model: DiTHIP, *, timesteps, diffusion_steps: int = 1000, noise_schedule: str = "squaredcos_cap_v2",
                  seq_len: int = 128, max_seq_len: int = 1024, overlap_buffer: int = 128, cfg_scale: float = 1.0,
                  refine_model: Optional[DiTHIP] = None, refine_iters: int = 10, random_init: bool = False,
-                 pad_sequence: bool = False, start_time: Optional[float] = None, end_time: Optional[float] = None):
+                 pad_sequence: bool = False, start_time: Optional[float] = None, end_time: Optional[float] = None,
+                 tokenizer=None, types_first: bool = False, has_sv: bool = True):
         # pad_sequence (reference diffusion_pipeline.py:186-193) pads every window to max_seq_len with zero positions and zero
         # context, pads the band mask with "allowed" and builds a key_padding_mask -- which DiTBlock.forward never hands to
         # its attention (models.py:133-150): every real query then attends all the pad tokens, so padding CHANGES the real
@@ -108,6 +443,32 @@ class DiffusionPipelineHIP:
         self.seq_len, self.max_seq_len, self.overlap_buffer = seq_len, max_seq_len, overlap_buffer
         self.cfg_scale, self.refine_iters, self.random_init = cfg_scale, refine_iters, random_init
         self.start_time, self.end_time, self.pad_sequence = start_time, end_time, bool(pad_sequence)
+        # what `generate` needs on top: the osu_diffusion Tokenizer pickled beside the checkpoint (class vectors) and the two
+        # stream-format flags of the T5 stage (`args.train.data.types_first` / `.add_sv`, diffusion_pipeline.py:58-62)
+        self.tokenizer, self.types_first, self.has_sv = tokenizer, bool(types_first), bool(has_sv)
+
+    @torch.no_grad()
+    def generate(self, events: Sequence, generation_config, timing: Optional[Sequence], verbose: bool = False,
+                 noise_source: Optional[Callable] = None) -> list:
+        """The reference's `DiffisionPipeline.generate` (diffusion_pipeline.py:111-287), same arguments and result:
+        events with DISTANCE events -> events with POS_X / POS_Y events.  `generation_config` is read for
+        `slider_multiplier`, the class fields of `get_class_vector`, and `negative_descriptors` (the null-class row of
+        the guidance pair keeps difficulty and circle size, :151-155)."""
+        seq_x, seq_o, seq_c, n, seq_indices, sliders = events_to_sequence(
+            events, timing, generation_config.slider_multiplier, types_first=self.types_first, has_sv=self.has_sv)
+        if verbose:
+            print(f"seq len {n}")
+        if n == 0:
+            return events
+        if self.tokenizer is None:
+            raise ValueError("DiffusionPipelineHIP.generate needs the osu_diffusion tokenizer (class vectors)")
+        null_config = DiffusionGenerationConfig(difficulty=getattr(generation_config, "difficulty", None),
+                                       descriptors=getattr(generation_config, "negative_descriptors", None),
+                                       circle_size=getattr(generation_config, "circle_size", None))
+        positions = self.generate_positions(seq_x, seq_o, seq_c, get_class_vector(self.tokenizer, generation_config),
+                                            get_class_vector(self.tokenizer, null_config), noise_source=noise_source,
+                                            sliders=sliders)
+        return events_with_pos(events, positions.squeeze(0), seq_indices)
 
     def to_positions(self, samples: torch.Tensor) -> torch.Tensor:
         """(:171-176) drop the null-class half, [-1, 1] -> playfield pixels, to the CPU.  (2B, 2, T) -> (B, 2, T)"""

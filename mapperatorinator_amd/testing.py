@@ -9,6 +9,10 @@ own initialisers (modeling_mapperatorinator.py:123-128: nn.Linear default, Embed
 """
 from __future__ import annotations
 
+import dataclasses
+import datetime
+from typing import Optional
+
 import numpy as np
 import torch
 
@@ -307,3 +311,127 @@ def pipeline_windows(seq_len: int, max_seq_len: int, overlap_buffer: int):
     """(start, end) of every diffusion window (reference diffusion_pipeline.py:277-278)."""
     return [(i, min(i + max_seq_len, seq_len))
             for i in range(0, seq_len - overlap_buffer * 2, max_seq_len - overlap_buffer * 2)]
+
+
+@dataclasses.dataclass
+class TimingPointLike:
+    """The attributes of `slider.TimingPoint` that the diffusion stage reads (diffusion_pipeline.py:423-424, 440-445)."""
+    offset: datetime.timedelta
+    ms_per_beat: float
+    parent: Optional["TimingPointLike"] = None
+
+
+def synthetic_timing(seed: int, span_ms: float = 60000.0):
+    """Three uninherited timing points, each followed by an inherited one (`parent` set) a little later."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for k in range(3):
+        red = TimingPointLike(datetime.timedelta(milliseconds=int(span_ms * k / 3) + (137 if k else 0)), float(rng.uniform(280, 520)))
+        out.append(red)
+        out.append(TimingPointLike(red.offset + datetime.timedelta(milliseconds=int(rng.integers(500, 4000))), -100.0 / float(rng.uniform(0.5, 2.0)), red))
+    return out
+
+
+def synthetic_event_stream(n_objects: int, seed: int, *, types_first: bool = False, with_positions: bool = False,
+                           oddities: bool = True):
+    """A hit-object event stream in the format the T5 stage emits (reference osuT5/osuT5/tokenizer + the group orders
+    drawn in data_utils.py:757-766): per object `t, (dist | pos_x pos_y), [new_combo], [scroll_speed], TYPE` -- the type
+    token first with `types_first` -- anchors without a time of their own, beats / measures / timing points / kiai in
+    between.  `oddities` adds what a sampled stream can contain and the reference's code tolerates: a coordinate of 0,
+    a distance of 0, a slider head without scroll speed, anchors and a slider end without a head, a slider end straight
+    after the head, attribute events no type token claims at the very end."""
+    from .event import Event, EventType as ET
+    rng = np.random.default_rng(seed)
+    ev, t = [], 0
+
+    def emit(type_name, *, time=None, x=None, y=None, dist=None, nc=False, sv=None, value=0):
+        attrs = []
+        if time is not None:
+            attrs.append(Event(ET.TIME_SHIFT, int(time)))
+            if rng.random() < 0.5:
+                attrs.append(Event(ET.SNAPPING, int(rng.integers(0, 16))))
+        if with_positions and x is not None:
+            attrs += [Event(ET.POS_X, int(x)), Event(ET.POS_Y, int(y))]
+        elif dist is not None:
+            attrs.append(Event(ET.DISTANCE, int(dist)))
+        if nc:
+            attrs.append(Event(ET.NEW_COMBO, 0))
+        if sv is not None:
+            attrs.append(Event(ET.SCROLL_SPEED, int(sv)))
+        head = [Event(ET[type_name], value)]
+        ev.extend(head + attrs if types_first else attrs + head)
+        if type_name in ("CIRCLE", "SLIDER_HEAD", "SLIDER_END") and rng.random() < 0.4:
+            ev.append(Event(ET.HITSOUND, int(rng.integers(0, 72))))
+            ev.append(Event(ET.VOLUME, int(rng.integers(0, 100))))
+
+    def xy():
+        return int(rng.integers(1, 512)), int(rng.integers(1, 384))
+
+    for k in range(n_objects):
+        t += int(rng.integers(60, 900))
+        if k % 5 == 0:
+            emit("BEAT" if k % 10 else "MEASURE", time=t - 30)
+        if k % 37 == 11:
+            emit("TIMING_POINT", time=t - 20)
+        if k % 41 == 13:
+            emit("KIAI", time=t - 10, value=1)
+        kind = rng.random()
+        x, y = xy()
+        if kind < 0.45:
+            zero = oddities and k % 23 == 7
+            emit("CIRCLE", time=t, x=0 if zero else x, y=y, dist=0 if zero else rng.integers(1, 400), nc=rng.random() < 0.3)
+        elif kind < 0.55:
+            emit("SPINNER", time=t, x=256, y=192, dist=rng.integers(0, 300))
+            t += int(rng.integers(400, 3000))
+            emit("SPINNER_END", time=t, x=256, y=192, dist=rng.integers(0, 300))
+        else:
+            no_sv = oddities and k % 17 == 5
+            emit("SLIDER_HEAD", time=t, x=x, y=y, dist=rng.integers(1, 400), nc=rng.random() < 0.3,
+                 sv=None if no_sv else rng.integers(30, 400))
+            head_t = t
+            if oddities and k % 29 == 3:                                  # slider end straight after the head
+                t += int(rng.integers(100, 600))
+                emit("SLIDER_END", time=t, x=x, y=y, dist=rng.integers(1, 400))
+                continue
+            curve = ("BEZIER_ANCHOR", "PERFECT_ANCHOR", "CATMULL_ANCHOR")[int(rng.integers(0, 3))]
+            for a in range(1 if curve == "PERFECT_ANCHOR" else int(rng.integers(0, 6))):
+                red = curve == "BEZIER_ANCHOR" and rng.random() < 0.25
+                emit("RED_ANCHOR" if red else curve, x=xy()[0], y=xy()[1], dist=rng.integers(1, 200))
+            span = int(rng.integers(80, 1200))
+            t += span
+            emit("LAST_ANCHOR", time=t, x=xy()[0], y=xy()[1], dist=rng.integers(1, 200))
+            repeats = int(rng.integers(1, 7))
+            t = head_t + span * repeats + int(rng.integers(-3, 4))
+            emit("SLIDER_END", time=max(t, head_t + 1), x=xy()[0], y=xy()[1], dist=rng.integers(1, 400))
+        if oddities and k % 31 == 19:                                     # anchors and an end nobody opened
+            emit("BEZIER_ANCHOR", x=xy()[0], y=xy()[1], dist=rng.integers(1, 200))
+            t += 50
+            emit("SLIDER_END", time=t, x=xy()[0], y=xy()[1], dist=rng.integers(1, 400))
+    if oddities:
+        t += 100
+        ev.append(Event(ET.TIME_SHIFT, t))
+        ev.append(Event(ET.DISTANCE, 17))
+    return ev
+
+
+def synthetic_diffusion_tokenizer_state(seed: int) -> dict:
+    """A state dict of the diffusion class tokenizer (osu_diffusion/utils/tokenizer.py:216-230): some beatmaps with a
+    style class, mapper and descriptors each; every fourth seed drops a family (its count stays 0)."""
+    rng = np.random.default_rng(seed)
+    n_maps, n_mappers, n_desc = int(rng.integers(3, 40)), int(rng.integers(2, 9)), int(rng.integers(2, 10))
+    ids = [int(i) for i in rng.choice(50, n_maps, replace=False)]
+    st = dict(beatmap_idx={b: k for k, b in enumerate(ids)}, num_classes=n_maps + 1,
+              num_diff_classes=int(rng.integers(3, 12)), max_difficulty=float(rng.uniform(6, 10)),
+              beatmap_mapper={b: int(rng.integers(0, n_mappers + 2)) for b in ids},
+              mapper_idx={u: u for u in range(n_mappers)}, num_mapper_classes=n_mappers + 1,
+              beatmap_descriptors={b: [int(i) for i in rng.choice(n_desc, int(rng.integers(1, 3)), replace=False)] for b in ids},
+              descriptor_idx={f"d{i}": i for i in range(n_desc)}, num_descriptor_classes=n_desc + 1,
+              num_cs_classes=int(rng.integers(3, 14)))
+    drop = seed % 4
+    if drop == 1:
+        st.update(beatmap_idx={}, num_classes=0)
+    elif drop == 2:
+        st.update(mapper_idx={}, beatmap_mapper={}, num_mapper_classes=0)
+    elif drop == 3:
+        st.update(num_cs_classes=0, num_diff_classes=0)
+    return st

@@ -543,10 +543,86 @@ def sliders_case():
     print("sliders", len(cases), "cases, moved", int(np.sum(moved)), "by type", np.bincount(types))
 
 
+# (seed, objects, types_first, with_positions): the host code either side of the diffusion stage
+EVENT_CASES = [(0, 22, False, False), (1, 22, True, False), (2, 22, False, True), (3, 22, True, True), (4, 60, False, False),
+               (5, 60, True, False)]
+CURVE_CODES = {"Bezier": 0, "PerfectCurve": 1, "Catmull": 2}
+GEN_CASE = dict(preset="DiT-XS", weight_seed=33, event_seed=12, objects=70, tokenizer_seed=8, noise_seed=21,
+                config=dict(beatmap_id=None, difficulty=5.3, mapper_id=None, circle_size=4.2, slider_multiplier=1.7,
+                            descriptors=["d1", "d0"], negative_descriptors=["d2"]),
+                knobs=dict(timesteps=[2, 0, 0, 0, 0, 0, 0, 0, 0, 0], seq_len=32, max_seq_len=96, overlap_buffer=12,
+                           cfg_scale=1.5, refine_iters=1))
+
+
+def events_case():
+    """Row a14's host code run through the REFERENCE: `update_event_times`, `events_to_sequence` (get_groups inside),
+    `events_with_pos`, and one whole `DiffisionPipeline.generate` (events in, events out, nothing replaced) on the event
+    streams of `mapperatorinator_amd.testing.synthetic_event_stream`."""
+    import types
+    from mapperatorinator_amd.testing import (pipeline_windows, synthetic_diffusion_tokenizer_state, synthetic_event_stream,
+                                              synthetic_timing)
+    rh.ref_shims.install()
+    import diffusion_pipeline as dp
+    from osuT5.osuT5.dataset.data_utils import update_event_times
+    from osuT5.osuT5.tokenizer import Event, EventType
+    out = {}
+    for seed, n_obj, tf, wp in EVENT_CASES:
+        ev = synthetic_event_stream(n_obj, seed, types_first=tf, with_positions=wp)
+        rev = [Event(EventType[e.type.name], e.value) for e in ev]
+        times = []
+        update_event_times(rev, times, types_first=tf)
+        pipe = object.__new__(dp.DiffisionPipeline)
+        pipe.types_first, pipe.has_sv = tf, True
+        seq_x, seq_o, seq_c, n, seq_indices, sliders = pipe.events_to_sequence(rev, synthetic_timing(seed), 1.4)
+        pos = torch.from_numpy(np.random.default_rng(seed).uniform(0, 512, (2, n)).astype(np.float32))
+        placed = dp.DiffisionPipeline.events_with_pos(rev, pos, seq_indices)
+        names = sorted({e.type.name for e in placed})
+        k = f"s{seed}_"
+        out.update({k + "times": np.array(times, np.int64), k + "seq_x": seq_x.numpy(), k + "seq_o": seq_o.numpy(),
+                    # full conditioning for the short streams; type rows + every 7th column of the embeddings for the long ones
+                    **({k + "seq_c": seq_c.numpy()} if n_obj <= 30 else {k + "seq_c_types": seq_c[256:].numpy(), k + "seq_c_cols": seq_c[:, ::7].numpy()}),
+                    k + "seq_indices": np.array([seq_indices[i] for i in range(len(rev))], np.int32),
+                    k + "slider_off": np.cumsum([0] + [len(sl.seq_indices) for sl in sliders]).astype(np.int32),
+                    k + "slider_idx": np.concatenate([sl.seq_indices for sl in sliders] + [np.zeros(0, np.int64)]).astype(np.int32),
+                    k + "slider_end": np.array([sl.end_index for sl in sliders], np.int32),
+                    k + "slider_curve": np.array([CURVE_CODES[sl.curve_type] for sl in sliders], np.int32),
+                    k + "slider_length": np.array([sl.length for sl in sliders], np.float64),
+                    k + "placed_names": np.array(names), k + "placed_type": np.array([names.index(e.type.name) for e in placed], np.int32),
+                    k + "placed_value": np.array([e.value for e in placed], np.int64)})
+        print("events", seed, "events", len(rev), "points", n, "sliders", len(sliders))
+
+    g = GEN_CASE
+    depth, hidden, heads = DIT_PRESETS[g["preset"]]
+    state = synthetic_diffusion_tokenizer_state(g["tokenizer_seed"])
+    from osu_diffusion.utils.tokenizer import Tokenizer
+    tok = Tokenizer()
+    tok.load_state_dict(state)
+    sd = random_dit_state_dict(depth, hidden, seed=g["weight_seed"], class_size=tok.num_tokens)
+    from osu_diffusion.utils.models import DiT
+    ref = DiT(context_size=272, hidden_size=hidden, depth=depth, num_heads=heads, class_size=tok.num_tokens).eval()
+    ref.load_state_dict(sd, strict=True)
+    ev = synthetic_event_stream(g["objects"], g["event_seed"])
+    timing = synthetic_timing(g["event_seed"])
+    pipe = object.__new__(dp.DiffisionPipeline)
+    pipe.types_first, pipe.has_sv = False, True
+    n = pipe.events_to_sequence([Event(EventType[e.type.name], e.value) for e in ev], timing, 1.0)[3]
+    kk = g["knobs"]
+    rng = np.random.default_rng(g["noise_seed"])
+    noise = [torch.from_numpy(rng.standard_normal((2, 2, b - a)).astype(np.float32))
+             for (a, b) in pipeline_windows(n, kk["max_seq_len"], kk["overlap_buffer"])
+             for _ in range(kk["timesteps"][0] + kk["refine_iters"])]
+    placed = rh.reference_pipeline_generate(ref, ev, types.SimpleNamespace(**g["config"]), timing, state, noise, **kk)
+    names = sorted({nm for nm, _ in placed})
+    out.update(gen_case=json.dumps(g), gen_points=n, gen_names=np.array(names),
+               gen_type=np.array([names.index(nm) for nm, _ in placed], np.int32), gen_value=np.array([v for _, v in placed], np.int64))
+    print("generate: points", n, "events", len(ev), "->", len(placed))
+    np.savez_compressed(os.path.join(OUT, "events_to_sequence.npz"), cases=json.dumps(EVENT_CASES), **out)
+
+
 def main(only=None):
     """`python -m oracle.make_golden` regenerates everything; `python -m oracle.make_golden NAME ...` only the named
     fixtures (t5_tiny, t5_small, t5_base, t5_large, vw_test, vw_test_nobias, vw_small, t5_base_bf16ref, t5_tiny_cond,
-    t5_tiny_tf, dit_xs, dit_s, dit_b, dit_b_1024, dit_pipeline, sliders, whisper_frontend, mel_oracle, tokenizer)."""
+    t5_tiny_tf, dit_xs, dit_s, dit_b, dit_b_1024, dit_pipeline, sliders, events, whisper_frontend, mel_oracle, tokenizer)."""
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(max(1, os.cpu_count() or 1))
     cases = {"tokenizer": tokenizer_case, "mel_oracle": mel_case, "whisper_frontend": whisper_frontend_case}
@@ -566,6 +642,7 @@ def main(only=None):
         "dit_pipeline": pipeline_case,
         "t5_tiny_beam": beam_case,
         "sliders": sliders_case,
+        "events": events_case,
     })
     for name, fn in cases.items():
         if only and name not in only:

@@ -289,6 +289,41 @@ def reference_pipeline_positions(model, seq_x, seq_o, seq_c, class_vector, unk_c
         gd.th.randn_like = orig
 
 
+def reference_pipeline_generate(model, events, generation_config, timing, tokenizer_state, noise_list, *, timesteps,
+                                seq_len, max_seq_len, overlap_buffer, cfg_scale, refine_iters=0, start_time=None,
+                                end_time=None, diffusion_steps=1000, noise_schedule="squaredcos_cap_v2",
+                                types_first=False, has_sv=True, pad_sequence=False):
+    """The reference's `DiffisionPipeline.generate` with NOTHING replaced: its own `events_to_sequence` (Event grouping,
+    slider list), `get_class_vector` over its own Tokenizer loaded from `tokenizer_state`, the window loop with
+    `denoised_fn`, and `events_with_pos`.  `events`: objects with `.type.name` / `.value` (translated to the reference's
+    Event class); returns the reference's events as (type name, value) pairs.  Gaussian draws from `noise_list`."""
+    ref_shims.install()
+    import diffusion_pipeline as dp
+    from osu_diffusion.utils.diffusion import gaussian_diffusion as gd
+    from osu_diffusion.utils.tokenizer import Tokenizer
+    from osuT5.osuT5.tokenizer import Event, EventType
+    tok = Tokenizer()
+    tok.load_state_dict(tokenizer_state)
+    pipe = object.__new__(dp.DiffisionPipeline)
+    pipe.device = "cpu"
+    pipe.model, pipe.tokenizer = model, tok
+    pipe.refine_model = model if refine_iters > 0 else None
+    pipe.diffusion_steps, pipe.noise_schedule = diffusion_steps, noise_schedule
+    pipe.seq_len, pipe.max_seq_len, pipe.overlap_buffer = seq_len, max_seq_len, overlap_buffer
+    pipe.timesteps, pipe.cfg_scale, pipe.refine_iters = list(timesteps), cfg_scale, refine_iters
+    pipe.random_init, pipe.types_first, pipe.pad_sequence = False, bool(types_first), bool(pad_sequence)
+    pipe.start_time, pipe.end_time, pipe.has_sv = start_time, end_time, bool(has_sv)
+    it = iter(noise_list)
+    orig = gd.th.randn_like
+    gd.th.randn_like = lambda x, *a, **k: next(it).to(x)
+    try:
+        with torch.no_grad():
+            out = pipe.generate([Event(EventType[e.type.name], e.value) for e in events], generation_config, timing)
+    finally:
+        gd.th.randn_like = orig
+    return [(e.type.name, int(e.value)) for e in out]
+
+
 def make_reference_processor(tok, model, *, src_seq_len: int, tgt_seq_len: int, lookback: float = 0.5, lookahead: float = 0.4,
                              train_lookahead: float = 0.0, cfg_scale: float = 1.0, types_first: bool = False,
                              add_pre_tokens: bool = False, hop_length: int = 128, sample_rate: int = 16000):

@@ -197,6 +197,50 @@ def test_dit_b_full_size_properties():
     assert not torch.equal(a[:, :, 990:], b[:, :, 990:])
 
 
+def test_generate_events_in_events_out_matches_the_reference_golden():
+    """Row a14 end to end with the reference's own signature: `DiffusionPipelineHIP.generate(events, config, timing)` against the
+    reference's `DiffisionPipeline.generate` with nothing replaced (its Event grouping, its Tokenizer's class vectors, its
+    SliderPath re-projection, its `events_with_pos`; oracle/ref_harness.py `reference_pipeline_generate`) on a 761-event
+    stream -> 199 points in three windows, 2 DDPM steps + 1 refine step per window, injected gaussian draws.  The result is
+    integer POS_X / POS_Y events: same event sequence, every coordinate within 1 of the reference's and >= 99 % identical
+    (an fp32 difference of 1e-3 px can still flip a round-half case)."""
+    import json
+    import types
+
+    from mapperatorinator_amd.diffusion_pipeline import DiffusionPipelineHIP, DiffusionTokenizer
+    from mapperatorinator_amd.dit import DiTHIP
+    from mapperatorinator_amd.testing import (DIT_PRESETS, random_dit_state_dict, synthetic_diffusion_tokenizer_state,
+                                              synthetic_event_stream, synthetic_timing)
+    g = np.load(f"{GOLDEN}/events_to_sequence.npz")
+    c = json.loads(str(g["gen_case"]))
+    depth, hidden, heads = DIT_PRESETS[c["preset"]]
+    tok = DiffusionTokenizer(synthetic_diffusion_tokenizer_state(c["tokenizer_seed"]))
+    dit = DiTHIP(random_dit_state_dict(depth, hidden, seed=c["weight_seed"], class_size=tok.num_tokens), depth, hidden, heads,
+                 device="cuda")
+    k = c["knobs"]
+    pipe = DiffusionPipelineHIP(dit, timesteps=k["timesteps"], seq_len=k["seq_len"], max_seq_len=k["max_seq_len"],
+                                overlap_buffer=k["overlap_buffer"], cfg_scale=k["cfg_scale"], refine_model=dit,
+                                refine_iters=k["refine_iters"], tokenizer=tok, types_first=False, has_sv=True)
+    rng = np.random.default_rng(c["noise_seed"])
+
+    def noise_source(n, shape):
+        return torch.from_numpy(np.stack([rng.standard_normal(shape).astype(np.float32) for _ in range(n)]))
+
+    events = synthetic_event_stream(c["objects"], c["event_seed"])
+    out = pipe.generate(events, types.SimpleNamespace(**c["config"]), synthetic_timing(c["event_seed"]), noise_source=noise_source)
+    names = g["gen_names"].tolist()
+    want = [(names[t], int(v)) for t, v in zip(g["gen_type"], g["gen_value"])]
+    assert [e.type.name for e in out] == [nm for nm, _ in want]
+    placed = [(e.value, v) for e, (nm, v) in zip(out, want) if nm in ("POS_X", "POS_Y")]
+    others = [(e.value, v) for e, (nm, v) in zip(out, want) if nm not in ("POS_X", "POS_Y")]
+    assert all(a == b for a, b in others) and len(placed) >= 2 * 150
+    diff = np.array([abs(a - b) for a, b in placed])
+    print(f"generate(): {len(placed)} coordinates, {int((diff == 0).sum())} identical, max |d| {diff.max()}")
+    assert diff.max() <= 1 and (diff == 0).mean() >= 0.99
+    # the coordinates really are the model's: most differ from the centre / from the stream's own distances
+    assert len({a for a, _ in placed}) > 50
+
+
 @pytest.mark.parametrize("variant", ["short", "full", "sliders_short", "sliders", "pad_short", "pad_sliders"])
 def test_window_pipeline_matches_reference_golden(variant):
     """Row a14: the reference's `DiffisionPipeline.generate` between `events_to_sequence` and `events_with_pos`

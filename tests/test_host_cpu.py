@@ -281,6 +281,83 @@ def test_diffusion_pipeline_host_glue():
         points_to_sequence(x, y, times, dist, typ + 16)
 
 
+def _golden_events():
+    import json
+    g = np.load(os.path.join(ROOT, "tests", "golden", "events_to_sequence.npz"))
+    return g, [tuple(c) for c in json.loads(str(g["cases"]))]
+
+
+def test_events_to_sequence_matches_the_reference_golden():
+    """Row a14's host code: event times, hit-object grouping, points, `seq_indices`, the DiffusionSlider list and the
+    write-back of positions, against the outputs of the reference's own `update_event_times` / `events_to_sequence` /
+    `events_with_pos` (tests/golden/events_to_sequence.npz, oracle/make_golden.py `events`) -- bit for bit: it is integer
+    bookkeeping plus the same torch ops in the same order."""
+    from mapperatorinator_amd import diffusion_pipeline as dp
+    from mapperatorinator_amd.testing import synthetic_event_stream, synthetic_timing
+    g, cases = _golden_events()
+    curves = ["Bezier", "PerfectCurve", "Catmull"]
+    for seed, n_obj, tf, wp in cases:
+        k = f"s{seed}_"
+        ev = synthetic_event_stream(n_obj, seed, types_first=bool(tf), with_positions=bool(wp))
+        assert dp.event_times(ev, types_first=bool(tf)) == g[k + "times"].tolist()
+        seq_x, seq_o, seq_c, n, seq_indices, sliders = dp.events_to_sequence(ev, synthetic_timing(seed), 1.4, types_first=bool(tf))
+        assert n == g[k + "seq_x"].shape[1] and len(seq_indices) == len(ev)
+        assert np.array_equal(seq_x.numpy(), g[k + "seq_x"]) and np.array_equal(seq_o.numpy(), g[k + "seq_o"])
+        if k + "seq_c" in g:
+            assert np.array_equal(seq_c.numpy(), g[k + "seq_c"])
+        else:
+            assert np.array_equal(seq_c[256:].numpy(), g[k + "seq_c_types"]) and np.array_equal(seq_c[:, ::7].numpy(), g[k + "seq_c_cols"])
+        assert [seq_indices[i] for i in range(len(ev))] == g[k + "seq_indices"].tolist()
+        off = g[k + "slider_off"]
+        assert len(sliders) == len(off) - 1 > 3
+        for j, sl in enumerate(sliders):
+            assert sl.seq_indices.tolist() == g[k + "slider_idx"][off[j]:off[j + 1]].tolist()
+            assert (sl.end_index, sl.curve_type, sl.length) == (g[k + "slider_end"][j], curves[g[k + "slider_curve"][j]], g[k + "slider_length"][j])
+        pos = torch.from_numpy(np.random.default_rng(seed).uniform(0, 512, (2, n)).astype(np.float32))
+        placed = dp.events_with_pos(ev, pos, seq_indices)
+        names = g[k + "placed_names"].tolist()
+        assert [(e.type.name, e.value) for e in placed] == [(names[t], v) for t, v in zip(g[k + "placed_type"], g[k + "placed_value"])]
+        assert all(isinstance(e, Event) for e in placed) and not any(e.type == EventType.DISTANCE for e in placed)
+    # the documented corner cases
+    empty = dp.events_to_sequence([], None, 1.4)
+    assert empty[0].shape == (2, 0) and empty[1].shape == (1, 0) and empty[2].shape == (1, 0) and empty[3:] == (0, {}, [])
+    assert dp.events_with_pos([], torch.zeros(2, 0), {}) == []
+    with pytest.raises(IndexError):                       # attribute events no type token claims and no record to join
+        dp.group_events([Event(EventType.TIME_SHIFT, 5), Event(EventType.DISTANCE, 3)])
+    zero_x = dp.events_to_sequence([Event(EventType.TIME_SHIFT, 10), Event(EventType.POS_X, 0), Event(EventType.POS_Y, 100),
+                                    Event(EventType.CIRCLE)], None, 1.4)
+    assert zero_x[0][:, 0].tolist() == [0.0, 0.0]          # a coordinate of 0 = "no position": the playfield centre
+    assert not dp.events_to_sequence(ev, None, 1.4)[5] and not dp.events_to_sequence(ev, synthetic_timing(1), 1.4, has_sv=False)[5]
+
+
+def test_diffusion_tokenizer_and_class_vector():
+    """`DiffusionTokenizer` (the class vocabulary restated from the tokenizer.pkl state) and `get_class_vector`: layout
+    [styles | difficulties | mappers | descriptors | circle sizes], unknown = the family's last id, clipping at both ends,
+    the state round trip, and a family that is absent from the state."""
+    from mapperatorinator_amd.diffusion_pipeline import DiffusionGenerationConfig, DiffusionTokenizer, get_class_vector
+    from mapperatorinator_amd.testing import synthetic_diffusion_tokenizer_state
+    st = synthetic_diffusion_tokenizer_state(8)
+    tok = DiffusionTokenizer(st)
+    n = [st["num_classes"], st["num_diff_classes"], st["num_mapper_classes"], st["num_descriptor_classes"], st["num_cs_classes"]]
+    base = np.cumsum([0] + n)
+    assert tok.num_tokens == base[5]
+    assert [tok.style_unk, tok.diff_unk, tok.mapper_unk, tok.descriptor_unk, tok.cs_unk] == (base[1:] - 1).tolist()
+    assert tok.encode_diff(-3.0) == base[1] and tok.encode_diff(1e9) == base[2] - 2
+    assert tok.encode_cs(-1.0) == base[4] and tok.encode_cs(99.0) == base[5] - 2
+    known = next(iter(st["beatmap_idx"]))
+    assert tok.encode_style(known) == st["beatmap_idx"][known] and tok.encode_style(-5) == tok.style_unk
+    assert tok.encode_descriptor_name("d1") == base[3] + 1 and tok.encode_descriptor_name("nope") == base[4]
+    assert DiffusionTokenizer(tok.state_dict()).state_dict() == tok.state_dict()
+    v = get_class_vector(tok, DiffusionGenerationConfig(difficulty=5.3, circle_size=4.2, descriptors=["d1", "nope", "d0"]))
+    on = set(torch.nonzero(v)[:, 0].tolist())
+    assert on == {tok.style_unk, tok.encode_diff(5.3), tok.mapper_unk, base[3], base[3] + 1, tok.encode_cs(4.2)}
+    v = get_class_vector(tok, DiffusionGenerationConfig(descriptors=["nope"]))
+    assert set(torch.nonzero(v)[:, 0].tolist()) == {tok.style_unk, tok.diff_unk, tok.mapper_unk, tok.descriptor_unk, tok.cs_unk}
+    lean = DiffusionTokenizer(synthetic_diffusion_tokenizer_state(3))      # no difficulty / circle-size family
+    assert lean.num_diff_classes == lean.num_cs_classes == 0
+    assert get_class_vector(lean, DiffusionGenerationConfig(difficulty=4.0, circle_size=4.0)).sum() == 3
+
+
 def test_graft_entry_build():
     """The driver's build check: `make` (incremental) + dlopen + ABI / layout verification, no GPU needed."""
     import __graft_entry__ as g
