@@ -19,6 +19,13 @@ server.py:106-134 are applied here with torch ops (the in-kernel sampler of the 
 cannot rank across beams): classifier-free guidance, MonotonicTimeShift, TimeshiftBias, (Conditional)Temperature and the lookback
 mask; the types_first lookback renormalisation is refused in beam mode.
 
+Beam-sample (`do_sample` with beams, round 5; processor.py:147-160 hands both to `generate`): HF appends its top-k / top-p warpers
+BEHIND the reference's processor list with `min_tokens_to_keep = #eos + 1` (utils.py `_get_logits_processor`), and
+`_get_top_k_continuations` draws the K continuations with `torch.multinomial(softmax(accumulated), K)` -- without replacement, in
+draw order (not sorted: "inside the top num_beams" then means "among the first num_beams draws").  The draw uses torch's generator
+on the engine's device, like HF on a GPU; `sample_fn(probs, k)` replaces it (parity tests inject the sampler the reference golden
+was drawn with).
+
 Guidance under beams (round 5; the timing pass sets beams, `super_timing_generator.py:28`, and `processor.py:709` halves its batch
 for exactly this case) follows what the reference + HF do, quirk included:
   * `prepare_inputs_for_generation` (modeling_mapperatorinator.py:243-254) doubles the (chunk, beam) rows every step: the first
@@ -49,7 +56,8 @@ def _gather(t: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
 class BeamProcessors:
     """The reference's processor list (server.py:106-134) on (rows, V) LOG-PROBABILITIES, from an MhSampling struct."""
 
-    def __init__(self, sp, device):
+    def __init__(self, sp, device, min_tokens_to_keep: int = 1):
+        self.min_tokens_to_keep = int(min_tokens_to_keep)
         if sp.lookback_types_first and sp.lookback_mask_end > sp.ts_start:
             raise NotImplementedError("beam search with the types_first lookback renormalisation is not on the HIP path")
         self.sp = sp
@@ -91,12 +99,22 @@ class BeamProcessors:
         scores = scores / temp[:, None]
         if sp.lookback_mask_end > sp.ts_start:                                # LookbackBiasLogitsWarper, types_first False (:111-114)
             scores[:, sp.ts_start:sp.lookback_mask_end] = float("-inf")
+        if sp.do_sample:      # HF's own warpers, appended behind the list: TopK then TopP, at least #eos + 1 tokens kept under beams
+            keep = self.min_tokens_to_keep
+            if sp.top_k > 0:
+                kth = torch.topk(scores, min(max(int(sp.top_k), keep), scores.shape[-1]))[0][..., -1, None]
+                scores = scores.masked_fill(scores < kth, float("-inf"))
+            if sp.top_p < 1.0:
+                srt, order = torch.sort(scores, descending=False)
+                drop = srt.softmax(dim=-1).cumsum(dim=-1) <= (1 - float(sp.top_p))
+                drop[..., -keep:] = False
+                scores = scores.masked_fill(drop.scatter(1, order, drop), float("-inf"))
         return scores
 
 
 @torch.no_grad()
 def beam_search(engine, cross_kv: torch.Tensor, prompt: torch.Tensor, prompt_mask: Optional[torch.Tensor], eos_ids, sp,
-                num_beams: int, length_penalty: float = 1.0, early_stopping=False) -> torch.Tensor:
+                num_beams: int, length_penalty: float = 1.0, early_stopping=False, sample_fn=None) -> torch.Tensor:
     """cross_kv: the G chunks' cross K/V (engine.cross_kv); prompt int (G, P) left-padded, prompt_mask (G, P) or None.
     Under guidance (sp.cfg_scale > 1) `prompt` / `prompt_mask` carry 2G rows, [negative-prompt rows | prompt rows] (what
     T5Engine.generate and the scheduler build), and cross_kv still has G rows.
@@ -123,8 +141,11 @@ def beam_search(engine, cross_kv: torch.Tensor, prompt: torch.Tensor, prompt_mas
     max_length = int(sp.max_length)
     if not (1 <= P < max_length <= p.tgt_len):
         raise ValueError("prompt / max_length do not fit the cache")
-    procs = BeamProcessors(sp, dev)
     eos_list = [int(e) for e in eos_ids]
+    procs = BeamProcessors(sp, dev, min_tokens_to_keep=len(eos_list) + 1 if eos_list else 2)
+    do_sample = bool(sp.do_sample)
+    if do_sample and sample_fn is None:
+        sample_fn = torch.multinomial
     eos_t = torch.tensor(sorted(set(eos_list)), dtype=torch.long, device=dev)
     n_eos = len(eos_list)
     K = max(2, 1 + n_eos) * nb
@@ -181,7 +202,11 @@ def beam_search(engine, cross_kv: torch.Tensor, prompt: torch.Tensor, prompt_mas
                 lsm = lsm[R:] + (lsm[:R] - lsm[R:]) * scale
             log_probs = procs(flat, lsm)
             acc = (log_probs.view(G, nb, V) + running_scores[:, :, None]).reshape(G, nb * V)
-            topk_lp, topk_idx = torch.topk(acc, k=K)
+            if do_sample:     # K continuations drawn without replacement, kept in draw order
+                topk_idx = sample_fn(torch.softmax(acc, dim=-1), K).to(dev)
+                topk_lp = torch.gather(acc, 1, topk_idx)
+            else:
+                topk_lp, topk_idx = torch.topk(acc, k=K)
             src_beam = topk_idx // V
             topk_bidx = _gather(running_bidx, src_beam)
             topk_seq = _gather(running, src_beam)

@@ -253,8 +253,6 @@ class MapperatorinatorHIP:
         (server.sampling_from_processors), `past_key_values` / `use_cache` are accepted and unused (the engine owns
         its caches).  Returns int64 (B, prompt + new) on the model's device, pad_token_id after each row's EOS."""
         from .server import sampling_from_processors
-        if num_beams != 1 and do_sample:
-            raise NotImplementedError("beam-sample (num_beams > 1 with do_sample) is not on the HIP path")
         audio = inputs if inputs is not None else frames
         if decoder_input_ids is None:
             raise ValueError("decoder_input_ids is required (the reference always passes the prompt)")
@@ -272,6 +270,8 @@ class MapperatorinatorHIP:
         row_bias = self._row_bias(decoder_input_ids.shape[0], unused)
         if num_beams != 1:
             out = self.engine.generate_beam(audio, decoder_input_ids, decoder_attention_mask, eos, sp, int(num_beams),
+                                            negative_prompt=negative_prompt if sp.cfg_scale > 1.0 else None,
+                                            sample_fn=unused.get("beam_sample_fn"),
                                             **({} if row_bias is None else dict(row_bias=row_bias)))
             return out["tokens"].to(self.device)
         out = self.engine.generate(audio, decoder_input_ids, decoder_attention_mask, eos, sp,

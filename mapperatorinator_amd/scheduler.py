@@ -213,7 +213,7 @@ class SequentialWindowScheduler:
             # hypotheses are ranked among themselves only, so a window decodes as in the reference's batch-1 call; rows that
             # end early carry HF's fill (the first EOS id) and are cut at their first EOS-set id below like any other row
             from .beam import beam_search
-            result = beam_search(eng, kv, p_all, m_all, eos, sp, nb).to(torch.int64).cpu()
+            result = beam_search(eng, kv, p_all, m_all, eos, sp, nb, sample_fn=gk.get("beam_sample_fn")).to(torch.int64).cpu()
         else:
             eng.synchronize()
             n_cols = int(n_out.item())

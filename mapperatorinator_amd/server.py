@@ -7,8 +7,8 @@ Same kwargs, same EOS-set construction (server.py:72-80), same processor order
 server.py:106-134), same stats dict (server.py:50-69).  Classifier-free guidance follows the reference's
 batch layout: the negative prompt rows first, the prompt rows second, one shared encoder output per pair
 (modeling_mapperatorinator.py:243-254).  `num_beams > 1` runs HF's beam search over the step-wise decode entry
-(mapperatorinator_amd/beam.py); beam-sample is the one combination that is not built and raises NotImplementedError --
-never a silent approximation.  `RequestBatcher` at the end of the file is the batching policy of the reference's
+(mapperatorinator_amd/beam.py), with `do_sample` as HF's beam-sample (`generate_kwargs["beam_sample_fn"]` replaces the device's
+`torch.multinomial` draw; what is not built raises NotImplementedError -- never a silent approximation).  `RequestBatcher` at the end of the file is the batching policy of the reference's
 InferenceServer (server.py:343-424) in front of this function.
 """
 from __future__ import annotations
@@ -170,8 +170,6 @@ def build_sampling(tokenizer, generate_kwargs: dict, max_target_positions: int):
     if context_type is not None:
         context_type = ContextType(getattr(context_type, "value", context_type))
     num_beams = int(gk.get("num_beams", 1) or 1)
-    if num_beams > 1 and gk.get("do_sample", False):
-        raise NotImplementedError("beam-sample (num_beams > 1 with do_sample) is not on the HIP path")
 
     ts0, ts1 = _ev(tokenizer.event_start, "TIME_SHIFT"), _ev(tokenizer.event_end, "TIME_SHIFT")
     sp = Sampling()
@@ -338,7 +336,8 @@ def model_generate(model, tokenizer, model_kwargs, generate_kwargs):
     extra = {} if row_bias is None else dict(row_bias=row_bias)
     if getattr(sp, "num_beams", 1) > 1:
         # HF beam search (processor.py:159 `num_beams`; the timing generator uses two beams): mapperatorinator_amd/beam.py
-        out = model.engine.generate_beam(audio, prompt, mask, eos, sp, sp.num_beams, negative_prompt=neg, **extra)
+        out = model.engine.generate_beam(audio, prompt, mask, eos, sp, sp.num_beams, negative_prompt=neg,
+                                         sample_fn=generate_kwargs.get("beam_sample_fn"), **extra)
     else:
         out = model.engine.generate(audio, prompt, mask, eos, sp, negative_prompt=neg, negative_mask=neg_mask,
                                     cross_kv_fp8=bool(generate_kwargs.get("cross_kv_fp8", False)), **extra)

@@ -435,3 +435,36 @@ def synthetic_diffusion_tokenizer_state(seed: int) -> dict:
     elif drop == 3:
         st.update(num_cs_classes=0, num_diff_classes=0)
     return st
+
+
+class SeededMultinomial:
+    """A deterministic, device-independent stand-in for `torch.multinomial(probs, k)` WITHOUT replacement, for the
+    beam-sample parity cases: the reference (CPU) and the HIP path (GPU) cannot share a torch generator, so both are handed
+    this sampler (oracle/make_golden.py patches it into HF's `_get_top_k_continuations`; beam.py takes it as `sample_fn`).
+    Per row, k times: inverse CDF of the remaining weights in float64 against one uniform of a numpy stream (once the
+    weighted categories are used up, the lowest unused index -- torch also keeps drawing zero-weight categories then).  Weights
+    that differ by fp32 rounding between the two sides select the same index unless a uniform lands within ~1e-7 of a
+    CDF step."""
+
+    def __init__(self, seed: int):
+        self.rng = np.random.default_rng(seed)
+        self.calls = 0
+
+    def __call__(self, probs: torch.Tensor, num_samples: int, replacement: bool = False, **_):
+        if replacement:
+            raise NotImplementedError("beam-sample draws without replacement")
+        self.calls += 1
+        w_all = probs.detach().to(torch.float64).cpu().numpy()
+        out = np.empty((w_all.shape[0], num_samples), np.int64)
+        for r, w in enumerate(w_all):
+            w, taken = w.copy(), set()
+            for j in range(num_samples):
+                c = np.cumsum(w)
+                if c[-1] > 0:
+                    i = min(int(np.searchsorted(c, self.rng.random() * c[-1], side="right")), len(w) - 1)
+                else:      # every weighted category is drawn: torch goes on with zero-weight ones (its exponential-race top-k does
+                    i = next(n for n in range(len(w)) if n not in taken)      # not stop); here the lowest unused index
+                out[r, j] = i
+                taken.add(i)
+                w[i] = 0.0
+        return torch.from_numpy(out).to(probs.device)

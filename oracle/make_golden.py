@@ -282,7 +282,13 @@ BEAM_CASE = dict(src=251, tgt=40, ns=32000, wseed=13, gain=1.5, aseed=6, prompts
                        # classifier-free guidance UNDER beams (the timing pass: processor.py:709 halves its batch for it): the doubled
                        # rows of prepare_inputs_for_generation + `beam_idx.repeat(2)` of MapperatorinatorCache.reorder_cache
                        "b2g": dict(num_beams=2, cfg_scale=2.0),
-                       "b3g": dict(num_beams=3, cfg_scale=1.5, temperature=0.8, timeshift_bias=0.3, lookahead_time=500)})
+                       "b3g": dict(num_beams=3, cfg_scale=1.5, temperature=0.8, timeshift_bias=0.3, lookahead_time=500),
+                       # beam-sample (do_sample under beams, processor.py:147-160): HF's top-k / top-p warpers behind the list with
+                       # min_tokens_to_keep = #eos + 1, K continuations drawn without replacement by testing.SeededMultinomial
+                       "b2s": dict(num_beams=2, do_sample=True, temperature=0.9, top_p=0.9),
+                       "b3s": dict(num_beams=3, do_sample=True, top_k=64, lookahead_time=500, timeshift_bias=0.3),
+                       "b2sg": dict(num_beams=2, do_sample=True, cfg_scale=1.5, top_p=0.95, top_k=40, temperature=1.1)},
+                 sample_seeds={"b2s": 1001, "b3s": 1002, "b2sg": 1003})
 
 
 def beam_case(name="t5_tiny_beam"):
@@ -297,12 +303,22 @@ def beam_case(name="t5_tiny_beam"):
     audio = synthetic_audio_varied(len(c["prompts"]), c["ns"], seed=c["aseed"])
     prompt, neg = torch.tensor(c["prompts"]), torch.tensor(c["negative"])
     out = dict(vocab_in=tok.vocab_size_in, vocab_out=tok.vocab_size_out, prompt=prompt.numpy(), negative=neg.numpy(), runs=json.dumps(c["runs"]),
-               **{k: v for k, v in c.items() if k not in ("prompts", "runs", "negative")})
+               sample_seeds=json.dumps(c["sample_seeds"]),
+               **{k: v for k, v in c.items() if k not in ("prompts", "runs", "negative", "sample_seeds")})
+    from mapperatorinator_amd.testing import SeededMultinomial
     for tag, kw in c["runs"].items():
         ng = neg if kw.get("cfg_scale", 1.0) > 1.0 else None
-        ids, _ = rh.reference_generate(model, tok, audio, prompt, rh.default_generate_kwargs(c["tgt"], **kw), prompt.ne(0), negative_prompt=ng)
-        greedy, _ = rh.reference_generate(model, tok, audio, prompt, rh.default_generate_kwargs(c["tgt"], **dict(kw, num_beams=1)), prompt.ne(0),
-                                          negative_prompt=ng)
+        real_multinomial = torch.multinomial
+        if kw.get("do_sample"):
+            torch.multinomial = SeededMultinomial(c["sample_seeds"][tag])
+        try:
+            ids, _ = rh.reference_generate(model, tok, audio, prompt, rh.default_generate_kwargs(c["tgt"], **kw), prompt.ne(0), negative_prompt=ng)
+            if kw.get("do_sample"):
+                print("   ", tag, "multinomial calls", torch.multinomial.calls)
+        finally:
+            torch.multinomial = real_multinomial
+        greedy, _ = rh.reference_generate(model, tok, audio, prompt, rh.default_generate_kwargs(c["tgt"], **dict(kw, num_beams=1, do_sample=False)),
+                                          prompt.ne(0), negative_prompt=ng)
         out["ids_" + tag], out["greedy_" + tag] = ids.numpy(), greedy.numpy()
         w = min(ids.shape[1], greedy.shape[1])
         print(name, tag, tuple(ids.shape), "greedy", tuple(greedy.shape), "positions where beams and greedy differ",

@@ -353,7 +353,8 @@ class T5Oracle:
 
 
     # ---- beam search ---------------------------------------------------------------------------------
-    def _processed_log_probs(self, logits, hist, ts_start, ts_end, sos_ids, temperature, timeshift_bias, lookback_mask_end):
+    def _processed_log_probs(self, logits, hist, ts_start, ts_end, sos_ids, temperature, timeshift_bias, lookback_mask_end,
+                             top_k=0, top_p=1.0, min_tokens_to_keep=1):
         """HF beam search hands the processors LOG-PROBABILITIES (generation/utils.py `_beam_search` step b)."""
         scores = torch.log_softmax(logits.float(), dim=-1)
         sos = set(int(v) for v in sos_ids)
@@ -368,15 +369,29 @@ class T5Oracle:
         scores = scores / temperature
         if lookback_mask_end > ts_start:
             scores[:, ts_start:lookback_mask_end] = float("-inf")
+        # beam-sample only: HF's TopK / TopP warpers, appended behind the reference's list (generation/utils.py
+        # `_get_logits_processor`; logits_process.py TopKLogitsWarper / TopPLogitsWarper), row by row
+        for r in range(scores.shape[0]):
+            if top_k > 0:
+                kth = torch.sort(scores[r], descending=True)[0][min(max(top_k, min_tokens_to_keep), scores.shape[1]) - 1]
+                scores[r][scores[r] < kth] = float("-inf")
+            if top_p < 1.0:
+                asc, order = torch.sort(scores[r], descending=False)
+                drop = asc.softmax(dim=-1).cumsum(dim=-1) <= (1 - top_p)
+                drop[-min_tokens_to_keep:] = False
+                scores[r][order[drop]] = float("-inf")
         return scores
 
     def generate_beam(self, enc, prompt, prompt_mask, eos_ids, max_length, ts_start, ts_end, sos_ids, num_beams, pad_id=0,
-                      temperature=1.0, timeshift_bias=0.0, lookback_mask_end=0, length_penalty=1.0):
+                      temperature=1.0, timeshift_bias=0.0, lookback_mask_end=0, length_penalty=1.0, sample_fn=None, top_k=0, top_p=1.0):
         """HF `GenerationMixin._beam_search` (third-party; the vectorised form of transformers >= 4.50, early_stopping =
         False, num_return_sequences = 1) as `model_generate` reaches it with `num_beams > 1` (processor.py:159), restated
         chunk by chunk with explicit candidate lists; the self-attention cache rows are re-gathered per step as
         `MapperatorinatorCache.reorder_cache` does (inference/cache_utils.py:16-20).  Returns ids (B, n_cols): the best
-        hypothesis per chunk, shorter rows filled with `pad_token_id or eos_token_id[0]` (HF's `output_fill_value`)."""
+        hypothesis per chunk, shorter rows filled with `pad_token_id or eos_token_id[0]` (HF's `output_fill_value`).
+        `sample_fn(probs (B, nb V), K)`: beam-SAMPLE -- the K continuations are drawn without replacement from
+        softmax(accumulated) in ONE call for all chunks (`_get_top_k_continuations`), kept in draw order, and the processed
+        log-probabilities pass HF's top-k / top-p warpers with `min_tokens_to_keep = #eos + 1` first."""
         B, P = prompt.shape
         nb, V = int(num_beams), self.sd[[k for k in self.sd if k.endswith("lm_head.weight") or k.endswith("proj_out.weight")][0]].shape[0]
         R = B * nb
@@ -401,12 +416,20 @@ class T5Oracle:
         while True:
             flat = torch.tensor([run_seq[b][k] for b in range(B) for k in range(nb)])
             logits = self.decoder_step(flat[:, cur - 1], cur - 1, cache, ckv, key_mask)
-            lp = self._processed_log_probs(logits, flat, ts_start, ts_end, sos_ids, temperature, timeshift_bias, lookback_mask_end)
+            lp = self._processed_log_probs(logits, flat, ts_start, ts_end, sos_ids, temperature, timeshift_bias, lookback_mask_end,
+                                           **(dict(top_k=top_k, top_p=top_p, min_tokens_to_keep=(len(eos_list) + 1) if eos_list else 2)
+                                              if sample_fn is not None else {}))
             src_rows = []
             all_hit = True
+            accs = [torch.stack([lp[b * nb + k] + run_score[b][k] for k in range(nb)]).reshape(-1) for b in range(B)]
+            drawn = None if sample_fn is None else sample_fn(torch.softmax(torch.stack(accs), dim=-1), min(K, accs[0].numel()))
             for b in range(B):
-                acc = torch.stack([lp[b * nb + k] + run_score[b][k] for k in range(nb)]).reshape(-1)
-                top_lp, top_idx = torch.topk(acc, k=min(K, acc.numel()))
+                acc = accs[b]
+                if drawn is None:
+                    top_lp, top_idx = torch.topk(acc, k=min(K, acc.numel()))
+                else:
+                    top_idx = drawn[b]
+                    top_lp = acc[top_idx]
                 cand = []
                 for lpv, ix in zip(top_lp, top_idx.tolist()):
                     k0, tok = ix // V, ix % V

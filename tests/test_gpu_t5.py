@@ -641,8 +641,13 @@ def test_model_object_generate_and_forward_seam_b2():
                          logits_processor=[MonotonicTimeShiftLogitsProcessor(), TimeshiftBias(), TemperatureLogitsWarper()])
     assert ids.device.type == "cuda" and ids.dtype == torch.int64
     assert np.array_equal(ids.cpu().numpy(), g["ids_processors"])       # = the reference's own output for these kwargs
-    with pytest.raises(NotImplementedError):
-        model.generate(inputs=audio, decoder_input_ids=prompt, num_beams=2, do_sample=True)     # beam-sample is not built
+    torch.manual_seed(11)       # beam-sample through the HF-style entry: the device's torch.multinomial, repeatable under a seed
+    a = model.generate(inputs=audio, decoder_input_ids=prompt, decoder_attention_mask=prompt.ne(0), num_beams=2, do_sample=True,
+                       top_p=0.9, max_length=tgt, pad_token_id=0, eos_token_id=eos)
+    torch.manual_seed(11)
+    b = model.generate(inputs=audio, decoder_input_ids=prompt, decoder_attention_mask=prompt.ne(0), num_beams=2, do_sample=True,
+                       top_p=0.9, max_length=tgt, pad_token_id=0, eos_token_id=eos)
+    assert torch.equal(a, b) and a.shape[0] == prompt.shape[0] and torch.equal(a[:, :prompt.shape[1]].cpu(), prompt)
 
     # forward: teacher-forced on the reference's greedy ids
     seq = torch.from_numpy(g["ids"])[:, :-1]
@@ -768,18 +773,21 @@ def test_conditioning_embedders_fp32_match_reference_golden():
         model_generate(model, tok, dict(inputs=audio, decoder_input_ids=prompt, decoder_attention_mask=prompt.ne(0)), gen_kwargs(tgt))
 
 
-@pytest.mark.parametrize("run", ["b2", "b3", "b2p", "b3p", "b2g", "b3g"])
+@pytest.mark.parametrize("run", ["b2", "b3", "b2p", "b3p", "b2g", "b3g", "b2s", "b3s", "b2sg"])
 def test_fp32_beam_search_matches_reference_golden(run):
     """`num_beams` 2 / 3 through `model_generate` on the HIP path (mapperatorinator_amd/beam.py over mh_t5_step /
     mh_t5_reorder_cache): the ids the REFERENCE returned for the same inputs through HF beam search and its cache reorder
     (tests/golden/t5_tiny_beam.npz), bit for bit -- hypotheses of different lengths, processors and EOS windows included.  `b2g` /
     `b3g`: classifier-free guidance under beams (doubled rows, HF's processor on log-probabilities, the reference's
-    `beam_idx.repeat(2)` cache gather)."""
+    `beam_idx.repeat(2)` cache gather).  `b2s` / `b3s` / `b2sg`: beam-SAMPLE (do_sample under beams; HF's top-k / top-p warpers with
+    `min_tokens_to_keep = #eos + 1`, K continuations drawn without replacement and kept in draw order) -- the reference and this
+    run draw through the same `testing.SeededMultinomial` (a CPU and a GPU torch generator cannot agree), handed in as
+    `generate_kwargs["beam_sample_fn"]`; without it the draw is torch.multinomial on the device (last assertion)."""
     import json
     from mapperatorinator_amd import Tokenizer
     from mapperatorinator_amd.server import model_generate
     from mapperatorinator_amd.t5_engine import T5_PRESETS
-    from mapperatorinator_amd.testing import DIVERSE_GAINS, random_t5_state_dict, synthetic_audio_varied
+    from mapperatorinator_amd.testing import DIVERSE_GAINS, SeededMultinomial, random_t5_state_dict, synthetic_audio_varied
     g = np.load(f"{GOLDEN}/t5_tiny_beam.npz")
     src, tgt = int(g["src"]), int(g["tgt"])
     tok = Tokenizer.benchmark_vocab(src_seq_len=src)
@@ -793,10 +801,18 @@ def test_fp32_beam_search_matches_reference_golden(run):
     if kw.get("cfg_scale", 1.0) > 1.0:
         neg = torch.from_numpy(g["negative"])
         mk.update(negative_prompt=neg, negative_prompt_attention_mask=neg.ne(0))
-    ids, stats = model_generate(model, tok, mk, gen_kwargs(tgt, **kw))
+    sampler = SeededMultinomial(json.loads(str(g["sample_seeds"]))[run]) if kw.get("do_sample") else None
+    ids, stats = model_generate(model, tok, mk, gen_kwargs(tgt, **kw, **({"beam_sample_fn": sampler} if sampler else {})))
     want = g["ids_" + run]
     assert ids.shape == want.shape and np.array_equal(ids.numpy(), want), (ids.tolist(), want.tolist())
     assert ids.dtype == torch.int64 and ids.device.type == "cpu" and stats["generated_tokens"] > 0
+    if sampler is not None:
+        assert sampler.calls == want.shape[1] - prompt.shape[1]          # one draw of K continuations per step, all chunks at once
+        torch.manual_seed(5)
+        own, _ = model_generate(model, tok, mk, gen_kwargs(tgt, **kw))       # the device's own torch.multinomial
+        torch.manual_seed(5)
+        again, _ = model_generate(model, tok, mk, gen_kwargs(tgt, **kw))
+        assert torch.equal(own, again) and own.shape[0] == want.shape[0] and not np.array_equal(own.numpy()[:, :want.shape[1]], want)
 
 
 def test_request_batcher_answers_every_request_like_a_call_of_its_own():

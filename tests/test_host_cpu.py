@@ -145,8 +145,8 @@ def test_eos_set_and_sampling_translation():
     assert eos[:2] == [2, 4]
     assert sp.cfg_scale == 1.0 and sp.n_cond == 0 and sp.lookback_types_first == 0 and sp.host_tok_flags is None
     assert build_sampling(tok, dict(num_beams=2), 512)[0].num_beams == 2       # beam search: mapperatorinator_amd/beam.py
-    with pytest.raises(NotImplementedError):
-        build_sampling(tok, dict(num_beams=2, do_sample=True), 512)            # beam-sample is not built
+    bs = build_sampling(tok, dict(num_beams=2, do_sample=True, top_k=30, top_p=0.9), 512)[0]      # beam-sample (round 5)
+    assert (bs.num_beams, bs.do_sample, bs.top_k) == (2, 1, 30) and abs(bs.top_p - 0.9) < 1e-6
 
 
 def test_types_first_sampling_translation():
@@ -356,6 +356,32 @@ def test_diffusion_tokenizer_and_class_vector():
     lean = DiffusionTokenizer(synthetic_diffusion_tokenizer_state(3))      # no difficulty / circle-size family
     assert lean.num_diff_classes == lean.num_cs_classes == 0
     assert get_class_vector(lean, DiffusionGenerationConfig(difficulty=4.0, circle_size=4.0)).sum() == 3
+
+
+def test_beam_sample_warpers_equal_hf():
+    """beam-sample: the top-k / top-p tail of `beam.BeamProcessors` against HF's own TopKLogitsWarper / TopPLogitsWarper
+    (transformers is third-party and installed) with `min_tokens_to_keep = #eos + 1`, on log-probabilities that already carry
+    -inf entries (the time-shift masks), ties included."""
+    from transformers.generation.logits_process import TopKLogitsWarper, TopPLogitsWarper
+    from mapperatorinator_amd.beam import BeamProcessors
+    from mapperatorinator_amd.server import Sampling
+    rng = torch.Generator().manual_seed(3)
+    for top_k, top_p, keep in ((0, 0.9, 2), (12, 1.0, 4), (5, 0.6, 9), (40, 0.95, 3), (0, 1.0, 2), (300, 0.2, 1)):
+        sp = Sampling()
+        sp.do_sample, sp.top_k, sp.top_p, sp.temperature = 1, top_k, top_p, 1.0
+        scores = torch.log_softmax(torch.randn(6, 200, generator=rng) * 3, -1)
+        scores[:, 17:40] = float("-inf")
+        scores[2, 100:110] = scores[2, 100]                                   # ties
+        want = scores.clone()
+        if top_k:
+            want = TopKLogitsWarper(top_k=top_k, min_tokens_to_keep=keep)(None, want)
+        if top_p < 1.0:
+            want = TopPLogitsWarper(top_p=top_p, min_tokens_to_keep=keep)(None, want)
+        got = BeamProcessors(sp, "cpu", min_tokens_to_keep=keep)(torch.zeros(6, 3, dtype=torch.long), scores)
+        assert torch.equal(got, want), (top_k, top_p, keep)
+        assert (torch.isfinite(got).sum(-1) >= min(keep, 177)).all()
+    sp.do_sample = 0
+    assert torch.equal(BeamProcessors(sp, "cpu")(torch.zeros(6, 3, dtype=torch.long), scores), scores)
 
 
 def test_graft_entry_build():
