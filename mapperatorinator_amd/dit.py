@@ -98,6 +98,13 @@ class DiTHIP:
         w.pos_freqs = t(torch.exp(-math.log(10000) * torch.arange(0, 64, dtype=torch.float32) / 64))
         w.t_freqs = t(torch.exp(-math.log(10000) * torch.arange(0, 128, dtype=torch.float32) / 128))
         sd = state_dict
+        # a state dict of another size would make the kernels read past its tensors: refuse before anything is packed
+        for key, want in (("y_embedder.class_embedding.0.weight", (hidden, class_size)),
+                          ("context_embedder.mlp.0.weight", (hidden, 2 * 128 + context_size)),
+                          ("blocks.0.attn.in_proj_weight", (3 * hidden, hidden))):
+            if tuple(sd[key].shape) != want:
+                raise ValueError(f"{key} is {tuple(sd[key].shape)}, the configuration (hidden {hidden}, context_size {context_size}, "
+                                 f"class_size {class_size}) needs {want}")
         w.first_w, w.first_b = t(sd["context_embedder.mlp.0.weight"], cfg.first_k_pad), t(sd["context_embedder.mlp.0.bias"])
         w.first_w3 = t3(sd["context_embedder.mlp.0.weight"], cfg.first_k_pad)
         w.t_w0, w.t_b0 = t(sd["t_embedder.mlp.0.weight"]), t(sd["t_embedder.mlp.0.bias"])

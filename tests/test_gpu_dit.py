@@ -215,8 +215,10 @@ def test_generate_events_in_events_out_matches_the_reference_golden():
     c = json.loads(str(g["gen_case"]))
     depth, hidden, heads = DIT_PRESETS[c["preset"]]
     tok = DiffusionTokenizer(synthetic_diffusion_tokenizer_state(c["tokenizer_seed"]))
-    dit = DiTHIP(random_dit_state_dict(depth, hidden, seed=c["weight_seed"], class_size=tok.num_tokens), depth, hidden, heads,
-                 device="cuda")
+    sd = random_dit_state_dict(depth, hidden, seed=c["weight_seed"], class_size=tok.num_tokens)
+    with pytest.raises(ValueError, match="class_size"):
+        DiTHIP(sd, depth, hidden, heads, device="cuda")                    # the default class_size (300) does not fit these weights
+    dit = DiTHIP(sd, depth, hidden, heads, class_size=tok.num_tokens, device="cuda")
     k = c["knobs"]
     pipe = DiffusionPipelineHIP(dit, timesteps=k["timesteps"], seq_len=k["seq_len"], max_seq_len=k["max_seq_len"],
                                 overlap_buffer=k["overlap_buffer"], cfg_scale=k["cfg_scale"], refine_model=dit,
