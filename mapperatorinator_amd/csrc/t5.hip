@@ -1179,8 +1179,9 @@ int prefill_prompt(const MhT5Config* c, const MhT5Weights* w, const void* cross_
   const int es = es_of(c->dtype);
   const int np_pad = round_up(np, 64);
   // arch 1 (VarWhisperDecoderLayer, modeling_varwhisper.py:633-741) through the same batched form: biased projections,
-  // rotate-half RoPE on q and on the cached keys, scores / 8 without a relative bias, fc1 -> gelu(erf) -> fc2.  Global layers
-  // only: the caller keeps the token-by-token path when the model has local (windowed) layers.
+  // rotate-half RoPE on q and on the cached keys, scores / 8 without a relative bias, fc1 -> gelu(erf) -> fc2.  A local
+  // (windowed) layer takes its own rotary table and the causal attention gets the band |k - q| <= local_window on top -- the
+  // keys the token-by-token step attends (decode_kernels.hpp `window`).
   const bool wh = c->arch == 1;
   if (wh) MH_REQUIRE(w->dec_rope != nullptr, "prefill: the Whisper family needs its rotary table");
   if (c->dtype == MH_BF16)
@@ -1207,14 +1208,16 @@ int prefill_prompt(const MhT5Config* c, const MhT5Weights* w, const void* cross_
     g.kv_H = H; g.kv_L = np; g.kv_Lpad = np_pad; g.cache_len = tgt;
     if (wh) g.bias = w->dec_qkv_b[l];
     MH_TRY(gemm(g, s));
+    const bool local = is_local_layer(c, l);
     if (wh) {   // rotate-half RoPE on q (all prompt positions) and on the keys just cached; position = column of the padded prompt
       const long wq = (long)rows * H * 4, wk = (long)B * H * np * 4;
+      const float* rope = (local && w->dec_rope_local) ? w->dec_rope_local : w->dec_rope;
       if (c->dtype == MH_BF16) {
-        hipLaunchKernelGGL(mh::rope_qk_kernel<bf16_t>, dim3((unsigned)((wq + 255) / 256)), dim3(256), 0, s, (bf16_t*)pb.q, inner, (long)rows, np, H, w->dec_rope);
-        hipLaunchKernelGGL(mh::rope_cache_kernel<bf16_t>, dim3((unsigned)((wk + 255) / 256)), dim3(256), 0, s, (bf16_t*)kc, (long)B * H, tgt, np, w->dec_rope);
+        hipLaunchKernelGGL(mh::rope_qk_kernel<bf16_t>, dim3((unsigned)((wq + 255) / 256)), dim3(256), 0, s, (bf16_t*)pb.q, inner, (long)rows, np, H, rope);
+        hipLaunchKernelGGL(mh::rope_cache_kernel<bf16_t>, dim3((unsigned)((wk + 255) / 256)), dim3(256), 0, s, (bf16_t*)kc, (long)B * H, tgt, np, rope);
       } else {
-        hipLaunchKernelGGL(mh::rope_qk_kernel<float>, dim3((unsigned)((wq + 255) / 256)), dim3(256), 0, s, (float*)pb.q, inner, (long)rows, np, H, w->dec_rope);
-        hipLaunchKernelGGL(mh::rope_cache_kernel<float>, dim3((unsigned)((wk + 255) / 256)), dim3(256), 0, s, (float*)kc, (long)B * H, tgt, np, w->dec_rope);
+        hipLaunchKernelGGL(mh::rope_qk_kernel<float>, dim3((unsigned)((wq + 255) / 256)), dim3(256), 0, s, (float*)pb.q, inner, (long)rows, np, H, rope);
+        hipLaunchKernelGGL(mh::rope_cache_kernel<float>, dim3((unsigned)((wk + 255) / 256)), dim3(256), 0, s, (float*)kc, (long)B * H, tgt, np, rope);
       }
       MH_TRY(check_launch("rope (prefill)"));
     }
@@ -1225,7 +1228,7 @@ int prefill_prompt(const MhT5Config* c, const MhT5Weights* w, const void* cross_
     if (!wh) { a.bias = w->dec_rel_bias; a.bias_hs = tgt; a.bias_center = 0; a.bias_sign = -1; a.bias_min = 0; a.bias_max = tgt - 1; }
     a.key_mask = prompt_mask; a.mask_ld = P; a.mask_len = np;
     a.out = pb.attn; a.out_rs = (long)inner * es; a.out_bs = (long)np * inner * es;
-    a.Lq = np; a.Lk = np; a.scale = wh ? c->attn_scale : 1.0f; a.band = 0; a.causal = 1; a.q_pos0 = 0;
+    a.Lq = np; a.Lk = np; a.scale = wh ? c->attn_scale : 1.0f; a.band = local ? -c->local_window : 0; a.causal = 1; a.q_pos0 = 0;
     MH_TRY(attention_general(a, B, H, c->dtype, s));
     g = MhGemm{};
     g.A = pb.attn; g.lda = inner; g.W = w->dec_o[l]; g.ldw = inner; g.C = pb.h; g.ldc = d; g.M = rows; g.N = d; g.K = inner;
@@ -1515,9 +1518,7 @@ extern "C" int mh_t5_generate(const MhT5Config* c, const MhT5Weights* w, const v
   // batched prompt prefill (positions 0..P-2); MH_DECODE_PREFILL=0 feeds the prompt token by token instead
   int start_pos = 0;
   {
-    bool has_local = false;
-    for (int l = 0; l < c->n_dec_layers; ++l) has_local = has_local || is_local_layer(c, l);
-    if (P > 1 && option(OPT_DECODE_PREFILL) != 0 && !has_local) {   // (a Whisper-family model with local layers feeds its prompt token by token)
+    if (P > 1 && option(OPT_DECODE_PREFILL) != 0) {
       PrefillBuf pb;
       const int64_t used_dec = ar.off;
       prefill_layout(c, B, P - 1, (char*)workspace + used_dec, workspace_bytes - used_dec, &pb);
@@ -1715,8 +1716,6 @@ extern "C" int mh_t5_decoder_forward(const MhT5Config* c, const MhT5Weights* w, 
                                      int64_t workspace_bytes, void* stream) {
   mh::OptionScope option_scope(c ? c->options : nullptr);
   MH_TRY(check_cfg(c, "mh_t5_decoder_forward"));
-  for (int l = 0; l < c->n_dec_layers; ++l)
-    MH_REQUIRE(!is_local_layer(c, l), "mh_t5_decoder_forward: local (windowed) layers have no batched prompt path -- use mh_t5_generate with `forced` and `logits_dump`");
   MH_REQUIRE(w && cross_kv && ids && logits && workspace, "mh_t5_decoder_forward: null argument");
   MH_REQUIRE(B > 0 && T >= 1 && T <= c->tgt_len, "mh_t5_decoder_forward: T=%d not in [1, tgt_len=%d]", T, c->tgt_len);
   MH_REQUIRE(workspace_bytes >= mh_t5_forward_workspace_bytes(c, B, T), "mh_t5_decoder_forward: workspace too small");

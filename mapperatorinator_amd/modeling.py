@@ -210,27 +210,6 @@ class MapperatorinatorHIP:
         mask = (decoder_attention_mask.to(eng.device).to(torch.uint8).contiguous()
                 if decoder_attention_mask is not None else None)
         row_bias = self._row_bias(ids.shape[0], unused) if encoder_outputs is None else None
-        if self.is_whisper and self._has_local_layers():
-            # local (windowed) layers have no batched teacher-forced path: the token loop with the ids forced and its scores
-            # dumped (no processors: an empty sampling struct leaves the logits as they are)
-            from .server import Sampling
-            sp = Sampling()
-            sp.temperature, sp.cfg_scale, sp.max_length, sp.pad_id = 1.0, 1.0, ids.shape[1] + 1, int(self.config.pad_token_id)
-            if sp.max_length > self.config.max_target_positions:
-                raise ValueError("forward(): sequence longer than max_target_positions - 1")
-            forced = torch.zeros((ids.shape[0], sp.max_length), dtype=torch.int32, device=eng.device)
-            forced[:, :ids.shape[1]] = ids
-            eos_table = torch.zeros(self.config.vocab_size, dtype=torch.uint8, device=eng.device)
-            eng._enter()
-            with torch.cuda.stream(eng.stream):
-                kv = self._cross_kv(frames, encoder_outputs, None)
-                m1 = None if mask is None else mask[:, :1].contiguous()
-                _, _, dump = eng.decode(kv, ids[:, :1].contiguous(), m1, eos_table, sp, forced=forced, dump_logits=True)
-                logits = dump[1:ids.shape[1] + 1].transpose(0, 1).contiguous()
-            eng._leave()
-            if mask is not None and not bool(mask.all()):
-                raise NotImplementedError("forward() of the Whisper family with padded decoder_input_ids")
-            return types.SimpleNamespace(logits=logits, encoder_last_hidden_state=None, past_key_values=None, loss=None)
         eng._enter()
         with torch.cuda.stream(eng.stream):
             logits = eng.decoder_forward(self._cross_kv(frames, encoder_outputs, row_bias), ids, mask)
@@ -238,10 +217,6 @@ class MapperatorinatorHIP:
         return types.SimpleNamespace(logits=logits, encoder_last_hidden_state=None, past_key_values=None, loss=None)
 
     __call__ = forward
-
-    def _has_local_layers(self) -> bool:
-        cfg = self.engine.packed.cfg
-        return bool(cfg.arch == 1 and cfg.local_every > 1 and cfg.local_window > 0 and cfg.n_dec_layers > 1)
 
     @torch.no_grad()
     def generate(self, inputs=None, frames=None, decoder_input_ids=None, decoder_attention_mask=None,

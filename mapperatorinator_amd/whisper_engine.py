@@ -16,8 +16,7 @@ reference applies on its flash-attention path (:330); its eager / sdpa paths ign
 every layer global (configs/model/default.yaml:24).
 
 Numerics contract: as t5_engine.py (bf16 storage = bf16 parameters and GEMM operands, fp32 accumulation / residual
-stream / norms / softmax / GELU / logits).  The prompt goes through the batched prefill (RoPE on q and on the cached keys, biased GEMMs); a model with local (windowed)
-layers feeds it token by token.
+stream / norms / softmax / GELU / logits).  The prompt goes through the batched prefill (RoPE on q and on the cached keys, biased GEMMs; local layers: their own rotary table + the causal band).
 """
 from __future__ import annotations
 
@@ -203,10 +202,3 @@ class VarWhisperEngine(T5Engine):
                              f"this engine was built for src_seq_len={p.in_frames}")
         return self.spectrogram.forward_padded(audio, p.n_mels_pad, self.dtype)
 
-    def decoder_forward(self, cross_kv, ids, mask=None):
-        """Batched teacher-forced logits (the prompt-prefill form over all positions); a model with local (windowed) layers
-        has no such path -- use generate(..., forced=ids, dump_logits=True)."""
-        cfg = self.packed.cfg
-        if cfg.local_every > 1 and cfg.local_window > 0 and cfg.n_dec_layers > 1:
-            raise NotImplementedError("teacher-forced forward with local layers: use generate(..., forced=ids, dump_logits=True)")
-        return super().decoder_forward(cross_kv, ids, mask)

@@ -140,6 +140,25 @@ def test_local_layers_fp32_vs_oracle_window():
     want = o.generate(enc_o, prompt, prompt.ne(0), [tok.eos_id], tgt, ts0, ts1, [tok.sos_id])
     ids, _ = model_generate(model, tok, dict(inputs=audio, decoder_input_ids=prompt, decoder_attention_mask=prompt.ne(0)), gen_kwargs(tgt))
     assert torch.equal(ids, want)
+    # round 5: local layers in the BATCHED prompt prefill.  A prompt longer than the window (8 keys back): the first 20 tokens of
+    # the run above as the prompt, one row left-padded -- the continuation must be the oracle's token-by-token one
+    long_prompt = want[:, :20].clone()
+    long_prompt[1, :3] = 0
+    long_prompt[1, 3] = 1
+    want_long = o.generate(enc_o, long_prompt, long_prompt.ne(0), [tok.eos_id], tgt, ts0, ts1, [tok.sos_id])
+    got_long, _ = model_generate(model, tok, dict(inputs=audio, decoder_input_ids=long_prompt, decoder_attention_mask=long_prompt.ne(0)),
+                                 gen_kwargs(tgt))
+    assert torch.equal(got_long, want_long), (got_long.tolist(), want_long.tolist())
+    glob_long = o_glob.generate(o_glob.encode_audio(audio), long_prompt, long_prompt.ne(0), [tok.eos_id], tgt, ts0, ts1, [tok.sos_id])
+    assert not torch.equal(glob_long, want_long), "the case must tell the windowed model from the global one"
+    # ... and in the batched teacher-forced forward (mh_t5_decoder_forward): logits of all 24 positions at once
+    seq = want[:, :24].contiguous()
+    seq[:, 0] = 1
+    _, sc = o.generate(enc_o, seq[:, :1], None, [], seq.shape[1] + 1, 0, 0, [], forced=torch.cat([seq, seq[:, :1]], 1), return_logits=True)
+    logits = model.forward(frames=audio, decoder_input_ids=seq).logits.cpu()
+    err = (logits - torch.stack(sc, 1)).abs().max().item()
+    print("local layers: batched forward max abs logit err vs the oracle's token loop", err)
+    assert err < 5e-4
 
 
 def test_forward_seam_and_guidance():
