@@ -907,6 +907,42 @@ def test_mx8_encoder_against_the_mx8_contract_oracle(name):
     assert err.mean() < 0.01 * want.pow(2).mean().sqrt()
 
 
+@pytest.mark.parametrize("size", ["base", "large"])
+def test_mx8_one_encoder_block_against_the_contract_oracle(size):
+    """The MX-fp8 mode held to its contract WITHOUT compounding: ONE encoder block (+ the final norm) at the dims config 5 quotes
+    (osuT5-base / -large, 1251 frames), HIP against oracle/t5.py under the same contract.  With a single block nothing re-quantises
+    the differences of a layer before: what is left are the elements whose bf16 / e4m3 rounding flips on fp32 summation order.
+    Measured: mean 7.8e-4 (base) / 9.3e-4 (large) of a state with rms 1.0 -- 0.2 bf16 ulp -- against a mode distance of 3.2e-3; 99.0 % /
+    98.7 % of the elements within 2 bf16 ulps, max 0.05-0.06 (a flipped e4m3 element is a 12 % change of one operand element; the matrix
+    core's 13-bit product alignment, DESIGN section 2, adds ~2^-11 per output).  Gates at ~1.4 x that: a mis-scaled block or a stale
+    operand moves EVERY element by the mode distance or more."""
+    import dataclasses
+    from mapperatorinator_amd import Tokenizer
+    from mapperatorinator_amd.modeling import MapperatorinatorHIP
+    from mapperatorinator_amd.t5_engine import T5_PRESETS
+    from mapperatorinator_amd.testing import random_t5_state_dict, synthetic_audio_varied
+    from oracle import t5 as ot5
+    src, tgt = 1251, 16
+    d = dataclasses.replace(T5_PRESETS[size], n_enc_layers=1, n_dec_layers=1)
+    tok = Tokenizer.benchmark_vocab(src_seq_len=src)
+    sd = random_t5_state_dict(d, tok.vocab_size_in, tok.vocab_size_out, seed=61, lm_head_gain=2.0)
+    audio = synthetic_audio_varied(2, (src - 1) * 128, seed=17)
+    states = {}
+    for mode in ("mx8", None):
+        m = MapperatorinatorHIP(sd, d, vocab_size_in=tok.vocab_size_in, vocab_size_out=tok.vocab_size_out, src_seq_len=src, tgt_seq_len=tgt,
+                                dtype=torch.bfloat16, device="cuda", **({"enc_operand_dtype": mode} if mode else {}))
+        states[mode] = m.engine.encode(audio.cuda(), want_f32=True)[1].cpu()
+        del m
+    want = ot5.T5Oracle(sd, d.d_model, d.d_ff, d.n_heads, 1, 1, rounding="bf16", enc_mx8=True).encode_audio(audio)
+    err, dist = (states["mx8"] - want).abs(), (want - states[None]).abs()
+    rms = want.pow(2).mean().sqrt().item()
+    ulp = rms * 2.0 ** -8
+    print(f"one {size} block: |HIP mx8 - oracle mx8| mean {err.mean():.2e} p99 {err.flatten().quantile(0.99):.2e} max {err.max():.2e}; "
+          f"mode distance mean {dist.mean():.2e}; state rms {rms:.3f} (bf16 ulp {ulp:.2e}); share within 2 ulp {(err <= 2 * ulp).float().mean():.4f}")
+    assert err.mean() <= 0.4 * dist.mean() and err.mean() <= 1.3e-3 * rms
+    assert (err <= 2 * ulp).float().mean() >= 0.98 and err.max() <= 0.1 * rms
+
+
 @pytest.mark.parametrize("name", ["t5_base", "t5_large"])
 def test_mx8_encoder_teacher_forced_on_the_reference_fp32_run(name):
     """The MX-fp8 encoder mode at the sizes config 5 quotes, teacher-forced on the ids the fp32 REFERENCE produced
