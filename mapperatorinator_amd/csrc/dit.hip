@@ -610,8 +610,7 @@ int dit_body(const MhDiTConfig* c, const MhDiTWeights* w, const float* x, const 
   }
   // fp32 semantics, big batches: the bf16 x 3 GEMMs with BOTH operands pre-split (gemm_s3g_kernel: three-stage LDS-DMA,
   // no conversion work inside the GEMM) -- LayerNorm-modulate, the attention and the GELU epilogue write their outputs as
-  // [32 x bf16 hi | 32 x bf16 lo] per 32 values straight away (the same bytes as fp32, the same buffers).  Option
-  // dit_s3_presplit = 0: the 64 x 64 kernel that splits A while staging it.
+  // [32 x bf16 hi | 32 x bf16 lo] per 32 values straight away (the same bytes as fp32, the same buffers).
   const bool s3g = !lowp && !lowp8 && s3 && D % 32 == 0;
   for (int l = 0; l < c->depth && s3g; ++l) {
     const float* mod = b.cond_cur + (long)l * 6 * D;
