@@ -436,7 +436,7 @@ __global__ __launch_bounds__(256) void dec_sample_kernel(SampleP p) {
   __shared__ int si[8];
   __shared__ float s3[12];
   __shared__ float s_e[256 * kSampleRegs];
-  __shared__ int s_tok[2];
+  __shared__ int s_is_last;
   __shared__ float s_sum, s_temp;
   __shared__ int s_timed;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -448,24 +448,37 @@ __global__ __launch_bounds__(256) void dec_sample_kernel(SampleP p) {
   const int bneg = p.b0 + lneg;
   const int gr = cfg ? lneg : b;               // index among the returned rows
   const int R = cfg ? p.pair : p.B;
+  // Requested before anything else, all in ONE round trip: this row's logits (vocabularies of <= 4096 ids sit in registers,
+  // thread t holds ids t, t + 256, ...), its finished flag and time-shift state -- none of them depends on the position.
+  // (The loop form `for (v = tid; v < V; v += 256) lg[v]` is a chain of V / 256 dependent round trips: the trip count is
+  // dynamic, so hipcc neither unrolls it nor hoists the loads.)
+  const float* lg = p.logits + (long)lb * p.ldl;
+  const float* lgn = p.logits + (long)lneg * p.ldl;
+  const bool in_regs = p.V <= 256 * kSampleRegs;
+  float raw[kSampleRegs], rawn[kSampleRegs];
+  if (in_regs) {
+#pragma unroll
+    for (int i = 0; i < kSampleRegs; ++i) {
+      int v = tid + 256 * i;
+      v = v < p.V ? v : p.V - 1;
+      raw[i] = lg[v];
+      rawn[i] = cfg ? lgn[v] : 0.f;
+    }
+  }
+  const bool was_finished = p.finished[b] != 0;
+  const int ltv = p.last_ts_val[b];
   const int pos = p.st->pos;
   const int col = pos + 1;  // column being produced
   const MhSampling& sp = p.sp;
   if (col >= p.max_length) return;
+  int nxt[2] = {0, 0};      // the ids the next step is fed (row b, and under guidance its negative-prompt row)
 
   if (col < p.P) {
     // still inside the prompt: the token is given; only advance the processor state + embedding
-    if (tid < nrow) {
-      const int row = tid == 0 ? b : bneg;
-      const int tok = p.tokens[(long)row * p.max_length + col];
-      if (tid == 0) dec::store_wt(&p.last_ts_val[b], next_ts_state(sp, tok, p.last_ts_val[b]));
-      s_tok[tid] = tok;
-    }
-    __syncthreads();
+    nxt[0] = p.tokens[(long)b * p.max_length + col];
+    if (cfg) nxt[1] = p.tokens[(long)bneg * p.max_length + col];
+    if (tid == 0) dec::store_wt(&p.last_ts_val[b], next_ts_state(sp, nxt[0], ltv));
   } else {
-    const float* lg = p.logits + (long)lb * p.ldl;
-    const float* lgn = p.logits + (long)lneg * p.ldl;
-    const int ltv = p.last_ts_val[b];
     if (tid == 0) {
       // ConditionalTemperatureLogitsWarper: the lookback is ROW 0's history for the whole batch
       // (logit_processors.py:75-80 `input_ids[0, -max_offset:]`), first matching rule wins; cond_per_row: the row's
@@ -484,11 +497,10 @@ __global__ __launch_bounds__(256) void dec_sample_kernel(SampleP p) {
     const float temp = s_temp;
     const bool lb_range_on = sp.lookback_mask_end > sp.ts_start;
     // CFG -> monotonic -> bias -> temperature
-    auto warped = [&](int v) -> float {
-      float x = lg[v];
+    auto warped_of = [&](int v, float x, float xn) -> float {
       // HF ClassifierFreeGuidanceLogitsProcessor on the reference's row order (first half = negative prompt):
       // uncond + (cond - uncond) * scale with cond = first half, no fused multiply-add
-      if (cfg) x = __fadd_rn(x, __fmul_rn(__fsub_rn(lgn[v], x), sp.cfg_scale));
+      if (cfg) x = __fadd_rn(x, __fmul_rn(__fsub_rn(xn, x), sp.cfg_scale));
       // MonotonicTimeShiftLogitsProcessor: ids [ts_start, ts_start + value) -> -inf
       if (ltv >= 0 && v >= sp.ts_start && v < sp.ts_start + ltv) x = -INFINITY;
       // TimeshiftBias
@@ -496,6 +508,7 @@ __global__ __launch_bounds__(256) void dec_sample_kernel(SampleP p) {
       // TemperatureLogitsWarper / ConditionalTemperatureLogitsWarper (scores / temperature)
       return x / temp;
     };
+    auto warped = [&](int v) -> float { return warped_of(v, lg[v], cfg ? lgn[v] : 0.f); };
     float* dump = p.logits_dump ? p.logits_dump + ((long)col * R + gr) * p.V : nullptr;
     float* fin = p.proc + (long)gr * p.V;
     float best = -INFINITY;
@@ -547,10 +560,20 @@ __global__ __launch_bounds__(256) void dec_sample_kernel(SampleP p) {
           consider(v, x);
         }
       }
+    } else if (in_regs) {
+#pragma unroll
+      for (int i = 0; i < kSampleRegs; ++i) {
+        const int v = tid + 256 * i;
+        if (v < p.V) {
+          float x = warped_of(v, raw[i], rawn[i]);
+          // LookbackBiasLogitsWarper, types_first == False branch
+          if (lb_range_on && v >= sp.ts_start && v < sp.lookback_mask_end) x = -INFINITY;
+          consider(v, x);
+        }
+      }
     } else {
       for (int v = tid; v < p.V; v += 256) {
         float x = warped(v);
-        // LookbackBiasLogitsWarper, types_first == False branch
         if (lb_range_on && v >= sp.ts_start && v < sp.lookback_mask_end) x = -INFINITY;
         consider(v, x);
       }
@@ -748,28 +771,29 @@ __global__ __launch_bounds__(256) void dec_sample_kernel(SampleP p) {
       __syncthreads();
       tok = si[5];
     }
+    // every thread knows the emitted id (the finished flag came with the first round trip), so the embedding row below is
+    // requested at once -- beside thread 0's EOS lookup and bookkeeping stores, not behind them
+    const bool forced = p.forced != nullptr;
+    const int emit = was_finished ? sp.pad_id : tok;      // HF: finished rows receive pad_token_id
+    nxt[0] = forced ? p.forced[(long)b * p.max_length + col] : emit;
+    if (cfg) nxt[1] = forced ? p.forced[(long)bneg * p.max_length + col] : emit;
     if (tid == 0) {
-      const bool forced = p.forced != nullptr;
-      const bool was_finished = p.finished[b] != 0;
-      const int emit = was_finished ? sp.pad_id : tok;      // HF: finished rows receive pad_token_id
       const bool done = !forced && !was_finished && (p.eos_table[emit] || col + 1 >= sp.max_length);
       for (int j = 0; j < nrow; ++j) {   // the rows of a CFG pair receive the same id (decoder_input_ids.repeat)
         const int row = j == 0 ? b : bneg;
         dec::store_wt(p.tokens + (long)row * p.max_length + col, (int32_t)emit);
-        s_tok[j] = forced ? p.forced[(long)row * p.max_length + col] : emit;
         if (done) {
           __hip_atomic_store(&p.finished[row], (uint8_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // read by the last-arriving workgroup below
           dec::store_wt(p.finish_col + row, (int32_t)col);
         }
       }
-      dec::store_wt(&p.last_ts_val[b], next_ts_state(sp, s_tok[0], ltv));
+      dec::store_wt(&p.last_ts_val[b], next_ts_state(sp, nxt[0], ltv));
     }
-    __syncthreads();
   }
   // embedding of the token that the next step consumes (decoder_embedder, modeling_mapperatorinator.py:205-206)
   for (int j = 0; j < nrow; ++j) {
     const int lrow = j == 0 ? lb : lneg;
-    const T* e = reinterpret_cast<const T*>(p.dec_embed) + (long)s_tok[j] * p.d;
+    const T* e = reinterpret_cast<const T*>(p.dec_embed) + (long)nxt[j] * p.d;
     for (int i = tid * 4; i < p.d; i += 1024) {   // 16-byte write-through pieces (d is a multiple of 4)
       float v4[4];
 #pragma unroll
@@ -781,14 +805,23 @@ __global__ __launch_bounds__(256) void dec_sample_kernel(SampleP p) {
   // last may advance it; it also recounts the running rows for the host's early-stop poll.  The `finished` flags are
   // agent-scope stores drained before the ticket is taken and agent-scope loads here (write-through hand-off, no
   // fence); a stale flag could only delay the early stop by a poll, never change a token.
+  // The recount is ONE round trip of the last workgroup's first wave (lane i reads row i's flag), not chain_rows serial ones.
   if (tid == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const int t = __hip_atomic_fetch_add(&p.st->ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (t == (int)gridDim.x - 1) {
+    s_is_last = t == (int)gridDim.x - 1;
+  }
+  __syncthreads();
+  if (s_is_last && wid == 0) {
+    int run = 0;
+    for (int i0 = 0; i0 < p.chain_rows; i0 += 64) {
+      const int i = i0 + lane;
+      const bool running = i < p.chain_rows &&
+                           __hip_atomic_load(&p.finished[p.b0 + (i < p.chain_rows ? i : 0)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
+      run += __popcll(__ballot(running));
+    }
+    if (lane == 0) {
       __hip_atomic_store(&p.st->ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      int run = 0;
-      for (int i = 0; i < p.chain_rows; ++i)
-        run += __hip_atomic_load(&p.finished[p.b0 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 0 : 1;
       dec::store_wt(&p.st->n_running, run);
       dec::store_wt(&p.st->pos, pos + 1);
     }
