@@ -492,8 +492,9 @@ def main():
     use_rows = rows_per_launch if in_situ_us else B
     achieved = use_rows * bytes_per_row / (use_us * 1e-6) / 1e9
     pmc_record = {}
+    pmc_file = "r05_pmc_cross_attn.json"      # the latest counter passes of this command (round 4's record: r04_pmc_cross_attn.json)
     try:
-        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r04_pmc_cross_attn.json")) as fh:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", pmc_file)) as fh:
             pmc_record = json.load(fh)
         pmc_record["rows_per_launch"] = 32 // int(pmc_record.get("step", {}).get("decode_chains", 1))
     except (OSError, ValueError):
@@ -504,7 +505,7 @@ def main():
         # PMC FETCH_SIZE / WRITE_SIZE need rocprofv3 around the process: not measurable from inside this run.  The committed
         # record of the counter passes of THIS command in the timed configuration (two 16-row chains) is quoted instead.
         "traffic": pmc_record.get("hbm_bytes_per_launch") if pmc_record.get("rows_per_launch") == use_rows else None,
-        "traffic_source": ("profiles/r04_pmc_cross_attn.json / r04_pmc_hbm_traffic.txt: rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE "
+        "traffic_source": ("profiles/" + pmc_file + " / r05_pmc_hbm_traffic.txt: rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE "
                            "(separate passes) around this command, builder-run, two 16-row decode chains fed by one launcher thread "
                            "(MH_DECODE_LAUNCH_THREADS=0); bytes = 2 x FETCH_SIZE x 1024 + WRITE_SIZE x 1024 per launch (gfx950 correction of "
                            "MI355X_MICROARCH.md); the counter passes cannot run inside this process"),
