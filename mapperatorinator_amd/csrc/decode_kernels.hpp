@@ -968,7 +968,9 @@ void dec_cross_attn_q_kernel(const float* h_, const float* lnw_, const void* W_,
   if (sizeof(T) == 2) proj.load(hp, row0);
   // (LDS-DMA prefetch of every wave's first 1-3 key iterations during this prologue -- 32 KB of LDS per iteration, issued as
   // inline asm behind shadow loads so that no wait of the prologue covers it -- was built and measured: 703 / 703 / 729 us
-  // per token step for 1 / 2 / 3 iterations against 679 without.  Not kept.)
+  // per token step for 1 / 2 / 3 iterations against 679 without.  Not kept.  Round 5, the same idea through REGISTERS (every lane
+  // group's first key / value row, 32 bytes per lane, requested beside the prologue's operands): 285.8-286.5 ms per batch against
+  // 276.7-277.0 -- the stream's requests queue in front of the weight slice the prologue waits for.  Not kept either.)
   unsigned long long t_start = 0;
   if (p.tstamp && threadIdx.x == 0) t_start = (unsigned long long)wall_clock64();
   nrow.finish(hp, xn, red16);
