@@ -5,8 +5,16 @@
   side mirroring the reference's Python seams: `model_generate`, `Mapperatorinator`,
   `DiT.forward_with_cfg`, `diffusion.p_sample_loop`, `Tokenizer` / `Event`.
 """
-from .event import ContextType, Event, EventRange, EventType  # noqa: F401
-from .tokenizer import Tokenizer  # noqa: F401
+import os as _os
+
+# HIP runtime knob (read once, when the runtime initialises -- import this package before the first torch.cuda call): the step
+# graphs of the decode loop replay faster through the runtime's classic per-node submission than through its captured-AQL-packet
+# path: 272-274 vs 277-278 ms per batch of the headline workload, 4 chains 335 vs 416 ms (profiles/r05_graph_packet_capture.txt).
+# An explicit value in the environment wins; C hosts of libmapperhip.so set it themselves (INTEGRATION.md).
+_os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+
+from .event import ContextType, Event, EventRange, EventType  # noqa: F401,E402
+from .tokenizer import Tokenizer  # noqa: F401,E402
 
 __all__ = ["ContextType", "Event", "EventRange", "EventType", "Tokenizer", "MapperatorinatorHIP",
            "model_generate", "DiTHIP", "create_diffusion", "MelSpectrogram"]

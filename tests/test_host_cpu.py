@@ -384,6 +384,19 @@ def test_beam_sample_warpers_equal_hf():
     assert torch.equal(BeamProcessors(sp, "cpu")(torch.zeros(6, 3, dtype=torch.long), scores), scores)
 
 
+def test_runtime_flag_default_does_not_override_the_environment():
+    """`import mapperatorinator_amd` sets DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 (the step graphs replay faster through the runtime's
+    per-node submission, profiles/r05_graph_packet_capture.txt) -- as a DEFAULT: an explicit value wins."""
+    import subprocess
+    import sys
+    code = "import os, mapperatorinator_amd; print(os.environ['DEBUG_CLR_GRAPH_PACKET_CAPTURE'])"
+    env = {k: v for k, v in os.environ.items() if k != "DEBUG_CLR_GRAPH_PACKET_CAPTURE"}
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.strip() == "0"
+    env["DEBUG_CLR_GRAPH_PACKET_CAPTURE"] = "1"
+    assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.strip() == "1"
+
+
 def test_graft_entry_build():
     """The driver's build check: `make` (incremental) + dlopen + ABI / layout verification, no GPU needed."""
     import __graft_entry__ as g
