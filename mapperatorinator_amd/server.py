@@ -19,7 +19,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .event import ContextType, EventType
+from .event import ContextType
 
 MILISECONDS_PER_SECOND = 1000
 MILISECONDS_PER_STEP = 10

@@ -12,7 +12,7 @@ Any object exposing the same attributes (e.g. the reference's own Tokenizer) can
 from __future__ import annotations
 
 import json
-from typing import Iterable, Optional
+from typing import Iterable
 
 from .event import ContextType, Event, EventRange, EventType
 

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN, assert_topk_scores_match, ts_range, vw_golden_case
+from conftest import assert_topk_scores_match, ts_range, vw_golden_case
 
 pytestmark = pytest.mark.gpu
 GAP_BF16 = 0.25
