@@ -384,6 +384,45 @@ def test_beam_sample_warpers_equal_hf():
     assert torch.equal(BeamProcessors(sp, "cpu")(torch.zeros(6, 3, dtype=torch.long), scores), scores)
 
 
+def test_diffusion_generate_host_flow_on_a_stand_in_denoiser():
+    """`DiffusionPipelineHIP.generate(events, config, timing)` without a GPU: the denoiser stage replaced by a stand-in that records
+    what it is handed.  The stage must receive the tensors / sliders of `events_to_sequence` under the pipeline's stream-format flags,
+    the class vector of the config and the null-class vector the reference builds (difficulty + circle size kept, descriptors =
+    negative_descriptors, diffusion_pipeline.py:151-155), and its positions must come back as POS_X / POS_Y events; an event stream
+    without hit objects is returned untouched and never reaches the stage."""
+    import types
+    from mapperatorinator_amd import diffusion_pipeline as dp
+    from mapperatorinator_amd.testing import synthetic_diffusion_tokenizer_state, synthetic_event_stream, synthetic_timing
+    tok = dp.DiffusionTokenizer(synthetic_diffusion_tokenizer_state(8))
+    pipe = dp.DiffusionPipelineHIP(types.SimpleNamespace(device="cpu"), timesteps=[2] + [0] * 9, tokenizer=tok, types_first=True, has_sv=True)
+    seen = {}
+
+    def stage(seq_x, seq_o, seq_c, cv, ucv, noise_source=None, sliders=None, **kw):
+        seen.update(seq_x=seq_x, seq_o=seq_o, seq_c=seq_c, cv=cv, ucv=ucv, sliders=sliders)
+        T = seq_x.shape[1]
+        return torch.stack([torch.arange(T, dtype=torch.float32) * 1.5 + 0.5, 300.0 - torch.arange(T, dtype=torch.float32)])[None]
+
+    pipe.generate_positions = stage
+    events, timing = synthetic_event_stream(30, 4, types_first=True), synthetic_timing(4)
+    cfg = dp.DiffusionGenerationConfig(difficulty=6.1, circle_size=3.5, slider_multiplier=1.9, descriptors=["d0"], negative_descriptors=["d3", "nope"])
+    out = pipe.generate(events, cfg, timing)
+    want = dp.events_to_sequence(events, timing, 1.9, types_first=True, has_sv=True)
+    assert torch.equal(seen["seq_x"], want[0]) and torch.equal(seen["seq_o"], want[1]) and torch.equal(seen["seq_c"], want[2])
+    assert [(s.seq_indices.tolist(), s.end_index, s.curve_type, s.length) for s in seen["sliders"]] == \
+           [(s.seq_indices.tolist(), s.end_index, s.curve_type, s.length) for s in want[5]] and len(want[5]) > 2
+    assert torch.equal(seen["cv"], dp.get_class_vector(tok, cfg))
+    null = dp.DiffusionGenerationConfig(difficulty=6.1, circle_size=3.5, descriptors=["d3", "nope"])
+    assert torch.equal(seen["ucv"], dp.get_class_vector(tok, null)) and not torch.equal(seen["ucv"], seen["cv"])
+    pos = stage(*want[:3], None, None)[0]
+    assert [(e.type.name, e.value) for e in out] == [(e.type.name, e.value) for e in dp.events_with_pos(events, pos, want[4])]
+    assert sum(e.type == EventType.POS_X for e in out) == sum(e.type == EventType.DISTANCE for e in events) > 20
+    seen.clear()
+    beats = [Event(EventType.TIME_SHIFT, 100), Event(EventType.BEAT), Event(EventType.TIME_SHIFT, 600), Event(EventType.MEASURE)]
+    assert pipe.generate(beats, cfg, timing) is beats and not seen
+    with pytest.raises(ValueError, match="tokenizer"):
+        dp.DiffusionPipelineHIP(types.SimpleNamespace(device="cpu"), timesteps=[2] + [0] * 9).generate(events, cfg, timing)
+
+
 def test_runtime_flag_default_does_not_override_the_environment():
     """`import mapperatorinator_amd` sets DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 (the step graphs replay faster through the runtime's
     per-node submission, profiles/r05_graph_packet_capture.txt) -- as a DEFAULT: an explicit value wins."""
