@@ -354,9 +354,14 @@ class T5Oracle:
 
     # ---- beam search ---------------------------------------------------------------------------------
     def _processed_log_probs(self, logits, hist, ts_start, ts_end, sos_ids, temperature, timeshift_bias, lookback_mask_end,
-                             top_k=0, top_p=1.0, min_tokens_to_keep=1):
-        """HF beam search hands the processors LOG-PROBABILITIES (generation/utils.py `_beam_search` step b)."""
+                             top_k=0, top_p=1.0, min_tokens_to_keep=1, cfg_scale=1.0):
+        """HF beam search hands the processors LOG-PROBABILITIES (generation/utils.py `_beam_search` step b).  `cfg_scale > 1`:
+        `logits` holds 2R rows [negative-prompt rows | prompt rows]; HF's ClassifierFreeGuidanceLogitsProcessor runs first and takes
+        the FIRST half as the conditional one (`uncond + (cond - uncond) * scale`, no renormalisation), R rows go on."""
         scores = torch.log_softmax(logits.float(), dim=-1)
+        if cfg_scale > 1.0:
+            first, second = scores.split(scores.shape[0] // 2, dim=0)
+            scores = second + (first - second) * cfg_scale
         sos = set(int(v) for v in sos_ids)
         for r in range(hist.shape[0]):
             row = hist[r].tolist()
@@ -383,7 +388,8 @@ class T5Oracle:
         return scores
 
     def generate_beam(self, enc, prompt, prompt_mask, eos_ids, max_length, ts_start, ts_end, sos_ids, num_beams, pad_id=0,
-                      temperature=1.0, timeshift_bias=0.0, lookback_mask_end=0, length_penalty=1.0, sample_fn=None, top_k=0, top_p=1.0):
+                      temperature=1.0, timeshift_bias=0.0, lookback_mask_end=0, length_penalty=1.0, sample_fn=None, top_k=0, top_p=1.0,
+                      negative_prompt=None, cfg_scale=1.0):
         """HF `GenerationMixin._beam_search` (third-party; the vectorised form of transformers >= 4.50, early_stopping =
         False, num_return_sequences = 1) as `model_generate` reaches it with `num_beams > 1` (processor.py:159), restated
         chunk by chunk with explicit candidate lists; the self-attention cache rows are re-gathered per step as
@@ -391,15 +397,28 @@ class T5Oracle:
         hypothesis per chunk, shorter rows filled with `pad_token_id or eos_token_id[0]` (HF's `output_fill_value`).
         `sample_fn(probs (B, nb V), K)`: beam-SAMPLE -- the K continuations are drawn without replacement from
         softmax(accumulated) in ONE call for all chunks (`_get_top_k_continuations`), kept in draw order, and the processed
-        log-probabilities pass HF's top-k / top-p warpers with `min_tokens_to_keep = #eos + 1` first."""
+        log-probabilities pass HF's top-k / top-p warpers with `min_tokens_to_keep = #eos + 1` first.
+        `negative_prompt` with `cfg_scale > 1`: guidance under beams as the reference + HF run it -- every (chunk, beam) row decoded
+        twice, [rows fed the negative prompt over the first prompt columns | the prompt's own rows] (prepare_inputs_for_generation,
+        modeling_mapperatorinator.py:243-254), guided log-probabilities for the ranking, and the doubled cache gathered with
+        `beam_idx.repeat(2)` (inference/cache_utils.py:16-20): BOTH halves take their rows from the FIRST half."""
         B, P = prompt.shape
+        cfg = negative_prompt is not None and cfg_scale > 1.0
         nb, V = int(num_beams), self.sd[[k for k in self.sd if k.endswith("lm_head.weight") or k.endswith("proj_out.weight")][0]].shape[0]
         R = B * nb
+        RE = 2 * R if cfg else R                                                   # rows the decoder runs
         ckv = self.cross_kv(enc.repeat_interleave(nb, 0))
-        cache = [(torch.zeros(R, self.H, max_length, 64), torch.zeros(R, self.H, max_length, 64)) for _ in range(self.nd)]
-        key_mask = torch.ones(R, max_length, dtype=torch.bool)
-        if prompt_mask is not None:
-            key_mask[:, :P] = prompt_mask.bool().repeat_interleave(nb, 0)
+        if cfg:
+            ckv = [(torch.cat([k, k], 0), torch.cat([v, v], 0)) for k, v in ckv]
+        cache = [(torch.zeros(RE, self.H, max_length, 64), torch.zeros(RE, self.H, max_length, 64)) for _ in range(self.nd)]
+        key_mask = torch.ones(RE, max_length, dtype=torch.bool)
+        if prompt_mask is not None:      # (the negative rows attend under the prompt's mask: HF swallows negative_prompt_attention_mask)
+            key_mask[:, :P] = prompt_mask.bool().repeat_interleave(nb, 0).repeat(2 if cfg else 1, 1)
+        fed_prompt = prompt.repeat_interleave(nb, 0)                               # what the decoder is fed over the prompt columns
+        if cfg:
+            neg = prompt.clone()
+            neg[:, :negative_prompt.shape[1]] = negative_prompt
+            fed_prompt = torch.cat([neg.repeat_interleave(nb, 0), fed_prompt], 0)
         eos_list = [int(e) for e in eos_ids]
         eos = set(eos_list)
         K = max(2, 1 + len(eos_list)) * nb
@@ -411,12 +430,16 @@ class T5Oracle:
         fin = [[(f32(-1e9), None, [], False) for _ in range(nb)] for _ in range(B)]  # (score, seq, beam-index history, finished)
         open_h = [True] * B
         for pos in range(P - 1):
-            self.decoder_step(prompt[:, pos].repeat_interleave(nb), pos, cache, ckv, key_mask)
+            self.decoder_step(fed_prompt[:, pos], pos, cache, ckv, key_mask)
         cur = P
         while True:
             flat = torch.tensor([run_seq[b][k] for b in range(B) for k in range(nb)])
-            logits = self.decoder_step(flat[:, cur - 1], cur - 1, cache, ckv, key_mask)
+            last = flat[:, cur - 1]
+            if cfg:      # both halves are fed the beam's last token; at the last prompt column the first half still has the negative prompt's
+                last = torch.cat([last if cur > P else fed_prompt[:R, P - 1], last], 0)
+            logits = self.decoder_step(last, cur - 1, cache, ckv, key_mask)
             lp = self._processed_log_probs(logits, flat, ts_start, ts_end, sos_ids, temperature, timeshift_bias, lookback_mask_end,
+                                           cfg_scale=cfg_scale if cfg else 1.0,
                                            **(dict(top_k=top_k, top_p=top_p, min_tokens_to_keep=(len(eos_list) + 1) if eos_list else 2)
                                               if sample_fn is not None else {}))
             src_rows = []
@@ -457,6 +480,8 @@ class T5Oracle:
                 run_seq[b], run_score[b], run_hist[b] = new_seq, new_score, new_hist
                 src_rows += [h[-1] for h in new_hist]
             src = torch.tensor(src_rows)
+            if cfg:
+                src = src.repeat(2)                                                # `beam_idx.repeat(2)`: indices into the FIRST half, twice
             for l in range(self.nd):                                               # reorder_cache(beam_idx)
                 Kc, Vc = cache[l]
                 cache[l] = (Kc[src].clone(), Vc[src].clone())
