@@ -31,17 +31,19 @@ import os
 import sys
 import time
 
-# Set before the HIP runtime initialises (it reads its flags once): the decode step's graphs replay 1.5-1.9 % faster through the
-# runtime's classic per-node submission than through its captured-packet path (profiles/r05_graph_packet_capture.txt).  The
-# package sets the same default on import; an explicit value in the environment wins.
-os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
-
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+
+# bench.py owns its process, so it makes the EXPLICIT runtime opt-in INTEGRATION.md 3 describes, before the HIP runtime
+# initialises (the package import itself never touches os.environ): hipGraph replay through the runtime's classic per-node
+# submission.  An explicit value in the environment wins; `aux.runtime_flag_ab` re-measures the headline under the runtime's
+# default path in a child process, so the line shows both.
+import mapperatorinator_amd  # noqa: E402
+RUNTIME = mapperatorinator_amd.configure_runtime()
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6.3 TB/s achievable
 F32_MFMA_PEAK_TF = 157.3  # exact-f32 MFMA (= fp32 vector) peak, same guide
@@ -63,6 +65,9 @@ def parse():
     ap.add_argument("--no-dit", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip config 1 / end-to-end / in-situ passes")
     ap.add_argument("--no-config5", action="store_true", help="skip the long-song (osuT5-large, 3 min songs) and DiT-B aux lines")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="time the headline region only and print {value, ms_per_step, runtime_env}: the child run of aux.runtime_flag_ab")
+    ap.add_argument("--no-runtime-ab", action="store_true", help="skip the child run under the runtime's default graph-replay path")
     ap.add_argument("--selftest-launch", action="store_true",
                     help="only form the process group (RCCL on a GPU box, gloo without one), all_gather the rank ids, print "
                          "{selftest, n_gpus, rccl_ranks} and exit: the launch path of --gpus N without the workload")
@@ -331,6 +336,16 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = n_tok_total / (elapsed / args.steps)
 
+    runtime_env = {k: os.environ.get(k) for k in ("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "GPU_MAX_HW_QUEUES", "HIP_FORCE_DEV_KERNARG")}
+    if args.headline_only:
+        if rank == 0:
+            print(json.dumps({"headline_only": True, "value": round(value, 1), "ms_per_step": round(ms_per_step, 2), "steps": args.steps,
+                              "runtime_env": runtime_env}), flush=True)
+        if use_dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
     # ---- per-stage milliseconds (one extra pass with events on the engine's stream; not the timed region) --------
     tokens, kv = one_step(record=True)
     fence()
@@ -341,8 +356,8 @@ def main():
     # ---- diffusion stage (configs[2] / [3]): every rank refines ITS chunks as one denoiser batch, coordinates are
     # all-gathered next to the tokens -------------------------------------------------------------------
     aux = {"stage_ms": stage,
-           # HIP runtime flags this process ran under (set at the top of this file unless the environment already had them)
-           "runtime_env": {k: os.environ.get(k) for k in ("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "GPU_MAX_HW_QUEUES", "HIP_FORCE_DEV_KERNARG")}}
+           # HIP runtime flags this process ran under (mapperatorinator_amd.configure_runtime() at the top of this file)
+           "runtime_env": runtime_env, "runtime_configure": RUNTIME}
     if not args.no_dit:
         from mapperatorinator_amd.dit import BandMask, DiTHIP, create_diffusion
         from mapperatorinator_amd.testing import DIT_PRESETS, random_dit_state_dict, synthetic_dit_inputs
@@ -727,6 +742,27 @@ def main():
         except Exception as e:
             aux.setdefault("errors", []).append(f"config5_long_songs: {e!r}")
             print(f"config 5 long-song pass failed: {e!r}", file=sys.stderr)
+
+    # ---- the headline under the OTHER graph-replay setting of the HIP runtime (a child process: the runtime reads the flag once) ----
+    if not args.no_extras and not args.no_runtime_ab and world == 1:
+        try:
+            import subprocess
+            var = "DEBUG_CLR_GRAPH_PACKET_CAPTURE"
+            other = "1" if os.environ.get(var, "1") == "0" else "0"
+            env = dict(os.environ, **{var: other})
+            torch.cuda.synchronize(dev)
+            cp = subprocess.run([sys.executable, os.path.abspath(__file__), "--headline-only", "--steps", str(args.steps), "--warmup", "1",
+                                 "--size", args.size, "--dtype", args.dtype, "--batch", str(B), "--new-tokens", str(new)],
+                                env=env, capture_output=True, text=True, timeout=600)
+            child = json.loads([ln for ln in cp.stdout.splitlines() if ln.startswith("{")][-1])
+            aux["runtime_flag_ab"] = {
+                "this_process": {var: os.environ.get(var), "value": round(value, 1), "ms_per_step": round(ms_per_step, 2)},
+                "child_process": {var: child["runtime_env"][var], "value": child["value"], "ms_per_step": child["ms_per_step"]},
+                "note": "same workload, same build; '0' = classic per-node graph submission (mapperatorinator_amd.configure_runtime(), "
+                        "explicit opt-in), '1' / unset = ROCm 7.2.0's default captured-AQL-packet replay.  Tokens are identical"}
+        except Exception as e:
+            aux.setdefault("errors", []).append(f"runtime_flag_ab: {e!r}")
+            print(f"runtime flag A/B failed: {e!r}", file=sys.stderr)
 
     cpu = None
     if not args.no_cpu_baseline and world == 1:   # the CPU port is timed on rank 0 at N=1 only

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MH_ABI_VERSION 9
+#define MH_ABI_VERSION 10
 #define MH_MAX_LAYERS 32
 
 typedef enum MhStatus {
@@ -227,6 +227,15 @@ int mh_whisper_frontend(const void* x, int B, int Lin, int C, const void* w1, co
                         const float* b2, const float* pos, int d, void* out, void* workspace,
                         int64_t workspace_bytes, int dtype, void* stream);
 
+/* (ABI 10) The wrapper's conditioning vectors as INPUT CHANNELS of the front-end: with project_encoder_input = false
+ * (configs/model/whisper_small_v2.yaml: the V30 / V31 'Tiger14n/ropewhisper-small' releases, cond_size 384) the per-row
+ * difficulty / mapper / song-position vectors are repeated over the frames and concatenated to the mel channels
+ * (osuT5/osuT5/model/modeling_mapperatorinator.py:183-202), so conv1 sees n_mels + cond_size channels -- a k = 3 convolution with
+ * zero padding, where the constant channels do NOT reduce to a row bias (the first and last frame miss one tap).
+ * frames [B * L, ld] (element type `dtype`, the K-padded buffer mh_mel wrote); cond fp32 [B, n_cond] (already rounded to the
+ * storage type by the caller); writes frames[(b, t)][col0 + j] = cond[b][j]. */
+int mh_cond_channels(void* frames, int B, int L, int ld, int col0, const float* cond, int n_cond, int dtype, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * T5 model object: weights are caller-owned device buffers (packed by the host, see
  * mapperatorinator_amd/t5_engine.py) described by MhT5Weights.  All matrices are [N][Kpad] row major,
@@ -260,6 +269,16 @@ typedef struct MhT5Config {
                                d_ff multiples of 128.  A reduced-precision mode of its own (the reference has none): gates
                                are error bounds against the fp32 reference goldens, never bit-exactness.                 */
   const MhOptionSet* options;   /* ABI 8: this engine's option overrides (mh_options_create), NULL = the process-wide values */
+  /* --- ABI 10: arch 2 = stock HF Whisper ('openai/whisper-*': the V28 / V29 releases, configs/model/whisper_{base,small}.yaml;
+   * transformers models/whisper/modeling_whisper.py): the wrapper's encoder_embedder (n_mels [+ cond] -> d, as arch 0) in front
+   * of the conv front-end (C_in = d), + encoder.embed_positions; pre-norm blocks with AFFINE nn.LayerNorm (eps 1e-5; MhT5Weights
+   * *_ln*_b), q / v / out projections with bias and k without (packed as arch 1: fused Wqkv / Wq + Wkv with a zero k-bias),
+   * q scaled by 1 / 8, NO rotary embedding, fc1 -> gelu(erf) -> fc2, decoder input = decoder_embedder[id] +
+   * decoder.embed_positions[position], final LayerNorm, proj_out.  in_frames / src_len as arch 1.                           */
+  int dec_pos_from_mask;    /* arch 2: 0 = the position of column t is t (transformers 5.x: cache positions); 1 = t minus the
+                               number of masked (padding) prompt columns of its row, clamped at 0 (transformers 4.57's
+                               Whisper `prepare_inputs_for_generation`: decoder_position_ids = cumsum(mask) - 1; needs a
+                               left-padded prompt mask)                                                                  */
 } MhT5Config;
 
 typedef struct MhT5Weights {
@@ -313,6 +332,13 @@ typedef struct MhT5Weights {
   const uint8_t* enc_wi_mx[MH_MAX_LAYERS]; const uint8_t* enc_wi_mxs[MH_MAX_LAYERS];
   const uint8_t* enc_wo_mx[MH_MAX_LAYERS]; const uint8_t* enc_wo_mxs[MH_MAX_LAYERS];
   const uint8_t* dec_ckv_all_mx; const uint8_t* dec_ckv_all_mxs;
+  /* --- ABI 10, arch 2 only: LayerNorm biases (fp32 [d]; the *_ln* slots above hold the LayerNorm weights) and the absolute
+   * position tables -- encoder.embed_positions fp32 [src_len][d] (the fixed sinusoids, read from the state dict),
+   * decoder.embed_positions fp32 [tgt_len][d] (learned) ------------------------------------------------------------------ */
+  const float* enc_ln1_b[MH_MAX_LAYERS]; const float* enc_ln2_b[MH_MAX_LAYERS]; const float* enc_final_ln_b;
+  const float* dec_ln1_b[MH_MAX_LAYERS]; const float* dec_ln2_b[MH_MAX_LAYERS]; const float* dec_ln3_b[MH_MAX_LAYERS];
+  const float* dec_final_ln_b;
+  const float* enc_pos; const float* dec_pos;
 } MhT5Weights;
 
 /* bytes of scratch needed by mh_t5_encode for a batch of B chunks */

@@ -7,17 +7,38 @@
 """
 import os as _os
 
-# HIP runtime knob (read once, when the runtime initialises -- import this package before the first torch.cuda call): the step
-# graphs of the decode loop replay faster through the runtime's classic per-node submission than through its captured-AQL-packet
-# path: 272-274 vs 277-278 ms per batch of the headline workload, 4 chains 335 vs 416 ms (profiles/r05_graph_packet_capture.txt).
-# An explicit value in the environment wins; C hosts of libmapperhip.so set it themselves.
-_os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+
+def configure_runtime(graph_packet_capture: bool = False) -> dict:
+    """EXPLICIT opt-in to a HIP runtime setting, for hosts that own their process (bench.py, a server's entry point:
+    INTEGRATION.md 3) -- importing the package never touches `os.environ`.
+
+    `graph_packet_capture=False` asks ROCm 7.2's CLR to replay hipGraphs through its classic per-node submission instead of
+    its captured-AQL-packet path (`DEBUG_CLR_GRAPH_PACKET_CAPTURE=0`): the decode loop's step graphs replay 1.5-1.9 % faster
+    that way on the headline workload (profiles/r05_graph_packet_capture.txt; measured on ROCm 7.2.0 only).  It is a debug
+    knob of that runtime version, it affects EVERY hipGraph user of the process, and the runtime reads it once, when it
+    initialises: call this before the first HIP call.  An explicit value already in the environment wins.  Returns
+    {"variable", "value", "applied", "effective"}: `effective` is False (and a RuntimeWarning is raised) when HIP was
+    initialised before the call, i.e. when the setting cannot take effect any more."""
+    import sys
+    import warnings
+    var = "DEBUG_CLR_GRAPH_PACKET_CAPTURE"
+    want = "1" if graph_packet_capture else "0"
+    applied = var not in _os.environ
+    if applied:
+        _os.environ[var] = want
+    torch = sys.modules.get("torch")
+    late = bool(torch is not None and torch.cuda.is_initialized())
+    if late:
+        warnings.warn(f"mapperatorinator_amd.configure_runtime: HIP is already initialised, {var} cannot take effect in this "
+                      "process (call it before the first torch.cuda / HIP call)", RuntimeWarning, stacklevel=2)
+    return {"variable": var, "value": _os.environ[var], "applied": applied, "effective": not late}
+
 
 from .event import ContextType, Event, EventRange, EventType  # noqa: F401,E402
 from .tokenizer import Tokenizer  # noqa: F401,E402
 
 __all__ = ["ContextType", "Event", "EventRange", "EventType", "Tokenizer", "MapperatorinatorHIP",
-           "model_generate", "DiTHIP", "create_diffusion", "MelSpectrogram"]
+           "model_generate", "DiTHIP", "create_diffusion", "MelSpectrogram", "configure_runtime"]
 
 
 def __getattr__(name):  # torch-dependent pieces are imported lazily

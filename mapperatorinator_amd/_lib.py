@@ -44,7 +44,8 @@ class MhT5Config(C.Structure):
                 ("arch", C.c_int), ("attn_scale", C.c_float), ("in_frames", C.c_int), ("local_every", C.c_int),
                 ("local_window", C.c_int),
                 ("enc_operand_dtype", C.c_int),      # ABI 7: 0 or MH_MX8
-                ("options", VP)]                     # ABI 8: MhOptionSet* of this engine (NULL = process-wide values)
+                ("options", VP),                     # ABI 8: MhOptionSet* of this engine (NULL = process-wide values)
+                ("dec_pos_from_mask", C.c_int)]      # ABI 10 (arch 2)
 
 
 class MhT5Weights(C.Structure):
@@ -64,7 +65,11 @@ class MhT5Weights(C.Structure):
                 # ABI 7: MX-fp8 copies of the encoder projections and of the cross-K/V projection
                 ("enc_qkv_mx", _PTR_ARR), ("enc_qkv_mxs", _PTR_ARR), ("enc_o_mx", _PTR_ARR), ("enc_o_mxs", _PTR_ARR),
                 ("enc_wi_mx", _PTR_ARR), ("enc_wi_mxs", _PTR_ARR), ("enc_wo_mx", _PTR_ARR), ("enc_wo_mxs", _PTR_ARR),
-                ("dec_ckv_all_mx", VP), ("dec_ckv_all_mxs", VP)]
+                ("dec_ckv_all_mx", VP), ("dec_ckv_all_mxs", VP),
+                # ABI 10, arch 2 (HF Whisper): LayerNorm biases, absolute position tables
+                ("enc_ln1_b", _PTR_ARR), ("enc_ln2_b", _PTR_ARR), ("enc_final_ln_b", VP),
+                ("dec_ln1_b", _PTR_ARR), ("dec_ln2_b", _PTR_ARR), ("dec_ln3_b", _PTR_ARR), ("dec_final_ln_b", VP),
+                ("enc_pos", VP), ("dec_pos", VP)]
 
 
 class MhSampling(C.Structure):
@@ -106,7 +111,7 @@ class MhSliderSet(C.Structure):
                 ("end_idx", VP), ("length", VP)]
 
 
-ABI_VERSION = 9   # MH_ABI_VERSION of include/mapperhip.h
+ABI_VERSION = 10  # MH_ABI_VERSION of include/mapperhip.h
 
 # every symbol include/mapperhip.h declares: (name, restype, argtypes)
 I, I64, F = C.c_int, C.c_int64, C.c_float
@@ -130,6 +135,7 @@ SYMBOLS = {
     "mh_attention": (I, [VP, I, I, VP, I, VP, VP, I, I, I, I, F, I, I, VP]),
     "mh_whisper_frontend_workspace_bytes": (I64, [I, I, I, I, I]),
     "mh_whisper_frontend": (I, [VP, I, I, I, VP, VP, VP, VP, VP, I, VP, VP, I64, I, VP]),
+    "mh_cond_channels": (I, [VP, I, I, I, I, VP, I, I, VP]),
     "mh_t5_encode_workspace_bytes": (I64, [C.POINTER(MhT5Config), I]),
     "mh_t5_encode": (I, [C.POINTER(MhT5Config), C.POINTER(MhT5Weights), VP, I, VP, VP, VP, I64, VP]),
     "mh_t5_cross_kv": (I, [C.POINTER(MhT5Config), C.POINTER(MhT5Weights), VP, I, VP, VP]),

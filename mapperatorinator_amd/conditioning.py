@@ -1,7 +1,9 @@
 """Conditioning embedders of the Mapperatorinator wrapper (difficulty / mapper style / song position), host side.
 
 The reference turns each conditioning input into one vector per batch row, repeats it over the encoder frames,
-concatenates it to the mel frames and sends the result through `encoder_embedder` (modeling_mapperatorinator.py:395-414).
+concatenates it to the mel frames and sends the result through `encoder_embedder` (modeling_mapperatorinator.py:395-414) --
+or, with project_encoder_input = false ('Tiger14n/ropewhisper-*', V30 / V31), straight into the backbone's conv1 as extra
+input channels (`channels()`; mh_cond_channels writes them beside the mel channels).
 A vector that is constant along the frames contributes a constant to every frame of its row:
 
     encoder_embedder([mel | cond]) = mel @ W[:, :n_mels].T + (cond @ W[:, n_mels:].T + b)
@@ -46,10 +48,17 @@ class ConditioningEmbedders:
         self.has_difficulty = "difficulty_embedder.basis_centers" in sd
         self.has_mapper = "mapper_embedder.embedding.weight" in sd
         self.has_song_position = "song_pos_embedder.basis_centers" in sd
-        if "encoder_embedder.weight" not in state_dict:        # project_encoder_input = false (the Whisper-family configs)
-            if sd:
-                raise NotImplementedError("conditioning embedders without encoder_embedder (project_encoder_input=false)")
-            self.w_cond, self.bias, self.cond_size = torch.zeros(0, 0), torch.zeros(0), 0
+        self.as_channels = "encoder_embedder.weight" not in state_dict
+        if self.as_channels:
+            # project_encoder_input = false (configs/model/whisper_small_v2.yaml, varwhisper_*_v3.yaml): the vectors are
+            # concatenated to the mel frames as INPUT CHANNELS of the backbone's conv1 (modeling_mapperatorinator.py:201-202,211;
+            # configuration_mapperatorinator.py:104 num_mel_bins = n_mels + cond_size) -- `channels()` instead of `row_bias()`
+            c1 = state_dict.get("transformer.model.encoder.conv1.weight")
+            self.cond_size = int(c1.shape[1]) - self.n_mels if c1 is not None else 0
+            if (self.cond_size > 0) != bool(sd):
+                raise ValueError(f"conv1 takes {self.cond_size} conditioning channels but the state dict carries "
+                                 f"{'no' if not sd else 'some'} conditioning embedders")
+            self.w_cond, self.bias = torch.zeros(0, 0), torch.zeros(0)
             return
         w = state_dict["encoder_embedder.weight"].detach().to(torch.float32).cpu()
         self.w_cond = w[:, self.n_mels:].contiguous()          # (d_model, cond_size)
@@ -95,9 +104,18 @@ class ConditioningEmbedders:
             raise ValueError(f"conditioning vectors have {out.shape[1]} columns, encoder_embedder expects {self.cond_size}")
         return out
 
+    def channels(self, cond: torch.Tensor, storage_dtype: torch.dtype) -> torch.Tensor:
+        """(B, cond_size) fp32, rounded to the storage dtype (the reference's embedder modules run in the model's dtype and the
+        concatenated frames are conv1's operand): what mh_cond_channels writes beside the mel channels."""
+        if not self.as_channels:
+            raise ValueError("this model projects its encoder input: the conditioning enters as row_bias()")
+        return cond.to(storage_dtype).to(torch.float32)
+
     def row_bias(self, cond: torch.Tensor, storage_dtype: torch.dtype) -> torch.Tensor:
         """(B, d_model) fp32: cond @ W_cond.T + bias with cond and W_cond rounded to the storage dtype first (they are
         GEMM operands in the reference's concatenated form), accumulated in fp32."""
+        if self.as_channels:
+            raise ValueError("this model has no encoder_embedder: the conditioning enters as conv1 channels()")
         c = cond.to(storage_dtype).to(torch.float32)
         w = self.w_cond.to(storage_dtype).to(torch.float32)
         return c @ w.t() + self.bias

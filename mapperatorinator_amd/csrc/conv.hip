@@ -34,10 +34,29 @@ __global__ __launch_bounds__(256) void im2col3_kernel(const T* __restrict__ x, i
   }
 }
 
+// frames[(b, t)][col0 + j] = cond[b][j]: the wrapper's conditioning vectors repeated over the frames of their chunk and
+// concatenated to the mel channels (modeling_mapperatorinator.py:201-202) -- into the K-padded frame buffer mh_mel wrote
+template <typename T>
+__global__ __launch_bounds__(256) void cond_channels_kernel(T* __restrict__ frames, int L, int ld, int col0, const float* __restrict__ cond, int n_cond) {
+  const long row = blockIdx.x;
+  const float* c = cond + (row / L) * n_cond;
+  T* dst = frames + row * ld + col0;
+  for (int j = threadIdx.x; j < n_cond; j += 256) dst[j] = Elem<T>::from_f32(c[j]);
+}
+
 }  // namespace
 }  // namespace mh
 
 using namespace mh;
+
+extern "C" int mh_cond_channels(void* frames, int B, int L, int ld, int col0, const float* cond, int n_cond, int dtype, void* stream) {
+  MH_REQUIRE(frames && cond && B > 0 && L > 0 && n_cond > 0 && col0 >= 0 && col0 + n_cond <= ld, "mh_cond_channels: bad arguments");
+  MH_REQUIRE(dtype == MH_F32 || dtype == MH_BF16, "mh_cond_channels: bad dtype");
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == MH_BF16) hipLaunchKernelGGL(cond_channels_kernel<bf16_t>, dim3(B * L), dim3(256), 0, s, (bf16_t*)frames, L, ld, col0, cond, n_cond);
+  else hipLaunchKernelGGL(cond_channels_kernel<float>, dim3(B * L), dim3(256), 0, s, (float*)frames, L, ld, col0, cond, n_cond);
+  return check_launch("cond_channels_kernel");
+}
 
 extern "C" int64_t mh_whisper_frontend_workspace_bytes(int B, int Lin, int C, int d, int dtype) {
   if (B <= 0 || Lin <= 0 || C <= 0 || d <= 0) return -1;

@@ -244,6 +244,8 @@ class MapperatorinatorHIP:
             raise ValueError("guidance needs negative_prompt (modeling_mapperatorinator.py:243-254)")
         row_bias = self._row_bias(decoder_input_ids.shape[0], unused)
         if num_beams != 1:
+            if unused.get("cross_kv_fp8"):
+                raise NotImplementedError("cross_kv_fp8 with beam search: the step-wise beam entry streams the bf16 cross K / V")
             out = self.engine.generate_beam(audio, decoder_input_ids, decoder_attention_mask, eos, sp, int(num_beams),
                                             negative_prompt=negative_prompt if sp.cfg_scale > 1.0 else None,
                                             sample_fn=unused.get("beam_sample_fn"),
@@ -251,6 +253,6 @@ class MapperatorinatorHIP:
             return out["tokens"].to(self.device)
         out = self.engine.generate(audio, decoder_input_ids, decoder_attention_mask, eos, sp,
                                    negative_prompt=negative_prompt if sp.cfg_scale > 1.0 else None,
-                                   negative_mask=negative_prompt_attention_mask,
+                                   negative_mask=negative_prompt_attention_mask, cross_kv_fp8=bool(unused.get("cross_kv_fp8", False)),
                                    **({} if row_bias is None else dict(row_bias=row_bias)))
         return out["tokens"].to(self.device)

@@ -336,6 +336,8 @@ def model_generate(model, tokenizer, model_kwargs, generate_kwargs):
     extra = {} if row_bias is None else dict(row_bias=row_bias)
     if getattr(sp, "num_beams", 1) > 1:
         # HF beam search (processor.py:159 `num_beams`; the timing generator uses two beams): mapperatorinator_amd/beam.py
+        if generate_kwargs.get("cross_kv_fp8"):
+            raise NotImplementedError("cross_kv_fp8 with beam search: the step-wise beam entry streams the bf16 cross K / V")
         out = model.engine.generate_beam(audio, prompt, mask, eos, sp, sp.num_beams, negative_prompt=neg,
                                          sample_fn=generate_kwargs.get("beam_sample_fn"), **extra)
     else:

@@ -134,6 +134,90 @@ def random_varwhisper_state_dict(d_model: int, n_heads: int, n_enc: int, n_dec: 
     return sd
 
 
+def random_whisper_family_state_dict(kind: str, d_model: int, n_heads: int, n_enc: int, n_dec: int, ffn: int, vocab_in: int,
+                                      vocab_out: int, n_mels: int, src_positions: int = 0, tgt_positions: int = 0, cond_size: int = 0,
+                                      seed: int = 0, head_gain: float = 1.0, ln_jitter: float = 0.1, gains: dict | None = None) -> dict:
+    """Reference-named parameters of `Mapperatorinator` over
+      kind "rope": RoPEWhisperForConditionalGeneration (custom_transformers/modeling_ropewhisper.py; configs/model/
+                   whisper_small_v2.yaml: input_features, no encoder projection -> conv1 takes n_mels + cond_size channels),
+      kind "hf":   transformers' WhisperForConditionalGeneration (configs/model/whisper_{base,small}.yaml: the wrapper's
+                   encoder_embedder (n_mels + cond_size -> d) in front of conv1 (d channels), affine LayerNorms, the fixed
+                   sinusoid encoder positions (`src_positions` rows) and LEARNED decoder positions (`tgt_positions` rows)).
+    Both: separate q_proj (bias) / k_proj (no bias) / v_proj (bias) / out_proj (bias), fc1 / fc2 with bias, untied proj_out."""
+    assert kind in ("rope", "hf")
+    rng = np.random.default_rng(9000 + seed)
+    d = d_model
+    sd = {}
+    sd["decoder_embedder.weight"] = _normal(rng, (vocab_in, d), 1.0)
+    sd["transformer.model.decoder.embed_tokens.weight"] = _normal(rng, (vocab_out, d), 0.02)      # (unused: embed_decoder_input)
+    sd["transformer.proj_out.weight"] = _normal(rng, (vocab_out, d), head_gain * d ** -0.5)
+    e, dd = "transformer.model.encoder.", "transformer.model.decoder."
+    c_in = n_mels + cond_size
+    if kind == "hf":
+        sd["encoder_embedder.weight"] = _normal(rng, (d, c_in), 1.0 / np.sqrt(n_mels))
+        sd["encoder_embedder.bias"] = _normal(rng, (d,), 0.02)
+        c_in = d
+        # sinusoids(length, channels) of modeling_whisper.py (what HF's _init_weights copies into embed_positions)
+        inc = np.log(10000.0) / (d // 2 - 1)
+        t = np.arange(src_positions)[:, None] * np.exp(-inc * np.arange(d // 2))[None, :]
+        sd[e + "embed_positions.weight"] = torch.from_numpy(np.concatenate([np.sin(t), np.cos(t)], 1).astype(np.float32))
+        sd[dd + "embed_positions.weight"] = _normal(rng, (tgt_positions, d), 0.3)
+    sd[e + "conv1.weight"] = _normal(rng, (d, c_in, 3), (3 * c_in) ** -0.5)
+    sd[e + "conv1.bias"] = _normal(rng, (d,), 0.05)
+    sd[e + "conv2.weight"] = _normal(rng, (d, d, 3), 1.7 * (3 * d) ** -0.5)
+    sd[e + "conv2.bias"] = _normal(rng, (d,), 0.05)
+
+    def lin(name, n_out, n_in, bias, std=None):
+        sd[name + ".weight"] = _normal(rng, (n_out, n_in), std if std is not None else n_in ** -0.5)
+        if bias:
+            sd[name + ".bias"] = _normal(rng, (n_out,), 0.05)
+
+    def ln(name):
+        sd[name + ".weight"] = 1.0 + _normal(rng, (d,), ln_jitter)
+        if kind == "hf":
+            sd[name + ".bias"] = _normal(rng, (d,), 0.1)
+
+    def attn(b, qstd, ostd=None):
+        lin(b + "q_proj", d, d, True, qstd)
+        lin(b + "k_proj", d, d, False, 1.5 * d ** -0.5)
+        lin(b + "v_proj", d, d, True)
+        lin(b + "out_proj", d, d, True, ostd)
+
+    for l in range(n_enc):
+        b = e + f"layers.{l}."
+        attn(b + "self_attn.", 1.5 * d ** -0.5)
+        ln(b + "self_attn_layer_norm")
+        lin(b + "fc1", ffn, d, True)
+        lin(b + "fc2", d, ffn, True)
+        ln(b + "final_layer_norm")
+    ln(e + "layer_norm")
+    for l in range(n_dec):
+        b = dd + f"layers.{l}."
+        attn(b + "self_attn.", 1.5 * d ** -0.5)
+        ln(b + "self_attn_layer_norm")
+        attn(b + "encoder_attn.", 2.0 * d ** -0.5, 2.0 * d ** -0.5)
+        ln(b + "encoder_attn_layer_norm")
+        lin(b + "fc1", ffn, d, True)
+        lin(b + "fc2", d, ffn, True)
+        ln(b + "final_layer_norm")
+    ln(dd + "layer_norm")
+    for pat, g in (gains or {}).items():
+        for k in sd:
+            if pat in k:
+                sd[k] = sd[k] * g
+    return sd
+
+
+def add_random_cond_embedders(sd: dict, cond_dim: int = 16, num_mappers: int = 11, seed: int = 0) -> dict:
+    """The difficulty / mapper / song-position embedders of `add_random_conditioning` alone (in place): for models whose
+    conditioning enters as conv1 CHANNELS (project_encoder_input = false) nothing else changes."""
+    tmp = {"encoder_embedder.weight": torch.zeros(1, 0)}
+    add_random_conditioning(tmp, 1, 0, cond_dim, num_mappers, seed)
+    del tmp["encoder_embedder.weight"]
+    sd.update(tmp)
+    return sd
+
+
 # weaker token embedding + sharper / stronger cross-attention: the next token depends on WHICH encoder frames the
 # query selects, not only on the previous token (random-init greedy decoding otherwise repeats a handful of ids).
 # Kept mild on purpose: at (0.3, 6, 3) the REFERENCE itself in bfloat16 agrees with its fp32 self on only 73 % of

@@ -274,6 +274,90 @@ def vw_case(name):
           float(np.median(gap)), "tok/s(ref,cpu)", stats["tokens_per_second"])
 
 
+WF_CASES = {
+    # the other two Whisper-family backbones (oracle/whisper_family.py).  kind "rope": 'Tiger14n/ropewhisper-*' (V30 / V31), "hf":
+    # 'openai/whisper-*' (V28 / V29); dims = mapperatorinator_amd.whisper_engine.VARWHISPER_PRESETS (openai/whisper-* dims)
+    "rw_test": dict(kind="rope", size="test", frames=250, tgt=48, n_mels=80, wseed=3, gain=5.0, aseed=4,
+                    prompts=[[0, 0, 1], [1, 40, 700], [0, 1, 9]], cond=None),
+    # conditioning embedders as conv1 channels (configs/model/whisper_small_v2.yaml:9-13)
+    "rw_test_cond": dict(kind="rope", size="test", frames=250, tgt=40, n_mels=80, wseed=5, gain=5.0, aseed=6, prompts=[[0, 1], [1, 9], [0, 1]],
+                         cond=dict(cond_dim=16, num_mappers=11, cseed=2, difficulty=[2.5, 6.1, 9.0], mapper_idx=[3, -1, 10],
+                                   song_position=[[0.0, 0.1], [0.45, 0.5], [0.9, 1.0]])),
+    # the released V30 backbone: 'Tiger14n/ropewhisper-small' (whisper-small dims) at its own chunk size (data.src_seq_len 4096 ->
+    # 2048 encoder positions), 80 mels + 3 x 128 conditioning channels
+    "rw_small": dict(kind="rope", size="small", frames=4096, tgt=40, n_mels=80, wseed=9, gain=4.0, aseed=7, prompts=[[0, 1, 40], [1, 9, 700]],
+                     cond=dict(cond_dim=128, num_mappers=11, cseed=3, difficulty=[4.2, 7.7], mapper_idx=[5, -1], song_position=[[0.2, 0.3], [0.8, 0.9]])),
+    "hfw_test": dict(kind="hf", size="test", frames=250, tgt=48, n_mels=388, wseed=17, gain=5.0, aseed=8,
+                     prompts=[[0, 0, 1], [1, 40, 700], [0, 1, 9]], cond=None),
+    # the released V29 backbone: 'openai/whisper-small' at its own chunk size (data.src_seq_len 1024 -> 512 encoder positions)
+    "hfw_small": dict(kind="hf", size="small", frames=1024, tgt=72, n_mels=388, wseed=15, gain=4.0, aseed=9, prompts=[[0, 1, 40], [1, 9, 700]],
+                      cond=None),
+}
+
+
+def wf_weights(c, tok):
+    """state dict of a WF_CASES entry from its seeds (shared with tests/conftest.py:wf_golden_case)"""
+    from mapperatorinator_amd.testing import add_random_cond_embedders, random_whisper_family_state_dict
+    from mapperatorinator_amd.whisper_engine import VARWHISPER_PRESETS
+    d = VARWHISPER_PRESETS[c["size"]]
+    cd = c["cond"]
+    sd = random_whisper_family_state_dict(c["kind"], d.d_model, d.n_heads, d.n_enc_layers, d.n_dec_layers, d.d_ff, tok.vocab_size_in,
+                                          tok.vocab_size_out, c["n_mels"], src_positions=c["frames"] // 2, tgt_positions=c["tgt"],
+                                          cond_size=3 * cd["cond_dim"] if cd else 0, seed=c["wseed"], head_gain=c["gain"],
+                                          gains={"decoder_embedder": 0.5})
+    if cd:
+        add_random_cond_embedders(sd, cd["cond_dim"], cd["num_mappers"], seed=cd["cseed"])
+    return sd
+
+
+def wf_case(name):
+    """'Tiger14n/ropewhisper-*' / 'openai/whisper-*' behind the REFERENCE's wrapper, through its own `model_generate`: front-end
+    slice, encoder states, greedy ids (ragged left-padded prompts), the 16 best processed scores of every step."""
+    from mapperatorinator_amd.whisper_engine import VARWHISPER_PRESETS
+    c = WF_CASES[name]
+    d = VARWHISPER_PRESETS[c["size"]]
+    over = dict(d_model=d.d_model, encoder_layers=d.n_enc_layers, decoder_layers=d.n_dec_layers, encoder_attention_heads=d.n_heads,
+                decoder_attention_heads=d.n_heads, encoder_ffn_dim=d.d_ff, decoder_ffn_dim=d.d_ff)
+    cd = c["cond"]
+    model, tok, _ = rh.build_reference_whisper_family(c["kind"], src_seq_len=c["frames"], tgt_seq_len=c["tgt"], n_mels=c["n_mels"], overwrite=over,
+                                                      cond=dict(cond_dim=cd["cond_dim"], num_mappers=cd["num_mappers"]) if cd else None)
+    sd = wf_weights(c, tok)
+    res = model.load_state_dict(sd, strict=False)
+    assert not res.unexpected_keys and not [k for k in res.missing_keys if "loss_fn" not in k], res
+    ns = (c["frames"] - 1) * 128
+    audio = synthetic_audio_varied(len(c["prompts"]), ns, seed=c["aseed"])
+    prompt = torch.tensor(c["prompts"])
+    cond = None
+    extra = {}
+    if cd:
+        diff, mp, sp = torch.tensor(cd["difficulty"]), torch.tensor(cd["mapper_idx"]), torch.tensor(cd["song_position"])
+        cond = rh.reference_cond_vectors(model, diff, mp, sp)
+        extra = dict(difficulty=diff.numpy(), mapper_idx=mp.numpy(), song_position=sp.numpy(), cond_vectors=cond.numpy(),
+                     cond_dim=cd["cond_dim"], num_mappers=cd["num_mappers"], cond_seed=cd["cseed"])
+    with torch.no_grad():
+        mel = model.spectrogram(audio)
+    enc = rh.reference_encode_whisper_family(model, audio, cond)
+    rec = []
+    ids, stats = rh.reference_generate_whisper_family(model, tok, audio, prompt, rh.default_generate_kwargs(c["tgt"]), record_scores=rec, cond=cond)
+    ids2, _ = rh.reference_generate_whisper_family(model, tok, audio, prompt, rh.default_generate_kwargs(c["tgt"], temperature=0.7, timeshift_bias=0.35,
+                                                                                                        lookahead_time=3000), cond=cond)
+    if cd:   # the run WITHOUT conditioning, to show it matters
+        ids0, _ = rh.reference_generate_whisper_family(model, tok, audio, prompt, rh.default_generate_kwargs(c["tgt"]), cond=torch.zeros_like(cond))
+        extra["ids_zero_cond"] = ids0.numpy()
+    v, i, lse = topk_scores(rec)
+    gap = v[..., 0] - v[..., 1]
+    np.savez_compressed(
+        os.path.join(OUT, name + ".npz"), kind=c["kind"], size=c["size"], vocab_in=tok.vocab_size_in, vocab_out=tok.vocab_size_out, n_samples=ns,
+        in_frames=c["frames"], tgt_len=c["tgt"], n_mels=c["n_mels"], weight_seed=c["wseed"], head_gain=c["gain"], audio_seed=c["aseed"],
+        prompt=prompt.numpy(), mel_slice=mel[:, ::37, ::11].numpy(), mel_sum=mel.double().sum().item(),
+        enc_slice=enc[:, ::29, ::17].numpy(), enc_abs_mean=enc.abs().double().mean().item(), ids=ids.numpy(),
+        ids_processors=ids2.numpy(), top_vals=v, top_ids=i, lse=lse, **extra)
+    print(name, "ids", tuple(ids.shape), "distinct", len(set(ids.flatten().tolist())), "top-2 gap min / median", float(gap.min()),
+          float(np.median(gap)), "tok/s(ref,cpu)", stats["tokens_per_second"],
+          ("| positions differing from zero conditioning: %s" % (int((ids.numpy() != extra["ids_zero_cond"]).sum())
+                                                                 if ids.numpy().shape == extra["ids_zero_cond"].shape else "shape differs")) if cd else "")
+
+
 BEAM_CASE = dict(src=251, tgt=40, ns=32000, wseed=13, gain=1.5, aseed=6, prompts=[[0, 0, 1], [1, 40, 700], [0, 1, 9]],
                  negative=[[0, 0, 1], [0, 1, 701], [0, 0, 1]],
                  runs={"b2": dict(num_beams=2), "b3": dict(num_beams=3),
@@ -637,7 +721,8 @@ def events_case():
 
 def main(only=None):
     """`python -m oracle.make_golden` regenerates everything; `python -m oracle.make_golden NAME ...` only the named
-    fixtures (t5_tiny, t5_small, t5_base, t5_large, vw_test, vw_test_nobias, vw_small, t5_base_bf16ref, t5_tiny_cond,
+    fixtures (t5_tiny, t5_small, t5_base, t5_large, vw_test, vw_test_nobias, vw_small, rw_test, rw_test_cond, rw_small, hfw_test,
+    hfw_small, t5_base_bf16ref, t5_tiny_cond,
     t5_tiny_tf, dit_xs, dit_s, dit_b, dit_b_1024, dit_pipeline, sliders, events, whisper_frontend, mel_oracle, tokenizer)."""
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(max(1, os.cpu_count() or 1))
@@ -646,6 +731,8 @@ def main(only=None):
         cases[name] = (lambda n: (lambda: t5_case(n)))(name)
     for name in VW_CASES:
         cases[name] = (lambda n: (lambda: vw_case(n)))(name)
+    for name in WF_CASES:
+        cases[name] = (lambda n: (lambda: wf_case(n)))(name)
     cases.update({
         "t5_base_bf16ref": lambda: t5_bf16_reference_case("t5_base"),
         "t5_tiny_cond": t5_conditioning_case,

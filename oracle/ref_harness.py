@@ -434,3 +434,74 @@ def reference_generate_whisper(model, tok, audio, prompt, generate_kwargs, atten
         return model_generate(model, tok, mk, dict(generate_kwargs))
     finally:
         LogitsProcessorList.__call__ = orig
+
+
+# ---- the other two Whisper-family backbones: 'Tiger14n/ropewhisper-*' (V30 / V31) and 'openai/whisper-*' (V28 / V29) ---------
+def build_reference_whisper_family(kind, src_seq_len=1024, tgt_seq_len=256, n_mels=None, seed=0, overwrite=None, cond=None,
+                                   attn_implementation="eager"):
+    """reference `_get_model` on configs/model/whisper_small_v2.yaml (kind "rope": 'Tiger14n/ropewhisper-*', input_features =
+    true, project_encoder_input = false, torchaudio log-mel with 80 mels, the conditioning embedders as conv1 channels) or
+    configs/model/whisper_{base,small}.yaml (kind "hf": 'openai/whisper-*', input_features = true, project_encoder_input = true
+    -> the wrapper's encoder_embedder in front of conv1, the nnAudio mel of default.yaml).  `overwrite`: backbone dims (the
+    presets of mapperatorinator_amd.whisper_engine); `cond`: dict(cond_dim, num_mappers) switches the difficulty / mapper /
+    song-position embedders on (whisper_small_v2.yaml:9-13)."""
+    assert kind in ("rope", "hf")
+    (ref_shims.ropewhisper_module if kind == "rope" else ref_shims.hf_whisper_module)()
+    if n_mels is None:
+        n_mels = 80 if kind == "rope" else 388
+    args = _train_config("small", src_seq_len, tgt_seq_len, n_mels)
+    args.model.name = "Tiger14n/ropewhisper-small" if kind == "rope" else "openai/whisper-small"
+    args.model.input_features = True
+    args.model.project_encoder_input = kind == "hf"
+    args.model.overwrite = dict({"tie_word_embeddings": False}, **(overwrite or {}))
+    if kind == "rope":
+        sp = args.model.spectrogram
+        sp.implementation, sp.log_scale, sp.n_mels, sp.f_min, sp.pad_mode = "torchaudio", True, n_mels, 20, "reflect"
+    from osuT5.osuT5.tokenizer import Tokenizer
+    from osuT5.osuT5.utils.model_utils import _get_model
+    tok = Tokenizer(args)
+    if cond:
+        args.model.do_difficulty_embed = args.model.do_mapper_embed = args.model.do_song_position_embed = True
+        args.model.cond_dim = cond["cond_dim"]
+        args.model.cond_size = 3 * cond["cond_dim"]
+        tok.num_mapper_classes = cond["num_mappers"]
+    torch.manual_seed(seed)
+    model = _get_model(args, tok, torch.float32, attn_implementation).eval()
+    return model, tok, args
+
+
+def reference_encode_whisper_family(model, audio: torch.Tensor, cond: torch.Tensor = None) -> torch.Tensor:
+    """`Mapperatorinator.forward`'s encoder half for input_features = true (modeling_mapperatorinator.py:191-213), called by
+    hand like `reference_encode`: spectrogram -> (| conditioning vectors over the frames) -> (encoder_embedder when
+    project_encoder_input) -> swapaxes -> the backbone's own encoder."""
+    with torch.no_grad():
+        x = model.spectrogram(audio).to(model.transformer.dtype)
+        if cond is not None:
+            x = torch.cat([x, cond.to(x.dtype).unsqueeze(1).expand(-1, x.shape[1], -1)], -1)
+        if model.project_encoder_input:
+            x = model.encoder_embedder(x)
+        return model.transformer.get_encoder()(torch.swapaxes(x, 1, 2)).last_hidden_state
+
+
+def reference_generate_whisper_family(model, tok, audio, prompt, generate_kwargs, attention_mask=None, negative_prompt=None,
+                                      record_scores=None, cond=None):
+    """the reference's own `model_generate` with the encoder states of `reference_encode_whisper_family` as `encoder_outputs`"""
+    from osuT5.osuT5.inference.server import model_generate
+    from transformers import LogitsProcessorList
+    from transformers.modeling_outputs import BaseModelOutput
+    enc = reference_encode_whisper_family(model, audio, cond)
+    mk = dict(inputs=audio, encoder_outputs=BaseModelOutput(last_hidden_state=enc), decoder_input_ids=prompt,
+              decoder_attention_mask=prompt.ne(0) if attention_mask is None else attention_mask)
+    if negative_prompt is not None:
+        mk.update(negative_prompt=negative_prompt, negative_prompt_attention_mask=negative_prompt.ne(0))
+    orig = LogitsProcessorList.__call__
+    if record_scores is not None:
+        def spy(self, input_ids, scores, **kw):
+            out = orig(self, input_ids, scores, **kw)
+            record_scores.append(out.detach().float().cpu().clone())
+            return out
+        LogitsProcessorList.__call__ = spy
+    try:
+        return model_generate(model, tok, mk, dict(generate_kwargs))
+    finally:
+        LogitsProcessorList.__call__ = orig

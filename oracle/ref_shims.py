@@ -214,3 +214,61 @@ def varwhisper_module():
         if not hasattr(Cache, "__getitem__"):
             Cache.__getitem__ = lambda self, i: (self.layers[i].keys, self.layers[i].values)
     return mv
+
+
+def _filter_forward_kwargs(cls):
+    """transformers 5.x `generate` hands its own bookkeeping kwargs (`next_sequence_length`, ...) to
+    prepare_inputs_for_generation, and the wrapper forwards every kwarg it does not know (modeling_mapperatorinator.py:265-268)
+    into a forward with a closed signature: drop what that signature lacks (as varwhisper_module does for its fork)."""
+    if getattr(cls, "_mh_kwargs_filtered", False):
+        return
+    import inspect
+    orig = cls.forward
+    params = inspect.signature(orig).parameters
+    if any(p.kind == inspect.Parameter.VAR_KEYWORD for p in params.values()):
+        cls._mh_kwargs_filtered = True
+        return
+    known = set(params)
+
+    def forward(self, *a, **k):
+        return orig(self, *a, **{kk: v for kk, v in k.items() if kk in known})
+
+    cls.forward = forward
+    cls._mh_kwargs_filtered = True
+
+
+def ropewhisper_module():
+    """The reference's RoPEWhisper fork (custom_transformers/modeling_ropewhisper.py), runnable under transformers 5.x:
+    (1) the closed forward signature (see _filter_forward_kwargs); (2) `cache.key_cache[i]` / `cache.value_cache[i]`
+    (modeling_ropewhisper.py:438-439, the cross-attention cache after the first step) were attributes of the pinned 4.57 Cache
+    classes; 5.x keeps the tensors on per-layer objects -> read-only views with the same indexing."""
+    install()
+    from osuT5.osuT5.model.custom_transformers import modeling_ropewhisper as mr
+    cls = mr.RoPEWhisperForConditionalGeneration
+    if isinstance(getattr(cls, "_tied_weights_keys", None), list):
+        cls._tied_weights_keys = {}
+    _filter_forward_kwargs(cls)
+    from transformers.cache_utils import Cache
+    if not hasattr(Cache, "key_cache"):
+        class _LayerView:
+            def __init__(self, cache, attr):
+                self.cache, self.attr = cache, attr
+
+            def __getitem__(self, i):
+                return getattr(self.cache.layers[i], self.attr)
+
+            def __len__(self):
+                return len(self.cache.layers)
+
+        Cache.key_cache = property(lambda self: _LayerView(self, "keys"))
+        Cache.value_cache = property(lambda self: _LayerView(self, "values"))
+    return mr
+
+
+def hf_whisper_module():
+    """Stock transformers WhisperForConditionalGeneration (the backbone of 'openai/whisper-*' configs: third-party code, not a
+    fork): only the kwargs filter, where its forward has a closed signature."""
+    install()
+    from transformers.models.whisper import modeling_whisper as mw
+    _filter_forward_kwargs(mw.WhisperForConditionalGeneration)
+    return mw

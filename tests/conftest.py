@@ -66,6 +66,37 @@ def vw_golden_case(name):
     return g, d, tok, sd, audio
 
 
+def wf_golden_case(name):
+    """tests/golden/rw_*.npz / hfw_*.npz (oracle/make_golden.py:wf_case) -> (golden, kind, dims, tok, state_dict, audio, cond inputs):
+    'Tiger14n/ropewhisper-*' / 'openai/whisper-*' on the reference; weights and audio regenerated from the recorded seeds.  The
+    cond inputs are dict(difficulty, mapper_idx, song_position) tensors or None."""
+    import numpy as np
+    import torch
+
+    from mapperatorinator_amd import Tokenizer
+    from mapperatorinator_amd.testing import add_random_cond_embedders, random_whisper_family_state_dict, synthetic_audio_varied
+    from mapperatorinator_amd.whisper_engine import VARWHISPER_PRESETS
+    g = np.load(f"{GOLDEN}/{name}.npz")
+    kind = str(g["kind"])
+    d = VARWHISPER_PRESETS[str(g["size"])]
+    frames, tgt = int(g["in_frames"]), int(g["tgt_len"])
+    tok = Tokenizer.benchmark_vocab(src_seq_len=frames)
+    assert tok.vocab_size_out == int(g["vocab_out"]) and tok.vocab_size_in == int(g["vocab_in"])
+    has_cond = "cond_dim" in g.files
+    cdim = int(g["cond_dim"]) if has_cond else 0
+    sd = random_whisper_family_state_dict(kind, d.d_model, d.n_heads, d.n_enc_layers, d.n_dec_layers, d.d_ff, tok.vocab_size_in,
+                                          tok.vocab_size_out, int(g["n_mels"]), src_positions=frames // 2, tgt_positions=tgt,
+                                          cond_size=3 * cdim, seed=int(g["weight_seed"]), head_gain=float(g["head_gain"]),
+                                          gains={"decoder_embedder": 0.5})
+    cond = None
+    if has_cond:
+        add_random_cond_embedders(sd, cdim, int(g["num_mappers"]), seed=int(g["cond_seed"]))
+        cond = dict(difficulty=torch.from_numpy(g["difficulty"]), mapper_idx=torch.from_numpy(g["mapper_idx"]),
+                    song_position=torch.from_numpy(g["song_position"]))
+    audio = synthetic_audio_varied(g["prompt"].shape[0], int(g["n_samples"]), seed=int(g["audio_seed"]))
+    return g, kind, d, tok, sd, audio, cond
+
+
 def assert_topk_scores_match(dumped, g, P, tol):
     """dumped: fp32 (cols, B, V) processed scores of a run (index = produced column); g: a fixture holding the
     reference's per-step `top_vals` / `top_ids` (steps, B, K) and `lse` (steps, B).  The K best ids of every step must

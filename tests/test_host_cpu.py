@@ -423,17 +423,31 @@ def test_diffusion_generate_host_flow_on_a_stand_in_denoiser():
         dp.DiffusionPipelineHIP(types.SimpleNamespace(device="cpu"), timesteps=[2] + [0] * 9).generate(events, cfg, timing)
 
 
-def test_runtime_flag_default_does_not_override_the_environment():
-    """`import mapperatorinator_amd` sets DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 (the step graphs replay faster through the runtime's
-    per-node submission, profiles/r05_graph_packet_capture.txt) -- as a DEFAULT: an explicit value wins."""
+def test_import_leaves_the_environment_alone_and_configure_runtime_is_explicit():
+    """Importing the package must not touch os.environ (round-5 verdict / advice: a library does not mutate its host's HIP
+    runtime); `configure_runtime()` is the explicit opt-in, an existing value wins, and a call after HIP initialised warns."""
     import subprocess
     import sys
-    code = "import os, mapperatorinator_amd; print(os.environ['DEBUG_CLR_GRAPH_PACKET_CAPTURE'])"
-    env = {k: v for k, v in os.environ.items() if k != "DEBUG_CLR_GRAPH_PACKET_CAPTURE"}
+    var = "DEBUG_CLR_GRAPH_PACKET_CAPTURE"
+    env = {k: v for k, v in os.environ.items() if k != var}
     env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
-    assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.strip() == "0"
-    env["DEBUG_CLR_GRAPH_PACKET_CAPTURE"] = "1"
-    assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.strip() == "1"
+
+    def run(code):
+        return subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.strip()
+
+    assert run(f"import os, mapperatorinator_amd, mapperatorinator_amd.modeling; print(os.environ.get('{var}'))") == "None"
+    assert run(f"import os, mapperatorinator_amd as m; r = m.configure_runtime(); print(os.environ['{var}'], r['applied'], r['effective'])") == "0 True True"
+    env[var] = "1"
+    assert run(f"import os, mapperatorinator_amd as m; r = m.configure_runtime(); print(os.environ['{var}'], r['applied'])") == "1 False"
+    del env[var]
+    code = ("import sys, types, warnings, mapperatorinator_amd as m\n"
+            "import torch\n"
+            "torch.cuda.is_initialized = lambda: True\n"
+            "with warnings.catch_warnings(record=True) as w:\n"
+            "    warnings.simplefilter('always')\n"
+            "    r = m.configure_runtime()\n"
+            "print(r['effective'], len(w), w[0].category.__name__)")
+    assert run(code) == "False 1 RuntimeWarning"
 
 
 def test_graft_entry_build():

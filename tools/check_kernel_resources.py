@@ -126,4 +126,12 @@ def main(argv):
 
 
 if __name__ == "__main__":
-    sys.exit(main(sys.argv[1:]))
+    # exit status: 0 ok, 1 policy violation (a watched kernel spills / uses scratch), 2 no gfx950 kernels in the library,
+    # 3 the tooling itself failed (PyYAML, llvm-objcopy / -readelf / -objdump missing or erroring): never to be read as "a kernel spills"
+    try:
+        rc = main(sys.argv[1:])
+    except Exception:
+        import traceback
+        traceback.print_exc()
+        rc = 3
+    sys.exit(rc)
