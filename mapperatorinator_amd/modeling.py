@@ -5,7 +5,8 @@ stands for the *generate* path: same attributes the callers read (`.device`, `.d
 `.config.{max_target_positions, max_source_positions, hidden_size, vocab_size, ...}`,
 `.spectrogram`, `.generate(**kwargs)`), but the arithmetic underneath is libmapperhip.
 
-Two backbones are wired: the T5 configuration of the north star (input_features=False, project_encoder_input=True,
+Four backbones are wired (round 6: + 'Tiger14n/ropewhisper-*' = V30 / V31 and stock 'openai/whisper-*' = V28 / V29, both through
+whisper_engine.py): the T5 configuration of the north star (input_features=False, project_encoder_input=True,
 embed_decoder_input=True: configs/model/default.yaml:1-4 + t5_small_v9.yaml:5) and the Whisper-family one of the released
 V30-V32 checkpoints ('OliBomby/varwhisper-*': input_features=True, project_encoder_input=False, torchaudio log-mel --
 configs/model/varwhisper_{small,base}_v3.yaml; whisper_engine.py); anything else raises NotImplementedError instead of
@@ -71,37 +72,56 @@ class MapperatorinatorHIP:
             max_source_positions=src_seq_len // 2 if self.is_whisper else src_seq_len, max_target_positions=tgt_seq_len, vocab_size=vocab_size_out,
             vocab_size_in=vocab_size_in, n_mels=n_mels, hop_length=hop_length, sample_rate=sample_rate,
             pad_token_id=pad_token_id, bos_token_id=bos_token_id, eos_token_id=eos_token_id,
-            is_encoder_decoder=True, backbone_model_name="OliBomby/varwhisper(hip)" if self.is_whisper else "google/t5-v1_1(hip)",
+            is_encoder_decoder=True,
+            backbone_model_name={"var": "OliBomby/varwhisper(hip)", "rope": "Tiger14n/ropewhisper(hip)", "hf": "openai/whisper(hip)"}[self.engine.kind]
+            if self.is_whisper else "google/t5-v1_1(hip)",
             # the fields `get_cache` / `MapperatorinatorCache` read (inference/cache_utils.py:23-35): the engine owns its
             # caches, they are here so that code inspecting the reference config finds them
             num_hidden_layers_decoder=dims.n_dec_layers, d_model=dims.d_model, d_kv=dims.d_kv, num_heads=dims.n_heads,
             num_layers=dims.n_enc_layers, num_decoder_layers=dims.n_dec_layers, d_ff=dims.d_ff,
-            torch_dtype=dtype, input_features=self.is_whisper, project_encoder_input=not self.is_whisper, embed_decoder_input=True)
+            torch_dtype=dtype, input_features=self.is_whisper,
+            project_encoder_input=(not self.is_whisper) or self.engine.kind == "hf", embed_decoder_input=True)
 
     # ---- construction from the reference object ---------------------------------------------------
     @classmethod
     def from_reference(cls, model, dtype: Optional[torch.dtype] = None, device="cuda"):
         """`model`: a reference `Mapperatorinator` with a google/t5 backbone (possibly on the CPU)."""
         cfg = model.config
-        if str(cfg.backbone_model_name).startswith("OliBomby/varwhisper"):
-            if not cfg.input_features or cfg.project_encoder_input or not cfg.embed_decoder_input or cfg.input_raw_wave:
-                raise NotImplementedError("HIP path of the Whisper family implements input_features=True, project_encoder_input="
-                                          "False, embed_decoder_input=True (configs/model/varwhisper_*_v3.yaml)")
-            if cfg.spectrogram_implementation != "torchaudio" or not cfg.spectrogram_log_scale or cfg.pad_mode != "reflect":
-                raise NotImplementedError("the Whisper-family configs use the torchaudio log-mel front-end with reflect padding")
+        name = str(cfg.backbone_model_name)
+        if name.startswith(("OliBomby/varwhisper", "Tiger14n/ropewhisper", "openai/whisper")):
+            hf = name.startswith("openai/whisper")
+            if not cfg.input_features or not cfg.embed_decoder_input or cfg.input_raw_wave or cfg.do_style_embed:
+                raise NotImplementedError("HIP path of the Whisper family implements input_features=True, embed_decoder_input=True, "
+                                          "do_style_embed=False (configs/model/whisper_*.yaml, varwhisper_*_v3.yaml)")
+            if bool(cfg.project_encoder_input) != hf:
+                # the fork configs feed the (log-)mel channels straight into conv1 (whisper_small_v2.yaml:7, varwhisper_*_v3.yaml:7),
+                # the stock-Whisper ones (whisper_{base,small}.yaml) keep default.yaml's encoder projection
+                raise NotImplementedError(f"{name} with project_encoder_input={cfg.project_encoder_input} is not a released wiring")
             bc = cfg.backbone_config
             dims = VarWhisperDims(bc.d_model, bc.encoder_attention_heads, bc.encoder_layers, bc.decoder_layers, bc.encoder_ffn_dim)
             if bc.decoder_attention_heads != bc.encoder_attention_heads or bc.decoder_ffn_dim != bc.encoder_ffn_dim or bc.activation_function != "gelu":
                 raise NotImplementedError("encoder and decoder of the HIP Whisper path share heads / ffn width; activation gelu")
+            if getattr(bc, "scale_embedding", False):
+                raise NotImplementedError("scale_embedding=True is not built")
+            opts = dict(spectrogram=dict(implementation=cfg.spectrogram_implementation, log_scale=bool(cfg.spectrogram_log_scale),
+                                         pad_mode=cfg.pad_mode))
+            if name.startswith("OliBomby/varwhisper"):
+                opts.update(global_rope_theta=bc.global_rope_theta, local_rope_theta=bc.local_rope_theta,
+                            global_attn_every_n_layers=bc.global_attn_every_n_layers, local_attention=bc.local_attention)
+            elif name.startswith("Tiger14n/ropewhisper"):
+                # rope_type "dynamic" (NTK): the base only changes for positions beyond max_position_embeddings
+                # (modeling_ropewhisper.py:299-305), which a StaticCache of max_target_positions never reaches; factor 1.0
+                if float(getattr(bc, "rope_encoder_scaling_factor", 1.0)) != 1.0 or float(getattr(bc, "rope_decoder_scaling_factor", 1.0)) != 1.0 \
+                        or str(getattr(bc, "rope_type", "dynamic")) not in ("dynamic", "default"):
+                    raise NotImplementedError("RoPEWhisper with a rope scaling factor != 1 or a rope_type other than dynamic / default")
             return cls(model.state_dict(), dims, vocab_size_in=cfg.vocab_size_in, vocab_size_out=cfg.vocab_size, n_mels=cfg.n_mels,
                        src_seq_len=2 * cfg.max_source_positions, tgt_seq_len=cfg.max_target_positions, dtype=dtype or model.dtype,
                        device=device, sample_rate=cfg.sample_rate, n_fft=cfg.n_fft, hop_length=cfg.hop_length, f_min=cfg.f_min,
-                       f_max=cfg.f_max, spectrogram_log_scale=True, pad_token_id=cfg.pad_token_id, bos_token_id=cfg.bos_token_id,
-                       eos_token_id=cfg.eos_token_id,
-                       backbone_options=dict(global_rope_theta=bc.global_rope_theta, local_rope_theta=bc.local_rope_theta,
-                                             global_attn_every_n_layers=bc.global_attn_every_n_layers, local_attention=bc.local_attention))
+                       f_max=cfg.f_max, spectrogram_log_scale=bool(cfg.spectrogram_log_scale), pad_token_id=cfg.pad_token_id,
+                       bos_token_id=cfg.bos_token_id, eos_token_id=cfg.eos_token_id, backbone_options=opts)
         if not str(cfg.backbone_model_name).startswith("google/t5"):
-            raise NotImplementedError("only google/t5 and OliBomby/varwhisper backbones run on the HIP path")
+            raise NotImplementedError("google/t5, OliBomby/varwhisper, Tiger14n/ropewhisper and openai/whisper backbones run on the HIP "
+                                      f"path; {name} (nwhisper / moonshine) does not")
         if cfg.input_features or not cfg.project_encoder_input or not cfg.embed_decoder_input or cfg.input_raw_wave:
             raise NotImplementedError("HIP path implements input_features=False, project_encoder_input=True, "
                                       "embed_decoder_input=True")
@@ -181,7 +201,8 @@ class MapperatorinatorHIP:
             return None
         vec = self.cond.vectors(batch, beatmap_idx=kw.get("beatmap_idx"), difficulty=kw.get("difficulty"),
                                 mapper_idx=kw.get("mapper_idx"), song_position=kw.get("song_position"))
-        return self.cond.row_bias(vec, self.dtype)
+        # project_encoder_input = false ('Tiger14n/ropewhisper-*'): the vectors are conv1 input channels, else a row bias of the projection
+        return self.cond.channels(vec, self.dtype) if self.cond.as_channels else self.cond.row_bias(vec, self.dtype)
 
     # ---- B2: the two calls the reference makes on the model object -----------------------------------------
     def _cross_kv(self, frames, encoder_outputs, row_bias=None):

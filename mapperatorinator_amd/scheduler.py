@@ -124,7 +124,8 @@ class SequentialWindowScheduler:
                 raise ValueError(f"conditioning input {k!r} is given for some windows only")
             kw[k] = torch.stack([torch.as_tensor(v, dtype=torch.float32 if k in ("difficulty", "song_position") else torch.long)
                                  for v in rows[k]])
-        return cond.row_bias(cond.vectors(n, **kw), self.model.dtype)
+        vec = cond.vectors(n, **kw)
+        return cond.channels(vec, self.model.dtype) if cond.as_channels else cond.row_bias(vec, self.model.dtype)
 
     # ---- stage 2: waves of dependent windows -----------------------------------------------------------------
     @torch.no_grad()

@@ -313,7 +313,7 @@ def model_generate(model, tokenizer, model_kwargs, generate_kwargs):
         vec = cond.vectors(model_kwargs["inputs"].shape[0], beatmap_idx=model_kwargs.get("beatmap_idx"),
                            difficulty=model_kwargs.get("difficulty"), mapper_idx=model_kwargs.get("mapper_idx"),
                            song_position=model_kwargs.get("song_position"))
-        row_bias = cond.row_bias(vec, model.dtype)
+        row_bias = cond.channels(vec, model.dtype) if cond.as_channels else cond.row_bias(vec, model.dtype)
     audio = model_kwargs["inputs"]
     prompt = model_kwargs["decoder_input_ids"]
     mask = model_kwargs.get("decoder_attention_mask")

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import assert_topk_scores_match, ts_range, vw_golden_case
+from conftest import assert_topk_scores_match, ts_range, vw_golden_case, wf_golden_case
 
 pytestmark = pytest.mark.gpu
 GAP_BF16 = 0.25
@@ -186,3 +186,62 @@ def test_forward_seam_and_guidance():
     ref = o.generate(enc_o, prompt, prompt.ne(0), [tok.eos_id], tgt, ts0, ts1, [tok.sos_id], negative_prompt=neg,
                      negative_mask=neg.ne(0), cfg_scale=2.0)
     assert torch.equal(out, ref)
+
+
+# ---- round 6: the backbones of the V28-V31 releases ('Tiger14n/ropewhisper-*', 'openai/whisper-*') ---------------------------
+def build_wf(g, d, tok, sd, dtype, **opts):
+    from mapperatorinator_amd.modeling import MapperatorinatorHIP
+    hf = str(g["kind"]) == "hf"
+    return MapperatorinatorHIP(sd, d, vocab_size_in=tok.vocab_size_in, vocab_size_out=tok.vocab_size_out, n_mels=int(g["n_mels"]),
+                               src_seq_len=int(g["in_frames"]), tgt_seq_len=int(g["tgt_len"]), dtype=dtype, device="cuda",
+                               f_min=0 if hf else 20, backbone_options=opts or None)
+
+
+@pytest.mark.parametrize("name", ["rw_test", "rw_test_cond", "rw_small", "hfw_test", "hfw_small"])
+def test_whisper_family_fp32_matches_reference_golden(name):
+    """rw_small = the released V30 backbone ('Tiger14n/ropewhisper-small': whisper-small dims, 4096 log-mel frames -> 2048 encoder
+    positions, 80 mels + 3 x 128 conditioning channels into conv1), hfw_small = the V29 backbone ('openai/whisper-small' behind the
+    wrapper's encoder_embedder, 1024 nnAudio-mel frames -> 512 positions, affine LayerNorm, learned decoder positions): front-end
+    slice, encoder states <= 2e-4, greedy ids of ragged left-padded prompts BIT-EXACT, the 16 best processed scores of every
+    step <= 5e-4 -- all against what the imported reference produced through its own `model_generate`."""
+    from mapperatorinator_amd.server import build_sampling, model_generate
+    g, kind, d, tok, sd, audio, cond = wf_golden_case(name)
+    tgt = int(g["tgt_len"])
+    model = build_wf(g, d, tok, sd, torch.float32)
+    assert model.engine.kind == kind
+    eng = model.engine
+    eng._enter()
+    with eng.on_stream():
+        mel = eng.mel(audio.cuda())
+    eng._leave()
+    err_mel = np.abs(mel.float().cpu()[:, ::37, :int(g["n_mels"]):11].numpy() - g["mel_slice"]).max()
+    ck = cond or {}
+    rb = model._row_bias(audio.shape[0], ck)
+    if cond is not None:
+        assert model.cond.active and np.abs(model.cond.vectors(audio.shape[0], **cond).numpy() - g["cond_vectors"]).max() < 2e-6
+    enc, enc32 = eng.encode(audio.cuda(), want_f32=True, row_bias=rb)
+    err = np.abs(enc32.cpu()[:, ::29, ::17].numpy() - g["enc_slice"]).max()
+    print(name, "mel max abs err vs the reference-side restatement", err_mel, "(scale", float(np.abs(g["mel_slice"]).max()), ") | encoder max abs err vs reference", err)
+    assert err_mel < 2e-4 * max(1.0, float(np.abs(g["mel_slice"]).max())) and err < 2e-4
+    prompt = torch.from_numpy(g["prompt"])
+    mk = dict(inputs=audio, decoder_input_ids=prompt, decoder_attention_mask=prompt.ne(0), **ck)
+    ids, stats = model_generate(model, tok, mk, gen_kwargs(tgt))
+    assert ids.shape == g["ids"].shape and np.array_equal(ids.numpy(), g["ids"]), np.argwhere(ids.numpy() != g["ids"])[:3]
+    if not name.endswith("_small"):      # the token-by-token prompt path gives the reference's ids too
+        from mapperatorinator_amd import _lib
+        old = _lib.set_option("decode_prefill", 0)
+        try:
+            ids_tok, _ = model_generate(model, tok, mk, gen_kwargs(tgt))
+        finally:
+            _lib.set_option("decode_prefill", old)
+        assert np.array_equal(ids_tok.numpy(), g["ids"])
+    ids2, _ = model_generate(model, tok, mk, gen_kwargs(tgt, temperature=0.7, timeshift_bias=0.35, lookahead_time=3000))
+    assert ids2.shape == g["ids_processors"].shape and np.array_equal(ids2.numpy(), g["ids_processors"])
+    sp, eos = build_sampling(tok, gen_kwargs(tgt), tgt)
+    out = eng.generate(audio, prompt, prompt.ne(0), eos, sp, dump_logits=True, row_bias=rb)
+    assert torch.equal(out["tokens"], ids)
+    worst = assert_topk_scores_match(out["logits"], g, prompt.shape[1], 5e-4)
+    print(name, "worst |d score| vs the reference over the 16 best ids of every step", worst)
+    if cond is not None:
+        with pytest.raises(ValueError, match="conditioning"):
+            eng.encode(audio.cuda())                    # a conditioned model without its conditioning must refuse, not guess

@@ -46,11 +46,11 @@ def test_argument_validation_without_gpu():
 
 def test_struct_layouts_match_header_sizes():
     # pointer arrays of MH_MAX_LAYERS entries, ints packed as in C
-    assert C.sizeof(_lib.MhT5Config) == 14 * 4 + 5 * 4 + 4 + 8            # ABI 5: arch, attn_scale, in_frames, local_every, local_window; ABI 7: enc_operand_dtype; ABI 8: options
+    assert C.sizeof(_lib.MhT5Config) == 14 * 4 + 5 * 4 + 4 + 8 + 4 + 4    # ABI 5: arch, attn_scale, in_frames, local_every, local_window; ABI 7: enc_operand_dtype; ABI 8: options; ABI 10: dec_pos_from_mask + tail pad
     assert C.sizeof(_lib.MhDiTConfig) == 11 * 4 + 4 + 8                    # 4B pad before the ABI 8 options pointer
     base = 4 * 8 + 16 * 4 + 3 * 4 + 4 + 8                                # 4B pad before the uint64 seed
     assert C.sizeof(_lib.MhSampling) == base + 9 * 4 + 4 + 8 + 2 * 4 + 8   # ABI 2 tail: 9 words, pad, tok_flags; ABI 3: 2 words; ABI 4: cross_kv_fp8
-    assert C.sizeof(_lib.MhT5Weights) == 8 * (5 + 6 * 32 + 1 + 5 * 32 + 1 + 4 * 32 + 2) + 8 * (4 + 4 * 32 + 3 * 32 + 1 + 3 * 32 + 4) + 8 * (8 * 32 + 2)   # + ABI 5 (arch 1) + ABI 7 (MX-fp8 copies)
+    assert C.sizeof(_lib.MhT5Weights) == 8 * (5 + 6 * 32 + 1 + 5 * 32 + 1 + 4 * 32 + 2) + 8 * (4 + 4 * 32 + 3 * 32 + 1 + 3 * 32 + 4) + 8 * (8 * 32 + 2) + 8 * (5 * 32 + 4)   # + ABI 5 (arch 1) + ABI 7 (MX-fp8 copies) + ABI 10 (arch 2: LayerNorm biases, position tables)
     assert C.sizeof(_lib.MhDiTWeights) == 8 * (12 + 10 * 32 + 4 + 1 + 4 * 32 + 4 * 32 + 8 * 32)   # + the pre-split (bf16 x 3), the bf16 and (ABI 7) the MX-fp8 copies
 
 
@@ -739,20 +739,46 @@ def test_fresh_seed_call_index_is_independent_of_process_history():
     assert s.fresh_seed(11) == a0
 
 
-def test_varwhisper_packer_refuses_conditioning_channels_in_conv1():
-    """a conv1 with n_mels + conditioning input channels must be refused, not cropped to n_mels."""
+def test_whisper_packer_keeps_conditioning_channels_of_conv1():
+    """ADVICE r3 asked that a conv1 with n_mels + conditioning input channels be refused rather than cropped to n_mels; round 6
+    builds it (configs/model/whisper_small_v2.yaml: the V30 / V31 wiring): the packer keeps EVERY input channel (tap-major, K
+    padded), reports `cond_channels`, and a state dict whose conv1 is wider than n_mels without conditioning embedders is
+    refused where the embedders are read."""
     import pytest
     import torch
 
-    from mapperatorinator_amd.testing import random_varwhisper_state_dict
-    from mapperatorinator_amd.whisper_engine import VARWHISPER_PRESETS, PackedVarWhisper
+    from mapperatorinator_amd.conditioning import ConditioningEmbedders
+    from mapperatorinator_amd.testing import add_random_cond_embedders, random_varwhisper_state_dict, random_whisper_family_state_dict
+    from mapperatorinator_amd.whisper_engine import VARWHISPER_PRESETS, PackedVarWhisper, fuse_split_projections, whisper_kind
     d = VARWHISPER_PRESETS["test"]
     sd = random_varwhisper_state_dict(d.d_model, d.n_heads, d.n_enc_layers, d.n_dec_layers, d.d_ff, 200, 180, seed=0)
     k = "transformer.model.encoder.conv1.weight"
     n_mels = sd[k].shape[1]
-    sd[k] = torch.cat([sd[k], torch.zeros(sd[k].shape[0], 16, 3)], 1)          # + 16 conditioning channels
-    with pytest.raises(NotImplementedError, match="conv1"):
-        PackedVarWhisper(sd, d, 200, 180, n_mels, 64, 32, torch.float32, "cpu")
+    sd[k] = torch.cat([sd[k], torch.full((sd[k].shape[0], 16, 3), 0.5)], 1)          # + 16 conditioning channels
+    p = PackedVarWhisper(sd, d, 200, 180, n_mels, 64, 32, torch.float32, "cpu")
+    assert p.kind == "var" and p.cond_channels == 16 and p.n_mels_pad == 160 and p.cfg.n_mels == n_mels + 16 and p.cfg.arch == 1
+    w1 = [t for t in p._keep if t.shape == (d.d_model, 3 * 160)][0]
+    assert torch.equal(w1[:, n_mels:n_mels + 16], torch.full((d.d_model, 16), 0.5)) and float(w1[:, n_mels + 16:160].abs().sum()) == 0
+    with pytest.raises(ValueError, match="conditioning"):
+        ConditioningEmbedders(sd, n_mels)
+    add_random_cond_embedders(sd, cond_dim=5)                # 3 x 5 = 15 != 16: the widths must agree when vectors are built
+    ce = ConditioningEmbedders(sd, n_mels)
+    assert ce.as_channels and ce.cond_size == 16
+    with pytest.raises(ValueError, match="columns"):
+        ce.vectors(2, difficulty=[1.0, 2.0], mapper_idx=[0, 1], song_position=[[0, 0.1], [0.5, 0.6]])
+    # the split-projection families: names fused, k bias zero, kinds told apart, arch 2 config for stock Whisper
+    for kind, n_m in (("rope", 80), ("hf", 388)):
+        sd2 = random_whisper_family_state_dict(kind, d.d_model, d.n_heads, d.n_enc_layers, d.n_dec_layers, d.d_ff, 200, 180, n_m,
+                                               src_positions=32, tgt_positions=32, cond_size=0, seed=1)
+        assert whisper_kind(sd2) == kind
+        f = fuse_split_projections(sd2)
+        b0 = "transformer.model.decoder.layers.0."
+        assert f[b0 + "self_attn.Wqkv.weight"].shape == (3 * d.d_model, d.d_model) and float(f[b0 + "self_attn.Wqkv.bias"][d.d_model:2 * d.d_model].abs().sum()) == 0
+        assert torch.equal(f[b0 + "cross_attn.Wkv.weight"][:d.d_model], sd2[b0 + "encoder_attn.k_proj.weight"])
+        assert b0 + "cross_attn_layer_norm.weight" in f and not [x for x in f if "q_proj" in x or "encoder_attn" in x]
+        p2 = PackedVarWhisper(sd2, d, 200, 180, n_m, 64, 32, torch.float32, "cpu")
+        assert p2.kind == kind and p2.cfg.arch == (2 if kind == "hf" else 1) and p2.cond_channels == 0
+        assert bool(p2.w.dec_pos) == (kind == "hf") and bool(p2.w.dec_ln1_b[0]) == (kind == "hf")
 
 
 def test_kernels_with_asm_issued_loads_have_no_scratch_and_no_spills():
