@@ -199,6 +199,12 @@ int mh_rmsnorm_mx8(const float* x, int ldx, const float* w, int rows, int d, flo
  * y[T] = w * x * rsqrt(mean(x^2) + eps), x fp32 [rows, d] (ldx), y [rows, ldy]. */
 int mh_rmsnorm(const float* x, int ldx, const float* w, void* y, int ldy, int rows, int d, float eps,
                int out_dtype, void* stream);
+/* (ABI 10) nn.LayerNorm with affine parameters -- the pre-norm of stock HF Whisper's blocks ('openai/whisper-*', the V28 / V29
+ * backbones; transformers models/whisper/modeling_whisper.py WhisperEncoderLayer / WhisperDecoderLayer): y = (x - mean) *
+ * rsqrt(var + eps) * w + b, biased variance of the centred values, fp32 arithmetic; x fp32 [rows, ldx], y [rows, ldy] of
+ * `out_dtype`. */
+int mh_layernorm(const float* x, int ldx, const float* w, const float* b, void* y, int ldy, int rows, int d, float eps,
+                 int out_dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K3  T5 encoder self-attention (HF T5Attention.forward, restated custom_transformers/t5.py:170-250):

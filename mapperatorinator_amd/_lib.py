@@ -129,6 +129,7 @@ SYMBOLS = {
     "mh_mel": (I, [VP, I, I, I, I, I, VP, VP, VP, VP, VP, VP, I, VP, I, I, VP]),
     "mh_gemm": (I, [C.POINTER(MhGemm), VP]),
     "mh_rmsnorm": (I, [VP, I, VP, VP, I, I, I, F, I, VP]),
+    "mh_layernorm": (I, [VP, I, VP, VP, VP, I, I, I, F, I, VP]),
     "mh_mx8_scale_row_bytes": (I64, [I]),
     "mh_quantize_mx8": (I, [VP, I, I, I, I, VP, I, VP, VP]),
     "mh_rmsnorm_mx8": (I, [VP, I, VP, I, I, F, I, VP, I, VP, VP]),

@@ -205,7 +205,7 @@ __device__ inline void store_head_row_from_lds_wt(T* dst, const float* src, int 
 //     1 KB runs take 3.35 -> 2.70 us alone, 4.13 -> 2.92 us beside a second chain).  Staging them through LDS with
 //     whole-line loads was built and measured: the extra LDS write / barrier / read costs what the loads save (o-projection
 //     3.61 us alone, 4.12 beside a second chain; whole step 37.4 k vs 38.1 k tok/s without it) -- not kept.
-enum { PRO_PLAIN = 0, PRO_RMSNORM = 1 };
+enum { PRO_PLAIN = 0, PRO_RMSNORM = 1, PRO_LAYERNORM = 2 };   // (LAYERNORM: HF Whisper's affine nn.LayerNorm, library arch 2)
 enum { SK_STORE = 0, SK_QKV = 1, SK_GEGLU = 2, SK_RESID = 3, SK_LOGITS = 4, SK_GELU_ERF = 5 };   // (GELU_ERF: the Whisper family's fc1)
 
 struct SkinnyP {
@@ -220,6 +220,7 @@ struct SkinnyP {
   int H, tgt_len, inner;
   const int* pos;
   const float* bias;           // kernel template BIAS (the Whisper family's biased projections): fp32 [N], else unused
+  const float* ln_b;           // PRO_LAYERNORM: the LayerNorm bias fp32 [K] (ln_w = its weight, eps = its epsilon)
 };
 
 template <typename T> struct VecOps;
@@ -234,6 +235,21 @@ template <> struct VecOps<bf16_t> {
   __device__ static inline float sumsq(const Raw& x) {
     return (x.a.x * x.a.x + x.a.y * x.a.y) + (x.a.z * x.a.z + x.a.w * x.a.w) + (x.b.x * x.b.x + x.b.y * x.b.y) +
            (x.b.z * x.b.z + x.b.w * x.b.w);
+  }
+  __device__ static inline float sum(const Raw& x) { return (x.a.x + x.a.y) + (x.a.z + x.a.w) + (x.b.x + x.b.y) + (x.b.z + x.b.w); }
+  __device__ static inline Raw centred(const Raw& x, float mu) {
+    Raw r;
+    r.a = make_float4(x.a.x - mu, x.a.y - mu, x.a.z - mu, x.a.w - mu);
+    r.b = make_float4(x.b.x - mu, x.b.y - mu, x.b.z - mu, x.b.w - mu);
+    return r;
+  }
+  // nn.LayerNorm: (x - mean) * rstd * weight + bias (x arrives centred)
+  __device__ static inline uint4 ln_frag(const Raw& x, const Raw& g, const Raw& b, float rs) {
+    const uint32_t o0 = pack_bf16x2(x.a.x * rs * g.a.x + b.a.x, x.a.y * rs * g.a.y + b.a.y);
+    const uint32_t o1 = pack_bf16x2(x.a.z * rs * g.a.z + b.a.z, x.a.w * rs * g.a.w + b.a.w);
+    const uint32_t o2 = pack_bf16x2(x.b.x * rs * g.b.x + b.b.x, x.b.y * rs * g.b.y + b.b.y);
+    const uint32_t o3 = pack_bf16x2(x.b.z * rs * g.b.z + b.b.z, x.b.w * rs * g.b.w + b.b.w);
+    return make_uint4(o0, o1, o2, o3);
   }
   __device__ static inline uint4 norm_frag(const Raw& x, const Raw& g, float rs) {
     const uint32_t o0 = pack_bf16x2(g.a.x * (x.a.x * rs), g.a.y * (x.a.y * rs));
@@ -257,6 +273,16 @@ template <> struct VecOps<float> {
     return r;
   }
   __device__ static inline float sumsq(const Raw& x) { return (x.a.x * x.a.x + x.a.y * x.a.y) + (x.a.z * x.a.z + x.a.w * x.a.w); }
+  __device__ static inline float sum(const Raw& x) { return (x.a.x + x.a.y) + (x.a.z + x.a.w); }
+  __device__ static inline Raw centred(const Raw& x, float mu) {
+    Raw r;
+    r.a = make_float4(x.a.x - mu, x.a.y - mu, x.a.z - mu, x.a.w - mu);
+    return r;
+  }
+  __device__ static inline uint4 ln_frag(const Raw& x, const Raw& g, const Raw& b, float rs) {
+    return make_uint4(__float_as_uint(x.a.x * rs * g.a.x + b.a.x), __float_as_uint(x.a.y * rs * g.a.y + b.a.y),
+                      __float_as_uint(x.a.z * rs * g.a.z + b.a.z), __float_as_uint(x.a.w * rs * g.a.w + b.a.w));
+  }
   __device__ static inline uint4 norm_frag(const Raw& x, const Raw& g, float rs) {
     return make_uint4(__float_as_uint(g.a.x * (x.a.x * rs)), __float_as_uint(g.a.y * (x.a.y * rs)),
                       __float_as_uint(g.a.z * (x.a.z * rs)), __float_as_uint(g.a.w * (x.a.w * rs)));
@@ -330,11 +356,14 @@ void gemv_kernel(MH_GEMV_LEAD_PARAMS, SkinnyP p) {
 #ifndef MH_GEMV_RLINES
 #define MH_GEMV_RLINES 1   // (0: A/B builds only)
 #endif
-  constexpr bool RLINES = (MF == 1 && PRO == PRO_RMSNORM && sizeof(T) == 2 && MH_GEMV_RLINES);
+  constexpr bool NORM = PRO != PRO_PLAIN, LN = PRO == PRO_LAYERNORM;
+  constexpr bool RLINES = (MF == 1 && NORM && sizeof(T) == 2 && MH_GEMV_RLINES);
   __shared__ __attribute__((aligned(16))) unsigned char Lw[(LINES || RLINES) ? NWV * PATCH : 16];
   __shared__ f32x4_t red[NWV * MF * 64];
-  __shared__ float ssw[PRO == PRO_RMSNORM ? NWV : 1][MF * 16];
-  __shared__ __attribute__((aligned(16))) float lnw[PRO == PRO_RMSNORM ? 1024 : 4];   // RMSNorm weight, staged once per workgroup
+  __shared__ float ssw[NORM ? NWV : 1][MF * 16];
+  __shared__ float ssw2[LN ? NWV : 1][MF * 16];    // LayerNorm: the centred sums of squares (second reduction)
+  __shared__ __attribute__((aligned(16))) float lnw[NORM ? 1024 : 4];   // norm weight, staged once per workgroup
+  __shared__ __attribute__((aligned(16))) float lnb[LN ? 1024 : 4];     // LayerNorm bias
 
   MH_STAMP0();
   constexpr int KID = KID_GEMV + EPI * 2 + (NWV == 8 ? 1 : 0);
@@ -344,10 +373,11 @@ void gemv_kernel(MH_GEMV_LEAD_PARAMS, SkinnyP p) {
   // The vector-memory path of a CU moves 64 B per clock and charges every LANE of a load instruction, duplicates
   // included: a tile whose 16 columns repeat nv real ones must not load the repeats (exec-masked W loads below), and
   // the RMSNorm weight is fetched once per workgroup through LDS instead of once per 16-lane row group.
-  float4 lnraw = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (PRO == PRO_RMSNORM) {
+  float4 lnraw = make_float4(0.f, 0.f, 0.f, 0.f), lnbraw = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (NORM) {
     const int i4 = tid * 4 < p.K ? tid * 4 : 0;     // K <= 1024 <= 4 * (NWV * 64)
     lnraw = *reinterpret_cast<const float4*>(p.ln_w + i4);
+    if (LN) lnbraw = *reinterpret_cast<const float4*>(p.ln_b + i4);
   }
   // weight row of this lane's tile column
   int wrow, ocol;      // ocol: output column of tile column l15 (GEGLU: of the gate / linear PAIR)
@@ -441,7 +471,7 @@ void gemv_kernel(MH_GEMV_LEAD_PARAMS, SkinnyP p) {
   do {   // ONE pass for every RMSNorm shape and for K <= NWV * CH * KB; every wave runs at least one (its barrier)
     uint4 wv[CH];
     uint4 av[PRO == PRO_PLAIN ? CH : 1][PRO == PRO_PLAIN ? MF : 1];
-    Raw hraw[PRO == PRO_RMSNORM ? CH : 1][PRO == PRO_RMSNORM ? MF : 1];
+    Raw hraw[NORM ? CH : 1][NORM ? MF : 1];
 #pragma unroll
     for (int c = 0; c < CH; ++c) wv[c] = make_uint4(0, 0, 0, 0);
     if (wload && !(PROBE & 2)) {     // ONE exec-masked region around all weight loads (a branch per load would serialise them)
@@ -501,7 +531,45 @@ void gemv_kernel(MH_GEMV_LEAD_PARAMS, SkinnyP p) {
       }
     }
     float rsr[MF];
-    if (PRO == PRO_RMSNORM) {
+    if (LN) {
+      // nn.LayerNorm statistics from the registers, two passes (mean, then the centred sum of squares -- the arithmetic of
+      // F.layer_norm, no E[x^2] - mu^2 cancellation): lane -> the 4 lane groups of the wave -> the NWV waves, twice
+#pragma unroll
+      for (int f = 0; f < MF; ++f) {
+        float q = 0.f;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) q += (kb0 + NWV * c < nkb) ? VecOps<T>::sum(hraw[c][f]) : 0.f;
+        q += __shfl_xor(q, 16, 64);
+        q += __shfl_xor(q, 32, 64);
+        if (lg == 0) ssw[wid][f * 16 + l15] = q;
+      }
+      if (tid * 4 < p.K) { *reinterpret_cast<float4*>(lnw + tid * 4) = lnraw; *reinterpret_cast<float4*>(lnb + tid * 4) = lnbraw; }
+      __syncthreads();
+#pragma unroll
+      for (int f = 0; f < MF; ++f) {
+        float su = 0.f;
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) su += ssw[w][f * 16 + l15];
+        const float mu = su / (float)p.K;
+        float q = 0.f;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          hraw[c][f] = VecOps<T>::centred(hraw[c][f], mu);
+          q += (kb0 + NWV * c < nkb) ? VecOps<T>::sumsq(hraw[c][f]) : 0.f;
+        }
+        q += __shfl_xor(q, 16, 64);
+        q += __shfl_xor(q, 32, 64);
+        if (lg == 0) ssw2[wid][f * 16 + l15] = q;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int f = 0; f < MF; ++f) {
+        float ss = 0.f;
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) ss += ssw2[w][f * 16 + l15];
+        rsr[f] = rsqrtf(ss / (float)p.K + p.eps);
+      }
+    } else if (PRO == PRO_RMSNORM) {
       // RMSNorm statistics of the rows from the registers: lane -> the 4 lane groups of the wave -> the NWV waves
 #pragma unroll
       for (int f = 0; f < MF; ++f) {
@@ -531,6 +599,7 @@ void gemv_kernel(MH_GEMV_LEAD_PARAMS, SkinnyP p) {
       for (int f = 0; f < MF; ++f) {
         uint4 a;
         if (PRO == PRO_PLAIN) a = av[c][f];
+        else if (LN) a = VecOps<T>::ln_frag(hraw[c][f], VecOps<T>::load_raw(lnw + kc_el), VecOps<T>::load_raw(lnb + kc_el), rsr[f]);
         else a = VecOps<T>::norm_frag(hraw[c][f], VecOps<T>::load_raw(lnw + kc_el), rsr[f]);
         a = make_uint4(a.x & keep, a.y & keep, a.z & keep, a.w & keep);
         acc[f] = VecOps<T>::mma(a, wv[c], acc[f]);
@@ -826,6 +895,7 @@ struct HeadProjP {
   const float* ln_w; float eps;
   const void* W; int ldw;             // [rows, ldw] element type T (cross: Wq [inner][d]; self: Wqkv [3 inner][d])
   int d;
+  const float* ln_b;                  // kernel template LN (HF Whisper, library arch 2): affine nn.LayerNorm -- its bias; ln_w = its weight
 };
 
 template <typename T> struct Raw8;
@@ -850,12 +920,13 @@ template <> struct Raw8<float> {
 // The statistics come from the row itself (wave sums -> 16 LDS floats that every thread adds in the same order).
 // Two halves: `issue` only REQUESTS the row and the weight (it needs nothing but preloaded kernel arguments), `finish`
 // waits for them -- whatever else the kernel can request goes in between.
-template <typename T>
+template <typename T, bool LN = false>
 struct NormRow {
-  float x, g;
+  float x, g, bb;
   __device__ inline void issue_weight(const HeadProjP& hp) {      // (independent of the predecessor)
     const int tid = threadIdx.x;
     g = hp.ln_w[tid < hp.d ? tid : hp.d - 1];
+    if (LN) bb = hp.ln_b[tid < hp.d ? tid : hp.d - 1];
   }
   __device__ inline void issue_row(const HeadProjP& hp, int b) {   // the residual row the predecessor wrote
     const int tid = threadIdx.x;
@@ -864,6 +935,17 @@ struct NormRow {
   __device__ inline void issue(const HeadProjP& hp, int b) { issue_row(hp, b); issue_weight(hp); }
   __device__ inline void finish(const HeadProjP& hp, float* xn, float* red16) {
     const int tid = threadIdx.x;
+    if (LN) {
+      // nn.LayerNorm: mean first, then the centred sum of squares (two block reductions over the same 16 LDS floats)
+      const float su = wave_sum(tid < hp.d ? x : 0.f);
+      if ((tid & 63) == 0) red16[tid >> 6] = su;
+      __syncthreads();
+      float tot = 0.f;
+#pragma unroll
+      for (int w = 0; w < 16; ++w) tot += red16[w];
+      x -= tot / (float)hp.d;
+      __syncthreads();      // (every thread has read red16 before it is written again)
+    }
     const float sq = wave_sum(tid < hp.d ? x * x : 0.f);
     if ((tid & 63) == 0) red16[tid >> 6] = sq;
     __syncthreads();
@@ -871,7 +953,7 @@ struct NormRow {
 #pragma unroll
     for (int w = 0; w < 16; ++w) tot += red16[w];
     const float rs = rsqrtf(tot / (float)hp.d + hp.eps);
-    if (tid < hp.d) xn[tid] = Elem<T>::to_f32(Elem<T>::from_f32(g * (x * rs)));
+    if (tid < hp.d) xn[tid] = Elem<T>::to_f32(Elem<T>::from_f32(LN ? x * rs * g + bb : g * (x * rs)));
     __syncthreads();
   }
 };
@@ -935,7 +1017,7 @@ struct HeadProj {
 // cross-attention of one (b, h) with its own query projection; 16 waves, one key split (the default configuration
 // of dec_cross_attn_kernel, same key interleave and merge order)
 // F8: K / V are the e4m3 copy (64-byte rows, 8 bytes per lane; the scales multiply the scores and the output)
-template <typename T, int KC, int U, bool F8 = false, bool WH = false>
+template <typename T, int KC, int U, bool F8 = false, bool WH = false, bool LN = false>
 #ifndef MH_CROSS_WPE_MIN
 #define MH_CROSS_WPE_MIN 8     // (A/B builds: 4 = up to 128 VGPRs, one 16-wave workgroup per CU)
 #endif
@@ -960,7 +1042,7 @@ void dec_cross_attn_q_kernel(const float* h_, const float* lnw_, const void* W_,
   const E* kb = reinterpret_cast<const E*>(p.k) + ((long)kvb * p.H + h) * p.L * 64;
   const E* vb = reinterpret_cast<const E*>(p.v) + ((long)kvb * p.H + h) * p.L * 64;
   HeadProj<T, KC, 1> proj;
-  NormRow<T> nrow;
+  NormRow<T, LN> nrow;
   // everything the prologue needs is requested at once, from preloaded arguments only: the residual row, the RMSNorm
   // weight and (bf16: fp32 -- the parity path -- would not fit the 64-register budget of two workgroups per CU) this
   // head's 64 x d slice of Wq, which does not depend on the activations; then the remaining kernel arguments
@@ -1002,7 +1084,7 @@ void dec_cross_attn_q_kernel(const float* h_, const float* lnw_, const void* W_,
 
 // self-attention of one (b, h) with its own q / k / v projections: appends the new key / value row to the caches and
 // attends over keys 0 .. pos-1 from the cache plus the new key straight from LDS (merged last)
-template <typename T, int KC, bool WH = false>
+template <typename T, int KC, bool WH = false, bool LN = false>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4)))   // 16 waves = 4 per SIMD: the whole 128-register budget
 void dec_self_attn_qkv_kernel(const float* h_, const float* lnw_, const void* W_, const int* pos_,
                                                                  const void* kc_, const void* vc_, int H_, int d_, SelfAttnP p,
@@ -1022,7 +1104,7 @@ void dec_self_attn_qkv_kernel(const float* h_, const float* lnw_, const void* W_
   // the first round trip carries everything that does not depend on another load: the residual row + RMSNorm weight, the
   // position, and the two loop-invariant values of the tail (the bias at distance 0 and the prompt mask of the new key:
   // they used to be two serial round trips at the END of the kernel)
-  NormRow<T> nrow;
+  NormRow<T, LN> nrow;
   nrow.issue(hp, b);
   const int pos = *p.pos;
   constexpr bool kAllAtOnce = sizeof(T) == 2 && KC <= 7;

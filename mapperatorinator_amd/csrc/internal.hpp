@@ -10,6 +10,8 @@ int gemm_prepare();  // one-time kernel attribute setup; call before any stream 
 int gemm(const MhGemm& g, hipStream_t s, bool ascending_k = false);
 int rmsnorm(const float* x, int ldx, const float* w, void* y, int ldy, int rows, int d, float eps, int out_dtype,
             hipStream_t s);
+int layernorm(const float* x, int ldx, const float* w, const float* b, void* y, int ldy, int rows, int d, float eps, int out_dtype,
+              hipStream_t s);
 // MX-fp8 operands (mx8.hip): scale bytes per row, producers that write the quantised operand directly
 int quantize_mx8(const void* x, int ldx, int rows, int K, int in_dtype, uint8_t* q, int ldq, uint8_t* scales, hipStream_t s);
 int rmsnorm_mx8(const float* x, int ldx, const float* w, int rows, int d, float eps, int round_dtype, uint8_t* q, int ldq,

@@ -33,6 +33,40 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
   }
 }
 
+// nn.LayerNorm with affine parameters (HF Whisper's blocks, library arch 2): y = (x - mean) * rsqrt(var + eps) * w + b, biased
+// variance of the CENTRED values (the two-pass arithmetic of F.layer_norm); one wave per row, the row is re-read from L1 / L2
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
+                                                       const float* __restrict__ b, T* __restrict__ y, int ldy, int rows, int d, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + (long)row * ldx;
+  float su = 0.f;
+  for (int i = lane * 4; i < d; i += 256) {
+    const float4 v = *reinterpret_cast<const float4*>(xr + i);
+    su += (v.x + v.y) + (v.z + v.w);
+  }
+  const float mu = wave_sum(su) / (float)d;
+  float ss = 0.f;
+  for (int i = lane * 4; i < d; i += 256) {
+    const float4 v = *reinterpret_cast<const float4*>(xr + i);
+    const float p = v.x - mu, q = v.y - mu, r = v.z - mu, t = v.w - mu;
+    ss += (p * p + q * q) + (r * r + t * t);
+  }
+  const float rs = rsqrtf(wave_sum(ss) / (float)d + eps);
+  T* yr = y + (long)row * ldy;
+  for (int i = lane * 4; i < d; i += 256) {
+    const float4 v = *reinterpret_cast<const float4*>(xr + i);
+    const float4 g = *reinterpret_cast<const float4*>(w + i);
+    const float4 c = *reinterpret_cast<const float4*>(b + i);
+    yr[i + 0] = Elem<T>::from_f32((v.x - mu) * rs * g.x + c.x);
+    yr[i + 1] = Elem<T>::from_f32((v.y - mu) * rs * g.y + c.y);
+    yr[i + 2] = Elem<T>::from_f32((v.z - mu) * rs * g.z + c.z);
+    yr[i + 3] = Elem<T>::from_f32((v.w - mu) * rs * g.w + c.w);
+  }
+}
+
 // x [rows, d] fp32; shift/scale: [n_batch, mod_ld] rows selected by row / rows_per_batch.  y: fp32 or bf16 (the operand
 // rounding of the DiT's bf16 mode happens here, after the fp32 arithmetic).  One wave per row; the row (d <= 256 * NC floats)
 // is read ONCE into registers -- mean, the centred sum of squares (same two-pass arithmetic as before, on the registers) and
@@ -113,6 +147,18 @@ int rmsnorm(const float* x, int ldx, const float* w, void* y, int ldy, int rows,
   return check_launch("rmsnorm_kernel");
 }
 
+int layernorm(const float* x, int ldx, const float* w, const float* b, void* y, int ldy, int rows, int d, float eps, int out_dtype,
+              hipStream_t s) {
+  MH_REQUIRE(x && w && b && y && rows > 0 && d > 0, "mh_layernorm: bad arguments");
+  MH_REQUIRE(d % 4 == 0 && ldx % 4 == 0, "mh_layernorm: d and ldx must be multiples of 4");
+  dim3 grid(ceil_div(rows, 4)), block(256);
+  if (out_dtype == MH_BF16)
+    hipLaunchKernelGGL(layernorm_kernel<bf16_t>, grid, block, 0, s, x, ldx, w, b, (bf16_t*)y, ldy, rows, d, eps);
+  else
+    hipLaunchKernelGGL(layernorm_kernel<float>, grid, block, 0, s, x, ldx, w, b, (float*)y, ldy, rows, d, eps);
+  return check_launch("layernorm_kernel");
+}
+
 template <typename T, int NC, bool SPLIT = false>
 static void launch_ln_modulate(const float* x, int ldx, const float* shift, const float* scale, int mod_ld, int rows_per_batch,
                                void* y, int ldy, int rows, int d, float eps, hipStream_t s) {
@@ -140,4 +186,8 @@ int ln_modulate(const float* x, int ldx, const float* shift, const float* scale,
 extern "C" int mh_rmsnorm(const float* x, int ldx, const float* w, void* y, int ldy, int rows, int d, float eps,
                           int out_dtype, void* stream) {
   return mh::rmsnorm(x, ldx, w, y, ldy, rows, d, eps, out_dtype, (hipStream_t)stream);
+}
+extern "C" int mh_layernorm(const float* x, int ldx, const float* w, const float* b, void* y, int ldy, int rows, int d, float eps,
+                            int out_dtype, void* stream) {
+  return mh::layernorm(x, ldx, w, b, y, ldy, rows, d, eps, out_dtype, (hipStream_t)stream);
 }

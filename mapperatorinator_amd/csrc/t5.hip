@@ -29,8 +29,9 @@ int check_cfg(const MhT5Config* c, const char* who) {
   MH_REQUIRE(c->d_model % 32 == 0 && c->d_ff % 32 == 0, "%s: d_model/d_ff must be multiples of 32", who);
   MH_REQUIRE(c->n_mels_pad % 32 == 0 && c->n_mels_pad >= c->n_mels, "%s: bad n_mels_pad", who);
   MH_REQUIRE(c->dtype == MH_F32 || c->dtype == MH_BF16, "%s: bad dtype", who);
-  MH_REQUIRE(c->arch == 0 || c->arch == 1, "%s: arch %d is neither 0 (T5) nor 1 (VarWhisper)", who, c->arch);
-  if (c->arch == 1) {
+  MH_REQUIRE(c->arch >= 0 && c->arch <= 2, "%s: arch %d is none of 0 (T5), 1 (VarWhisper / RoPEWhisper), 2 (HF Whisper)", who, c->arch);
+  MH_REQUIRE(c->dec_pos_from_mask == 0 || c->arch == 2, "%s: dec_pos_from_mask belongs to arch 2 (absolute decoder positions)", who);
+  if (c->arch >= 1) {
     MH_REQUIRE(c->d_model == c->n_heads * 64, "%s: the Whisper family needs d_model = 64 heads", who);
     MH_REQUIRE(c->in_frames >= 1 && c->src_len == (c->in_frames - 1) / 2 + 1, "%s: src_len must be the conv-strided in_frames", who);
     MH_REQUIRE(c->attn_scale > 0.f, "%s: attn_scale must be positive", who);
@@ -43,6 +44,14 @@ int check_cfg(const MhT5Config* c, const char* who) {
 }
 inline bool enc_mx(const MhT5Config* c) { return c->enc_operand_dtype == MH_MX8; }
 inline int64_t mx_operand_bytes(int64_t rows, int K) { return align256(rows * K) + align256(rows * mx8_scale_row_bytes(K)); }
+// the pre-norm of a block: T5LayerNorm / nn.RMSNorm (arch 0 / 1) or the affine nn.LayerNorm of HF Whisper (arch 2, bias != NULL there)
+inline int pre_norm(const MhT5Config* c, const float* x, const float* w, const float* b, void* y, int rows, int out_dtype, hipStream_t s) {
+  if (c->arch == 2) {
+    MH_REQUIRE(b, "arch 2 needs the LayerNorm biases (MhT5Weights.*_ln*_b)");
+    return layernorm(x, c->d_model, w, b, y, c->d_model, rows, c->d_model, c->eps, out_dtype, s);
+  }
+  return rmsnorm(x, c->d_model, w, y, c->d_model, rows, c->d_model, c->eps, out_dtype, s);
+}
 inline bool is_local_layer(const MhT5Config* c, int l) { return c->arch == 1 && c->local_every > 1 && c->local_window > 0 && l % c->local_every != 0; }
 
 #define MH_TRY(expr)              \
@@ -65,8 +74,11 @@ extern "C" int64_t mh_t5_encode_workspace_bytes(const MhT5Config* c, int B) {
   const int64_t rows = (int64_t)B * c->src_len, es = es_of(c->dtype);
   const int inner = c->n_heads * 64, Lpad = round_up(c->src_len, 64);
   int64_t t = 0;
-  if (c->arch == 1)   // front-end scratch + its output (storage type) in front of the layer buffers
-    t += align256(mh_whisper_frontend_workspace_bytes(B, c->in_frames, c->n_mels_pad, c->d_model, c->dtype)) + align256(rows * c->d_model * es);
+  if (c->arch >= 1)   // front-end scratch + its output (storage type) in front of the layer buffers
+    t += align256(mh_whisper_frontend_workspace_bytes(B, c->in_frames, c->arch == 2 ? c->d_model : c->n_mels_pad, c->d_model, c->dtype)) +
+         align256(rows * c->d_model * es);
+  if (c->arch == 2)   // encoder_embedder output in front of conv1: fp32 accumulator rows + their storage-typed copy
+    t += align256((int64_t)B * c->in_frames * c->d_model * 4) + align256((int64_t)B * c->in_frames * c->d_model * es);
   t += align256(rows * c->d_model * 4);                    // h
   t += align256(rows * c->d_model * es);                   // n
   t += align256(rows * 2 * inner * es);                    // qk
@@ -88,6 +100,17 @@ __global__ __launch_bounds__(256) void rows_to_f32_kernel(const T* __restrict__ 
     *reinterpret_cast<float4*>(h + i) = make_float4(Elem<T>::to_f32(x[i]), Elem<T>::to_f32(x[i + 1]), Elem<T>::to_f32(x[i + 2]), Elem<T>::to_f32(x[i + 3]));
   } else {
     for (long j = i; j < n; ++j) h[j] = Elem<T>::to_f32(x[j]);
+  }
+}
+// storage-typed rows <- fp32 rows (arch 2: encoder_embedder's output becomes conv1's operand)
+template <typename T>
+__global__ __launch_bounds__(256) void f32_to_rows_kernel(const float* __restrict__ h, T* __restrict__ x, long n) {
+  const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i + 3 < n) {
+    const float4 v = *reinterpret_cast<const float4*>(h + i);
+    x[i] = Elem<T>::from_f32(v.x); x[i + 1] = Elem<T>::from_f32(v.y); x[i + 2] = Elem<T>::from_f32(v.z); x[i + 3] = Elem<T>::from_f32(v.w);
+  } else {
+    for (long j = i; j < n; ++j) x[j] = Elem<T>::from_f32(h[j]);
   }
 }
 // rotate-half RoPE in place on the q | k block of a QKV GEMM output (apply_rotary_pos_emb,
@@ -167,13 +190,21 @@ extern "C" int mh_t5_encode_cond(const MhT5Config* c, const MhT5Weights* w, cons
   const int L = c->src_len, d = c->d_model, H = c->n_heads, inner = H * 64, dff = c->d_ff;
   const int rows = B * L, es = es_of(c->dtype), Lpad = round_up(L, 64);
   Arena ar(workspace, workspace_bytes);
-  if (c->arch == 1) {
-    // ---- VarWhisperEncoder.forward (modeling_varwhisper.py:779-852) --------------------------------------------------
-    MH_REQUIRE(!row_bias, "mh_t5_encode: the Whisper-family configs carry no conditioning embedders");
-    MH_REQUIRE(w->conv1_w && w->conv1_b && w->conv2_w && w->conv2_b && w->enc_rope, "mh_t5_encode: arch 1 needs the conv front-end weights and the rotary table");
-    const int64_t fe_bytes = mh_whisper_frontend_workspace_bytes(B, c->in_frames, c->n_mels_pad, d, c->dtype);
+  if (c->arch >= 1) {
+    // ---- VarWhisperEncoder.forward (modeling_varwhisper.py:779-852) / RoPEWhisperEncoder.forward (modeling_ropewhisper.py:
+    // 1167-1278); arch 2: HF WhisperEncoder.forward behind the wrapper's encoder_embedder ---------------------------------
+    const bool hf = c->arch == 2;
+    MH_REQUIRE(hf || !row_bias, "mh_t5_encode: arch 1 takes its conditioning as conv1 input channels (mh_cond_channels), not as a row bias");
+    MH_REQUIRE(w->conv1_w && w->conv1_b && w->conv2_w && w->conv2_b, "mh_t5_encode: arch 1 / 2 need the conv front-end weights");
+    MH_REQUIRE(hf || w->enc_rope, "mh_t5_encode: arch 1 needs the rotary table");
+    MH_REQUIRE(!hf || (w->enc_embed_w && w->enc_pos && w->enc_final_ln_b), "mh_t5_encode: arch 2 needs encoder_embedder, embed_positions and the LayerNorm biases");
+    const int fe_C = hf ? d : c->n_mels_pad;
+    const int64_t fe_bytes = mh_whisper_frontend_workspace_bytes(B, c->in_frames, fe_C, d, c->dtype);
     void* fe_ws = ar.take(fe_bytes);
     void* x0 = ar.take((int64_t)rows * d * es);
+    const int64_t rows_in = (int64_t)B * c->in_frames;
+    float* hin = hf ? (float*)ar.take(rows_in * d * 4) : nullptr;
+    void* xin = hf ? ar.take(rows_in * d * es) : nullptr;
     float* h = (float*)ar.take((int64_t)rows * d * 4);
     void* n = ar.take((int64_t)rows * d * es);
     void* qk = ar.take((int64_t)rows * 2 * inner * es);
@@ -181,7 +212,27 @@ extern "C" int mh_t5_encode_cond(const MhT5Config* c, const MhT5Weights* w, cons
     void* attn = ar.take((int64_t)rows * inner * es);
     void* ff = ar.take((int64_t)rows * dff * es);
     MH_REQUIRE(ar.ok() && ff, "mh_t5_encode: arena overflow");
-    MH_TRY(mh_whisper_frontend(mel, B, c->in_frames, c->n_mels_pad, w->conv1_w, w->conv1_b, w->conv2_w, w->conv2_b, nullptr, d, x0,
+    const void* fe_in = mel;
+    if (hf) {
+      // input_features = encoder_embedder([mel | cond]) (modeling_mapperatorinator.py:204-205,211): the T5 path's projection
+      // (row_bias = the conditioning columns' contribution incl. the bias), rounded to the storage type = conv1's operand
+      MH_REQUIRE(xin != nullptr, "mh_t5_encode: arena overflow");
+      MhGemm ge = MhGemm{};
+      ge.A = mel; ge.lda = c->n_mels_pad; ge.W = w->enc_embed_w; ge.ldw = c->n_mels_pad; ge.C = hin; ge.ldc = d;
+      ge.M = (int)rows_in; ge.N = d; ge.K = c->n_mels_pad; ge.bias = w->enc_embed_b; ge.dtype = c->dtype; ge.epilogue = MH_EPI_STORE_F32;
+      if (row_bias) {
+        hipLaunchKernelGGL(mh::fill_rows_kernel, dim3((unsigned)rows_in), dim3(256), 0, s, hin, row_bias, c->in_frames, d);
+        MH_TRY(check_launch("fill_rows_kernel"));
+        ge.bias = nullptr; ge.epilogue = MH_EPI_RESID;
+      }
+      MH_TRY(gemm(ge, s));
+      const long n_in = (long)rows_in * d;
+      if (c->dtype == MH_BF16) hipLaunchKernelGGL(mh::f32_to_rows_kernel<bf16_t>, dim3((unsigned)((n_in / 4 + 255) / 256 + 1)), dim3(256), 0, s, hin, (bf16_t*)xin, n_in);
+      else hipLaunchKernelGGL(mh::f32_to_rows_kernel<float>, dim3((unsigned)((n_in / 4 + 255) / 256 + 1)), dim3(256), 0, s, hin, (float*)xin, n_in);
+      MH_TRY(check_launch("f32_to_rows_kernel"));
+      fe_in = xin;
+    }
+    MH_TRY(mh_whisper_frontend(fe_in, B, c->in_frames, fe_C, w->conv1_w, w->conv1_b, w->conv2_w, w->conv2_b, hf ? w->enc_pos : nullptr, d, x0,
                                fe_ws, fe_bytes, c->dtype, stream));
     const long nel = (long)rows * d;
     if (c->dtype == MH_BF16) hipLaunchKernelGGL(mh::rows_to_f32_kernel<bf16_t>, dim3((unsigned)((nel / 4 + 255) / 256 + 1)), dim3(256), 0, s, (const bf16_t*)x0, h, nel);
@@ -191,23 +242,25 @@ extern "C" int mh_t5_encode_cond(const MhT5Config* c, const MhT5Weights* w, cons
     MhGemm g;
     for (int l = 0; l < c->n_enc_layers; ++l) {
       const bool local = is_local_layer(c, l);
-      MH_TRY(rmsnorm(h, d, w->enc_ln1[l], n, d, rows, d, c->eps, c->dtype, s));
+      MH_TRY(pre_norm(c, h, w->enc_ln1[l], w->enc_ln1_b[l], n, rows, c->dtype, s));
       g = MhGemm{};
       g.A = n; g.lda = d; g.W = w->enc_qkv[l]; g.ldw = d; g.C = qk; g.ldc = 2 * inner; g.M = rows; g.N = 3 * inner;
       g.K = d; g.bias = w->enc_qkv_b[l]; g.dtype = c->dtype; g.epilogue = MH_EPI_QKV_VT; g.C2 = vt; g.n_split = 2 * inner;
       g.kv_B = B; g.kv_H = H; g.kv_L = L; g.kv_Lpad = Lpad;
       MH_TRY(gemm(g, s));
-      const float* rope = (local && w->enc_rope_local) ? w->enc_rope_local : w->enc_rope;
-      const long work = (long)rows * 2 * H * 4;
-      if (c->dtype == MH_BF16) hipLaunchKernelGGL(mh::rope_qk_kernel<bf16_t>, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, (bf16_t*)qk, 2 * inner, (long)rows, L, 2 * H, rope);
-      else hipLaunchKernelGGL(mh::rope_qk_kernel<float>, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, (float*)qk, 2 * inner, (long)rows, L, 2 * H, rope);
-      MH_TRY(check_launch("rope_qk_kernel"));
+      if (!hf) {   // (HF Whisper: absolute positions were added by the front-end, no rotation)
+        const float* rope = (local && w->enc_rope_local) ? w->enc_rope_local : w->enc_rope;
+        const long work = (long)rows * 2 * H * 4;
+        if (c->dtype == MH_BF16) hipLaunchKernelGGL(mh::rope_qk_kernel<bf16_t>, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, (bf16_t*)qk, 2 * inner, (long)rows, L, 2 * H, rope);
+        else hipLaunchKernelGGL(mh::rope_qk_kernel<float>, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, (float*)qk, 2 * inner, (long)rows, L, 2 * H, rope);
+        MH_TRY(check_launch("rope_qk_kernel"));
+      }
       MH_TRY(attention(qk, 2 * inner, inner, vt, Lpad, nullptr, attn, inner, B, L, H, c->attn_scale, local ? -c->local_window : 0, c->dtype, s));
       g = MhGemm{};
       g.A = attn; g.lda = inner; g.W = w->enc_o[l]; g.ldw = inner; g.C = h; g.ldc = d; g.M = rows; g.N = d; g.K = inner;
       g.bias = w->enc_o_b[l]; g.dtype = c->dtype; g.epilogue = MH_EPI_RESID;
       MH_TRY(gemm(g, s));
-      MH_TRY(rmsnorm(h, d, w->enc_ln2[l], n, d, rows, d, c->eps, c->dtype, s));
+      MH_TRY(pre_norm(c, h, w->enc_ln2[l], w->enc_ln2_b[l], n, rows, c->dtype, s));
       MH_REQUIRE(w->enc_fc1_b[l] && w->enc_fc2_b[l], "mh_t5_encode: fc1 / fc2 carry biases in the Whisper family");
       g = MhGemm{};
       g.A = n; g.lda = d; g.W = w->enc_wi[l]; g.ldw = d; g.C = ff; g.ldc = dff; g.M = rows; g.N = dff; g.K = d;
@@ -218,8 +271,8 @@ extern "C" int mh_t5_encode_cond(const MhT5Config* c, const MhT5Weights* w, cons
       g.bias = w->enc_fc2_b[l]; g.dtype = c->dtype; g.epilogue = MH_EPI_RESID;
       MH_TRY(gemm(g, s));
     }
-    MH_TRY(rmsnorm(h, d, w->enc_final_ln, enc_out, d, rows, d, c->eps, c->dtype, s));
-    if (enc_out_f32) MH_TRY(rmsnorm(h, d, w->enc_final_ln, enc_out_f32, d, rows, d, c->eps, MH_F32, s));
+    MH_TRY(pre_norm(c, h, w->enc_final_ln, w->enc_final_ln_b, enc_out, rows, c->dtype, s));
+    if (enc_out_f32) MH_TRY(pre_norm(c, h, w->enc_final_ln, w->enc_final_ln_b, enc_out_f32, rows, MH_F32, s));
     return MH_OK;
   }
   float* h = (float*)ar.take((int64_t)rows * d * 4);
@@ -343,7 +396,7 @@ extern "C" int mh_t5_cross_kv(const MhT5Config* c, const MhT5Weights* w, const v
   MhGemm g = MhGemm{};
   g.A = enc_out; g.lda = c->d_model; g.W = w->dec_ckv_all; g.ldw = c->d_model; g.C = cross_kv; g.ldc = 0;
   g.M = B * c->src_len; g.N = c->n_dec_layers * 2 * inner; g.K = c->d_model; g.dtype = c->dtype;
-  g.bias = c->arch == 1 ? w->dec_ckv_b_all : nullptr;
+  g.bias = c->arch >= 1 ? w->dec_ckv_b_all : nullptr;
   g.epilogue = MH_EPI_KV_SCATTER; g.kv_B = B; g.kv_H = c->n_heads; g.kv_L = c->src_len;
   return gemm(g, (hipStream_t)stream);
 }
@@ -374,6 +427,9 @@ struct SampleP {
   float* proc;                        // [R][V] processed scores of this step (read back by the sampling passes)
   float* hist_scores;                 // [2][R][V] scores entering LookbackBias at this / the previous step
   const void* dec_embed; float* h; int d;
+  // arch 2 (HF Whisper): decoder.embed_positions fp32 [tgt_len][d] added to the token embedding (NULL otherwise); pos_off [B] =
+  // masked prompt columns of each row when MhT5Config.dec_pos_from_mask (written by dec_init_kernel), NULL = cache positions
+  const float* dec_pos; int32_t* pos_off; const uint8_t* prompt_mask;
   MhSampling sp;
   DecState* st;
   int B, P;                           // B = rows of the WHOLE batch
@@ -390,6 +446,12 @@ __device__ inline int32_t next_ts_state(const MhSampling& sp, int tok, int32_t c
   for (int i = 0; i < sp.n_sos; ++i)
     if (tok == sp.sos_ids[i]) return -1;
   return cur;
+}
+
+// row of decoder.embed_positions for column `col` of global row b (arch 2)
+__device__ inline int dec_pos_row(const SampleP& p, int b, int col) {
+  const int off = p.pos_off ? p.pos_off[b] : 0;
+  return col - off > 0 ? col - off : 0;
 }
 
 // input_ids[row][i] as the reference's processors see it: the prompt, then the ids that were FED (the forced ids
@@ -420,9 +482,21 @@ __global__ __launch_bounds__(256) void dec_init_kernel(SampleP p, int chain_rows
     p.finish_col[b] = p.max_length - 1;
     if (lb == 0) { p.st->pos = start_pos; p.st->n_running = chain_rows; p.st->ticket = 0; p.st->rng_row0 = p.sp.rng_row0; p.st->seed = p.sp.seed; }
   }
+  __shared__ int s_off;
+  if (threadIdx.x == 0) {
+    int off = 0;
+    if (p.pos_off) {   // transformers 4.57's Whisper decoder_position_ids = cumsum(mask) - 1, clamped at 0: a left-padded row counts from its first real token
+      if (p.prompt_mask)
+        for (int i = 0; i < p.P; ++i) off += p.prompt_mask[(long)b * p.P + i] == 0;
+      p.pos_off[b] = off;
+    }
+    s_off = off;
+  }
+  __syncthreads();
   const int tok = p.tokens[(long)b * p.max_length + start_pos];
   const T* e = reinterpret_cast<const T*>(p.dec_embed) + (long)tok * p.d;
-  for (int i = threadIdx.x; i < p.d; i += 256) p.h[(long)lb * p.d + i] = Elem<T>::to_f32(e[i]);
+  const float* pe = p.dec_pos ? p.dec_pos + (long)(start_pos - s_off > 0 ? start_pos - s_off : 0) * p.d : nullptr;
+  for (int i = threadIdx.x; i < p.d; i += 256) p.h[(long)lb * p.d + i] = Elem<T>::to_f32(e[i]) + (pe ? pe[i] : 0.f);
 }
 
 constexpr int kSampleRegs = 16;   // the register sampling path holds up to 16 ids per thread: vocabularies of <= 4096 ids
@@ -794,10 +868,11 @@ __global__ __launch_bounds__(256) void dec_sample_kernel(SampleP p) {
   for (int j = 0; j < nrow; ++j) {
     const int lrow = j == 0 ? lb : lneg;
     const T* e = reinterpret_cast<const T*>(p.dec_embed) + (long)nxt[j] * p.d;
+    const float* pe = p.dec_pos ? p.dec_pos + (long)dec_pos_row(p, j == 0 ? b : bneg, col) * p.d : nullptr;   // (arch 2: + embed_positions[col])
     for (int i = tid * 4; i < p.d; i += 1024) {   // 16-byte write-through pieces (d is a multiple of 4)
       float v4[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) v4[k] = Elem<T>::to_f32(e[i + k]);
+      for (int k = 0; k < 4; ++k) v4[k] = Elem<T>::to_f32(e[i + k]) + (pe ? pe[i + k] : 0.f);
       dec::store_piece_wt<float>(p.h + (long)lrow * p.d + i, v4, 4, 4);
     }
   }
@@ -856,14 +931,15 @@ int launch_skinny(dec::SkinnyP p, hipStream_t s) {
   MH_REQUIRE(PRO != dec::PRO_PLAIN || nkb % 2 == 0, "decode: K=%d must be a multiple of %d", p.K, 2 * kb);
   // waves per workgroup: a function of K ONLY (batch invariance of the summation order)
   const bool wide = nkb > 4 * dec::kGemvCH;
-  MH_REQUIRE(PRO != dec::PRO_RMSNORM || nkb <= 8 * dec::kGemvCH, "decode: RMSNorm prologue needs K <= %d", 8 * dec::kGemvCH * kb);
+  MH_REQUIRE(PRO == dec::PRO_PLAIN || nkb <= 8 * dec::kGemvCH, "decode: the norm prologue needs K <= %d", 8 * dec::kGemvCH * kb);
+  MH_REQUIRE(PRO != dec::PRO_LAYERNORM || p.ln_b, "decode: LayerNorm prologue without its bias");
   MH_REQUIRE(p.lda == p.K && p.ldw == p.K, "decode: the GEMV operands must be dense (lda = ldw = K)");
   MH_REQUIRE(EPI != dec::SK_RESID || (p.N % 4 == 0 && p.ldh == p.N), "decode: residual GEMV needs a dense [B, N] residual stream, N a multiple of 4");
   int tiles;
   if (EPI == dec::SK_GEGLU) { p.nv = 8; tiles = ceil_div(p.N / 2, 8); }
   else { p.nv = gemv_cols(p.N); tiles = ceil_div(p.N, p.nv); }
   if (wide) {
-    if constexpr (PRO == dec::PRO_RMSNORM && sizeof(T) == 2) {   // d_model > 1024 in bf16: not a shape of this model family
+    if constexpr (PRO != dec::PRO_PLAIN && sizeof(T) == 2) {   // d_model > 1024 in bf16: not a shape of this model family
       set_error("decode: RMSNorm GEMV needs d_model <= 1024 in bf16 storage");
       return MH_ERR_ARG;
     } else {
@@ -913,7 +989,9 @@ bool fused_proj_enabled(int d) { return option(OPT_DECODE_FUSED_PROJ) != 0 && d 
 template <typename T, int KC>
 int launch_self_qkv(const dec::SelfAttnP& sa, const dec::HeadProjP& hp, int inner, hipStream_t s) {
   MH_REQUIRE(hp.ldh == hp.d && hp.ldw == hp.d && inner == sa.H * 64, "decode: dense residual rows / projection weights expected");
-  if (sa.rope)   // the Whisper family: biased fused Wqkv, RoPE, scaled scores, optional window
+  if (sa.rope && hp.ln_b)   // HF Whisper (arch 2): the same behind an affine LayerNorm, identity rotary table
+    hipLaunchKernelGGL((dec::dec_self_attn_qkv_kernel<T, KC, true, true>), dim3(sa.B * sa.H), dim3(1024), 0, s, MH_SELF_LEAD_ARGS, sa, hp);
+  else if (sa.rope)   // the Whisper family: biased fused Wqkv, RoPE, scaled scores, optional window
     hipLaunchKernelGGL((dec::dec_self_attn_qkv_kernel<T, KC, true>), dim3(sa.B * sa.H), dim3(1024), 0, s, MH_SELF_LEAD_ARGS, sa, hp);
   else
     hipLaunchKernelGGL((dec::dec_self_attn_qkv_kernel<T, KC>), dim3(sa.B * sa.H), dim3(1024), 0, s, MH_SELF_LEAD_ARGS, sa, hp);
@@ -942,7 +1020,8 @@ int launch_cross_q(const dec::CrossAttnP& ca, const dec::HeadProjP& hp, hipStrea
   // same bandwidth in the stand-alone kernel
   if (ca.scale != 0.f) {   // the Whisper family: biased Wq, scaled scores
     MH_REQUIRE(ca.kscale == nullptr, "decode: the fp8 cross K/V copy is not wired for the Whisper family");
-    hipLaunchKernelGGL((dec::dec_cross_attn_q_kernel<T, KC, MH_CROSS_U, false, true>), dim3(ca.B * ca.H), dim3(1024), 0, s, MH_CROSS_LEAD_ARGS, ca, hp);
+    if (hp.ln_b) hipLaunchKernelGGL((dec::dec_cross_attn_q_kernel<T, KC, MH_CROSS_U, false, true, true>), dim3(ca.B * ca.H), dim3(1024), 0, s, MH_CROSS_LEAD_ARGS, ca, hp);
+    else hipLaunchKernelGGL((dec::dec_cross_attn_q_kernel<T, KC, MH_CROSS_U, false, true>), dim3(ca.B * ca.H), dim3(1024), 0, s, MH_CROSS_LEAD_ARGS, ca, hp);
   } else if (ca.kscale != nullptr) {
     if constexpr (sizeof(T) == 2)
       hipLaunchKernelGGL((dec::dec_cross_attn_q_kernel<T, KC, MH_CROSS_U, true>), dim3(ca.B * ca.H), dim3(1024), 0, s, MH_CROSS_LEAD_ARGS, ca, hp);
@@ -983,7 +1062,7 @@ int enqueue_step(const MhT5Config* c, const MhT5Weights* w, const void* cross_kv
   const int d = c->d_model, H = c->n_heads, inner = H * 64, dff = c->d_ff, L = c->src_len, tgt = c->tgt_len;
   const int es = (int)sizeof(T);
   const int* posp = &bf.st->pos;
-  const bool wh = c->arch == 1;
+  const bool wh = c->arch >= 1, hf = c->arch == 2;   // (arch 2: affine LayerNorm prologues, the identity rotary table the host packs)
   if (wh) MH_REQUIRE(fused_proj_enabled(d) && option(OPT_DECODE_FUSED_PROJ) == 1 && w->dec_rope,
                      "decode: the Whisper family runs on the fused attention kernels (d_model a multiple of 128 <= 1024) and needs its rotary table");
   for (int l = 0; l < c->n_dec_layers; ++l) {
@@ -999,6 +1078,8 @@ int enqueue_step(const MhT5Config* c, const MhT5Weights* w, const void* cross_kv
       sa.scale = c->attn_scale; sa.window = local ? c->local_window : 0;
       dec::HeadProjP hp{};
       hp.h = bf.h; hp.ldh = d; hp.ln_w = w->dec_ln1[l]; hp.eps = c->eps; hp.W = w->dec_qkv[l]; hp.ldw = d; hp.d = d;
+      hp.ln_b = hf ? w->dec_ln1_b[l] : nullptr;
+      MH_REQUIRE(!hf || (w->dec_ln1_b[l] && w->dec_ln2_b[l] && w->dec_ln3_b[l]), "decode: arch 2 needs the LayerNorm biases of layer %d", l);
       MH_TRY(launch_self_qkv_d<T>(sa, hp, inner, s));
       sk = dec::SkinnyP{};
       sk.A = bf.attn; sk.lda = inner; sk.W = w->dec_o[l]; sk.ldw = inner; sk.B = B; sk.N = d; sk.K = inner; sk.h = bf.h; sk.ldh = d;
@@ -1016,6 +1097,7 @@ int enqueue_step(const MhT5Config* c, const MhT5Weights* w, const void* cross_kv
       }
       hp = dec::HeadProjP{};
       hp.h = bf.h; hp.ldh = d; hp.ln_w = w->dec_ln2[l]; hp.eps = c->eps; hp.W = w->dec_cq[l]; hp.ldw = d; hp.d = d;
+      hp.ln_b = hf ? w->dec_ln2_b[l] : nullptr;
       MH_TRY(launch_cross_q_d<T>(ca, hp, s));
       sk = dec::SkinnyP{};
       sk.A = bf.attn; sk.lda = inner; sk.W = w->dec_co[l]; sk.ldw = inner; sk.B = B; sk.N = d; sk.K = inner; sk.h = bf.h; sk.ldh = d;
@@ -1024,7 +1106,8 @@ int enqueue_step(const MhT5Config* c, const MhT5Weights* w, const void* cross_kv
       sk = dec::SkinnyP{};
       sk.A = bf.h; sk.lda = d; sk.ln_w = w->dec_ln3[l]; sk.eps = c->eps; sk.W = w->dec_wi[l]; sk.ldw = d; sk.B = B;
       sk.N = dff; sk.K = d; sk.out = bf.ff; sk.ldo = dff; sk.bias = w->dec_fc1_b[l];
-      MH_TRY((skinny<T, dec::PRO_RMSNORM, dec::SK_GELU_ERF, true>(sk, s)));
+      if (hf) { sk.ln_b = w->dec_ln3_b[l]; MH_TRY((skinny<T, dec::PRO_LAYERNORM, dec::SK_GELU_ERF, true>(sk, s))); }
+      else MH_TRY((skinny<T, dec::PRO_RMSNORM, dec::SK_GELU_ERF, true>(sk, s)));
       sk = dec::SkinnyP{};
       sk.A = bf.ff; sk.lda = dff; sk.W = w->dec_wo[l]; sk.ldw = dff; sk.B = B; sk.N = d; sk.K = dff; sk.h = bf.h; sk.ldh = d;
       sk.bias = w->dec_fc2_b[l];
@@ -1099,7 +1182,8 @@ int enqueue_step(const MhT5Config* c, const MhT5Weights* w, const void* cross_kv
   dec::SkinnyP sk{};
   sk.A = bf.h; sk.lda = d; sk.ln_w = w->dec_final_ln; sk.eps = c->eps; sk.W = w->lm_head; sk.ldw = d; sk.B = B;
   sk.N = c->vocab_out; sk.K = d; sk.out = bf.logits; sk.ldo = c->vocab_out;
-  MH_TRY((skinny<T, dec::PRO_RMSNORM, dec::SK_LOGITS>(sk, s)));
+  if (hf) { sk.ln_b = w->dec_final_ln_b; MH_TRY((skinny<T, dec::PRO_LAYERNORM, dec::SK_LOGITS>(sk, s))); }
+  else MH_TRY((skinny<T, dec::PRO_RMSNORM, dec::SK_LOGITS>(sk, s)));
   if (!with_sampler) return MH_OK;
   hipLaunchKernelGGL(dec_sample_kernel<T>, dim3(smp.pair > 0 ? smp.pair : B), dim3(256), 0, s, smp);
   return check_launch("dec_sample_kernel");
@@ -1108,11 +1192,23 @@ int enqueue_step(const MhT5Config* c, const MhT5Weights* w, const void* cross_kv
 // ---- step-wise decode (beam search) ----------------------------------------------------------------------------------
 // h[b][:] = dec_embed[ids[b]] and the position word of the step
 template <typename T>
-__global__ __launch_bounds__(256) void step_embed_kernel(const int32_t* ids, const T* emb, int d, float* h, DecState* st, int pos) {
+__global__ __launch_bounds__(256) void step_embed_kernel(const int32_t* ids, const T* emb, int d, float* h, DecState* st, int pos,
+                                                        const float* dec_pos, const uint8_t* prompt_mask, int P) {
+  // dec_pos (arch 2): + decoder.embed_positions[position]; prompt_mask != NULL here means dec_pos_from_mask: the position is the
+  // column minus this row's masked prompt columns
   const int b = blockIdx.x;
   if (b == 0 && threadIdx.x == 0) { st->pos = pos; st->n_running = 0; st->ticket = 0; }
+  __shared__ int s_off;
+  if (threadIdx.x == 0) {
+    int off = 0;
+    if (dec_pos && prompt_mask)
+      for (int i = 0; i < P; ++i) off += prompt_mask[(long)b * P + i] == 0;
+    s_off = off;
+  }
+  __syncthreads();
   const T* e = emb + (long)ids[b] * d;
-  for (int i = threadIdx.x; i < d; i += 256) h[(long)b * d + i] = Elem<T>::to_f32(e[i]);
+  const float* pe = dec_pos ? dec_pos + (long)(pos - s_off > 0 ? pos - s_off : 0) * d : nullptr;
+  for (int i = threadIdx.x; i < d; i += 256) h[(long)b * d + i] = Elem<T>::to_f32(e[i]) + (pe ? pe[i] : 0.f);
 }
 // cache rows [l][b][h][0 .. n_pos) <- [l][src[b]][h][..]: gather into `tmp`, then copy back (in place would read rows that
 // were already overwritten); one workgroup per (k|v, layer, row, head)
@@ -1160,7 +1256,7 @@ extern "C" int64_t mh_t5_decode_workspace_bytes(const MhT5Config* c, int B) {
   t += align256((int64_t)B * c->d_ff * es);                                       // ff
   t += align256((int64_t)B * c->vocab_out * 4);                                   // logits
   t += align256((int64_t)c->n_dec_layers * B * inner * c->tgt_len * es) * 2;      // self K, V caches
-  t += align256(B) + align256((int64_t)B * 4) * 2 + align256(sizeof(DecState)) * kMaxChains;   // flags / state
+  t += align256(B) + align256((int64_t)B * 4) * 3 + align256(sizeof(DecState)) * kMaxChains;   // flags / state (+ pos_off)
   t += align256((int64_t)B * c->vocab_out * 4) * 3;                               // processed scores + LookbackBias history
   t += prefill_layout(c, B, c->tgt_len - 1, nullptr, 0, nullptr);                  // batched prompt prefill
   return t;
@@ -1172,10 +1268,21 @@ namespace {
 // rows r = b*np + i  <-  dec_embed[prompt[b][i]]   (fp32 residual stream of the prompt prefill)
 template <typename T>
 __global__ __launch_bounds__(256) void prefill_embed_kernel(const int32_t* __restrict__ prompt, int P, int np,
-                                                           const T* __restrict__ emb, int d, float* __restrict__ h) {
+                                                           const T* __restrict__ emb, int d, float* __restrict__ h,
+                                                           const float* __restrict__ dec_pos, const uint8_t* __restrict__ pos_mask) {
+  // dec_pos (arch 2): + decoder.embed_positions[position of column i]; pos_mask != NULL (dec_pos_from_mask): minus the row's masked columns
   const int r = blockIdx.x, b = r / np, i = r - b * np;
+  __shared__ int s_off;
+  if (threadIdx.x == 0) {
+    int off = 0;
+    if (dec_pos && pos_mask)
+      for (int k = 0; k < P; ++k) off += pos_mask[(long)b * P + k] == 0;
+    s_off = off;
+  }
+  __syncthreads();
   const T* e = emb + (long)prompt[(long)b * P + i] * d;
-  for (int k = threadIdx.x; k < d; k += 256) h[(long)r * d + k] = Elem<T>::to_f32(e[k]);
+  const float* pe = dec_pos ? dec_pos + (long)(i - s_off > 0 ? i - s_off : 0) * d : nullptr;
+  for (int k = threadIdx.x; k < d; k += 256) h[(long)r * d + k] = Elem<T>::to_f32(e[k]) + (pe ? pe[k] : 0.f);
 }
 
 struct PrefillBuf {
@@ -1215,12 +1322,16 @@ int prefill_prompt(const MhT5Config* c, const MhT5Weights* w, const void* cross_
   // rotate-half RoPE on q and on the cached keys, scores / 8 without a relative bias, fc1 -> gelu(erf) -> fc2.  A local
   // (windowed) layer takes its own rotary table and the causal attention gets the band |k - q| <= local_window on top -- the
   // keys the token-by-token step attends (decode_kernels.hpp `window`).
-  const bool wh = c->arch == 1;
-  if (wh) MH_REQUIRE(w->dec_rope != nullptr, "prefill: the Whisper family needs its rotary table");
+  // arch 2 (HF WhisperDecoderLayer): the same with affine LayerNorms, absolute positions added to the embedding, no rotation
+  const bool wh = c->arch >= 1, hf = c->arch == 2;
+  if (wh && !hf) MH_REQUIRE(w->dec_rope != nullptr, "prefill: the Whisper family needs its rotary table");
+  if (hf) MH_REQUIRE(w->dec_pos && w->dec_final_ln_b, "prefill: arch 2 needs decoder.embed_positions and the LayerNorm biases");
+  const float* dpos = hf ? w->dec_pos : nullptr;
+  const uint8_t* pmask = (hf && c->dec_pos_from_mask) ? prompt_mask : nullptr;
   if (c->dtype == MH_BF16)
-    hipLaunchKernelGGL(prefill_embed_kernel<bf16_t>, dim3(rows), dim3(256), 0, s, prompt, P, np, (const bf16_t*)w->dec_embed, d, pb.h);
+    hipLaunchKernelGGL(prefill_embed_kernel<bf16_t>, dim3(rows), dim3(256), 0, s, prompt, P, np, (const bf16_t*)w->dec_embed, d, pb.h, dpos, pmask);
   else
-    hipLaunchKernelGGL(prefill_embed_kernel<float>, dim3(rows), dim3(256), 0, s, prompt, P, np, (const float*)w->dec_embed, d, pb.h);
+    hipLaunchKernelGGL(prefill_embed_kernel<float>, dim3(rows), dim3(256), 0, s, prompt, P, np, (const float*)w->dec_embed, d, pb.h, dpos, pmask);
   MH_TRY(check_launch("prefill_embed_kernel"));
   if (hipMemsetAsync(pb.vt, 0, (size_t)B * inner * np_pad * es, s) != hipSuccess) return check_launch("memset prefill vt");
   if (hipMemsetAsync(pb.cross_vt, 0, (size_t)c->n_dec_layers * kvB * inner * pb.Lpad * es, s) != hipSuccess)
@@ -1234,7 +1345,7 @@ int prefill_prompt(const MhT5Config* c, const MhT5Weights* w, const void* cross_
     char* kc = (char*)self_k + (long)l * B * H * tgt * 64 * es;
     char* vc = (char*)self_v + (long)l * B * H * tgt * 64 * es;
     // self attention over the prompt
-    MH_TRY(rmsnorm(pb.h, d, w->dec_ln1[l], pb.n, d, rows, d, c->eps, c->dtype, s));
+    MH_TRY(pre_norm(c, pb.h, w->dec_ln1[l], w->dec_ln1_b[l], pb.n, rows, c->dtype, s));
     g = MhGemm{};
     g.A = pb.n; g.lda = d; g.W = w->dec_qkv[l]; g.ldw = d; g.C = pb.q; g.ldc = inner; g.M = rows; g.N = 3 * inner; g.K = d;
     g.dtype = c->dtype; g.epilogue = MH_EPI_QKV_CACHE; g.n_split = inner; g.C2 = kc; g.C3 = vc; g.C4 = pb.vt; g.kv_B = B;
@@ -1242,7 +1353,7 @@ int prefill_prompt(const MhT5Config* c, const MhT5Weights* w, const void* cross_
     if (wh) g.bias = w->dec_qkv_b[l];
     MH_TRY(gemm(g, s));
     const bool local = is_local_layer(c, l);
-    if (wh) {   // rotate-half RoPE on q (all prompt positions) and on the keys just cached; position = column of the padded prompt
+    if (wh && !hf) {   // rotate-half RoPE on q (all prompt positions) and on the keys just cached; position = column of the padded prompt
       const long wq = (long)rows * H * 4, wk = (long)B * H * np * 4;
       const float* rope = (local && w->dec_rope_local) ? w->dec_rope_local : w->dec_rope;
       if (c->dtype == MH_BF16) {
@@ -1269,7 +1380,7 @@ int prefill_prompt(const MhT5Config* c, const MhT5Weights* w, const void* cross_
     if (wh) g.bias = w->dec_o_b[l];
     MH_TRY(gemm(g, s));
     // cross attention of every prompt position over the encoder keys
-    MH_TRY(rmsnorm(pb.h, d, w->dec_ln2[l], pb.n, d, rows, d, c->eps, c->dtype, s));
+    MH_TRY(pre_norm(c, pb.h, w->dec_ln2[l], w->dec_ln2_b[l], pb.n, rows, c->dtype, s));
     g = MhGemm{};
     g.A = pb.n; g.lda = d; g.W = w->dec_cq[l]; g.ldw = d; g.C = pb.q; g.ldc = inner; g.M = rows; g.N = inner; g.K = d;
     g.dtype = c->dtype; g.epilogue = MH_EPI_STORE;
@@ -1292,7 +1403,7 @@ int prefill_prompt(const MhT5Config* c, const MhT5Weights* w, const void* cross_
     if (wh) g.bias = w->dec_co_b[l];
     MH_TRY(gemm(g, s));
     // feed forward
-    MH_TRY(rmsnorm(pb.h, d, w->dec_ln3[l], pb.n, d, rows, d, c->eps, c->dtype, s));
+    MH_TRY(pre_norm(c, pb.h, w->dec_ln3[l], w->dec_ln3_b[l], pb.n, rows, c->dtype, s));
     g = MhGemm{};
     g.A = pb.n; g.lda = d; g.W = w->dec_wi[l]; g.ldw = d; g.C = pb.ff; g.ldc = dff; g.M = rows; g.K = d;
     g.dtype = c->dtype;
@@ -1508,6 +1619,7 @@ extern "C" int mh_t5_generate(const MhT5Config* c, const MhT5Weights* w, const v
   const int kvB = cfg ? B / 2 : B;
   MH_REQUIRE(!sp->cross_kv_fp8 || c->dtype == MH_BF16, "mh_t5_generate: cross_kv_fp8 needs bf16 storage");
   MH_REQUIRE(workspace_bytes >= mh_t5_decode_workspace_bytes(c, B), "mh_t5_generate: workspace too small");
+  MH_REQUIRE(c->arch != 2 || (w->dec_pos && w->dec_final_ln_b), "mh_t5_generate: arch 2 needs decoder.embed_positions and the LayerNorm biases");
   hipStream_t s = (hipStream_t)stream;
   const int es = es_of(c->dtype), H = c->n_heads, inner = H * 64, d = c->d_model, V = c->vocab_out;
 
@@ -1523,6 +1635,7 @@ extern "C" int mh_t5_generate(const MhT5Config* c, const MhT5Weights* w, const v
   all.finished = (uint8_t*)ar.take(B);
   all.finish_col = (int32_t*)ar.take((int64_t)B * 4);
   all.last_ts = (int32_t*)ar.take((int64_t)B * 4);
+  int32_t* pos_off = (int32_t*)ar.take((int64_t)B * 4);
   DecState* st_all = (DecState*)ar.take((int64_t)align256(sizeof(DecState)) * kMaxChains);
   float* proc = (float*)ar.take((int64_t)B * V * 4);
   float* hist_scores = (float*)ar.take((int64_t)B * V * 4 * 2);
@@ -1596,6 +1709,11 @@ extern "C" int mh_t5_generate(const MhT5Config* c, const MhT5Weights* w, const v
     smp.last_ts_val = all.last_ts; smp.logits_dump = logits_dump; smp.dec_embed = w->dec_embed; smp.h = bf.h;
     smp.d = d; smp.sp = *sp; smp.st = bf.st; smp.B = B; smp.P = P; smp.b0 = b0;
     smp.proc = proc; smp.hist_scores = hist_scores; smp.pair = cfg ? B / 2 : 0; smp.chain_rows = Bc;
+    if (c->arch == 2) {
+      smp.dec_pos = w->dec_pos;
+      smp.pos_off = c->dec_pos_from_mask ? pos_off : nullptr;
+      smp.prompt_mask = prompt_mask;
+    }
 
     if (bf16) hipLaunchKernelGGL(dec_init_kernel<bf16_t>, dim3(Bc), dim3(256), 0, cs, smp, Bc, start_pos);
     else hipLaunchKernelGGL(dec_init_kernel<float>, dim3(Bc), dim3(256), 0, cs, smp, Bc, start_pos);
@@ -1761,7 +1879,7 @@ extern "C" int mh_t5_decoder_forward(const MhT5Config* c, const MhT5Weights* w, 
   prefill_layout(c, B, T, self_v + cache, workspace_bytes - 2 * cache, &pb);
   MH_TRY(prefill_prompt(c, w, cross_kv, B, B, ids, mask, T, T, self_k, self_v, pb, s));
   const int rows = B * T, d = c->d_model;
-  MH_TRY(rmsnorm(pb.h, d, w->dec_final_ln, pb.n, d, rows, d, c->eps, c->dtype, s));
+  MH_TRY(pre_norm(c, pb.h, w->dec_final_ln, w->dec_final_ln_b, pb.n, rows, c->dtype, s));
   MhGemm g{};
   g.A = pb.n; g.lda = d; g.W = w->lm_head; g.ldw = d; g.C = logits; g.ldc = c->vocab_out; g.M = rows; g.N = c->vocab_out;
   g.K = d; g.dtype = c->dtype; g.epilogue = MH_EPI_STORE_F32;
@@ -1899,8 +2017,11 @@ extern "C" int mh_t5_step(const MhT5Config* c, const MhT5Weights* w, const void*
   bf.st = (DecState*)ar.take((int64_t)align256(sizeof(DecState)) * kMaxChains);
   bf.chain = 0;
   MH_REQUIRE(ar.ok(), "mh_t5_step: arena overflow");
-  if (c->dtype == MH_BF16) hipLaunchKernelGGL(step_embed_kernel<bf16_t>, dim3(B), dim3(256), 0, s, ids, (const bf16_t*)w->dec_embed, d, bf.h, bf.st, pos);
-  else hipLaunchKernelGGL(step_embed_kernel<float>, dim3(B), dim3(256), 0, s, ids, (const float*)w->dec_embed, d, bf.h, bf.st, pos);
+  MH_REQUIRE(c->arch != 2 || (w->dec_pos && w->dec_final_ln_b), "mh_t5_step: arch 2 needs decoder.embed_positions and the LayerNorm biases");
+  const float* dpos = c->arch == 2 ? w->dec_pos : nullptr;
+  const uint8_t* pmask = (c->arch == 2 && c->dec_pos_from_mask) ? prompt_mask : nullptr;
+  if (c->dtype == MH_BF16) hipLaunchKernelGGL(step_embed_kernel<bf16_t>, dim3(B), dim3(256), 0, s, ids, (const bf16_t*)w->dec_embed, d, bf.h, bf.st, pos, dpos, pmask, P);
+  else hipLaunchKernelGGL(step_embed_kernel<float>, dim3(B), dim3(256), 0, s, ids, (const float*)w->dec_embed, d, bf.h, bf.st, pos, dpos, pmask, P);
   MH_TRY(check_launch("step_embed_kernel"));
   SampleP smp{};
   const int kvB = B / kv_group;

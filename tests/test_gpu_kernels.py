@@ -287,6 +287,27 @@ def test_rmsnorm(dtype_name):
     assert torch.allclose(y.float().cpu(), ref, atol=tol, rtol=8e-3 if dt == L.MH_BF16 else 1e-5)
 
 
+@pytest.mark.parametrize("dtype_name", ["f32", "bf16"])
+def test_layernorm_affine(dtype_name):
+    """mh_layernorm (the pre-norm of HF Whisper's blocks, library arch 2) vs torch F.layer_norm in fp64, rows with a mean far above
+    their spread included (|mu| >> sigma: the two-pass arithmetic must hold)."""
+    L, lib = _lib()
+    dt = L.MH_F32 if dtype_name == "f32" else L.MH_BF16
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(41, 768, generator=g) * 3
+    x[5] = x[5] * 0.01 + 300.0
+    x[6] = x[6] * 1e-3 - 1000.0
+    w, b = 1 + 0.1 * torch.randn(768, generator=g), 0.1 * torch.randn(768, generator=g)
+    xd, wd, bd = x.cuda(), w.cuda(), b.cuda()
+    y = torch.empty((41, 768), dtype=torch.bfloat16 if dt == L.MH_BF16 else torch.float32, device="cuda")
+    L.check(lib.mh_layernorm(xd.data_ptr(), 768, wd.data_ptr(), bd.data_ptr(), y.data_ptr(), 768, 41, 768, 1e-5, dt, _stream()))
+    ref = torch.nn.functional.layer_norm(x.double(), (768,), w.double(), b.double(), 1e-5).float()
+    err = (y.float().cpu() - ref).abs()
+    # (row 6: sigma = 3e-3 at |mu| = 1000 -- fp32 spacing there is 6e-5, i.e. 2 % of sigma: the input itself is that coarse)
+    tol = 2e-2 if dt == L.MH_BF16 else 2e-5
+    assert err[:6].max().item() < tol and err[7:].max().item() < tol and err[6].max().item() < 5e-2, (err[:6].max(), err[6].max())
+
+
 def ref_attention(q, k, v, bias=None, scale=1.0, band=0):
     """q,k,v [B,H,L,64] fp64 reference of mh_attention."""
     s = torch.matmul(q.double(), k.double().transpose(-1, -2)) * scale
