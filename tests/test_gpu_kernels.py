@@ -303,9 +303,12 @@ def test_layernorm_affine(dtype_name):
     L.check(lib.mh_layernorm(xd.data_ptr(), 768, wd.data_ptr(), bd.data_ptr(), y.data_ptr(), 768, 41, 768, 1e-5, dt, _stream()))
     ref = torch.nn.functional.layer_norm(x.double(), (768,), w.double(), b.double(), 1e-5).float()
     err = (y.float().cpu() - ref).abs()
-    # (row 6: sigma = 3e-3 at |mu| = 1000 -- fp32 spacing there is 6e-5, i.e. 2 % of sigma: the input itself is that coarse)
+    # rows 5 / 6: sigma = 0.03 / 3e-3 at |mu| = 300 / 1000.  The fp32 MEAN of 768 such values is good to a few ulp of the sum
+    # (2.3e5 -> 0.016 / 768 = 2e-5), i.e. 1e-3 / 2e-2 of sigma: that is the floor of any fp32 two-pass LayerNorm (measured 3.5e-4 /
+    # 6e-3 here); a single-pass E[x^2] - mu^2 form would lose ALL digits on these rows
     tol = 2e-2 if dt == L.MH_BF16 else 2e-5
-    assert err[:6].max().item() < tol and err[7:].max().item() < tol and err[6].max().item() < 5e-2, (err[:6].max(), err[6].max())
+    assert err[:5].max().item() < tol and err[7:].max().item() < tol and err[5].max().item() < max(tol, 2e-3) and err[6].max().item() < 5e-2, \
+        (err[:5].max(), err[5].max(), err[6].max())
 
 
 def ref_attention(q, k, v, bias=None, scale=1.0, band=0):

@@ -22,7 +22,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 HBM_PEAK_GBS = 8000.0
 
 
-def build(model_name: str, tgt: int, device, dtype=torch.bfloat16):
+def build(model_name: str, tgt: int, device, dtype=torch.bfloat16, options=None):
     from mapperatorinator_amd import Tokenizer
     from mapperatorinator_amd.modeling import MapperatorinatorHIP
     from mapperatorinator_amd.t5_engine import T5_PRESETS
@@ -51,7 +51,7 @@ def build(model_name: str, tgt: int, device, dtype=torch.bfloat16):
                                                   gains={"decoder_embedder": 0.5})
         kw = dict(f_min=0 if fam == "whisper" else 20)
     model = MapperatorinatorHIP(sd, dims, vocab_size_in=tok.vocab_size_in, vocab_size_out=tok.vocab_size_out, n_mels=n_mels,
-                                src_seq_len=frames, tgt_seq_len=tgt, dtype=dtype, device=device, **kw)
+                                src_seq_len=frames, tgt_seq_len=tgt, dtype=dtype, device=device, options=options, **kw)
     return model, tok, dims, frames
 
 
@@ -66,11 +66,11 @@ def step_bytes(dims, n_rows: int, kv_rows: int, src_len: int, vocab_out: int, es
     return weights + kv_rows * cross + n_rows * self_kv
 
 
-def run(model_name="t5-base", new_tokens=256, device="cuda:0", reps=3, model_tuple=None):
+def run(model_name="t5-base", new_tokens=256, device="cuda:0", reps=3, model_tuple=None, options=None):
     from mapperatorinator_amd.server import build_sampling
     dev = torch.device(device)
     tgt = 1 + new_tokens
-    model, tok, dims, frames = model_tuple or build(model_name, tgt, dev)
+    model, tok, dims, frames = model_tuple or build(model_name, tgt, dev, options=options)
     eng = model.engine
     gated = not model.is_whisper
     src_len = eng.packed.src_len
@@ -117,5 +117,10 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--model", default="t5-base")
     ap.add_argument("--new-tokens", type=int, default=256)
+    ap.add_argument("--options", default="", help="engine options, name=value[,name=value...] (include/mapperhip.h)")
     a = ap.parse_args()
-    print(json.dumps(run(a.model, a.new_tokens)))
+    opts = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in a.options.split(",") if kv}
+    r = run(a.model, a.new_tokens, options=opts or None)
+    if opts:
+        r["options"] = opts
+    print(json.dumps(r))
