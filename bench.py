@@ -630,42 +630,68 @@ def main():
                           "gpu_tokens_per_s": round(128 / dt1, 1), "gpu_ms": round(dt1 * 1e3, 2)}
         del m1
 
-    # ---- the Whisper-family backbone of the released V30-V32 checkpoints (varwhisper small: d 768, 12 + 12 layers, 1024 frames) ----
+    # ---- the Whisper-family backbones of the released checkpoints at their own chunk sizes: V32 'OliBomby/varwhisper-small' (2048
+    # log-mel frames), V30 / V31 'Tiger14n/ropewhisper-small' (4096 frames, 80 mels + 3 x 128 conditioning channels into conv1),
+    # V28 / V29 'openai/whisper-small' (1024 nnAudio-mel frames behind encoder_embedder; library arch 2) -- batch 32, greedy.
+    # V29 + DiT-B is the one released pairing whose inference config runs BOTH stages (configs/inference/v29.yaml:7-8 with
+    # generate_positions inherited true): its chunks/s is the T5-side time of the V29 line + the DiT-B batch of aux.config5_dit_b.
     if not args.no_extras and not args.no_config5 and world == 1:
         try:
-            from mapperatorinator_amd.testing import random_varwhisper_state_dict
-            from mapperatorinator_amd.whisper_engine import VARWHISPER_PRESETS
-            dv, fr = VARWHISPER_PRESETS["small"], 2048
-            tokw = Tokenizer.benchmark_vocab(src_seq_len=fr // 2)
-            sdw = random_varwhisper_state_dict(dv.d_model, dv.n_heads, dv.n_enc_layers, dv.n_dec_layers, dv.d_ff, tokw.vocab_size_in,
-                                               tokw.vocab_size_out, seed=0, head_gain=5.0, gains={"decoder_embedder": 0.5})
-            mw = MapperatorinatorHIP(sdw, dv, vocab_size_in=tokw.vocab_size_in, vocab_size_out=tokw.vocab_size_out, n_mels=128,
-                                     src_seq_len=fr, tgt_seq_len=tgt_len, dtype=torch.bfloat16, device=dev, f_min=20)
-            aw = synthetic_audio(B, (fr - 1) * 128, seed=5).to(dev)
-            pw = torch.full((B, 1), tokw.sos_id, dtype=torch.int32, device=dev)
-            spw, _ = build_sampling(tokw, dict(gk), tgt_len)
-            ew = mw.engine
-            eos_w = torch.zeros(tokw.vocab_size_out, dtype=torch.uint8, device=dev)
+            import importlib.util
+            spec_sb = importlib.util.spec_from_file_location("small_batch_decode", os.path.join(ROOT, "tools", "small_batch_decode.py"))
+            sbd = importlib.util.module_from_spec(spec_sb)
+            spec_sb.loader.exec_module(sbd)
+            fam_lines = {}
+            for mname, release in (("varwhisper-small", "V32"), ("ropewhisper-small", "V30 / V31"), ("whisper-small", "V28 / V29")):
+                mw, tokw, dv, fr = sbd.build(mname, tgt_len, dev)
+                ew = mw.engine
+                aw = synthetic_audio(B, (fr - 1) * 128, seed=5).to(dev)
+                pw = torch.full((B, 1), tokw.sos_id, dtype=torch.int32, device=dev)
+                spw, _ = build_sampling(tokw, dict(gk), tgt_len)
+                eos_w = torch.zeros(tokw.vocab_size_out, dtype=torch.uint8, device=dev)
+                rbw = None
+                if ew.packed.cond_channels:      # (the V30 wiring: difficulty / mapper / song-position vectors as conv1 channels)
+                    rbw = torch.randn(B, ew.packed.cond_channels, generator=torch.Generator().manual_seed(1)).to(dev)
 
-            def vw_step():
-                ew._enter()
-                with torch.cuda.stream(ew.stream):
-                    t_, _, _ = ew.decode(ew.cross_kv(ew.encode_mel(ew.mel(aw))), pw, None, eos_w, spw, poll_every=64)
-                ew._leave()
-                return t_
-            vw_step()
-            torch.cuda.synchronize(dev)
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                tw = vw_step()
-            torch.cuda.synchronize(dev)
-            dtw = (time.perf_counter() - t0) / args.steps
-            aux["whisper_family"] = {"workload": f"varwhisper-small bf16 (d 768, 12 + 12 layers, 2048 log-mel frames -> 1024 encoder "
-                                                 f"positions per 16.4 s chunk), batch={B}, {new} greedy tokens per chunk",
-                                     "tokens_per_s": round(int((tw[:, 1:] != 0).sum().item()) / dtw, 1), "ms_per_step": round(dtw * 1e3, 2)}
-            del mw, ew
+                def vw_step():
+                    ew._enter()
+                    with torch.cuda.stream(ew.stream):
+                        t_, _, _ = ew.decode(ew.cross_kv(ew.encode_mel(ew.mel(aw), row_bias=rbw)), pw, None, eos_w, spw, poll_every=64)
+                    ew._leave()
+                    return t_
+                vw_step()
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    tw = vw_step()
+                torch.cuda.synchronize(dev)
+                dtw = (time.perf_counter() - t0) / args.steps
+                fam_lines[mname] = {"release": release, "kind": ew.kind, "mel_frames": fr, "encoder_positions": ew.src_len,
+                                    "tokens_per_s": round(int((tw[:, 1:] != 0).sum().item()) / dtw, 1), "ms_per_step": round(dtw * 1e3, 2)}
+                del mw, ew
+                torch.cuda.empty_cache()
+            aux["whisper_family"] = dict(fam_lines, workload=f"backbone-small dims (d 768, 12 + 12 layers) bf16, batch={B} chunks of the release's own "
+                                         f"length, {new} greedy tokens per chunk, mel + conv front-end + encoder + cross-K/V + AR decode, "
+                                         "synthetic audio, random-init weights in the reference's parameter layout")
+            if "config5_dit_b" in aux:
+                t5s, dbs = fam_lines["whisper-small"]["ms_per_step"] / 1e3, aux["config5_dit_b"]["ms_per_100_steps"] / 1e3
+                aux["released_pairing_v29_dit_b"] = {
+                    "workload": f"BASELINE configs[2] on a RELEASED pairing: 'openai/whisper-small' event model (V29) + DiT-B (osu-diffusion-v2), "
+                                f"{B} chunks: event tokens, then 100-step DDPM refine of all chunks as one denoiser batch",
+                    "t5_ms": round(t5s * 1e3, 2), "diffusion_ms": round(dbs * 1e3, 2), "chunks_per_s": round(B / (t5s + dbs), 2),
+                    "event_tokens_per_s": fam_lines["whisper-small"]["tokens_per_s"],
+                    "diffusion_steps_per_s_per_chunk": aux["config5_dit_b"]["steps_per_s_per_chunk"]}
+            # ---- the reference's DEFAULT call shape (configs/inference/default.yaml:54 `parallel: false`): one window per call ----
+            for mname in ("t5-base", "varwhisper-small"):
+                r = sbd.run(mname, new_tokens=256, device=str(dev))
+                for key in ("b1", "b2_cfg"):
+                    r[key]["workload"] = r["workload"]
+                    aux.setdefault("decode_" + key, {})[mname] = r[key]
+            aux["decode_b1"]["cpu_reference_tokens_per_s"] = 44.0      # the unmodified reference at this shape, other host
+            aux["decode_b1"]["note"] = ("one row: the token step is 74 dependent kernels of 5-13 us (profiles/r06_small_batch_decode.txt); "
+                                        "roofline_step = SURVEY 8d bytes of one step / measured step time / 8 TB/s")
         except Exception as e:   # an auxiliary figure must never cost the bench line -- but it must not vanish silently either
-            aux.setdefault("errors", []).append(f"whisper_family: {e!r}")
+            aux.setdefault("errors", []).append(f"whisper_family / small batch: {e!r}")
             print(f"whisper-family pass failed: {e!r}", file=sys.stderr)
 
     # ---- BASELINE configs[4] "fp8 MFMA", T5 side: mel + encoder + cross-K/V of the headline batch with MX-fp8 operands ----

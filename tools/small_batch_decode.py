@@ -45,10 +45,14 @@ def build(model_name: str, tgt: int, device, dtype=torch.bfloat16, options=None)
             sd = random_varwhisper_state_dict(dims.d_model, dims.n_heads, dims.n_enc_layers, dims.n_dec_layers, dims.d_ff, tok.vocab_size_in,
                                               tok.vocab_size_out, seed=0, head_gain=6.0, gains={"decoder_embedder": 0.5})
         else:
+            # (ropewhisper: the V30 wiring -- difficulty / mapper / song-position vectors, 3 x 128 conditioning channels into conv1)
             sd = random_whisper_family_state_dict("hf" if fam == "whisper" else "rope", dims.d_model, dims.n_heads, dims.n_enc_layers,
                                                   dims.n_dec_layers, dims.d_ff, tok.vocab_size_in, tok.vocab_size_out, n_mels,
-                                                  src_positions=frames // 2, tgt_positions=tgt, seed=0, head_gain=6.0,
-                                                  gains={"decoder_embedder": 0.5})
+                                                  src_positions=frames // 2, tgt_positions=tgt, cond_size=384 if fam == "ropewhisper" else 0,
+                                                  seed=0, head_gain=6.0, gains={"decoder_embedder": 0.5})
+            if fam == "ropewhisper":
+                from mapperatorinator_amd.testing import add_random_cond_embedders
+                add_random_cond_embedders(sd, cond_dim=128, num_mappers=11, seed=0)
         kw = dict(f_min=0 if fam == "whisper" else 20)
     model = MapperatorinatorHIP(sd, dims, vocab_size_in=tok.vocab_size_in, vocab_size_out=tok.vocab_size_out, n_mels=n_mels,
                                 src_seq_len=frames, tgt_seq_len=tgt, dtype=dtype, device=device, options=options, **kw)
@@ -81,7 +85,9 @@ def run(model_name="t5-base", new_tokens=256, device="cuda:0", reps=3, model_tup
     with torch.no_grad():
         eng._enter()
         with torch.cuda.stream(eng.stream):
-            kv = eng.cross_kv(eng.encode_mel(eng.mel(audio)))
+            cc = getattr(eng.packed, "cond_channels", 0)
+            rb = torch.randn(1, cc, generator=torch.Generator().manual_seed(1)).to(dev) if cc else None
+            kv = eng.cross_kv(eng.encode_mel(eng.mel(audio), row_bias=rb))
         eng._leave()
         torch.cuda.synchronize(dev)
         for name, rows, cfg_scale in (("b1", 1, 1.0), ("b2_cfg", 2, 2.0)):
