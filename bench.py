@@ -418,6 +418,17 @@ def main():
                 return diff.p_sample_loop(dit_b.forward_with_cfg, z.shape, z, model_kwargs=kw, step_noise=torch.randn(100, *z.shape, device=dev))
             dt_b = timed(dit_b_stage, 1)
             fl_b = dit_flops_per_step(db, hb, 2 * B, Tq) * 100
+
+            def dit_b_one():      # the reference's own call shape (diffusion_pipeline.py:243-252): ONE chunk per p_sample_loop, CFG batch 2
+                kw1 = dict(c=c[[0, B]], y=y[[0, B]], cfg_scale=1.0, attn_mask=BandMask(Tq, 128))
+                return diff.p_sample_loop(dit_b.forward_with_cfg, z[[0, B]].shape, z[[0, B]], model_kwargs=kw1,
+                                          step_noise=torch.randn(100, 2, *z.shape[1:], device=dev))
+            dt_b1 = timed(dit_b_one, 3)
+            fl_b1 = dit_flops_per_step(db, hb, 2, Tq) * 100
+            aux["diffusion"]["one_chunk_dit_b"] = {
+                "dit": "DiT-B (the released diffusion checkpoint's size, configs/diffusion/v1.yaml:11) fp32 exact-f32 MFMA, one chunk, Tq=128",
+                "ms_per_100_steps": round(dt_b1 * 1e3, 2), "steps_per_s_per_chunk": round(100 / dt_b1, 1),
+                "tflops": round(fl_b1 / dt_b1 / 1e12, 1), "frac_of_f32_mfma_peak": round(fl_b1 / dt_b1 / 1e12 / F32_MFMA_PEAK_TF, 3)}
             aux["config5_dit_b"] = {
                 "dit": "DiT-B fp32 semantics (big GEMMs bf16 x 3 on the matrix cores), Tq=128, 100-step DDPM, one replayed hipGraph",
                 "chunks": B, "denoiser_batch": 2 * B, "ms_per_100_steps": round(dt_b * 1e3, 2),

@@ -255,13 +255,18 @@ struct DitSkinnyP {
   float* xs; int ldx; const float* gate; int gate_ld;                 // GATE: xs[m][n] += gate[batch][n] * (acc + bias[n])
 };
 
-template <int NWV, int CH, int MF, int PRO, int EPI>
+// NF 16-column fragments per workgroup (round 6): the workgroup's activation rows are loaded ONCE for NF x 16 output columns.  A
+// 16 x 16 tile re-reads every activation row N / 16 times and every weight row M / 16 times through L2 -- at DiT-B (hidden 768, one
+// chunk = 256 rows) 113-302 MB of L2 -> CU traffic per GEMM, which is what bounded the form there (rocprofv3: fc2 35.9 us).  Each
+// output element is still the same products in the same order (k-block -> wave assignment, in-wave order, wave-order sum): NF
+// changes no bit of the result.
+template <int NWV, int CH, int MF, int PRO, int EPI, int NF = 1>
 __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(NWV / 4, 4)))   // registers are free here: hipcc must not trade a load in flight for one
 void dit_skinny_kernel(DitSkinnyP p) {
   // MF 16-row fragments per workgroup (MF = 2: the weight fragments are shared by 32 rows -- half the workgroups, so that the wide
   // projections (N = 3 D, 4 D: 1152 / 1536 tiles of 16 x 16 at DiT-S) fit the chip in ONE round of resident workgroups; the host
   // picks it only when rows_per_batch % 32 == 0, i.e. a row block never straddles two batch entries)
-  __shared__ f32x4_t red[NWV * MF * 64];
+  __shared__ f32x4_t red[NWV * MF * NF * 64];
   __shared__ float st1[PRO == DSK_PRO_LNMOD ? NWV : 1][MF * 16], st2[PRO == DSK_PRO_LNMOD ? NWV : 1][MF * 16];
   // LNMOD, MF = 2 (the workgroup's rows share ONE batch entry: host condition): the modulation vectors go through LDS -- one
   // 16-byte load per thread instead of 2 CH float4 per lane held across the statistics (48 registers: 184 -> ~120, i.e. four
@@ -270,10 +275,14 @@ void dit_skinny_kernel(DitSkinnyP p) {
   __shared__ __attribute__((aligned(16))) float modv[kModLds ? 2 * 16 * NWV * CH : 4];     // [scale | shift] over K <= 16 NWV CH
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l15 = lane & 15, lg = lane >> 4;
-  const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16 * MF;
-  const int wrow = (n0 + l15) < p.N ? (n0 + l15) : p.N - 1;          // this lane's weight row (B fragment row = l15 = output column)
+  const int n0 = blockIdx.x * 16 * NF, m0 = blockIdx.y * 16 * MF;
   const int nkb = p.K / 16;
-  const float* Wp = p.W + (long)wrow * p.ldw + lg * 4;
+  const float* Wp[NF];                                               // this lane's weight row of column fragment nf (B fragment row = l15 = output column)
+#pragma unroll
+  for (int nf = 0; nf < NF; ++nf) {
+    const int wrow = (n0 + nf * 16 + l15) < p.N ? (n0 + nf * 16 + l15) : p.N - 1;
+    Wp[nf] = p.W + (long)wrow * p.ldw + lg * 4;
+  }
   const float* Ap[MF];
   int batch_a[MF];
 #pragma unroll
@@ -284,24 +293,30 @@ void dit_skinny_kernel(DitSkinnyP p) {
   }
   // epilogue elements of this lane: unit = wid + u NWV -> fragment ef = unit >> 2, accumulator register r = unit & 3:
   // row m0 + ef*16 + lg*4 + r, column n0 + l15.  What the epilogue needs besides the product is requested with the operands.
-  constexpr int UPW = (MF * 4 + NWV - 1) / NWV;
-  const int ecol = (n0 + l15) < p.N ? (n0 + l15) : p.N - 1;
-  const float e_bias = p.bias[ecol];
-  float e_old[UPW], e_gate[UPW];
+  // (unit = (row fragment ef, column fragment nf, accumulator register r): ef = unit / (4 NF), nf = (unit >> 2) % NF, r = unit & 3)
+  constexpr int UPW = (MF * NF * 4 + NWV - 1) / NWV;
+  float e_bias[UPW], e_old[UPW], e_gate[UPW];
 #pragma unroll
   for (int u = 0; u < UPW; ++u) {
-    e_old[u] = 0.f; e_gate[u] = 0.f;
+    e_old[u] = 0.f; e_gate[u] = 0.f; e_bias[u] = 0.f;
     const int unit = wid + u * NWV;
-    if (EPI == DSK_EPI_GATE && unit < MF * 4) {
-      int er = m0 + (unit >> 2) * 16 + lg * 4 + (unit & 3);
-      er = er < p.M ? er : p.M - 1;
-      e_old[u] = p.xs[(long)er * p.ldx + ecol];
-      e_gate[u] = p.gate[(long)(er / p.rows_per_batch) * p.gate_ld + ecol];
+    if (unit < MF * NF * 4) {
+      const int ec0 = n0 + ((unit >> 2) % NF) * 16 + l15;
+      const int ecol = ec0 < p.N ? ec0 : p.N - 1;
+      e_bias[u] = p.bias[ecol];
+      if (EPI == DSK_EPI_GATE) {
+        int er = m0 + (unit / (4 * NF)) * 16 + lg * 4 + (unit & 3);
+        er = er < p.M ? er : p.M - 1;
+        e_old[u] = p.xs[(long)er * p.ldx + ecol];
+        e_gate[u] = p.gate[(long)(er / p.rows_per_batch) * p.gate_ld + ecol];
+      }
     }
   }
-  f32x4_t acc[MF];
+  f32x4_t acc[MF][NF];
 #pragma unroll
-  for (int f = 0; f < MF; ++f) acc[f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  for (int f = 0; f < MF; ++f)
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) acc[f][nf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   float4 mod_raw = make_float4(0.f, 0.f, 0.f, 0.f);
   if constexpr (kModLds) {   // thread t < K/4: scale[4t .. 4t+3]; K/4 <= t < K/2: shift (K/2 <= NWV * 64 * ... : checked below)
     const int t4 = tid * 4;
@@ -310,14 +325,15 @@ void dit_skinny_kernel(DitSkinnyP p) {
   }
   int kb0 = wid;
   do {   // ONE pass unless K > 16 NWV CH (LNMOD: checked on the host); every wave runs at least one (the barrier of the statistics)
-    float4 av[MF][CH], wv[CH], sc[(PRO == DSK_PRO_LNMOD && !kModLds) ? CH : 1], sh[(PRO == DSK_PRO_LNMOD && !kModLds) ? CH : 1];
+    float4 av[MF][CH], wv[NF][CH], sc[(PRO == DSK_PRO_LNMOD && !kModLds) ? CH : 1], sh[(PRO == DSK_PRO_LNMOD && !kModLds) ? CH : 1];
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
       const int kb = kb0 + NWV * c;
       const int kel = (kb < nkb ? kb : nkb - 1) * 16;          // clamped address, value masked below (no predicated load)
 #pragma unroll
       for (int f = 0; f < MF; ++f) av[f][c] = *reinterpret_cast<const float4*>(Ap[f] + kel);
-      wv[c] = *reinterpret_cast<const float4*>(Wp + kel);
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) wv[nf][c] = *reinterpret_cast<const float4*>(Wp[nf] + kel);
       if constexpr (PRO == DSK_PRO_LNMOD && !kModLds) {
         sc[c] = *reinterpret_cast<const float4*>(p.scale + (long)batch_a[0] * p.mod_ld + kel + lg * 4);
         sh[c] = *reinterpret_cast<const float4*>(p.shift + (long)batch_a[0] * p.mod_ld + kel + lg * 4);
@@ -376,29 +392,36 @@ void dit_skinny_kernel(DitSkinnyP p) {
       // element i of every lane's 4-float vector forms one 16x16x4 product (a permutation of k, the same for both operands)
 #pragma unroll
       for (int f = 0; f < MF; ++f) {
-        acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[f][c].x * keep, wv[c].x, acc[f], 0, 0, 0);
-        acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[f][c].y * keep, wv[c].y, acc[f], 0, 0, 0);
-        acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[f][c].z * keep, wv[c].z, acc[f], 0, 0, 0);
-        acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[f][c].w * keep, wv[c].w, acc[f], 0, 0, 0);
+        const float ax = av[f][c].x * keep, ay = av[f][c].y * keep, az = av[f][c].z * keep, aw = av[f][c].w * keep;
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) {
+          acc[f][nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax, wv[nf][c].x, acc[f][nf], 0, 0, 0);
+          acc[f][nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(ay, wv[nf][c].y, acc[f][nf], 0, 0, 0);
+          acc[f][nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(az, wv[nf][c].z, acc[f][nf], 0, 0, 0);
+          acc[f][nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw, wv[nf][c].w, acc[f][nf], 0, 0, 0);
+        }
       }
     }
     kb0 += NWV * CH;
   } while (kb0 < nkb);
 #pragma unroll
-  for (int f = 0; f < MF; ++f) red[(wid * MF + f) * 64 + lane] = acc[f];
+  for (int f = 0; f < MF; ++f)
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) red[((wid * MF + f) * NF + nf) * 64 + lane] = acc[f][nf];
   __syncthreads();
   const float* redf = reinterpret_cast<const float*>(red);
 #pragma unroll
   for (int u = 0; u < UPW; ++u) {
     const int unit = wid + u * NWV;
-    if (unit >= MF * 4) break;
-    const int ef = unit >> 2, r = unit & 3;
+    if (unit >= MF * NF * 4) break;
+    const int ef = unit / (4 * NF), enf = (unit >> 2) % NF, r = unit & 3;
     float v = 0.f;
 #pragma unroll
-    for (int w = 0; w < NWV; ++w) v += redf[((w * MF + ef) * 64 + lane) * 4 + r];       // wave order: deterministic
-    v += e_bias;
+    for (int w = 0; w < NWV; ++w) v += redf[(((w * MF + ef) * NF + enf) * 64 + lane) * 4 + r];       // wave order: deterministic
+    v += e_bias[u];
     const int erow = m0 + ef * 16 + lg * 4 + r;
-    if (erow >= p.M || (n0 + l15) >= p.N) continue;
+    const int ecol = n0 + enf * 16 + l15;
+    if (erow >= p.M || ecol >= p.N) continue;
     const int batch_e = erow / p.rows_per_batch;
     if (EPI == DSK_EPI_GATE) {
       p.xs[(long)erow * p.ldx + ecol] = e_old[u] + e_gate[u] * v;
@@ -431,8 +454,19 @@ int dit_skinny(const DitSkinnyP& p, hipStream_t s) {
       if (mf2) hipLaunchKernelGGL((dit_skinny_kernel<8, 6, 2, PRO, EPI>), grid, dim3(512), 0, s, p);
       else hipLaunchKernelGGL((dit_skinny_kernel<8, 6, 1, PRO, EPI>), grid, dim3(512), 0, s, p);
     }
-  } else {
-    if (nkb <= 4 * 6) {
+  } else if constexpr (PRO == DSK_PRO_PLAIN) {
+    // wide form (round 6, hidden > 512): 32 rows x NF x 16 columns per workgroup -- the L2 -> CU traffic of a 16 x 16 tile is what
+    // bounds these GEMMs at DiT-B (see the kernel's header); bit-identical to the narrow form
+    // (measured at DiT-B, one chunk, ms per 100 steps: NF = 1 138.6, NF = 2 129.4, NF = 4 140.5 -- four column fragments leave
+    // 288-384 workgroups for 256 CUs; at DiT-S dims (K = 384) the narrow forms stay faster: 59.6 vs 82.4)
+    const bool wide = p.rows_per_batch % 32 == 0 && p.N % 32 == 0 && p.K >= 768;
+    if (wide && nkb <= 8 * 6) {
+      dim3 gw(p.N / 32, ceil_div(p.M, 32));
+      hipLaunchKernelGGL((dit_skinny_kernel<8, 6, 2, PRO, EPI, 2>), gw, dim3(512), 0, s, p);
+    } else if (wide && nkb > 16 * 6) {
+      dim3 gw(p.N / 32, ceil_div(p.M, 32));
+      hipLaunchKernelGGL((dit_skinny_kernel<8, 12, 2, PRO, EPI, 2>), gw, dim3(512), 0, s, p);
+    } else if (nkb <= 4 * 6) {
       if (mf2) hipLaunchKernelGGL((dit_skinny_kernel<4, 6, 2, PRO, EPI>), grid, dim3(256), 0, s, p);
       else hipLaunchKernelGGL((dit_skinny_kernel<4, 6, 1, PRO, EPI>), grid, dim3(256), 0, s, p);
     } else if (nkb <= 8 * 6) {
@@ -441,7 +475,7 @@ int dit_skinny(const DitSkinnyP& p, hipStream_t s) {
     } else if (nkb <= 16 * 6 && p.rows_per_batch % 32 == 0) {
       // long K (fc2: K = 4 D), 32 rows x 16 columns per workgroup, SIXTEEN waves split K: 6 k-blocks per wave in one round trip
       dim3 g2(ceil_div(p.N, 16), ceil_div(p.M, 32));
-      if constexpr (PRO == DSK_PRO_PLAIN) hipLaunchKernelGGL((dit_skinny_kernel<16, 6, 2, PRO, EPI>), g2, dim3(1024), 0, s, p);
+      hipLaunchKernelGGL((dit_skinny_kernel<16, 6, 2, PRO, EPI>), g2, dim3(1024), 0, s, p);
     } else {
       if (mf2) hipLaunchKernelGGL((dit_skinny_kernel<8, 12, 2, PRO, EPI>), grid, dim3(512), 0, s, p);
       else hipLaunchKernelGGL((dit_skinny_kernel<8, 12, 1, PRO, EPI>), grid, dim3(512), 0, s, p);
@@ -639,9 +673,9 @@ int dit_body(const MhDiTConfig* c, const MhDiTWeights* w, const float* x, const 
   }
   // one chunk (a few hundred rows): the four block GEMMs as one-round-trip latency kernels (dit_skinny_kernel above)
   // (hidden <= 512: DiT-XS / -S.  At DiT-B's 768 the LayerNorm form needs 180 registers in 8-wave workgroups -- one per CU for 1152-2304
-  // tiles: measured 208 vs 192 ms per 100 steps; the test override `>= 1 << 20` admits every size the kernel can run)
+  // tiles: hidden > 512 takes the pre-pass form below)
   const long sk_rows = option(OPT_DIT_SKINNY_MAX_ROWS);
-  const bool skinny = !lowp && !lowp8 && !s3 && NT <= sk_rows && D % 16 == 0 && (D <= 512 || (sk_rows >= (1 << 20) && D <= 768));
+  const bool skinny = !lowp && !lowp8 && !s3 && NT <= sk_rows && D % 16 == 0 && D <= 512;
   for (int l = 0; l < c->depth && skinny; ++l) {
     const float* mod = b.cond_cur + (long)l * 6 * D;
     DitSkinnyP q{};
@@ -665,7 +699,35 @@ int dit_body(const MhDiTConfig* c, const MhDiTWeights* w, const float* x, const 
     q.xs = b.xs; q.ldx = D; q.gate = mod + 5 * D; q.gate_ld = ld_row;
     MH_TRY((dit_skinny<DSK_PRO_PLAIN, DSK_EPI_GATE>(q, s)));
   }
-  for (int l = 0; l < c->depth && !lowp && !lowp8 && !s3g && !skinny; ++l) {
+  // one chunk at hidden > 512 (DiT-B: the released diffusion checkpoint, configs/diffusion/v1.yaml:11; round 6): the LayerNorm-
+  // modulate as its own tiny pass (5 us for 256 x 768), then all four block GEMMs in the PLAIN skinny form -- 32 rows x 32 columns
+  // per workgroup (dit_skinny_kernel NF = 2).  The LayerNorm-in-registers form needs ~180 VGPRs at K = 768 (one 8-wave workgroup
+  // per CU; 182.8 ms per 100 steps) and the LDS-tiled GEMMs with the fused LayerNorm prologue take 178.9; this form 129.0
+  // (profiles/r06_dit_b_one_chunk.txt).  Same arithmetic per output element as the narrow skinny form.
+  const bool skinny_pre = !lowp && !lowp8 && !s3 && !skinny && NT <= sk_rows && D > 512 && D % 16 == 0;
+  for (int l = 0; l < c->depth && skinny_pre; ++l) {
+    const float* mod = b.cond_cur + (long)l * 6 * D;
+    MH_TRY(ln_modulate(b.xs, D, mod + 0 * D, mod + 1 * D, ld_row, T, b.xm, D, NT, D, 1e-6f, MH_F32, s));
+    DitSkinnyP q{};
+    q.A = b.xm; q.lda = D; q.W = w->qkv_w[l]; q.ldw = D; q.bias = w->qkv_b[l]; q.M = NT; q.N = 3 * D; q.K = D; q.rows_per_batch = T;
+    q.out = b.qk; q.ldo = 2 * D; q.vt = b.vt; q.n_split = 2 * D; q.H = H; q.Tpad = b.Tpad;
+    MH_TRY((dit_skinny<DSK_PRO_PLAIN, DSK_EPI_QKV>(q, s)));
+    MH_TRY(attention(b.qk, 2 * D, D, b.vt, b.Tpad, nullptr, b.attn, D, N, T, H, 0.125f, band, MH_F32, s, open_from));
+    q = DitSkinnyP{};
+    q.A = b.attn; q.lda = D; q.W = w->out_w[l]; q.ldw = D; q.bias = w->out_b[l]; q.M = NT; q.N = D; q.K = D; q.rows_per_batch = T;
+    q.xs = b.xs; q.ldx = D; q.gate = mod + 2 * D; q.gate_ld = ld_row;
+    MH_TRY((dit_skinny<DSK_PRO_PLAIN, DSK_EPI_GATE>(q, s)));
+    MH_TRY(ln_modulate(b.xs, D, mod + 3 * D, mod + 4 * D, ld_row, T, b.xm, D, NT, D, 1e-6f, MH_F32, s));
+    q = DitSkinnyP{};
+    q.A = b.xm; q.lda = D; q.W = w->fc1_w[l]; q.ldw = D; q.bias = w->fc1_b[l]; q.M = NT; q.N = 4 * D; q.K = D; q.rows_per_batch = T;
+    q.out = b.hid; q.ldo = 4 * D;
+    MH_TRY((dit_skinny<DSK_PRO_PLAIN, DSK_EPI_GELU>(q, s)));
+    q = DitSkinnyP{};
+    q.A = b.hid; q.lda = 4 * D; q.W = w->fc2_w[l]; q.ldw = 4 * D; q.bias = w->fc2_b[l]; q.M = NT; q.N = D; q.K = 4 * D; q.rows_per_batch = T;
+    q.xs = b.xs; q.ldx = D; q.gate = mod + 5 * D; q.gate_ld = ld_row;
+    MH_TRY((dit_skinny<DSK_PRO_PLAIN, DSK_EPI_GATE>(q, s)));
+  }
+  for (int l = 0; l < c->depth && !lowp && !lowp8 && !s3g && !skinny && !skinny_pre; ++l) {
     const float* mod = b.cond_cur + (long)l * 6 * D;
     // attention branch
     g = MhGemm{};
