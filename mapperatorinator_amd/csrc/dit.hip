@@ -341,20 +341,21 @@ void dit_skinny_kernel(DitSkinnyP p) {
     }
     __builtin_amdgcn_sched_barrier(0);     // every load of the pass is issued ABOVE this line (hipcc otherwise sinks each load to its MFMA)
     if (PRO == DSK_PRO_LNMOD) {
-      // LayerNorm statistics of row l15 from the registers: this lane's 4 CH values -> the 4 lane groups -> the NWV waves
+      // LayerNorm statistics of row l15 from the registers: this lane's 4 CH values -> the 4 lane groups -> the NWV waves, TWICE
+      // (round 6, ADVICE r5: the mean first, then the sum of squares of the CENTRED values -- F.layer_norm's arithmetic; the
+      // single-pass E[x^2] - mu^2 of round 5 loses every digit on rows whose mean dwarfs their spread)
+      float mu_f[MF];
 #pragma unroll
       for (int f = 0; f < MF; ++f) {
-        float s1 = 0.f, s2 = 0.f;
+        float s1 = 0.f;
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
           const float m = (kb0 + NWV * c < nkb) ? 1.f : 0.f;
           const float4 x = av[f][c];
           s1 += m * ((x.x + x.y) + (x.z + x.w));
-          s2 += m * ((x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w));
         }
         s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
-        s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
-        if (lg == 0) { st1[wid][f * 16 + l15] = s1; st2[wid][f * 16 + l15] = s2; }
+        if (lg == 0) st1[wid][f * 16 + l15] = s1;
       }
       if constexpr (kModLds) {
         if (tid * 4 < 2 * p.K) *reinterpret_cast<float4*>(modv + tid * 4) = mod_raw;      // [0, K): scale, [K, 2K): shift
@@ -362,11 +363,29 @@ void dit_skinny_kernel(DitSkinnyP p) {
       __syncthreads();
 #pragma unroll
       for (int f = 0; f < MF; ++f) {
-        float t1 = 0.f, t2 = 0.f;
+        float t1 = 0.f;
 #pragma unroll
-        for (int w = 0; w < NWV; ++w) { t1 += st1[w][f * 16 + l15]; t2 += st2[w][f * 16 + l15]; }
-        const float mu = t1 / (float)p.K;
-        const float rs = rsqrtf(fmaxf(t2 / (float)p.K - mu * mu, 0.f) + p.eps);
+        for (int w = 0; w < NWV; ++w) t1 += st1[w][f * 16 + l15];
+        mu_f[f] = t1 / (float)p.K;
+        float s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          const float m = (kb0 + NWV * c < nkb) ? 1.f : 0.f;
+          const float4 x = av[f][c];
+          const float a0 = x.x - mu_f[f], a1 = x.y - mu_f[f], a2 = x.z - mu_f[f], a3 = x.w - mu_f[f];
+          s2 += m * ((a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3));
+        }
+        s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+        if (lg == 0) st2[wid][f * 16 + l15] = s2;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int f = 0; f < MF; ++f) {
+        float t2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) t2 += st2[w][f * 16 + l15];
+        const float mu = mu_f[f];
+        const float rs = rsqrtf(t2 / (float)p.K + p.eps);
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
           float4 x = av[f][c], qs, qh;
