@@ -4,7 +4,7 @@ ARCH ?= gfx950
 CSRC := mapperatorinator_amd/csrc
 OBJDIR := build/obj
 LIB := mapperatorinator_amd/lib/libmapperhip.so
-SRCS := $(CSRC)/api.hip $(CSRC)/gemm.hip $(CSRC)/mx8.hip $(CSRC)/norm.hip $(CSRC)/attention.hip $(CSRC)/mel.hip $(CSRC)/conv.hip $(CSRC)/t5.hip $(CSRC)/dit.hip $(CSRC)/slider.hip
+SRCS := $(CSRC)/api.hip $(CSRC)/gemm.hip $(CSRC)/mx8.hip $(CSRC)/norm.hip $(CSRC)/attention.hip $(CSRC)/mel.hip $(CSRC)/conv.hip $(CSRC)/t5.hip $(CSRC)/beam.hip $(CSRC)/dit.hip $(CSRC)/slider.hip
 OBJS := $(patsubst $(CSRC)/%.hip,$(OBJDIR)/%.o,$(SRCS))
 HDRS := $(wildcard $(CSRC)/*.hpp) include/mapperhip.h
 # -amdgpu-kernarg-preload-count: leading scalar kernel arguments arrive in SGPRs with the wave launch (gfx950 firmware)

@@ -698,6 +698,12 @@ def main():
                 for key in ("b1", "b2_cfg"):
                     r[key]["workload"] = r["workload"]
                     aux.setdefault("decode_" + key, {})[mname] = r[key]
+            # beam search as the reference's timing pass runs it (2 beams, super_timing_generator.py:28): the per-token bookkeeping in ONE
+            # kernel (mh_beam_step) against the torch-op form of round 5
+            spec_bb = importlib.util.spec_from_file_location("beam_bench", os.path.join(ROOT, "tools", "beam_bench.py"))
+            bbm = importlib.util.module_from_spec(spec_bb)
+            spec_bb.loader.exec_module(bbm)
+            aux["beam2"] = {"one_window": bbm.run(chunks=1, beams=2, device=str(dev)), "eight_windows": bbm.run(chunks=8, beams=2, device=str(dev))}
             aux["decode_b1"]["cpu_reference_tokens_per_s"] = 44.0      # the unmodified reference at this shape, other host
             aux["decode_b1"]["note"] = ("one row: the token step is 74 dependent kernels of 5-13 us (profiles/r06_small_batch_decode.txt); "
                                         "roofline_step = SURVEY 8d bytes of one step / measured step time / 8 TB/s")

@@ -460,6 +460,38 @@ int mh_t5_generate(const MhT5Config* cfg, const MhT5Weights* w, const void* cros
                    const int32_t* forced, void* workspace, int64_t workspace_bytes, int poll_every,
                    void* stream);
 
+/* (ABI 10) One beam-search step between two decoder positions as ONE kernel (csrc/beam.hip).  Replaces the per-step body of HF
+ * `GenerationMixin._beam_search` (third-party, transformers >= 4.50's vectorised form) as the reference reaches it with
+ * `num_beams > 1` (osuT5/osuT5/inference/processor.py:147,159; server.py:137; super_timing_generator.py:28 decodes with two beams):
+ * log_softmax of the step's logits (mh_t5_step) -> [HF ClassifierFreeGuidanceLogitsProcessor on the reference's row order, rows
+ * [negative | prompt]: modeling_mapperatorinator.py:243-254] -> the reference's processor list on log-probabilities (server.py:
+ * 106-134; logit_processors.py:36-44,47-82,111-114,136-183) -> + running beam scores -> the K best continuations of every chunk
+ * (sorted, ties by flat index) -> EOS / max_length split -> the next running beams -> merge of the finished hypotheses by score /
+ * length ** penalty -> the early_stopping = False heuristic.  Greedy beams only (sp.do_sample = 0).
+ * State: G chunks x num_beams rows, int32 sequences [G][nb][max_length] (columns beyond the current length hold the fill value),
+ * fp32 scores [G][nb], int32 beam-index trails [G][nb][max_length - P], finished flags [G][nb]; the kernel reads the *_in arrays
+ * and writes the *_out arrays (the caller swaps them every step), `heuristic_open` [G] in place.  Outputs for the caller: `src` [G
+ * nb] = the row each new running beam continues (the argument of mh_t5_reorder_cache: MapperatorinatorCache.reorder_cache,
+ * inference/cache_utils.py:16-20), `last` [G nb] = the token each running beam is fed next, `flags` [G][3] = (heuristic still
+ * open, every candidate hit EOS / max_length, every finished slot filled) from which the host forms HF's loop condition.
+ * num_beams in 2 .. 8, num_beams x V <= 16384 (the sort runs in LDS), K <= 4096. */
+typedef struct MhBeamStep {
+  const float* logits;          /* [RE][V] fp32: RE = G nb rows, or 2 G nb under guidance ([negative rows | prompt rows]) */
+  const uint8_t* eos_table;     /* [V] 1 = an EOS id (get_eos_token_id, server.py:72-80)                                    */
+  int G, num_beams, V, P, max_length, K, cur_len;
+  int cfg; float cfg_scale;     /* classifier-free guidance (sp.cfg_scale is not read)                                      */
+  float length_penalty; int early_stopping;   /* 0 = False, 1 = True, 2 = "never"                                           */
+  MhSampling sp;                /* ts_start / ts_end / sos_ids / timeshift_bias / temperature / cond_* / lookback_mask_end / tok_flags */
+  const int32_t* run_in; const float* rs_in; const int32_t* rb_in;      /* running beams: sequences, scores, beam-index trail */
+  const int32_t* seq_in; const float* bs_in; const int32_t* bb_in; const uint8_t* fin_in;   /* finished set                 */
+  int32_t* run_out; float* rs_out; int32_t* rb_out;
+  int32_t* seq_out; float* bs_out; int32_t* bb_out; uint8_t* fin_out;
+  uint8_t* heuristic_open;      /* [G] in place                                                                              */
+  int32_t* src; int32_t* last; int32_t* flags;
+} MhBeamStep;
+int64_t mh_beam_step_lds_bytes(int num_beams, int V);
+int mh_beam_step(const MhBeamStep* bs, void* stream);
+
 /* Step-wise decode for host-driven search.  Replaces the per-position `self(**model_inputs)` of HF
  * `GenerationMixin._beam_search` (num_beams > 1: osuT5/osuT5/inference/processor.py:147,159; server.py:137) and
  * `MapperatorinatorCache.reorder_cache` (osuT5/osuT5/inference/cache_utils.py:16-20).

@@ -83,6 +83,16 @@ class MhSampling(C.Structure):
                 ("cross_kv_fp8", C.c_void_p)]
 
 
+class MhBeamStep(C.Structure):
+    _fields_ = [("logits", VP), ("eos_table", VP),
+                ("G", C.c_int), ("num_beams", C.c_int), ("V", C.c_int), ("P", C.c_int), ("max_length", C.c_int), ("K", C.c_int),
+                ("cur_len", C.c_int), ("cfg", C.c_int), ("cfg_scale", C.c_float), ("length_penalty", C.c_float),
+                ("early_stopping", C.c_int), ("sp", MhSampling),
+                ("run_in", VP), ("rs_in", VP), ("rb_in", VP), ("seq_in", VP), ("bs_in", VP), ("bb_in", VP), ("fin_in", VP),
+                ("run_out", VP), ("rs_out", VP), ("rb_out", VP), ("seq_out", VP), ("bs_out", VP), ("bb_out", VP), ("fin_out", VP),
+                ("heuristic_open", VP), ("src", VP), ("last", VP), ("flags", VP)]
+
+
 class MhDiTConfig(C.Structure):
     _fields_ = [("hidden", C.c_int), ("depth", C.c_int), ("n_heads", C.c_int), ("context_size", C.c_int),
                 ("class_size", C.c_int), ("in_channels", C.c_int), ("freq_dim", C.c_int),
@@ -149,6 +159,8 @@ SYMBOLS = {
     "mh_t5_generate": (I, [C.POINTER(MhT5Config), C.POINTER(MhT5Weights), VP, I, VP, VP, I, VP,
                            C.POINTER(MhSampling), VP, VP, VP, VP, VP, I64, I, VP]),
     "mh_t5_step": (I, [C.POINTER(MhT5Config), C.POINTER(MhT5Weights), VP, I, I, VP, I, VP, I, VP, VP, I64, VP]),
+    "mh_beam_step_lds_bytes": (I64, [I, I]),
+    "mh_beam_step": (I, [C.POINTER(MhBeamStep), VP]),
     "mh_t5_reorder_cache_scratch_bytes": (I64, [C.POINTER(MhT5Config), I, I]),
     "mh_t5_reorder_cache": (I, [C.POINTER(MhT5Config), I, VP, I, VP, I64, VP, I64, VP]),
     "mh_t5_forward_workspace_bytes": (I64, [C.POINTER(MhT5Config), I, I]),
@@ -195,7 +207,7 @@ def load():
         fn.argtypes = args
     if lib.mh_abi_version() != ABI_VERSION:
         raise RuntimeError("libmapperhip.so ABI version mismatch")
-    for which, st in enumerate((MhGemm, MhT5Config, MhT5Weights, MhSampling, MhDiTConfig, MhDiTWeights, MhSliderSet)):
+    for which, st in enumerate((MhGemm, MhT5Config, MhT5Weights, MhSampling, MhDiTConfig, MhDiTWeights, MhSliderSet, MhBeamStep)):
         if lib.mh_struct_size(which) != C.sizeof(st):
             raise RuntimeError(f"libmapperhip.so: layout of {st.__name__} differs from the binding "
                                f"({lib.mh_struct_size(which)} vs {C.sizeof(st)} bytes)")

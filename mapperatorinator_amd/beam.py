@@ -14,7 +14,11 @@ vectorised `GenerationMixin._beam_search` -- transformers >= 4.50; line referenc
     stop when no running beam can still beat the worst finished one (early_stopping = False heuristic)
 
 The device side is the step-wise entry of the library (`mh_t5_step`: one decoder position for all (chunk, beam) rows, raw
-logits out; `mh_t5_reorder_cache`); the bookkeeping above runs as torch ops on the same GPU.  The logits processors of
+logits out; `mh_t5_reorder_cache`).  Round 6: for greedy beams the WHOLE bookkeeping above is one kernel per token, `mh_beam_step`
+(csrc/beam.hip: log_softmax, guidance, processors, top-K over beams x V by an in-LDS sort, EOS split, next-beam selection, finished-set
+merge, the early-stopping heuristic) -- `_beam_search_kernel` below; the host reads three flags per chunk and step.  The torch-op
+form (`beam_search` with use_kernel=False; ~40 ATen launches per token) stays for beam-SAMPLE, whose continuations are drawn by
+torch.multinomial / an injected sampler, and as the cross-check of the kernel (tests run both against the reference goldens).  The logits processors of
 server.py:106-134 are applied here with torch ops (the in-kernel sampler of the greedy / sampling path selects per row and
 cannot rank across beams): classifier-free guidance, MonotonicTimeShift, TimeshiftBias, (Conditional)Temperature and the lookback
 mask; the types_first lookback renormalisation is refused in beam mode.
@@ -112,14 +116,154 @@ class BeamProcessors:
         return scores
 
 
+def kernel_path_available(sp, num_beams: int, vocab_out: int, n_eos: int) -> bool:
+    """mh_beam_step covers greedy beams (no beam-sample), 2 .. 8 beams, beams x V <= 16384 (the sort runs in LDS), K <= 4096."""
+    K = min(max(2, 1 + n_eos) * num_beams, num_beams * vocab_out)
+    return (not sp.do_sample) and 2 <= num_beams <= 8 and num_beams * vocab_out <= 16384 and K <= 4096
+
+
+@torch.no_grad()
+def _beam_search_kernel(engine, cross_kv, prompt, prompt_mask, eos_ids, sp, num_beams, length_penalty, early_stopping) -> torch.Tensor:
+    """`beam_search` with the per-token bookkeeping in mh_beam_step: per token mh_t5_step -> mh_beam_step -> mh_t5_reorder_cache and ONE
+    D2H copy of 3 G flags (HF's loop condition); the hypotheses live in int32 device arrays that the kernel ping-pongs."""
+    dev, lib, p = engine.device, engine.lib, engine.packed
+    cfg = sp.cfg_scale > 1.0
+    neg_prompt = neg_mask = None
+    if cfg:
+        if prompt.shape[0] % 2:
+            raise ValueError("guidance: the prompt batch must be [negative rows | prompt rows]")
+        half = prompt.shape[0] // 2
+        neg_prompt, prompt = prompt[:half], prompt[half:]
+        neg_mask = None if prompt_mask is None else prompt_mask[:half]
+        prompt_mask = None if prompt_mask is None else prompt_mask[half:]
+        cross_kv = torch.cat([cross_kv, cross_kv], dim=2)
+    G, P = prompt.shape
+    nb = int(num_beams)
+    R = G * nb
+    RE = 2 * R if cfg else R
+    if RE > 64:
+        raise ValueError(f"{G} chunks x {nb} beams{' x 2 (guidance)' if cfg else ''} exceed the engine's 64-row decode batch")
+    V = p.vocab_out
+    max_length = int(sp.max_length)
+    if not (1 <= P < max_length <= p.tgt_len):
+        raise ValueError("prompt / max_length do not fit the cache")
+    if sp.lookback_types_first and sp.lookback_mask_end > sp.ts_start:
+        raise NotImplementedError("beam search with the types_first lookback renormalisation is not on the HIP path")
+    eos_list = [int(e) for e in eos_ids]
+    K = min(max(2, 1 + len(eos_list)) * nb, nb * V)
+    fill = int(sp.pad_id) or (eos_list[0] if eos_list else -1)
+    n_new = max_length - P
+    eos_table = torch.zeros(V, dtype=torch.uint8, device=dev)
+    good = [e for e in eos_list if 0 <= e < V]
+    if good:
+        eos_table[torch.tensor(good, dtype=torch.long, device=dev)] = 1
+    flags_h = getattr(sp, "host_tok_flags", None)
+    if flags_h is not None:
+        flags_d = torch.as_tensor(flags_h, dtype=torch.uint8).to(dev)
+        sp.tok_flags = flags_d.data_ptr()
+    elif sp.n_cond:
+        raise ValueError("conditional temperature needs tok_flags (build the sampling struct with server.build_sampling)")
+    ids0 = prompt.to(dev, torch.int32).repeat_interleave(nb, 0)
+    mask = None if prompt_mask is None else prompt_mask.to(dev).to(torch.uint8).repeat_interleave(nb, 0).contiguous()
+    ids0e = ids0
+    if cfg:
+        ids0e = torch.cat([neg_prompt.to(dev, torch.int32).repeat_interleave(nb, 0), ids0], 0)
+        if mask is not None:
+            mask = torch.cat([neg_mask.to(dev).to(torch.uint8).repeat_interleave(nb, 0), mask], 0).contiguous()
+
+    def state():
+        run = torch.full((G, nb, max_length), fill, dtype=torch.int32, device=dev)
+        run[:, :, :P] = ids0.view(G, nb, P)
+        rs = torch.zeros((G, nb), dtype=torch.float32, device=dev)
+        rs[:, 1:] = -1e9
+        return dict(run=run, rs=rs, rb=torch.full((G, nb, n_new), -1, dtype=torch.int32, device=dev), seq=run.clone(),
+                    bs=torch.full((G, nb), -1e9, dtype=torch.float32, device=dev),
+                    bb=torch.full((G, nb, n_new), -1, dtype=torch.int32, device=dev),
+                    fin=torch.zeros((G, nb), dtype=torch.uint8, device=dev))
+    st = [state(), state()]
+    heuristic_open = torch.ones(G, dtype=torch.uint8, device=dev)
+    src = torch.zeros(R, dtype=torch.int32, device=dev)
+    last = torch.zeros(R, dtype=torch.int32, device=dev)
+    flags = torch.zeros((G, 3), dtype=torch.int32, device=dev)
+    flags_host = torch.zeros((G, 3), dtype=torch.int32).pin_memory()
+    need = lib.mh_t5_decode_workspace_bytes(C.byref(p.cfg), RE)
+    ws = torch.empty(int(need), dtype=torch.uint8, device=dev)
+    scratch = torch.empty(int(lib.mh_t5_reorder_cache_scratch_bytes(C.byref(p.cfg), RE, max_length)), dtype=torch.uint8, device=dev)
+    logits = torch.empty((RE, V), dtype=torch.float32, device=dev)
+    src2 = torch.zeros(RE, dtype=torch.int32, device=dev)
+    feed = torch.zeros(RE, dtype=torch.int32, device=dev)
+    stream = engine._s()
+    bs = _lib.MhBeamStep()
+    bs.logits, bs.eos_table = logits.data_ptr(), eos_table.data_ptr()
+    bs.G, bs.num_beams, bs.V, bs.P, bs.max_length, bs.K = G, nb, V, P, max_length, K
+    bs.cfg, bs.cfg_scale, bs.length_penalty = int(cfg), float(sp.cfg_scale), float(length_penalty)
+    bs.early_stopping = 2 if early_stopping == "never" else (1 if early_stopping is True else 0)
+    bs.sp = sp
+    bs.heuristic_open, bs.src, bs.last, bs.flags = heuristic_open.data_ptr(), src.data_ptr(), last.data_ptr(), flags.data_ptr()
+
+    def step(tokens: torch.Tensor, pos: int):
+        rc = lib.mh_t5_step(C.byref(p.cfg), C.byref(p.w), cross_kv.data_ptr(), RE, nb, tokens.data_ptr(), pos, _lib.ptr(mask), P,
+                            logits.data_ptr(), ws.data_ptr(), ws.numel(), stream)
+        _lib.check(rc, "mh_t5_step")
+
+    engine._enter()
+    with torch.cuda.stream(engine.stream):
+        for pos in range(P - 1):
+            step(ids0e[:, pos].contiguous(), pos)
+        feed.copy_(ids0e[:, P - 1])                    # the last prompt column (under guidance the first half has the negative prompt's)
+        cur_len, par = P, 0
+        while True:
+            step(feed, cur_len - 1)
+            a, b = st[par], st[par ^ 1]
+            bs.cur_len = cur_len
+            bs.run_in, bs.rs_in, bs.rb_in = a["run"].data_ptr(), a["rs"].data_ptr(), a["rb"].data_ptr()
+            bs.seq_in, bs.bs_in, bs.bb_in, bs.fin_in = a["seq"].data_ptr(), a["bs"].data_ptr(), a["bb"].data_ptr(), a["fin"].data_ptr()
+            bs.run_out, bs.rs_out, bs.rb_out = b["run"].data_ptr(), b["rs"].data_ptr(), b["rb"].data_ptr()
+            bs.seq_out, bs.bs_out, bs.bb_out, bs.fin_out = b["seq"].data_ptr(), b["bs"].data_ptr(), b["bb"].data_ptr(), b["fin"].data_ptr()
+            _lib.check(lib.mh_beam_step(C.byref(bs), stream), "mh_beam_step")
+            par ^= 1
+            if cfg:      # `beam_idx.repeat(2)` (cache_utils.py:18): BOTH halves take their rows from the first half; both are fed the beam's token
+                src2[:R].copy_(src)
+                src2[R:].copy_(src)
+                feed[:R].copy_(last)
+                feed[R:].copy_(last)
+            rc = lib.mh_t5_reorder_cache(C.byref(p.cfg), RE, (src2 if cfg else src).data_ptr(), cur_len, ws.data_ptr(), ws.numel(),
+                                         scratch.data_ptr(), scratch.numel(), stream)
+            _lib.check(rc, "mh_t5_reorder_cache")
+            if not cfg:
+                feed.copy_(last)
+            cur_len += 1
+            flags_host.copy_(flags, non_blocking=True)
+            engine.stream.synchronize()
+            f = flags_host.numpy()
+            go_on = bool(f[:, 0].any()) and not (bool(f[:, 2].all()) and early_stopping is True) and not bool(f[:, 1].all())
+            if not go_on:
+                break
+        fin = st[par]
+        best = fin["seq"][:, 0, :].to(torch.int64)
+        n_gen = int(((fin["bb"][:, 0, :] + 1).bool()).sum(dim=1).max())
+        out = best[:, :P + n_gen].clone()
+    engine._leave()
+    engine.synchronize()
+    return out
+
+
 @torch.no_grad()
 def beam_search(engine, cross_kv: torch.Tensor, prompt: torch.Tensor, prompt_mask: Optional[torch.Tensor], eos_ids, sp,
-                num_beams: int, length_penalty: float = 1.0, early_stopping=False, sample_fn=None) -> torch.Tensor:
+                num_beams: int, length_penalty: float = 1.0, early_stopping=False, sample_fn=None,
+                use_kernel: Optional[bool] = None) -> torch.Tensor:
     """cross_kv: the G chunks' cross K/V (engine.cross_kv); prompt int (G, P) left-padded, prompt_mask (G, P) or None.
     Under guidance (sp.cfg_scale > 1) `prompt` / `prompt_mask` carry 2G rows, [negative-prompt rows | prompt rows] (what
     T5Engine.generate and the scheduler build), and cross_kv still has G rows.
     Returns int64 (G, P + new) on the engine's device: the best hypothesis per chunk, shorter ones filled the way HF does
-    (`pad_token_id or eos_token_id[0]`: with pad id 0 that is the FIRST EOS id)."""
+    (`pad_token_id or eos_token_id[0]`: with pad id 0 that is the FIRST EOS id).
+    `use_kernel`: None = mh_beam_step whenever it covers the call (greedy beams, see kernel_path_available), False = the torch-op
+    bookkeeping below, True = the kernel or an error."""
+    can = kernel_path_available(sp, int(num_beams), engine.packed.vocab_out, len(list(eos_ids))) and sample_fn is None
+    if use_kernel is True and not can:
+        raise NotImplementedError("mh_beam_step does not cover this call (beam-sample, > 8 beams, beams x V > 16384 or K > 4096)")
+    if can and use_kernel is not False:
+        return _beam_search_kernel(engine, cross_kv, prompt, prompt_mask, eos_ids, sp, num_beams, length_penalty, early_stopping)
     dev, lib, p = engine.device, engine.lib, engine.packed
     cfg = sp.cfg_scale > 1.0
     neg_prompt = None

@@ -141,6 +141,7 @@ extern "C" int mh_struct_size(int which) {
     case 4: return (int)sizeof(MhDiTConfig);
     case 5: return (int)sizeof(MhDiTWeights);
     case 6: return (int)sizeof(MhSliderSet);
+    case 7: return (int)sizeof(MhBeamStep);
   }
   return -1;
 }

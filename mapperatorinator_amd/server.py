@@ -339,7 +339,8 @@ def model_generate(model, tokenizer, model_kwargs, generate_kwargs):
         if generate_kwargs.get("cross_kv_fp8"):
             raise NotImplementedError("cross_kv_fp8 with beam search: the step-wise beam entry streams the bf16 cross K / V")
         out = model.engine.generate_beam(audio, prompt, mask, eos, sp, sp.num_beams, negative_prompt=neg,
-                                         sample_fn=generate_kwargs.get("beam_sample_fn"), **extra)
+                                         sample_fn=generate_kwargs.get("beam_sample_fn"),
+                                         use_kernel=generate_kwargs.get("beam_use_kernel"), **extra)
     else:
         out = model.engine.generate(audio, prompt, mask, eos, sp, negative_prompt=neg, negative_mask=neg_mask,
                                     cross_kv_fp8=bool(generate_kwargs.get("cross_kv_fp8", False)), **extra)

@@ -395,7 +395,7 @@ class T5Engine:
     def generate_beam(self, audio: torch.Tensor, prompt: torch.Tensor, prompt_mask: Optional[torch.Tensor], eos_ids,
                       sampling: _lib.MhSampling, num_beams: int, row_bias: Optional[torch.Tensor] = None,
                       length_penalty: float = 1.0, early_stopping=False, negative_prompt: Optional[torch.Tensor] = None,
-                      sample_fn=None):
+                      sample_fn=None, use_kernel: Optional[bool] = None):
         """mel -> encoder -> cross K/V, then HF-style beam search over the step-wise decode entry (beam.py).  Returns
         dict(tokens=int64 CPU (B, n_cols), n_cols, logits=None) like `generate`.  `negative_prompt` with sampling.cfg_scale > 1:
         classifier-free guidance under beams (the doubled batch of modeling_mapperatorinator.py:243-254; beam.py).  With
@@ -418,7 +418,7 @@ class T5Engine:
             kv = self.cross_kv(self.encode_mel(self.mel(audio), row_bias=row_bias))
         self._leave()
         out = beam_search(self, kv, prompt, prompt_mask, eos_ids, sampling, num_beams, length_penalty, early_stopping,
-                          sample_fn=sample_fn)
+                          sample_fn=sample_fn, use_kernel=use_kernel)
         return dict(tokens=out.cpu(), n_cols=int(out.shape[1]), logits=None)
 
     def generate(self, audio: torch.Tensor, prompt: torch.Tensor, prompt_mask: Optional[torch.Tensor],

@@ -806,6 +806,23 @@ def test_fp32_beam_search_matches_reference_golden(run):
     want = g["ids_" + run]
     assert ids.shape == want.shape and np.array_equal(ids.numpy(), want), (ids.tolist(), want.tolist())
     assert ids.dtype == torch.int64 and ids.device.type == "cpu" and stats["generated_tokens"] > 0
+    if sampler is None:
+        # round 6: the greedy-beam runs above went through mh_beam_step (ONE kernel per token for the whole bookkeeping); the torch-op
+        # form of the same algorithm must return the same ids, and forcing the kernel on a beam-sample call must refuse
+        from mapperatorinator_amd import beam as _beam
+        calls = []
+        orig = _beam._beam_search_kernel
+        _beam._beam_search_kernel = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+        try:
+            ids_k, _ = model_generate(model, tok, mk, gen_kwargs(tgt, **kw))
+        finally:
+            _beam._beam_search_kernel = orig
+        assert calls and np.array_equal(ids_k.numpy(), want)
+        ids_t, _ = model_generate(model, tok, mk, gen_kwargs(tgt, beam_use_kernel=False, **kw))
+        assert np.array_equal(ids_t.numpy(), want)
+    else:
+        with pytest.raises(NotImplementedError, match="mh_beam_step"):
+            model_generate(model, tok, mk, gen_kwargs(tgt, beam_use_kernel=True, **kw))
     if sampler is not None:
         assert sampler.calls == want.shape[1] - prompt.shape[1]          # one draw of K continuations per step, all chunks at once
         torch.manual_seed(5)
