@@ -136,7 +136,7 @@ def cpu_baseline(size: str, vocab, seconds_budget: float = 25.0):
     """The CPU oracle (a port of the reference's algorithm: oracle/t5.py, torch-CPU fp32) on a BOUNDED sample of the
     headline workload."""
     from mapperatorinator_amd.t5_engine import T5_PRESETS
-    from mapperatorinator_amd.testing import random_t5_state_dict, synthetic_audio
+    from mh_testing import random_t5_state_dict, synthetic_audio
     from oracle import t5 as ot5
     cores = _cpu_threads()
     d = T5_PRESETS[size]
@@ -184,7 +184,7 @@ def cpu_baseline(size: str, vocab, seconds_budget: float = 25.0):
 def cpu_config1(vocab, new_tokens: int = 128):
     """BASELINE configs[0] (osuT5-small, ONE 10 s chunk, greedy, 128 new tokens) through the CPU port."""
     from mapperatorinator_amd.t5_engine import T5_PRESETS
-    from mapperatorinator_amd.testing import random_t5_state_dict, synthetic_audio
+    from mh_testing import random_t5_state_dict, synthetic_audio
     from oracle import t5 as ot5
     cores = _cpu_threads()
     d = T5_PRESETS["small"]
@@ -202,7 +202,7 @@ def cpu_config1(vocab, new_tokens: int = 128):
 
 def cpu_dit_baseline(n_steps: int = 6):
     """The DiT-S denoiser of configs[2] through the CPU oracle: `n_steps` forward_with_cfg calls at Tq = 128, CFG batch 2."""
-    from mapperatorinator_amd.testing import DIT_PRESETS, random_dit_state_dict, synthetic_dit_inputs
+    from mh_testing import DIT_PRESETS, random_dit_state_dict, synthetic_dit_inputs
     from oracle import dit as odit
     cores = _cpu_threads()
     depth, hidden, heads = DIT_PRESETS["DiT-S"]
@@ -265,7 +265,7 @@ def main():
     from mapperatorinator_amd.modeling import MapperatorinatorHIP
     from mapperatorinator_amd.server import build_sampling, model_generate
     from mapperatorinator_amd.t5_engine import T5_PRESETS
-    from mapperatorinator_amd.testing import random_t5_state_dict, synthetic_audio
+    from mh_testing import random_t5_state_dict, synthetic_audio
 
     lib = _lib.load()
     tdtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
@@ -360,7 +360,7 @@ def main():
            "runtime_env": runtime_env, "runtime_configure": RUNTIME}
     if not args.no_dit:
         from mapperatorinator_amd.dit import BandMask, DiTHIP, create_diffusion
-        from mapperatorinator_amd.testing import DIT_PRESETS, random_dit_state_dict, synthetic_dit_inputs
+        from mh_testing import DIT_PRESETS, random_dit_state_dict, synthetic_dit_inputs
         depth, hidden, heads = DIT_PRESETS["DiT-S"]
         dit = DiTHIP(random_dit_state_dict(depth, hidden, seed=0), depth, hidden, heads, device=dev)
         Tq = 128

@@ -22,7 +22,13 @@ import numpy as np
 import torch
 
 from . import _lib
-from .testing import DIT_PRESETS
+# osu_diffusion/utils/models.py:384-405 (depth, hidden, heads); "DiT-XS" is a test-only size
+DIT_PRESETS = {
+    "DiT-XS": (2, 128, 2),
+    "DiT-S": (12, 384, 6),
+    "DiT-B": (12, 768, 12),
+    "DiT-L": (24, 1024, 16),
+}
 
 
 def _round_up(a, b):

@@ -252,8 +252,15 @@ class MapperatorinatorHIP:
         audio = inputs if inputs is not None else frames
         if decoder_input_ids is None:
             raise ValueError("decoder_input_ids is required (the reference always passes the prompt)")
-        if encoder_outputs is not None:
-            raise NotImplementedError("generate(encoder_outputs=...) : pass the audio, the encoder is part of the hot path")
+        enc_states = None
+        if encoder_outputs is not None:      # B2: `generate(encoder_outputs=BaseModelOutput(...))` -- the encoder stage is skipped
+            enc_states = getattr(encoder_outputs, "last_hidden_state", encoder_outputs)
+            if isinstance(enc_states, (tuple, list)):
+                enc_states = enc_states[0]
+            if num_beams != 1:
+                raise NotImplementedError("generate(encoder_outputs=...) with beams: pass the audio")
+        elif audio is None:
+            raise ValueError("either inputs / frames (raw audio) or encoder_outputs is required")
         cfgm = self.config
         max_length = int(max_length or cfgm.max_target_positions)
         pad = cfgm.pad_token_id if pad_token_id is None else pad_token_id
@@ -263,7 +270,7 @@ class MapperatorinatorHIP:
         eos = [eos] if isinstance(eos, int) else list(eos)
         if sp.cfg_scale > 1.0 and negative_prompt is None:
             raise ValueError("guidance needs negative_prompt (modeling_mapperatorinator.py:243-254)")
-        row_bias = self._row_bias(decoder_input_ids.shape[0], unused)
+        row_bias = None if enc_states is not None else self._row_bias(decoder_input_ids.shape[0], unused)   # (the conditioning acts in the encoder)
         if num_beams != 1:
             if unused.get("cross_kv_fp8"):
                 raise NotImplementedError("cross_kv_fp8 with beam search: the step-wise beam entry streams the bf16 cross K / V")
@@ -275,5 +282,6 @@ class MapperatorinatorHIP:
         out = self.engine.generate(audio, decoder_input_ids, decoder_attention_mask, eos, sp,
                                    negative_prompt=negative_prompt if sp.cfg_scale > 1.0 else None,
                                    negative_mask=negative_prompt_attention_mask, cross_kv_fp8=bool(unused.get("cross_kv_fp8", False)),
+                                   encoder_states=enc_states,
                                    **({} if row_bias is None else dict(row_bias=row_bias)))
         return out["tokens"].to(self.device)

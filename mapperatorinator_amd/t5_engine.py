@@ -425,15 +425,21 @@ class T5Engine:
                  eos_ids, sampling: _lib.MhSampling, forced: Optional[torch.Tensor] = None,
                  dump_logits: bool = False, poll_every: int = 16, negative_prompt: Optional[torch.Tensor] = None,
                  negative_mask: Optional[torch.Tensor] = None, cross_kv_fp8: bool = False,
-                 row_bias: Optional[torch.Tensor] = None):
-        """Full hot path for one batch of chunks.  `cross_kv_fp8`: the token steps stream the e4m3 copy of the
+                 row_bias: Optional[torch.Tensor] = None, encoder_states: Optional[torch.Tensor] = None):
+        """Full hot path for one batch of chunks.  `encoder_states` (B, src_len, d_model): the encoder's last_hidden_state given by
+        the caller (`generate(encoder_outputs=...)` of the reference's signature) -- mel and encoder are skipped, `audio` may be None.  `cross_kv_fp8`: the token steps stream the e4m3 copy of the
         cross-attention K / V (see `cross_kv_fp8()`).  Inputs may be CPU tensors (copied like
         server.py:86-87 does).  Returns dict(tokens=int64 CPU (B, n_cols), logits=..., n_cols=int).
         With `negative_prompt` (classifier-free guidance) the decode batch is doubled the way the reference's
         prepare_inputs_for_generation does it (modeling_mapperatorinator.py:243-254): the first half carries the
         negative prompt over the first columns of the prompt; the returned rows are the prompt rows."""
         dev = self.device
-        audio = audio.to(dev, torch.float32)
+        if encoder_states is None:
+            audio = audio.to(dev, torch.float32)
+        else:
+            encoder_states = encoder_states.to(dev, self.dtype).contiguous()
+            if tuple(encoder_states.shape) != (prompt.shape[0], self.packed.src_len, self.dims.d_model):
+                raise ValueError(f"encoder_states must be ({prompt.shape[0]}, {self.packed.src_len}, {self.dims.d_model}), got {tuple(encoder_states.shape)}")
         G = prompt.shape[0]
         cfg = negative_prompt is not None
         if cfg != (sampling.cfg_scale > 1.0):
@@ -461,7 +467,7 @@ class T5Engine:
         eos_table = eos_table.to(dev)
         self._enter()
         with torch.cuda.stream(self.stream):
-            enc = self.encode_mel(self.mel(audio), row_bias=row_bias)
+            enc = encoder_states if encoder_states is not None else self.encode_mel(self.mel(audio), row_bias=row_bias)
             kv = self.cross_kv(enc)
             kv8 = self.cross_kv_fp8(kv) if cross_kv_fp8 else None
             tokens, n_out, logits = self.decode(kv, prompt_d, mask_d, eos_table, sampling, forced_d, dump_logits,

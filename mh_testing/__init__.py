@@ -1,5 +1,5 @@
-"""Deterministic synthetic inputs / random-init weights shared by tests, bench.py and the golden
-generator (oracle/make_golden.py).  numpy's PCG64 stream is platform-stable, so the GPU box
+"""TEST SUPPORT (not part of the product package; round 6 moved it out of mapperatorinator_amd/): deterministic synthetic inputs /
+random-init weights shared by tests, bench.py, tools/ and the golden generator (oracle/make_golden.py).  numpy's PCG64 stream is platform-stable, so the GPU box
 regenerates bit-identical weights from a seed instead of shipping 100s of MB of fixtures.
 
 Weight scales follow HF `T5PreTrainedModel._init_weights` (factor 1.0) and the reference wrapper's
@@ -16,7 +16,7 @@ from typing import Optional
 import numpy as np
 import torch
 
-from .t5_engine import T5Dims
+from mapperatorinator_amd.t5_engine import T5Dims
 
 
 def _normal(rng, shape, std):
@@ -293,12 +293,7 @@ def synthetic_audio_varied(batch: int, n_samples: int = 160000, seed: int = 0) -
 
 
 # ---- DiT ------------------------------------------------------------------------------------------
-DIT_PRESETS = {  # osu_diffusion/utils/models.py:384-405 (depth, hidden, heads)
-    "DiT-XS": (2, 128, 2),  # test-only
-    "DiT-S": (12, 384, 6),
-    "DiT-B": (12, 768, 12),
-    "DiT-L": (24, 1024, 16),
-}
+from mapperatorinator_amd.dit import DIT_PRESETS  # noqa: E402,F401  (depth, hidden, heads) per preset name
 
 
 def random_dit_state_dict(depth: int, hidden: int, context_size: int = 272, class_size: int = 300, seed: int = 0,
@@ -349,7 +344,7 @@ def boost_timed_rows(sd: dict, tok, gain: float) -> dict:
     """Random weights almost never emit a timed event (CIRCLE, BEAT, HOLD_NOTE ...); scale their lm_head rows so that
     the types_first processors, which key on them, fire in the parity cases.  In place; used identically by
     oracle/make_golden.py and the tests."""
-    from .server import TIMED_EVENT_NAMES, _ev, _has
+    from mapperatorinator_amd.server import TIMED_EVENT_NAMES, _ev, _has
     w = sd["transformer.lm_head.weight"]
     for name in TIMED_EVENT_NAMES:
         if _has(tok.event_start, name):
@@ -372,7 +367,7 @@ def synthetic_sliders(T: int, seed: int, every: int = 9):
     """DiffusionSlider lists over the points of `synthetic_hit_objects`: head, 1-6 anchors (a red anchor = the same point
     twice, as `events_to_sequence` emits it), last anchor, and the slider end as the next point; curve types cycle through
     Bezier / PerfectCurve / Catmull.  Consecutive sliders use disjoint points, like a real event stream."""
-    from .diffusion_pipeline import DiffusionSlider
+    from mapperatorinator_amd.diffusion_pipeline import DiffusionSlider
     rng = np.random.default_rng(seed)
     out, i, k = [], 2, 0
     while i + 9 < T:
@@ -424,7 +419,7 @@ def synthetic_event_stream(n_objects: int, seed: int, *, types_first: bool = Fal
     between.  `oddities` adds what a sampled stream can contain and the reference's code tolerates: a coordinate of 0,
     a distance of 0, a slider head without scroll speed, anchors and a slider end without a head, a slider end straight
     after the head, attribute events no type token claims at the very end."""
-    from .event import Event, EventType as ET
+    from mapperatorinator_amd.event import Event, EventType as ET
     rng = np.random.default_rng(seed)
     ev, t = [], 0
 

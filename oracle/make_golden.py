@@ -18,7 +18,7 @@ import numpy as np
 import torch
 
 from mapperatorinator_amd.t5_engine import T5_PRESETS
-from mapperatorinator_amd.testing import (DIT_PRESETS, DIVERSE_GAINS, boost_timed_rows, random_dit_state_dict,
+from mh_testing import (DIT_PRESETS, DIVERSE_GAINS, boost_timed_rows, random_dit_state_dict,
                                           random_t5_state_dict, synthetic_audio, synthetic_audio_varied,
                                           synthetic_dit_inputs)
 
@@ -109,7 +109,7 @@ def t5_conditioning_case(name="t5_tiny_cond"):
     """The wrapper's conditioning embedders (difficulty, mapper style, song position; modeling_mapperatorinator.py:104-128,
     395-414) on the reference: the per-row conditioning vectors its own modules produce, the encoder states with them
     concatenated to the mel frames, and the greedy ids -- plus the ids WITHOUT conditioning, to show it matters."""
-    from mapperatorinator_amd.testing import add_random_conditioning
+    from mh_testing import add_random_conditioning
     c = COND_CASE
     model, tok, _ = rh.build_reference_t5(c["size"], src_seq_len=c["src"], tgt_seq_len=c["tgt"],
                                           cond=dict(cond_dim=c["cond_dim"], num_mappers=c["num_mappers"]))
@@ -239,7 +239,7 @@ def vw_case(name):
     """The Whisper-family backbone on the REFERENCE: `Mapperatorinator` over VarWhisperForConditionalGeneration
     (custom_transformers/modeling_varwhisper.py) as configs/model/varwhisper_*_v3.yaml wire it, through the reference's own
     `model_generate`: log-mel slice, encoder states, greedy ids, the 16 best processed scores of every step."""
-    from mapperatorinator_amd.testing import random_varwhisper_state_dict
+    from mh_testing import random_varwhisper_state_dict
     from mapperatorinator_amd.whisper_engine import VARWHISPER_PRESETS
     c = VW_CASES[name]
     d = VARWHISPER_PRESETS[c["size"]]
@@ -297,7 +297,7 @@ WF_CASES = {
 
 def wf_weights(c, tok):
     """state dict of a WF_CASES entry from its seeds (shared with tests/conftest.py:wf_golden_case)"""
-    from mapperatorinator_amd.testing import add_random_cond_embedders, random_whisper_family_state_dict
+    from mh_testing import add_random_cond_embedders, random_whisper_family_state_dict
     from mapperatorinator_amd.whisper_engine import VARWHISPER_PRESETS
     d = VARWHISPER_PRESETS[c["size"]]
     cd = c["cond"]
@@ -389,7 +389,7 @@ def beam_case(name="t5_tiny_beam"):
     out = dict(vocab_in=tok.vocab_size_in, vocab_out=tok.vocab_size_out, prompt=prompt.numpy(), negative=neg.numpy(), runs=json.dumps(c["runs"]),
                sample_seeds=json.dumps(c["sample_seeds"]),
                **{k: v for k, v in c.items() if k not in ("prompts", "runs", "negative", "sample_seeds")})
-    from mapperatorinator_amd.testing import SeededMultinomial
+    from mh_testing import SeededMultinomial
     for tag, kw in c["runs"].items():
         ng = neg if kw.get("cfg_scale", 1.0) > 1.0 else None
         real_multinomial = torch.multinomial
@@ -485,7 +485,7 @@ def pipeline_case():
     """Reference `DiffisionPipeline.generate` (window loop, in-paint masks with start/end time, refine steps) on
     synthetic hit objects, gaussian draws injected from a numpy stream (one draw per p_sample call, in call order)."""
     from mapperatorinator_amd.diffusion_pipeline import points_to_sequence
-    from mapperatorinator_amd.testing import pipeline_windows, synthetic_hit_objects, synthetic_sliders
+    from mh_testing import pipeline_windows, synthetic_hit_objects, synthetic_sliders
     c = PIPE_CASE
     depth, hidden, heads = DIT_PRESETS[c["preset"]]
     sd = random_dit_state_dict(depth, hidden, seed=c["weight_seed"])
@@ -505,7 +505,7 @@ def pipeline_case():
     start_time, end_time = float(times[20]), float(times[280])
     out = {}
     # "short": 2 DDPM steps + 1 refine step per window -- errors cannot compound, pins the window / mask logic tightly
-    # "sliders": the slider end re-projection of `denoised_fn` on synthetic sliders (mapperatorinator_amd.testing)
+    # "sliders": the slider end re-projection of `denoised_fn` on synthetic sliders (mh_testing)
     sliders = synthetic_sliders(c["T"], c["point_seed"] + 1)
     for tag, kk, seed in (("", k, c["noise_seed"]),
                           ("_short", dict(k, timesteps=[2] + [0] * 9, refine_iters=1), c["noise_seed"] + 1),
@@ -657,9 +657,9 @@ GEN_CASE = dict(preset="DiT-XS", weight_seed=33, event_seed=12, objects=70, toke
 def events_case():
     """Row a14's host code run through the REFERENCE: `update_event_times`, `events_to_sequence` (get_groups inside),
     `events_with_pos`, and one whole `DiffisionPipeline.generate` (events in, events out, nothing replaced) on the event
-    streams of `mapperatorinator_amd.testing.synthetic_event_stream`."""
+    streams of `mh_testing.synthetic_event_stream`."""
     import types
-    from mapperatorinator_amd.testing import (pipeline_windows, synthetic_diffusion_tokenizer_state, synthetic_event_stream,
+    from mh_testing import (pipeline_windows, synthetic_diffusion_tokenizer_state, synthetic_event_stream,
                                               synthetic_timing)
     rh.ref_shims.install()
     import diffusion_pipeline as dp

@@ -36,7 +36,7 @@ def main():
     ap.add_argument("--dit-steps", type=int, default=20)
     args = ap.parse_args()
     torch.set_num_threads(args.threads)
-    from mapperatorinator_amd.testing import synthetic_audio, synthetic_dit_inputs
+    from mh_testing import synthetic_audio, synthetic_dit_inputs
     from oracle import dit as odit
     from oracle import ref_harness as rh
     rec = {"what": "the unmodified reference (/root/reference) on this container's CPU, via oracle/ref_harness.py",

@@ -32,7 +32,7 @@ def t5_golden_case(name):
 
     from mapperatorinator_amd import Tokenizer
     from mapperatorinator_amd.t5_engine import T5_PRESETS
-    from mapperatorinator_amd.testing import DIVERSE_GAINS, random_t5_state_dict, synthetic_audio, synthetic_audio_varied
+    from mh_testing import DIVERSE_GAINS, random_t5_state_dict, synthetic_audio, synthetic_audio_varied
     g = np.load(f"{GOLDEN}/{name}.npz")
     size = name.split("_")[1]
     src, tgt = int(g["src_len"]), int(g["tgt_len"])
@@ -53,7 +53,7 @@ def vw_golden_case(name):
     import numpy as np
 
     from mapperatorinator_amd import Tokenizer
-    from mapperatorinator_amd.testing import random_varwhisper_state_dict, synthetic_audio_varied
+    from mh_testing import random_varwhisper_state_dict, synthetic_audio_varied
     from mapperatorinator_amd.whisper_engine import VARWHISPER_PRESETS
     g = np.load(f"{GOLDEN}/{name}.npz")
     d = VARWHISPER_PRESETS[str(g["size"])]
@@ -74,7 +74,7 @@ def wf_golden_case(name):
     import torch
 
     from mapperatorinator_amd import Tokenizer
-    from mapperatorinator_amd.testing import add_random_cond_embedders, random_whisper_family_state_dict, synthetic_audio_varied
+    from mh_testing import add_random_cond_embedders, random_whisper_family_state_dict, synthetic_audio_varied
     from mapperatorinator_amd.whisper_engine import VARWHISPER_PRESETS
     g = np.load(f"{GOLDEN}/{name}.npz")
     kind = str(g["kind"])
@@ -129,7 +129,7 @@ def types_first_case():
 
     from mapperatorinator_amd import Tokenizer
     from mapperatorinator_amd.t5_engine import T5_PRESETS
-    from mapperatorinator_amd.testing import boost_timed_rows, random_t5_state_dict, synthetic_audio
+    from mh_testing import boost_timed_rows, random_t5_state_dict, synthetic_audio
     g = np.load(f"{GOLDEN}/t5_tiny_tf.npz")
     tok = Tokenizer.from_json(f"{GOLDEN}/tokenizer_types_first.json")
     assert tok.vocab_size_out == int(g["vocab_out"]) and tok.vocab_size_in == int(g["vocab_in"])

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 def setup(name):
     from mapperatorinator_amd.dit import DiTHIP
-    from mapperatorinator_amd.testing import DIT_PRESETS, random_dit_state_dict, synthetic_dit_inputs
+    from mh_testing import DIT_PRESETS, random_dit_state_dict, synthetic_dit_inputs
     from oracle import dit as odit
     g = np.load(f"{GOLDEN}/{name}.npz")
     preset = str(g["preset"])
@@ -138,7 +138,7 @@ def test_one_chunk_skinny_forms_ragged_T_and_large_mean_rows(preset, T):
     dit_skinny_kernel are two-pass now (DiT-S: in registers; DiT-B: the ln_modulate pass in front of the PLAIN wide form, round 6).
     Gate: eps within 2e-4 of the CPU oracle (fp32 torch, F.layer_norm), as for the goldens."""
     from mapperatorinator_amd.dit import BandMask, DiTHIP
-    from mapperatorinator_amd.testing import DIT_PRESETS, random_dit_state_dict, synthetic_dit_inputs
+    from mh_testing import DIT_PRESETS, random_dit_state_dict, synthetic_dit_inputs
     from oracle import dit as odit
     depth, hidden, heads = DIT_PRESETS[preset]
     sd = random_dit_state_dict(depth, hidden, seed=6)
@@ -218,7 +218,7 @@ def test_dit_b_full_size_properties():
     """DiT-B at T=1024 (max window): finite, CFG halves identical, band locality (perturbing a point
     further than band*depth away cannot change a far query... checked at depth-1 granularity)."""
     from mapperatorinator_amd.dit import DiTHIP
-    from mapperatorinator_amd.testing import DIT_PRESETS, random_dit_state_dict, synthetic_dit_inputs
+    from mh_testing import DIT_PRESETS, random_dit_state_dict, synthetic_dit_inputs
     from oracle import dit as odit
     depth, hidden, heads = DIT_PRESETS["DiT-B"]
     sd = random_dit_state_dict(depth, hidden, seed=4)
@@ -248,7 +248,7 @@ def test_generate_events_in_events_out_matches_the_reference_golden():
 
     from mapperatorinator_amd.diffusion_pipeline import DiffusionPipelineHIP, DiffusionTokenizer
     from mapperatorinator_amd.dit import DiTHIP
-    from mapperatorinator_amd.testing import (DIT_PRESETS, random_dit_state_dict, synthetic_diffusion_tokenizer_state,
+    from mh_testing import (DIT_PRESETS, random_dit_state_dict, synthetic_diffusion_tokenizer_state,
                                               synthetic_event_stream, synthetic_timing)
     g = np.load(f"{GOLDEN}/events_to_sequence.npz")
     c = json.loads(str(g["gen_case"]))
@@ -300,7 +300,7 @@ def test_window_pipeline_matches_reference_golden(variant):
 
     from mapperatorinator_amd.diffusion_pipeline import DiffusionPipelineHIP, points_to_sequence
     from mapperatorinator_amd.dit import DiTHIP
-    from mapperatorinator_amd.testing import DIT_PRESETS, random_dit_state_dict, synthetic_hit_objects, synthetic_sliders
+    from mh_testing import DIT_PRESETS, random_dit_state_dict, synthetic_hit_objects, synthetic_sliders
     g = np.load(f"{GOLDEN}/dit_pipeline.npz")
     c = json.loads(str(g["case"]))
     depth, hidden, heads = DIT_PRESETS[c["preset"]]
@@ -379,7 +379,7 @@ def test_reference_closure_protocol_on_the_device_vs_pipeline_golden():
 
     from mapperatorinator_amd.diffusion_pipeline import DiffusionPipelineHIP, points_to_sequence
     from mapperatorinator_amd.dit import DiTHIP
-    from mapperatorinator_amd.testing import DIT_PRESETS, random_dit_state_dict, synthetic_hit_objects
+    from mh_testing import DIT_PRESETS, random_dit_state_dict, synthetic_hit_objects
     g = np.load(f"{GOLDEN}/dit_pipeline.npz")
     c = json.loads(str(g["case"]))
     depth, hidden, heads = DIT_PRESETS[c["preset"]]
@@ -430,7 +430,7 @@ def test_batched_chunks_equal_independent_runs(variant):
     from mapperatorinator_amd import _lib
     from mapperatorinator_amd.diffusion_pipeline import DiffusionPipelineHIP, points_to_sequence
     from mapperatorinator_amd.dit import DiTHIP
-    from mapperatorinator_amd.testing import DIT_PRESETS, random_dit_state_dict, synthetic_hit_objects
+    from mh_testing import DIT_PRESETS, random_dit_state_dict, synthetic_hit_objects
     g = np.load(f"{GOLDEN}/dit_pipeline.npz")
     c = json.loads(str(g["case"]))
     depth, hidden, heads = DIT_PRESETS[c["preset"]]
@@ -513,7 +513,7 @@ def test_batched_denoiser_eps_vs_oracle_per_chunk(B):
     tiles start; B = 32: 8192 rows = the shape bench.py's config 3 runs): every chunk's CFG-combined eps within 2e-4 of
     the CPU oracle run on that chunk alone -- the same gate as the single-chunk golden tests."""
     from mapperatorinator_amd.dit import BandMask, DiTHIP
-    from mapperatorinator_amd.testing import DIT_PRESETS, random_dit_state_dict, synthetic_dit_inputs
+    from mh_testing import DIT_PRESETS, random_dit_state_dict, synthetic_dit_inputs
     from oracle import dit as odit
     depth, hidden, heads = DIT_PRESETS["DiT-S"]
     sd = random_dit_state_dict(depth, hidden, seed=4)
@@ -625,7 +625,7 @@ def test_bf16_operand_mode_error_bounds(name):
     itself ends up to 0.8 / 4.8 px from the reference at its worst point), so the per-evaluation gates are the parity
     statement of this mode and the trajectory gate is a sanity bound."""
     from mapperatorinator_amd.dit import DiTHIP, create_diffusion
-    from mapperatorinator_amd.testing import DIT_PRESETS, random_dit_state_dict
+    from mh_testing import DIT_PRESETS, random_dit_state_dict
     from oracle import dit as odit
     g, dit32, orc, z, c, y, mask, cfg = setup(name)
     depth, hidden, heads = DIT_PRESETS[str(g["preset"])]
@@ -668,7 +668,7 @@ def test_padded_window_at_the_pipeline_default_size_vs_oracle():
     operands, the flash fp32 kernel's `open_from` mask and its pre-split output all meet.  eps against the oracle under the
     padded mask tensor the reference builds (band padded with "allowed")."""
     from mapperatorinator_amd.dit import BandMask, DiTHIP
-    from mapperatorinator_amd.testing import DIT_PRESETS, random_dit_state_dict, synthetic_dit_inputs
+    from mh_testing import DIT_PRESETS, random_dit_state_dict, synthetic_dit_inputs
     from oracle import dit as odit
     depth, hidden, heads = DIT_PRESETS["DiT-S"]
     sd = random_dit_state_dict(depth, hidden, seed=5)
@@ -699,7 +699,7 @@ def test_mx8_operand_mode_error_bounds(name):
       eps vs the fp32 REFERENCE golden -- what the mode costs (e4m3 carries 3 mantissa bits);
       one p_sample step from the reference's x: worst position error in pixels."""
     from mapperatorinator_amd.dit import DiTHIP, create_diffusion
-    from mapperatorinator_amd.testing import DIT_PRESETS, random_dit_state_dict
+    from mh_testing import DIT_PRESETS, random_dit_state_dict
     from oracle import dit as odit
     g, dit32, orc, z, c, y, mask, cfg = setup(name)
     depth, hidden, heads = DIT_PRESETS[str(g["preset"])]

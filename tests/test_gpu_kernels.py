@@ -417,7 +417,7 @@ def test_attention(dtype_name, case):
 @pytest.mark.parametrize("B,ns", [(1, 16000), (3, 160000), (2, 32000 + 77)])
 def test_mel_vs_oracle(B, ns):
     from mapperatorinator_amd.mel import MelSpectrogram
-    from mapperatorinator_amd.testing import synthetic_audio
+    from mh_testing import synthetic_audio
     from oracle import mel as omel
     a = synthetic_audio(B, ns, seed=9)
     m = MelSpectrogram().cuda()
@@ -449,7 +449,7 @@ def test_mel_torchaudio_parameterisation_vs_oracle(ns):
     from 20 Hz, reflect padding) against the torch.stft restatement of that branch (oracle/mel.py; parity unpinned:
     torchaudio itself is not installed).  The edge frames are the ones reflect padding changes."""
     from mapperatorinator_amd.mel import MelSpectrogram
-    from mapperatorinator_amd.testing import synthetic_audio
+    from mh_testing import synthetic_audio
     from oracle import mel as omel
     a = synthetic_audio(2, ns, seed=4)
     m = MelSpectrogram(implementation="torchaudio", log_scale=True, n_mels=128, f_min=20, pad_mode="reflect").cuda()

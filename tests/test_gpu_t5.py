@@ -226,7 +226,7 @@ def test_bf16_headline_batch_teacher_forced_vs_oracle():
     from mapperatorinator_amd import Tokenizer
     from mapperatorinator_amd.server import build_sampling
     from mapperatorinator_amd.t5_engine import T5_PRESETS
-    from mapperatorinator_amd.testing import DIVERSE_GAINS, random_t5_state_dict, synthetic_audio_varied
+    from mh_testing import DIVERSE_GAINS, random_t5_state_dict, synthetic_audio_varied
     src, tgt, B = 1251, 385, 32
     tok = Tokenizer.benchmark_vocab(src_seq_len=src)
     sd = random_t5_state_dict(T5_PRESETS["base"], tok.vocab_size_in, tok.vocab_size_out, seed=17, lm_head_gain=4.0,
@@ -307,7 +307,7 @@ def test_bf16_cfg_and_types_first_teacher_forced(size):
     encoder window (the d_model = 768 instantiations of the fused-projection kernels, K/V rows shared by a pair)."""
     from mapperatorinator_amd.server import build_sampling
     from mapperatorinator_amd.t5_engine import T5_PRESETS
-    from mapperatorinator_amd.testing import boost_timed_rows, random_t5_state_dict, synthetic_audio
+    from mh_testing import boost_timed_rows, random_t5_state_dict, synthetic_audio
     g, tok, sd, audio, tgt, runs = types_first_case()
     src = int(g["src"])
     prompt, neg = torch.from_numpy(g["prompt"]), torch.from_numpy(g["negative"])
@@ -364,7 +364,7 @@ def test_fp32_fresh_seeds_vs_oracle(seed):
     from mapperatorinator_amd import Tokenizer
     from mapperatorinator_amd.server import build_sampling
     from mapperatorinator_amd.t5_engine import T5_PRESETS
-    from mapperatorinator_amd.testing import random_t5_state_dict, synthetic_audio
+    from mh_testing import random_t5_state_dict, synthetic_audio
     src, tgt = 251, 40
     tok = Tokenizer.benchmark_vocab(src_seq_len=src)
     sd = random_t5_state_dict(T5_PRESETS["tiny"], tok.vocab_size_in, tok.vocab_size_out, seed=seed, lm_head_gain=8.0)
@@ -398,7 +398,7 @@ def test_bf16_teacher_forced_vs_bf16_oracle(size, B, src, ns, tgt):
     from mapperatorinator_amd import Tokenizer
     from mapperatorinator_amd.server import build_sampling
     from mapperatorinator_amd.t5_engine import T5_PRESETS
-    from mapperatorinator_amd.testing import random_t5_state_dict, synthetic_audio
+    from mh_testing import random_t5_state_dict, synthetic_audio
     tok = Tokenizer.benchmark_vocab(src_seq_len=src)
     sd = random_t5_state_dict(T5_PRESETS[size], tok.vocab_size_in, tok.vocab_size_out, seed=77, lm_head_gain=6.0)
     model = build(size, tok, sd, src, tgt, torch.bfloat16)
@@ -446,7 +446,7 @@ def test_full_size_base_bf16_properties():
     from mapperatorinator_amd import Tokenizer
     from mapperatorinator_amd.server import model_generate
     from mapperatorinator_amd.t5_engine import T5_PRESETS
-    from mapperatorinator_amd.testing import random_t5_state_dict, synthetic_audio
+    from mh_testing import random_t5_state_dict, synthetic_audio
     src, tgt, B = 1251, 96, 32
     tok = Tokenizer.benchmark_vocab(src_seq_len=src)
     sd = random_t5_state_dict(T5_PRESETS["base"], tok.vocab_size_in, tok.vocab_size_out, seed=5, lm_head_gain=6.0)
@@ -492,7 +492,7 @@ def test_rows_do_not_depend_on_the_rows_beside_them(dtype, B, chains):
     from mapperatorinator_amd import Tokenizer, _lib
     from mapperatorinator_amd.server import build_sampling
     from mapperatorinator_amd.t5_engine import T5_PRESETS
-    from mapperatorinator_amd.testing import random_t5_state_dict, synthetic_audio
+    from mh_testing import random_t5_state_dict, synthetic_audio
     src, tgt = 251, 48
     tok = Tokenizer.benchmark_vocab(src_seq_len=src)
     sd = random_t5_state_dict(T5_PRESETS["small"], tok.vocab_size_in, tok.vocab_size_out, seed=9, lm_head_gain=6.0)
@@ -527,7 +527,7 @@ def test_sampling_topk_topp_distribution():
     from mapperatorinator_amd import Tokenizer
     from mapperatorinator_amd.server import build_sampling
     from mapperatorinator_amd.t5_engine import T5_PRESETS
-    from mapperatorinator_amd.testing import random_t5_state_dict, synthetic_audio
+    from mh_testing import random_t5_state_dict, synthetic_audio
     src, tgt, B = 251, 24, 64
     tok = Tokenizer.benchmark_vocab(src_seq_len=src)
     sd = random_t5_state_dict(T5_PRESETS["tiny"], tok.vocab_size_in, tok.vocab_size_out, seed=31, lm_head_gain=2.0)
@@ -581,7 +581,7 @@ def test_long_left_padded_prompts_batched_prefill(dtype):
     from mapperatorinator_amd import Tokenizer
     from mapperatorinator_amd.server import build_sampling
     from mapperatorinator_amd.t5_engine import T5_PRESETS
-    from mapperatorinator_amd.testing import random_t5_state_dict, synthetic_audio
+    from mh_testing import random_t5_state_dict, synthetic_audio
     src, tgt, B, P = 251, 80, 5, 45
     tok = Tokenizer.benchmark_vocab(src_seq_len=src)
     sd = random_t5_state_dict(T5_PRESETS["tiny"], tok.vocab_size_in, tok.vocab_size_out, seed=404, lm_head_gain=8.0)
@@ -682,7 +682,7 @@ def test_window_scheduler_matches_sequential_loop(beams, monkeypatch):
     from mapperatorinator_amd.scheduler import SequentialWindowScheduler, SongJob
     from mapperatorinator_amd.server import model_generate
     g, size, tok, sd, _, src, tgt = golden_case("t5_tiny")
-    from mapperatorinator_amd.testing import synthetic_audio
+    from mh_testing import synthetic_audio
     model = build(size, tok, sd, src, tgt, torch.float32)
     n_windows = [3, 2, 4]
     songs = [synthetic_audio(n, int(g["n_samples"]), seed=40 + k) for k, n in enumerate(n_windows)]
@@ -787,7 +787,7 @@ def test_fp32_beam_search_matches_reference_golden(run):
     from mapperatorinator_amd import Tokenizer
     from mapperatorinator_amd.server import model_generate
     from mapperatorinator_amd.t5_engine import T5_PRESETS
-    from mapperatorinator_amd.testing import DIVERSE_GAINS, SeededMultinomial, random_t5_state_dict, synthetic_audio_varied
+    from mh_testing import DIVERSE_GAINS, SeededMultinomial, random_t5_state_dict, synthetic_audio_varied
     g = np.load(f"{GOLDEN}/t5_tiny_beam.npz")
     src, tgt = int(g["src"]), int(g["tgt"])
     tok = Tokenizer.benchmark_vocab(src_seq_len=src)
@@ -832,6 +832,29 @@ def test_fp32_beam_search_matches_reference_golden(run):
         assert torch.equal(own, again) and own.shape[0] == want.shape[0] and not np.array_equal(own.numpy()[:, :want.shape[1]], want)
 
 
+def test_generate_with_encoder_outputs_of_the_reference_signature():
+    """`Mapperatorinator.generate(encoder_outputs=BaseModelOutput(last_hidden_state=...))` -- the route the oracle harness
+    itself drives the reference through (oracle/ref_harness.py reference_generate).  The HIP object takes the states `get_encoder()`
+    returned and must produce the ids of the audio route."""
+    import types as _types
+    from mapperatorinator_amd.t5_engine import T5_PRESETS
+    g, size, tok, sd, audio, src, tgt = t5_golden_case("t5_tiny")
+    model = build(size, tok, sd, src, tgt, torch.float32)
+    prompt = torch.from_numpy(g["prompt"])
+    enc = model.get_encoder()(frames=audio).last_hidden_state
+    assert enc.shape == (audio.shape[0], src, T5_PRESETS[size].d_model)
+    kw = dict(decoder_input_ids=prompt, decoder_attention_mask=prompt.ne(0), max_length=tgt, do_sample=False, eos_token_id=[tok.eos_id])
+    a = model.generate(inputs=audio, **kw).cpu()
+    b = model.generate(encoder_outputs=_types.SimpleNamespace(last_hidden_state=enc), **kw).cpu()
+    # (no logits_processor list here, so these are not the golden's ids -- model_generate adds the reference's processors; the two
+    # ROUTES must agree bit for bit)
+    assert torch.equal(a, b) and a.shape[1] > prompt.shape[1]
+    with pytest.raises(ValueError, match="encoder_states"):
+        model.generate(encoder_outputs=_types.SimpleNamespace(last_hidden_state=enc[:, :-1]), **kw)
+    with pytest.raises(ValueError, match="either inputs"):
+        model.generate(**kw)
+
+
 def test_request_batcher_answers_every_request_like_a_call_of_its_own():
     """`RequestBatcher` (the batching policy of the reference's InferenceServer, server.py:343-424) over the HIP engine:
     six requests with ragged batch sizes and prompt widths in two generate-kwargs groups, max_batch_size 16.  Batches:
@@ -842,7 +865,7 @@ def test_request_batcher_answers_every_request_like_a_call_of_its_own():
     from mapperatorinator_amd import Tokenizer
     from mapperatorinator_amd.server import RequestBatcher, model_generate
     from mapperatorinator_amd.t5_engine import T5_PRESETS
-    from mapperatorinator_amd.testing import random_t5_state_dict, synthetic_audio
+    from mh_testing import random_t5_state_dict, synthetic_audio
     src, tgt = 251, 40
     tok = Tokenizer.benchmark_vocab(src_seq_len=src)
     sd = random_t5_state_dict(T5_PRESETS["small"], tok.vocab_size_in, tok.vocab_size_out, seed=21, lm_head_gain=6.0)
@@ -937,7 +960,7 @@ def test_mx8_one_encoder_block_against_the_contract_oracle(size):
     from mapperatorinator_amd import Tokenizer
     from mapperatorinator_amd.modeling import MapperatorinatorHIP
     from mapperatorinator_amd.t5_engine import T5_PRESETS
-    from mapperatorinator_amd.testing import random_t5_state_dict, synthetic_audio_varied
+    from mh_testing import random_t5_state_dict, synthetic_audio_varied
     from oracle import t5 as ot5
     src, tgt = 1251, 16
     d = dataclasses.replace(T5_PRESETS[size], n_enc_layers=1, n_dec_layers=1)

@@ -73,7 +73,7 @@ def test_fp32_matches_reference_golden(name):
 def test_bf16_teacher_forced_vs_bf16_oracle(size, B, frames, tgt):
     from mapperatorinator_amd import Tokenizer
     from mapperatorinator_amd.server import build_sampling
-    from mapperatorinator_amd.testing import random_varwhisper_state_dict, synthetic_audio_varied
+    from mh_testing import random_varwhisper_state_dict, synthetic_audio_varied
     from mapperatorinator_amd.whisper_engine import VARWHISPER_PRESETS
     from oracle import varwhisper as ovw
     d = VARWHISPER_PRESETS[size]
@@ -254,7 +254,7 @@ def test_whisper_family_bf16_teacher_forced_vs_bf16_oracle(kind, size, B, frames
     from mapperatorinator_amd import Tokenizer
     from mapperatorinator_amd.modeling import MapperatorinatorHIP
     from mapperatorinator_amd.server import build_sampling
-    from mapperatorinator_amd.testing import random_whisper_family_state_dict, synthetic_audio_varied
+    from mh_testing import random_whisper_family_state_dict, synthetic_audio_varied
     from mapperatorinator_amd.whisper_engine import VARWHISPER_PRESETS
     from oracle import whisper_family as wf
     d = VARWHISPER_PRESETS[size]

@@ -259,7 +259,7 @@ def test_diffusion_pipeline_host_glue():
 
     from conftest import GOLDEN
     from mapperatorinator_amd.diffusion_pipeline import band_mask, points_to_sequence, repeat_type
-    from mapperatorinator_amd.testing import pipeline_windows, synthetic_hit_objects
+    from mh_testing import pipeline_windows, synthetic_hit_objects
     g = np.load(f"{GOLDEN}/dit_pipeline.npz")
     c = json.loads(str(g["case"]))
     x, y, times, dist, typ = synthetic_hit_objects(c["T"], c["point_seed"])
@@ -293,7 +293,7 @@ def test_events_to_sequence_matches_the_reference_golden():
     `events_with_pos` (tests/golden/events_to_sequence.npz, oracle/make_golden.py `events`) -- bit for bit: it is integer
     bookkeeping plus the same torch ops in the same order."""
     from mapperatorinator_amd import diffusion_pipeline as dp
-    from mapperatorinator_amd.testing import synthetic_event_stream, synthetic_timing
+    from mh_testing import synthetic_event_stream, synthetic_timing
     g, cases = _golden_events()
     curves = ["Bezier", "PerfectCurve", "Catmull"]
     for seed, n_obj, tf, wp in cases:
@@ -335,7 +335,7 @@ def test_diffusion_tokenizer_and_class_vector():
     [styles | difficulties | mappers | descriptors | circle sizes], unknown = the family's last id, clipping at both ends,
     the state round trip, and a family that is absent from the state."""
     from mapperatorinator_amd.diffusion_pipeline import DiffusionGenerationConfig, DiffusionTokenizer, get_class_vector
-    from mapperatorinator_amd.testing import synthetic_diffusion_tokenizer_state
+    from mh_testing import synthetic_diffusion_tokenizer_state
     st = synthetic_diffusion_tokenizer_state(8)
     tok = DiffusionTokenizer(st)
     n = [st["num_classes"], st["num_diff_classes"], st["num_mapper_classes"], st["num_descriptor_classes"], st["num_cs_classes"]]
@@ -392,7 +392,7 @@ def test_diffusion_generate_host_flow_on_a_stand_in_denoiser():
     without hit objects is returned untouched and never reaches the stage."""
     import types
     from mapperatorinator_amd import diffusion_pipeline as dp
-    from mapperatorinator_amd.testing import synthetic_diffusion_tokenizer_state, synthetic_event_stream, synthetic_timing
+    from mh_testing import synthetic_diffusion_tokenizer_state, synthetic_event_stream, synthetic_timing
     tok = dp.DiffusionTokenizer(synthetic_diffusion_tokenizer_state(8))
     pipe = dp.DiffusionPipelineHIP(types.SimpleNamespace(device="cpu"), timesteps=[2] + [0] * 9, tokenizer=tok, types_first=True, has_sv=True)
     seen = {}
@@ -619,7 +619,7 @@ def test_window_scheduler_hands_per_window_conditioning_to_the_encoder():
     from mapperatorinator_amd.conditioning import ConditioningEmbedders
     from mapperatorinator_amd.scheduler import SequentialWindowScheduler, SongJob
     from mapperatorinator_amd.t5_engine import T5_PRESETS
-    from mapperatorinator_amd.testing import add_random_conditioning, random_t5_state_dict
+    from mh_testing import add_random_conditioning, random_t5_state_dict
     tok = Tokenizer.benchmark_vocab(src_seq_len=251)
     sd = random_t5_state_dict(T5_PRESETS["tiny"], tok.vocab_size_in, tok.vocab_size_out, seed=3)
     add_random_conditioning(sd, 128, 388, 16, 11, seed=1)
@@ -748,7 +748,7 @@ def test_whisper_packer_keeps_conditioning_channels_of_conv1():
     import torch
 
     from mapperatorinator_amd.conditioning import ConditioningEmbedders
-    from mapperatorinator_amd.testing import add_random_cond_embedders, random_varwhisper_state_dict, random_whisper_family_state_dict
+    from mh_testing import add_random_cond_embedders, random_varwhisper_state_dict, random_whisper_family_state_dict
     from mapperatorinator_amd.whisper_engine import VARWHISPER_PRESETS, PackedVarWhisper, fuse_split_projections, whisper_kind
     d = VARWHISPER_PRESETS["test"]
     sd = random_varwhisper_state_dict(d.d_model, d.n_heads, d.n_enc_layers, d.n_dec_layers, d.d_ff, 200, 180, seed=0)

@@ -133,6 +133,15 @@ def test_bench_gpus_2_forms_two_ranks_by_itself():
     assert lines[0]["n_gpus"] == 2 and lines[0]["rccl_ranks"] == [0, 1]
 
 
+def test_bench_gpus_8_forms_eight_ranks_by_itself():
+    """the shape of the driver's scaling run (N = 8, one rank per GPU of a node): eight ranks formed by bench.py itself, rank ids
+    all-gathered in order (gloo here; the same code path takes RCCL on a GPU node)"""
+    p, lines = _run_bench(["--gpus", "8", "--selftest-launch"], timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert len(lines) == 1, p.stdout
+    assert lines[0]["n_gpus"] == 8 and lines[0]["rccl_ranks"] == list(range(8))
+
+
 def test_bench_refuses_a_world_that_disagrees_with_gpus():
     """a launcher that formed 1 rank while the command says --gpus 2 is an error, not a 1-GPU measurement"""
     p, lines = _run_bench(["--gpus", "2", "--selftest-launch"], env_extra={"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"})

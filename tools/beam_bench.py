@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 def run(chunks=1, beams=2, new_tokens=128, device="cuda:0", model_tuple=None):
     from mapperatorinator_amd.server import build_sampling
-    from mapperatorinator_amd.testing import synthetic_audio_varied
+    from mh_testing import synthetic_audio_varied
     import importlib.util
     spec = importlib.util.spec_from_file_location("small_batch_decode", os.path.join(os.path.dirname(os.path.abspath(__file__)), "small_batch_decode.py"))
     sbd = importlib.util.module_from_spec(spec)

@@ -61,7 +61,7 @@ def teacher_forced_agreement(songs, new_tokens, dev):
     from mapperatorinator_amd.modeling import MapperatorinatorHIP
     from mapperatorinator_amd.server import build_sampling
     from mapperatorinator_amd.t5_engine import T5_PRESETS
-    from mapperatorinator_amd.testing import random_t5_state_dict, synthetic_audio_varied
+    from mh_testing import random_t5_state_dict, synthetic_audio_varied
     src, tgt = 1251, 1 + new_tokens
     tok = Tokenizer.benchmark_vocab(src_seq_len=src)
     dims = T5_PRESETS["large"]
@@ -101,7 +101,7 @@ def teacher_forced_agreement(songs, new_tokens, dev):
 def run(songs=32, windows=18, new_tokens=384, device="cuda:0", bf16_tokens=None, bf16_line=None):
     """bf16_tokens / bf16_line: the bf16-operand run of the same songs if the caller has it already (bench.py does)."""
     from mapperatorinator_amd.dit import BandMask, DiTHIP, create_diffusion
-    from mapperatorinator_amd.testing import DIT_PRESETS, random_dit_state_dict, synthetic_dit_inputs
+    from mh_testing import DIT_PRESETS, random_dit_state_dict, synthetic_dit_inputs
     dev = torch.device(device)
     lsb = _lsb()
     if bf16_tokens is None:

@@ -35,7 +35,7 @@ def main():
     from mapperatorinator_amd.modeling import MapperatorinatorHIP
     from mapperatorinator_amd.server import build_sampling
     from mapperatorinator_amd.t5_engine import T5_PRESETS
-    from mapperatorinator_amd.testing import random_t5_state_dict, synthetic_audio
+    from mh_testing import random_t5_state_dict, synthetic_audio
     lib = _lib.load()
     lib.mh_debug_phase_stamps.restype = C.c_int
     lib.mh_debug_phase_stamps.argtypes = [C.c_void_p, C.c_int]

@@ -3,7 +3,7 @@
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mapperatorinator_amd.dit import BandMask, DiTHIP, create_diffusion
-from mapperatorinator_amd.testing import DIT_PRESETS, random_dit_state_dict, synthetic_dit_inputs
+from mh_testing import DIT_PRESETS, random_dit_state_dict, synthetic_dit_inputs
 dev = torch.device("cuda", 0)
 B, Tq = int(sys.argv[1]), 128
 preset = sys.argv[2] if len(sys.argv) > 2 else "DiT-S"

@@ -4,7 +4,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from mapperatorinator_amd.dit import DiTHIP, create_diffusion
-from mapperatorinator_amd.testing import DIT_PRESETS, random_dit_state_dict, synthetic_dit_inputs
+from mh_testing import DIT_PRESETS, random_dit_state_dict, synthetic_dit_inputs
 name = sys.argv[1] if len(sys.argv) > 1 else "DiT-S"
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 depth, hidden, heads = DIT_PRESETS[name]

@@ -20,7 +20,7 @@ from mapperatorinator_amd import Tokenizer  # noqa: E402
 from mapperatorinator_amd.modeling import MapperatorinatorHIP  # noqa: E402
 from mapperatorinator_amd.scheduler import SequentialWindowScheduler, SongJob  # noqa: E402
 from mapperatorinator_amd.t5_engine import T5_PRESETS  # noqa: E402
-from mapperatorinator_amd.testing import random_t5_state_dict, synthetic_audio_varied  # noqa: E402
+from mh_testing import random_t5_state_dict, synthetic_audio_varied  # noqa: E402
 
 
 def run(size="large", songs=32, windows=18, new_tokens=384, context_tokens=32, fp8_kv=(False,), device="cuda:0", model=None,

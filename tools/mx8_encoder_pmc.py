@@ -8,7 +8,7 @@ sys.path.insert(0, ".")
 from mapperatorinator_amd import Tokenizer  # noqa: E402
 from mapperatorinator_amd.modeling import MapperatorinatorHIP  # noqa: E402
 from mapperatorinator_amd.t5_engine import T5_PRESETS  # noqa: E402
-from mapperatorinator_amd.testing import random_t5_state_dict, synthetic_audio  # noqa: E402
+from mh_testing import random_t5_state_dict, synthetic_audio  # noqa: E402
 
 size = sys.argv[1] if len(sys.argv) > 1 else "base"
 src, tgt, B = 1251, 512, 32

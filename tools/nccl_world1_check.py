@@ -27,7 +27,7 @@ def main():
     from mapperatorinator_amd.server import model_generate
     from mapperatorinator_amd.sharding import sharded_generate
     from mapperatorinator_amd.t5_engine import T5_PRESETS
-    from mapperatorinator_amd.testing import (DIT_PRESETS, random_dit_state_dict, random_t5_state_dict, synthetic_audio,
+    from mh_testing import (DIT_PRESETS, random_dit_state_dict, random_t5_state_dict, synthetic_audio,
                                               synthetic_dit_inputs)
     src, tgt, B, Tq = 126, 48, 5, 32
     tok = Tokenizer.benchmark_vocab(src_seq_len=src)

@@ -7,7 +7,7 @@ from mapperatorinator_amd import Tokenizer
 from mapperatorinator_amd.modeling import MapperatorinatorHIP
 from mapperatorinator_amd.server import build_sampling
 from mapperatorinator_amd.t5_engine import T5_PRESETS
-from mapperatorinator_amd.testing import random_t5_state_dict, synthetic_audio
+from mh_testing import random_t5_state_dict, synthetic_audio
 
 dev = torch.device("cuda:0")
 tok = Tokenizer.benchmark_vocab(src_seq_len=1251)

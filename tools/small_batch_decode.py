@@ -26,7 +26,7 @@ def build(model_name: str, tgt: int, device, dtype=torch.bfloat16, options=None)
     from mapperatorinator_amd import Tokenizer
     from mapperatorinator_amd.modeling import MapperatorinatorHIP
     from mapperatorinator_amd.t5_engine import T5_PRESETS
-    from mapperatorinator_amd.testing import random_t5_state_dict, random_varwhisper_state_dict, random_whisper_family_state_dict
+    from mh_testing import random_t5_state_dict, random_varwhisper_state_dict, random_whisper_family_state_dict
     from mapperatorinator_amd.whisper_engine import VARWHISPER_PRESETS
     fam, size = model_name.split("-")
     if fam == "t5":
@@ -51,7 +51,7 @@ def build(model_name: str, tgt: int, device, dtype=torch.bfloat16, options=None)
                                                   src_positions=frames // 2, tgt_positions=tgt, cond_size=384 if fam == "ropewhisper" else 0,
                                                   seed=0, head_gain=6.0, gains={"decoder_embedder": 0.5})
             if fam == "ropewhisper":
-                from mapperatorinator_amd.testing import add_random_cond_embedders
+                from mh_testing import add_random_cond_embedders
                 add_random_cond_embedders(sd, cond_dim=128, num_mappers=11, seed=0)
         kw = dict(f_min=0 if fam == "whisper" else 20)
     model = MapperatorinatorHIP(sd, dims, vocab_size_in=tok.vocab_size_in, vocab_size_out=tok.vocab_size_out, n_mels=n_mels,
@@ -78,7 +78,7 @@ def run(model_name="t5-base", new_tokens=256, device="cuda:0", reps=3, model_tup
     eng = model.engine
     gated = not model.is_whisper
     src_len = eng.packed.src_len
-    from mapperatorinator_amd.testing import synthetic_audio_varied
+    from mh_testing import synthetic_audio_varied
     audio = synthetic_audio_varied(1, (frames - 1) * 128, seed=5).to(dev)
     eos_table = torch.zeros(tok.vocab_size_out, dtype=torch.uint8, device=dev)
     out = {}
