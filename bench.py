@@ -525,7 +525,7 @@ def main():
     use_rows = rows_per_launch if in_situ_us else B
     achieved = use_rows * bytes_per_row / (use_us * 1e-6) / 1e9
     pmc_record = {}
-    pmc_file = "r05_pmc_cross_attn.json"      # the latest counter passes of this command (round 4's record: r04_pmc_cross_attn.json)
+    pmc_file = "r06_pmc_cross_attn.json"      # the latest counter passes (tools/profile_bench_pmc.sh: the headline loop of this command; earlier rounds: r04 / r05_pmc_cross_attn.json)
     try:
         with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", pmc_file)) as fh:
             pmc_record = json.load(fh)
@@ -538,8 +538,9 @@ def main():
         # PMC FETCH_SIZE / WRITE_SIZE need rocprofv3 around the process: not measurable from inside this run.  The committed
         # record of the counter passes of THIS command in the timed configuration (two 16-row chains) is quoted instead.
         "traffic": pmc_record.get("hbm_bytes_per_launch") if pmc_record.get("rows_per_launch") == use_rows else None,
-        "traffic_source": ("profiles/" + pmc_file + " / r05_pmc_hbm_traffic.txt: rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE "
-                           "(separate passes) around this command, builder-run, two 16-row decode chains fed by one launcher thread "
+        "traffic_source": ("profiles/" + pmc_file + " / r06_pmc_hbm_traffic.txt: rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE "
+                           "(separate passes) around `bench.py --headline-only` (this command's timed loop; a counter pass around the whole "
+                           "default command did not finish in 42 minutes), builder-run, two 16-row decode chains fed by one launcher thread "
                            "(MH_DECODE_LAUNCH_THREADS=0); bytes = 2 x FETCH_SIZE x 1024 + WRITE_SIZE x 1024 per launch (gfx950 correction of "
                            "MI355X_MICROARCH.md); the counter passes cannot run inside this process"),
         "traffic_over_algorithmic": (round(pmc_record["hbm_bytes_per_launch"] / (use_rows * bytes_per_row), 4)
