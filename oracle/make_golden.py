@@ -341,6 +341,9 @@ def wf_case(name):
     ids, stats = rh.reference_generate_whisper_family(model, tok, audio, prompt, rh.default_generate_kwargs(c["tgt"]), record_scores=rec, cond=cond)
     ids2, _ = rh.reference_generate_whisper_family(model, tok, audio, prompt, rh.default_generate_kwargs(c["tgt"], temperature=0.7, timeshift_bias=0.35,
                                                                                                         lookahead_time=3000), cond=cond)
+    if c["kind"] == "hf":   # transformers 4.57's mask-derived decoder positions (the reference's pin), through the same reference objects
+        idsm, _ = rh.reference_generate_whisper_family(model, tok, audio, prompt, rh.default_generate_kwargs(c["tgt"]), positions_from_mask=True)
+        extra["ids_mask_positions"] = idsm.numpy()
     if cd:   # the run WITHOUT conditioning, to show it matters
         ids0, _ = rh.reference_generate_whisper_family(model, tok, audio, prompt, rh.default_generate_kwargs(c["tgt"]), cond=torch.zeros_like(cond))
         extra["ids_zero_cond"] = ids0.numpy()

@@ -484,8 +484,14 @@ def reference_encode_whisper_family(model, audio: torch.Tensor, cond: torch.Tens
 
 
 def reference_generate_whisper_family(model, tok, audio, prompt, generate_kwargs, attention_mask=None, negative_prompt=None,
-                                      record_scores=None, cond=None):
-    """the reference's own `model_generate` with the encoder states of `reference_encode_whisper_family` as `encoder_outputs`"""
+                                      record_scores=None, cond=None, positions_from_mask=False):
+    """the reference's own `model_generate` with the encoder states of `reference_encode_whisper_family` as `encoder_outputs`.
+    `positions_from_mask` (stock HF Whisper only): hand the decoder the position ids transformers 4.57's Whisper
+    `prepare_inputs_for_generation` derives itself -- decoder_position_ids = (decoder_attention_mask.cumsum(-1) - 1).clamp(min=0), the
+    code the RoPEWhisper fork copied (modeling_ropewhisper.py:2015-2018) -- as an explicit model kwarg: the installed 5.x forwards it to
+    the decoder and extends it per step by itself (generation/utils.py `_update_model_kwargs_for_generation`), so the run shows what
+    the reference's PINNED transformers does with left-padded prompts.  (HF's check of kwarg names against the wrapper's forward
+    signature is switched off for the call: the wrapper takes it through **kwargs.)"""
     from osuT5.osuT5.inference.server import model_generate
     from transformers import LogitsProcessorList
     from transformers.modeling_outputs import BaseModelOutput
@@ -494,6 +500,11 @@ def reference_generate_whisper_family(model, tok, audio, prompt, generate_kwargs
               decoder_attention_mask=prompt.ne(0) if attention_mask is None else attention_mask)
     if negative_prompt is not None:
         mk.update(negative_prompt=negative_prompt, negative_prompt_attention_mask=negative_prompt.ne(0))
+    from transformers import GenerationMixin
+    orig_validate = GenerationMixin._validate_model_kwargs
+    if positions_from_mask:
+        mk["decoder_position_ids"] = (mk["decoder_attention_mask"].long().cumsum(-1) - 1).clamp(min=0)
+        GenerationMixin._validate_model_kwargs = lambda self, kw: None
     orig = LogitsProcessorList.__call__
     if record_scores is not None:
         def spy(self, input_ids, scores, **kw):
@@ -505,3 +516,4 @@ def reference_generate_whisper_family(model, tok, audio, prompt, generate_kwargs
         return model_generate(model, tok, mk, dict(generate_kwargs))
     finally:
         LogitsProcessorList.__call__ = orig
+        GenerationMixin._validate_model_kwargs = orig_validate

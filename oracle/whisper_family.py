@@ -33,7 +33,8 @@ modeling_mapperatorinator.py:204-205,211) and decoder_embedder (:217-219).
   decoder attention mask (the code the RoPEWhisper fork copied, modeling_ropewhisper.py:2015-2018); the installed 5.x hands
   the decoder no position ids, so it uses cache positions (`torch.arange(...) + past_key_values_length`).  The two differ for
   left-padded rows only.  `positions="cache"` (default: what the imported reference does HERE and what the goldens pin) or
-  "mask" (the 4.57 behaviour: parity unpinned for that mode, no reference run can produce it in this container).
+  "mask" (the 4.57 behaviour: pinned by goldens `ids_mask_positions`, which the imported reference produces when it is
+  handed those position ids explicitly -- ref_harness.reference_generate_whisper_family(positions_from_mask=True)).
 
 PINNING: tests/golden/rw_*.npz and hfw_*.npz come from the imported reference (oracle/make_golden.py: encoder states, greedy
 ids, per-step scores through its own `model_generate`); tests/test_oracle_pinned.py checks these restatements against them.

@@ -306,7 +306,8 @@ def test_whisper_family_bf16_teacher_forced_vs_bf16_oracle(kind, size, B, frames
 def test_hf_whisper_decoder_positions_from_the_mask_and_seams():
     """transformers 4.57's Whisper derives decoder_position_ids from the decoder attention mask, 5.x uses cache positions
     (oracle/whisper_family.py, VERSION-SKEW HAZARD).  `decoder_positions="mask"` (MhT5Config.dec_pos_from_mask) against the
-    oracle's restatement of the 4.57 behaviour -- parity unpinned for this mode: no reference run can produce it here -- for
+    reference's own run with the 4.57 position ids handed in explicitly (golden `ids_mask_positions`, oracle/ref_harness.py
+    positions_from_mask) and the oracle's restatement -- for
     ragged left-padded prompts through the batched prefill AND the token-by-token prompt path; the two modes must differ on
     padded rows and agree on unpadded ones.  Then the teacher-forced `forward` seam, guidance and a 2-beam search on the
     arch-2 kernels against the oracle."""
@@ -321,6 +322,8 @@ def test_hf_whisper_decoder_positions_from_the_mask_and_seams():
     o_mask = wf.HFWhisperOracle(sd, d.d_model, d.n_heads, d.n_enc_layers, d.n_dec_layers, positions="mask")
     enc_o = o_mask.encoder(o_mask.frontend(o_mask.log_mel(audio)))
     want = o_mask.generate(enc_o, prompt, prompt.ne(0), [tok.eos_id], tgt, ts0, ts1, [tok.sos_id])
+    # pinned since round 6: the reference's own objects, handed the position ids transformers 4.57 derives (golden ids_mask_positions)
+    assert np.array_equal(want.numpy(), g["ids_mask_positions"])
     model = build_wf(g, d, tok, sd, torch.float32, decoder_positions="mask")
     ids, _ = model_generate(model, tok, mk, gen_kwargs(tgt))
     assert torch.equal(ids, want), np.argwhere(ids.numpy() != want.numpy())[:3]
