@@ -108,7 +108,16 @@ class MapperatorinatorHIP:
             if name.startswith("OliBomby/varwhisper"):
                 opts.update(global_rope_theta=bc.global_rope_theta, local_rope_theta=bc.local_rope_theta,
                             global_attn_every_n_layers=bc.global_attn_every_n_layers, local_attention=bc.local_attention)
-            elif name.startswith("Tiger14n/ropewhisper"):
+            elif hf:
+                # decoder positions of left-padded rows follow the transformers the reference RUNS UNDER: 4.x (its pin, 4.57.3) derives
+                # them from the attention mask in Whisper's own prepare_inputs_for_generation, 5.x uses cache positions
+                try:
+                    import transformers
+                    major = int(str(transformers.__version__).split(".")[0])
+                except Exception:      # no transformers next to us: the reference's pin
+                    major = 4
+                opts.update(decoder_positions="mask" if major < 5 else "cache")
+            if name.startswith("Tiger14n/ropewhisper"):
                 # rope_type "dynamic" (NTK): the base only changes for positions beyond max_position_embeddings
                 # (modeling_ropewhisper.py:299-305), which a StaticCache of max_target_positions never reaches; factor 1.0
                 if float(getattr(bc, "rope_encoder_scaling_factor", 1.0)) != 1.0 or float(getattr(bc, "rope_decoder_scaling_factor", 1.0)) != 1.0 \
