@@ -354,3 +354,45 @@ def test_hf_whisper_decoder_positions_from_the_mask_and_seams():
     refb = o.generate_beam(enc_o, prompt, prompt.ne(0), [tok.eos_id], tgt, ts0, ts1, [tok.sos_id], 2)
     refb = refb[0] if isinstance(refb, tuple) else refb
     assert torch.equal(outb, refb), (outb.tolist(), refb.tolist())
+
+
+def test_hf_whisper_with_conditioning_embedders_through_the_encoder_projection():
+    """Not a released wiring (configs/model/whisper_{base,small}.yaml carry no embedders), but the wrapper allows it: with
+    project_encoder_input = true the conditioning vectors are COLUMNS of encoder_embedder (modeling_mapperatorinator.py:201-205), i.e.
+    the row-bias route of the T5 engine in front of the conv front-end (library arch 2).  fp32: encoder states and greedy ids against
+    the oracle (oracle/whisper_family.py with the vectors concatenated to the mel columns); a missing conditioning input refuses."""
+    from mapperatorinator_amd import Tokenizer
+    from mapperatorinator_amd.modeling import MapperatorinatorHIP
+    from mapperatorinator_amd.server import model_generate
+    from mapperatorinator_amd.whisper_engine import VARWHISPER_PRESETS
+    from mh_testing import add_random_cond_embedders, random_whisper_family_state_dict, synthetic_audio_varied
+    from oracle import whisper_family as wf
+    d, frames, tgt, n_mels, cdim = VARWHISPER_PRESETS["test"], 250, 40, 388, 16
+    tok = Tokenizer.benchmark_vocab(src_seq_len=frames)
+    sd = random_whisper_family_state_dict("hf", d.d_model, d.n_heads, d.n_enc_layers, d.n_dec_layers, d.d_ff, tok.vocab_size_in,
+                                          tok.vocab_size_out, n_mels, src_positions=frames // 2, tgt_positions=tgt, cond_size=3 * cdim, seed=31,
+                                          head_gain=5.0, gains={"decoder_embedder": 0.5})
+    add_random_cond_embedders(sd, cdim, 11, seed=4)
+    model = MapperatorinatorHIP(sd, d, vocab_size_in=tok.vocab_size_in, vocab_size_out=tok.vocab_size_out, n_mels=n_mels, src_seq_len=frames,
+                                tgt_seq_len=tgt, dtype=torch.float32, device="cuda")
+    assert model.engine.kind == "hf" and model.cond.active and not model.cond.as_channels and model.engine.packed.cond_cols == 3 * cdim
+    B = 3
+    audio = synthetic_audio_varied(B, (frames - 1) * 128, seed=12)
+    ck = dict(difficulty=torch.tensor([2.5, 6.1, 9.0]), mapper_idx=torch.tensor([3, -1, 10]),
+              song_position=torch.tensor([[0.0, 0.1], [0.45, 0.5], [0.9, 1.0]]))
+    cv = model.cond.vectors(B, **ck)
+    o = wf.HFWhisperOracle(sd, d.d_model, d.n_heads, d.n_enc_layers, d.n_dec_layers, n_mels=n_mels)
+    enc_o = o.encoder(o.frontend(o.with_cond(o.log_mel(audio), cv)))
+    enc, enc32 = model.engine.encode(audio.cuda(), want_f32=True, row_bias=model._row_bias(B, ck))
+    err = (enc32.cpu() - enc_o).abs().max().item()
+    print("hf whisper + conditioning columns: encoder max abs err vs oracle", err)
+    assert err < 2e-4
+    prompt = torch.tensor([[0, 1], [1, 40], [0, 1]])
+    ts0, ts1 = ts_range(tok)
+    want = o.generate(enc_o, prompt, prompt.ne(0), [tok.eos_id], tgt, ts0, ts1, [tok.sos_id])
+    ids, _ = model_generate(model, tok, dict(inputs=audio, decoder_input_ids=prompt, decoder_attention_mask=prompt.ne(0), **ck), gen_kwargs(tgt))
+    assert torch.equal(ids, want)
+    zero = o.encoder(o.frontend(o.with_cond(o.log_mel(audio), torch.zeros_like(cv))))
+    assert (zero - enc_o).abs().max().item() > 1e-2, "the conditioning must matter"
+    with pytest.raises(ValueError, match="difficulty"):
+        model_generate(model, tok, dict(inputs=audio, decoder_input_ids=prompt, decoder_attention_mask=prompt.ne(0)), gen_kwargs(tgt))
