@@ -470,7 +470,8 @@ int mh_t5_generate(const MhT5Config* cfg, const MhT5Weights* w, const void* cros
  * length ** penalty -> the early_stopping = False heuristic.  Greedy beams only (sp.do_sample = 0).
  * State: G chunks x num_beams rows, int32 sequences [G][nb][max_length] (columns beyond the current length hold the fill value),
  * fp32 scores [G][nb], int32 beam-index trails [G][nb][max_length - P], finished flags [G][nb]; the kernel reads the *_in arrays
- * and writes the *_out arrays (the caller swaps them every step), `heuristic_open` [G] in place.  Outputs for the caller: `src` [G
+ * and writes the *_out arrays (the caller swaps them every step), `heuristic_open` [G] in place.  Outputs for the caller (G nb entries,
+ * 2 G nb under guidance: the second half repeats the first, as `beam_idx.repeat(2)` does): `src` [G
  * nb] = the row each new running beam continues (the argument of mh_t5_reorder_cache: MapperatorinatorCache.reorder_cache,
  * inference/cache_utils.py:16-20), `last` [G nb] = the token each running beam is fed next, `flags` [G][3] = (heuristic still
  * open, every candidate hit EOS / max_length, every finished slot filled) from which the host forms HF's loop condition.

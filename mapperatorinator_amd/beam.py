@@ -182,16 +182,14 @@ def _beam_search_kernel(engine, cross_kv, prompt, prompt_mask, eos_ids, sp, num_
                     fin=torch.zeros((G, nb), dtype=torch.uint8, device=dev))
     st = [state(), state()]
     heuristic_open = torch.ones(G, dtype=torch.uint8, device=dev)
-    src = torch.zeros(R, dtype=torch.int32, device=dev)
-    last = torch.zeros(R, dtype=torch.int32, device=dev)
+    src = torch.zeros(RE, dtype=torch.int32, device=dev)       # the kernel writes both halves under guidance
+    feed = torch.zeros(RE, dtype=torch.int32, device=dev)      # ... and the token every row is fed next
     flags = torch.zeros((G, 3), dtype=torch.int32, device=dev)
     flags_host = torch.zeros((G, 3), dtype=torch.int32).pin_memory()
     need = lib.mh_t5_decode_workspace_bytes(C.byref(p.cfg), RE)
     ws = torch.empty(int(need), dtype=torch.uint8, device=dev)
     scratch = torch.empty(int(lib.mh_t5_reorder_cache_scratch_bytes(C.byref(p.cfg), RE, max_length)), dtype=torch.uint8, device=dev)
     logits = torch.empty((RE, V), dtype=torch.float32, device=dev)
-    src2 = torch.zeros(RE, dtype=torch.int32, device=dev)
-    feed = torch.zeros(RE, dtype=torch.int32, device=dev)
     stream = engine._s()
     bs = _lib.MhBeamStep()
     bs.logits, bs.eos_table = logits.data_ptr(), eos_table.data_ptr()
@@ -199,7 +197,7 @@ def _beam_search_kernel(engine, cross_kv, prompt, prompt_mask, eos_ids, sp, num_
     bs.cfg, bs.cfg_scale, bs.length_penalty = int(cfg), float(sp.cfg_scale), float(length_penalty)
     bs.early_stopping = 2 if early_stopping == "never" else (1 if early_stopping is True else 0)
     bs.sp = sp
-    bs.heuristic_open, bs.src, bs.last, bs.flags = heuristic_open.data_ptr(), src.data_ptr(), last.data_ptr(), flags.data_ptr()
+    bs.heuristic_open, bs.src, bs.last, bs.flags = heuristic_open.data_ptr(), src.data_ptr(), feed.data_ptr(), flags.data_ptr()
 
     def step(tokens: torch.Tensor, pos: int):
         rc = lib.mh_t5_step(C.byref(p.cfg), C.byref(p.w), cross_kv.data_ptr(), RE, nb, tokens.data_ptr(), pos, _lib.ptr(mask), P,
@@ -222,16 +220,11 @@ def _beam_search_kernel(engine, cross_kv, prompt, prompt_mask, eos_ids, sp, num_
             bs.seq_out, bs.bs_out, bs.bb_out, bs.fin_out = b["seq"].data_ptr(), b["bs"].data_ptr(), b["bb"].data_ptr(), b["fin"].data_ptr()
             _lib.check(lib.mh_beam_step(C.byref(bs), stream), "mh_beam_step")
             par ^= 1
-            if cfg:      # `beam_idx.repeat(2)` (cache_utils.py:18): BOTH halves take their rows from the first half; both are fed the beam's token
-                src2[:R].copy_(src)
-                src2[R:].copy_(src)
-                feed[:R].copy_(last)
-                feed[R:].copy_(last)
-            rc = lib.mh_t5_reorder_cache(C.byref(p.cfg), RE, (src2 if cfg else src).data_ptr(), cur_len, ws.data_ptr(), ws.numel(),
+            # (`src` / `feed` were written by the kernel for all RE rows: under guidance `beam_idx.repeat(2)`, cache_utils.py:18, and the
+            # beam's token for both halves)
+            rc = lib.mh_t5_reorder_cache(C.byref(p.cfg), RE, src.data_ptr(), cur_len, ws.data_ptr(), ws.numel(),
                                          scratch.data_ptr(), scratch.numel(), stream)
             _lib.check(rc, "mh_t5_reorder_cache")
-            if not cfg:
-                feed.copy_(last)
             cur_len += 1
             flags_host.copy_(flags, non_blocking=True)
             engine.stream.synchronize()

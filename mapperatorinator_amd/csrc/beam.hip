@@ -178,6 +178,10 @@ __global__ __launch_bounds__(kBeamThreads) void beam_step_kernel(MhBeamStep p) {
       p.rs_out[g * nb + s] = s_run_lp[s];
       p.src[g * nb + s] = parent + g * nb;             // g. the cache rows follow the beams that keep running
       p.last[g * nb + s] = tok;
+      if (p.cfg) {   // `beam_idx.repeat(2)` (cache_utils.py:18): BOTH halves gather from the first half, and both are fed the beam's token
+        p.src[R + g * nb + s] = parent + g * nb;
+        p.last[R + g * nb + s] = tok;
+      }
     }
     // finished slot s <- merged entry s_sel_fin[s]
     const int m = s_sel_fin[s];
