@@ -396,3 +396,49 @@ def test_hf_whisper_with_conditioning_embedders_through_the_encoder_projection()
     assert (zero - enc_o).abs().max().item() > 1e-2, "the conditioning must matter"
     with pytest.raises(ValueError, match="difficulty"):
         model_generate(model, tok, dict(inputs=audio, decoder_input_ids=prompt, decoder_attention_mask=prompt.ne(0)), gen_kwargs(tgt))
+
+
+@pytest.mark.parametrize("kind", ["hf", "rope"])
+def test_whisper_family_rows_do_not_depend_on_their_batch(kind):
+    """Batch invariance on the round-6 backbones, across every chain shape the LayerNorm / RMSNorm prologues are instantiated for:
+    24 rows without guidance (two chains of 12 rows: 16-row MFMA fragments), 10 and 20 chunks under guidance (ONE chain of 20 / 40
+    rows: the 32- and 64-row GEMV forms, MF = 2 / 4) -- every returned row must be bit-equal (fp32, greedy) to the same chunk decoded
+    alone with the same left padding."""
+    from mapperatorinator_amd import Tokenizer
+    from mapperatorinator_amd.modeling import MapperatorinatorHIP
+    from mapperatorinator_amd.server import model_generate
+    from mapperatorinator_amd.whisper_engine import VARWHISPER_PRESETS
+    from mh_testing import random_whisper_family_state_dict, synthetic_audio_varied
+    d, frames, tgt = VARWHISPER_PRESETS["test"], 250, 28
+    n_mels = 388 if kind == "hf" else 80
+    tok = Tokenizer.benchmark_vocab(src_seq_len=frames)
+    sd = random_whisper_family_state_dict(kind, d.d_model, d.n_heads, d.n_enc_layers, d.n_dec_layers, d.d_ff, tok.vocab_size_in,
+                                          tok.vocab_size_out, n_mels, src_positions=frames // 2, tgt_positions=tgt, seed=41, head_gain=5.0,
+                                          gains={"decoder_embedder": 0.5})
+    model = MapperatorinatorHIP(sd, d, vocab_size_in=tok.vocab_size_in, vocab_size_out=tok.vocab_size_out, n_mels=n_mels, src_seq_len=frames,
+                                tgt_seq_len=tgt, dtype=torch.float32, device="cuda", f_min=0 if kind == "hf" else 20)
+    G = 24
+    audio = synthetic_audio_varied(G, (frames - 1) * 128, seed=17)
+    g = torch.Generator().manual_seed(2)
+    prompt = torch.randint(20, tok.vocab_size_in - 1, (G, 3), generator=g)
+    prompt[:, 0] = 1
+    prompt[::3, 0] = 0            # every third row left-padded by one
+    prompt[::3, 1] = 1
+    neg = prompt.clone()
+    neg[:, 2] = 5
+
+    def run(rows, cfg):
+        mk = dict(inputs=audio[rows], decoder_input_ids=prompt[rows], decoder_attention_mask=prompt[rows].ne(0))
+        if cfg:
+            mk.update(negative_prompt=neg[rows], negative_prompt_attention_mask=neg[rows].ne(0))
+        return model_generate(model, tok, mk, gen_kwargs(tgt, cfg_scale=2.0 if cfg else 1.0))[0]
+
+    alone = {(i, c): run([i], c) for i in (0, 1, 7, 19) for c in (False, True)}
+    for rows, cfg in ((list(range(24)), False), (list(range(10)), True), (list(range(20)), True)):
+        out = run(rows, cfg)
+        for i in (0, 1, 7, 19):
+            if i >= len(rows):
+                continue
+            a = alone[(i, cfg)]
+            n = min(a.shape[1], out.shape[1])      # a batch runs until its longest row ends
+            assert torch.equal(out[i:i + 1, :n], a[:, :n]) and (a[:, n:] == 0).all() and (out[i, n:] == 0).all(), (kind, len(rows), cfg, i)
