@@ -475,7 +475,7 @@ int mh_t5_generate(const MhT5Config* cfg, const MhT5Weights* w, const void* cros
  * nb] = the row each new running beam continues (the argument of mh_t5_reorder_cache: MapperatorinatorCache.reorder_cache,
  * inference/cache_utils.py:16-20), `last` [G nb] = the token each running beam is fed next, `flags` [G][3] = (heuristic still
  * open, every candidate hit EOS / max_length, every finished slot filled) from which the host forms HF's loop condition.
- * num_beams in 2 .. 8, num_beams x V <= 16384 (the sort runs in LDS), K <= 4096. */
+ * num_beams in 2 .. 8, K <= 4096, 4 num_beams V + 8 K' bytes (K' = K rounded up to a power of two) within 120 KB of LDS. */
 typedef struct MhBeamStep {
   const float* logits;          /* [RE][V] fp32: RE = G nb rows, or 2 G nb under guidance ([negative rows | prompt rows]) */
   const uint8_t* eos_table;     /* [V] 1 = an EOS id (get_eos_token_id, server.py:72-80)                                    */

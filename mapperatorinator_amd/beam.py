@@ -117,9 +117,11 @@ class BeamProcessors:
 
 
 def kernel_path_available(sp, num_beams: int, vocab_out: int, n_eos: int) -> bool:
-    """mh_beam_step covers greedy beams (no beam-sample), 2 .. 8 beams, beams x V <= 16384 (the sort runs in LDS), K <= 4096."""
+    """mh_beam_step covers greedy beams (no beam-sample), 2 .. 8 beams, K <= 4096 candidates, beams x V scores + the K candidates
+    within 120 KB of LDS."""
     K = min(max(2, 1 + n_eos) * num_beams, num_beams * vocab_out)
-    return (not sp.do_sample) and 2 <= num_beams <= 8 and num_beams * vocab_out <= 16384 and K <= 4096
+    k_pad = 1 << max(0, (K - 1).bit_length())
+    return (not sp.do_sample) and 2 <= num_beams <= 8 and K <= 4096 and num_beams * vocab_out * 4 + 16 + k_pad * 8 <= 120 * 1024
 
 
 @torch.no_grad()

@@ -1115,3 +1115,28 @@ def test_step_graphs_are_replayed_across_generate_calls():
     for x, y in zip(*outs):
         assert torch.equal(x, y)
     assert not torch.equal(outs[0][0], outs[0][1]), "different seeds must draw different tokens"
+
+
+@pytest.mark.parametrize("beams,n_eos", [(2, 0), (2, 1), (3, 40), (2, 700), (5, 300), (8, 2)])
+def test_beam_step_kernel_matches_torch_bookkeeping_across_candidate_counts(beams, n_eos):
+    """mh_beam_step picks its K = max(2, 1 + #eos) x beams candidates with a radix select + a sort of the K only; the torch-op form
+    (torch.topk over beams x V) is the same algorithm one ATen call at a time.  Same ids and same scores for K from 4 to ~1500, with
+    EOS sets that end hypotheses at different steps and three ragged windows per call."""
+    from mapperatorinator_amd import Tokenizer
+    from mapperatorinator_amd.server import build_sampling
+    from mapperatorinator_amd.t5_engine import T5_PRESETS
+    from mh_testing import DIVERSE_GAINS, random_t5_state_dict, synthetic_audio_varied
+    src, tgt = 64, 24
+    tok = Tokenizer.benchmark_vocab(src_seq_len=src)
+    sd = random_t5_state_dict(T5_PRESETS["tiny"], tok.vocab_size_in, tok.vocab_size_out, seed=3 + beams, lm_head_gain=6.0, gains=DIVERSE_GAINS)
+    model = build("tiny", tok, sd, src, tgt, torch.float32)
+    eng = model.engine
+    audio = synthetic_audio_varied(3, (src - 1) * 128, seed=9).cuda()
+    prompt = torch.tensor([[tok.sos_id, 0, 0], [tok.sos_id, 7, 0], [tok.sos_id, 9, 11]], dtype=torch.long)
+    mask = prompt.ne(0)
+    sp, _ = build_sampling(tok, gen_kwargs(tgt, num_beams=beams), tgt)
+    gen = torch.Generator().manual_seed(n_eos)
+    eos = sorted(set((torch.randperm(tok.vocab_size_out - 20, generator=gen)[:n_eos] + 20).tolist()))
+    outs = [eng.generate_beam(audio, prompt, mask, eos, sp, beams, use_kernel=uk) for uk in (True, False)]
+    assert torch.equal(outs[0]["tokens"], outs[1]["tokens"]), (outs[0]["tokens"].tolist(), outs[1]["tokens"].tolist())
+    assert outs[0]["tokens"].shape[1] > prompt.shape[1]
