@@ -19,6 +19,7 @@ from typing import Optional
 
 import torch
 
+from . import _lib
 from .conditioning import ConditioningEmbedders
 from .t5_engine import T5Dims, T5Engine, T5_PRESETS
 from .whisper_engine import VARWHISPER_PRESETS, VarWhisperDims, VarWhisperEngine
@@ -34,6 +35,88 @@ def dims_from_backbone_config(bc) -> T5Dims:
                   n_dec_layers=bc.num_decoder_layers, d_kv=64,
                   n_buckets=bc.relative_attention_num_buckets,
                   max_distance=bc.relative_attention_max_distance, eps=bc.layer_norm_epsilon)
+
+
+class HIPDecodeCache:
+    """`past_key_values` of the HIP path: the decoder's self-attention K / V of every position fed so far (inside the engine's decode
+    workspace, owned by this object), the cross K / V of the call's audio and the count of positions seen -- the role
+    `MapperatorinatorCache` (osuT5/osuT5/inference/cache_utils.py:8-20, around HF's EncoderDecoderCache) plays between two
+    `forward` calls of the reference.  `reorder_cache(beam_idx)` is that class's method (:16-20)."""
+
+    def __init__(self, engine, cross_kv: torch.Tensor, rows: int, prompt_mask: Optional[torch.Tensor]):
+        import ctypes as C
+        p = engine.packed
+        if rows > 64:
+            raise ValueError(f"{rows} rows exceed the engine's 64-row decode batch")
+        if cross_kv.shape[2] != rows:
+            raise ValueError(f"cross K/V holds {cross_kv.shape[2]} rows, the decoder ids {rows}")
+        self.engine, self.cross_kv, self.rows, self.seen = engine, cross_kv, int(rows), 0
+        self.max_positions = int(p.tgt_len)
+        dev = engine.device
+        self.ws = torch.empty(int(engine.lib.mh_t5_decode_workspace_bytes(C.byref(p.cfg), self.rows)), dtype=torch.uint8, device=dev)
+        self._scratch = None
+        # the prompt's attention mask is fixed by the FIRST call (HF appends ones behind it)
+        self.mask = None if prompt_mask is None else prompt_mask.to(dev).to(torch.uint8).contiguous()
+        self.P = 0 if self.mask is None else int(self.mask.shape[1])
+
+    def get_seq_length(self, layer_idx: int = 0) -> int:
+        return self.seen
+
+    def append(self, ids: torch.Tensor, attention_mask: Optional[torch.Tensor]) -> torch.Tensor:
+        import ctypes as C
+        eng = self.engine
+        lib, p, dev = eng.lib, eng.packed, eng.device
+        if ids.shape[0] != self.rows:
+            raise ValueError(f"{ids.shape[0]} rows given, the cache holds {self.rows}")
+        T = int(ids.shape[1])
+        if self.seen + T > self.max_positions:
+            raise ValueError(f"{self.seen} + {T} positions exceed the cache ({self.max_positions})")
+        if attention_mask is not None and self.seen > 0:
+            m = attention_mask.to(dev).to(torch.uint8)
+            if m.shape[1] != self.seen + T:
+                raise ValueError("decoder_attention_mask must cover the cached positions and the new ones")
+            if self.P and not torch.equal(m[:, :self.P], self.mask):
+                raise ValueError("the mask of the cached prompt positions changed between calls")
+            if not bool(m[:, max(self.P, 0):].all()):
+                raise NotImplementedError("masked positions behind the first call's prompt are not built (HF's loop appends ones)")
+        P = self.P if self.mask is not None else max(self.seen + T, 1)
+        ids = ids.to(dev, torch.int32)
+        out = torch.empty((T, self.rows, p.vocab_out), dtype=torch.float32, device=dev)
+        eng._enter()
+        with torch.cuda.stream(eng.stream):
+            for t in range(T):
+                rc = lib.mh_t5_step(C.byref(p.cfg), C.byref(p.w), self.cross_kv.data_ptr(), self.rows, 1, ids[:, t].contiguous().data_ptr(),
+                                    self.seen + t, _lib.ptr(self.mask), P, out[t].data_ptr(), self.ws.data_ptr(), self.ws.numel(), eng._s())
+                _lib.check(rc, "mh_t5_step")
+        eng._leave()
+        eng.synchronize()
+        self.seen += T
+        return out.transpose(0, 1).contiguous()
+
+    def reorder_cache(self, beam_idx: torch.Tensor):
+        """Rows follow `beam_idx` (cache_utils.py:16-20: `index_select(0, beam_idx)` on every self-attention tensor; the cross K / V
+        rows are per row here, so they are gathered too)."""
+        import ctypes as C
+        eng = self.engine
+        lib, p, dev = eng.lib, eng.packed, eng.device
+        idx = torch.as_tensor(beam_idx).to(dev, torch.int32).contiguous()
+        if idx.numel() != self.rows:
+            raise ValueError("beam_idx must name one source row per cache row")
+        if self._scratch is None:
+            self._scratch = torch.empty(int(lib.mh_t5_reorder_cache_scratch_bytes(C.byref(p.cfg), self.rows, self.max_positions)),
+                                        dtype=torch.uint8, device=dev)
+        eng._enter()
+        with torch.cuda.stream(eng.stream):
+            if self.seen > 0:
+                rc = lib.mh_t5_reorder_cache(C.byref(p.cfg), self.rows, idx.data_ptr(), self.seen, self.ws.data_ptr(), self.ws.numel(),
+                                             self._scratch.data_ptr(), self._scratch.numel(), eng._s())
+                _lib.check(rc, "mh_t5_reorder_cache")
+            self.cross_kv = self.cross_kv.index_select(2, idx.to(torch.int64))
+            if self.mask is not None:
+                self.mask = self.mask.index_select(0, idx.to(torch.int64)).contiguous()
+        eng._leave()
+        eng.synchronize()
+        return self
 
 
 class MapperatorinatorHIP:
@@ -226,16 +309,38 @@ class MapperatorinatorHIP:
         return eng.cross_kv(eng.encode_mel(eng.mel(frames.to(eng.device, torch.float32)), row_bias=row_bias))
 
     @torch.no_grad()
-    def forward(self, frames=None, decoder_input_ids=None, decoder_attention_mask=None, encoder_outputs=None, **unused):
+    def forward(self, frames=None, decoder_input_ids=None, decoder_attention_mask=None, encoder_outputs=None, past_key_values=None,
+                use_cache=None, cache_position=None, **unused):
         """Teacher-forced logits (B, T, vocab) fp32 -- `Mapperatorinator.forward` (modeling_mapperatorinator.py:174-228)
         as `model_forward` uses it (server.py:160-181).  `frames` is raw audio, as in the reference (the spectrogram is
-        part of the model, :175).  Returns an object with `.logits` (+ `.encoder_last_hidden_state=None`)."""
-        for k in ("labels", "past_key_values", "decoder_inputs_embeds", "inputs_embeds"):
+        part of the model, :175).  Returns an object with `.logits` (+ `.encoder_last_hidden_state=None`).
+        With `use_cache=True` / `past_key_values=<HIPDecodeCache>` the call is INCREMENTAL, as HF's generation loop makes it
+        (:186-228 hand `past_key_values` / `cache_position` to the transformer): the ids given are appended behind the positions the
+        cache has seen (one mh_t5_step per column), the logits of exactly those columns come back and `.past_key_values` is the cache
+        to pass to the next call.  `cache_position`, when given, must be the positions the cache expects next."""
+        for k in ("labels", "decoder_inputs_embeds", "inputs_embeds"):
             if unused.get(k) is not None:
                 raise NotImplementedError(f"forward({k}=...) is not part of the inference seam")
         if decoder_input_ids is None:
             raise ValueError("decoder_input_ids is required")
         eng = self.engine
+        if past_key_values is not None or use_cache:
+            cache = past_key_values
+            if cache is None:
+                row_bias = self._row_bias(decoder_input_ids.shape[0], unused) if encoder_outputs is None else None
+                eng._enter()
+                with torch.cuda.stream(eng.stream):
+                    kv = self._cross_kv(frames, encoder_outputs, row_bias)
+                eng._leave()
+                cache = HIPDecodeCache(eng, kv, decoder_input_ids.shape[0], decoder_attention_mask)
+            elif not isinstance(cache, HIPDecodeCache):
+                raise TypeError("past_key_values must be the HIPDecodeCache a previous forward(use_cache=True) returned")
+            if cache_position is not None:
+                want = torch.arange(cache.seen, cache.seen + decoder_input_ids.shape[1])
+                if not torch.equal(torch.as_tensor(cache_position).cpu().to(torch.int64).view(-1), want):
+                    raise ValueError(f"cache_position {cache_position} does not continue the cache ({cache.seen} positions seen)")
+            logits = cache.append(decoder_input_ids, decoder_attention_mask)
+            return types.SimpleNamespace(logits=logits, encoder_last_hidden_state=None, past_key_values=cache, loss=None)
         ids = decoder_input_ids.to(eng.device, torch.int32).contiguous()
         mask = (decoder_attention_mask.to(eng.device).to(torch.uint8).contiguous()
                 if decoder_attention_mask is not None else None)

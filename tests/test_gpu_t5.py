@@ -1140,3 +1140,48 @@ def test_beam_step_kernel_matches_torch_bookkeeping_across_candidate_counts(beam
     outs = [eng.generate_beam(audio, prompt, mask, eos, sp, beams, use_kernel=uk) for uk in (True, False)]
     assert torch.equal(outs[0]["tokens"], outs[1]["tokens"]), (outs[0]["tokens"].tolist(), outs[1]["tokens"].tolist())
     assert outs[0]["tokens"].shape[1] > prompt.shape[1]
+
+
+def test_incremental_forward_with_past_key_values():
+    """SURVEY B2's `forward(past_key_values=..., cache_position=...)` (modeling_mapperatorinator.py:186-228 pass both to the
+    transformer; HF's generation loop calls the model this way): prompt in one call with `use_cache=True`, then one id per call with
+    the returned cache -- the logits must be those of the teacher-forced full pass (step GEMVs against the prefill GEMMs: 5e-4), a
+    plain greedy loop over the cached calls must return `generate`'s ids, and `reorder_cache` (cache_utils.py:16-20) must permute the
+    rows."""
+    from mapperatorinator_amd.modeling import HIPDecodeCache
+    g, size, tok, sd, audio, src, tgt = t5_golden_case("t5_tiny")
+    model = build(size, tok, sd, src, tgt, torch.float32)
+    prompt = torch.from_numpy(g["prompt"])
+    B, P = prompt.shape
+    pmask = prompt.ne(0)
+    kw = dict(decoder_input_ids=prompt, decoder_attention_mask=pmask, max_length=tgt, do_sample=False, eos_token_id=[])
+    ids = model.generate(inputs=audio, **kw).cpu()                      # greedy, no processors, runs to max_length
+    assert ids.shape == (B, tgt)
+    full_mask = torch.cat([pmask, torch.ones(B, tgt - P, dtype=torch.bool)], 1)
+    full = model(frames=audio, decoder_input_ids=ids, decoder_attention_mask=full_mask).logits.cpu()
+    out = model(frames=audio, decoder_input_ids=prompt, decoder_attention_mask=pmask, use_cache=True)
+    cache = out.past_key_values
+    assert isinstance(cache, HIPDecodeCache) and cache.get_seq_length() == P and out.logits.shape == (B, P, tok.vocab_size_out)
+    steps, cur = [out.logits.cpu()], prompt.clone()
+    for t in range(P, tgt):
+        nxt = steps[-1][:, -1].argmax(-1)
+        assert torch.equal(nxt, ids[:, t]), t                            # the cached loop IS greedy decoding
+        cur = torch.cat([cur, nxt[:, None]], 1)
+        o = model(decoder_input_ids=nxt[:, None], decoder_attention_mask=full_mask[:, :t + 1], past_key_values=cache,
+                  cache_position=torch.tensor([t]))
+        assert o.past_key_values is cache and cache.get_seq_length() == t + 1
+        steps.append(o.logits.cpu())
+    inc = torch.cat(steps, 1)
+    assert inc.shape == full.shape
+    real = full_mask[:, :, None].expand_as(full)                         # (a padded position's own logits are not defined)
+    assert float((inc - full)[real].abs().max()) < 5e-4
+    with pytest.raises(ValueError, match="cache_position"):
+        model(decoder_input_ids=ids[:, :1], past_key_values=cache, cache_position=torch.tensor([3]))
+    with pytest.raises(ValueError, match="exceed the cache"):
+        model(decoder_input_ids=ids[:, :1], past_key_values=cache)
+    # reorder: a second cache over the prompt, rows permuted, then the same next id per (moved) row
+    perm = torch.tensor([(i + 1) % B for i in range(B)])
+    c2 = model(frames=audio, decoder_input_ids=prompt, decoder_attention_mask=pmask, use_cache=True).past_key_values
+    c2.reorder_cache(perm)
+    o2 = model(decoder_input_ids=ids[perm, P:P + 1], past_key_values=c2)
+    assert torch.equal(o2.logits.cpu()[:, 0], steps[1][perm, 0])

@@ -442,3 +442,43 @@ def test_whisper_family_rows_do_not_depend_on_their_batch(kind):
             a = alone[(i, cfg)]
             n = min(a.shape[1], out.shape[1])      # a batch runs until its longest row ends
             assert torch.equal(out[i:i + 1, :n], a[:, :n]) and (a[:, n:] == 0).all() and (out[i, n:] == 0).all(), (kind, len(rows), cfg, i)
+
+
+@pytest.mark.parametrize("kind,positions", [("rope", "cache"), ("hf", "cache"), ("hf", "mask")])
+def test_whisper_family_incremental_forward_with_past_key_values(kind, positions):
+    """`forward(past_key_values=..., cache_position=...)` on the round-6 backbones (rotary positions / learned decoder positions from
+    the cache length or from the attention mask): prompt with `use_cache=True`, then one id per call -- logits of the teacher-forced
+    full pass (5e-4) and the greedy ids of `generate`."""
+    from mapperatorinator_amd import Tokenizer
+    from mapperatorinator_amd.modeling import HIPDecodeCache, MapperatorinatorHIP
+    from mapperatorinator_amd.whisper_engine import VARWHISPER_PRESETS
+    from mh_testing import random_whisper_family_state_dict, synthetic_audio_varied
+    d, frames, tgt = VARWHISPER_PRESETS["test"], 250, 20
+    n_mels = 388 if kind == "hf" else 80
+    tok = Tokenizer.benchmark_vocab(src_seq_len=frames)
+    sd = random_whisper_family_state_dict(kind, d.d_model, d.n_heads, d.n_enc_layers, d.n_dec_layers, d.d_ff, tok.vocab_size_in,
+                                          tok.vocab_size_out, n_mels, src_positions=frames // 2, tgt_positions=tgt, seed=43, head_gain=5.0,
+                                          gains={"decoder_embedder": 0.5})
+    opts = dict(backbone_options=dict(decoder_positions=positions)) if kind == "hf" else {}
+    model = MapperatorinatorHIP(sd, d, vocab_size_in=tok.vocab_size_in, vocab_size_out=tok.vocab_size_out, n_mels=n_mels, src_seq_len=frames,
+                                tgt_seq_len=tgt, dtype=torch.float32, device="cuda", f_min=0 if kind == "hf" else 20, **opts)
+    B, P = 4, 3
+    audio = synthetic_audio_varied(B, (frames - 1) * 128, seed=19)
+    prompt = torch.tensor([[1, 30, 31], [0, 1, 40], [1, 50, 51], [0, 0, 1]])
+    pmask = prompt.ne(0)
+    ids = model.generate(inputs=audio, decoder_input_ids=prompt, decoder_attention_mask=pmask, max_length=tgt, do_sample=False,
+                         eos_token_id=[]).cpu()
+    full_mask = torch.cat([pmask, torch.ones(B, tgt - P, dtype=torch.bool)], 1)
+    full = model(frames=audio, decoder_input_ids=ids, decoder_attention_mask=full_mask).logits.cpu()
+    out = model(frames=audio, decoder_input_ids=prompt, decoder_attention_mask=pmask, use_cache=True)
+    cache = out.past_key_values
+    assert isinstance(cache, HIPDecodeCache)
+    steps = [out.logits.cpu()]
+    for t in range(P, tgt):
+        nxt = steps[-1][:, -1].argmax(-1)
+        assert torch.equal(nxt, ids[:, t]), t
+        steps.append(model(decoder_input_ids=nxt[:, None], decoder_attention_mask=full_mask[:, :t + 1], past_key_values=cache,
+                           cache_position=torch.tensor([t])).logits.cpu())
+    inc = torch.cat(steps, 1)
+    real = full_mask[:, :, None].expand_as(full)
+    assert float((inc - full)[real].abs().max()) < 5e-4
