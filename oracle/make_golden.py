@@ -40,6 +40,11 @@ T5_CASES = {
                     prompts=[[0, 0, 1], [1, 40, 700], [0, 1, 9], [1, 5, 1003]], audio="varied", gains="diverse",
                     scores=True),
     # BASELINE configs[4] dims ("osuT5-large" = google/t5-v1_1-large through the same wrapper): 2 ragged rows, 69 new tokens
+    # one full 16-row decode chain of the headline shape (bench.py runs two of them): 16 ragged rows, 197 new tokens each, fp32 and bf16
+    "t5_base_wide": dict(size="base", ns=160000, src=1251, tgt=200, wseed=13, gain=4.0, aseed=6,
+                         prompts=[[0, 0, 1], [1, 40, 700], [0, 1, 9], [1, 5, 1003], [0, 0, 1], [0, 1, 77], [1, 300, 301], [0, 1, 1500],
+                                  [1, 9, 10], [0, 0, 1], [0, 1, 64], [1, 800, 1800], [0, 1, 3], [1, 21, 22], [0, 0, 1], [0, 1, 1200]],
+                         audio="varied", gains="diverse", scores=True),
     "t5_large": dict(size="large", ns=160000, src=1251, tgt=72, wseed=7, gain=4.0, aseed=3,
                      prompts=[[0, 1, 40], [1, 9, 700]], audio="varied", gains="diverse", scores=True),
 }
@@ -725,7 +730,7 @@ def events_case():
 def main(only=None):
     """`python -m oracle.make_golden` regenerates everything; `python -m oracle.make_golden NAME ...` only the named
     fixtures (t5_tiny, t5_small, t5_base, t5_large, vw_test, vw_test_nobias, vw_small, rw_test, rw_test_cond, rw_small, hfw_test,
-    hfw_small, t5_base_bf16ref, t5_tiny_cond,
+    hfw_small, t5_base_wide, t5_base_bf16ref, t5_base_wide_bf16ref, t5_tiny_cond,
     t5_tiny_tf, dit_xs, dit_s, dit_b, dit_b_1024, dit_pipeline, sliders, events, whisper_frontend, mel_oracle, tokenizer)."""
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(max(1, os.cpu_count() or 1))
@@ -738,6 +743,7 @@ def main(only=None):
         cases[name] = (lambda n: (lambda: wf_case(n)))(name)
     cases.update({
         "t5_base_bf16ref": lambda: t5_bf16_reference_case("t5_base"),
+        "t5_base_wide_bf16ref": lambda: t5_bf16_reference_case("t5_base_wide"),
         "t5_tiny_cond": t5_conditioning_case,
         "t5_tiny_tf": types_first_case,
         "dit_xs": lambda: dit_case("dit_xs", "DiT-XS", 96, 21, 5, 1.5),

@@ -45,10 +45,11 @@ def gen_kwargs(tgt, **over):
     return kw
 
 
-@pytest.mark.parametrize("name", ["t5_tiny", "t5_small", "t5_base", "t5_large"])
+@pytest.mark.parametrize("name", ["t5_tiny", "t5_small", "t5_base", "t5_base_wide", "t5_large"])
 def test_fp32_matches_reference_golden(name):
     """t5_base = BASELINE configs[1] dims at their own size (osuT5-base, 1251 frames, ragged prompts, 133 new
     tokens per row): ids bit-exact and the 16 best processed scores of every step within 5e-4 of the reference's.
+    t5_base_wide (round 6) = the same dims with 16 ragged rows x 197 new tokens: one full 16-row decode chain of the headline shape.
     t5_large = configs[4]'s backbone (google/t5-v1_1-large dims through the same wrapper: d 1024, 16 heads, 24 + 24
     layers) at 1251 frames, 2 ragged rows, 69 new tokens."""
     from mapperatorinator_amd.server import build_sampling, model_generate
@@ -103,15 +104,17 @@ def test_decode_kernel_variants_reproduce_the_reference_tokens(opts):
             _lib.set_option(k, v)
 
 
-def test_bf16_teacher_forced_on_the_reference_bf16_run():
-    """tests/golden/t5_base_bf16ref.npz = the REFERENCE itself in torch.bfloat16 (model.to(bfloat16), the precision
+@pytest.mark.parametrize("name", ["t5_base", "t5_base_wide"])
+def test_bf16_teacher_forced_on_the_reference_bf16_run(name):
+    """tests/golden/<name>_bf16ref.npz (t5_base: 4 rows x 133 tokens; t5_base_wide, round 6: 16 rows x 197 tokens -- a full decode
+    chain of the headline shape) = the REFERENCE itself in torch.bfloat16 (model.to(bfloat16), the precision
     switch of osuT5/osuT5/utils/model_utils.py:375-376) on the t5_base case.  The HIP bf16 path, teacher-forced on the
     reference's ids, must take the reference's decision on >= 99 % of the steps the reference decided by more than 0.5 (its own
     bf16 logits are spaced 0.06-0.125), and on >= 90 % of all live steps; the recorded rates of the CPU oracles are
     printed next to ours."""
     from mapperatorinator_amd.server import build_sampling
-    g, size, tok, sd, audio, src, tgt = golden_case("t5_base")
-    r = np.load(f"{GOLDEN}/t5_base_bf16ref.npz")
+    g, size, tok, sd, audio, src, tgt = golden_case(name)
+    r = np.load(f"{GOLDEN}/{name}_bf16ref.npz")
     ids16 = torch.from_numpy(r["ids"])
     n_cols = ids16.shape[1]
     model = build(size, tok, sd, src, tgt, torch.bfloat16)
