@@ -697,13 +697,31 @@ __global__ __launch_bounds__(256, QB == 1 ? 3 : 2) void flash2_bf16_kernel(AttnA
   for (int qb = 0; qb < QB; ++qb) {
     const float l = sum_over_lane_groups(lsum[qb]);
     const int qg = q0w + qb * 16 + l15;
-    if (qg >= Lq) continue;
-    const float inv = l > 0.f ? 1.0f / l : 0.f;
-    T* op = reinterpret_cast<T*>((char*)p.out + (long)b * p.out_bs + (long)qg * p.out_rs) + h * 64 + lg * 4;
+    const float inv = l > 0.f ? 1.0f / l : 0.f;         // (no early exit for qg >= Lq: every lane takes part in the lane swaps below)
+    // 16 bytes per lane: one v_permlane16_swap per dword on the registers of two d blocks leaves lanes lg = 0 / 2 with d 0-7 / 8-15
+    // of block 2 pr and lanes 1 / 3 with those of block 2 pr + 1 -- 64 contiguous bytes per query row and store instruction instead
+    // of 32 (the memory system takes 16-byte-per-lane stores at 1.6-1.7 x the rate: tools/micro/store_pattern_probe.hip)
+    if constexpr (!SIMPLE) {      // (the band / mask forms sit at 168 registers = three workgroups per CU: 8-byte stores, no extra registers)
+      if (qg < Lq) {
+        T* op8 = reinterpret_cast<T*>((char*)p.out + (long)b * p.out_bs + (long)qg * p.out_rs) + h * 64 + lg * 4;
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+          *reinterpret_cast<uint2*>(op8 + db * 16) = make_uint2(pack_bf16x2(o[qb][db][0] * inv, o[qb][db][1] * inv),
+                                                                pack_bf16x2(o[qb][db][2] * inv, o[qb][db][3] * inv));
+      }
+      continue;
+    }
+    uint2 w[4];
 #pragma unroll
     for (int db = 0; db < 4; ++db)
-      *reinterpret_cast<uint2*>(op + db * 16) = make_uint2(pack_bf16x2(o[qb][db][0] * inv, o[qb][db][1] * inv),
-                                                           pack_bf16x2(o[qb][db][2] * inv, o[qb][db][3] * inv));
+      w[db] = make_uint2(pack_bf16x2(o[qb][db][0] * inv, o[qb][db][1] * inv), pack_bf16x2(o[qb][db][2] * inv, o[qb][db][3] * inv));
+    T* op = reinterpret_cast<T*>((char*)p.out + (long)b * p.out_bs + (long)(qg < Lq ? qg : Lq - 1) * p.out_rs) + h * 64;
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+      const auto s0 = __builtin_amdgcn_permlane16_swap(w[2 * pr].x, w[2 * pr + 1].x, false, false);
+      const auto s1 = __builtin_amdgcn_permlane16_swap(w[2 * pr].y, w[2 * pr + 1].y, false, false);
+      if (qg < Lq) *reinterpret_cast<uint4*>(op + (2 * pr + (lg & 1)) * 16 + (lg >> 1) * 8) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+    }
   }
 }
 
@@ -736,7 +754,7 @@ int attention_general(const AttnArgs& a, int B, int H, int dtype, hipStream_t s)
                  a.vt_bs % 16 == 0 && a.vt_hs % 16 == 0,
              "attention: strides must be multiples of 16 bytes");
   const int es = dtype == MH_BF16 ? 2 : 4;
-  if (dtype == MH_BF16 && a.out_rs % 8 == 0 && a.out_bs % 8 == 0) {
+  if (dtype == MH_BF16 && a.out_rs % 16 == 0 && a.out_bs % 16 == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0) {
     // bf16: transposed-S kernel, 128 queries per workgroup (the 64-query kernel below only for outputs it cannot store 8 bytes at a time)
     const bool simple = a.band == 0 && !a.causal && a.key_mask == nullptr;
 #ifndef MH_F2_QB_SIMPLE

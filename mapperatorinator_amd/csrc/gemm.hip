@@ -681,6 +681,62 @@ __device__ __forceinline__ void g3_epilogue(const GemmP& p, f32x4_t (&acc)[4][MI
       }
       continue;
     }
+    // ---- bf16 outputs, WIDE form: the four lanes (lgc = 0..3) of an output row hold 4 consecutive columns each of every 16-column
+    // block jj.  One v_permlane16_swap per dword on the registers of two blocks (ja, jb) leaves lanes lgc = 0 / 2 with columns
+    // 0-7 / 8-15 of block ja and lanes 1 / 3 with those of block jb: ONE 16-byte store per lane and pair, 64 contiguous bytes per
+    // row and instruction instead of 32.  The write phase of these kernels is paced by the memory system, not by the waves:
+    // tools/micro/store_pattern_probe.hip -- 184 MB in 52 us (3.5 TB/s) with the 8-byte form, 30 us (6.1 TB/s) with this one.
+    // Same values to the same addresses.
+    constexpr bool kWideCapable = (EPI == MH_EPI_STORE || EPI == MH_EPI_BIAS_GELU || EPI == MH_EPI_BIAS_GELU_ERF || EPI == MH_EPI_GEGLU ||
+                                   EPI == MH_EPI_KV_SCATTER || EPI == MH_EPI_QKV_VT);
+    if constexpr (kWideCapable) {
+      const bool wide_ok = (p.N % 16 == 0) && (p.ldc % 8 == 0) && (EPI != MH_EPI_QKV_VT || p.n_split % 32 == 0);    // kernel-uniform
+      if (wide_ok) {
+        uint2 w[NI];
+#pragma unroll
+        for (int jj = 0; jj < NI; ++jj) w[jj] = make_uint2(pack_bf16x2(vv[jj][0], vv[jj][1]), pack_bf16x2(vv[jj][2], vv[jj][3]));
+        const int blk = lgc & 1, half = lgc >> 1;
+#pragma unroll
+        for (int pr = 0; pr < (EPI == MH_EPI_GEGLU ? 1 : 2); ++pr) {
+          constexpr bool kG = EPI == MH_EPI_GEGLU;
+          const int ja = kG ? 0 : 2 * pr, jb = kG ? 2 : 2 * pr + 1;
+          if constexpr (EPI == MH_EPI_QKV_VT) {
+            if (n0 + wc * WN + ja * 16 >= p.n_split) {          // (wave-uniform) the V columns: transposed scatter, as below
+#pragma unroll
+              for (int jj = ja; jj <= jb; ++jj) {
+                const int c = ecol_base + jj * 16;
+                if (!rok || c >= p.N) continue;
+                const int c2 = c - p.n_split;
+                const int b = row / p.kv_L, key = row - b * p.kv_L;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                  reinterpret_cast<T*>(p.C2)[((long)b * p.kv_H * 64 + c2 + r) * p.kv_Lpad + key] = Elem<T>::from_f32(vv[jj][r]);
+              }
+              continue;
+            }
+          }
+          const auto s0 = __builtin_amdgcn_permlane16_swap(w[ja].x, w[jb].x, false, false);
+          const auto s1 = __builtin_amdgcn_permlane16_swap(w[ja].y, w[jb].y, false, false);
+          const uint4 q = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+          if constexpr (kG) {
+            const int oc = (n0 + wc * WN) / 2 + blk * 16 + half * 8;
+            if (rok && oc < p.N / 2) *reinterpret_cast<uint4*>(reinterpret_cast<T*>(p.C) + (long)row * p.ldc + oc) = q;
+          } else {
+            const int c = n0 + wc * WN + (ja + blk) * 16 + half * 8;
+            if (rok && c < p.N) {
+              if constexpr (EPI == MH_EPI_KV_SCATTER) {
+                const int dd = c & 63, h = (c >> 6) % p.kv_H, lk = (c >> 6) / p.kv_H;
+                const int b = row / p.kv_L, key = row - b * p.kv_L;
+                *reinterpret_cast<uint4*>(reinterpret_cast<T*>(p.C) + ((((long)lk * p.kv_B + b) * p.kv_H + h) * p.kv_L + key) * 64 + dd) = q;
+              } else {
+                *reinterpret_cast<uint4*>(reinterpret_cast<T*>(p.C) + (long)row * p.ldc + c) = q;
+              }
+            }
+          }
+        }
+        continue;
+      }
+    }
 #pragma unroll
     for (int jj = 0; jj < NI; ++jj) {
       const int c = ecol_base + jj * 16;
