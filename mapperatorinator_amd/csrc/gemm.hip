@@ -624,7 +624,7 @@ __device__ __forceinline__ void g3_epilogue(const GemmP& p, f32x4_t (&acc)[4][MI
       if constexpr (EPI == MH_EPI_GEGLU) {
         if (!(jj & 1)) {                             // 16-row weight blocks alternate wi_0 / wi_1: jj the gate, jj + 1 the linear half
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = gelu_tanh(v[r]) * acc[jj + 1][i][r];
+          for (int r = 0; r < 4; ++r) v[r] = gelu_tanh_fast(v[r]) * acc[jj + 1][i][r];   // (bf16 / MX outputs only here: the one-exponential form is ~1e-6 relative, 4 000 x below the output rounding; tanhf's ~45 instructions and two branches per value made this epilogue 5 us of VALU per 256 x 256 tile.  The fp32 kernels keep gelu_tanh: their results decide bit-exact greedy ids)
         }
       } else if constexpr (EPI == MH_EPI_RESID) {
         v[0] += old4[jj].x; v[1] += old4[jj].y; v[2] += old4[jj].z; v[3] += old4[jj].w;
@@ -637,7 +637,7 @@ __device__ __forceinline__ void g3_epilogue(const GemmP& p, f32x4_t (&acc)[4][MI
       } else if constexpr (EPI == MH_EPI_BIAS_GELU_ERF) {
         const float gq[4] = {g4[jj].x, g4[jj].y, g4[jj].z, g4[jj].w};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = 0.5f * v[r] * (1.0f + erff(v[r] * 0.70710678118654752f)) + gq[r];
+        for (int r = 0; r < 4; ++r) v[r] = gelu_erf_fast(v[r]) + gq[r];    // (bf16 / MX outputs: see gelu_erf_fast)
       }
       asm volatile("" : "+v"(v));
       vv[jj] = v;
