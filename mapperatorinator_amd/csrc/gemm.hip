@@ -1491,6 +1491,37 @@ __global__ __launch_bounds__(512) void gemm_s3g_kernel(GemmP p) {
       }
       vv[jj] = v;
     }
+    if constexpr (EPI == MH_EPI_BIAS_GELU) {
+      // pre-split output, WIDE form (see g3_epilogue): the hi / lo halves of two 16-column blocks of one 32-column group are exchanged
+      // across lane rows, every lane then stores 16 bytes of hi and 16 bytes of lo: 64 contiguous bytes per row, half and instruction
+      if (p.N % 32 == 0 && p.ldc % 32 == 0) {      // kernel-uniform
+#pragma unroll
+        for (int pr = 0; pr < NI / 2; ++pr) {
+          uint32_t hi[2][2], lo[2][2];
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const f32x4_t v = vv[2 * pr + q];
+            const uint32_t h01 = pack_bf16x2(v[0], v[1]), h23 = pack_bf16x2(v[2], v[3]);
+            const float r0 = v[0] - __uint_as_float(h01 << 16), r1 = v[1] - __uint_as_float(h01 & 0xffff0000u);
+            const float r2 = v[2] - __uint_as_float(h23 << 16), r3 = v[3] - __uint_as_float(h23 & 0xffff0000u);
+            hi[q][0] = h01; hi[q][1] = h23; lo[q][0] = pack_bf16x2(r0, r1); lo[q][1] = pack_bf16x2(r2, r3);
+          }
+          const auto a0 = __builtin_amdgcn_permlane16_swap(hi[0][0], hi[1][0], false, false);
+          const auto a1 = __builtin_amdgcn_permlane16_swap(hi[0][1], hi[1][1], false, false);
+          const auto b0 = __builtin_amdgcn_permlane16_swap(lo[0][0], lo[1][0], false, false);
+          const auto b1 = __builtin_amdgcn_permlane16_swap(lo[0][1], lo[1][1], false, false);
+          const int lgc_ = lane >> 4;
+          const int cblk = n0 + wc * WN + pr * 32;                       // first column of the 32-column group
+          if (rok && cblk < p.N) {
+            // lanes lgc 0 / 2: block 2 pr, columns 0-7 / 8-15; lanes 1 / 3: block 2 pr + 1 -- byte offset of column c in its group half: (c % 32) * 2
+            char* dst = reinterpret_cast<char*>(p.C) + ((long)row * p.ldc + cblk) * 4 + ((lgc_ & 1) * 16 + (lgc_ >> 1) * 8) * 2;
+            *reinterpret_cast<uint4*>(dst) = make_uint4(a0[0], a1[0], a0[1], a1[1]);
+            *reinterpret_cast<uint4*>(dst + 64) = make_uint4(b0[0], b1[0], b0[1], b1[1]);
+          }
+        }
+        continue;
+      }
+    }
 #pragma unroll
     for (int jj = 0; jj < NI; ++jj) {
       const int c = ecol_base + jj * 16;
