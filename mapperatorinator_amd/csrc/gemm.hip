@@ -690,7 +690,8 @@ __device__ __forceinline__ void g3_epilogue(const GemmP& p, f32x4_t (&acc)[4][MI
     constexpr bool kWideCapable = (EPI == MH_EPI_STORE || EPI == MH_EPI_BIAS_GELU || EPI == MH_EPI_BIAS_GELU_ERF || EPI == MH_EPI_GEGLU ||
                                    EPI == MH_EPI_KV_SCATTER || EPI == MH_EPI_QKV_VT);
     if constexpr (kWideCapable) {
-      const bool wide_ok = (p.N % 16 == 0) && (p.ldc % 8 == 0) && (EPI != MH_EPI_QKV_VT || p.n_split % 32 == 0);    // kernel-uniform
+      const bool wide_ok = (p.N % 16 == 0) && (p.ldc % 8 == 0) && ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0) &&
+                           (EPI != MH_EPI_QKV_VT || p.n_split % 32 == 0);    // kernel-uniform
       if (wide_ok) {
         uint2 w[NI];
 #pragma unroll
@@ -1494,7 +1495,7 @@ __global__ __launch_bounds__(512) void gemm_s3g_kernel(GemmP p) {
     if constexpr (EPI == MH_EPI_BIAS_GELU) {
       // pre-split output, WIDE form (see g3_epilogue): the hi / lo halves of two 16-column blocks of one 32-column group are exchanged
       // across lane rows, every lane then stores 16 bytes of hi and 16 bytes of lo: 64 contiguous bytes per row, half and instruction
-      if (p.N % 32 == 0 && p.ldc % 32 == 0) {      // kernel-uniform
+      if (p.N % 32 == 0 && p.ldc % 32 == 0 && (reinterpret_cast<uintptr_t>(p.C) & 15) == 0) {      // kernel-uniform
 #pragma unroll
         for (int pr = 0; pr < NI / 2; ++pr) {
           uint32_t hi[2][2], lo[2][2];

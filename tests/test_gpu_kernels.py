@@ -603,3 +603,49 @@ def test_gemm_two_stage_tile_is_bit_identical_to_the_three_stage_kernel(case):
     a, b = outs
     assert all(torch.equal(x, y) for x, y in zip(a, b)) if isinstance(a, tuple) else torch.equal(a, b)
 
+
+
+@pytest.mark.parametrize("tile256", [0, 1])
+def test_lds_dma_kernels_wide_epilogues_vs_fp64(tile256):
+    """Round 6: the bf16 epilogues of gemm_glds3_kernel / gemm_glds4_kernel store 16 bytes per lane (two 16-column blocks exchanged
+    across lane rows with v_permlane16_swap) and evaluate the gated-GELU through one exponential.  Against fp64 references at shapes
+    that take those kernels (M = 4099 ragged rows): STORE, BIAS_GELU, GEGLU, KV_SCATTER, QKV_VT (q | k block wide, V^T scatter
+    narrow), and a STORE whose N is not a multiple of 16 (the 8-byte fallback inside the same kernel) -- every element within one
+    bf16 rounding of the exact value."""
+    L, _ = _lib()
+    g = torch.Generator().manual_seed(77 + tile256)
+    B_, H_, L_ = 3, 12, 1367            # M = 4101 rows: ragged last tile
+    M, K = B_ * L_, 768
+    A = _bf16r(torch.randn(M, K, generator=g) * 0.5)
+    w = lambda n: _bf16r(torch.randn(n, K, generator=g) * 0.05)
+
+    def close(out, exp, what):
+        err = (out.double() - exp.double()).abs()
+        tol = exp.double().abs() * 2.0 ** -8 + 2e-3          # one bf16 rounding of the value (+ the fp32 accumulation noise of K = 768)
+        assert bool((err <= tol).all()), (what, float(err.max()), int((err > tol).sum()))
+
+    old = L.set_option("gemm_tile256sq_min", tile256)
+    try:
+        W = w(2304)
+        bias = torch.randn(2304, generator=g) * 0.1
+        full = A.double() @ W.double().t()
+        close(run_gemm(A, W, L.EPI_STORE, L.MH_BF16, bias=bias), full + bias.double(), "STORE")
+        close(run_gemm(A, W, L.EPI_BIAS_GELU, L.MH_BF16, bias=bias), gelu_tanh((full + bias.double()).float()), "BIAS_GELU")
+        Wn = W[:2296]                      # N % 16 == 8: the narrow stores of the same kernel
+        close(run_gemm(A, Wn, L.EPI_STORE, L.MH_BF16), full[:, :2296], "STORE narrow")
+        dff = 2048
+        wi0, wi1 = w(dff), w(dff)
+        Wi = torch.stack([wi0.reshape(dff // 16, 16, K), wi1.reshape(dff // 16, 16, K)], 1).reshape(2 * dff, K)
+        exp = gelu_tanh((A.double() @ wi0.double().t()).float()).double() * (A.double() @ wi1.double().t())
+        close(run_gemm(A, Wi, L.EPI_GEGLU, L.MH_BF16), exp, "GEGLU")
+        Wkv = w(2 * 2 * H_ * 64)
+        out = run_gemm(A, Wkv, L.EPI_KV_SCATTER, L.MH_BF16, kv=(B_, H_, L_))
+        exp = (A.double() @ Wkv.double().t()).view(B_, L_, 4, H_, 64).permute(2, 0, 3, 1, 4)
+        close(out, exp, "KV_SCATTER")
+        Wq = w(3 * H_ * 64)
+        qk, vt = run_gemm(A, Wq, L.EPI_QKV_VT, L.MH_BF16, kv=(B_, H_, L_), n_split=2 * H_ * 64, Lpad=1408)
+        fq = A.double() @ Wq.double().t()
+        close(qk, fq[:, :2 * H_ * 64], "QKV_VT q|k")
+        close(vt[..., :L_], fq[:, 2 * H_ * 64:].view(B_, L_, H_, 64).permute(0, 2, 3, 1), "QKV_VT v^T")
+    finally:
+        L.set_option("gemm_tile256sq_min", old)
