@@ -1,6 +1,13 @@
 import os
 import sys
 
+# The CPU suite's oracle runs are multi-threaded torch; on a shared host (this container is a VM whose cores come and go) OpenMP's
+# default spin-waiting turns a descheduled worker into minutes of busy waiting for everyone else (seen twice: the t5_base oracle case
+# making no progress at 600 % CPU).  Passive waiting costs a few percent on an idle host and cannot livelock.  Before torch is imported.
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+os.environ.setdefault("KMP_BLOCKTIME", "0")
+os.environ.setdefault("GOMP_SPINCOUNT", "0")
+
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
