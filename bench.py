@@ -582,6 +582,36 @@ def main():
                                        "mode and not `value`",
                                "same_tokens_as_bf16_kv": round(float((t8 == tokens).float().mean().item()), 4)}
 
+    # ---- 64 chunks per call (the engine's maximum: two 32-row chains): more rows under the same dependent-kernel chain ----
+    if not args.no_extras and rank == 0 and B == 32:
+        try:
+            audio64 = torch.cat([audio, audio.flip(0)], 0)
+            prompt64 = torch.cat([prompt, prompt], 0)
+
+            def step64():
+                eng._enter()
+                with torch.cuda.stream(eng.stream):
+                    kv_ = eng.cross_kv(eng.encode_mel(eng.mel(audio64)))
+                    t_, _, _ = eng.decode(kv_, prompt64, None, eos_table, sp, poll_every=64)
+                eng._leave()
+                return t_
+            step64()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(2):
+                t64 = step64()
+            torch.cuda.synchronize(dev)
+            dt64 = (time.perf_counter() - t0) / 2
+            aux["rows64"] = {"tokens_per_s": round(int((t64[:, 1:] != 0).sum().item()) / dt64, 1), "ms_per_step": round(dt64 * 1e3, 2),
+                             "chunks_per_call": 64, "first_half_same_tokens_as_headline": bool(torch.equal(t64[:B], tokens)),
+                             "note": "NOT `value` (BASELINE configs[1] is 32 chunks per call): the same model and chunk shape with 64 chunks per "
+                                     "call -- two 32-row decode chains.  The token step is a chain of dependent kernels whose time grows "
+                                     "slowly with the rows it carries (profiles/r06_small_batch_decode.txt), so a caller with >= 64 windows "
+                                     "in hand gets more tokens per second at ~1.75 x the per-token latency"}
+            del audio64, t64
+        except Exception as e:  # noqa: BLE001
+            aux["rows64"] = {"error": f"{type(e).__name__}: {e}"}
+
     # ---- the reference's default USER settings: sampling with temperature 0.9 / top_p 0.9 (configs/inference/v32.yaml:12-13) ----
     if not args.no_extras and rank == 0:
         sp_s, _ = build_sampling(tok, dict(gk, do_sample=True, top_p=0.9, temperature=0.9, seed=1), tgt_len)
